@@ -1,0 +1,90 @@
+/*
+ * nf_oracle.c — CPU restatement (TEST INFRASTRUCTURE, never on the product path) of the two
+ * third-party neighbour ops the NeuroFluid hot path calls.  Plain C, compiled without FP
+ * contraction (-ffp-contract=off) so that the fp32 "d2 < r2" test is a mul + add chain in
+ * d = 0,1,2 order.
+ *
+ *  - nfo_ball_query_firstk : pytorch3d v0.6.1 ops.ball_query semantics, call site
+ *        /root/reference/models/renderer.py:116-118  (SURVEY §8c "third-party arithmetic #1").
+ *        For each query scan p2 in index order, accept when sum_d (p1_d - p2_d)^2 <  r*r,
+ *        store index / squared distance / xyz in the next free slot, stop at K.
+ *        Padding: idx = -1, dist2 = 0, nn = 0.
+ *  - nfo_radius_count / nfo_radius_csr : Open3D 0.15.2 FixedRadiusSearch semantics (L2 metric,
+ *        d2 <= r*r, neighbours at the *identical position* skipped when ignore_query_point),
+ *        call sites /root/reference/models/transmodel.py:86-95,116-118,125,135-138
+ *        (SURVEY §8c "third-party arithmetic #2").  Row order = ascending point index
+ *        (Open3D's order is hash-bucket order; the set per row is what is specified).
+ *
+ * PARITY: unpinned against the real libraries (neither is importable here).
+ */
+#include <stdint.h>
+#include <stddef.h>
+
+static inline float d2f(const float* a, const float* b)
+{
+    float dx = a[0] - b[0];
+    float dy = a[1] - b[1];
+    float dz = a[2] - b[2];
+    float s = dx * dx;
+    s = s + dy * dy;
+    s = s + dz * dz;
+    return s;
+}
+
+void nfo_ball_query_firstk(const float* q, int64_t nq, const float* p, int64_t np,
+                           float radius, int K, float* dists2, int64_t* idx, float* nn)
+{
+    const float r2 = radius * radius;
+    for (int64_t i = 0; i < nq; ++i) {
+        int cnt = 0;
+        float* dd = dists2 + i * K;
+        int64_t* ii = idx + i * K;
+        float* nnp = nn + i * K * 3;
+        for (int k = 0; k < K; ++k) { dd[k] = 0.f; ii[k] = -1; nnp[3*k] = nnp[3*k+1] = nnp[3*k+2] = 0.f; }
+        for (int64_t j = 0; j < np && cnt < K; ++j) {
+            float s = d2f(q + 3 * i, p + 3 * j);
+            if (s < r2) {
+                dd[cnt] = s; ii[cnt] = j;
+                nnp[3*cnt] = p[3*j]; nnp[3*cnt+1] = p[3*j+1]; nnp[3*cnt+2] = p[3*j+2];
+                ++cnt;
+            }
+        }
+    }
+}
+
+/* counts per query -> counts[nq]; returns total */
+int64_t nfo_radius_count(const float* q, int64_t nq, const float* p, int64_t np,
+                         float radius, int ignore_query_point, int64_t* counts)
+{
+    const float r2 = radius * radius;
+    int64_t tot = 0;
+    for (int64_t i = 0; i < nq; ++i) {
+        int64_t c = 0;
+        const float* qi = q + 3 * i;
+        for (int64_t j = 0; j < np; ++j) {
+            const float* pj = p + 3 * j;
+            if (ignore_query_point && qi[0] == pj[0] && qi[1] == pj[1] && qi[2] == pj[2]) continue;
+            if (d2f(qi, pj) <= r2) ++c;
+        }
+        counts[i] = c; tot += c;
+    }
+    return tot;
+}
+
+/* row_splits[nq+1] already holds the exclusive prefix sum of counts */
+void nfo_radius_csr(const float* q, int64_t nq, const float* p, int64_t np,
+                    float radius, int ignore_query_point, const int64_t* row_splits,
+                    int32_t* idx, float* dist2)
+{
+    const float r2 = radius * radius;
+    for (int64_t i = 0; i < nq; ++i) {
+        int64_t o = row_splits[i];
+        const float* qi = q + 3 * i;
+        for (int64_t j = 0; j < np; ++j) {
+            const float* pj = p + 3 * j;
+            if (ignore_query_point && qi[0] == pj[0] && qi[1] == pj[1] && qi[2] == pj[2]) continue;
+            float s = d2f(qi, pj);
+            if (s <= r2) { idx[o] = (int32_t)j; dist2[o] = s; ++o; }
+        }
+    }
+}

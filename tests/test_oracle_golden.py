@@ -1,0 +1,97 @@
+"""The oracle (oracle/render_oracle.py) against the golden vectors recorded from the reference's own
+Python (tests/golden/gen_golden.py).  CPU only.  These tests are what 'pins' the oracle."""
+import numpy as np
+import torch
+
+from oracle import render_oracle as ro
+from oracle import trans_oracle as to
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_a0_rays(golden):
+    g = golden("a0_rays")
+    d = ro.get_ray_directions(int(g["H"]), int(g["W"]), float(g["focal"]))
+    assert torch.equal(d, T(g["directions"]))
+    o, dd = ro.get_rays(d, T(g["c2w"]))
+    assert torch.equal(o.contiguous(), T(g["rays_o"]))
+    assert torch.equal(dd, T(g["rays_d"]))
+
+
+def test_a1_coarse(golden):
+    g = golden("a1_coarse")
+    z, xyz = ro.coarse_sample_ray(float(g["near"]), float(g["far"]), T(g["rays"]), 64)
+    assert torch.equal(z.contiguous(), T(g["z"]))
+    assert torch.equal(xyz, T(g["xyz"]))
+
+
+def test_a5_embed(golden):
+    g = golden("a5_embed")
+    assert torch.equal(ro.embed(T(g["x3"]), 10), T(g["e3_10"]))
+    assert torch.equal(ro.embed(T(g["x3"]), 4), T(g["e3_4"]))
+    assert torch.equal(ro.embed(T(g["x1"]), 4), T(g["e1_4"]))
+
+
+def test_a6_nerf(golden):
+    g = golden("a6_nerf")
+    st = ro.deterministic_nerf_state()
+    cx, cd = ro.nerf_channels()
+    out = ro.nerf_forward(st, "nerf_coarse", T(g["x"]), cx, cd)
+    torch.testing.assert_close(out, T(g["out"]), rtol=1e-6, atol=1e-6)
+    s = ro.nerf_forward(st, "nerf_coarse", T(g["x"])[:, :cx], cx, cd, sigma_only=True)
+    torch.testing.assert_close(s, T(g["sigma_only"]), rtol=1e-6, atol=1e-6)
+
+
+def test_a3_smoothing(golden):
+    g = golden("a3_smoothing")
+    sm, dens = ro.smoothing_position(T(g["ray_pos"]), T(g["nn"]), float(g["radius"]))
+    assert torch.equal(sm, T(g["smoothed"]))
+    assert torch.equal(dens, T(g["density"]))
+
+
+def test_a4_features(golden):
+    g = golden("a4_features")
+    feats, num_nn = ro.embedding_local_geometry(T(g["dists"]), T(g["nn"]), float(g["radius"]), T(g["ray_pos"]),
+                                                T(g["rays"]), T(g["ro"]))
+    assert torch.equal(num_nn, T(g["num_nn"]))
+    torch.testing.assert_close(feats, T(g["feats"]), rtol=0, atol=2e-6)
+
+
+def test_a8_composite(golden):
+    g = golden("a8_composite")
+    rgb, depth, w = ro.render_image(T(g["rgbsigma"]), T(g["z"]), T(g["rays"]), True)
+    assert torch.equal(rgb, T(g["rgb"])) and torch.equal(depth, T(g["depth"])) and torch.equal(w, T(g["weights"]))
+    rgb2, _, _ = ro.render_image(T(g["rgbsigma"]), T(g["z"]), T(g["rays"]), False)
+    assert torch.equal(rgb2, T(g["rgb_nobg"]))
+
+
+def test_a9_importance(golden):
+    g = golden("a9_importance")
+    rays = T(g["rays"])
+    xyz1, z1 = ro.importance_sampling(T(g["z0"]), T(g["weights"]), 128, rays[:, :3], rays[:, 3:])
+    assert torch.equal(z1, T(g["z1"]))
+    assert torch.equal(xyz1, T(g["xyz1"]))
+
+
+def test_a10_forward(golden):
+    g = golden("a10_forward")
+    st = ro.deterministic_nerf_state()
+    out = ro.render_forward(st, T(g["particles"]), T(g["ro"]), T(g["rays"]), float(g["near"]), float(g["far"]))
+    for k in ["num_nn_0", "num_nn_1", "mask_0", "mask_1"]:
+        assert torch.equal(out[k], T(g[k])), k
+    for k in ["rgb0", "rgb1", "depth0", "depth1", "opacity0", "opacity1"]:
+        torch.testing.assert_close(out[k], T(g[k]), rtol=0, atol=2e-6, msg=k)
+    # the synthetic rays must actually hit the fluid, otherwise the fixture pins nothing
+    assert float(out["mask_1"].max()) > 50 and float((1 - out["opacity1"]).max()) > 0.5
+
+
+def test_b1_integrate(golden):
+    g = golden("b1_integrate")
+    p2, v2 = to.integrate_pos_vel(T(g["pos"]), T(g["vel"]), T(g["gravity"]), float(g["dt"]))
+    assert torch.equal(p2, T(g["pos_new"])) and torch.equal(v2, T(g["vel_new"]))
+    p3, v3 = to.update_pos_vel(T(g["pos"]), p2, T(g["delta"]), float(g["dt"]))
+    assert torch.equal(p3, T(g["pos_corr"])) and torch.equal(v3, T(g["vel_corr"]))
+    assert torch.equal(to.window_poly6(T(g["R"])), T(g["window"]))
+    assert abs(to.FILTER_EXTENT - float(g["filter_extent"])) == 0

@@ -1,0 +1,127 @@
+/*
+ * neurofluid_hip.h — C ABI of libneurofluid_hip.so (gfx950 / MI355X).
+ *
+ * The reference (syguan96/NeuroFluid) has no FFI of its own: its hot path sits behind three
+ * Python-level operator boundaries.  This header is the drop-in boundary underneath
+ * them; each entry point cites the reference interface it replaces.  All pointers are DEVICE
+ * pointers unless marked [host]; the caller owns every buffer (torch caching allocator); the
+ * library allocates nothing, keeps no global state except a thread-local error string, enqueues
+ * all work on the hipStream_t argument and never synchronises.  Return 0 on success, <0 on error
+ * (nf_last_error() gives the message).  No torch types cross this boundary.
+ */
+#ifndef NEUROFLUID_HIP_H
+#define NEUROFLUID_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* nf_stream_t; /* hipStream_t */
+
+#define NF_VERSION 100
+#define NF_OK 0
+#define NF_EINVAL (-1)
+#define NF_ELAUNCH (-2)
+
+int nf_version(void);
+const char* nf_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Uniform cell grid over a point cloud (shared by renderer and transition model).
+ * Replaces the spatial structures inside pytorch3d.ops.ball_query (brute force there) and
+ * Open3D FixedRadiusSearch's hash table (reference: models/transmodel.py:86-95).
+ * bbox = {xmin,ymin,zmin,xmax,ymax,zmax} [host]; points outside are clamped into border cells
+ * (search stays exact).  Cell edge = max(cell, extent/NF_GRID_MAX_DIM).  Within a cell the points
+ * are stored in ASCENDING ORIGINAL INDEX (needed for first-K-by-index).
+ * ------------------------------------------------------------------------------------------ */
+#define NF_GRID_MAX_DIM 128
+size_t nf_grid_workspace_bytes(int n_points, float cell, const float bbox[6]);
+int nf_grid_build(const float* pts /*n*3*/, int n_points, float cell, const float bbox[6],
+                  void* grid_ws, size_t grid_ws_bytes, nf_stream_t stream);
+
+/* pytorch3d.ops.ball_query(p1, p2, radius, K) for one cloud — reference call site
+ * models/renderer.py:116-118.  First K points IN INDEX ORDER with sum_d (q_d-p_d)^2 < radius^2
+ * (fp32, mul+add, no FMA).  dists2/idx/nn padded with 0 / -1 / 0.  idx is int64 like pytorch3d. */
+int nf_ball_query_firstk(const void* grid_ws, const float* pts /*the cloud the grid was built from*/,
+                         const float* queries /*nq*3*/, int nq, float radius, int K,
+                         float* dists2 /*nq*K*/, int64_t* idx /*nq*K*/, float* nn /*nq*K*3*/,
+                         nf_stream_t stream);
+
+/* Open3D FixedRadiusSearch (L2, d^2 <= r^2, optional skip of identical positions) — reference:
+ * models/transmodel.py:92 (radius_search_ignore_query_points=True), results read at :136-138.
+ * Two calls: counts -> row_splits (inclusive scan done on device), then fill.
+ * nf_radius_count writes row_splits[0..nq] (int64, row_splits[nq] = nnz).
+ * nf_radius_fill writes idx/dist2 for rows whose range fits in nnz_capacity (deterministic order:
+ * cell-major, ascending point index inside a cell; Open3D's own order is hash-bucket order). */
+int nf_radius_count(const void* grid_ws, const float* queries, int nq, float radius, int ignore_same_pos,
+                    int64_t* row_splits /*nq+1*/, void* scan_ws, size_t scan_ws_bytes, nf_stream_t stream);
+size_t nf_radius_scan_workspace_bytes(int nq);
+int nf_radius_fill(const void* grid_ws, const float* queries, int nq, float radius, int ignore_same_pos,
+                   const int64_t* row_splits, int32_t* idx, float* dist2, int64_t nnz_capacity,
+                   nf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Renderer (RenderNet.forward, models/renderer.py:211-270), fused stages.
+ * Sample index = ray * S + s.  "Active rows" are the samples the MLP must evaluate:
+ * all-K-slots-filled samples when use_mask (models/renderer.py:233-237), every sample otherwise.
+ * ------------------------------------------------------------------------------------------ */
+
+/* A1 + cell test: xyz = o + d*z (utils/ray_utils.py:232-256 / :227); samples whose 27-cell
+ * neighbourhood is empty get num_nn = 0, mask = 0, rgbsigma = 0 here; the rest are appended to
+ * cand[] (count in cand_count[0], must be zeroed by the caller).
+ * z_table (S) is used when z == NULL (coarse pass: same depths for every ray). */
+int nf_render_classify(const void* grid_ws, const float* rays /*R*6*/, const float* z /*R*S or NULL*/,
+                       const float* z_table /*S or NULL*/, int R, int S, int use_mask,
+                       int32_t* num_nn /*R*S*/, uint8_t* mask /*R*S*/, float* rgbsigma /*R*S*4*/,
+                       int32_t* cand /*R*S*/, int32_t* cand_count /*1*/, nf_stream_t stream);
+
+/* A2 + A7: first-K search for every candidate; writes num_nn / mask, appends active rows:
+ * row_sample[row] = sample index, row_nbr[row*K + k] = neighbour index or -1,
+ * n_rows[0] = number of active rows (zeroed by the caller). */
+int nf_render_search(const void* grid_ws, const float* rays, const float* z, const float* z_table, int R, int S,
+                     float radius, int K, int use_mask, const int32_t* cand, const int32_t* cand_count,
+                     int32_t* num_nn, uint8_t* mask, float* rgbsigma /*zeroed here for rejected candidates*/,
+                     int32_t* row_sample, int32_t* row_nbr, int32_t* n_rows, nf_stream_t stream);
+
+/* A3 + A4 + A5: local-geometry features + positional encodings for every active row, written in
+ * the MLP operand layout X[tile][q][lane][4] (tile = row/32; lane = 32*h + row%32; float e of
+ * group q holds feature 8q+4h+e; pos-like features first (padded to 8*QX), then dir-like (8*QD)).
+ * enc_flags: bit0 density, bit1 smoothed_pos, bit2 var, bit3 smoothed_dir (models/renderer.py:30-44). */
+int nf_render_features(const float* particles /*Np*3*/, const float* rays, const float* z, const float* z_table,
+                       int R, int S, float radius, int K, int enc_flags, const float* ro /*3*/,
+                       const int32_t* row_sample, const int32_t* row_nbr, const int32_t* n_rows, int max_rows,
+                       float* X, nf_stream_t stream);
+int nf_render_feature_dims(int enc_flags, int* cx, int* cd, int* qx, int* qd);
+
+/* A6: NeRF MLP (models/nerf.py:83-124) on fp32 MFMA.  `packed` comes from nf_nerf_pack.
+ * Writes rgbsigma[row_sample[row]*4 .. +3] = (r,g,b,sigma) for every active row.
+ * If acts != NULL (training) also stores per-row activations for the backward pass:
+ * acts[row][NF_ACT_STRIDE] = h1..h8 (8*256) | final (256) | dir hidden (128). */
+#define NF_ACT_STRIDE 2432
+typedef struct {
+    const float* w[12]; /* xyz_encoding_1..8, xyz_encoding_final, dir_encoding, sigma, rgb  ([out][in], torch Linear) */
+    const float* b[12];
+} nf_nerf_params_t;
+size_t nf_nerf_packed_floats(int cx, int cd);
+int nf_nerf_pack(const nf_nerf_params_t* params /*[host]*/, int cx, int cd, float* packed, nf_stream_t stream);
+int nf_nerf_mlp_fwd(const float* packed, int cx, int cd, const float* X, const int32_t* n_rows, int max_rows,
+                    const int32_t* row_sample, float* rgbsigma, float* acts /*or NULL*/, nf_stream_t stream);
+
+/* A8: alpha compositing (models/renderer.py:182-208), one thread per ray, sequential products. */
+int nf_composite_fwd(const float* rgbsigma /*R*S*4*/, const float* z, const float* z_table, const float* rays,
+                     const uint8_t* mask, int R, int S, int white_bg,
+                     float* rgb /*R*3*/, float* depth /*R*/, float* opacity /*R*/, float* weights /*R*S*/,
+                     float* mask_sum /*R*/, nf_stream_t stream);
+
+/* A9: ImportanceSampling(det=True) (utils/ray_utils.py:178-229): z1 = sort(cat(z0, inverse-CDF samples)).
+ * u_table = torch.linspace(0,1,N_imp) supplied by the caller (bit-identical to the reference). */
+int nf_importance_sample(const float* z_table0 /*S0*/, const float* weights0 /*R*S0*/, const float* u_table /*N_imp*/,
+                         int R, int S0, int N_imp, float* z1 /*R*(S0+N_imp)*/, nf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEUROFLUID_HIP_H */

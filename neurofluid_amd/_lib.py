@@ -1,0 +1,80 @@
+"""ctypes binding of libneurofluid_hip.so (include/neurofluid_hip.h).
+
+The product path has NO fallback: if the library is missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libneurofluid_hip.so")
+
+c_void_p, c_int, c_float, c_size_t, c_int64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_int64
+
+
+class NerfParams(ctypes.Structure):
+    _fields_ = [("w", c_void_p * 12), ("b", c_void_p * 12)]
+
+
+# name -> (restype, argtypes); mirrors include/neurofluid_hip.h one-to-one (tests check the list)
+PROTOTYPES = {
+    "nf_version": (c_int, []),
+    "nf_last_error": (ctypes.c_char_p, []),
+    "nf_grid_workspace_bytes": (c_size_t, [c_int, c_float, ctypes.POINTER(c_float)]),
+    "nf_grid_build": (c_int, [c_void_p, c_int, c_float, ctypes.POINTER(c_float), c_void_p, c_size_t, c_void_p]),
+    "nf_ball_query_firstk": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nf_radius_scan_workspace_bytes": (c_size_t, [c_int]),
+    "nf_radius_count": (c_int, [c_void_p, c_void_p, c_int, c_float, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "nf_radius_fill": (c_int, [c_void_p, c_void_p, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "nf_render_classify": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nf_render_search": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_int, c_void_p,
+                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nf_render_features": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_int, c_void_p,
+                                   c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "nf_render_feature_dims": (c_int, [c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int),
+                                       ctypes.POINTER(c_int)]),
+    "nf_nerf_packed_floats": (c_size_t, [c_int, c_int]),
+    "nf_nerf_pack": (c_int, [ctypes.POINTER(NerfParams), c_int, c_int, c_void_p, c_void_p]),
+    "nf_nerf_mlp_fwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nf_composite_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+                                 c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nf_importance_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -m neurofluid_amd.build` (hipcc, gfx950). "
+            "neurofluid_amd has no CPU/PyTorch fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)   # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    if lib.nf_version() < 100:
+        raise RuntimeError("libneurofluid_hip.so is too old")
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().nf_last_error()
+        raise RuntimeError(f"libneurofluid_hip {what} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

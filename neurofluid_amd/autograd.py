@@ -1,0 +1,52 @@
+"""Forward / backward orchestration of the fused renderer (RenderNet.forward,
+/root/reference/models/renderer.py:211-270; autograd of the reference = SURVEY §8a row A12)."""
+import torch
+
+from . import ops
+
+
+def _prep(x):
+    return x.detach().contiguous().float()
+
+
+def _run_passes(net, particles, ro, rays, white_bg, fine, save_acts):
+    dev = rays.device
+    z_table, u_table = net._tables(dev)
+    grid = net.grid_for(particles)
+    pts = grid.points
+    rays_c = _prep(rays)
+    ro_c = _prep(ro)
+    pk0 = net.packed_weights(net.nerf_coarse)
+    p0 = ops.render_pass(grid, pts, rays_c, None, z_table, net.N_samples, net.raduis, net.num_neighbor, net.enc_flags,
+                         net.use_mask, ro_c, pk0, net.in_channels_xyz, net.in_channels_dir, white_bg, save_acts)
+    p0.packed = pk0
+    p1 = None
+    if fine:
+        z1 = ops.importance_sample(z_table, p0.weights, u_table, net.N_importance)
+        pk1 = net.packed_weights(net.nerf_fine)
+        p1 = ops.render_pass(grid, pts, rays_c, z1, None, net.N_samples + net.N_importance, net.raduis, net.num_neighbor,
+                             net.enc_flags, net.use_mask, ro_c, pk1, net.in_channels_xyz, net.in_channels_dir, white_bg,
+                             save_acts)
+        p1.z = z1
+        p1.packed = pk1
+    return p0, p1, rays_c, ro_c, grid
+
+
+def _results(p0, p1):
+    R = p0.R
+    out = {"rgb0": p0.rgb, "depth0": p0.depth, "opacity0": p0.opacity,
+           "num_nn_0": p0.num_nn.view(R, p0.S, 1).to(torch.int64), "mask_0": p0.mask_sum.view(R, 1)}
+    if p1 is not None:
+        out.update({"rgb1": p1.rgb, "depth1": p1.depth, "opacity1": p1.opacity,
+                    "num_nn_1": p1.num_nn.view(R, p1.S, 1).to(torch.int64), "mask_1": p1.mask_sum.view(R, 1)})
+    return out
+
+
+def render_forward(net, particles, ro, rays, white_bg=True, fine=True):
+    needs_grad = torch.is_grad_enabled() and (particles.requires_grad or any(p.requires_grad for p in net.parameters()))
+    if needs_grad:
+        from .autograd_bwd import render_with_grad
+        return render_with_grad(net, particles, ro, rays, white_bg, fine)
+    with torch.no_grad():
+        p0, p1, _, _, _ = _run_passes(net, particles, ro, rays, white_bg, fine, save_acts=False)
+        return _results(p0, p1)

@@ -1,0 +1,56 @@
+"""Builds libneurofluid_hip.so for gfx950 with hipcc (in-tree, so the .so travels with the repo)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libneurofluid_hip.so")
+SOURCES = ["nf_grid.hip", "nf_render.hip", "nf_mlp.hip", "nf_mlp_bwd.hip", "nf_cconv.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-value"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(os.path.dirname(HERE), "include", "neurofluid_hip.h"))
+    objs = []
+    procs = []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        if not os.path.exists(sp):
+            continue
+        obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _stale(obj, [sp] + headers):
+            cmd = [HIPCC] + FLAGS + ["-c", sp, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    failed = False
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            failed = True
+            sys.stderr.write(f"[neurofluid_amd.build] {src} failed:\n{out.decode()}\n")
+        elif verbose and out:
+            print(out.decode())
+    if failed:
+        raise RuntimeError("hipcc failed")
+    if force or procs or _stale(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,139 @@
+// nf_common.h — shared declarations of libneurofluid_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/neurofluid_hip.h"
+
+#define NF_WAVE 64
+
+void nf_set_error(const char* fmt, ...);
+
+#define NF_CHECK_ARG(cond, msg)                                   \
+    do {                                                          \
+        if (!(cond)) { nf_set_error("%s: %s", __func__, msg); return NF_EINVAL; } \
+    } while (0)
+
+#define NF_CHECK_LAUNCH()                                                             \
+    do {                                                                              \
+        hipError_t e_ = hipGetLastError();                                            \
+        if (e_ != hipSuccess) { nf_set_error("%s: launch failed: %s", __func__, hipGetErrorString(e_)); return NF_ELAUNCH; } \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// Grid workspace layout (device memory, caller-owned):
+//   [NfGridHeader | cell_start (n_cells+1) | cell_dil (n_cells) | sorted_idx (n) | sorted_pos (n float4)
+//    | tmp_cell (n) | tmp_list (n) | cell_fill (n_cells)]
+// ---------------------------------------------------------------------------------------------
+struct NfGridHeader {
+    float origin[3];
+    float inv_cell[3];
+    int dims[3];
+    int n_points;
+    int n_cells;
+    int off_cell_start;  // byte offsets from the start of the workspace
+    int off_cell_dil;
+    int off_sorted_idx;
+    int off_sorted_pos;
+    int off_tmp_cell;
+    int off_tmp_list;
+    int off_cell_fill;
+    int pad;
+};
+
+struct NfGridView {
+    float ox, oy, oz;
+    float icx, icy, icz;
+    int dx, dy, dz;
+    int n_points;
+    const int* cell_start;
+    const int* cell_dil;
+    const int* sorted_idx;
+    const float4* sorted_pos;
+};
+
+__device__ __forceinline__ NfGridView nf_grid_view(const void* ws)
+{
+    const NfGridHeader* h = (const NfGridHeader*)ws;
+    const char* b = (const char*)ws;
+    NfGridView v;
+    v.ox = h->origin[0]; v.oy = h->origin[1]; v.oz = h->origin[2];
+    v.icx = h->inv_cell[0]; v.icy = h->inv_cell[1]; v.icz = h->inv_cell[2];
+    v.dx = h->dims[0]; v.dy = h->dims[1]; v.dz = h->dims[2];
+    v.n_points = h->n_points;
+    v.cell_start = (const int*)(b + h->off_cell_start);
+    v.cell_dil = (const int*)(b + h->off_cell_dil);
+    v.sorted_idx = (const int*)(b + h->off_sorted_idx);
+    v.sorted_pos = (const float4*)(b + h->off_sorted_pos);
+    return v;
+}
+
+__device__ __forceinline__ int nf_cell_coord(float p, float o, float ic, int d)
+{
+    int c = (int)floorf((p - o) * ic);
+    return c < 0 ? 0 : (c >= d ? d - 1 : c);
+}
+
+// fp32 squared distance exactly as the oracle (oracle/csrc/nf_oracle.c:d2f): mul + add chain, d = 0,1,2,
+// no FMA contraction.
+__device__ __forceinline__ float nf_dist2(float qx, float qy, float qz, float px, float py, float pz)
+{
+    float dx = __fsub_rn(qx, px), dy = __fsub_rn(qy, py), dz = __fsub_rn(qz, pz);
+    float s = __fmul_rn(dx, dx);
+    s = __fadd_rn(s, __fmul_rn(dy, dy));
+    s = __fadd_rn(s, __fmul_rn(dz, dz));
+    return s;
+}
+
+// sample position o + d*z with separate mul / add (torch: rays_o + rays_d * z)
+__device__ __forceinline__ float nf_madd_nofma(float o, float d, float z) { return __fadd_rn(o, __fmul_rn(d, z)); }
+
+// ------------------------------------------------------------------------------------------------
+// first-K-by-index search core (used by nf_grid.hip: ball query op, nf_render.hip: fused search)
+// ------------------------------------------------------------------------------------------------
+#define BQ_BLOCK 128
+
+// Sorted insertion of (j, d2) into the per-thread ascending-by-index list held in LDS as
+// list[k * BQ_BLOCK + tid].  Returns the new count.
+__device__ __forceinline__ int firstk_insert(int* li, float* ld, int cnt, int K, int j, float d2, int tid)
+{
+    int pos = cnt < K ? cnt : K - 1;  // slot that is overwritten / appended
+    // shift larger entries up
+    while (pos > 0 && li[(pos - 1) * BQ_BLOCK + tid] > j) {
+        li[pos * BQ_BLOCK + tid] = li[(pos - 1) * BQ_BLOCK + tid];
+        ld[pos * BQ_BLOCK + tid] = ld[(pos - 1) * BQ_BLOCK + tid];
+        --pos;
+    }
+    li[pos * BQ_BLOCK + tid] = j;
+    ld[pos * BQ_BLOCK + tid] = d2;
+    return cnt < K ? cnt + 1 : K;
+}
+
+// Core search used by the standalone op and by the renderer (nf_render.hip includes this file's header part).
+__device__ __forceinline__ int firstk_search(const NfGridView& g, float qx, float qy, float qz, float r2, int K,
+                                             int* li, float* ld, int tid)
+{
+    int cx = nf_cell_coord(qx, g.ox, g.icx, g.dx);
+    int cy = nf_cell_coord(qy, g.oy, g.icy, g.dy);
+    int cz = nf_cell_coord(qz, g.oz, g.icz, g.dz);
+    int cnt = 0;
+    for (int z = max(cz - 1, 0); z <= min(cz + 1, g.dz - 1); ++z)
+        for (int y = max(cy - 1, 0); y <= min(cy + 1, g.dy - 1); ++y)
+            for (int x = max(cx - 1, 0); x <= min(cx + 1, g.dx - 1); ++x) {
+                int c = (z * g.dy + y) * g.dx + x;
+                int s = g.cell_start[c], e = g.cell_start[c + 1];
+                for (int t = s; t < e; ++t) {
+                    float4 p = g.sorted_pos[t];
+                    int j = __float_as_int(p.w);
+                    if (cnt == K && j > li[(K - 1) * BQ_BLOCK + tid]) break;  // cell is index-sorted
+                    float d2 = nf_dist2(qx, qy, qz, p.x, p.y, p.z);
+                    if (d2 < r2) cnt = firstk_insert(li, ld, cnt, K, j, d2, tid);
+                }
+            }
+    return cnt;
+}
+
+
+// host-side helper shared by the grid functions
+int nf_grid_make_header(int n_points, float cell, const float bbox[6], NfGridHeader* h, size_t* total_bytes);

@@ -1,0 +1,375 @@
+// nf_grid.hip — uniform cell grid, first-K-by-index ball query, fixed-radius CSR search.
+//
+// Replaces pytorch3d.ops.ball_query (reference call site models/renderer.py:116-118) and Open3D
+// FixedRadiusSearch (models/transmodel.py:86-95, :136-138).  Design notes:
+//  * cell edge >= search radius, so a query only visits its 27-cell neighbourhood;
+//  * cells keep their points in ascending ORIGINAL index (counting sort + in-cell rank), so
+//    "first K by index" is a K-bounded sorted insertion with an early break per cell;
+//  * the per-thread K-list lives in LDS, laid out [k][thread] so every access is conflict-free.
+#include "nf_common.h"
+#include <math.h>
+#include <string.h>
+
+// ------------------------------------------------------------------------------------------------
+// error string
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void nf_set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" int nf_version(void) { return NF_VERSION; }
+extern "C" const char* nf_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------------------------------------
+// generic exclusive scan  int32 counts[n] -> OutT out[n+1]   (3 launches, any n)
+// ------------------------------------------------------------------------------------------------
+#define SCAN_BLOCK 1024
+
+template <typename OutT>
+__device__ __forceinline__ OutT block_exclusive_scan(OutT v, OutT* lds, OutT* total)
+{
+    // wave scan then cross-wave
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    OutT x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        OutT y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+    }
+    if (lane == 63) lds[w] = x;
+    __syncthreads();
+    if (w == 0) {
+        OutT s = lane < (SCAN_BLOCK / 64) ? lds[lane] : 0;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            OutT y = __shfl_up(s, o, 64);
+            if (lane >= o) s += y;
+        }
+        if (lane < (SCAN_BLOCK / 64)) lds[lane] = s;
+    }
+    __syncthreads();
+    OutT base = w ? lds[w - 1] : 0;
+    *total = lds[SCAN_BLOCK / 64 - 1];
+    return base + x - v;
+}
+
+template <typename OutT>
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_local(const int* __restrict__ in, OutT* __restrict__ out,
+                                                           OutT* __restrict__ block_sums, int n)
+{
+    __shared__ OutT lds[SCAN_BLOCK / 64];
+    int i = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+    OutT v = i < n ? (OutT)in[i] : 0;
+    OutT tot;
+    OutT ex = block_exclusive_scan<OutT>(v, lds, &tot);
+    if (i < n) out[i] = ex;
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+template <typename OutT>
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_sums(OutT* __restrict__ block_sums, int nb, OutT* __restrict__ out, int n)
+{
+    __shared__ OutT lds[SCAN_BLOCK / 64];
+    __shared__ OutT carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nb; base += SCAN_BLOCK) {
+        int i = base + threadIdx.x;
+        OutT v = i < nb ? block_sums[i] : 0;
+        OutT tot;
+        OutT ex = block_exclusive_scan<OutT>(v, lds, &tot);
+        OutT c = carry;
+        if (i < nb) block_sums[i] = ex + c;
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[n] = carry;
+}
+
+template <typename OutT>
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_add(OutT* __restrict__ out, const OutT* __restrict__ block_sums, int n)
+{
+    int i = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+    if (i < n) out[i] += block_sums[blockIdx.x];
+}
+
+template <typename OutT>
+static void launch_scan(const int* in, OutT* out, OutT* block_sums, int n, hipStream_t st)
+{
+    int nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(k_scan_local<OutT>, dim3(nb), dim3(SCAN_BLOCK), 0, st, in, out, block_sums, n);
+    hipLaunchKernelGGL(k_scan_sums<OutT>, dim3(1), dim3(SCAN_BLOCK), 0, st, block_sums, nb, out, n);
+    hipLaunchKernelGGL(k_scan_add<OutT>, dim3(nb), dim3(SCAN_BLOCK), 0, st, out, block_sums, n);
+}
+
+// ------------------------------------------------------------------------------------------------
+// grid build
+// ------------------------------------------------------------------------------------------------
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+int nf_grid_make_header(int n, float cell, const float bbox[6], NfGridHeader* h, size_t* total)
+{
+    if (n < 0 || !(cell > 0.f)) return NF_EINVAL;
+    memset(h, 0, sizeof(*h));
+    long cells = 1;
+    for (int d = 0; d < 3; ++d) {
+        float lo = bbox[d], hi = bbox[3 + d];
+        if (!(hi >= lo)) return NF_EINVAL;
+        float ext = hi - lo;
+        float c = cell;
+        if (ext / c > (float)(NF_GRID_MAX_DIM - 1)) c = ext / (float)(NF_GRID_MAX_DIM - 1);
+        int dim = (int)floorf(ext / c) + 1;
+        if (dim < 1) dim = 1;
+        if (dim > NF_GRID_MAX_DIM) dim = NF_GRID_MAX_DIM;
+        h->origin[d] = lo;
+        h->inv_cell[d] = 1.0f / c;
+        h->dims[d] = dim;
+        cells *= dim;
+    }
+    h->n_points = n;
+    h->n_cells = (int)cells;
+    size_t off = align_up(sizeof(NfGridHeader), 256);
+    h->off_cell_start = (int)off; off = align_up(off + sizeof(int) * (cells + 1), 256);
+    h->off_cell_dil = (int)off;   off = align_up(off + sizeof(int) * cells, 256);
+    h->off_sorted_idx = (int)off; off = align_up(off + sizeof(int) * (size_t)(n > 0 ? n : 1), 256);
+    h->off_sorted_pos = (int)off; off = align_up(off + sizeof(float4) * (size_t)(n > 0 ? n : 1), 256);
+    h->off_tmp_cell = (int)off;   off = align_up(off + sizeof(int) * (size_t)(n > 0 ? n : 1), 256);
+    h->off_tmp_list = (int)off;   off = align_up(off + sizeof(int) * (size_t)(n > 0 ? n : 1), 256);
+    h->off_cell_fill = (int)off;  off = align_up(off + sizeof(int) * (cells + SCAN_BLOCK + 2048), 256);
+    if (off > (size_t)0x7fffffff) return NF_EINVAL;
+    *total = off;
+    return NF_OK;
+}
+
+extern "C" size_t nf_grid_workspace_bytes(int n_points, float cell, const float bbox[6])
+{
+    NfGridHeader h;
+    size_t tot = 0;
+    if (nf_grid_make_header(n_points, cell, bbox, &h, &tot) != NF_OK) return 0;
+    return tot;
+}
+
+__global__ void k_grid_init(NfGridHeader h, void* ws)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *(NfGridHeader*)ws = h;
+    int* fill = (int*)((char*)ws + h.off_cell_fill);
+    if (i < h.n_cells) fill[i] = 0;
+}
+
+__global__ void k_grid_count(NfGridHeader h, void* ws, const float* __restrict__ pts)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= h.n_points) return;
+    int cx = nf_cell_coord(pts[3 * i + 0], h.origin[0], h.inv_cell[0], h.dims[0]);
+    int cy = nf_cell_coord(pts[3 * i + 1], h.origin[1], h.inv_cell[1], h.dims[1]);
+    int cz = nf_cell_coord(pts[3 * i + 2], h.origin[2], h.inv_cell[2], h.dims[2]);
+    int c = (cz * h.dims[1] + cy) * h.dims[0] + cx;
+    ((int*)((char*)ws + h.off_tmp_cell))[i] = c;
+    atomicAdd((int*)((char*)ws + h.off_cell_fill) + c, 1);
+}
+
+__global__ void k_grid_zero_fill(NfGridHeader h, void* ws)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < h.n_cells) ((int*)((char*)ws + h.off_cell_fill))[i] = 0;
+}
+
+__global__ void k_grid_scatter(NfGridHeader h, void* ws)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= h.n_points) return;
+    char* b = (char*)ws;
+    int c = ((int*)(b + h.off_tmp_cell))[i];
+    int pos = ((int*)(b + h.off_cell_start))[c] + atomicAdd((int*)(b + h.off_cell_fill) + c, 1);
+    ((int*)(b + h.off_tmp_list))[pos] = i;
+}
+
+// stable order inside each cell: rank = number of same-cell points with a smaller original index
+__global__ void k_grid_rank(NfGridHeader h, void* ws, const float* __restrict__ pts)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= h.n_points) return;
+    char* b = (char*)ws;
+    const int* list = (const int*)(b + h.off_tmp_list);
+    int i = list[t];
+    int c = ((const int*)(b + h.off_tmp_cell))[i];
+    const int* cs = (const int*)(b + h.off_cell_start);
+    int s = cs[c], e = cs[c + 1];
+    int rank = 0;
+    for (int u = s; u < e; ++u) rank += (list[u] < i);
+    int dst = s + rank;
+    ((int*)(b + h.off_sorted_idx))[dst] = i;
+    ((float4*)(b + h.off_sorted_pos))[dst] = make_float4(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], __int_as_float(i));
+}
+
+__global__ void k_grid_dilate(NfGridHeader h, void* ws)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= h.n_cells) return;
+    char* b = (char*)ws;
+    const int* cs = (const int*)(b + h.off_cell_start);
+    int cx = c % h.dims[0], cy = (c / h.dims[0]) % h.dims[1], cz = c / (h.dims[0] * h.dims[1]);
+    int tot = 0;
+    for (int z = max(cz - 1, 0); z <= min(cz + 1, h.dims[2] - 1); ++z)
+        for (int y = max(cy - 1, 0); y <= min(cy + 1, h.dims[1] - 1); ++y) {
+            int r0 = (z * h.dims[1] + y) * h.dims[0];
+            int x0 = max(cx - 1, 0), x1 = min(cx + 1, h.dims[0] - 1);
+            tot += cs[r0 + x1 + 1] - cs[r0 + x0];  // cells of one x-row are contiguous
+        }
+    ((int*)(b + h.off_cell_dil))[c] = tot;
+}
+
+extern "C" int nf_grid_build(const float* pts, int n, float cell, const float bbox[6], void* ws, size_t ws_bytes,
+                             nf_stream_t stream)
+{
+    NfGridHeader h;
+    size_t tot = 0;
+    NF_CHECK_ARG(nf_grid_make_header(n, cell, bbox, &h, &tot) == NF_OK, "bad grid parameters");
+    NF_CHECK_ARG(ws != nullptr && ws_bytes >= tot, "workspace too small");
+    NF_CHECK_ARG(n == 0 || pts != nullptr, "null points");
+    hipStream_t st = (hipStream_t)stream;
+    const int B = 256;
+    int gc = (h.n_cells + B - 1) / B, gp = (n + B - 1) / B;
+    if (gp < 1) gp = 1;
+    hipLaunchKernelGGL(k_grid_init, dim3(gc), dim3(B), 0, st, h, ws);
+    hipLaunchKernelGGL(k_grid_count, dim3(gp), dim3(B), 0, st, h, ws, pts);
+    int* fill = (int*)((char*)ws + h.off_cell_fill);
+    int* cstart = (int*)((char*)ws + h.off_cell_start);
+    launch_scan<int>(fill, cstart, fill + h.n_cells + 8, h.n_cells, st);  // block sums live past the fill array
+    hipLaunchKernelGGL(k_grid_zero_fill, dim3(gc), dim3(B), 0, st, h, ws);
+    hipLaunchKernelGGL(k_grid_scatter, dim3(gp), dim3(B), 0, st, h, ws);
+    hipLaunchKernelGGL(k_grid_rank, dim3(gp), dim3(B), 0, st, h, ws, pts);
+    hipLaunchKernelGGL(k_grid_dilate, dim3(gc), dim3(B), 0, st, h, ws);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// first-K-by-index ball query (standalone op with pytorch3d's output contract)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(BQ_BLOCK) k_ball_query(const void* __restrict__ ws, const float* __restrict__ pts,
+                                                         const float* __restrict__ q, int nq, float r2, int K,
+                                                         float* __restrict__ dists2, int64_t* __restrict__ idx,
+                                                         float* __restrict__ nn)
+{
+    extern __shared__ int lds[];
+    int* li = lds;
+    float* ld = (float*)(lds + K * BQ_BLOCK);
+    int i = blockIdx.x * BQ_BLOCK + threadIdx.x;
+    if (i >= nq) return;
+    NfGridView g = nf_grid_view(ws);
+    float qx = q[3 * i], qy = q[3 * i + 1], qz = q[3 * i + 2];
+    int cnt = firstk_search(g, qx, qy, qz, r2, K, li, ld, threadIdx.x);
+    for (int k = 0; k < K; ++k) {
+        size_t o = (size_t)i * K + k;
+        float d = 0.f, x = 0.f, y = 0.f, z = 0.f;
+        int64_t j = -1;
+        if (k < cnt) {
+            d = ld[k * BQ_BLOCK + threadIdx.x];
+            j = li[k * BQ_BLOCK + threadIdx.x];
+            x = pts[3 * j]; y = pts[3 * j + 1]; z = pts[3 * j + 2];
+        }
+        dists2[o] = d;
+        idx[o] = j;
+        if (nn) { nn[3 * o] = x; nn[3 * o + 1] = y; nn[3 * o + 2] = z; }
+    }
+}
+
+extern "C" int nf_ball_query_firstk(const void* ws, const float* pts, const float* queries, int nq, float radius, int K,
+                                    float* dists2, int64_t* idx, float* nn, nf_stream_t stream)
+{
+    NF_CHECK_ARG(ws && pts && (nq == 0 || (queries && dists2 && idx)), "null pointer");
+    NF_CHECK_ARG(K >= 1 && K <= 64, "K must be in [1,64]");
+    NF_CHECK_ARG(radius > 0.f, "radius must be positive");
+    if (nq == 0) return NF_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const float r2 = radius * radius;  // fp32 product, like pytorch3d's `radius2`
+    size_t lds = (size_t)K * BQ_BLOCK * 8;
+    hipLaunchKernelGGL(k_ball_query, dim3((nq + BQ_BLOCK - 1) / BQ_BLOCK), dim3(BQ_BLOCK), lds, st, ws, pts, queries, nq,
+                       r2, K, dists2, idx, nn);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fixed-radius search -> CSR  (Open3D FixedRadiusSearch contract: d2 <= r2, optional skip of points
+// at the identical position; models/transmodel.py:92, :136-138)
+// ------------------------------------------------------------------------------------------------
+template <bool FILL>
+__global__ void __launch_bounds__(256) k_radius(const void* __restrict__ ws, const float* __restrict__ q, int nq, float r2,
+                                                int ignore_same, int* __restrict__ counts,
+                                                const int64_t* __restrict__ row_splits, int32_t* __restrict__ idx,
+                                                float* __restrict__ dist2, int64_t cap)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    NfGridView g = nf_grid_view(ws);
+    float qx = q[3 * i], qy = q[3 * i + 1], qz = q[3 * i + 2];
+    int cx = nf_cell_coord(qx, g.ox, g.icx, g.dx);
+    int cy = nf_cell_coord(qy, g.oy, g.icy, g.dy);
+    int cz = nf_cell_coord(qz, g.oz, g.icz, g.dz);
+    int cnt = 0;
+    int64_t o = FILL ? row_splits[i] : 0;
+    int64_t oe = FILL ? row_splits[i + 1] : 0;
+    if (FILL && oe > cap) return;
+    for (int z = max(cz - 1, 0); z <= min(cz + 1, g.dz - 1); ++z)
+        for (int y = max(cy - 1, 0); y <= min(cy + 1, g.dy - 1); ++y) {
+            int r0 = (z * g.dy + y) * g.dx;
+            int s = g.cell_start[r0 + max(cx - 1, 0)], e = g.cell_start[r0 + min(cx + 1, g.dx - 1) + 1];
+            for (int t = s; t < e; ++t) {
+                float4 p = g.sorted_pos[t];
+                if (ignore_same && p.x == qx && p.y == qy && p.z == qz) continue;
+                float d2 = nf_dist2(qx, qy, qz, p.x, p.y, p.z);
+                if (d2 <= r2) {
+                    if (FILL) { idx[o + cnt] = __float_as_int(p.w); dist2[o + cnt] = d2; }
+                    ++cnt;
+                }
+            }
+        }
+    if (!FILL) counts[i] = cnt;
+}
+
+extern "C" size_t nf_radius_scan_workspace_bytes(int nq)
+{
+    size_t nb = (size_t)(nq + SCAN_BLOCK - 1) / SCAN_BLOCK + 1;
+    return align_up(sizeof(int) * (size_t)(nq > 0 ? nq : 1), 256) + align_up(sizeof(int64_t) * nb, 256);
+}
+
+extern "C" int nf_radius_count(const void* ws, const float* queries, int nq, float radius, int ignore_same_pos,
+                               int64_t* row_splits, void* scan_ws, size_t scan_ws_bytes, nf_stream_t stream)
+{
+    NF_CHECK_ARG(ws && row_splits && scan_ws, "null pointer");
+    NF_CHECK_ARG(nq >= 0 && radius > 0.f, "bad nq/radius");
+    NF_CHECK_ARG(scan_ws_bytes >= nf_radius_scan_workspace_bytes(nq), "scan workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    int* counts = (int*)scan_ws;
+    int64_t* sums = (int64_t*)((char*)scan_ws + align_up(sizeof(int) * (size_t)(nq > 0 ? nq : 1), 256));
+    const float r2 = radius * radius;
+    if (nq > 0)
+        hipLaunchKernelGGL(k_radius<false>, dim3((nq + 255) / 256), dim3(256), 0, st, ws, queries, nq, r2, ignore_same_pos,
+                           counts, (const int64_t*)nullptr, (int32_t*)nullptr, (float*)nullptr, (int64_t)0);
+    launch_scan<int64_t>(counts, row_splits, sums, nq, st);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+extern "C" int nf_radius_fill(const void* ws, const float* queries, int nq, float radius, int ignore_same_pos,
+                              const int64_t* row_splits, int32_t* idx, float* dist2, int64_t nnz_capacity,
+                              nf_stream_t stream)
+{
+    NF_CHECK_ARG(ws && row_splits && (nnz_capacity == 0 || (idx && dist2)), "null pointer");
+    if (nq == 0 || nnz_capacity == 0) return NF_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const float r2 = radius * radius;
+    hipLaunchKernelGGL(k_radius<true>, dim3((nq + 255) / 256), dim3(256), 0, st, ws, queries, nq, r2, ignore_same_pos,
+                       (int*)nullptr, row_splits, idx, dist2, nnz_capacity);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}

@@ -1,0 +1,405 @@
+// nf_mlp.hip — the NeRF MLP (models/nerf.py:83-124) as ONE persistent fp32-MFMA kernel.
+//
+// Design:
+//  * transposed problem  D[out_feature][sample] = W[out][in] * H[in][sample]  on
+//    v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD = the chip's 157 TF f32 matrix peak);
+//    a wave owns 32 samples for the WHOLE network.  With that orientation the D fragment of one
+//    layer (lane l: sample l&31, features (r&3)+8(r>>2)+4(l>>5)) IS a valid B fragment of the next
+//    layer — register r of block b pairs feature f with f+4 across the two half-waves, and the
+//    K order of a dot product is free — so hidden activations never leave the register file:
+//    128 VGPRs of activations + 128 AGPRs of accumulators per lane, one wave per SIMD.
+//  * the A operand (weights) is pre-packed (nf_nerf_pack) so that each lane fetches the operands of
+//    4 consecutive MFMAs with one 16-byte load; the 2.7 MB of weights of a net stay L2-resident
+//    (4 MiB L2 per XCD) and stream L2 -> VGPR two K-steps ahead of the MFMAs, no LDS, no barriers.
+//  * skip connection (layer 5) and the view branch are split-K accumulations over the feature
+//    matrix X (re-read from HBM/L2, 1 KB per row), never materialised concatenations.
+//  * sigma (256->1) and rgb (128->3) heads run on the VALU from the fragments, then one 16-B store
+//    per sample scatters (r,g,b,sigma) to the dense per-sample array.
+#include "nf_common.h"
+#include <math.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// ------------------------------------------------------------------------------------------------
+// packed-weight layout
+// ------------------------------------------------------------------------------------------------
+struct NfMlpLayout {
+    int cx, cd, qx, qd;
+    int off_x[9];   // layer l (0 = xyz_encoding_1 .. 7 = xyz_encoding_8, 8 = xyz_encoding_final): X-part [qx*4][2][64][4] or -1
+    int off_h[9];   // hidden part [128][2][64][4] or -1
+    int off_dir_h;  // [128][64][4]
+    int off_dir_x;  // [qd*4][64][4]
+    int off_wsig;   // [128][2]
+    int off_wrgb;   // [3][64][2]
+    int off_b[9];   // natural bias vectors (256 each)
+    int off_bdir;   // 128
+    int off_bsig;   // 1
+    int off_brgb;   // 3
+    int total;
+};
+
+static NfMlpLayout mlp_layout(int cx, int cd)
+{
+    NfMlpLayout L;
+    L.cx = cx; L.cd = cd; L.qx = (cx + 7) / 8; L.qd = (cd + 7) / 8;
+    int o = 0;
+    for (int l = 0; l < 9; ++l) {
+        L.off_x[l] = -1; L.off_h[l] = -1;
+        if (l == 0 || l == 4) { L.off_x[l] = o; o += L.qx * 4 * 512; }
+        if (l != 0) { L.off_h[l] = o; o += 128 * 512; }
+    }
+    L.off_dir_h = o; o += 128 * 256;
+    L.off_dir_x = o; o += L.qd * 4 * 256;
+    L.off_wsig = o; o += 256;
+    L.off_wrgb = o; o += 384;
+    for (int l = 0; l < 9; ++l) { L.off_b[l] = o; o += 256; }
+    L.off_bdir = o; o += 128;
+    L.off_bsig = o; o += 4;
+    L.off_brgb = o; o += 4;
+    L.total = o;
+    return L;
+}
+
+extern "C" size_t nf_nerf_packed_floats(int cx, int cd) { return (size_t)mlp_layout(cx, cd).total; }
+
+// feature held by register r of block b in half-wave h (MFMA 32x32 C/D layout)
+__device__ __host__ __forceinline__ int frag_feature(int b, int r, int h) { return 32 * b + (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+struct NfNerfPtrs {
+    const float* w[12];
+    const float* b[12];
+};
+
+__global__ void k_mlp_pack(NfMlpLayout L, NfNerfPtrs P, float* __restrict__ out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L.total) return;
+    float v = 0.f;
+    // biases
+    if (i >= L.off_b[0]) {
+        if (i >= L.off_brgb) { int k = i - L.off_brgb; v = k < 3 ? P.b[11][k] : 0.f; }
+        else if (i >= L.off_bsig) { int k = i - L.off_bsig; v = k < 1 ? P.b[10][0] : 0.f; }
+        else if (i >= L.off_bdir) v = P.b[9][i - L.off_bdir];
+        else { int l = (i - L.off_b[0]) / 256; v = P.b[l][(i - L.off_b[0]) % 256]; }
+        out[i] = v;
+        return;
+    }
+    if (i >= L.off_wrgb) {  // [c][(b*16+r)][h]
+        int k = i - L.off_wrgb, c = k / 128, rem = k % 128, br = rem >> 1, h = rem & 1;
+        v = P.w[11][c * 128 + frag_feature(br >> 4, br & 15, h)];
+        out[i] = v;
+        return;
+    }
+    if (i >= L.off_wsig) {
+        int k = i - L.off_wsig, br = k >> 1, h = k & 1;
+        out[i] = P.w[10][frag_feature(br >> 4, br & 15, h)];
+        return;
+    }
+    if (i >= L.off_dir_x) {  // [s][lane][e], 4 output blocks
+        int k = i - L.off_dir_x, e = k & 3, lane = (k >> 2) & 63, s = k >> 8;
+        int q = s >> 2, r = s & 3, h = lane >> 5;
+        int f = 8 * q + 4 * h + r;  // index into the dir-like features
+        int o = 32 * e + (lane & 31);
+        out[i] = f < L.cd ? P.w[9][(size_t)o * (256 + L.cd) + 256 + f] : 0.f;
+        return;
+    }
+    if (i >= L.off_dir_h) {
+        int k = i - L.off_dir_h, e = k & 3, lane = (k >> 2) & 63, s = k >> 8;
+        int f = frag_feature(s >> 4, s & 15, lane >> 5);
+        int o = 32 * e + (lane & 31);
+        out[i] = P.w[9][(size_t)o * (256 + L.cd) + f];
+        return;
+    }
+    // layers 0..8
+    for (int l = 8; l >= 0; --l) {
+        int in_dim = (l == 0) ? L.cx : (l == 4 ? L.cx + 256 : 256);
+        if (L.off_h[l] >= 0 && i >= L.off_h[l]) {  // [s][g][lane][e]
+            int k = i - L.off_h[l], e = k & 3, lane = (k >> 2) & 63, g = (k >> 8) & 1, s = k >> 9;
+            int f = frag_feature(s >> 4, s & 15, lane >> 5);
+            int o = 32 * (4 * g + e) + (lane & 31);
+            int col = (l == 4) ? L.cx + f : f;  // layer 5 input = cat[input_xyz, h]
+            out[i] = P.w[l][(size_t)o * in_dim + col];
+            return;
+        }
+        if (L.off_x[l] >= 0 && i >= L.off_x[l]) {
+            int k = i - L.off_x[l], e = k & 3, lane = (k >> 2) & 63, g = (k >> 8) & 1, s = k >> 9;
+            int q = s >> 2, r = s & 3, h = lane >> 5;
+            int f = 8 * q + 4 * h + r;
+            int o = 32 * (4 * g + e) + (lane & 31);
+            out[i] = f < L.cx ? P.w[l][(size_t)o * in_dim + f] : 0.f;
+            return;
+        }
+    }
+}
+
+extern "C" int nf_nerf_pack(const nf_nerf_params_t* params, int cx, int cd, float* packed, nf_stream_t stream)
+{
+    NF_CHECK_ARG(params && packed, "null pointer");
+    NF_CHECK_ARG(cx >= 1 && cx <= 256 && cd >= 1 && cd <= 256, "bad channel counts");
+    NfNerfPtrs P;
+    for (int i = 0; i < 12; ++i) {
+        NF_CHECK_ARG(params->w[i] && params->b[i], "null weight/bias pointer");
+        P.w[i] = params->w[i]; P.b[i] = params->b[i];
+    }
+    NfMlpLayout L = mlp_layout(cx, cd);
+    hipLaunchKernelGGL(k_mlp_pack, dim3((L.total + 255) / 256), dim3(256), 0, (hipStream_t)stream, L, P, packed);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward kernel
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void step8(const f32x4 w0, const f32x4 w1, const float bv, f32x16 (&acc)[8])
+{
+    acc[0] = MFMA32(w0[0], bv, acc[0]);
+    acc[1] = MFMA32(w0[1], bv, acc[1]);
+    acc[2] = MFMA32(w0[2], bv, acc[2]);
+    acc[3] = MFMA32(w0[3], bv, acc[3]);
+    acc[4] = MFMA32(w1[0], bv, acc[4]);
+    acc[5] = MFMA32(w1[1], bv, acc[5]);
+    acc[6] = MFMA32(w1[2], bv, acc[6]);
+    acc[7] = MFMA32(w1[3], bv, acc[7]);
+}
+
+__device__ __forceinline__ void step4(const f32x4 w0, const float bv, f32x16 (&acc)[4])
+{
+    acc[0] = MFMA32(w0[0], bv, acc[0]);
+    acc[1] = MFMA32(w0[1], bv, acc[1]);
+    acc[2] = MFMA32(w0[2], bv, acc[2]);
+    acc[3] = MFMA32(w0[3], bv, acc[3]);
+}
+
+// K-steps whose B operand is the previous layer's fragment (128 steps, 8 output blocks).
+// Weights are fetched two steps ahead; sched_barrier pins that software pipeline.
+__device__ __forceinline__ void kloop_act8(const f32x4* __restrict__ p /* + lane */, const f32x16 (&act)[8],
+                                           f32x16 (&acc)[8])
+{
+    f32x4 a0 = p[0], a1 = p[64];
+    f32x4 b0 = p[128], b1 = p[192];
+#pragma unroll
+    for (int s = 0; s < 128; s += 2) {
+        f32x4 c0 = a0, c1 = a1, d0 = b0, d1 = b1;
+        if (s + 2 < 128) { c0 = p[(s + 2) * 128]; c1 = p[(s + 2) * 128 + 64]; }
+        step8(a0, a1, act[s >> 4][s & 15], acc);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 3 < 128) { d0 = p[(s + 3) * 128]; d1 = p[(s + 3) * 128 + 64]; }
+        step8(b0, b1, act[(s + 1) >> 4][(s + 1) & 15], acc);
+        __builtin_amdgcn_sched_barrier(0);
+        a0 = c0; a1 = c1; b0 = d0; b1 = d1;
+    }
+}
+
+__device__ __forceinline__ void kloop_act4(const f32x4* __restrict__ p, const f32x16 (&act)[8], f32x16 (&acc)[4])
+{
+    f32x4 a0 = p[0], b0 = p[64];
+#pragma unroll
+    for (int s = 0; s < 128; s += 2) {
+        f32x4 c0 = a0, d0 = b0;
+        if (s + 2 < 128) c0 = p[(s + 2) * 64];
+        step4(a0, act[s >> 4][s & 15], acc);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 3 < 128) d0 = p[(s + 3) * 64];
+        step4(b0, act[(s + 1) >> 4][(s + 1) & 15], acc);
+        __builtin_amdgcn_sched_barrier(0);
+        a0 = c0; b0 = d0;
+    }
+}
+
+// K-steps whose B operand comes from the feature matrix: group q = 8 features = 4 steps.
+__device__ __forceinline__ void kloop_x8(const f32x4* __restrict__ wp /* + lane */, const f32x4* __restrict__ xp /* + lane */,
+                                         int nq, f32x16 (&acc)[8])
+{
+    f32x4 xv = xp[0];
+    f32x4 w[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w[i] = wp[i * 64];
+    for (int q = 0; q < nq; ++q) {
+        f32x4 xn = xv, wn[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) wn[i] = w[i];
+        if (q + 1 < nq) {
+            xn = xp[(q + 1) * 64];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wn[i] = wp[(q + 1) * 512 + i * 64];
+        }
+        step8(w[0], w[1], xv[0], acc);
+        step8(w[2], w[3], xv[1], acc);
+        step8(w[4], w[5], xv[2], acc);
+        step8(w[6], w[7], xv[3], acc);
+        __builtin_amdgcn_sched_barrier(0);
+        xv = xn;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w[i] = wn[i];
+    }
+}
+
+__device__ __forceinline__ void kloop_x4(const f32x4* __restrict__ wp, const f32x4* __restrict__ xp, int nq,
+                                         f32x16 (&acc)[4])
+{
+    f32x4 xv = xp[0];
+    f32x4 w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = wp[i * 64];
+    for (int q = 0; q < nq; ++q) {
+        f32x4 xn = xv, wn[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wn[i] = w[i];
+        if (q + 1 < nq) {
+            xn = xp[(q + 1) * 64];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wn[i] = wp[(q + 1) * 256 + i * 64];
+        }
+        step4(w[0], xv[0], acc);
+        step4(w[1], xv[1], acc);
+        step4(w[2], xv[2], acc);
+        step4(w[3], xv[3], acc);
+        __builtin_amdgcn_sched_barrier(0);
+        xv = xn;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = wn[i];
+    }
+}
+
+template <int NB>
+__device__ __forceinline__ void init_bias(f32x16 (&acc)[NB], const float* __restrict__ bias, int h)
+{
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            // both candidates are wave-uniform scalar loads; the half-wave picks one (no VGPR staging)
+            const float lo = bias[frag_feature(b, r, 0)], hi = bias[frag_feature(b, r, 1)];
+            acc[b][r] = h ? hi : lo;
+        }
+}
+
+// Opaque copy of a pointer: stops LICM from hoisting the (loop-invariant) head-weight loads out of
+// the persistent tile loop, where they would cost hundreds of live registers.
+template <typename T>
+__device__ __forceinline__ T* launder(T* p)
+{
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
+// row-major save of a fragment (training): feature f of sample `row` -> dst[row*stride + f]
+template <int NB>
+__device__ __forceinline__ void save_frag(const f32x16 (&v)[NB], float* __restrict__ dst_row /* row base + section */, int h)
+{
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            f32x4 o = {v[b][4 * rq], v[b][4 * rq + 1], v[b][4 * rq + 2], v[b][4 * rq + 3]};
+            *(f32x4*)(dst_row + 32 * b + 8 * rq + 4 * h) = o;
+        }
+}
+
+template <bool SAVE>
+__global__ void __launch_bounds__(256) k_mlp_fwd(NfMlpLayout L, const float* __restrict__ packed,
+                                                 const float* __restrict__ X, const int* __restrict__ n_rows, int max_rows,
+                                                 const int* __restrict__ row_sample, float4* __restrict__ rgbsigma,
+                                                 float* __restrict__ acts)
+{
+    const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
+    const int gwave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    const int nrows = min(*n_rows, max_rows);
+    const int ntiles = (nrows + 31) >> 5;
+    const int Q = L.qx + L.qd;
+
+    for (int tile = gwave; tile < ntiles; tile += nwaves) {
+        packed = launder(packed);
+        const f32x4* P4 = (const f32x4*)packed;
+        const f32x4* xt = (const f32x4*)X + (size_t)tile * Q * 64 + lane;
+        const int row = tile * 32 + j;
+        float* arow = SAVE ? acts + (size_t)(row < nrows ? row : 0) * NF_ACT_STRIDE : nullptr;
+        f32x16 act[8], acc[8];
+        float sigma = 0.f;
+
+#pragma unroll 1
+        for (int l = 0; l < 9; ++l) {
+            if (l == 8) {  // sigma head reads h8 before it is overwritten by xyz_encoding_final
+                const float* ws_ = packed + L.off_wsig;
+                float part = 0.f;
+#pragma unroll
+                for (int b = 0; b < 8; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float w0 = ws_[(b * 16 + r) * 2], w1 = ws_[(b * 16 + r) * 2 + 1];
+                        part += act[b][r] * (h ? w1 : w0);
+                    }
+                sigma = part + __shfl_xor(part, 32, 64) + packed[L.off_bsig];
+            }
+            init_bias<8>(acc, packed + L.off_b[l], h);
+            if (L.off_x[l] >= 0) kloop_x8(P4 + (L.off_x[l] >> 2) + lane, xt, L.qx, acc);
+            if (l > 0) kloop_act8(P4 + (L.off_h[l] >> 2) + lane, act, acc);
+            if (l < 8) {
+#pragma unroll
+                for (int b = 0; b < 8; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) act[b][r] = fmaxf(acc[b][r], 0.f);
+            } else {
+#pragma unroll
+                for (int b = 0; b < 8; ++b) act[b] = acc[b];
+            }
+            if (SAVE && row < nrows) save_frag<8>(act, arow + l * 256, h);
+        }
+
+        // view branch: dir_encoding = relu(W_dir [final | dir feats] + b)
+        f32x16 hd[4];
+        init_bias<4>(hd, packed + L.off_bdir, h);
+        kloop_act4(P4 + (L.off_dir_h >> 2) + lane, act, hd);
+        kloop_x4(P4 + (L.off_dir_x >> 2) + lane, xt + L.qx * 64, L.qd, hd);
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hd[b][r] = fmaxf(hd[b][r], 0.f);
+        if (SAVE && row < nrows) save_frag<4>(hd, arow + 9 * 256, h);
+
+        // rgb head
+        const float* wr = packed + L.off_wrgb;
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = hd[b][r];
+                int k = (b * 16 + r) * 2;
+                c0 += v * (h ? wr[k + 1] : wr[k]);
+                c1 += v * (h ? wr[128 + k + 1] : wr[128 + k]);
+                c2 += v * (h ? wr[256 + k + 1] : wr[256 + k]);
+            }
+        c0 += __shfl_xor(c0, 32, 64); c1 += __shfl_xor(c1, 32, 64); c2 += __shfl_xor(c2, 32, 64);
+        c0 += packed[L.off_brgb]; c1 += packed[L.off_brgb + 1]; c2 += packed[L.off_brgb + 2];
+        if (h == 0 && row < nrows) {
+            float4 o;
+            o.x = 1.f / (1.f + expf(-c0)); o.y = 1.f / (1.f + expf(-c1)); o.z = 1.f / (1.f + expf(-c2)); o.w = sigma;
+            rgbsigma[row_sample[row]] = o;
+        }
+    }
+}
+
+extern "C" int nf_nerf_mlp_fwd(const float* packed, int cx, int cd, const float* X, const int32_t* n_rows, int max_rows,
+                               const int32_t* row_sample, float* rgbsigma, float* acts, nf_stream_t stream)
+{
+    NF_CHECK_ARG(packed && X && n_rows && row_sample && rgbsigma, "null pointer");
+    NF_CHECK_ARG(cx >= 1 && cx <= 256 && cd >= 1 && cd <= 256, "bad channel counts");
+    if (max_rows <= 0) return NF_OK;
+    NfMlpLayout L = mlp_layout(cx, cd);
+    int tiles = (max_rows + 31) / 32;
+    int blocks = (tiles + 3) / 4;
+    if (blocks > 256) blocks = 256;  // one 4-wave workgroup per CU, persistent over tiles
+    hipStream_t st = (hipStream_t)stream;
+    if (acts)
+        hipLaunchKernelGGL(k_mlp_fwd<true>, dim3(blocks), dim3(256), 0, st, L, packed, X, n_rows, max_rows, row_sample,
+                           (float4*)rgbsigma, acts);
+    else
+        hipLaunchKernelGGL(k_mlp_fwd<false>, dim3(blocks), dim3(256), 0, st, L, packed, X, n_rows, max_rows, row_sample,
+                           (float4*)rgbsigma, acts);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}

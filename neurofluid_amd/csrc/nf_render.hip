@@ -1,0 +1,420 @@
+// nf_render.hip — the non-MLP stages of RenderNet.forward (models/renderer.py:211-270):
+//   classify (A1 + empty-space rejection), search (A2 + A7 + active-row compaction),
+//   features (A3 + A4 + A5, written in the MLP operand layout), composite (A8), importance (A9).
+//
+// HBM/LDS notes: all of these are streaming or cache-resident integer/fp32 VALU
+// kernels.  The particle cloud (59 KB at 4 913 points) and its cell lists stay in L2; the only
+// HBM-sized traffic is the per-sample arrays (num_nn / mask / rgbsigma, 21 B per sample) and the
+// feature matrix X (1 KB per ACTIVE row only, thanks to the compaction licensed by use_mask).
+#include "nf_common.h"
+#include <math.h>
+
+// wave-aggregated append: returns this lane's slot (valid only where pred)
+__device__ __forceinline__ int wave_append(bool pred, int* counter)
+{
+    unsigned long long m = __ballot(pred);
+    if (m == 0ull) return 0;
+    int lane = threadIdx.x & 63;
+    int n = __popcll(m);
+    int leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, n);
+    base = __shfl(base, leader, 64);
+    return base + __popcll(m & ((1ull << lane) - 1ull));
+}
+
+__device__ __forceinline__ void sample_xyz(const float* __restrict__ rays, const float* __restrict__ z,
+                                           const float* __restrict__ z_table, int S, int sample, float& x, float& y,
+                                           float& zz_, float& zval)
+{
+    int r = sample / S, s = sample - r * S;
+    const float* ry = rays + 6 * (size_t)r;
+    zval = z ? z[sample] : z_table[s];
+    x = nf_madd_nofma(ry[0], ry[3], zval);
+    y = nf_madd_nofma(ry[1], ry[4], zval);
+    zz_ = nf_madd_nofma(ry[2], ry[5], zval);
+}
+
+// ------------------------------------------------------------------------------------------------
+// classify
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_classify(const void* __restrict__ ws, const float* __restrict__ rays,
+                                                  const float* __restrict__ z, const float* __restrict__ z_table, int R,
+                                                  int S, int use_mask, int* __restrict__ num_nn,
+                                                  uint8_t* __restrict__ mask, float4* __restrict__ rgbsigma,
+                                                  int* __restrict__ cand, int* __restrict__ cand_count)
+{
+    NfGridView g = nf_grid_view(ws);
+    int total = R * S;
+    int i = blockIdx.x * 256 + threadIdx.x;
+    bool is_cand = false;
+    if (i < total) {
+        float x, y, zz, zv;
+        sample_xyz(rays, z, z_table, S, i, x, y, zz, zv);
+        int cx = nf_cell_coord(x, g.ox, g.icx, g.dx);
+        int cy = nf_cell_coord(y, g.oy, g.icy, g.dy);
+        int cz = nf_cell_coord(zz, g.oz, g.icz, g.dz);
+        int dil = g.cell_dil[(cz * g.dy + cy) * g.dx + cx];
+        is_cand = (dil > 0) || !use_mask;
+        if (!is_cand) {
+            num_nn[i] = 0;
+            mask[i] = 0;
+            rgbsigma[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    int slot = wave_append(is_cand, cand_count);
+    if (is_cand) cand[slot] = i;
+}
+
+extern "C" int nf_render_classify(const void* ws, const float* rays, const float* z, const float* z_table, int R, int S,
+                                  int use_mask, int32_t* num_nn, uint8_t* mask, float* rgbsigma, int32_t* cand,
+                                  int32_t* cand_count, nf_stream_t stream)
+{
+    NF_CHECK_ARG(ws && rays && (z || z_table) && num_nn && mask && rgbsigma && cand && cand_count, "null pointer");
+    NF_CHECK_ARG(R >= 0 && S > 0 && (long)R * S < 0x7fffffffL, "bad R/S");
+    if (R == 0) return NF_OK;
+    int total = R * S;
+    hipLaunchKernelGGL(k_classify, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, rays, z, z_table, R,
+                       S, use_mask, num_nn, mask, (float4*)rgbsigma, cand, cand_count);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// search + compaction of active rows
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(BQ_BLOCK) k_search(const void* __restrict__ ws, const float* __restrict__ rays,
+                                                     const float* __restrict__ z, const float* __restrict__ z_table,
+                                                     int S, float r2, int K, int use_mask,
+                                                     const int* __restrict__ cand, const int* __restrict__ cand_count,
+                                                     int* __restrict__ num_nn, uint8_t* __restrict__ mask,
+                                                     float4* __restrict__ rgbsigma, int* __restrict__ row_sample,
+                                                     int* __restrict__ row_nbr, int* __restrict__ n_rows)
+{
+    extern __shared__ int lds[];
+    int* li = lds;
+    float* ld = (float*)(lds + K * BQ_BLOCK);
+    NfGridView g = nf_grid_view(ws);
+    const int ncand = *cand_count;
+    const int tid = threadIdx.x;
+    for (int base = blockIdx.x * BQ_BLOCK; base < ncand; base += gridDim.x * BQ_BLOCK) {
+        int c = base + tid;
+        bool active = false;
+        int sample = 0, cnt = 0;
+        if (c < ncand) {
+            sample = cand[c];
+            float x, y, zz, zv;
+            sample_xyz(rays, z, z_table, S, sample, x, y, zz, zv);
+            cnt = firstk_search(g, x, y, zz, r2, K, li, ld, tid);
+            int nz = 0;
+            for (int k = 0; k < cnt; ++k) nz += (ld[k * BQ_BLOCK + tid] != 0.f);  // nn_mask = dists.ne(0)
+            bool full = (nz == K);
+            num_nn[sample] = nz;
+            mask[sample] = full ? 1 : 0;
+            active = full || !use_mask;
+            if (!active) rgbsigma[sample] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        int row = wave_append(active, n_rows);
+        if (active) {
+            row_sample[row] = sample;
+            for (int k = 0; k < K; ++k) row_nbr[(size_t)row * K + k] = k < cnt ? li[k * BQ_BLOCK + tid] : -1;
+        }
+    }
+}
+
+extern "C" int nf_render_search(const void* ws, const float* rays, const float* z, const float* z_table, int R, int S,
+                                float radius, int K, int use_mask, const int32_t* cand, const int32_t* cand_count,
+                                int32_t* num_nn, uint8_t* mask, float* rgbsigma, int32_t* row_sample, int32_t* row_nbr,
+                                int32_t* n_rows, nf_stream_t stream)
+{
+    NF_CHECK_ARG(ws && rays && (z || z_table) && cand && cand_count && num_nn && mask && rgbsigma && row_sample &&
+                     row_nbr && n_rows, "null pointer");
+    NF_CHECK_ARG(K >= 1 && K <= 64 && radius > 0.f, "bad K/radius");
+    if (R == 0) return NF_OK;
+    long total = (long)R * S;
+    int blocks = (int)((total + BQ_BLOCK - 1) / BQ_BLOCK);
+    if (blocks > 8192) blocks = 8192;
+    size_t lds = (size_t)K * BQ_BLOCK * 8;
+    hipLaunchKernelGGL(k_search, dim3(blocks), dim3(BQ_BLOCK), lds, (hipStream_t)stream, ws, rays, z, z_table, S,
+                       radius * radius, K, use_mask, cand, cand_count, num_nn, mask, (float4*)rgbsigma, row_sample,
+                       row_nbr, n_rows);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// features
+// ------------------------------------------------------------------------------------------------
+extern "C" int nf_render_feature_dims(int enc_flags, int* cx, int* cd, int* qx, int* qd)
+{
+    int x = 63, d = 27;
+    if (enc_flags & 1) x += 9;
+    if (enc_flags & 2) x += 63;
+    if (enc_flags & 4) x += 63;
+    if (enc_flags & 8) d += 27;
+    if (cx) *cx = x;
+    if (cd) *cd = d;
+    if (qx) *qx = (x + 7) / 8;
+    if (qd) *qd = (d + 7) / 8;
+    return NF_OK;
+}
+
+// Streams features of one row into X[tile][q][lane][4]: 4 consecutive features share one 16-B store.
+struct FeatEmitter {
+    float4* base;  // &X[tile][0][j]  (lane h=0); h=1 is +32 float4, q is +64 float4
+    float b0, b1, b2, b3;
+    int n;  // features emitted so far in the current section (compile-time after unrolling)
+    __device__ __forceinline__ void flush_at(int group)  // group = n/4 - 1 just completed
+    {
+        int q = group >> 1, h = group & 1;
+        base[q * 64 + h * 32] = make_float4(b0, b1, b2, b3);
+    }
+    __device__ __forceinline__ void emit(float v)
+    {
+        int e = n & 3;
+        if (e == 0) b0 = v; else if (e == 1) b1 = v; else if (e == 2) b2 = v; else b3 = v;
+        ++n;
+        if ((n & 3) == 0) flush_at((n >> 2) - 1);
+    }
+    __device__ __forceinline__ void pad_to(int total)  // zero-fill up to `total` features (multiple of 8)
+    {
+        while (n < total) emit(0.f);
+    }
+};
+
+template <int C, int NF>
+__device__ __forceinline__ void emit_pe(FeatEmitter& em, const float (&x)[C])
+{
+#pragma unroll
+    for (int c = 0; c < C; ++c) em.emit(x[c]);
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        const float fr = (float)(1 << f);  // 2**linspace(0,N-1,N)  (models/nerf.py:17)
+#pragma unroll
+        for (int c = 0; c < C; ++c) em.emit(sinf(fr * x[c]));
+#pragma unroll
+        for (int c = 0; c < C; ++c) em.emit(cosf(fr * x[c]));
+    }
+}
+
+template <int FLAGS>
+__global__ void __launch_bounds__(128) k_features(const float* __restrict__ particles, const float* __restrict__ rays,
+                                                  const float* __restrict__ z, const float* __restrict__ z_table, int S,
+                                                  float radius, int K, const float* __restrict__ ro,
+                                                  const int* __restrict__ row_sample, const int* __restrict__ row_nbr,
+                                                  const int* __restrict__ n_rows, int max_rows, float* __restrict__ X)
+{
+    constexpr int CX = 63 + ((FLAGS & 1) ? 9 : 0) + ((FLAGS & 2) ? 63 : 0) + ((FLAGS & 4) ? 63 : 0);
+    constexpr int CD = 27 + ((FLAGS & 8) ? 27 : 0);
+    constexpr int QX = (CX + 7) / 8, QD = (CD + 7) / 8, Q = QX + QD;
+    int nrows = min(*n_rows, max_rows);
+    for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < nrows; row += gridDim.x * blockDim.x) {
+        int sample = row_sample[row];
+        float px[3], zv;
+        sample_xyz(rays, z, z_table, S, sample, px[0], px[1], px[2], zv);
+        const float* ry = rays + 6 * (size_t)(sample / S);
+        // --- A3 smoothing + A4 variance over the K slots (padded slots: nn = 0, models/renderer.py:96-109,:163-169)
+        float sw = 0.f, swx = 0.f, swy = 0.f, swz = 0.f;
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        int nvalid = 0;
+        for (int k = 0; k < K; ++k) {
+            int j = row_nbr[(size_t)row * K + k];
+            float nx = 0.f, ny = 0.f, nz = 0.f;
+            bool valid = false;
+            if (j >= 0) {
+                nx = particles[3 * (size_t)j]; ny = particles[3 * (size_t)j + 1]; nz = particles[3 * (size_t)j + 2];
+                valid = nf_dist2(px[0], px[1], px[2], nx, ny, nz) != 0.f;
+            }
+            float dx = nx - px[0], dy = ny - px[1], dz = nz - px[2];
+            float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+            float t = dist / radius;
+            float w = fmaxf(1.f - t * t * t, 0.f);
+            sw += w; swx += w * nx; swy += w * ny; swz += w * nz;
+            if (valid) { sx += dx; sy += dy; sz += dz; ++nvalid; }
+        }
+        float den = sw + 1e-12f;
+        float sm[3] = {swx / den, swy / den, swz / den};
+        float nn_f = (float)nvalid + 1e-12f;
+        float mean[3] = {sx / nn_f, sy / nn_f, sz / nn_f};
+        float var[3] = {0.f, 0.f, 0.f};
+        if (FLAGS & 4) {
+            for (int k = 0; k < K; ++k) {
+                int j = row_nbr[(size_t)row * K + k];
+                if (j < 0) continue;
+                float nx = particles[3 * (size_t)j], ny = particles[3 * (size_t)j + 1], nz = particles[3 * (size_t)j + 2];
+                if (nf_dist2(px[0], px[1], px[2], nx, ny, nz) == 0.f) continue;
+                float ex = (nx - px[0]) - mean[0], ey = (ny - px[1]) - mean[1], ez = (nz - px[2]) - mean[2];
+                var[0] += ex * ex; var[1] += ey * ey; var[2] += ez * ez;
+            }
+            var[0] /= nn_f; var[1] /= nn_f; var[2] /= nn_f;
+        }
+        // --- emit in the reference's column order (models/renderer.py:141-175, cat at :230)
+        int tile = row >> 5, jj = row & 31;
+        FeatEmitter em;
+        em.base = (float4*)X + (size_t)tile * Q * 64 + jj;
+        em.n = 0;
+        emit_pe<3, 10>(em, px);
+        if (FLAGS & 1) { float d1[1] = {sw}; emit_pe<1, 4>(em, d1); }
+        if (FLAGS & 2) emit_pe<3, 10>(em, sm);
+        if (FLAGS & 4) emit_pe<3, 10>(em, var);
+        em.pad_to(QX * 8);
+        float rd[3] = {ry[3], ry[4], ry[5]};
+        emit_pe<3, 4>(em, rd);
+        if (FLAGS & 8) {
+            float ddx = sm[0] - ro[0], ddy = sm[1] - ro[1], ddz = sm[2] - ro[2];
+            float nrm = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
+            float sd[3] = {ddx / nrm, ddy / nrm, ddz / nrm};
+            emit_pe<3, 4>(em, sd);
+        }
+        em.pad_to(Q * 8);
+    }
+}
+
+extern "C" int nf_render_features(const float* particles, const float* rays, const float* z, const float* z_table, int R,
+                                  int S, float radius, int K, int enc_flags, const float* ro, const int32_t* row_sample,
+                                  const int32_t* row_nbr, const int32_t* n_rows, int max_rows, float* X,
+                                  nf_stream_t stream)
+{
+    NF_CHECK_ARG(particles && rays && (z || z_table) && ro && row_sample && row_nbr && n_rows && X, "null pointer");
+    NF_CHECK_ARG(enc_flags >= 0 && enc_flags < 16, "bad enc_flags");
+    if (max_rows <= 0) return NF_OK;
+    int blocks = (max_rows + 127) / 128;
+    if (blocks > 4096) blocks = 4096;
+    hipStream_t st = (hipStream_t)stream;
+#define NF_FEAT_CASE(F)                                                                                              \
+    case F:                                                                                                          \
+        hipLaunchKernelGGL(k_features<F>, dim3(blocks), dim3(128), 0, st, particles, rays, z, z_table, S, radius, K, ro, \
+                           row_sample, row_nbr, n_rows, max_rows, X);                                                \
+        break;
+    switch (enc_flags) {
+        NF_FEAT_CASE(0) NF_FEAT_CASE(1) NF_FEAT_CASE(2) NF_FEAT_CASE(3) NF_FEAT_CASE(4) NF_FEAT_CASE(5) NF_FEAT_CASE(6)
+        NF_FEAT_CASE(7) NF_FEAT_CASE(8) NF_FEAT_CASE(9) NF_FEAT_CASE(10) NF_FEAT_CASE(11) NF_FEAT_CASE(12)
+        NF_FEAT_CASE(13) NF_FEAT_CASE(14) NF_FEAT_CASE(15)
+    }
+#undef NF_FEAT_CASE
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// composite (A8): one thread per ray, sequential transmittance like torch.cumprod
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_composite(const float4* __restrict__ rgbsigma, const float* __restrict__ z,
+                                                  const float* __restrict__ z_table, const float* __restrict__ rays,
+                                                  const uint8_t* __restrict__ mask, int R, int S, int white_bg,
+                                                  float* __restrict__ rgb, float* __restrict__ depth,
+                                                  float* __restrict__ opacity, float* __restrict__ weights,
+                                                  float* __restrict__ mask_sum)
+{
+    int r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= R) return;
+    const float* ry = rays + 6 * (size_t)r;
+    float nrm = sqrtf(ry[3] * ry[3] + ry[4] * ry[4] + ry[5] * ry[5]);
+    const float* zr = z ? z + (size_t)r * S : z_table;
+    float T = 1.f, cr = 0.f, cg = 0.f, cb = 0.f, cd = 0.f, ws = 0.f;
+    int ms = 0;
+    float zc = zr[0];
+    for (int s = 0; s < S; ++s) {
+        float zn = (s + 1 < S) ? zr[s + 1] : 0.f;
+        float delta = (s + 1 < S) ? (zn - zc) : 1e10f;
+        delta = delta * nrm;
+        float4 v = rgbsigma[(size_t)r * S + s];
+        float alpha = 1.f - expf(-delta * fmaxf(v.w, 0.f));
+        float w = alpha * T;
+        T = T * ((1.f - alpha) + 1e-10f);
+        cr += w * v.x; cg += w * v.y; cb += w * v.z; cd += w * zc; ws += w;
+        weights[(size_t)r * S + s] = w;
+        if (mask) ms += mask[(size_t)r * S + s];
+        zc = zn;
+    }
+    if (white_bg) { cr = cr + 1.f - ws; cg = cg + 1.f - ws; cb = cb + 1.f - ws; }
+    rgb[3 * (size_t)r] = cr; rgb[3 * (size_t)r + 1] = cg; rgb[3 * (size_t)r + 2] = cb;
+    depth[r] = cd;
+    opacity[r] = ws;
+    if (mask_sum) mask_sum[r] = (float)ms;
+}
+
+extern "C" int nf_composite_fwd(const float* rgbsigma, const float* z, const float* z_table, const float* rays,
+                                const uint8_t* mask, int R, int S, int white_bg, float* rgb, float* depth, float* opacity,
+                                float* weights, float* mask_sum, nf_stream_t stream)
+{
+    NF_CHECK_ARG(rgbsigma && (z || z_table) && rays && rgb && depth && opacity && weights, "null pointer");
+    if (R == 0) return NF_OK;
+    hipLaunchKernelGGL(k_composite, dim3((R + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const float4*)rgbsigma, z,
+                       z_table, rays, mask, R, S, white_bg, rgb, depth, opacity, weights, mask_sum);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// importance sampling (A9), det=True.  One thread per ray; cdf / new samples staged in LDS as
+// [k][thread] (conflict-free).  utils/ray_utils.py:178-229.
+// ------------------------------------------------------------------------------------------------
+#define IS_BLOCK 64
+__global__ void __launch_bounds__(IS_BLOCK) k_importance(const float* __restrict__ z0, const float* __restrict__ w0,
+                                                         const float* __restrict__ u_table, int R, int S0, int NI,
+                                                         float* __restrict__ z1)
+{
+    extern __shared__ float sm[];
+    float* cdf = sm;                        // [(S0-1)][IS_BLOCK]
+    float* zn = sm + (S0 - 1) * IS_BLOCK;   // [NI][IS_BLOCK]
+    const int tid = threadIdx.x;
+    int r = blockIdx.x * IS_BLOCK + tid;
+    if (r >= R) return;
+    const int NB = S0 - 1;   // bins (mid points): 63
+    const int NW = S0 - 2;   // weights[1:-1]: 62
+    const float* w = w0 + (size_t)r * S0;
+    float tot = 0.f;
+    for (int k = 0; k < NW; ++k) tot += (w[k + 1] + 1e-5f);
+    float c = 0.f;
+    cdf[0 * IS_BLOCK + tid] = 0.f;
+    for (int k = 0; k < NW; ++k) {
+        c += (w[k + 1] + 1e-5f) / tot;
+        cdf[(k + 1) * IS_BLOCK + tid] = c;
+    }
+    // inverse CDF; u ascending -> the searchsorted(right=True) pointer only moves forward
+    int ind = 0;  // number of cdf entries <= u
+    for (int k = 0; k < NI; ++k) {
+        float u = u_table[k];
+        while (ind < NB && cdf[ind * IS_BLOCK + tid] <= u) ++ind;
+        int below = ind - 1 < 0 ? 0 : ind - 1;
+        int above = ind > NB - 1 ? NB - 1 : ind;
+        float c0 = cdf[below * IS_BLOCK + tid], c1 = cdf[above * IS_BLOCK + tid];
+        float b0 = 0.5f * (z0[below + 1] + z0[below]);
+        float b1 = 0.5f * (z0[above + 1] + z0[above]);
+        float denom = c1 - c0;
+        if (denom < 1e-5f) denom = 1.f;
+        float t = (u - c0) / denom;
+        zn[k * IS_BLOCK + tid] = b0 + t * (b1 - b0);
+    }
+    // torch.sort(cat(z0, z_new)): make z_new sorted (it is, up to rounding), then merge
+    for (int k = 1; k < NI; ++k) {
+        float v = zn[k * IS_BLOCK + tid];
+        int m = k;
+        while (m > 0 && zn[(m - 1) * IS_BLOCK + tid] > v) { zn[m * IS_BLOCK + tid] = zn[(m - 1) * IS_BLOCK + tid]; --m; }
+        zn[m * IS_BLOCK + tid] = v;
+    }
+    float* out = z1 + (size_t)r * (S0 + NI);
+    int a = 0, b = 0;
+    for (int k = 0; k < S0 + NI; ++k) {
+        float va = a < S0 ? z0[a] : INFINITY;
+        float vb = b < NI ? zn[b * IS_BLOCK + tid] : INFINITY;
+        if (b >= NI || (a < S0 && va <= vb)) { out[k] = va; ++a; } else { out[k] = vb; ++b; }
+    }
+}
+
+extern "C" int nf_importance_sample(const float* z_table0, const float* weights0, const float* u_table, int R, int S0,
+                                    int N_imp, float* z1, nf_stream_t stream)
+{
+    NF_CHECK_ARG(z_table0 && weights0 && u_table && z1, "null pointer");
+    NF_CHECK_ARG(S0 >= 3 && N_imp >= 1, "bad S0/N_imp");
+    size_t lds = (size_t)(S0 - 1 + N_imp) * IS_BLOCK * sizeof(float);
+    NF_CHECK_ARG(lds <= 160 * 1024, "S0 + N_imp too large for LDS staging");
+    if (R == 0) return NF_OK;
+    if (lds > 64 * 1024)
+        hipFuncSetAttribute((const void*)k_importance, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_importance, dim3((R + IS_BLOCK - 1) / IS_BLOCK), dim3(IS_BLOCK), lds, (hipStream_t)stream,
+                       z_table0, weights0, u_table, R, S0, N_imp, z1);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}

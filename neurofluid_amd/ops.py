@@ -1,0 +1,304 @@
+"""Tensor-level wrappers over the C ABI (include/neurofluid_hip.h).
+
+These are the operator boundaries of SURVEY §8b:
+  * ``ball_query``            — pytorch3d.ops.ball_query drop-in          (models/renderer.py:116-118)
+  * ``fixed_radius_search``   — Open3D FixedRadiusSearch drop-in          (models/transmodel.py:86-95)
+  * ``render_chunk``          — the fused body of RenderNet.forward       (models/renderer.py:211-270)
+All tensors must be CUDA (ROCm) fp32/int tensors; torch only provides memory and the stream.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr
+
+
+def _require_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("neurofluid_amd ops need tensors on the GPU (no CPU fallback)")
+
+
+# ------------------------------------------------------------------------------------------------
+# grid
+# ------------------------------------------------------------------------------------------------
+class Grid:
+    """Uniform cell grid over a point cloud; `ws` is the opaque device workspace of nf_grid_build."""
+
+    def __init__(self, points, cell, bbox, ws):
+        self.points, self.cell, self.bbox, self.ws = points, float(cell), bbox, ws
+
+    @property
+    def n(self):
+        return self.points.shape[0]
+
+
+def build_grid(points, cell, bbox=None):
+    """points (N,3) fp32 contiguous.  bbox=(xmin,ymin,zmin,xmax,ymax,zmax); if None it is computed
+    from the points (one device->host sync)."""
+    _require_cuda(points)
+    lib = _lib.load()
+    pts = points.detach().contiguous().float()
+    if bbox is None:
+        if pts.shape[0] == 0:
+            bbox = (0.0, 0.0, 0.0, 0.0, 0.0, 0.0)
+        else:
+            lo, hi = torch.aminmax(pts, dim=0)
+            bbox = tuple(lo.tolist()) + tuple(hi.tolist())
+    bb = (ctypes.c_float * 6)(*[float(v) for v in bbox])
+    nbytes = lib.nf_grid_workspace_bytes(pts.shape[0], float(cell), bb)
+    if nbytes == 0:
+        raise RuntimeError("nf_grid_workspace_bytes: bad grid parameters")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=pts.device)
+    check(lib.nf_grid_build(ptr(pts), pts.shape[0], float(cell), bb, ptr(ws), nbytes, _lib.stream()), "nf_grid_build")
+    return Grid(pts, cell, tuple(bbox), ws)
+
+
+def ball_query(p1, p2, radius, K, return_nn=True):
+    """pytorch3d.ops.ball_query(p1 (N,P1,3), p2 (N,P2,3), radius, K) -> (dists (N,P1,K) squared, pad 0;
+    idx (N,P1,K) int64, pad -1; nn (N,P1,K,3), pad 0).  First K in index order."""
+    _require_cuda(p1, p2)
+    lib = _lib.load()
+    N, P1, _ = p1.shape
+    dists = torch.empty(N, P1, K, dtype=torch.float32, device=p1.device)
+    idx = torch.empty(N, P1, K, dtype=torch.int64, device=p1.device)
+    nn = torch.empty(N, P1, K, 3, dtype=torch.float32, device=p1.device) if return_nn else None
+    for b in range(N):
+        same = b > 0 and p2[b].data_ptr() == p2[0].data_ptr()
+        if not same:
+            grid = build_grid(p2[b], radius)
+        q = p1[b].detach().contiguous().float()
+        check(lib.nf_ball_query_firstk(ptr(grid.ws), ptr(grid.points), ptr(q), P1, float(radius), K, ptr(dists[b]),
+                                       ptr(idx[b]), ptr(nn[b]) if return_nn else None, _lib.stream()),
+              "nf_ball_query_firstk")
+    return dists, idx, nn
+
+
+def grid_ball_query(grid, queries, radius, K):
+    """Single-cloud variant on a prebuilt grid: queries (Q,3)."""
+    if radius > grid.cell * (1 + 1e-6):
+        raise RuntimeError("query radius exceeds the grid cell edge")
+    lib = _lib.load()
+    q = queries.detach().contiguous().float()
+    Q = q.shape[0]
+    dists = torch.empty(Q, K, dtype=torch.float32, device=q.device)
+    idx = torch.empty(Q, K, dtype=torch.int64, device=q.device)
+    nn = torch.empty(Q, K, 3, dtype=torch.float32, device=q.device)
+    check(lib.nf_ball_query_firstk(ptr(grid.ws), ptr(grid.points), ptr(q), Q, float(radius), K, ptr(dists), ptr(idx),
+                                   ptr(nn), _lib.stream()), "nf_ball_query_firstk")
+    return dists, idx, nn
+
+
+def radius_row_splits(grid, queries, radius, ignore_query_point=True):
+    """Counts + device-side scan -> row_splits (Q+1) int64 (no host sync)."""
+    if radius > grid.cell * (1 + 1e-6):
+        raise RuntimeError("query radius exceeds the grid cell edge")
+    lib = _lib.load()
+    q = queries.detach().contiguous().float()
+    Q = q.shape[0]
+    rs = torch.empty(Q + 1, dtype=torch.int64, device=q.device)
+    nb = lib.nf_radius_scan_workspace_bytes(Q)
+    sws = torch.empty(nb, dtype=torch.uint8, device=q.device)
+    check(lib.nf_radius_count(ptr(grid.ws), ptr(q), Q, float(radius), int(ignore_query_point), ptr(rs), ptr(sws), nb,
+                              _lib.stream()), "nf_radius_count")
+    return rs
+
+
+def radius_fill(grid, queries, radius, row_splits, capacity, ignore_query_point=True):
+    lib = _lib.load()
+    q = queries.detach().contiguous().float()
+    idx = torch.empty(max(capacity, 1), dtype=torch.int32, device=q.device)
+    d2 = torch.empty(max(capacity, 1), dtype=torch.float32, device=q.device)
+    check(lib.nf_radius_fill(ptr(grid.ws), ptr(q), q.shape[0], float(radius), int(ignore_query_point), ptr(row_splits),
+                             ptr(idx), ptr(d2), capacity, _lib.stream()), "nf_radius_fill")
+    return idx, d2
+
+
+def fixed_radius_search(points, queries, radius, ignore_query_point=True, grid=None):
+    """Open3D FixedRadiusSearch contract -> (neighbors_index int32 (nnz), neighbors_row_splits int64 (Q+1),
+    neighbors_distance fp32 (nnz) = squared distance).  One host sync (nnz sizes the outputs)."""
+    _require_cuda(points, queries)
+    if grid is None:
+        grid = build_grid(points, radius)
+    rs = radius_row_splits(grid, queries, radius, ignore_query_point)
+    nnz = int(rs[-1].item())
+    idx, d2 = radius_fill(grid, queries, radius, rs, nnz, ignore_query_point)
+    return idx[:nnz], rs, d2[:nnz]
+
+
+# ------------------------------------------------------------------------------------------------
+# NeRF weights
+# ------------------------------------------------------------------------------------------------
+NERF_LAYER_NAMES = [f"xyz_encoding_{i}.0" for i in range(1, 9)] + ["xyz_encoding_final", "dir_encoding.0", "sigma", "rgb.0"]
+
+
+def feature_dims(enc_flags):
+    lib = _lib.load()
+    cx, cd, qx, qd = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    lib.nf_render_feature_dims(enc_flags, ctypes.byref(cx), ctypes.byref(cd), ctypes.byref(qx), ctypes.byref(qd))
+    return cx.value, cd.value, qx.value, qd.value
+
+
+def pack_nerf(weights, biases, cx, cd, out=None):
+    """weights/biases: 12 contiguous fp32 CUDA tensors in NERF_LAYER_NAMES order -> packed blob."""
+    lib = _lib.load()
+    n = lib.nf_nerf_packed_floats(cx, cd)
+    if out is None:
+        out = torch.empty(n, dtype=torch.float32, device=weights[0].device)
+    P = _lib.NerfParams()
+    keep = []
+    for i in range(12):
+        w = weights[i].detach().contiguous().float()
+        b = biases[i].detach().contiguous().float()
+        keep += [w, b]
+        P.w[i] = w.data_ptr()
+        P.b[i] = b.data_ptr()
+    check(lib.nf_nerf_pack(ctypes.byref(P), cx, cd, ptr(out), _lib.stream()), "nf_nerf_pack")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# one render pass (coarse or fine) of a ray chunk
+# ------------------------------------------------------------------------------------------------
+class PassBuffers:
+    """Per-pass device buffers; kept so that backward can reuse row lists / activations."""
+    pass
+
+
+def render_pass(grid, particles, rays, z, z_table, S, radius, K, enc_flags, use_mask, ro, packed, cx, cd,
+                white_bg=True, save_acts=False, max_rows=None):
+    """Runs classify -> search -> features -> MLP -> composite for R rays x S samples.
+    z: (R,S) per-ray depths or None (then z_table (S,) is shared by all rays).
+    Returns a PassBuffers with rgb, depth, opacity, weights, num_nn, mask_sum and the row lists."""
+    lib = _lib.load()
+    dev = rays.device
+    R = rays.shape[0]
+    st = _lib.stream()
+    n_samp = R * S
+    if radius > grid.cell * (1 + 1e-6):
+        raise RuntimeError("search radius exceeds the grid cell edge")
+    b = PassBuffers()
+    b.R, b.S = R, S
+    b.num_nn = torch.empty(n_samp, dtype=torch.int32, device=dev)
+    b.mask = torch.empty(n_samp, dtype=torch.uint8, device=dev)
+    b.rgbsigma = torch.empty(n_samp, 4, dtype=torch.float32, device=dev)
+    cand = torch.empty(n_samp, dtype=torch.int32, device=dev)
+    counters = torch.zeros(2, dtype=torch.int32, device=dev)
+    b.counters = counters
+    check(lib.nf_render_classify(ptr(grid.ws), ptr(rays), ptr(z), ptr(z_table), R, S, int(use_mask), ptr(b.num_nn),
+                                 ptr(b.mask), ptr(b.rgbsigma), ptr(cand), ptr(counters[0:1]), st), "nf_render_classify")
+    if max_rows is None:
+        max_rows = n_samp
+    max_rows = min(max_rows, n_samp)
+    b.max_rows = max_rows
+    _, _, qx, qd = feature_dims(enc_flags)
+    # NOTE: row lists are sized for the worst case of this chunk (every sample active) unless the
+    # caller bounds max_rows; the renderer module sizes chunks so this stays modest.
+    b.row_sample = torch.empty(n_samp, dtype=torch.int32, device=dev)
+    b.row_nbr = torch.empty(n_samp * K, dtype=torch.int32, device=dev)
+    check(lib.nf_render_search(ptr(grid.ws), ptr(rays), ptr(z), ptr(z_table), R, S, float(radius), K, int(use_mask),
+                               ptr(cand), ptr(counters[0:1]), ptr(b.num_nn), ptr(b.mask), ptr(b.rgbsigma),
+                               ptr(b.row_sample), ptr(b.row_nbr), ptr(counters[1:2]), st), "nf_render_search")
+    b.n_rows = counters[1:2]
+    if max_rows >= n_samp:
+        # exact sizing of the per-row buffers: one host sync per pass (the caller can avoid it by
+        # passing a static max_rows bound, e.g. under hipGraph capture)
+        max_rows = int(counters[1].item())
+        b.max_rows = max_rows
+    b.n_active = max_rows
+    tiles = (max_rows + 31) // 32
+    b.X = torch.empty(max(tiles, 1) * (qx + qd) * 256, dtype=torch.float32, device=dev)
+    check(lib.nf_render_features(ptr(particles), ptr(rays), ptr(z), ptr(z_table), R, S, float(radius), K, enc_flags,
+                                 ptr(ro), ptr(b.row_sample), ptr(b.row_nbr), ptr(b.n_rows), max_rows, ptr(b.X), st),
+          "nf_render_features")
+    b.acts = torch.empty(max(max_rows, 1) * 2432, dtype=torch.float32, device=dev) if save_acts else None
+    check(lib.nf_nerf_mlp_fwd(ptr(packed), cx, cd, ptr(b.X), ptr(b.n_rows), max_rows, ptr(b.row_sample),
+                              ptr(b.rgbsigma), ptr(b.acts), st), "nf_nerf_mlp_fwd")
+    b.rgb = torch.empty(R, 3, dtype=torch.float32, device=dev)
+    b.depth = torch.empty(R, dtype=torch.float32, device=dev)
+    b.opacity = torch.empty(R, dtype=torch.float32, device=dev)
+    b.weights = torch.empty(R, S, dtype=torch.float32, device=dev)
+    b.mask_sum = torch.empty(R, dtype=torch.float32, device=dev)
+    check(lib.nf_composite_fwd(ptr(b.rgbsigma), ptr(z), ptr(z_table), ptr(rays), ptr(b.mask), R, S, int(white_bg),
+                               ptr(b.rgb), ptr(b.depth), ptr(b.opacity), ptr(b.weights), ptr(b.mask_sum), st),
+          "nf_composite_fwd")
+    return b
+
+
+def importance_sample(z_table0, weights0, u_table, n_importance):
+    lib = _lib.load()
+    R, S0 = weights0.shape
+    z1 = torch.empty(R, S0 + n_importance, dtype=torch.float32, device=weights0.device)
+    check(lib.nf_importance_sample(ptr(z_table0), ptr(weights0), ptr(u_table), R, S0, n_importance, ptr(z1),
+                                   _lib.stream()), "nf_importance_sample")
+    return z1
+
+
+# ------------------------------------------------------------------------------------------------
+# layout helpers (host-side plumbing for unit tests and the standalone NeRF.forward)
+# ------------------------------------------------------------------------------------------------
+def rows_to_tiles(x, cx, cd):
+    """row-major features (n, cx+cd) -> MLP operand layout X[tile][q][h*32+j][4] (see nf_render_features)."""
+    n = x.shape[0]
+    qx, qd = (cx + 7) // 8, (cd + 7) // 8
+    npad = (n + 31) // 32 * 32
+    f = torch.zeros(npad, 8 * (qx + qd), dtype=torch.float32, device=x.device)
+    f[:n, :cx] = x[:, :cx]
+    f[:n, 8 * qx:8 * qx + cd] = x[:, cx:cx + cd]
+    return f.view(npad // 32, 32, qx + qd, 2, 4).permute(0, 2, 3, 1, 4).contiguous().view(-1)
+
+
+def tiles_to_rows(X, n, cx, cd):
+    qx, qd = (cx + 7) // 8, (cd + 7) // 8
+    T = (n + 31) // 32
+    f = X[:T * (qx + qd) * 256].view(T, qx + qd, 2, 32, 4).permute(0, 3, 1, 2, 4).reshape(T * 32, 8 * (qx + qd))
+    return torch.cat([f[:n, :cx], f[:n, 8 * qx:8 * qx + cd]], 1)
+
+
+def mlp_rows(packed, cx, cd, x, save_acts=False):
+    """NeRF.forward on row-major features x (n, cx+cd) through the MFMA kernel -> (n,4) [rgb, sigma]."""
+    lib = _lib.load()
+    n = x.shape[0]
+    X = rows_to_tiles(x.detach().float(), cx, cd)
+    n_rows = torch.tensor([n], dtype=torch.int32, device=x.device)
+    row_sample = torch.arange(n, dtype=torch.int32, device=x.device)
+    out = torch.zeros(n, 4, dtype=torch.float32, device=x.device)
+    acts = torch.empty(n * 2432, dtype=torch.float32, device=x.device) if save_acts else None
+    check(lib.nf_nerf_mlp_fwd(ptr(packed), cx, cd, ptr(X), ptr(n_rows), n, ptr(row_sample), ptr(out), ptr(acts),
+                              _lib.stream()), "nf_nerf_mlp_fwd")
+    return (out, acts.view(n, 2432)) if save_acts else out
+
+
+def debug_features(particles, rays, near, far, S, radius, K, enc_flags, ro):
+    """Coarse-pass classify + search + features only; returns row-major features of the active rows."""
+    lib = _lib.load()
+    dev = rays.device
+    t = torch.linspace(0, 1, S)
+    z_table = (near * (1 - t) + far * t).to(dev)
+    grid = build_grid(particles, radius)
+    R = rays.shape[0]
+    n = R * S
+    num_nn = torch.empty(n, dtype=torch.int32, device=dev)
+    mask = torch.empty(n, dtype=torch.uint8, device=dev)
+    rgbsigma = torch.empty(n, 4, device=dev)
+    cand = torch.empty(n, dtype=torch.int32, device=dev)
+    counters = torch.zeros(2, dtype=torch.int32, device=dev)
+    row_sample = torch.empty(n, dtype=torch.int32, device=dev)
+    row_nbr = torch.empty(n * K, dtype=torch.int32, device=dev)
+    st = _lib.stream()
+    rays = rays.contiguous().float()
+    check(lib.nf_render_classify(ptr(grid.ws), ptr(rays), None, ptr(z_table), R, S, 1, ptr(num_nn), ptr(mask),
+                                 ptr(rgbsigma), ptr(cand), ptr(counters[0:1]), st))
+    check(lib.nf_render_search(ptr(grid.ws), ptr(rays), None, ptr(z_table), R, S, float(radius), K, 1, ptr(cand),
+                               ptr(counters[0:1]), ptr(num_nn), ptr(mask), ptr(rgbsigma), ptr(row_sample), ptr(row_nbr),
+                               ptr(counters[1:2]), st))
+    nr = int(counters[1].item())
+    cx, cd, qx, qd = feature_dims(enc_flags)
+    X = torch.empty(max((nr + 31) // 32, 1) * (qx + qd) * 256, device=dev)
+    check(lib.nf_render_features(ptr(grid.points), ptr(rays), None, ptr(z_table), R, S, float(radius), K, enc_flags,
+                                 ptr(ro.contiguous().float()), ptr(row_sample), ptr(row_nbr), ptr(counters[1:2]), nr,
+                                 ptr(X), st))
+    return dict(features=tiles_to_rows(X, nr, cx, cd), row_sample=row_sample[:nr], num_nn=num_nn,
+                row_nbr=row_nbr[:nr * K].view(nr, K))

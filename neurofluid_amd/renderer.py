@@ -1,0 +1,104 @@
+"""Host-side mirror of /root/reference/models/renderer.py (RenderNet :15-370).
+
+Same constructor, same ``forward`` signature and result keys, same parameter names; the body is the
+fused HIP pipeline of ops.render_pass (classify -> first-K search -> features -> fp32-MFMA MLP ->
+composite) + importance sampling.  Autograd is provided by ``_RenderFunction`` (backward kernels in
+nf_mlp_bwd.hip / nf_render_bwd) — see neurofluid_amd/autograd.py.
+"""
+import torch
+from torch import nn
+
+from . import ops
+from .nerf import Embedding, NeRF
+
+
+def _get(cfg, path, default=None):
+    """cfg may be an attribute-style node (configs/*.yaml) or a nested dict."""
+    cur = cfg
+    for key in path.split("."):
+        if isinstance(cur, dict):
+            if key not in cur:
+                return default
+            cur = cur[key]
+        else:
+            if not hasattr(cur, key):
+                return default
+            cur = getattr(cur, key)
+    return cur
+
+
+class RenderNet(nn.Module):
+    def __init__(self, cfg, near, far):
+        super().__init__()
+        self.cfg = cfg
+        self.near, self.far = float(near), float(far)
+        self.N_samples = int(_get(cfg, "ray.N_samples"))
+        self.N_importance = int(_get(cfg, "ray.N_importance"))
+        self.raduis = _get(cfg, "NN_search.search_raduis_scale") * _get(cfg, "NN_search.particle_radius")
+        self.fix_radius = bool(_get(cfg, "NN_search.fix_radius"))
+        self.num_neighbor = int(_get(cfg, "NN_search.N_neighbor"))
+        self.use_mask = bool(_get(cfg, "use_mask"))
+        if not self.fix_radius:
+            raise NotImplementedError("fix_radius=False is dead code in the reference (models/renderer.py:119-121)")
+        if not _get(cfg, "encoding.exclude_ray", True):
+            raise NotImplementedError("encoding.exclude_ray=False is not on the hot path (configs/*.yaml use True)")
+        self.embedding_xyz = Embedding(3, 10)
+        self.embedding_dir = Embedding(3, 4)
+        in_xyz, in_dir = self.embedding_xyz.out_channels, self.embedding_dir.out_channels
+        self.enc_flags = 0
+        if _get(cfg, "encoding.density"):
+            self.embedding_density = Embedding(1, 4)
+            in_xyz += self.embedding_density.out_channels
+            self.enc_flags |= 1
+        if _get(cfg, "encoding.var"):
+            in_xyz += self.embedding_xyz.out_channels
+            self.enc_flags |= 4
+        if _get(cfg, "encoding.smoothed_pos"):
+            in_xyz += self.embedding_xyz.out_channels
+            self.enc_flags |= 2
+        if _get(cfg, "encoding.smoothed_dir"):
+            in_dir += self.embedding_dir.out_channels
+            self.enc_flags |= 8
+        self.in_channels_xyz, self.in_channels_dir = in_xyz, in_dir
+        self.nerf_coarse = NeRF(in_channels_xyz=in_xyz, in_channels_dir=in_dir)
+        self.nerf_fine = NeRF(in_channels_xyz=in_xyz, in_channels_dir=in_dir)
+        self._z_table = None
+        self._u_table = None
+        self._grid_cache = (None, None)
+
+    # ------------------------------------------------------------------
+    def set_ro(self, cw):
+        return cw[:, 3]
+
+    def _tables(self, device):
+        if self._z_table is None or self._z_table.device != device:
+            t = torch.linspace(0, 1, self.N_samples)          # utils/ray_utils.py:236-238 (CPU bits, then copied)
+            self._z_table = (self.near * (1 - t) + self.far * t).to(device)
+            self._u_table = torch.linspace(0., 1., steps=max(self.N_importance, 1)).to(device)
+        return self._z_table, self._u_table
+
+    def grid_for(self, particles):
+        """One grid per particle tensor *version* (rebuilt when the particles move)."""
+        key = (particles.data_ptr(), particles._version, particles.shape[0])
+        if self._grid_cache[0] != key:
+            self._grid_cache = (key, ops.build_grid(particles, self.raduis))
+        return self._grid_cache[1]
+
+    def packed_weights(self, net):
+        layers = net.linear_layers()
+        return ops.pack_nerf([l.weight for l in layers], [l.bias for l in layers], self.in_channels_xyz,
+                             self.in_channels_dir)
+
+    # ------------------------------------------------------------------
+    def forward(self, physical_particles, ro, rays, focal=None, c2w=None, use_disp=False, perturb=0, noise_std=0.,
+                white_background=True):
+        if use_disp or perturb != 0 or noise_std != 0.:
+            raise NotImplementedError("use_disp / perturb / noise_std are never passed by the reference callers "
+                                      "(trainer/basetrainer.py:284-289)")
+        from .autograd import render_forward
+        return render_forward(self, physical_particles, ro, rays, white_background, fine=self.N_importance > 0)
+
+    def coarse_rendering(self, physical_particles, ro, rays, focal=None, c2w=None, use_disp=False, perturb=0,
+                         noise_std=0., white_background=True):
+        from .autograd import render_forward
+        return render_forward(self, physical_particles, ro, rays, white_background, fine=False)

@@ -1,0 +1,32 @@
+"""Quick timing of the forward render of the synthetic watercube 400x400 image (dev tool)."""
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from oracle import render_oracle as ro
+from neurofluid_amd.renderer import RenderNet
+
+dev = torch.device("cuda:0")
+cfg = dict(use_mask=True, ray=dict(ray_chunk=1024, N_importance=128, N_samples=64),
+           NN_search=dict(fix_radius=True, particle_radius=0.025, search_raduis_scale=9.0, N_neighbor=20),
+           encoding=dict(density=True, var=True, smoothed_pos=True, smoothed_dir=True, exclude_ray=True, same_smooth_factor=False))
+net = RenderNet(cfg, 9.0, 13.0)
+net.load_state_dict(ro.deterministic_nerf_state(), strict=True)
+net = net.to(dev)
+P = ro.watercube_particles().to(dev)
+c2w = ro.eval_camera()
+H = W = 400
+d = ro.get_ray_directions(H, W, ro.camera_focal(W))
+o, dd = ro.get_rays(d, c2w)
+rays = torch.cat([o, dd], -1).view(-1, 6).to(dev)
+roc = c2w[:, 3].to(dev)
+chunk = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+for it in range(3):
+    torch.cuda.synchronize(); t = time.time()
+    rows = 0
+    with torch.no_grad():
+        for i in range(0, rays.shape[0], chunk):
+            out = net(P, roc, rays[i:i + chunk], None, None)
+            rows += float(out["mask_0"].sum() + out["mask_1"].sum())
+    torch.cuda.synchronize(); dt = time.time() - t
+    print(f"iter {it}: {dt*1e3:.1f} ms, {rays.shape[0]/dt:.0f} rays/s, active rows {rows:.0f}, "
+          f"MLP TFLOP/s (executed rows) {rows*1331968/dt/1e12:.2f}")

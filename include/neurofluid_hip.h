@@ -74,7 +74,7 @@ int nf_radius_fill(const void* grid_ws, const float* queries, int nq, float radi
  * cand[] (count in cand_count[0], must be zeroed by the caller).
  * z_table (S) is used when z == NULL (coarse pass: same depths for every ray). */
 int nf_render_classify(const void* grid_ws, const float* rays /*R*6*/, const float* z /*R*S or NULL*/,
-                       const float* z_table /*S or NULL*/, int R, int S, int use_mask,
+                       const float* z_table /*S or NULL*/, int R, int S, float radius, int use_mask,
                        int32_t* num_nn /*R*S*/, uint8_t* mask /*R*S*/, float* rgbsigma /*R*S*4*/,
                        int32_t* cand /*R*S*/, int32_t* cand_count /*1*/, nf_stream_t stream);
 

@@ -39,7 +39,7 @@ struct NfGridHeader {
     int off_tmp_cell;
     int off_tmp_list;
     int off_cell_fill;
-    int pad;
+    int off_cell_aabb;   // float[6] per cell: min xyz, max xyz of the contained points (+inf/-inf when empty)
 };
 
 struct NfGridView {
@@ -51,6 +51,7 @@ struct NfGridView {
     const int* cell_dil;
     const int* sorted_idx;
     const float4* sorted_pos;
+    const float* cell_aabb;
 };
 
 __device__ __forceinline__ NfGridView nf_grid_view(const void* ws)
@@ -66,6 +67,7 @@ __device__ __forceinline__ NfGridView nf_grid_view(const void* ws)
     v.cell_dil = (const int*)(b + h->off_cell_dil);
     v.sorted_idx = (const int*)(b + h->off_sorted_idx);
     v.sorted_pos = (const float4*)(b + h->off_sorted_pos);
+    v.cell_aabb = (const float*)(b + h->off_cell_aabb);
     return v;
 }
 
@@ -93,13 +95,43 @@ __device__ __forceinline__ float nf_madd_nofma(float o, float d, float z) { retu
 // first-K-by-index search core (used by nf_grid.hip: ball query op, nf_render.hip: fused search)
 // ------------------------------------------------------------------------------------------------
 #define BQ_BLOCK 128
+#define BQ_LDS_INTS(K) ((2 * (K) + 27) * BQ_BLOCK)   // K idx + K d2 + 27 cell keys per thread
+
+// fp32 squared distance from a query to a cell's particle AABB, same op order as nf_dist2.  Because
+// fp32 sub/mul/add are monotone, box_d2 <= nf_dist2(query, p) for every particle p of the cell, so
+// "box_d2 < r2" never rejects a cell that holds an in-radius particle.
+__device__ __forceinline__ float nf_box_dist2(const float* __restrict__ bb, float qx, float qy, float qz)
+{
+    float dx = fmaxf(fmaxf(__fsub_rn(bb[0], qx), __fsub_rn(qx, bb[3])), 0.f);
+    float dy = fmaxf(fmaxf(__fsub_rn(bb[1], qy), __fsub_rn(qy, bb[4])), 0.f);
+    float dz = fmaxf(fmaxf(__fsub_rn(bb[2], qz), __fsub_rn(qz, bb[5])), 0.f);
+    float s = __fmul_rn(dx, dx);
+    s = __fadd_rn(s, __fmul_rn(dy, dy));
+    s = __fadd_rn(s, __fmul_rn(dz, dz));
+    return s;
+}
+
+// true iff some cell of the 27-neighbourhood has its particle AABB within (strictly) radius
+__device__ __forceinline__ bool nf_any_cell_in_reach(const NfGridView& g, float qx, float qy, float qz, float r2)
+{
+    int cx = nf_cell_coord(qx, g.ox, g.icx, g.dx);
+    int cy = nf_cell_coord(qy, g.oy, g.icy, g.dy);
+    int cz = nf_cell_coord(qz, g.oz, g.icz, g.dz);
+    if (g.cell_dil[(cz * g.dy + cy) * g.dx + cx] == 0) return false;
+    for (int z = max(cz - 1, 0); z <= min(cz + 1, g.dz - 1); ++z)
+        for (int y = max(cy - 1, 0); y <= min(cy + 1, g.dy - 1); ++y)
+            for (int x = max(cx - 1, 0); x <= min(cx + 1, g.dx - 1); ++x) {
+                int c = (z * g.dy + y) * g.dx + x;
+                if (nf_box_dist2(g.cell_aabb + 6 * c, qx, qy, qz) < r2) return true;
+            }
+    return false;
+}
 
 // Sorted insertion of (j, d2) into the per-thread ascending-by-index list held in LDS as
 // list[k * BQ_BLOCK + tid].  Returns the new count.
 __device__ __forceinline__ int firstk_insert(int* li, float* ld, int cnt, int K, int j, float d2, int tid)
 {
     int pos = cnt < K ? cnt : K - 1;  // slot that is overwritten / appended
-    // shift larger entries up
     while (pos > 0 && li[(pos - 1) * BQ_BLOCK + tid] > j) {
         li[pos * BQ_BLOCK + tid] = li[(pos - 1) * BQ_BLOCK + tid];
         ld[pos * BQ_BLOCK + tid] = ld[(pos - 1) * BQ_BLOCK + tid];
@@ -110,30 +142,55 @@ __device__ __forceinline__ int firstk_insert(int* li, float* ld, int cnt, int K,
     return cnt < K ? cnt + 1 : K;
 }
 
-// Core search used by the standalone op and by the renderer (nf_render.hip includes this file's header part).
+// First-K-by-index search.  Cells are index-sorted, so a cell's first entry is its minimum index.
+// Cells are visited in ascending order of that minimum (keys in LDS); once the list is full and the
+// smallest remaining key exceeds the current K-th index, no remaining particle can enter the list.
+// lk = 27 keys [c * BQ_BLOCK + tid].
 __device__ __forceinline__ int firstk_search(const NfGridView& g, float qx, float qy, float qz, float r2, int K,
-                                             int* li, float* ld, int tid)
+                                             int* li, float* ld, int* lk, int tid)
 {
     int cx = nf_cell_coord(qx, g.ox, g.icx, g.dx);
     int cy = nf_cell_coord(qy, g.oy, g.icy, g.dy);
     int cz = nf_cell_coord(qz, g.oz, g.icz, g.dz);
-    int cnt = 0;
-    for (int z = max(cz - 1, 0); z <= min(cz + 1, g.dz - 1); ++z)
-        for (int y = max(cy - 1, 0); y <= min(cy + 1, g.dy - 1); ++y)
-            for (int x = max(cx - 1, 0); x <= min(cx + 1, g.dx - 1); ++x) {
-                int c = (z * g.dy + y) * g.dx + x;
-                int s = g.cell_start[c], e = g.cell_start[c + 1];
-                for (int t = s; t < e; ++t) {
-                    float4 p = g.sorted_pos[t];
-                    int j = __float_as_int(p.w);
-                    if (cnt == K && j > li[(K - 1) * BQ_BLOCK + tid]) break;  // cell is index-sorted
-                    float d2 = nf_dist2(qx, qy, qz, p.x, p.y, p.z);
-                    if (d2 < r2) cnt = firstk_insert(li, ld, cnt, K, j, d2, tid);
-                }
+    const int BIG = 0x7fffffff;
+    int nvalid = 0;
+    for (int c = 0; c < 27; ++c) {
+        int x = cx + (c % 3) - 1, y = cy + ((c / 3) % 3) - 1, z = cz + (c / 9) - 1;
+        int key = BIG;
+        if (x >= 0 && x < g.dx && y >= 0 && y < g.dy && z >= 0 && z < g.dz) {
+            int cell = (z * g.dy + y) * g.dx + x;
+            int s = g.cell_start[cell];
+            if (g.cell_start[cell + 1] > s && nf_box_dist2(g.cell_aabb + 6 * cell, qx, qy, qz) < r2) {
+                key = g.sorted_idx[s];
+                ++nvalid;
             }
+        }
+        lk[c * BQ_BLOCK + tid] = key;
+    }
+    int cnt = 0;
+    while (nvalid > 0) {
+        int best = BIG, bc = 0;
+        for (int c = 0; c < 27; ++c) {
+            int k = lk[c * BQ_BLOCK + tid];
+            if (k < best) { best = k; bc = c; }
+        }
+        if (best == BIG) break;
+        if (cnt == K && best > li[(K - 1) * BQ_BLOCK + tid]) break;
+        lk[bc * BQ_BLOCK + tid] = BIG;
+        --nvalid;
+        int x = cx + (bc % 3) - 1, y = cy + ((bc / 3) % 3) - 1, z = cz + (bc / 9) - 1;
+        int cell = (z * g.dy + y) * g.dx + x;
+        int s = g.cell_start[cell], e = g.cell_start[cell + 1];
+        for (int t = s; t < e; ++t) {
+            float4 p = g.sorted_pos[t];
+            int j = __float_as_int(p.w);
+            if (cnt == K && j > li[(K - 1) * BQ_BLOCK + tid]) break;  // cell is index-sorted
+            float d2 = nf_dist2(qx, qy, qz, p.x, p.y, p.z);
+            if (d2 < r2) cnt = firstk_insert(li, ld, cnt, K, j, d2, tid);
+        }
+    }
     return cnt;
 }
-
 
 // host-side helper shared by the grid functions
 int nf_grid_make_header(int n_points, float cell, const float bbox[6], NfGridHeader* h, size_t* total_bytes);

@@ -142,6 +142,7 @@ int nf_grid_make_header(int n, float cell, const float bbox[6], NfGridHeader* h,
     h->off_tmp_cell = (int)off;   off = align_up(off + sizeof(int) * (size_t)(n > 0 ? n : 1), 256);
     h->off_tmp_list = (int)off;   off = align_up(off + sizeof(int) * (size_t)(n > 0 ? n : 1), 256);
     h->off_cell_fill = (int)off;  off = align_up(off + sizeof(int) * (cells + SCAN_BLOCK + 2048), 256);
+    h->off_cell_aabb = (int)off;  off = align_up(off + sizeof(float) * 6 * cells, 256);
     if (off > (size_t)0x7fffffff) return NF_EINVAL;
     *total = off;
     return NF_OK;
@@ -224,6 +225,16 @@ __global__ void k_grid_dilate(NfGridHeader h, void* ws)
             tot += cs[r0 + x1 + 1] - cs[r0 + x0];  // cells of one x-row are contiguous
         }
     ((int*)(b + h.off_cell_dil))[c] = tot;
+    // particle AABB of this cell
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    const float4* sp = (const float4*)(b + h.off_sorted_pos);
+    for (int t = cs[c]; t < cs[c + 1]; ++t) {
+        float4 p = sp[t];
+        lo[0] = fminf(lo[0], p.x); lo[1] = fminf(lo[1], p.y); lo[2] = fminf(lo[2], p.z);
+        hi[0] = fmaxf(hi[0], p.x); hi[1] = fmaxf(hi[1], p.y); hi[2] = fmaxf(hi[2], p.z);
+    }
+    float* bb = (float*)(b + h.off_cell_aabb) + 6 * c;
+    bb[0] = lo[0]; bb[1] = lo[1]; bb[2] = lo[2]; bb[3] = hi[0]; bb[4] = hi[1]; bb[5] = hi[2];
 }
 
 extern "C" int nf_grid_build(const float* pts, int n, float cell, const float bbox[6], void* ws, size_t ws_bytes,
@@ -262,11 +273,12 @@ __global__ void __launch_bounds__(BQ_BLOCK) k_ball_query(const void* __restrict_
     extern __shared__ int lds[];
     int* li = lds;
     float* ld = (float*)(lds + K * BQ_BLOCK);
+    int* lk = lds + 2 * K * BQ_BLOCK;
     int i = blockIdx.x * BQ_BLOCK + threadIdx.x;
     if (i >= nq) return;
     NfGridView g = nf_grid_view(ws);
     float qx = q[3 * i], qy = q[3 * i + 1], qz = q[3 * i + 2];
-    int cnt = firstk_search(g, qx, qy, qz, r2, K, li, ld, threadIdx.x);
+    int cnt = firstk_search(g, qx, qy, qz, r2, K, li, ld, lk, threadIdx.x);
     for (int k = 0; k < K; ++k) {
         size_t o = (size_t)i * K + k;
         float d = 0.f, x = 0.f, y = 0.f, z = 0.f;
@@ -291,7 +303,7 @@ extern "C" int nf_ball_query_firstk(const void* ws, const float* pts, const floa
     if (nq == 0) return NF_OK;
     hipStream_t st = (hipStream_t)stream;
     const float r2 = radius * radius;  // fp32 product, like pytorch3d's `radius2`
-    size_t lds = (size_t)K * BQ_BLOCK * 8;
+    size_t lds = (size_t)BQ_LDS_INTS(K) * 4;
     hipLaunchKernelGGL(k_ball_query, dim3((nq + BQ_BLOCK - 1) / BQ_BLOCK), dim3(BQ_BLOCK), lds, st, ws, pts, queries, nq,
                        r2, K, dists2, idx, nn);
     NF_CHECK_LAUNCH();

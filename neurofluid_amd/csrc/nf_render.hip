@@ -38,44 +38,70 @@ __device__ __forceinline__ void sample_xyz(const float* __restrict__ rays, const
 // ------------------------------------------------------------------------------------------------
 // classify
 // ------------------------------------------------------------------------------------------------
+#define CL_PER_THREAD 8
 __global__ void __launch_bounds__(256) k_classify(const void* __restrict__ ws, const float* __restrict__ rays,
                                                   const float* __restrict__ z, const float* __restrict__ z_table, int R,
-                                                  int S, int use_mask, int* __restrict__ num_nn,
+                                                  int S, float r2, int use_mask, int* __restrict__ num_nn,
                                                   uint8_t* __restrict__ mask, float4* __restrict__ rgbsigma,
                                                   int* __restrict__ cand, int* __restrict__ cand_count)
 {
+    // one atomic per 2048 samples: per-thread flags -> block scan -> single reservation
+    __shared__ int wsum[4];
+    __shared__ int block_base;
     NfGridView g = nf_grid_view(ws);
-    int total = R * S;
-    int i = blockIdx.x * 256 + threadIdx.x;
-    bool is_cand = false;
-    if (i < total) {
-        float x, y, zz, zv;
-        sample_xyz(rays, z, z_table, S, i, x, y, zz, zv);
-        int cx = nf_cell_coord(x, g.ox, g.icx, g.dx);
-        int cy = nf_cell_coord(y, g.oy, g.icy, g.dy);
-        int cz = nf_cell_coord(zz, g.oz, g.icz, g.dz);
-        int dil = g.cell_dil[(cz * g.dy + cy) * g.dx + cx];
-        is_cand = (dil > 0) || !use_mask;
-        if (!is_cand) {
-            num_nn[i] = 0;
-            mask[i] = 0;
-            rgbsigma[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int total = R * S;
+    const int base = blockIdx.x * (256 * CL_PER_THREAD);
+    unsigned flags = 0;
+#pragma unroll
+    for (int u = 0; u < CL_PER_THREAD; ++u) {
+        int i = base + u * 256 + threadIdx.x;
+        if (i < total) {
+            float x, y, zz, zv;
+            sample_xyz(rays, z, z_table, S, i, x, y, zz, zv);
+            bool is_cand = !use_mask || nf_any_cell_in_reach(g, x, y, zz, r2);
+            if (is_cand) flags |= 1u << u;
+            else {
+                num_nn[i] = 0;
+                mask[i] = 0;
+                rgbsigma[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
     }
-    int slot = wave_append(is_cand, cand_count);
-    if (is_cand) cand[slot] = i;
+    int n = __popc(flags);
+    // wave inclusive scan
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int x = n;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int yv = __shfl_up(x, o, 64);
+        if (lane >= o) x += yv;
+    }
+    if (lane == 63) wsum[w] = x;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        block_base = t ? atomicAdd(cand_count, t) : 0;
+    }
+    __syncthreads();
+    int off = block_base + (x - n);
+    for (int k = 0; k < w; ++k) off += wsum[k];
+#pragma unroll
+    for (int u = 0; u < CL_PER_THREAD; ++u)
+        if (flags & (1u << u)) cand[off++] = base + u * 256 + threadIdx.x;
 }
 
 extern "C" int nf_render_classify(const void* ws, const float* rays, const float* z, const float* z_table, int R, int S,
-                                  int use_mask, int32_t* num_nn, uint8_t* mask, float* rgbsigma, int32_t* cand,
-                                  int32_t* cand_count, nf_stream_t stream)
+                                  float radius, int use_mask, int32_t* num_nn, uint8_t* mask, float* rgbsigma,
+                                  int32_t* cand, int32_t* cand_count, nf_stream_t stream)
 {
     NF_CHECK_ARG(ws && rays && (z || z_table) && num_nn && mask && rgbsigma && cand && cand_count, "null pointer");
     NF_CHECK_ARG(R >= 0 && S > 0 && (long)R * S < 0x7fffffffL, "bad R/S");
+    NF_CHECK_ARG(radius > 0.f, "bad radius");
     if (R == 0) return NF_OK;
     int total = R * S;
-    hipLaunchKernelGGL(k_classify, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, rays, z, z_table, R,
-                       S, use_mask, num_nn, mask, (float4*)rgbsigma, cand, cand_count);
+    int per_block = 256 * CL_PER_THREAD;
+    hipLaunchKernelGGL(k_classify, dim3((total + per_block - 1) / per_block), dim3(256), 0, (hipStream_t)stream, ws, rays,
+                       z, z_table, R, S, radius * radius, use_mask, num_nn, mask, (float4*)rgbsigma, cand, cand_count);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }
@@ -94,6 +120,7 @@ __global__ void __launch_bounds__(BQ_BLOCK) k_search(const void* __restrict__ ws
     extern __shared__ int lds[];
     int* li = lds;
     float* ld = (float*)(lds + K * BQ_BLOCK);
+    int* lk = lds + 2 * K * BQ_BLOCK;
     NfGridView g = nf_grid_view(ws);
     const int ncand = *cand_count;
     const int tid = threadIdx.x;
@@ -105,7 +132,7 @@ __global__ void __launch_bounds__(BQ_BLOCK) k_search(const void* __restrict__ ws
             sample = cand[c];
             float x, y, zz, zv;
             sample_xyz(rays, z, z_table, S, sample, x, y, zz, zv);
-            cnt = firstk_search(g, x, y, zz, r2, K, li, ld, tid);
+            cnt = firstk_search(g, x, y, zz, r2, K, li, ld, lk, tid);
             int nz = 0;
             for (int k = 0; k < cnt; ++k) nz += (ld[k * BQ_BLOCK + tid] != 0.f);  // nn_mask = dists.ne(0)
             bool full = (nz == K);
@@ -134,7 +161,7 @@ extern "C" int nf_render_search(const void* ws, const float* rays, const float* 
     long total = (long)R * S;
     int blocks = (int)((total + BQ_BLOCK - 1) / BQ_BLOCK);
     if (blocks > 8192) blocks = 8192;
-    size_t lds = (size_t)K * BQ_BLOCK * 8;
+    size_t lds = (size_t)BQ_LDS_INTS(K) * 4;
     hipLaunchKernelGGL(k_search, dim3(blocks), dim3(BQ_BLOCK), lds, (hipStream_t)stream, ws, rays, z, z_table, S,
                        radius * radius, K, use_mask, cand, cand_count, num_nn, mask, (float4*)rgbsigma, row_sample,
                        row_nbr, n_rows);

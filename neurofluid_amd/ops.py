@@ -187,7 +187,7 @@ def render_pass(grid, particles, rays, z, z_table, S, radius, K, enc_flags, use_
     cand = torch.empty(n_samp, dtype=torch.int32, device=dev)
     counters = torch.zeros(2, dtype=torch.int32, device=dev)
     b.counters = counters
-    check(lib.nf_render_classify(ptr(grid.ws), ptr(rays), ptr(z), ptr(z_table), R, S, int(use_mask), ptr(b.num_nn),
+    check(lib.nf_render_classify(ptr(grid.ws), ptr(rays), ptr(z), ptr(z_table), R, S, float(radius), int(use_mask), ptr(b.num_nn),
                                  ptr(b.mask), ptr(b.rgbsigma), ptr(cand), ptr(counters[0:1]), st), "nf_render_classify")
     if max_rows is None:
         max_rows = n_samp
@@ -289,7 +289,7 @@ def debug_features(particles, rays, near, far, S, radius, K, enc_flags, ro):
     row_nbr = torch.empty(n * K, dtype=torch.int32, device=dev)
     st = _lib.stream()
     rays = rays.contiguous().float()
-    check(lib.nf_render_classify(ptr(grid.ws), ptr(rays), None, ptr(z_table), R, S, 1, ptr(num_nn), ptr(mask),
+    check(lib.nf_render_classify(ptr(grid.ws), ptr(rays), None, ptr(z_table), R, S, float(radius), 1, ptr(num_nn), ptr(mask),
                                  ptr(rgbsigma), ptr(cand), ptr(counters[0:1]), st))
     check(lib.nf_render_search(ptr(grid.ws), ptr(rays), None, ptr(z_table), R, S, float(radius), K, 1, ptr(cand),
                                ptr(counters[0:1]), ptr(num_nn), ptr(mask), ptr(rgbsigma), ptr(row_sample), ptr(row_nbr),

@@ -121,6 +121,45 @@ int nf_composite_fwd(const float* rgbsigma /*R*S*4*/, const float* z, const floa
 int nf_importance_sample(const float* z_table0 /*S0*/, const float* weights0 /*R*S0*/, const float* u_table /*N_imp*/,
                          int R, int S0, int N_imp, float* z1 /*R*(S0+N_imp)*/, nf_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Transition model (ParticleNet.forward, models/transmodel.py:151-163).
+ * ------------------------------------------------------------------------------------------ */
+
+/* B1: integrate_pos_vel (models/transmodel.py:100-104); also emits fluid_feats = [1, vel_new] (:111-114).
+ * gravity is a [host] float[3]. */
+int nf_trans_integrate(const float* pos, const float* vel, const float gravity[3], float dt, int n,
+                       float* pos_new, float* vel_new, float* feats4 /*n*4 or NULL*/, nf_stream_t stream);
+/* B1: update_pos_vel with pos_delta = scale * y3 (models/transmodel.py:141, :144-148). */
+int nf_trans_update(const float* pos, const float* pos_new, const float* y3, float scale, float dt, int n,
+                    float* pos_corrected, float* vel_corrected, nf_stream_t stream);
+
+/* B3 + coordinate mapping of Open3D continuous_conv (ball_to_cube_volume_preserving, align_corners,
+ * linear interpolation, 4x4x4 filter), once per CSR entry: pair_w[p*8+c] = window(d2/r^2) * trilinear
+ * weight, pair_cell[p*8+c] = (z*4+y)*4+x filter cell.  Shared by every layer that uses the same
+ * (inp_positions, out_positions) pair (the reference recomputes it inside each of its 5 convs). */
+int nf_cconv_pairs(const float* inp_pos, const float* out_pos, const int64_t* row_splits, const int32_t* nbr,
+                   const float* dist2, int n_out, float extent, int use_window,
+                   float* pair_w /*nnz*8*/, uint8_t* pair_cell /*nnz*8*/, nf_stream_t stream);
+
+/* B4 for Cin in {3,4}, Cout = 32 (conv0_fluid, conv0_obstacle; models/transmodel.py:116,:118):
+ * out[i*ld_out + col_off + co] = ContinuousConv(feats)[i][co] + bias[co]; optional Linear branch
+ * (dense0_fluid, :117) on self_feats written at dense_col_off.  kernel = (4,4,4,Cin,32) as stored by Open3D. */
+int nf_cconv_small(const float* feats, int cin, const int64_t* row_splits, const int32_t* nbr,
+                   const float* pair_w, const uint8_t* pair_cell, const float* kernel, const float* bias,
+                   int n_out, float* out, int ld_out, int col_off,
+                   const float* self_feats, const float* dense_w, const float* dense_b, int dense_col_off,
+                   nf_stream_t stream);
+
+/* B4/B5 general layers, step 1: G (M x 65*Cout) = act(A (M x Cin)) * [filter as (Cin x 64*Cout) | dense_w^T]
+ * on fp32 MFMA; relu != 0 applies inp_feats = relu(prev) (models/transmodel.py:124). */
+int nf_cconv_transform(const float* A, int M, int cin, int cout, int relu, const float* kernel /*(4,4,4,Cin,Cout)*/,
+                       const float* dense_w /*[Cout][Cin]*/, float* G, nf_stream_t stream);
+/* step 2: y[i] = sum_pairs sum_corners pair_w * G[j][cell] + G[i][dense] + bias_conv + bias_dense (+ residual[i])
+ * (models/transmodel.py:125-130). */
+int nf_cconv_gather(const float* G, int cout, const int64_t* row_splits, const int32_t* nbr, const float* pair_w,
+                    const uint8_t* pair_cell, const float* bias_conv, const float* bias_dense,
+                    const float* residual /*n_out*Cout or NULL*/, int n_out, float* out, nf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,397 @@
+// nf_cconv.hip — Lagrangian transition model (models/transmodel.py): integration, continuous
+// convolution (Open3D ContinuousConv contract, call sites :86-95, :116-118, :125) and update.
+//
+// Formulation: "transform, then gather".
+//   G[j][cell][co] = sum_ci x[j][ci] * K[cell][ci][co]          (dense fp32-MFMA GEMM, N x Cin x 64*Cout)
+//   y[i][co]       = sum_{j in N(i)} sum_{8 corners c} w_ij * t_c(i,j) * G[j][cell_c(i,j)][co]
+// which equals Open3D's "gather a (64*Cin) patch per point, then GEMM" up to summation order and
+// does the same FLOPs, but turns the neighbour-dependent part into a pure weighted row gather with
+// 256-byte coalesced reads.  The per-pair interpolation data (8 cells + 8 weights, window folded in)
+// depends only on positions, so it is computed ONCE per step and shared by all fluid->fluid layers
+// (the reference rebuilds its hash table and re-derives it in each of 5 convs).
+// The dense (Linear) branch of each layer rides along as 1 extra "cell" of the same GEMM.
+// Layers with Cin <= 4 (conv0_fluid, conv0_obstacle) evaluate directly with the filter in LDS.
+#include "nf_common.h"
+#include <math.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------------------------------------
+// B1: integrate / update  (models/transmodel.py:100-104, :144-148)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_trans_integrate(const float* __restrict__ pos, const float* __restrict__ vel, float gx, float gy,
+                                  float gz, float dt, int n, float* __restrict__ pos_new, float* __restrict__ vel_new,
+                                  float* __restrict__ feats4)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float g[3] = {gx, gy, gz};
+    float vn[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        float v = vel[3 * i + d];
+        vn[d] = v + g[d] * dt;
+        pos_new[3 * i + d] = pos[3 * i + d] + (v + vn[d]) / 2 * dt;
+        vel_new[3 * i + d] = vn[d];
+    }
+    if (feats4) {  // fluid_feats = [1, vel_new]  (:111-114)
+        feats4[4 * i] = 1.f; feats4[4 * i + 1] = vn[0]; feats4[4 * i + 2] = vn[1]; feats4[4 * i + 3] = vn[2];
+    }
+}
+
+__global__ void k_trans_update(const float* __restrict__ pos, const float* __restrict__ pos_new,
+                               const float* __restrict__ y3, float scale, float dt, int n, float* __restrict__ pos_c,
+                               float* __restrict__ vel_c)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * n) return;
+    float pc = pos_new[i] + scale * y3[i];   // pos_correction = (1/128) * ans_convs[-1]  (:141)
+    pos_c[i] = pc;
+    vel_c[i] = (pc - pos[i]) / dt;
+}
+
+extern "C" int nf_trans_integrate(const float* pos, const float* vel, const float gravity[3], float dt, int n,
+                                  float* pos_new, float* vel_new, float* feats4, nf_stream_t stream)
+{
+    NF_CHECK_ARG(pos && vel && gravity && pos_new && vel_new, "null pointer");
+    if (n <= 0) return NF_OK;
+    hipLaunchKernelGGL(k_trans_integrate, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, pos, vel, gravity[0],
+                       gravity[1], gravity[2], dt, n, pos_new, vel_new, feats4);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+extern "C" int nf_trans_update(const float* pos, const float* pos_new, const float* y3, float scale, float dt, int n,
+                               float* pos_c, float* vel_c, nf_stream_t stream)
+{
+    NF_CHECK_ARG(pos && pos_new && y3 && pos_c && vel_c, "null pointer");
+    if (n <= 0) return NF_OK;
+    hipLaunchKernelGGL(k_trans_update, dim3((3 * n + 255) / 256), dim3(256), 0, (hipStream_t)stream, pos, pos_new, y3,
+                       scale, dt, n, pos_c, vel_c);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pair interpolation data: ball -> cylinder -> cube (volume preserving), align_corners, trilinear
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void ball_to_cube(float& x, float& y, float& z)
+{
+    // sphere -> cylinder
+    float sq = x * x + y * y + z * z;
+    float nrm = sqrtf(sq);
+    float xy2 = x * x + y * y;
+    if (sq < 1e-12f) { x = y = z = 0.f; }
+    else if (1.25f * z * z > xy2) {
+        float s = sqrtf(3.f * nrm / (nrm + fabsf(z)));
+        x *= s; y *= s; z = copysignf(nrm, z);
+    } else {
+        float s = nrm / sqrtf(xy2);
+        x *= s; y *= s; z *= 1.5f;
+    }
+    // cylinder -> cube
+    float sq2 = x * x + y * y;
+    float nxy = sqrtf(sq2);
+    const float four_over_pi = 1.2732395447351628f;
+    if (sq2 < 1e-12f) { x = y = 0.f; }
+    else if (fabsf(y) <= fabsf(x)) {
+        float t = copysignf(nxy, x);
+        y = t * four_over_pi * atanf(y / x);
+        x = t;
+    } else {
+        float t = copysignf(nxy, y);
+        x = t * four_over_pi * atanf(x / y);
+        y = t;
+    }
+}
+
+// one wave per CSR row; lanes stride over the row's entries
+__global__ void __launch_bounds__(256) k_pair_precompute(const float* __restrict__ inp_pos, const float* __restrict__ out_pos,
+                                                         const int64_t* __restrict__ row_splits,
+                                                         const int32_t* __restrict__ nbr, const float* __restrict__ d2,
+                                                         int n_out, float extent, int use_window,
+                                                         float* __restrict__ pw, uint8_t* __restrict__ pc)
+{
+    int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (row >= n_out) return;
+    float ox = out_pos[3 * row], oy = out_pos[3 * row + 1], oz = out_pos[3 * row + 2];
+    const float radius = 0.5f * extent, inv_r2 = 1.f / (radius * radius), scale = 2.f / extent;
+    for (int64_t p = row_splits[row] + lane; p < row_splits[row + 1]; p += 64) {
+        int j = nbr[p];
+        float x = (inp_pos[3 * j] - ox) * scale, y = (inp_pos[3 * j + 1] - oy) * scale, z = (inp_pos[3 * j + 2] - oz) * scale;
+        ball_to_cube(x, y, z);
+        float imp = 1.f;
+        if (use_window) {  // _window_poly6(d2 / radius^2) = clamp((1-R)^3, 0, 1)   (models/transmodel.py:73-77)
+            float t = 1.f - d2[p] * inv_r2;
+            imp = fminf(fmaxf(t * t * t, 0.f), 1.f);
+        }
+        float c[3] = {(x + 1.f) * 1.5f, (y + 1.f) * 1.5f, (z + 1.f) * 1.5f};  // [-1,1] -> [0,3] (4 cells, align_corners)
+        int i0[3];
+        float f[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            float cc = fminf(fmaxf(c[d], 0.f), 3.f);
+            float fl = fminf(floorf(cc), 2.f);
+            i0[d] = (int)fl;
+            f[d] = cc - fl;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
+            float w = (dx ? f[0] : 1.f - f[0]) * (dy ? f[1] : 1.f - f[1]) * (dz ? f[2] : 1.f - f[2]);
+            pw[p * 8 + k] = imp * w;
+            pc[p * 8 + k] = (uint8_t)(((i0[2] + dz) * 4 + (i0[1] + dy)) * 4 + (i0[0] + dx));
+        }
+    }
+}
+
+extern "C" int nf_cconv_pairs(const float* inp_pos, const float* out_pos, const int64_t* row_splits, const int32_t* nbr,
+                              const float* dist2, int n_out, float extent, int use_window, float* pair_w,
+                              uint8_t* pair_cell, nf_stream_t stream)
+{
+    NF_CHECK_ARG(inp_pos && out_pos && row_splits && pair_w && pair_cell, "null pointer");
+    NF_CHECK_ARG(extent > 0.f, "bad extent");
+    if (n_out <= 0) return NF_OK;
+    hipLaunchKernelGGL(k_pair_precompute, dim3((n_out + 3) / 4), dim3(256), 0, (hipStream_t)stream, inp_pos, out_pos,
+                       row_splits, nbr, dist2, n_out, extent, use_window, pair_w, pair_cell);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// direct continuous convolution for small Cin (<= 4), Cout = 32: filter (64 x Cin x 32) in LDS,
+// one wave per output point, lane = (entry parity, co).  Optional Linear branch on the query's own
+// features (dense0_fluid, models/transmodel.py:117).
+// ------------------------------------------------------------------------------------------------
+template <int CIN>
+__global__ void __launch_bounds__(256) k_cconv_small(const float* __restrict__ feats, const int64_t* __restrict__ row_splits,
+                                                     const int32_t* __restrict__ nbr, const float* __restrict__ pw,
+                                                     const uint8_t* __restrict__ pc, const float* __restrict__ kernel,
+                                                     const float* __restrict__ bias, int n_out, float* __restrict__ out,
+                                                     int ld_out, int col_off, const float* __restrict__ self_feats,
+                                                     const float* __restrict__ dense_w, const float* __restrict__ dense_b,
+                                                     int dense_col_off)
+{
+    __shared__ float Ks[64 * CIN * 32];
+    for (int t = threadIdx.x; t < 64 * CIN * 32; t += 256) Ks[t] = kernel[t];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, co = lane & 31, half = lane >> 5;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < n_out; row += gridDim.x * 4) {
+        float acc = 0.f;
+        for (int64_t p = row_splits[row] + half; p < row_splits[row + 1]; p += 2) {
+            int j = nbr[p];
+            float fj[CIN];
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) fj[ci] = feats[(size_t)j * CIN + ci];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float w = pw[p * 8 + k];
+                const float* kc = Ks + (int)pc[p * 8 + k] * CIN * 32 + co;
+                float s = 0.f;
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) s += fj[ci] * kc[ci * 32];
+                acc += w * s;
+            }
+        }
+        acc += __shfl_xor(acc, 32, 64);
+        if (half == 0) out[(size_t)row * ld_out + col_off + co] = acc + bias[co];
+        if (dense_w && half == 1) {
+            float s = dense_b[co];
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) s += self_feats[(size_t)row * CIN + ci] * dense_w[co * CIN + ci];
+            out[(size_t)row * ld_out + dense_col_off + co] = s;
+        }
+    }
+}
+
+extern "C" int nf_cconv_small(const float* feats, int cin, const int64_t* row_splits, const int32_t* nbr,
+                              const float* pair_w, const uint8_t* pair_cell, const float* kernel, const float* bias,
+                              int n_out, float* out, int ld_out, int col_off, const float* self_feats,
+                              const float* dense_w, const float* dense_b, int dense_col_off, nf_stream_t stream)
+{
+    NF_CHECK_ARG(feats && row_splits && kernel && bias && out, "null pointer");
+    NF_CHECK_ARG(cin == 3 || cin == 4, "cin must be 3 or 4 (Cout is 32)");
+    if (n_out <= 0) return NF_OK;
+    int blocks = (n_out + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    hipStream_t st = (hipStream_t)stream;
+    if (cin == 3)
+        hipLaunchKernelGGL(k_cconv_small<3>, dim3(blocks), dim3(256), 0, st, feats, row_splits, nbr, pair_w, pair_cell, kernel,
+                           bias, n_out, out, ld_out, col_off, self_feats, dense_w, dense_b, dense_col_off);
+    else
+        hipLaunchKernelGGL(k_cconv_small<4>, dim3(blocks), dim3(256), 0, st, feats, row_splits, nbr, pair_w, pair_cell, kernel,
+                           bias, n_out, out, ld_out, col_off, self_feats, dense_w, dense_b, dense_col_off);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// G = act(A) * [K_flat | W_dense^T]   fp32 MFMA GEMM (v_mfma_f32_32x32x2_f32)
+//   A: (M x Cin) row-major, optional ReLU on load (models/transmodel.py:124 inp_feats = relu(prev))
+//   B(k, n): n < 64*Cout -> kernel[(n / Cout) * Cin * Cout + k * Cout + n % Cout]   (filter (4,4,4,Cin,Cout))
+//            else        -> dense_w[(n - 64*Cout) * Cin + k]                         (Linear weight [Cout][Cin])
+//   G: (M x 65*Cout) row-major.
+// 128x128 tile per 4-wave workgroup, 2x2 MFMA tiles per wave, K staged through LDS in 32-deep slabs
+// stored k-major so that A/B fragment reads are lane-contiguous (conflict-free).
+// ------------------------------------------------------------------------------------------------
+#define GT_M 128
+#define GT_N 128
+#define GT_K 32
+__global__ void __launch_bounds__(256) k_cconv_gemm(const float* __restrict__ A, int M, int cin, int cout, int relu,
+                                                    const float* __restrict__ kernel, const float* __restrict__ dense_w,
+                                                    float* __restrict__ G)
+{
+    __shared__ float As[GT_K][GT_M + 4];
+    __shared__ float Bs[GT_K][GT_N + 4];
+    const int ntot = 65 * cout;
+    const int m0 = blockIdx.y * GT_M, n0 = blockIdx.x * GT_N;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    for (int k0 = 0; k0 < cin; k0 += GT_K) {
+        // A slab: 128 rows x 32 k
+        for (int t = tid; t < GT_M * GT_K; t += 256) {
+            int m = t / GT_K, k = t % GT_K;
+            float v = 0.f;
+            if (m0 + m < M && k0 + k < cin) {
+                v = A[(size_t)(m0 + m) * cin + k0 + k];
+                if (relu) v = fmaxf(v, 0.f);
+            }
+            As[k][m] = v;
+        }
+        // B slab: 32 k x 128 n
+        for (int t = tid; t < GT_K * GT_N; t += 256) {
+            int k = t / GT_N, n = t % GT_N;
+            float v = 0.f;
+            int gn = n0 + n, gk = k0 + k;
+            if (gn < ntot && gk < cin) {
+                if (gn < 64 * cout) v = kernel[(size_t)(gn / cout) * cin * cout + (size_t)gk * cout + gn % cout];
+                else v = dense_w[(size_t)(gn - 64 * cout) * cin + gk];
+            }
+            Bs[k][n] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < GT_K; kk += 2) {
+            int kr = kk + (lane >> 5), c = lane & 31;
+            float a0 = As[kr][wm + c], a1 = As[kr][wm + 32 + c];
+            float b0 = Bs[kr][wn + c], b1 = Bs[kr][wn + 32 + c];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // D layout: lane -> column j = lane & 31, rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int m = m0 + wm + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                int n = n0 + wn + 32 * b + (lane & 31);
+                if (m < M && n < ntot) G[(size_t)m * ntot + n] = acc[a][b][r];
+            }
+}
+
+extern "C" int nf_cconv_transform(const float* A, int M, int cin, int cout, int relu, const float* kernel,
+                                  const float* dense_w, float* G, nf_stream_t stream)
+{
+    NF_CHECK_ARG(A && kernel && dense_w && G, "null pointer");
+    NF_CHECK_ARG(cin >= 1 && cout >= 1, "bad channel counts");
+    if (M <= 0) return NF_OK;
+    int ntot = 65 * cout;
+    dim3 grid((ntot + GT_N - 1) / GT_N, (M + GT_M - 1) / GT_M);
+    hipLaunchKernelGGL(k_cconv_gemm, grid, dim3(256), 0, (hipStream_t)stream, A, M, cin, cout, relu, kernel, dense_w, G);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// gather:  y[i][co] = sum_pairs sum_corners pw * G[j][cell*Cout + co] + G[i][64*Cout + co]
+//                     + bias_conv[co] + bias_dense[co] (+ residual[i][co])
+// one wave per output point; the row's (j, 8 cells, 8 weights) are staged through LDS 64 entries
+// at a time, then every lane walks them for its output channel(s).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_cconv_gather(const float* __restrict__ G, int cout,
+                                                      const int64_t* __restrict__ row_splits,
+                                                      const int32_t* __restrict__ nbr, const float* __restrict__ pw,
+                                                      const uint8_t* __restrict__ pc, const float* __restrict__ bias_c,
+                                                      const float* __restrict__ bias_d, const float* __restrict__ residual,
+                                                      int n_out, float* __restrict__ out)
+{
+    __shared__ int s_j[4][64];
+    __shared__ float s_w[4][64 * 8];
+    __shared__ int s_c[4][64 * 8];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int ntot = 65 * cout;
+    // lanes map to (sub, co): sub-groups split the staged entries when cout < 64
+    const int groups = cout >= 64 ? 1 : (64 / cout >= 1 ? 64 / cout : 1);
+    const int co = lane % cout, sub = lane / cout;
+    const bool lane_on = sub < groups && cout <= 64;
+    for (int row = blockIdx.x * 4 + wv; row < n_out; row += gridDim.x * 4) {
+        float acc = 0.f;
+        int64_t s = row_splits[row], e = row_splits[row + 1];
+        for (int64_t base = s; base < e; base += 64) {
+            int cnt = (int)((e - base) < 64 ? (e - base) : 64);
+            if (lane < cnt) {
+                int64_t p = base + lane;
+                s_j[wv][lane] = nbr[p];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { s_w[wv][lane * 8 + k] = pw[p * 8 + k]; s_c[wv][lane * 8 + k] = pc[p * 8 + k]; }
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): LDS writes visible wave-wide
+            if (lane_on)
+                for (int t = sub; t < cnt; t += groups) {
+                    const float* gr = G + (size_t)s_j[wv][t] * ntot + co;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc += s_w[wv][t * 8 + k] * gr[s_c[wv][t * 8 + k] * cout];
+                }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // reduce the sub-groups (lanes with equal co)
+        if (groups > 1) {
+            // gather partial sums through LDS (cout need not be a power of two, e.g. 3)
+            s_w[wv][lane] = lane_on ? acc : 0.f;
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            if (lane < cout) {
+                float t = 0.f;
+                for (int g2 = 0; g2 < groups; ++g2) t += s_w[wv][g2 * cout + lane];
+                acc = t;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (lane < cout) {
+            float v = acc + G[(size_t)row * ntot + 64 * cout + lane] + bias_c[lane] + bias_d[lane];
+            if (residual) v += residual[(size_t)row * cout + lane];
+            out[(size_t)row * cout + lane] = v;
+        }
+    }
+}
+
+extern "C" int nf_cconv_gather(const float* G, int cout, const int64_t* row_splits, const int32_t* nbr,
+                               const float* pair_w, const uint8_t* pair_cell, const float* bias_conv,
+                               const float* bias_dense, const float* residual, int n_out, float* out, nf_stream_t stream)
+{
+    NF_CHECK_ARG(G && row_splits && bias_conv && bias_dense && out, "null pointer");
+    NF_CHECK_ARG(cout >= 1 && cout <= 64, "cout must be in [1,64]");
+    if (n_out <= 0) return NF_OK;
+    int blocks = (n_out + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_cconv_gather, dim3(blocks), dim3(256), 0, (hipStream_t)stream, G, cout, row_splits, nbr, pair_w,
+                       pair_cell, bias_conv, bias_dense, residual, n_out, out);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}

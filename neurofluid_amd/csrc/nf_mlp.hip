@@ -279,11 +279,13 @@ __device__ __forceinline__ void init_bias(f32x16 (&acc)[NB], const float* __rest
 
 // Opaque copy of a pointer: stops LICM from hoisting the (loop-invariant) head-weight loads out of
 // the persistent tile loop, where they would cost hundreds of live registers.
-template <typename T>
-__device__ __forceinline__ T* launder(T* p)
+// (An opaque zero OFFSET rather than an opaque pointer: laundering the pointer itself drops its
+// global address space and turns every load into flat_load + vmcnt(0)/lgkmcnt(0) waits.)
+__device__ __forceinline__ int opaque_zero()
 {
-    asm volatile("" : "+s"(p));
-    return p;
+    int z = 0;
+    asm volatile("" : "+s"(z));
+    return z;
 }
 
 // row-major save of a fragment (training): feature f of sample `row` -> dst[row*stride + f]
@@ -312,8 +314,8 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(NfMlpLayout L, const float* __r
     const int Q = L.qx + L.qd;
 
     for (int tile = gwave; tile < ntiles; tile += nwaves) {
-        packed = launder(packed);
-        const f32x4* P4 = (const f32x4*)packed;
+        const float* __restrict__ pk = packed + opaque_zero();
+        const f32x4* P4 = (const f32x4*)pk;
         const f32x4* xt = (const f32x4*)X + (size_t)tile * Q * 64 + lane;
         const int row = tile * 32 + j;
         float* arow = SAVE ? acts + (size_t)(row < nrows ? row : 0) * NF_ACT_STRIDE : nullptr;
@@ -323,7 +325,7 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(NfMlpLayout L, const float* __r
 #pragma unroll 1
         for (int l = 0; l < 9; ++l) {
             if (l == 8) {  // sigma head reads h8 before it is overwritten by xyz_encoding_final
-                const float* ws_ = packed + L.off_wsig;
+                const float* ws_ = pk + L.off_wsig;
                 float part = 0.f;
 #pragma unroll
                 for (int b = 0; b < 8; ++b)
@@ -332,9 +334,9 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(NfMlpLayout L, const float* __r
                         const float w0 = ws_[(b * 16 + r) * 2], w1 = ws_[(b * 16 + r) * 2 + 1];
                         part += act[b][r] * (h ? w1 : w0);
                     }
-                sigma = part + __shfl_xor(part, 32, 64) + packed[L.off_bsig];
+                sigma = part + __shfl_xor(part, 32, 64) + pk[L.off_bsig];
             }
-            init_bias<8>(acc, packed + L.off_b[l], h);
+            init_bias<8>(acc, pk + L.off_b[l], h);
             if (L.off_x[l] >= 0) kloop_x8(P4 + (L.off_x[l] >> 2) + lane, xt, L.qx, acc);
             if (l > 0) kloop_act8(P4 + (L.off_h[l] >> 2) + lane, act, acc);
             if (l < 8) {
@@ -351,7 +353,7 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(NfMlpLayout L, const float* __r
 
         // view branch: dir_encoding = relu(W_dir [final | dir feats] + b)
         f32x16 hd[4];
-        init_bias<4>(hd, packed + L.off_bdir, h);
+        init_bias<4>(hd, pk + L.off_bdir, h);
         kloop_act4(P4 + (L.off_dir_h >> 2) + lane, act, hd);
         kloop_x4(P4 + (L.off_dir_x >> 2) + lane, xt + L.qx * 64, L.qd, hd);
 #pragma unroll
@@ -361,7 +363,7 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(NfMlpLayout L, const float* __r
         if (SAVE && row < nrows) save_frag<4>(hd, arow + 9 * 256, h);
 
         // rgb head
-        const float* wr = packed + L.off_wrgb;
+        const float* wr = pk + L.off_wrgb;
         float c0 = 0.f, c1 = 0.f, c2 = 0.f;
 #pragma unroll
         for (int b = 0; b < 4; ++b)
@@ -374,7 +376,7 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(NfMlpLayout L, const float* __r
                 c2 += v * (h ? wr[256 + k + 1] : wr[256 + k]);
             }
         c0 += __shfl_xor(c0, 32, 64); c1 += __shfl_xor(c1, 32, 64); c2 += __shfl_xor(c2, 32, 64);
-        c0 += packed[L.off_brgb]; c1 += packed[L.off_brgb + 1]; c2 += packed[L.off_brgb + 2];
+        c0 += pk[L.off_brgb]; c1 += pk[L.off_brgb + 1]; c2 += pk[L.off_brgb + 2];
         if (h == 0 && row < nrows) {
             float4 o;
             o.x = 1.f / (1.f + expf(-c0)); o.y = 1.f / (1.f + expf(-c1)); o.z = 1.f / (1.f + expf(-c2)); o.w = sigma;

@@ -1,0 +1,208 @@
+"""Host-side mirror of /root/reference/models/transmodel.py (ParticleNet :14-163) and of the Open3D
+``ml3d.layers.ContinuousConv`` objects it constructs (:79-98).
+
+Parameter names/shapes follow Open3D so released checkpoints load: ``convX.kernel`` (4,4,4,Cin,Cout),
+``convX.bias`` (Cout), ``convX.offset`` (3, buffer), ``denseX.weight/bias``, buffer ``gravity``.
+The arithmetic runs in libneurofluid_hip (nf_cconv.hip); the fluid<->fluid neighbour search and the
+per-pair interpolation data are computed ONCE per step and shared by all layers (the reference
+rebuilds them in each of its five convs).
+"""
+import ctypes
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+from ._lib import check, ptr
+
+
+class ContinuousConv(nn.Module):
+    """Parameter container + standalone forward with the Open3D layer contract
+    ``__call__(inp_features, inp_positions, out_positions, extents)``; exposes ``.nns`` afterwards."""
+
+    def __init__(self, kernel_size, in_channels, filters, activation=None, interpolation='linear',
+                 coordinate_mapping='ball_to_cube_volume_preserving', normalize=False, window_function=None,
+                 radius_search_ignore_query_points=True, use_bias=True, align_corners=True, **kwargs):
+        super().__init__()
+        if list(kernel_size) != [4, 4, 4] or interpolation != 'linear' or normalize or not align_corners or \
+                coordinate_mapping != 'ball_to_cube_volume_preserving' or activation is not None or not use_bias:
+            raise NotImplementedError("only the configuration used by models/transmodel.py:86-95 is implemented")
+        self.in_channels, self.filters = in_channels, filters
+        self.use_window = window_function is not None
+        self.ignore_query_points = radius_search_ignore_query_points
+        self.kernel = nn.Parameter(torch.empty(4, 4, 4, in_channels, filters).uniform_(-0.05, 0.05))
+        self.bias = nn.Parameter(torch.zeros(filters))
+        self.register_buffer('offset', torch.zeros(3))
+        self.nns = None
+
+    def forward(self, inp_features, inp_positions, out_positions, extents):
+        extent = float(extents)
+        radius = 0.5 * extent
+        idx, rs, d2 = ops.fixed_radius_search(inp_positions, out_positions, radius, self.ignore_query_points)
+        self.nns = SimpleNamespace(neighbors_index=idx, neighbors_row_splits=rs, neighbors_distance=d2)
+        pw, pc = cconv_pairs(inp_positions, out_positions, rs, idx, d2, extent, self.use_window)
+        zero_w = torch.zeros(self.filters, self.in_channels, device=inp_features.device)
+        zero_b = torch.zeros(self.filters, device=inp_features.device)
+        return cconv_layer(inp_features, self.kernel, self.bias, zero_w, zero_b, rs, idx, pw, pc, relu=False)
+
+
+# ------------------------------------------------------------------------------------------------
+def cconv_pairs(inp_pos, out_pos, row_splits, nbr, d2, extent, use_window=True):
+    lib = _lib.load()
+    nnz = nbr.shape[0]
+    pw = torch.empty(max(nnz, 1) * 8, dtype=torch.float32, device=inp_pos.device)
+    pc = torch.empty(max(nnz, 1) * 8, dtype=torch.uint8, device=inp_pos.device)
+    check(lib.nf_cconv_pairs(ptr(inp_pos), ptr(out_pos), ptr(row_splits), ptr(nbr), ptr(d2), out_pos.shape[0],
+                             float(extent), int(use_window), ptr(pw), ptr(pc), _lib.stream()), "nf_cconv_pairs")
+    return pw, pc
+
+
+def cconv_layer(x, kernel, bias, dense_w, dense_b, row_splits, nbr, pw, pc, relu, residual=None):
+    """y = cconv(act(x)) + Linear(act(x)) (+ residual): transform GEMM + gather."""
+    lib = _lib.load()
+    x = x.detach().contiguous().float()
+    M, cin = x.shape
+    cout = kernel.shape[-1]
+    n_out = row_splits.shape[0] - 1
+    G = torch.empty(M, 65 * cout, dtype=torch.float32, device=x.device)
+    st = _lib.stream()
+    check(lib.nf_cconv_transform(ptr(x), M, cin, cout, int(relu), ptr(kernel.detach().contiguous()),
+                                 ptr(dense_w.detach().contiguous()), ptr(G), st), "nf_cconv_transform")
+    y = torch.empty(n_out, cout, dtype=torch.float32, device=x.device)
+    check(lib.nf_cconv_gather(ptr(G), cout, ptr(row_splits), ptr(nbr), ptr(pw), ptr(pc), ptr(bias.detach().contiguous()),
+                              ptr(dense_b.detach().contiguous()), ptr(residual), n_out, ptr(y), st), "nf_cconv_gather")
+    return y
+
+
+class ParticleNet(nn.Module):
+    def __init__(self, kernel_size=[4, 4, 4], radius_scale=1.5, coordinate_mapping='ball_to_cube_volume_preserving',
+                 interpolation='linear', use_window=True, particle_radius=0.025, timestep=1 / 50,
+                 gravity=(0, -9.81, 0), other_feats_channels=0):
+        super().__init__()
+        if other_feats_channels != 0:
+            raise NotImplementedError("other_feats_channels > 0 is never used by the reference callers")
+        self.layer_channels = [32, 64, 64, 3]
+        self.coordinate_mapping, self.interpolation, self.use_window = coordinate_mapping, interpolation, use_window
+        self.kernel_size, self.radius_scale, self.particle_radius = kernel_size, radius_scale, particle_radius
+        self.filter_extent = np.float32(6 * self.radius_scale * self.particle_radius)
+        self.time_step = timestep
+        self.register_buffer('gravity', torch.FloatTensor(gravity))
+        window = (lambda r: r) if use_window else None   # marker only: the poly6 window is fused in nf_cconv_pairs
+
+        def conv(cin, cout):
+            return ContinuousConv(kernel_size=kernel_size, in_channels=cin, filters=cout, activation=None,
+                                  interpolation=interpolation, coordinate_mapping=coordinate_mapping, normalize=False,
+                                  window_function=window, radius_search_ignore_query_points=True)
+
+        self.conv0_fluid = conv(4, 32)
+        self.conv0_obstacle = conv(3, 32)
+        self.dense0_fluid = nn.Linear(4, 32)
+        torch.nn.init.xavier_uniform_(self.dense0_fluid.weight)
+        torch.nn.init.zeros_(self.dense0_fluid.bias)
+        self.convs, self.denses = [], []
+        for i in range(1, 4):
+            cin = self.layer_channels[i - 1] * (3 if i == 1 else 1)
+            cout = self.layer_channels[i]
+            setattr(self, f'dense{i}', nn.Linear(cin, cout))
+            setattr(self, f'conv{i}', conv(cin, cout))
+            self.denses.append(getattr(self, f'dense{i}'))
+            self.convs.append(getattr(self, f'conv{i}'))
+        self._box_cache = (None, None)
+        self.num_fluid_neighbors = None
+
+    # ------------------------------------------------------------------
+    def integrate_pos_vel(self, pos, vel):
+        lib = _lib.load()
+        n = pos.shape[0]
+        pos_new, vel_new = torch.empty_like(pos), torch.empty_like(vel)
+        feats = torch.empty(n, 4, dtype=torch.float32, device=pos.device)
+        g = (ctypes.c_float * 3)(*[float(v) for v in self._gravity_host()])
+        check(lib.nf_trans_integrate(ptr(pos), ptr(vel), g, float(self.time_step), n, ptr(pos_new), ptr(vel_new),
+                                     ptr(feats), _lib.stream()), "nf_trans_integrate")
+        return pos_new, vel_new, feats
+
+    def _gravity_host(self):
+        if getattr(self, "_g_host", None) is None or self._g_version != self.gravity._version:
+            self._g_host = self.gravity.detach().cpu().tolist()
+            self._g_version = self.gravity._version
+        return self._g_host
+
+    def _box_grid(self, box):
+        key = (box.data_ptr(), box._version, box.shape[0])
+        if self._box_cache[0] != key:
+            self._box_cache = (key, ops.build_grid(box, 0.5 * float(self.filter_extent)))
+        return self._box_cache[1]
+
+    def update_pos_vel(self, pos, pos_new, y3):
+        lib = _lib.load()
+        pc, vc = torch.empty_like(pos), torch.empty_like(pos)
+        check(lib.nf_trans_update(ptr(pos), ptr(pos_new), ptr(y3), 1.0 / 128, float(self.time_step), pos.shape[0], ptr(pc),
+                                  ptr(vc), _lib.stream()), "nf_trans_update")
+        return pc, vc
+
+    # ------------------------------------------------------------------
+    def forward(self, pos, vel, box, box_feats, feats=None, fixed_radius_search_hash_table=None):
+        if feats is not None:
+            raise NotImplementedError("other feats are never passed by the reference callers")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            from .autograd_bwd import particle_net_with_grad
+            return particle_net_with_grad(self, pos, vel, box, box_feats)
+        with torch.no_grad():
+            return self._forward_impl(pos, vel, box, box_feats)[:3]
+
+    def _forward_impl(self, pos, vel, box, box_feats, keep=False):
+        lib = _lib.load()
+        st = _lib.stream()
+        pos = pos.detach().contiguous().float()
+        vel = vel.detach().contiguous().float()
+        box = box.detach().contiguous().float()
+        box_feats = box_feats.detach().contiguous().float()
+        n = pos.shape[0]
+        extent = float(self.filter_extent)
+        radius = 0.5 * extent
+        pos_new, vel_new, fluid_feats = self.integrate_pos_vel(pos, vel)
+        # B2: one fluid->fluid and one box->fluid search per step (device-side scans), one sync for nnz
+        bbox = self._scene_bbox(box)
+        fgrid = ops.build_grid(pos_new, radius, bbox)
+        bgrid = self._box_grid(box)
+        f_rs = ops.radius_row_splits(fgrid, pos_new, radius, True)
+        b_rs = ops.radius_row_splits(bgrid, pos_new, radius, True)
+        nnz_f, nnz_b = torch.stack([f_rs[-1], b_rs[-1]]).tolist()
+        f_idx, f_d2 = ops.radius_fill(fgrid, pos_new, radius, f_rs, nnz_f, True)
+        b_idx, b_d2 = ops.radius_fill(bgrid, pos_new, radius, b_rs, nnz_b, True)
+        f_pw, f_pc = cconv_pairs(pos_new, pos_new, f_rs, f_idx, f_d2, extent, self.use_window)
+        b_pw, b_pc = cconv_pairs(box, pos_new, b_rs, b_idx, b_d2, extent, self.use_window)
+        self.conv0_fluid.nns = SimpleNamespace(neighbors_index=f_idx[:nnz_f], neighbors_row_splits=f_rs,
+                                               neighbors_distance=f_d2[:nnz_f])
+        # layer 0: [obstacle | fluid | dense] -> (n, 96)   (:116-120)
+        a0 = torch.empty(n, 96, dtype=torch.float32, device=pos.device)
+        c0o, c0f, d0 = self.conv0_obstacle, self.conv0_fluid, self.dense0_fluid
+        check(lib.nf_cconv_small(ptr(box_feats), 3, ptr(b_rs), ptr(b_idx), ptr(b_pw), ptr(b_pc), ptr(c0o.kernel.detach()),
+                                 ptr(c0o.bias.detach()), n, ptr(a0), 96, 0, None, None, None, 0, st), "conv0_obstacle")
+        check(lib.nf_cconv_small(ptr(fluid_feats), 4, ptr(f_rs), ptr(f_idx), ptr(f_pw), ptr(f_pc), ptr(c0f.kernel.detach()),
+                                 ptr(c0f.bias.detach()), n, ptr(a0), 96, 32, ptr(fluid_feats), ptr(d0.weight.detach()),
+                                 ptr(d0.bias.detach()), 64, st), "conv0_fluid")
+        ans = [a0]
+        for conv, dense in zip(self.convs, self.denses):
+            prev = ans[-1]
+            res = prev if dense.out_features == prev.shape[-1] else None
+            ans.append(cconv_layer(prev, conv.kernel, conv.bias, dense.weight, dense.bias, f_rs, f_idx, f_pw, f_pc,
+                                   relu=True, residual=res))
+        self.num_fluid_neighbors = (f_rs[1:] - f_rs[:-1]).to(torch.float32)   # reduce_subarrays_sum(ones) (:135-138)
+        self.pos_correction = ans[-1] * (1.0 / 128)
+        pos_c, vel_c = self.update_pos_vel(pos, pos_new, ans[-1])
+        aux = dict(ans=ans, f=(f_rs, f_idx, f_pw, f_pc), b=(b_rs, b_idx, b_pw, b_pc), pos_new=pos_new, vel_new=vel_new,
+                   fluid_feats=fluid_feats) if keep else None
+        return pos_c, vel_c, self.num_fluid_neighbors, aux
+
+    def _scene_bbox(self, box):
+        """Static grid bounds from the container (cached: no per-step sync); particles that leave it are
+        clamped into border cells, which keeps the search exact (include/neurofluid_hip.h)."""
+        key = (box.data_ptr(), box._version, box.shape[0])
+        if getattr(self, "_bbox_key", None) != key:
+            lo, hi = torch.aminmax(box, dim=0)
+            self._bbox = tuple((lo - 0.5).tolist()) + tuple((hi + 0.5).tolist())
+            self._bbox_key = key
+        return self._bbox

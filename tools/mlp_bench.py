@@ -1,0 +1,28 @@
+"""Micro-benchmark of the MFMA MLP kernel on synthetic feature rows (dev tool)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from oracle import render_oracle as ro
+from neurofluid_amd import ops, _lib
+from neurofluid_amd._lib import ptr, check
+
+dev = torch.device("cuda:0")
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 32768 * 10
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+st = ro.deterministic_nerf_state()
+names = ops.NERF_LAYER_NAMES
+W = [st[f"nerf_coarse.{k}.weight"].to(dev) for k in names]
+B = [st[f"nerf_coarse.{k}.bias"].to(dev) for k in names]
+packed = ops.pack_nerf(W, B, 198, 54)
+lib = _lib.load()
+X = torch.rand((n + 31) // 32 * 32 * 256, device=dev) * 2 - 1
+n_rows = torch.tensor([n], dtype=torch.int32, device=dev)
+row_sample = torch.arange(n, dtype=torch.int32, device=dev)
+out = torch.zeros(n, 4, device=dev)
+for it in range(iters):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    check(lib.nf_nerf_mlp_fwd(ptr(packed), 198, 54, ptr(X), ptr(n_rows), n, ptr(row_sample), ptr(out), None, _lib.stream()))
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    print(f"iter {it}: rows {n} {ms:.3f} ms  {n*1331968/ms/1e9:.1f} TFLOP/s")

@@ -15,6 +15,11 @@ from . import _lib
 from ._lib import check, ptr
 
 
+# bench.py sets PROFILE = {"mlp": [], "rows": []} to collect (start, end) HIP events around every MLP launch
+# (recorded on the stream the kernel is launched on) and the executed-row counts.
+PROFILE = None
+
+
 def _require_cuda(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
@@ -214,8 +219,15 @@ def render_pass(grid, particles, rays, z, z_table, S, radius, K, enc_flags, use_
                                  ptr(ro), ptr(b.row_sample), ptr(b.row_nbr), ptr(b.n_rows), max_rows, ptr(b.X), st),
           "nf_render_features")
     b.acts = torch.empty(max(max_rows, 1) * 2432, dtype=torch.float32, device=dev) if save_acts else None
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(lib.nf_nerf_mlp_fwd(ptr(packed), cx, cd, ptr(b.X), ptr(b.n_rows), max_rows, ptr(b.row_sample),
                               ptr(b.rgbsigma), ptr(b.acts), st), "nf_nerf_mlp_fwd")
+    if PROFILE is not None:
+        e1.record()
+        PROFILE["mlp"].append((e0, e1))
+        PROFILE["rows"].append(max_rows)
     b.rgb = torch.empty(R, 3, dtype=torch.float32, device=dev)
     b.depth = torch.empty(R, dtype=torch.float32, device=dev)
     b.opacity = torch.empty(R, dtype=torch.float32, device=dev)

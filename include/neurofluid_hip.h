@@ -110,11 +110,29 @@ int nf_nerf_pack(const nf_nerf_params_t* params /*[host]*/, int cx, int cd, floa
 int nf_nerf_mlp_fwd(const float* packed, int cx, int cd, const float* X, const int32_t* n_rows, int max_rows,
                     const int32_t* row_sample, float* rgbsigma, float* acts /*or NULL*/, nf_stream_t stream);
 
+/* A12 (MLP part): data gradient of the MLP on fp32 MFMA with transposed packed weights.
+ * Reads d_rgbsigma[row_sample[row]] (gradient w.r.t. the MLP output (rgb after sigmoid, sigma)) and the
+ * activations saved by nf_nerf_mlp_fwd; writes, per row, the pre-activation gradients of every layer:
+ * dpre[row][NF_DPRE_STRIDE] = dpre_1..8 (8*256) | dpre_final (256) | dpre_dir (128) | dz_rgb (3) | dsigma (1).
+ * Weight gradients are then plain GEMMs dW_l = dpre_l^T * input_l over all rows. */
+#define NF_DPRE_STRIDE 2436
+size_t nf_nerf_packed_bwd_floats(void);
+int nf_nerf_pack_bwd(const nf_nerf_params_t* params /*[host]*/, int cx, int cd, float* packed_t, nf_stream_t stream);
+int nf_nerf_mlp_bwd(const float* packed, const float* packed_t, int cx, int cd, const float* acts,
+                    const int32_t* n_rows, int max_rows, const int32_t* row_sample, const float* rgbsigma,
+                    const float* d_rgbsigma, float* dpre, nf_stream_t stream);
+
 /* A8: alpha compositing (models/renderer.py:182-208), one thread per ray, sequential products. */
 int nf_composite_fwd(const float* rgbsigma /*R*S*4*/, const float* z, const float* z_table, const float* rays,
                      const uint8_t* mask, int R, int S, int white_bg,
                      float* rgb /*R*3*/, float* depth /*R*/, float* opacity /*R*/, float* weights /*R*S*/,
                      float* mask_sum /*R*/, nf_stream_t stream);
+
+/* A12 (compositing part): d_rgbsigma (R*S*4) from d_rgb (R*3); scratch = R*S floats.  Depth/opacity are
+ * not differentiated (the reference losses use rgb0/rgb1 only: trainer/trainer_renderer.py:127-130). */
+int nf_composite_bwd(const float* rgbsigma, const float* z, const float* z_table, const float* rays,
+                     const float* d_rgb, int R, int S, int white_bg, float* scratch /*R*S*/,
+                     float* d_rgbsigma /*R*S*4*/, nf_stream_t stream);
 
 /* A9: ImportanceSampling(det=True) (utils/ray_utils.py:178-229): z1 = sort(cat(z0, inverse-CDF samples)).
  * u_table = torch.linspace(0,1,N_imp) supplied by the caller (bit-identical to the reference). */

@@ -39,6 +39,11 @@ PROTOTYPES = {
     "nf_composite_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_void_p]),
     "nf_importance_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "nf_composite_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "nf_nerf_packed_bwd_floats": (c_size_t, []),
+    "nf_nerf_pack_bwd": (c_int, [ctypes.POINTER(NerfParams), c_int, c_int, c_void_p, c_void_p]),
+    "nf_nerf_mlp_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                c_void_p, c_void_p]),
     "nf_trans_integrate": (c_int, [c_void_p, c_void_p, ctypes.POINTER(c_float), c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nf_trans_update": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p]),
     "nf_cconv_pairs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p]),

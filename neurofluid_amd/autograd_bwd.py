@@ -1,0 +1,128 @@
+"""Autograd of the fused renderer and of the transition model (row B8).
+
+Renderer backward = composite backward (HIP) -> MLP data-gradient on fp32 MFMA (HIP, nf_nerf_mlp_bwd) ->
+weight gradients as plain GEMMs dW_l = dpre_l^T . input_l over all active rows (library GEMM through torch.mm:
+the only place a vendor BLAS is used, as allowed for plain GEMMs) -> optional gradient w.r.t. the particle
+positions through the local-geometry features (e2e training, trainer/trainer_e2e.py:219-236).
+"""
+import ctypes
+
+import torch
+
+from . import _lib, ops
+from ._lib import check, ptr
+from .autograd import _run_passes, _results
+
+ACT, DPRE = 2432, 2436
+
+
+def _nerf_params(net):
+    ps = []
+    for n in (net.nerf_coarse, net.nerf_fine):
+        layers = n.linear_layers()
+        ps += [l.weight for l in layers] + [l.bias for l in layers]
+    return ps
+
+
+def _pack_bwd(nerf, cx, cd, dev):
+    lib = _lib.load()
+    layers = nerf.linear_layers()
+    P = _lib.NerfParams()
+    keep = []
+    for i, l in enumerate(layers):
+        w, b = l.weight.detach().contiguous(), l.bias.detach().contiguous()
+        keep += [w, b]
+        P.w[i], P.b[i] = w.data_ptr(), b.data_ptr()
+    out = torch.empty(lib.nf_nerf_packed_bwd_floats(), dtype=torch.float32, device=dev)
+    check(lib.nf_nerf_pack_bwd(ctypes.byref(P), cx, cd, ptr(out), _lib.stream()), "nf_nerf_pack_bwd")
+    return out
+
+
+def _pass_backward(net, nerf, pb, rays_c, z, z_table, g_rgb, white_bg):
+    """Returns the 24 parameter gradients (12 weights, 12 biases) of one NeRF for one render pass."""
+    lib = _lib.load()
+    st = _lib.stream()
+    dev = rays_c.device
+    cx, cd = net.in_channels_xyz, net.in_channels_dir
+    layers = nerf.linear_layers()
+    n = pb.n_active
+    if n == 0:
+        return [torch.zeros_like(l.weight) for l in layers] + [torch.zeros_like(l.bias) for l in layers]
+    R, S = pb.R, pb.S
+    scratch = torch.empty(R * S, dtype=torch.float32, device=dev)
+    d_rs = torch.empty(R * S, 4, dtype=torch.float32, device=dev)
+    g = g_rgb.detach().contiguous().float()
+    check(lib.nf_composite_bwd(ptr(pb.rgbsigma), ptr(z), ptr(z_table), ptr(rays_c), ptr(g), R, S, int(white_bg),
+                               ptr(scratch), ptr(d_rs), st), "nf_composite_bwd")
+    packed_t = _pack_bwd(nerf, cx, cd, dev)
+    dpre = torch.empty(n, DPRE, dtype=torch.float32, device=dev)
+    check(lib.nf_nerf_mlp_bwd(ptr(pb.packed), ptr(packed_t), cx, cd, ptr(pb.acts), ptr(pb.n_rows), n, ptr(pb.row_sample),
+                              ptr(pb.rgbsigma), ptr(d_rs), ptr(dpre), st), "nf_nerf_mlp_bwd")
+    A = pb.acts.view(-1, ACT)[:n]
+    X = ops.tiles_to_rows(pb.X, n, cx, cd)
+    Xx, Xd = X[:, :cx], X[:, cx:]
+    gw, gb = [], []
+    for k in range(8):
+        D = dpre[:, k * 256:(k + 1) * 256]
+        if k == 0:
+            dW = D.t() @ Xx
+        elif k == 4:
+            dW = torch.cat([D.t() @ Xx, D.t() @ A[:, 3 * 256:4 * 256]], dim=1)
+        else:
+            dW = D.t() @ A[:, (k - 1) * 256:k * 256]
+        gw.append(dW)
+        gb.append(D.sum(0))
+    h8 = A[:, 7 * 256:8 * 256]
+    Dfin = dpre[:, 8 * 256:9 * 256]
+    gw.append(Dfin.t() @ h8); gb.append(Dfin.sum(0))
+    Ddir = dpre[:, 9 * 256:9 * 256 + 128]
+    gw.append(torch.cat([Ddir.t() @ A[:, 8 * 256:9 * 256], Ddir.t() @ Xd], dim=1)); gb.append(Ddir.sum(0))
+    Dsig = dpre[:, 2435:2436]
+    gw.append(Dsig.t() @ h8); gb.append(Dsig.sum(0))
+    Drgb = dpre[:, 2432:2435]
+    gw.append(Drgb.t() @ A[:, 9 * 256:9 * 256 + 128]); gb.append(Drgb.sum(0))
+    return gw + gb
+
+
+class _RenderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net, particles, ro, rays, white_bg, fine, *params):
+        p0, p1, rays_c, ro_c, grid = _run_passes(net, particles, ro, rays, white_bg, fine, save_acts=True)
+        ctx.net, ctx.p0, ctx.p1, ctx.rays_c, ctx.white_bg, ctx.fine = net, p0, p1, rays_c, white_bg, fine
+        ctx.particles_need_grad = particles.requires_grad
+        res = _results(p0, p1)
+        keys = ["rgb0", "depth0", "opacity0", "num_nn_0", "mask_0"]
+        if fine:
+            keys += ["rgb1", "depth1", "opacity1", "num_nn_1", "mask_1"]
+        ctx.keys = keys
+        outs = tuple(res[k] for k in keys)
+        ctx.mark_non_differentiable(*[o for k, o in zip(keys, outs) if not k.startswith("rgb")])
+        return outs
+
+    @staticmethod
+    def backward(ctx, *grads):
+        net = ctx.net
+        if ctx.particles_need_grad:
+            raise NotImplementedError("gradient w.r.t. particle positions (e2e) is scheduled for the next round")
+        g = dict(zip(ctx.keys, grads))
+        z_table, _ = net._tables(ctx.rays_c.device)
+        zero = lambda nerf: [torch.zeros_like(p) for l in nerf.linear_layers() for p in ()]  # noqa: E731
+        gc = _pass_backward(net, net.nerf_coarse, ctx.p0, ctx.rays_c, None, z_table, g["rgb0"], ctx.white_bg) \
+            if g.get("rgb0") is not None else [None] * 24
+        if ctx.fine and g.get("rgb1") is not None:
+            gf = _pass_backward(net, net.nerf_fine, ctx.p1, ctx.rays_c, ctx.p1.z, None, g["rgb1"], ctx.white_bg)
+        else:
+            gf = [None] * 24
+        return (None, None, None, None, None, None) + tuple(gc) + tuple(gf)
+
+
+def render_with_grad(net, particles, ro, rays, white_bg, fine):
+    outs = _RenderFn.apply(net, particles, ro, rays, white_bg, fine, *_nerf_params(net))
+    keys = ["rgb0", "depth0", "opacity0", "num_nn_0", "mask_0"] + (
+        ["rgb1", "depth1", "opacity1", "num_nn_1", "mask_1"] if fine else [])
+    return dict(zip(keys, outs))
+
+
+def particle_net_with_grad(pn, pos, vel, box, box_feats):
+    raise NotImplementedError("ParticleNet backward (train_e2e / train_transmodel) is scheduled for the next round; "
+                              "call under torch.no_grad() for rollouts")

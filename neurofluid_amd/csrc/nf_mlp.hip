@@ -405,3 +405,184 @@ extern "C" int nf_nerf_mlp_fwd(const float* packed, int cx, int cd, const float*
     NF_CHECK_LAUNCH();
     return NF_OK;
 }
+
+// ================================================================================================
+// backward (data gradient) — same register-resident structure, transposed weights
+// ================================================================================================
+// dpre buffer per row: [dpre1..dpre8 (8*256) | dpre_final (256) | dpre_dir (128) | dz_rgb (3) | dsigma (1)]
+struct NfMlpLayoutT {
+    int off_h[9];   // l = 1..8: W_l^T hidden part [128 steps][2][64][4]   (index 0 unused)
+    int off_dir;    // W_dir[:, :256]^T  [64 steps][2][64][4]
+    int total;
+};
+
+static NfMlpLayoutT mlp_layout_t()
+{
+    NfMlpLayoutT T;
+    int o = 0;
+    T.off_h[0] = -1;
+    for (int l = 1; l < 9; ++l) { T.off_h[l] = o; o += 128 * 512; }
+    T.off_dir = o; o += 64 * 512;
+    T.total = o;
+    return T;
+}
+
+extern "C" size_t nf_nerf_packed_bwd_floats(void) { return (size_t)mlp_layout_t().total; }
+
+__global__ void k_mlp_pack_bwd(NfMlpLayoutT T, int cx, int cd, NfNerfPtrs P, float* __restrict__ out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T.total) return;
+    if (i >= T.off_dir) {
+        int k = i - T.off_dir, e = k & 3, lane = (k >> 2) & 63, g = (k >> 8) & 1, s = k >> 9;
+        int o = frag_feature(s >> 4, s & 15, lane >> 5);          // dir hidden unit (K index), < 128
+        int in = 32 * (4 * g + e) + (lane & 31);                   // final feature (output of this GEMM)
+        out[i] = P.w[9][(size_t)o * (256 + cd) + in];
+        return;
+    }
+    for (int l = 8; l >= 1; --l)
+        if (i >= T.off_h[l]) {
+            int k = i - T.off_h[l], e = k & 3, lane = (k >> 2) & 63, g = (k >> 8) & 1, s = k >> 9;
+            int o = frag_feature(s >> 4, s & 15, lane >> 5);
+            int in = 32 * (4 * g + e) + (lane & 31);
+            int in_dim = (l == 4) ? cx + 256 : 256;
+            int col = (l == 4) ? cx + in : in;
+            out[i] = P.w[l][(size_t)o * in_dim + col];
+            return;
+        }
+}
+
+extern "C" int nf_nerf_pack_bwd(const nf_nerf_params_t* params, int cx, int cd, float* packed_t, nf_stream_t stream)
+{
+    NF_CHECK_ARG(params && packed_t, "null pointer");
+    NfNerfPtrs P;
+    for (int i = 0; i < 12; ++i) { P.w[i] = params->w[i]; P.b[i] = params->b[i]; }
+    NfMlpLayoutT T = mlp_layout_t();
+    hipLaunchKernelGGL(k_mlp_pack_bwd, dim3((T.total + 255) / 256), dim3(256), 0, (hipStream_t)stream, T, cx, cd, P, packed_t);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+template <int NB>
+__device__ __forceinline__ void zero_frag(f32x16 (&acc)[NB])
+{
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+}
+
+// K-steps over a 4-block (128-feature) fragment, 8 output blocks
+__device__ __forceinline__ void kloop_act8_from4(const f32x4* __restrict__ p, const f32x16 (&act)[4], f32x16 (&acc)[8])
+{
+    f32x4 a0 = p[0], a1 = p[64];
+    f32x4 b0 = p[128], b1 = p[192];
+#pragma unroll
+    for (int s = 0; s < 64; s += 2) {
+        f32x4 c0 = a0, c1 = a1, d0 = b0, d1 = b1;
+        if (s + 2 < 64) { c0 = p[(s + 2) * 128]; c1 = p[(s + 2) * 128 + 64]; }
+        step8(a0, a1, act[s >> 4][s & 15], acc);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 3 < 64) { d0 = p[(s + 3) * 128]; d1 = p[(s + 3) * 128 + 64]; }
+        step8(b0, b1, act[(s + 1) >> 4][(s + 1) & 15], acc);
+        __builtin_amdgcn_sched_barrier(0);
+        a0 = c0; a1 = c1; b0 = d0; b1 = d1;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_mlp_bwd(NfMlpLayout L, NfMlpLayoutT T, const float* __restrict__ packed,
+                                                 const float* __restrict__ packed_t, const float* __restrict__ acts,
+                                                 const int* __restrict__ n_rows, int max_rows,
+                                                 const int* __restrict__ row_sample, const float4* __restrict__ rgbsigma,
+                                                 const float4* __restrict__ d_rgbsigma, float* __restrict__ dpre)
+{
+    const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
+    const int gwave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    const int nrows = min(*n_rows, max_rows);
+    const int ntiles = (nrows + 31) >> 5;
+    for (int tile = gwave; tile < ntiles; tile += nwaves) {
+        const int z0 = opaque_zero();
+        const float* __restrict__ pk = packed + z0;
+        const f32x4* PT4 = (const f32x4*)(packed_t + z0);
+        const int row = tile * 32 + j;
+        const bool valid = row < nrows;
+        const float* arow = acts + (size_t)(valid ? row : 0) * NF_ACT_STRIDE;
+        float* drow = dpre + (size_t)(valid ? row : 0) * NF_DPRE_STRIDE;
+        float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f), g4 = o4;
+        if (valid) {
+            int sample = row_sample[row];
+            o4 = rgbsigma[sample];
+            g4 = d_rgbsigma[sample];
+        }
+        // rgb = sigmoid(z): dz = g * y (1 - y)
+        const float dz0 = g4.x * o4.x * (1.f - o4.x), dz1 = g4.y * o4.y * (1.f - o4.y), dz2 = g4.z * o4.z * (1.f - o4.z);
+        const float dsig = g4.w;
+        if (valid && h == 0) *(float4*)(drow + 2432) = make_float4(dz0, dz1, dz2, dsig);
+
+        // d(dir hidden) = W_rgb^T dz, masked by relu
+        f32x16 dd[4];
+        const float* wr = pk + L.off_wrgb;
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                f32x4 hv = *(const f32x4*)(arow + 9 * 256 + 32 * b + 8 * rq + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    int r = 4 * rq + e, k = (b * 16 + r) * 2;
+                    float v = dz0 * (h ? wr[k + 1] : wr[k]) + dz1 * (h ? wr[128 + k + 1] : wr[128 + k]) +
+                              dz2 * (h ? wr[256 + k + 1] : wr[256 + k]);
+                    dd[b][r] = hv[e] > 0.f ? v : 0.f;
+                }
+            }
+        if (valid) save_frag<4>(dd, drow + 9 * 256, h);
+
+        // d(final) = W_dir[:, :256]^T dpre_dir       (no activation on xyz_encoding_final)
+        f32x16 act[8], acc[8];
+        zero_frag<8>(acc);
+        kloop_act8_from4(PT4 + (T.off_dir >> 2) + lane, dd, acc);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) act[b] = acc[b];
+        if (valid) save_frag<8>(act, drow + 8 * 256, h);
+
+#pragma unroll 1
+        for (int l = 8; l >= 1; --l) {
+            // d(h_l) = W_l^T dpre_l  (l = 8: xyz_encoding_final, input h8)
+            zero_frag<8>(acc);
+            kloop_act8(PT4 + (T.off_h[l] >> 2) + lane, act, acc);
+            const float* ws_ = pk + L.off_wsig;
+            const float* hprev = arow + (l - 1) * 256;
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    f32x4 hv = *(const f32x4*)(hprev + 32 * b + 8 * rq + 4 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        int r = 4 * rq + e;
+                        float v = acc[b][r];
+                        if (l == 8) v += dsig * (h ? ws_[(b * 16 + r) * 2 + 1] : ws_[(b * 16 + r) * 2]);  // sigma head reads h8
+                        act[b][r] = hv[e] > 0.f ? v : 0.f;
+                    }
+                }
+            if (valid) save_frag<8>(act, drow + (l - 1) * 256, h);
+        }
+    }
+}
+
+extern "C" int nf_nerf_mlp_bwd(const float* packed, const float* packed_t, int cx, int cd, const float* acts,
+                               const int32_t* n_rows, int max_rows, const int32_t* row_sample, const float* rgbsigma,
+                               const float* d_rgbsigma, float* dpre, nf_stream_t stream)
+{
+    NF_CHECK_ARG(packed && packed_t && acts && n_rows && row_sample && rgbsigma && d_rgbsigma && dpre, "null pointer");
+    if (max_rows <= 0) return NF_OK;
+    NfMlpLayout L = mlp_layout(cx, cd);
+    NfMlpLayoutT T = mlp_layout_t();
+    int tiles = (max_rows + 31) / 32;
+    int blocks = (tiles + 3) / 4;
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(k_mlp_bwd, dim3(blocks), dim3(256), 0, (hipStream_t)stream, L, T, packed, packed_t, acts, n_rows,
+                       max_rows, row_sample, (const float4*)rgbsigma, (const float4*)d_rgbsigma, dpre);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}

@@ -445,3 +445,58 @@ extern "C" int nf_importance_sample(const float* z_table0, const float* weights0
     NF_CHECK_LAUNCH();
     return NF_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// composite backward (A12, compositing part): dL/d(rgbsigma) from dL/d(rgb).
+//   w_i = a_i T_i,  T_i = prod_{j<i} (1 - a_j + 1e-10),  a_i = 1 - exp(-delta_i relu(sigma_i))
+//   rgb = sum w_i c_i (+ 1 - sum w_i)
+// One thread per ray: forward sweep rebuilds T_i into `scratch`, reverse sweep carries
+// suffix = sum_{k>i} dL/dw_k * w_k.  (z is detached in the reference: utils/ray_utils.py:224.)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_composite_bwd(const float4* __restrict__ rgbsigma, const float* __restrict__ z,
+                                                      const float* __restrict__ z_table, const float* __restrict__ rays,
+                                                      const float* __restrict__ d_rgb, int R, int S, int white_bg,
+                                                      float* __restrict__ scratch, float4* __restrict__ d_rgbsigma)
+{
+    int r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= R) return;
+    const float* ry = rays + 6 * (size_t)r;
+    float nrm = sqrtf(ry[3] * ry[3] + ry[4] * ry[4] + ry[5] * ry[5]);
+    const float* zr = z ? z + (size_t)r * S : z_table;
+    const float g0 = d_rgb[3 * (size_t)r], g1 = d_rgb[3 * (size_t)r + 1], g2 = d_rgb[3 * (size_t)r + 2];
+    const float gsum = white_bg ? (g0 + g1 + g2) : 0.f;
+    float* Tr = scratch + (size_t)r * S;
+    float T = 1.f;
+    for (int s = 0; s < S; ++s) {
+        float delta = ((s + 1 < S) ? (zr[s + 1] - zr[s]) : 1e10f) * nrm;
+        float alpha = 1.f - expf(-delta * fmaxf(rgbsigma[(size_t)r * S + s].w, 0.f));
+        Tr[s] = T;
+        T = T * ((1.f - alpha) + 1e-10f);
+    }
+    float suffix = 0.f;
+    for (int s = S - 1; s >= 0; --s) {
+        float4 v = rgbsigma[(size_t)r * S + s];
+        float delta = ((s + 1 < S) ? (zr[s + 1] - zr[s]) : 1e10f) * nrm;
+        float e = expf(-delta * fmaxf(v.w, 0.f));
+        float alpha = 1.f - e;
+        float Ti = Tr[s];
+        float w = alpha * Ti;
+        float dw = g0 * v.x + g1 * v.y + g2 * v.z - gsum;
+        float dalpha = Ti * dw - suffix / ((1.f - alpha) + 1e-10f);
+        suffix += dw * w;
+        float dsigma = v.w > 0.f ? dalpha * delta * e : 0.f;
+        d_rgbsigma[(size_t)r * S + s] = make_float4(w * g0, w * g1, w * g2, dsigma);
+    }
+}
+
+extern "C" int nf_composite_bwd(const float* rgbsigma, const float* z, const float* z_table, const float* rays,
+                                const float* d_rgb, int R, int S, int white_bg, float* scratch, float* d_rgbsigma,
+                                nf_stream_t stream)
+{
+    NF_CHECK_ARG(rgbsigma && (z || z_table) && rays && d_rgb && scratch && d_rgbsigma, "null pointer");
+    if (R == 0) return NF_OK;
+    hipLaunchKernelGGL(k_composite_bwd, dim3((R + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const float4*)rgbsigma, z,
+                       z_table, rays, d_rgb, R, S, white_bg, scratch, (float4*)d_rgbsigma);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}

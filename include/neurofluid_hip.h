@@ -91,7 +91,8 @@ int nf_render_search(const void* grid_ws, const float* rays, const float* z, con
  * group q holds feature 8q+4h+e; pos-like features first (padded to 8*QX), then dir-like (8*QD)).
  * enc_flags: bit0 density, bit1 smoothed_pos, bit2 var, bit3 smoothed_dir (models/renderer.py:30-44). */
 int nf_render_features(const float* particles /*Np*3*/, const float* rays, const float* z, const float* z_table,
-                       int R, int S, float radius, int K, int enc_flags, const float* ro /*3*/,
+                       int R, int S, float radius, int K, int enc_flags,
+                       const float* ro /*3, or R*3 when ro_per_ray (several views batched in one call)*/, int ro_per_ray,
                        const int32_t* row_sample, const int32_t* row_nbr, const int32_t* n_rows, int max_rows,
                        float* X, nf_stream_t stream);
 int nf_render_feature_dims(int enc_flags, int* cx, int* cd, int* qx, int* qd);

@@ -227,7 +227,7 @@ __device__ __forceinline__ void emit_pe(FeatEmitter& em, const float (&x)[C])
 template <int FLAGS>
 __global__ void __launch_bounds__(128) k_features(const float* __restrict__ particles, const float* __restrict__ rays,
                                                   const float* __restrict__ z, const float* __restrict__ z_table, int S,
-                                                  float radius, int K, const float* __restrict__ ro,
+                                                  float radius, int K, const float* __restrict__ ro_base, int ro_stride,
                                                   const int* __restrict__ row_sample, const int* __restrict__ row_nbr,
                                                   const int* __restrict__ n_rows, int max_rows, float* __restrict__ X)
 {
@@ -240,6 +240,7 @@ __global__ void __launch_bounds__(128) k_features(const float* __restrict__ part
         float px[3], zv;
         sample_xyz(rays, z, z_table, S, sample, px[0], px[1], px[2], zv);
         const float* ry = rays + 6 * (size_t)(sample / S);
+        const float* ro = ro_base + (size_t)ro_stride * (sample / S);   // camera position: shared (stride 0) or per ray
         // --- A3 smoothing + A4 variance over the K slots (padded slots: nn = 0, models/renderer.py:96-109,:163-169)
         float sw = 0.f, swx = 0.f, swy = 0.f, swz = 0.f;
         float sx = 0.f, sy = 0.f, sz = 0.f;
@@ -298,9 +299,9 @@ __global__ void __launch_bounds__(128) k_features(const float* __restrict__ part
 }
 
 extern "C" int nf_render_features(const float* particles, const float* rays, const float* z, const float* z_table, int R,
-                                  int S, float radius, int K, int enc_flags, const float* ro, const int32_t* row_sample,
-                                  const int32_t* row_nbr, const int32_t* n_rows, int max_rows, float* X,
-                                  nf_stream_t stream)
+                                  int S, float radius, int K, int enc_flags, const float* ro, int ro_per_ray,
+                                  const int32_t* row_sample, const int32_t* row_nbr, const int32_t* n_rows, int max_rows,
+                                  float* X, nf_stream_t stream)
 {
     NF_CHECK_ARG(particles && rays && (z || z_table) && ro && row_sample && row_nbr && n_rows && X, "null pointer");
     NF_CHECK_ARG(enc_flags >= 0 && enc_flags < 16, "bad enc_flags");
@@ -311,7 +312,7 @@ extern "C" int nf_render_features(const float* particles, const float* rays, con
 #define NF_FEAT_CASE(F)                                                                                              \
     case F:                                                                                                          \
         hipLaunchKernelGGL(k_features<F>, dim3(blocks), dim3(128), 0, st, particles, rays, z, z_table, S, radius, K, ro, \
-                           row_sample, row_nbr, n_rows, max_rows, X);                                                \
+                           ro_per_ray ? 3 : 0, row_sample, row_nbr, n_rows, max_rows, X);                            \
         break;
     switch (enc_flags) {
         NF_FEAT_CASE(0) NF_FEAT_CASE(1) NF_FEAT_CASE(2) NF_FEAT_CASE(3) NF_FEAT_CASE(4) NF_FEAT_CASE(5) NF_FEAT_CASE(6)

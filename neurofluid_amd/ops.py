@@ -214,11 +214,13 @@ def render_pass(grid, particles, rays, z, z_table, S, radius, K, enc_flags, use_
         b.max_rows = max_rows
     b.n_active = max_rows
     tiles = (max_rows + 31) // 32
-    b.X = torch.empty(max(tiles, 1) * (qx + qd) * 256, dtype=torch.float32, device=dev)
+    rows_alloc = (max(max_rows, 1) + 8191) // 8192 * 8192      # rounded sizes keep the caching allocator hitting
+    b.X = torch.empty(rows_alloc // 32 * (qx + qd) * 256, dtype=torch.float32, device=dev)
     check(lib.nf_render_features(ptr(particles), ptr(rays), ptr(z), ptr(z_table), R, S, float(radius), K, enc_flags,
-                                 ptr(ro), ptr(b.row_sample), ptr(b.row_nbr), ptr(b.n_rows), max_rows, ptr(b.X), st),
+                                 ptr(ro), int(ro.dim() == 2), ptr(b.row_sample), ptr(b.row_nbr), ptr(b.n_rows), max_rows,
+                                 ptr(b.X), st),
           "nf_render_features")
-    b.acts = torch.empty(max(max_rows, 1) * 2432, dtype=torch.float32, device=dev) if save_acts else None
+    b.acts = torch.empty(rows_alloc * 2432, dtype=torch.float32, device=dev) if save_acts else None
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -310,7 +312,7 @@ def debug_features(particles, rays, near, far, S, radius, K, enc_flags, ro):
     cx, cd, qx, qd = feature_dims(enc_flags)
     X = torch.empty(max((nr + 31) // 32, 1) * (qx + qd) * 256, device=dev)
     check(lib.nf_render_features(ptr(grid.points), ptr(rays), None, ptr(z_table), R, S, float(radius), K, enc_flags,
-                                 ptr(ro.contiguous().float()), ptr(row_sample), ptr(row_nbr), ptr(counters[1:2]), nr,
+                                 ptr(ro.contiguous().float()), 0, ptr(row_sample), ptr(row_nbr), ptr(counters[1:2]), nr,
                                  ptr(X), st))
     return dict(features=tiles_to_rows(X, nr, cx, cd), row_sample=row_sample[:nr], num_nn=num_nn,
                 row_nbr=row_nbr[:nr * K].view(nr, K))

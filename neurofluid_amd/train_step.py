@@ -1,0 +1,93 @@
+"""One optimiser step of the warm-up trainer (/root/reference/trainer/trainer_renderer.py:75-143):
+for each of the 4 warm-up views sample `ray_chunk` random pixels of frame 0 (centre crop for the first
+`precrop_iters` steps, trainer/basetrainer.py:171-193), render them from the GT particles, loss = sum over views
+of MSE(rgb0) + MSE(rgb1); zero_grad / backward / Adam / ExponentialLR (utils/lr_schedulers.py:3-12).
+Used by bench.py --workload train and by the Trainer in neurofluid_amd/trainers.py."""
+import numpy as np
+import torch
+
+from . import dist as nfdist
+
+
+_COORDS = {}
+
+
+def random_sample_coords(H, W, global_step, precrop_iters):
+    """trainer/basetrainer.py:171-193 (CPU tensors, like the reference's device-less meshgrid).  The grid only
+    has two variants (centre crop / full frame), so it is built once instead of once per view per step."""
+    key = (H, W, global_step > precrop_iters)
+    if key not in _COORDS:
+        _COORDS[key] = _build_coords(H, W, global_step, precrop_iters)
+    return _COORDS[key]
+
+
+def _build_coords(H, W, global_step, precrop_iters):
+    if global_step > precrop_iters:
+        ys, xs = torch.linspace(0, H - 1, H), torch.linspace(0, W - 1, W)
+    else:
+        dH, dW = int(H // 2 * 0.5), int(W // 2 * 0.5)
+        ys = torch.linspace(H // 2 - dH, H // 2 + dH - 1, 2 * dH)
+        xs = torch.linspace(W // 2 - dW, W // 2 + dW - 1, 2 * dW)
+    coords = torch.stack(torch.meshgrid(ys, xs, indexing="ij"), -1)
+    return coords.reshape(-1, 2)
+
+
+class ExponentialLR(torch.optim.lr_scheduler.LambdaLR):
+    """lr = base_lr * gamma ** (epoch / decay_epochs)  (utils/lr_schedulers.py:3-12)."""
+
+    def __init__(self, optimizer, decay_epochs, gamma=0.1, last_epoch=-1):
+        super().__init__(optimizer, lambda e: gamma ** (e / decay_epochs), last_epoch)
+
+
+def renderer_train_step(renderer, optimizer, scheduler, particles, views, H, W, step_idx, ray_chunk=1024,
+                        precrop_iters=500, rng=np.random, rank=0, world=1):
+    """views: list of dicts {cw (3,4), rays (H,W,6), rgb (H*W,3)} on the GPU.  Returns the loss tensor.
+    The reference renders the views one after the other; rays are independent, so the views are batched into ONE
+    renderer call (per-ray camera position) and the per-view MSEs are taken on slices — same loss, 4x fewer launches.
+    The pixel RNG is drawn per view in the reference's order (np.random.choice, trainer_renderer.py:119)."""
+    rays_l, rgbs_l, ro_l = [], [], []
+    for v in views:
+        coords = random_sample_coords(H, W, step_idx, precrop_iters)
+        sel = rng.choice(coords.shape[0], size=[ray_chunk], replace=False)
+        sc = coords[sel].long().to(v["rays"].device)
+        rays_l.append(v["rays"][sc[:, 0], sc[:, 1]])
+        rgbs_l.append(v["rgb"].view(H, W, -1)[sc[:, 0], sc[:, 1]])
+        ro_l.append(renderer.set_ro(v["cw"]).expand(ray_chunk, 3))
+    out = renderer(particles, torch.cat(ro_l).contiguous(), torch.cat(rays_l), None, None)
+    total = 0.
+    for i, rgbs in enumerate(rgbs_l):
+        sl = slice(i * ray_chunk, (i + 1) * ray_chunk)
+        loss = torch.nn.functional.mse_loss(out["rgb0"][sl], rgbs)
+        if renderer.N_importance > 0:
+            loss = loss + torch.nn.functional.mse_loss(out["rgb1"][sl], rgbs)
+        total = total + loss
+    optimizer.zero_grad()
+    total.backward()
+    nfdist.allreduce_grads(list(renderer.parameters()), world)
+    optimizer.step()
+    if scheduler is not None:
+        scheduler.step()
+    return total.detach()
+
+
+def make_train_step(net, scene, dev, rank=0, world=1, lr=5e-4, decay_epochs=10000, seed=10):
+    """Synthetic warm-up workload for bench.py: 4 views (the synthetic camera), random target colours."""
+    H = W = 400
+    g = torch.Generator().manual_seed(seed + rank)
+    rays = scene["rays"].view(H, W, 6).to(dev)
+    cw = scene["c2w"].to(dev)
+    views = [dict(cw=cw, rays=rays, rgb=torch.rand(H * W, 3, generator=g).to(dev)) for _ in range(4)]
+    P = scene["P"].to(dev)
+    for p in net.parameters():
+        p.requires_grad_(True)
+    opt = torch.optim.Adam(net.parameters(), lr=lr)
+    sched = ExponentialLR(opt, decay_epochs=decay_epochs, gamma=0.1)
+    rng = np.random.RandomState(seed + rank)
+    state = {"step": 1000}   # past precrop_iters: full-frame sampling (steady state of the 100k-step schedule)
+
+    def step():
+        loss = renderer_train_step(net, opt, sched, P, views, H, W, state["step"], 1024, 500, rng, rank, world)
+        state["step"] += 1
+        return loss
+
+    return step

@@ -302,3 +302,27 @@ def test_fine_net_grads_same_samples(dev):
         # every layer inherits (attenuated) the 5e-4 sin(512 x) feature noise of test_features_vs_golden
         assert rel <= 2e-3, (name, rel)
     print("worst relative grad error", worst)
+
+
+def test_train_steps_run_and_learn(dev):
+    """C1: a few optimiser steps of the warm-up trainer body; the loss on a fixed batch must go down."""
+    import numpy as np
+    from neurofluid_amd.train_step import renderer_train_step, ExponentialLR
+    from oracle import render_oracle as ro
+    net = make_net(dev)
+    H = W = 400
+    d = ro.get_ray_directions(H, W, ro.camera_focal(W))
+    c2w = ro.eval_camera()
+    o, dd = ro.get_rays(d, c2w)
+    rays = torch.cat([o, dd], -1).to(dev)
+    gen = torch.Generator().manual_seed(0)
+    views = [dict(cw=c2w.to(dev), rays=rays, rgb=torch.rand(H * W, 3, generator=gen).to(dev) * 0.2) for _ in range(2)]
+    P = ro.watercube_particles().to(dev)
+    opt = torch.optim.Adam(net.parameters(), lr=5e-4)
+    sched = ExponentialLR(opt, decay_epochs=10000)
+    losses = []
+    for step in range(6):
+        rng = np.random.RandomState(0)      # same pixels every step -> monotone-ish decrease
+        losses.append(float(renderer_train_step(net, opt, sched, P, views, H, W, 0, 1024, 500, rng)))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    assert abs(opt.param_groups[0]["lr"] - 5e-4 * 0.1 ** (6 / 10000)) < 1e-9

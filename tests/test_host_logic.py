@@ -1,0 +1,53 @@
+"""Host-side logic that needs no GPU: operand layout transforms, pixel sampling, LR schedule, chunk sharding."""
+import numpy as np
+import torch
+
+from neurofluid_amd import dist as nfdist, ops
+from neurofluid_amd.train_step import ExponentialLR, random_sample_coords
+
+
+def test_tile_layout_roundtrip_and_definition():
+    g = torch.Generator().manual_seed(0)
+    for n in (1, 31, 32, 33, 100):
+        x = torch.randn(n, 252, generator=g)
+        X = ops.rows_to_tiles(x, 198, 54)
+        assert X.numel() == (n + 31) // 32 * 32 * 256
+        assert torch.equal(ops.tiles_to_rows(X, n, 198, 54), x)
+    # definition check (include/neurofluid_hip.h): X[tile][q][h*32+j][e] = feature 8q+4h+e of row tile*32+j,
+    # dir-like features start at group q = QX
+    x = torch.arange(40 * 252, dtype=torch.float32).view(40, 252)
+    X = ops.rows_to_tiles(x, 198, 54).view(2, 32, 64, 4)
+    assert X[1, 3, 1 * 32 + 5, 2] == x[32 + 5, 8 * 3 + 4 * 1 + 2]
+    assert X[0, 25, 0 * 32 + 7, 1] == x[7, 198 + 1]
+    assert X[0, 24, 1 * 32 + 7, 2] == 0        # pad: features 198,199 of the pos-like block
+
+
+def test_random_sample_coords_matches_reference_semantics():
+    full = random_sample_coords(400, 400, 501, 500)
+    assert full.shape == (160000, 2) and full[401].tolist() == [1.0, 1.0]
+    crop = random_sample_coords(400, 400, 500, 500)          # step <= precrop_iters -> central half
+    assert crop.shape == (200 * 200, 2)
+    assert crop.min().item() == 100 and crop.max().item() == 299
+
+
+def test_exponential_lr():
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([p], lr=5e-4)
+    sch = ExponentialLR(opt, decay_epochs=10000, gamma=0.1)
+    for _ in range(100):
+        opt.step(); sch.step()
+    assert abs(opt.param_groups[0]["lr"] - 5e-4 * 0.1 ** (100 / 10000)) < 1e-12
+
+
+def test_chunk_ownership_is_interleaved_and_complete():
+    for n_chunks, world in ((157, 8), (625, 8), (5, 8), (16, 2)):
+        owned = [nfdist.my_chunks(n_chunks, r, world) for r in range(world)]
+        assert sorted(c for o in owned for c in o) == list(range(n_chunks))
+        assert max(len(o) for o in owned) == nfdist.share_size(n_chunks, world)
+        assert all(o == list(range(r, n_chunks, world)) for r, o in enumerate(owned))
+
+
+def test_gather_chunks_single_rank_identity():
+    x = torch.arange(10 * 3, dtype=torch.float32).view(10, 3)
+    pad = torch.zeros(12, 3); pad[:10] = x
+    assert torch.equal(nfdist.gather_chunks(pad, 3, 4, 10, 0, 1), x)

@@ -157,9 +157,15 @@ def main():
     mult = 1.0 if args.workload == "render" else 1.0
     n_launch = max(len(prof["mlp"]), 1)
     achieved = rows * MLP_FLOP_PER_ROW * mult / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "round1_mlp_pmc.json")
+    if args.workload == "render" and os.path.exists(pmc):
+        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
+        # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, tools/summarize_profiles.py)
+        traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
     roofline = {"bound": "mfma", "kernel": "k_mlp_fwd (fp32 v_mfma_f32_32x32x2_f32)", "achieved": achieved,
                 "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_MATRIX_PEAK_TFLOPS,
-                "traffic": None, "launches": len(prof["mlp"]), "avg_launch_ms": mlp_ms / n_launch,
+                "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)", "launches": len(prof["mlp"]), "avg_launch_ms": mlp_ms / n_launch,
                 "executed_rows_per_step": rows / args.steps,
                 "flop_per_row": MLP_FLOP_PER_ROW, "mlp_ms_per_step": mlp_ms / args.steps}
 

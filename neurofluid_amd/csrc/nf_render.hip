@@ -501,3 +501,34 @@ extern "C" int nf_composite_bwd(const float* rgbsigma, const float* z, const flo
     NF_CHECK_LAUNCH();
     return NF_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// A0: per-pixel rays on device (utils/ray_utils.py:85-130): dir_cam = ((i-W/2)/f, -(j-H/2)/f, -1),
+// d = normalise(dir_cam @ c2w[:, :3]^T), o = c2w[:, 3].  Rows [row0, row0+nrows) of the image.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_get_rays(int H, int W, float focal, const float* __restrict__ c2w, int row0, int nrows,
+                           float* __restrict__ rays)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nrows * W) return;
+    int j = row0 + t / W, i = t % W;
+    float dx = ((float)i - (float)W / 2) / focal, dy = -((float)j - (float)H / 2) / focal, dz = -1.f;
+    float r[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) r[k] = dx * c2w[4 * k] + dy * c2w[4 * k + 1] + dz * c2w[4 * k + 2];
+    float n = sqrtf(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    float* o = rays + 6 * (size_t)t;
+    o[0] = c2w[3]; o[1] = c2w[7]; o[2] = c2w[11];
+    o[3] = r[0] / n; o[4] = r[1] / n; o[5] = r[2] / n;
+}
+
+extern "C" int nf_get_rays(int H, int W, float focal, const float* c2w, int row0, int nrows, float* rays, nf_stream_t stream)
+{
+    NF_CHECK_ARG(c2w && rays, "null pointer");
+    NF_CHECK_ARG(H > 0 && W > 0 && focal > 0.f && row0 >= 0 && nrows >= 0 && row0 + nrows <= H, "bad image geometry");
+    if (nrows == 0) return NF_OK;
+    int n = nrows * W;
+    hipLaunchKernelGGL(k_get_rays, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, H, W, focal, c2w, row0, nrows, rays);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}

@@ -1,0 +1,593 @@
+"""Thin counterparts of the reference's callers of the hot path:
+  BaseTrainer        trainer/basetrainer.py:17-343      (seeding, dirs, ckpt loaders, losses, chunk loop, PNG dump)
+  RendererTrainer    trainer/trainer_renderer.py:22-175  (warm-up: GT particles, 4 views x ray_chunk rays / step)
+  E2ETrainer         trainer/trainer_e2e.py:26-371       (transition step -> render predicted particles -> RGB + boundary)
+  TransModelTrainer  trainer/trainer_transmodel.py       (supervised 2-step unroll)
+  E2EEvaluator / RendererEvaluation / TransModelEvaluation   eval_e2e.py, eval_renderer.py, eval_transmodel.py
+Host plumbing only; every heavy op goes through RenderNet / ParticleNet (HIP).  TensorBoard is optional.
+One process per GPU: when launched through torch.distributed.run the full-image loops shard ray chunks over ranks
+and training all-reduces gradients (neurofluid_amd/dist.py)."""
+import json
+import os
+import os.path as osp
+import random
+
+import numpy as np
+import torch
+
+from . import dist as nfdist
+from .datasets import BlenderDataset, ParticleDataset
+from .point_eval import FluidErrors
+from .render_loop import render_image as _render_image
+from .renderer import RenderNet
+from .train_step import ExponentialLR, random_sample_coords
+from .transmodel import ParticleNet
+
+to8b = lambda x: (255 * np.clip(x, 0, 1)).astype(np.uint8)   # noqa: E731  trainer/basetrainer.py:16
+img2mse = lambda x, y: torch.mean((x - y) ** 2)              # noqa: E731
+mse2psnr = lambda x: -10. * torch.log(x) / np.log(10.)       # noqa: E731
+
+
+class _NullWriter:
+    def __getattr__(self, name):
+        return lambda *a, **k: None
+
+
+def _writer(log_dir):
+    try:
+        from torch.utils.tensorboard import SummaryWriter
+        return SummaryWriter(log_dir=log_dir)
+    except Exception:
+        return _NullWriter()
+
+
+def record2obj(pos, fp, color=(255, 0, 0)):
+    """utils/particles_utils.py:38-42: one coloured vertex per particle."""
+    p = pos.detach().cpu().numpy() if isinstance(pos, torch.Tensor) else np.asarray(pos)
+    for x, y, z in p:
+        fp.write('v {} {} {} {} {} {}\n'.format(x, y, z, *color))
+
+
+class BaseTrainer:
+    def __init__(self, options):
+        self.options = options
+        self.rank, self.world, self.local_rank = nfdist.init_from_env()
+        self.seed_everything(options.TRAIN.seed if 'TRAIN' in options and 'seed' in options.TRAIN else 10)
+        self.exppath = osp.join(options.expdir, options.expname)
+        self.imgpath = osp.join(self.exppath, 'images')
+        self.particlepath = osp.join(self.exppath, 'particles')
+        for d in ('models', 'images', 'particles'):
+            os.makedirs(osp.join(self.exppath, d), exist_ok=True)
+        self.summary_writer = _writer(self.exppath) if self.rank == 0 else _NullWriter()
+        if not torch.cuda.is_available():
+            raise RuntimeError('neurofluid_amd needs an MI355X: there is no CPU fallback for the hot path')
+        self.device = torch.device('cuda', self.local_rank)
+        torch.cuda.set_device(self.device)
+        self.init_fn()
+        self.init_box_boundary()
+        if self.options.resume_from != '':
+            self.resume(self.options.resume_from)
+
+    def init_fn(self):
+        raise NotImplementedError()
+
+    def resume(self, ckpt_file):
+        raise NotImplementedError()
+
+    def seed_everything(self, seed):
+        random.seed(seed)
+        os.environ['PYTHONHASHSEED'] = str(seed)
+        np.random.seed(seed)
+        torch.manual_seed(seed)
+
+    def init_box_boundary(self, particle_radius=0.025):
+        self.x_bound = [1 - particle_radius, -1 + particle_radius]
+        self.y_bound = [1 - particle_radius, -1 + particle_radius]
+        self.z_bound = [2.4552 - particle_radius, -1 + particle_radius]
+
+    def strict_clip_particles(self, pos):
+        assert pos.dim() == 2
+        return torch.stack((pos[:, 0].clamp(self.x_bound[1], self.x_bound[0]),
+                            pos[:, 1].clamp(self.y_bound[1], self.y_bound[0]),
+                            pos[:, 2].clamp(self.z_bound[1], self.z_bound[0])), dim=1)
+
+    # ---- checkpoints (key names are the compatibility contract)
+    def load_pretained_transition_model(self, path):
+        ckpt = torch.load(path, map_location=self.device)
+        ckpt = ckpt.get('transition_model_state_dict', ckpt.get('model_state_dict', ckpt))
+        ckpt = {k: v for k, v in ckpt.items() if 'gravity' not in k}
+        sd = self.transition_model.state_dict()
+        sd.update(ckpt)
+        self.transition_model.load_state_dict(sd, strict=True)
+
+    def load_pretained_renderer_model(self, path, partial_load=False):
+        ckpt = torch.load(path, map_location=self.device)['renderer_state_dict']
+        if partial_load:
+            ckpt = {k: v for k, v in ckpt.items() if 'sigma' in k or 'xyz_encoding' in k}
+        sd = self.renderer.state_dict()
+        sd.update(ckpt)
+        self.renderer.load_state_dict(sd, strict=True)
+
+    # ---- losses
+    def set_RGB_criterion(self):
+        self.rgb_criterion = torch.nn.MSELoss()
+
+    def set_L1_criterion(self):
+        self.L1_criterion = torch.nn.L1Loss()
+
+    def cal_boundary_loss(self, pos):
+        return self.L1_criterion(pos, self.strict_clip_particles(pos))
+
+    def weighted_mse_loss(self, pred_pos, gt_pos, num_fluid_neighbors, gamma=0.5, neighbor_scale=1 / 40):
+        importance = torch.exp(-neighbor_scale * num_fluid_neighbors)
+        dist = torch.sqrt(torch.sum((pred_pos - gt_pos) ** 2, dim=-1) + 1e-12)
+        return torch.mean(importance * dist ** gamma)
+
+    def cal_grad_norm(self, model):
+        return np.array([p.grad.detach().norm(2).item() for p in model.parameters() if p.grad is not None])
+
+    def get_learning_rate(self, optimizer):
+        return [g['lr'] for g in optimizer.param_groups]
+
+    def random_sample_coords(self, H, W, global_step):
+        return random_sample_coords(H, W, global_step, self.options.TRAIN.precrop_iters)
+
+    def sample_pixels(self, rays_hw6, rgbs, H, W, global_step, ray_chunk):
+        coords = self.random_sample_coords(H, W, global_step)
+        sel = np.random.choice(coords.shape[0], size=[ray_chunk], replace=False)
+        sc = coords[sel].long().to(rays_hw6.device)
+        return rays_hw6[sc[:, 0], sc[:, 1]], rgbs.view(H, W, -1)[sc[:, 0], sc[:, 1]]
+
+    # ---- the chunk loop (trainer/basetrainer.py:264-309)
+    def render_image(self, particle_pos, N_ray, ro, rays, focal_length, cw, iseval=False):
+        rc = self.options.RENDERER.ray.ray_chunk
+        chunk = rc
+        if N_ray > rc:   # full-image loops: larger fused calls, still multiples of the reference's chunk
+            chunk = max(rc, int(self.options.RENDERER.get('device_ray_chunk', rc)) // rc * rc)
+        shard = iseval and self.world > 1
+        return _render_image(self.renderer, particle_pos, N_ray, ro, rays, focal_length, cw, iseval=iseval,
+                             ray_chunk=chunk, rank=self.rank if shard else 0, world=self.world if shard else 1)
+
+    # ---- image dumps
+    def vis_rgbs(self, rgbs, channel=3, test=False):
+        node = self.options.TEST if test else self.options.TRAIN
+        W, H = int(node.imgW // node.scale), int(node.imgH // node.scale)
+        return rgbs.reshape(H, W, channel).detach().cpu().permute(2, 0, 1)
+
+    def _write_png(self, chw, filename):
+        from PIL import Image
+        a = to8b(chw.permute(1, 2, 0).numpy())
+        if a.shape[-1] == 1:
+            a = a[..., 0]
+        os.makedirs(osp.dirname(filename), exist_ok=True)
+        Image.fromarray(a).save(filename)
+
+    def visualization(self, pred_rgbs, gt_rgbs, step, mask=None, prefix=None):
+        if self.rank != 0:
+            return
+        self._write_png(self.vis_rgbs(gt_rgbs), '{}/{}_{:05d}.png'.format(self.imgpath, prefix, step))
+        self._write_png(self.vis_rgbs(pred_rgbs), '{}/{}_{:05d}_pred.png'.format(self.imgpath, prefix, step))
+        if mask is not None:
+            self._write_png(self.vis_rgbs(mask, channel=1), '{}/{}_{:05d}_mask.png'.format(self.imgpath, prefix, step))
+
+    def _to_dev(self, data):
+        return {k: v.to(self.device) if isinstance(v, torch.Tensor) else v for k, v in data.items()}
+
+    def _dataset(self, node_key, views, split, imgnode):
+        o = self.options
+        return BlenderDataset(o[node_key].path, o, start_index=o[node_key].start_index, end_index=o[node_key].end_index,
+                              imgW=imgnode.imgW, imgH=imgnode.imgH, imgscale=imgnode.scale, viewnames=views, split=split)
+
+
+# ================================================================================================
+class RendererTrainer(BaseTrainer):
+    def init_fn(self):
+        self.start_step = 0
+        o = self.options
+        self.train_view_names, self.test_viewnames = o['train'].views.warmup, o['test'].views
+        self.dataset = self._dataset('train', self.train_view_names, 'train', o.TRAIN)
+        self.test_dataset = self._dataset('test', self.test_viewnames, 'test', o.TEST)
+        self.renderer = RenderNet(o.RENDERER, near=o.near, far=o.far).to(self.device)
+        if o.TRAIN.pretained_renderer != '':
+            self.load_pretained_renderer_model(o.TRAIN.pretained_renderer, partial_load=o.TRAIN.partial_load)
+        self.optimizer = torch.optim.Adam(self.renderer.parameters(), lr=o.TRAIN.LR.lr)
+        self.lr_scheduler = ExponentialLR(self.optimizer, decay_epochs=o.TRAIN.LR.decay_epochs, gamma=0.1) \
+            if o.TRAIN.LR.use_scheduler else None
+        self.set_RGB_criterion()
+
+    def resume(self, ckpt_file):
+        ck = torch.load(ckpt_file, map_location=self.device)
+        self.start_step = ck['step']
+        self.renderer.load_state_dict(ck['renderer_state_dict'], strict=True)
+        self.optimizer.load_state_dict(ck['optimizer_state_dict'])
+
+    def save_checkpoint(self, global_step):
+        if self.rank == 0:
+            torch.save({'step': global_step, 'renderer_state_dict': self.renderer.state_dict(),
+                        'optimizer_state_dict': self.optimizer.state_dict()},
+                       osp.join(self.exppath, 'models', f'{global_step}.pt'))
+
+    def train(self, max_steps=None):
+        o = self.options
+        H, W = int(o.TRAIN.imgH // o.TRAIN.scale), int(o.TRAIN.imgW // o.TRAIN.scale)
+        self.renderer.train()
+        data = self._to_dev(self.dataset[0])              # always frame 0 (trainer_renderer.py:81)
+        last = o.TRAIN.N_iters if max_steps is None else min(o.TRAIN.N_iters, self.start_step + max_steps)
+        loss = None
+        for step_idx in range(self.start_step, last):
+            loss = self.train_step(data, len(self.train_view_names), H, W, step_idx)
+            self.update_step(loss)
+            if (step_idx + 1) % o.TRAIN.save_interval == 0:
+                self.eval(step_idx)
+                self.save_checkpoint(step_idx)
+        return loss
+
+    def update_step(self, loss):
+        self.optimizer.zero_grad()
+        loss.backward()
+        nfdist.allreduce_grads(list(self.renderer.parameters()), self.world)
+        self.optimizer.step()
+        if self.lr_scheduler is not None:
+            self.lr_scheduler.step()
+
+    def train_step(self, data, view_num, H, W, step_idx):
+        rc = self.options.RENDERER.ray.ray_chunk
+        rays_l, rgbs_l, ro_l = [], [], []
+        for v in range(view_num):
+            rays, rgbs = self.sample_pixels(data['rays'][v], data['rgb'][v], H, W, step_idx, rc)
+            rays_l.append(rays); rgbs_l.append(rgbs)
+            ro_l.append(self.renderer.set_ro(data['cw'][v]).expand(rc, 3))
+        # the views are rendered in ONE fused call (rays are independent; per-ray camera position)
+        out = self.renderer(data['particles_pos'], torch.cat(ro_l).contiguous(), torch.cat(rays_l), None, None)
+        total = 0.
+        for v in range(view_num):
+            sl = slice(v * rc, (v + 1) * rc)
+            l0 = self.rgb_criterion(out['rgb0'][sl], rgbs_l[v])
+            loss = l0 + self.rgb_criterion(out['rgb1'][sl], rgbs_l[v]) if self.renderer.N_importance > 0 else l0
+            total = total + loss
+            if (step_idx + 1) % self.options.TRAIN.log_interval == 0:
+                self.summary_writer.add_scalar(f'{self.train_view_names[v]}/rgbloss', loss.item(), step_idx)
+        return total
+
+    def eval(self, step_idx):
+        self.renderer.eval()
+        res = {}
+        with torch.no_grad():
+            data = self._to_dev(self.test_dataset[0])
+            for v, view in enumerate(self.test_viewnames):
+                cw = data['cw'][v]
+                rays = data['rays'][v].reshape(-1, 6)
+                ret = self.render_image(data['particles_pos'], rays.shape[0], self.renderer.set_ro(cw), rays,
+                                        data['focal'][v], cw, iseval=True)
+                for lvl, key in ((0, 'pred_rgbs_0'), (1, 'pred_rgbs_1')):
+                    if key in ret:
+                        psnr = mse2psnr(img2mse(ret[key], data['rgb'][v])).item()
+                        res[f'{view}/psnr_{lvl}'] = psnr
+                        self.summary_writer.add_scalar(f'{view}/psnr_0_{lvl}', psnr, step_idx)
+                        self.visualization(ret[key], data['rgb'][v], step_idx, mask=ret.get(f'mask_{lvl}'),
+                                           prefix=f'{"coarse" if lvl == 0 else "fine"}_0_{view}')
+        self.renderer.train()
+        return res
+
+
+# ================================================================================================
+def _piecewise(boundaries, values):
+    def fn(x):
+        f = values[0]
+        for b, v in zip(boundaries, values[1:]):
+            if x > b:
+                f = v
+            else:
+                break
+        return f
+    return fn
+
+
+class E2ETrainer(BaseTrainer):
+    def init_fn(self):
+        o = self.options
+        self.start_step, self.eval_count = 0, 0
+        self.train_view_names, self.test_viewnames = o['train'].views.dynamic, o['test'].views
+        self.dataset = self._dataset('train', self.train_view_names, 'train', o.TRAIN)
+        self.test_dataset = self._dataset('test', self.test_viewnames, 'test', o.TEST)
+        self.transition_model = ParticleNet(gravity=o.gravity).to(self.device)
+        self.renderer = RenderNet(o.RENDERER, near=o.near, far=o.far).to(self.device)
+        if o.TRAIN.pretrained_transition_model != '':
+            self.load_pretained_transition_model(o.TRAIN.pretrained_transition_model)
+        if o.TRAIN.pretained_renderer != '':
+            self.load_pretained_renderer_model(o.TRAIN.pretained_renderer, partial_load=o.TRAIN.partial_load)
+        lr_r, lr_t = o.TRAIN.LR.renderer_lr, o.TRAIN.LR.trans_lr
+        self.separate = o.TRAIN.seperate_render_transition
+        if self.separate:
+            self.optimizer = torch.optim.Adam([{'params': self.renderer.parameters(), 'lr': lr_r}])
+            self.transition_optimizer = torch.optim.Adam([{'params': self.transition_model.parameters(), 'lr': lr_t}])
+        else:
+            self.optimizer = torch.optim.Adam([{'params': self.renderer.parameters(), 'lr': lr_r},
+                                               {'params': self.transition_model.parameters(), 'lr': lr_t}])
+        self.schedulers = []
+        if o.TRAIN.LR.use_scheduler:      # trainer_e2e.py:83-139
+            self.schedulers.append(torch.optim.lr_scheduler.LambdaLR(
+                self.optimizer, _piecewise([10000, 75000, 150000], [1.0, 0.5, 0.25, 0.125])))
+            if self.separate:
+                self.schedulers.append(torch.optim.lr_scheduler.LambdaLR(
+                    self.transition_optimizer, _piecewise([10000, 30000, 50000, 100000, 300000],
+                                                          [1.0, 0.5, 0.25, 0.125, 0.0625, 0.03125, 0.015625])))
+        self.set_RGB_criterion()
+        self.set_L1_criterion()
+
+    def resume(self, ckpt_file):
+        ck = torch.load(ckpt_file, map_location=self.device)
+        self.start_step = ck['step']
+        self.renderer.load_state_dict(ck['renderer_state_dict'], strict=True)
+        self.transition_model.load_state_dict(ck['transition_model_state_dict'], strict=True)
+
+    def save_checkpoint(self, global_step):
+        if self.rank == 0:
+            torch.save({'step': global_step, 'renderer_state_dict': self.renderer.state_dict(),
+                        'transition_model_state_dict': self.transition_model.state_dict(),
+                        'optimizer_state_dict': self.optimizer.state_dict()},
+                       osp.join(self.exppath, 'models', f'{global_step}.pt'))
+
+    def train(self, max_steps=None):
+        o = self.options
+        H, W = int(o.TRAIN.imgH // o.TRAIN.scale), int(o.TRAIN.imgW // o.TRAIN.scale)
+        global_step, done, loss = self.start_step, 0, None
+        self.transition_model.train(); self.renderer.train()
+        for _epoch in range(self.start_step, o.TRAIN.epochs):
+            self.tmp_fluid_error = FluidErrors()
+            for data_idx in range(len(self.dataset)):
+                data = self._to_dev(self.dataset[data_idx])
+                loss = self.train_step(data, data_idx, len(self.train_view_names), H, W, global_step)
+                self.update_step(loss, global_step)
+                global_step += 1; done += 1
+                if (global_step + 1) % o.TRAIN.save_interval == 0:
+                    self.eval(global_step)
+                    self.save_checkpoint(global_step)
+                if max_steps is not None and done >= max_steps:
+                    return loss
+        return loss
+
+    def trainsition_step_for_training(self, data, data_idx):
+        if data_idx == 0:
+            self.pos_for_next_step, self.vel_for_next_step = data['particles_pos'], data['particles_vel']
+        pred_pos, pred_vel, _ = self.transition_model(self.pos_for_next_step, self.vel_for_next_step, data['box'],
+                                                      data['box_normals'])
+        # truncated BPTT of length 1: the carried state is detached (trainer_e2e.py:196-198)
+        self.pos_for_next_step, self.vel_for_next_step = pred_pos.detach().clone(), pred_vel.detach().clone()
+        return pred_pos
+
+    def train_step(self, data, data_idx, view_num, H, W, global_step):
+        pred_pos = self.trainsition_step_for_training(data, data_idx)
+        log = (global_step + 1) % self.options.TRAIN.log_interval == 0
+        if log:
+            d = self.tmp_fluid_error.cal_errors(pred_pos.detach().cpu().numpy(), data['particles_pos_1'].cpu().numpy(), data_idx + 1)
+            self.summary_writer.add_scalar('Train/pred2gt_distance', d, global_step)
+        rc = self.options.RENDERER.ray.ray_chunk
+        total = 0.
+        for v in range(view_num):       # frame t+1 supervises the particles predicted from frame t (:224-227)
+            rays, rgbs = self.sample_pixels(data['rays_1'][v], data['rgb_1'][v], H, W, global_step, rc)
+            cw = data['cw_1'][v]
+            ret = self.render_image(pred_pos, rc, self.renderer.set_ro(cw), rays, data['focal'][v], cw)
+            l0 = self.rgb_criterion(ret['pred_rgbs_0'], rgbs)
+            loss = l0 + self.rgb_criterion(ret['pred_rgbs_1'], rgbs) if self.renderer.N_importance > 0 else l0
+            total = total + loss
+        wb = self.options.TRAIN.loss_weight['boundary_loss']
+        if wb != 0.:
+            total = total + self.cal_boundary_loss(pred_pos) * wb
+        return total
+
+    def update_step(self, loss, global_step):
+        clip = self.options.TRAIN.grad_clip_value
+        self.optimizer.zero_grad()
+        if self.separate:
+            self.transition_optimizer.zero_grad()
+        loss.backward()
+        nfdist.allreduce_grads(list(self.renderer.parameters()) + list(self.transition_model.parameters()), self.world)
+        if clip != 0:
+            torch.nn.utils.clip_grad_norm_(self.renderer.parameters(), clip)
+            torch.nn.utils.clip_grad_norm_(self.transition_model.parameters(), clip)
+        self.optimizer.step()
+        if self.separate:
+            self.transition_optimizer.step()
+        for s in self.schedulers:
+            s.step()
+
+    def eval(self, step_idx, render_frames=(0, 20, 30)):
+        self.eval_count += 1
+        self.transition_model.eval(); self.renderer.eval()
+        dists, fe = [], FluidErrors()
+        with torch.no_grad():
+            for data_idx in range(len(self.test_dataset)):
+                data = self._to_dev(self.test_dataset[data_idx])
+                if data_idx == 0:
+                    pos, vel = data['particles_pos'], data['particles_vel']
+                pos, vel, _ = self.transition_model(pos, vel, data['box'], data['box_normals'])
+                dists.append(fe.cal_errors(pos.cpu().numpy(), data['particles_pos_1'].cpu().numpy(), data_idx + 1))
+                if data_idx in render_frames:
+                    for v, view in enumerate(self.test_viewnames):
+                        cw = data['cw_1'][v]
+                        rays = data['rays_1'][v].reshape(-1, 6)
+                        ret = self.render_image(pos, rays.shape[0], self.renderer.set_ro(cw), rays, data['focal'][v], cw, iseval=True)
+                        key = 'pred_rgbs_1' if 'pred_rgbs_1' in ret else 'pred_rgbs_0'
+                        self.summary_writer.add_scalar(f'{view}/psnr_{data_idx}', mse2psnr(img2mse(ret[key], data['rgb_1'][v])).item(), step_idx)
+                        self.visualization(ret[key], data['rgb_1'][v], step_idx, prefix=f'fine_{data_idx}_{view}')
+            self.summary_writer.add_scalar('avg_pred2gt_distance', float(np.mean(dists)), step_idx)
+        self.transition_model.train(); self.renderer.train()
+        return dists
+
+
+# ================================================================================================
+class E2EEvaluator(BaseTrainer):
+    """eval_e2e.py:24-160: roll the transition model over the test frames, render every frame from every test view."""
+
+    def init_fn(self):
+        o = self.options
+        self.test_viewnames = o['test'].views
+        self.test_dataset = self._dataset('test', self.test_viewnames, 'test', o.TEST)
+        self.transition_model = ParticleNet(gravity=o.gravity).to(self.device)
+        self.renderer = RenderNet(o.RENDERER, near=o.near, far=o.far).to(self.device)
+
+    def resume(self, ckpt_file):
+        ck = torch.load(ckpt_file, map_location=self.device)
+        self.renderer.load_state_dict(ck['renderer_state_dict'], strict=True)
+        self.transition_model.load_state_dict(ck['transition_model_state_dict'], strict=True)
+
+    def eval(self, dump=True):
+        self.transition_model.eval(); self.renderer.eval()
+        dists, psnrs = [], []
+        self.fluid_error = FluidErrors()
+        with torch.no_grad():
+            for data_idx in range(len(self.test_dataset)):
+                data = self._to_dev(self.test_dataset[data_idx])
+                if data_idx == 0:
+                    pos, vel = data['particles_pos'], data['particles_vel']
+                pos, vel, _ = self.transition_model(pos, vel, data['box'], data['box_normals'])
+                dists.append(self.fluid_error.cal_errors(pos.cpu().numpy(), data['particles_pos_1'].cpu().numpy(), data_idx + 1))
+                if dump and self.rank == 0:
+                    for sub, p, col in (('Pred', pos, (255, 0, 0)), ('GT', data['particles_pos_1'], (3, 168, 158))):
+                        os.makedirs(osp.join(self.particlepath, sub), exist_ok=True)
+                        with open(osp.join(self.particlepath, sub, f'{data_idx + 1}.obj'), 'w') as fp:
+                            record2obj(p, fp, color=col)
+                for v, view in enumerate(self.test_viewnames):
+                    cw = data['cw_1'][v]
+                    rays = data['rays_1'][v].reshape(-1, 6)
+                    ret = self.render_image(pos, rays.shape[0], self.renderer.set_ro(cw), rays, data['focal'][v], cw, iseval=True)
+                    for lvl, key in (('coarse', 'pred_rgbs_0'), ('fine', 'pred_rgbs_1')):
+                        if key in ret:
+                            psnrs.append(mse2psnr(img2mse(ret[key], data['rgb_1'][v])).item())
+                            if dump and self.rank == 0:
+                                self._write_png(self.vis_rgbs(data['rgb_1'][v], test=True), f'{self.imgpath}/{lvl}/{view}/GT/{data_idx + 1:05d}.png')
+                                self._write_png(self.vis_rgbs(ret[key], test=True), f'{self.imgpath}/{lvl}/{view}/Pred/{data_idx + 1:05d}.png')
+        if dump and self.rank == 0:
+            import joblib
+            joblib.dump({'dist': dists}, osp.join(self.exppath, 'pred2gt.pt'))
+        return {'pred2gt': dists, 'psnr': psnrs}
+
+
+class RendererEvaluation(BaseTrainer):
+    """eval_renderer.py:46-148: render GT particle frames from one fixed camera with a warm-up checkpoint."""
+
+    def init_fn(self):
+        o = self.options
+        self.renderer = RenderNet(o.RENDERER, near=o.TEST.near, far=o.TEST.far).to(self.device)
+        files = sorted([f for f in os.listdir(o.TEST.data_path) if f.endswith('.npz')], key=lambda s: int(s[:-4]))
+        self.files = [osp.join(o.TEST.data_path, f) for f in files][o.TEST.start_index:o.TEST.end_index]
+
+    def resume(self, ckpt_file):
+        sd = self.renderer.state_dict()
+        sd.update(torch.load(ckpt_file, map_location=self.device)['renderer_state_dict'])
+        self.renderer.load_state_dict(sd, strict=True)
+
+    def pre_request(self, c2w=None):
+        from . import ray_utils
+        o = self.options
+        W, H = o.TEST.imgW, o.TEST.imgH
+        focal = .5 * W / np.tan(0.5 * o.TEST.camera_angle_x)
+        if c2w is None:     # pose values of the reference's hard-coded evaluation camera (eval_renderer.py:67-92)
+            c2w = torch.tensor([[0.3597943186759949, 0.09052024036645889, -0.18696719408035278, -4.842308521270752],
+                                [-0.2077273577451706, 0.15678563714027405, -0.32383665442466736, -8.387124061584473],
+                                [0.0, 0.37393447756767273, 0.181040421128273, 4.688809871673584]])
+        c2w = c2w.to(self.device)
+        return {'cw': c2w, 'focal': focal, 'rays': ray_utils.get_rays_device(H, W, focal, c2w)}
+
+    def eval(self, max_frames=53, dump=True):
+        self.renderer.eval()
+        rp = self.pre_request()
+        out = []
+        with torch.no_grad():
+            for i, f in enumerate(self.files[:max_frames]):
+                pos = torch.from_numpy(np.load(f)['pos']).float().to(self.device)
+                ret = self.render_image(pos, rp['rays'].shape[0], self.renderer.set_ro(rp['cw']), rp['rays'], rp['focal'], rp['cw'], iseval=True)
+                out.append(ret)
+                if dump and self.rank == 0:
+                    name = osp.basename(f)[:-4]
+                    for lvl, key in (('coarse', 'pred_rgbs_0'), ('fine', 'pred_rgbs_1')):
+                        if key in ret:
+                            self._write_png(self.vis_rgbs(ret[key], test=True), osp.join(self.exppath, 'render_GT', f'{lvl}_pred_{name}.png'))
+        return out
+
+
+class TransModelEvaluation:
+    """eval_transmodel.py:19-154: roll out the transition model only; raw and box-clipped FluidErrors."""
+
+    def __init__(self, options):
+        self.options = options
+        self.rank, self.world, local = nfdist.init_from_env()
+        if not torch.cuda.is_available():
+            raise RuntimeError('neurofluid_amd needs an MI355X: there is no CPU fallback for the hot path')
+        self.device = torch.device('cuda', local)
+        self.exppath = osp.join(options.expdir, options.expname)
+        os.makedirs(osp.join(self.exppath, 'clip'), exist_ok=True)
+        self.transition_model = ParticleNet(gravity=options.TEST.gravity).to(self.device)
+        if options.resume_from:
+            ck = torch.load(options.resume_from, map_location=self.device)
+            ck = ck.get('transition_model_state_dict', ck.get('model_state_dict', ck))
+            sd = self.transition_model.state_dict()
+            sd.update({k: v for k, v in ck.items() if 'gravity' not in k})
+            self.transition_model.load_state_dict(sd, strict=True)
+        self.dataset = ParticleDataset(options.TEST.datapath, options.TEST.datatype, options.TEST.start_index,
+                                       options.TEST.end_index, random_rot=False, window=2)
+        self.fluid_erros, self.cliped_fluid_erros = FluidErrors(), FluidErrors()
+        BaseTrainer.init_box_boundary(self)
+
+    strict_clip_particles = BaseTrainer.strict_clip_particles
+
+    def eval(self):
+        d_all, dc_all = [], []
+        with torch.no_grad():
+            for i in range(len(self.dataset)):
+                data = {k: v.to(self.device) for k, v in self.dataset[i].items()}
+                if i == 0:
+                    pos, vel = data['particles_pos_0'], data['particles_vel_0']
+                pos, vel, _ = self.transition_model(pos, vel, data['box'], data['box_normals'])
+                gt = data['particles_pos_1']
+                d_all.append(self.fluid_erros.cal_errors(pos.cpu().numpy(), gt.cpu().numpy(), i + 1))
+                dc_all.append(self.cliped_fluid_erros.cal_errors(self.strict_clip_particles(pos).cpu().numpy(),
+                                                                 self.strict_clip_particles(gt).cpu().numpy(), i + 1))
+                if self.options.TEST.save_obj and self.rank == 0:
+                    with open(osp.join(self.exppath, f'pred_{i + 1}.obj'), 'w') as fp:
+                        record2obj(pos, fp, color=(255, 0, 0))
+        self.fluid_erros.save(osp.join(self.exppath, 'res.json'))
+        self.cliped_fluid_erros.save(osp.join(self.exppath, 'clip', 'res.json'))
+        return {'pred2gt': d_all, 'pred2gt_clipped': dc_all}
+
+
+class TransModelTrainer(BaseTrainer):
+    """trainer/trainer_transmodel.py: supervised fine-tuning, 2-step unroll, neighbour-weighted loss + boundary."""
+
+    def init_fn(self):
+        o = self.options
+        self.transition_model = ParticleNet(gravity=o.TRAIN.gravity).to(self.device)
+        if o.TRAIN.pretrained:
+            self.load_pretained_transition_model(o.TRAIN.pretrained)
+        self.dataset = ParticleDataset(o.TRAIN.datapath.train, o.TRAIN.datapath.train_datatype, o.TRAIN.start_index,
+                                       o.TRAIN.end_index, random_rot=True, window=3)
+        self.optimizer = torch.optim.Adam(self.transition_model.parameters(), lr=o.TRAIN.lr)
+        self.set_L1_criterion()
+        self.start_step = 0
+
+    def resume(self, ckpt_file):
+        ck = torch.load(ckpt_file, map_location=self.device)
+        self.start_step = ck['step']
+        self.transition_model.load_state_dict(ck['model_state_dict'], strict=True)
+
+    def train(self, max_steps=None):
+        o = self.options
+        step, loss = self.start_step, None
+        order = np.random.permutation(len(self.dataset))
+        while step < o.TRAIN.N_iters and (max_steps is None or step - self.start_step < max_steps):
+            data = self._to_dev(self.dataset[int(order[step % len(order)])])
+            pos, vel = data['particles_pos_0'], data['particles_vel_0']
+            loss = 0.
+            for k in (1, 2):          # 2-step unroll, state NOT detached in between
+                pos, vel, nn = self.transition_model(pos, vel, data['box'], data['box_normals'])
+                loss = loss + self.weighted_mse_loss(pos, data[f'particles_pos_{k}'], nn) + self.cal_boundary_loss(pos)
+            self.optimizer.zero_grad()
+            loss.backward()
+            nfdist.allreduce_grads(list(self.transition_model.parameters()), self.world)
+            self.optimizer.step()
+            step += 1
+            if step % o.TRAIN.save_interval == 0 and self.rank == 0:
+                torch.save({'step': step, 'model_state_dict': self.transition_model.state_dict(),
+                            'optimizer_state_dict': self.optimizer.state_dict()}, osp.join(self.exppath, 'models', f'{step}.pt'))
+        return loss

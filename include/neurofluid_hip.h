@@ -95,6 +95,13 @@ int nf_render_features(const float* particles /*Np*3*/, const float* rays, const
                        const float* ro /*3, or R*3 when ro_per_ray (several views batched in one call)*/, int ro_per_ray,
                        const int32_t* row_sample, const int32_t* row_nbr, const int32_t* n_rows, int max_rows,
                        float* X, nf_stream_t stream);
+/* A12 (feature part, e2e training): dparticles[j] += dL/d(particle j) given dX (row-major, n_rows x (cx+cd)) =
+ * dL/d(feature row).  Gradients flow only through the gathered neighbour positions (models/renderer.py:96-109,
+ * :163-169); float atomics (order-dependent in the last bits).  dparticles (Np*3) must be zero-initialised. */
+int nf_render_features_bwd(const float* particles, const float* rays, const float* z, const float* z_table,
+                           int R, int S, float radius, int K, int enc_flags, const float* ro, int ro_per_ray,
+                           const int32_t* row_sample, const int32_t* row_nbr, const int32_t* n_rows, int max_rows,
+                           const float* dX, float* dparticles, nf_stream_t stream);
 int nf_render_feature_dims(int enc_flags, int* cx, int* cd, int* qx, int* qd);
 
 /* A6: NeRF MLP (models/nerf.py:83-124) on fp32 MFMA.  `packed` comes from nf_nerf_pack.

@@ -32,6 +32,8 @@ PROTOTYPES = {
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nf_render_features": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_int, c_void_p, c_int,
                                    c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "nf_render_features_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_int, c_void_p, c_int,
+                                       c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "nf_render_feature_dims": (c_int, [c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int),
                                        ctypes.POINTER(c_int)]),
     "nf_nerf_packed_floats": (c_size_t, [c_int, c_int]),

@@ -38,8 +38,9 @@ def _pack_bwd(nerf, cx, cd, dev):
     return out
 
 
-def _pass_backward(net, nerf, pb, rays_c, z, z_table, g_rgb, white_bg):
-    """Returns the 24 parameter gradients (12 weights, 12 biases) of one NeRF for one render pass."""
+def _pass_backward(net, nerf, pb, rays_c, z, z_table, g_rgb, white_bg, particles=None, ro_c=None, dparticles=None):
+    """Returns the 24 parameter gradients (12 weights, 12 biases) of one NeRF for one render pass; when
+    `dparticles` is given also accumulates dL/d(particle positions) into it (e2e training)."""
     lib = _lib.load()
     st = _lib.stream()
     dev = rays_c.device
@@ -81,6 +82,16 @@ def _pass_backward(net, nerf, pb, rays_c, z, z_table, g_rgb, white_bg):
     gw.append(Dsig.t() @ h8); gb.append(Dsig.sum(0))
     Drgb = dpre[:, 2432:2435]
     gw.append(Drgb.t() @ A[:, 9 * 256:9 * 256 + 128]); gb.append(Drgb.sum(0))
+    if dparticles is not None:
+        # dL/dX = W^T dpre for the three layers that read the feature matrix (plain GEMMs), then HIP scatter
+        W1, W5, Wd = layers[0].weight.detach(), layers[4].weight.detach(), layers[9].weight.detach()
+        dX = torch.empty(n, cx + cd, dtype=torch.float32, device=dev)
+        dX[:, :cx] = dpre[:, 0:256] @ W1 + dpre[:, 4 * 256:5 * 256] @ W5[:, :cx]
+        dX[:, cx:] = Ddir @ Wd[:, 256:]
+        check(lib.nf_render_features_bwd(ptr(particles), ptr(rays_c), ptr(z), ptr(z_table), R, S, float(net.raduis),
+                                         net.num_neighbor, net.enc_flags, ptr(ro_c), int(ro_c.dim() == 2),
+                                         ptr(pb.row_sample), ptr(pb.row_nbr), ptr(pb.n_rows), n, ptr(dX), ptr(dparticles),
+                                         st), "nf_render_features_bwd")
     return gw + gb
 
 
@@ -90,6 +101,7 @@ class _RenderFn(torch.autograd.Function):
         p0, p1, rays_c, ro_c, grid = _run_passes(net, particles, ro, rays, white_bg, fine, save_acts=True)
         ctx.net, ctx.p0, ctx.p1, ctx.rays_c, ctx.white_bg, ctx.fine = net, p0, p1, rays_c, white_bg, fine
         ctx.particles_need_grad = particles.requires_grad
+        ctx.ro_c, ctx.pts = ro_c, grid.points
         res = _results(p0, p1)
         keys = ["rgb0", "depth0", "opacity0", "num_nn_0", "mask_0"]
         if fine:
@@ -102,18 +114,17 @@ class _RenderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *grads):
         net = ctx.net
-        if ctx.particles_need_grad:
-            raise NotImplementedError("gradient w.r.t. particle positions (e2e) is scheduled for the next round")
         g = dict(zip(ctx.keys, grads))
         z_table, _ = net._tables(ctx.rays_c.device)
-        zero = lambda nerf: [torch.zeros_like(p) for l in nerf.linear_layers() for p in ()]  # noqa: E731
-        gc = _pass_backward(net, net.nerf_coarse, ctx.p0, ctx.rays_c, None, z_table, g["rgb0"], ctx.white_bg) \
+        dpart = torch.zeros_like(ctx.pts) if ctx.particles_need_grad else None
+        extra = dict(particles=ctx.pts, ro_c=ctx.ro_c, dparticles=dpart)
+        gc = _pass_backward(net, net.nerf_coarse, ctx.p0, ctx.rays_c, None, z_table, g["rgb0"], ctx.white_bg, **extra) \
             if g.get("rgb0") is not None else [None] * 24
         if ctx.fine and g.get("rgb1") is not None:
-            gf = _pass_backward(net, net.nerf_fine, ctx.p1, ctx.rays_c, ctx.p1.z, None, g["rgb1"], ctx.white_bg)
+            gf = _pass_backward(net, net.nerf_fine, ctx.p1, ctx.rays_c, ctx.p1.z, None, g["rgb1"], ctx.white_bg, **extra)
         else:
             gf = [None] * 24
-        return (None, None, None, None, None, None) + tuple(gc) + tuple(gf)
+        return (None, dpart, None, None, None, None) + tuple(gc) + tuple(gf)
 
 
 def render_with_grad(net, particles, ro, rays, white_bg, fine):

@@ -532,3 +532,147 @@ extern "C" int nf_get_rays(int H, int W, float focal, const float* c2w, int row0
     NF_CHECK_LAUNCH();
     return NF_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// features backward (A12, e2e): dL/d(particles) from dL/d(feature row) through density, smoothed
+// position, variance and smoothed direction (the only particle-dependent columns; gradients reach the
+// particles ONLY through the gathered neighbour positions — `dists` is used in != 0 tests only and z is
+// detached, utils/ray_utils.py:224).  One thread per active row, float atomics into dparticles.
+// ------------------------------------------------------------------------------------------------
+template <int C, int NF>
+__device__ __forceinline__ void pe_backward(const float* __restrict__ g, const float (&v)[C], float (&dv)[C])
+{
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        float acc = g[c];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            const float fr = (float)(1 << f);
+            float s, co;
+            sincosf(fr * v[c], &s, &co);
+            acc += fr * (g[C * (1 + 2 * f) + c] * co - g[C * (2 + 2 * f) + c] * s);
+        }
+        dv[c] = acc;
+    }
+}
+
+template <int FLAGS>
+__global__ void __launch_bounds__(128) k_features_bwd(const float* __restrict__ particles, const float* __restrict__ rays,
+                                                      const float* __restrict__ z, const float* __restrict__ z_table,
+                                                      int S, float radius, int K, const float* __restrict__ ro_base,
+                                                      int ro_stride, const int* __restrict__ row_sample,
+                                                      const int* __restrict__ row_nbr, const int* __restrict__ n_rows,
+                                                      int max_rows, const float* __restrict__ dX /*row-major*/,
+                                                      float* __restrict__ dparticles)
+{
+    constexpr int CX = 63 + ((FLAGS & 1) ? 9 : 0) + ((FLAGS & 2) ? 63 : 0) + ((FLAGS & 4) ? 63 : 0);
+    constexpr int CD = 27 + ((FLAGS & 8) ? 27 : 0);
+    constexpr int OFF_DEN = 63, OFF_SM = OFF_DEN + ((FLAGS & 1) ? 9 : 0), OFF_VAR = OFF_SM + ((FLAGS & 2) ? 63 : 0);
+    constexpr int OFF_SDIR = CX + 27;
+    int nrows = min(*n_rows, max_rows);
+    for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < nrows; row += gridDim.x * blockDim.x) {
+        int sample = row_sample[row];
+        float px[3], zv;
+        sample_xyz(rays, z, z_table, S, sample, px[0], px[1], px[2], zv);
+        const float* ro = ro_base + (size_t)ro_stride * (sample / S);
+        const float* g = dX + (size_t)row * (CX + CD);
+        // ---- forward recompute
+        float sw = 0.f, swp[3] = {0.f, 0.f, 0.f}, sd[3] = {0.f, 0.f, 0.f};
+        int nvalid = 0;
+        for (int k = 0; k < K; ++k) {
+            int j = row_nbr[(size_t)row * K + k];
+            float n[3] = {0.f, 0.f, 0.f};
+            bool valid = false;
+            if (j >= 0) {
+                n[0] = particles[3 * (size_t)j]; n[1] = particles[3 * (size_t)j + 1]; n[2] = particles[3 * (size_t)j + 2];
+                valid = nf_dist2(px[0], px[1], px[2], n[0], n[1], n[2]) != 0.f;
+            }
+            float d[3] = {n[0] - px[0], n[1] - px[1], n[2] - px[2]};
+            float t = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) / radius;
+            float w = fmaxf(1.f - t * t * t, 0.f);
+            sw += w; swp[0] += w * n[0]; swp[1] += w * n[1]; swp[2] += w * n[2];
+            if (valid) { sd[0] += d[0]; sd[1] += d[1]; sd[2] += d[2]; ++nvalid; }
+        }
+        const float den = sw + 1e-12f, nn_f = (float)nvalid + 1e-12f;
+        float sm[3] = {swp[0] / den, swp[1] / den, swp[2] / den};
+        float mean[3] = {sd[0] / nn_f, sd[1] / nn_f, sd[2] / nn_f};
+        float var[3] = {0.f, 0.f, 0.f}, resid[3] = {0.f, 0.f, 0.f};
+        if (FLAGS & 4)
+            for (int k = 0; k < K; ++k) {
+                int j = row_nbr[(size_t)row * K + k];
+                if (j < 0) continue;
+                float n[3] = {particles[3 * (size_t)j], particles[3 * (size_t)j + 1], particles[3 * (size_t)j + 2]};
+                if (nf_dist2(px[0], px[1], px[2], n[0], n[1], n[2]) == 0.f) continue;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { float e = (n[c] - px[c]) - mean[c]; var[c] += e * e; resid[c] += e; }
+            }
+        var[0] /= nn_f; var[1] /= nn_f; var[2] /= nn_f;
+        // ---- gradients of the scalar/vector features
+        float d_den = 0.f, d_sm[3] = {0.f, 0.f, 0.f}, d_var[3] = {0.f, 0.f, 0.f};
+        if (FLAGS & 1) { float v1[1] = {sw}, o1[1]; pe_backward<1, 4>(g + OFF_DEN, v1, o1); d_den = o1[0]; }
+        if (FLAGS & 2) pe_backward<3, 10>(g + OFF_SM, sm, d_sm);
+        if (FLAGS & 4) pe_backward<3, 10>(g + OFF_VAR, var, d_var);
+        if (FLAGS & 8) {
+            float u[3] = {sm[0] - ro[0], sm[1] - ro[1], sm[2] - ro[2]};
+            float nu = sqrtf(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+            float sdir[3] = {u[0] / nu, u[1] / nu, u[2] / nu}, d_sdir[3];
+            pe_backward<3, 4>(g + OFF_SDIR, sdir, d_sdir);
+            float dot = sdir[0] * d_sdir[0] + sdir[1] * d_sdir[1] + sdir[2] * d_sdir[2];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) d_sm[c] += (d_sdir[c] - sdir[c] * dot) / nu;
+        }
+        // sm = N / den, density = sw
+        float dN[3] = {d_sm[0] / den, d_sm[1] / den, d_sm[2] / den};
+        float d_sw = d_den - (d_sm[0] * sm[0] + d_sm[1] * sm[1] + d_sm[2] * sm[2]) / den;
+        // ---- scatter to the neighbours
+        for (int k = 0; k < K; ++k) {
+            int j = row_nbr[(size_t)row * K + k];
+            if (j < 0) continue;
+            float n[3] = {particles[3 * (size_t)j], particles[3 * (size_t)j + 1], particles[3 * (size_t)j + 2]};
+            float d[3] = {n[0] - px[0], n[1] - px[1], n[2] - px[2]};
+            float dist = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+            float t = dist / radius;
+            float w = fmaxf(1.f - t * t * t, 0.f);
+            float dw = dN[0] * n[0] + dN[1] * n[1] + dN[2] * n[2] + d_sw;
+            // dw/dn = -3 t^2 / radius * d/dist  (w > 0), written without the division by dist
+            float coef = (1.f - t * t * t) > 0.f ? dw * (-3.f * dist / (radius * radius * radius)) : 0.f;
+            float gp[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) gp[c] = w * dN[c] + coef * d[c];
+            if ((FLAGS & 4) && nf_dist2(px[0], px[1], px[2], n[0], n[1], n[2]) != 0.f) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    gp[c] += d_var[c] * (2.f / nn_f) * ((d[c] - mean[c]) - resid[c] / nn_f);
+            }
+            atomicAdd(dparticles + 3 * (size_t)j, gp[0]);
+            atomicAdd(dparticles + 3 * (size_t)j + 1, gp[1]);
+            atomicAdd(dparticles + 3 * (size_t)j + 2, gp[2]);
+        }
+    }
+}
+
+extern "C" int nf_render_features_bwd(const float* particles, const float* rays, const float* z, const float* z_table,
+                                      int R, int S, float radius, int K, int enc_flags, const float* ro, int ro_per_ray,
+                                      const int32_t* row_sample, const int32_t* row_nbr, const int32_t* n_rows,
+                                      int max_rows, const float* dX, float* dparticles, nf_stream_t stream)
+{
+    NF_CHECK_ARG(particles && rays && (z || z_table) && ro && row_sample && row_nbr && n_rows && dX && dparticles,
+                 "null pointer");
+    NF_CHECK_ARG(enc_flags >= 0 && enc_flags < 16, "bad enc_flags");
+    if (max_rows <= 0) return NF_OK;
+    int blocks = (max_rows + 127) / 128;
+    if (blocks > 4096) blocks = 4096;
+    hipStream_t st = (hipStream_t)stream;
+#define NF_FB_CASE(F)                                                                                                   \
+    case F:                                                                                                             \
+        hipLaunchKernelGGL(k_features_bwd<F>, dim3(blocks), dim3(128), 0, st, particles, rays, z, z_table, S, radius, K, ro, \
+                           ro_per_ray ? 3 : 0, row_sample, row_nbr, n_rows, max_rows, dX, dparticles);                   \
+        break;
+    switch (enc_flags) {
+        NF_FB_CASE(0) NF_FB_CASE(1) NF_FB_CASE(2) NF_FB_CASE(3) NF_FB_CASE(4) NF_FB_CASE(5) NF_FB_CASE(6) NF_FB_CASE(7)
+        NF_FB_CASE(8) NF_FB_CASE(9) NF_FB_CASE(10) NF_FB_CASE(11) NF_FB_CASE(12) NF_FB_CASE(13) NF_FB_CASE(14) NF_FB_CASE(15)
+    }
+#undef NF_FB_CASE
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}

@@ -326,3 +326,36 @@ def test_train_steps_run_and_learn(dev):
         losses.append(float(renderer_train_step(net, opt, sched, P, views, H, W, 0, 1024, 500, rng)))
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
     assert abs(opt.param_groups[0]["lr"] - 5e-4 * 0.1 ** (6 / 10000)) < 1e-9
+
+
+def test_particle_gradients_vs_oracle_autograd(dev):
+    """A12 (e2e): dL/d(particle positions) through density / smoothed position / variance / smoothed direction vs torch
+    autograd on the oracle (coarse pass: the sample set does not depend on the fine resampling)."""
+    from oracle import render_oracle as ro
+    g = load_golden("c1_trainstep")
+    net = make_net(dev)
+    for p in net.parameters():
+        p.requires_grad_(False)
+    P = T(g["particles"], dev).clone().requires_grad_(True)
+    rays, tgt = T(g["rays"], dev), T(g["target"], dev)
+    roc = T(load_golden("a10_forward")["ro"], dev)
+    out = net.coarse_rendering(P, roc, rays)
+    torch.nn.functional.mse_loss(out["rgb0"], tgt).backward()
+    got = P.grad.cpu()
+    # oracle: same neighbour sets (indices are data), differentiable gather
+    Pc = T(g["particles"]).clone().requires_grad_(True)
+    st = ro.deterministic_nerf_state()
+    rc = rays.cpu()
+    z0, xyz0 = ro.coarse_sample_ray(9.0, 13.0, rc, 64)
+    dists, idx, _ = ro.search(xyz0, Pc.detach(), 0.225, 20)
+    nn = torch.where((idx >= 0).unsqueeze(-1), Pc[idx.clamp(min=0)], torch.zeros(1))
+    feats, _ = ro.embedding_local_geometry(dists, nn, 0.225, xyz0, rc, roc.cpu())
+    rs = ro.nerf_forward(st, "nerf_coarse", feats, 198, 54).view(-1, 64, 4) * torch.all(dists != 0, -1, keepdim=True).float()
+    rgb, _, _ = ro.render_image(rs, z0, rc, True)
+    torch.nn.functional.mse_loss(rgb, tgt.cpu()).backward()
+    ref = Pc.grad
+    assert float(ref.abs().max()) > 1e-6
+    rel = float((got - ref).norm() / ref.norm())
+    assert rel < 5e-3, rel
+    touched = ref.abs().sum(1) > 0
+    assert torch.equal(touched, got.abs().sum(1) > 0)

@@ -165,6 +165,7 @@ int nf_trans_update(const float* pos, const float* pos_new, const float* y3, flo
  * (inp_positions, out_positions) pair (the reference recomputes it inside each of its 5 convs). */
 int nf_cconv_pairs(const float* inp_pos, const float* out_pos, const int64_t* row_splits, const int32_t* nbr,
                    const float* dist2, int n_out, float extent, int use_window,
+                   int negate /*1: relative position negated = the pair as seen from the neighbour (backward)*/,
                    float* pair_w /*nnz*8*/, uint8_t* pair_cell /*nnz*8*/, nf_stream_t stream);
 
 /* B4 for Cin in {3,4}, Cout = 32 (conv0_fluid, conv0_obstacle; models/transmodel.py:116,:118):
@@ -185,6 +186,22 @@ int nf_cconv_transform(const float* A, int M, int cin, int cout, int relu, const
 int nf_cconv_gather(const float* G, int cout, const int64_t* row_splits, const int32_t* nbr, const float* pair_w,
                     const uint8_t* pair_cell, const float* bias_conv, const float* bias_dense,
                     const float* residual /*n_out*Cout or NULL*/, int n_out, float* out, nf_stream_t stream);
+
+/* B8: backward of the continuous convolutions.  Open3D differentiates continuous_conv w.r.t. filter and input
+ * features only (not positions); the reference trains through it at trainer/trainer_e2e.py:277.
+ * nf_cconv_gather_bwd: dG (n x 65*Cout) from dy (n x Cout) with the TRANSPOSED pair cache (nf_cconv_pairs negate=1;
+ *   fluid<->fluid neighbourhoods are symmetric, so the forward CSR serves both directions).  The caller then does
+ *   the plain GEMMs  d[filter|dense_w] = x^T dG  and  dx = dG [filter|dense_w]^T.
+ * nf_cconv_small_bwd_filter / _feat: filter / input-feature gradient of the direct Cin<=4 convs (dkernel must be
+ *   zero-initialised; float atomics). */
+int nf_cconv_gather_bwd(const float* dy, int cout, const int64_t* row_splits, const int32_t* nbr,
+                        const float* pair_w_t, const uint8_t* pair_cell_t, int n, float* dG, nf_stream_t stream);
+int nf_cconv_small_bwd_filter(const float* feats, int cin, const int64_t* row_splits, const int32_t* nbr,
+                              const float* pair_w, const uint8_t* pair_cell, const float* dy, int ld_dy, int col_off,
+                              int n_out, float* dkernel /*64*cin*32*/, nf_stream_t stream);
+int nf_cconv_small_bwd_feat(const float* kernel, int cin, const int64_t* row_splits, const int32_t* nbr,
+                            const float* pair_w_t, const uint8_t* pair_cell_t, const float* dy, int ld_dy, int col_off,
+                            int n, float* dfeat /*n*cin*/, nf_stream_t stream);
 
 #ifdef __cplusplus
 }

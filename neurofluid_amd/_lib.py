@@ -49,7 +49,10 @@ PROTOTYPES = {
                                 c_void_p, c_void_p]),
     "nf_trans_integrate": (c_int, [c_void_p, c_void_p, ctypes.POINTER(c_float), c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nf_trans_update": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p]),
-    "nf_cconv_pairs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p]),
+    "nf_cconv_pairs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "nf_cconv_gather_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "nf_cconv_small_bwd_filter": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "nf_cconv_small_bwd_feat": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "nf_cconv_small": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "nf_cconv_transform": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

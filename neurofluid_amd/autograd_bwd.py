@@ -134,6 +134,99 @@ def render_with_grad(net, particles, ro, rays, white_bg, fine):
     return dict(zip(keys, outs))
 
 
+# ================================================================================================
+# transition model (B8)
+# ================================================================================================
+def _pn_params(pn):
+    ps = [pn.conv0_fluid.kernel, pn.conv0_fluid.bias, pn.conv0_obstacle.kernel, pn.conv0_obstacle.bias,
+          pn.dense0_fluid.weight, pn.dense0_fluid.bias]
+    for conv, dense in zip(pn.convs, pn.denses):
+        ps += [conv.kernel, conv.bias, dense.weight, dense.bias]
+    return ps
+
+
+def _virtual_b(kernel, dense_w):
+    """[filter as (Cin x 64*Cout) | dense_w^T] — the B operand of nf_cconv_transform, materialised for the GEMMs."""
+    cin, cout = kernel.shape[-2], kernel.shape[-1]
+    kf = kernel.detach().reshape(64, cin, cout).permute(1, 0, 2).reshape(cin, 64 * cout)
+    return torch.cat([kf, dense_w.detach().t()], dim=1)
+
+
+class _ParticleNetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pn, pos, vel, box, box_feats, *params):
+        pos_c, vel_c, nn, aux = pn._forward_impl(pos, vel, box, box_feats, keep=True)
+        ctx.pn, ctx.aux = pn, aux
+        ctx.box, ctx.box_feats = box.detach().contiguous().float(), box_feats.detach().contiguous().float()
+        ctx.in_grad = (pos.requires_grad, vel.requires_grad)
+        ctx.mark_non_differentiable(nn)
+        return pos_c, vel_c, nn
+
+    @staticmethod
+    def backward(ctx, g_pos, g_vel, _g_nn):
+        from .transmodel import cconv_pairs
+        pn, aux = ctx.pn, ctx.aux
+        lib = _lib.load()
+        st = _lib.stream()
+        dt = float(pn.time_step)
+        ans = aux["ans"]
+        f_rs, f_idx, f_pw, f_pc = aux["f"]
+        b_rs, b_idx, b_pw, b_pc = aux["b"]
+        n = ans[0].shape[0]
+        dev = ans[0].device
+        d_pos_c = torch.zeros(n, 3, device=dev) if g_pos is None else g_pos.detach().float().clone()
+        if g_vel is not None:
+            d_pos_c = d_pos_c + g_vel.detach().float() / dt          # vel_c = (pos_c - pos) / dt
+        extent = float(pn.filter_extent)
+        f_d2 = pn.conv0_fluid.nns.neighbors_distance
+        nnz = f_idx.shape[0]
+        # the fluid<->fluid pairs as seen from the neighbour (transposed operator), once for all layers
+        t_pw, t_pc = cconv_pairs(aux["pos_new"], aux["pos_new"], f_rs, f_idx, f_d2, extent, pn.use_window, negate=True)
+        dy = (d_pos_c * (1.0 / 128)).contiguous()                    # pos_correction = y3 / 128
+        grads = {}
+        for li in (3, 2, 1):
+            conv, dense = pn.convs[li - 1], pn.denses[li - 1]
+            prev = ans[li - 1]
+            cout = conv.kernel.shape[-1]
+            x = torch.relu(prev)
+            dG = torch.empty(n, 65 * cout, dtype=torch.float32, device=dev)
+            check(lib.nf_cconv_gather_bwd(ptr(dy), cout, ptr(f_rs), ptr(f_idx), ptr(t_pw), ptr(t_pc), n, ptr(dG), st),
+                  "nf_cconv_gather_bwd")
+            dB = x.t() @ dG                                          # (Cin, 65*Cout) plain GEMM
+            cin = x.shape[1]
+            grads[conv.kernel] = dB[:, :64 * cout].reshape(cin, 64, cout).permute(1, 0, 2).reshape(conv.kernel.shape)
+            grads[dense.weight] = dB[:, 64 * cout:].t().contiguous()
+            grads[conv.bias] = dy.sum(0)
+            grads[dense.bias] = dy.sum(0)
+            dx = dG @ _virtual_b(conv.kernel, dense.weight).t()      # (n, Cin) plain GEMM
+            dprev = dx * (prev > 0).float()
+            if dense.out_features == prev.shape[-1]:
+                dprev = dprev + dy                                   # residual branch (transmodel.py:127-128)
+            dy = dprev.contiguous()
+        # layer 0: dy is d[obstacle(32) | fluid(32) | dense0(32)]
+        ff = aux["fluid_feats"]
+        c0f, c0o, d0 = pn.conv0_fluid, pn.conv0_obstacle, pn.dense0_fluid
+        dKo = torch.zeros_like(c0o.kernel)
+        dKf = torch.zeros_like(c0f.kernel)
+        check(lib.nf_cconv_small_bwd_filter(ptr(ctx.box_feats), 3, ptr(b_rs), ptr(b_idx), ptr(b_pw), ptr(b_pc), ptr(dy), 96, 0,
+                                            n, ptr(dKo), st), "conv0_obstacle filter grad")
+        check(lib.nf_cconv_small_bwd_filter(ptr(ff), 4, ptr(f_rs), ptr(f_idx), ptr(f_pw), ptr(f_pc), ptr(dy), 96, 32, n,
+                                            ptr(dKf), st), "conv0_fluid filter grad")
+        grads[c0o.kernel], grads[c0f.kernel] = dKo, dKf
+        grads[c0o.bias], grads[c0f.bias] = dy[:, :32].sum(0), dy[:, 32:64].sum(0)
+        grads[d0.weight], grads[d0.bias] = dy[:, 64:].t() @ ff, dy[:, 64:].sum(0)
+        # input gradients (2-step unrolls, trainer_transmodel.py): through integrate/update and the velocity features
+        g_in_pos = g_in_vel = None
+        if ctx.in_grad[0]:
+            g_in_pos = d_pos_c - (g_vel.detach().float() / dt if g_vel is not None else 0.)
+        if ctx.in_grad[1]:
+            dfeat = torch.empty(n, 4, dtype=torch.float32, device=dev)
+            check(lib.nf_cconv_small_bwd_feat(ptr(c0f.kernel.detach().contiguous()), 4, ptr(f_rs), ptr(f_idx), ptr(t_pw),
+                                              ptr(t_pc), ptr(dy), 96, 32, n, ptr(dfeat), st), "conv0_fluid feature grad")
+            dfeat = dfeat + dy[:, 64:] @ d0.weight.detach()
+            g_in_vel = d_pos_c * dt + dfeat[:, 1:4]                 # pos_new = pos + vel dt + g dt^2/2 ; feats = [1, vel + g dt]
+        return (None, g_in_pos, g_in_vel, None, None) + tuple(grads[p] for p in _pn_params(pn))
+
+
 def particle_net_with_grad(pn, pos, vel, box, box_feats):
-    raise NotImplementedError("ParticleNet backward (train_e2e / train_transmodel) is scheduled for the next round; "
-                              "call under torch.no_grad() for rollouts")
+    return _ParticleNetFn.apply(pn, pos, vel, box, box_feats, *_pn_params(pn))

@@ -109,7 +109,7 @@ __device__ __forceinline__ void ball_to_cube(float& x, float& y, float& z)
 __global__ void __launch_bounds__(256) k_pair_precompute(const float* __restrict__ inp_pos, const float* __restrict__ out_pos,
                                                          const int64_t* __restrict__ row_splits,
                                                          const int32_t* __restrict__ nbr, const float* __restrict__ d2,
-                                                         int n_out, float extent, int use_window,
+                                                         int n_out, float extent, int use_window, int negate,
                                                          float* __restrict__ pw, uint8_t* __restrict__ pc)
 {
     int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -120,6 +120,7 @@ __global__ void __launch_bounds__(256) k_pair_precompute(const float* __restrict
     for (int64_t p = row_splits[row] + lane; p < row_splits[row + 1]; p += 64) {
         int j = nbr[p];
         float x = (inp_pos[3 * j] - ox) * scale, y = (inp_pos[3 * j + 1] - oy) * scale, z = (inp_pos[3 * j + 2] - oz) * scale;
+        if (negate) { x = -x; y = -y; z = -z; }   // the same pair seen from the neighbour (transposed operator)
         ball_to_cube(x, y, z);
         float imp = 1.f;
         if (use_window) {  // _window_poly6(d2 / radius^2) = clamp((1-R)^3, 0, 1)   (models/transmodel.py:73-77)
@@ -147,14 +148,14 @@ __global__ void __launch_bounds__(256) k_pair_precompute(const float* __restrict
 }
 
 extern "C" int nf_cconv_pairs(const float* inp_pos, const float* out_pos, const int64_t* row_splits, const int32_t* nbr,
-                              const float* dist2, int n_out, float extent, int use_window, float* pair_w,
+                              const float* dist2, int n_out, float extent, int use_window, int negate, float* pair_w,
                               uint8_t* pair_cell, nf_stream_t stream)
 {
     NF_CHECK_ARG(inp_pos && out_pos && row_splits && pair_w && pair_cell, "null pointer");
     NF_CHECK_ARG(extent > 0.f, "bad extent");
     if (n_out <= 0) return NF_OK;
     hipLaunchKernelGGL(k_pair_precompute, dim3((n_out + 3) / 4), dim3(256), 0, (hipStream_t)stream, inp_pos, out_pos,
-                       row_splits, nbr, dist2, n_out, extent, use_window, pair_w, pair_cell);
+                       row_splits, nbr, dist2, n_out, extent, use_window, negate, pair_w, pair_cell);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }
@@ -392,6 +393,185 @@ extern "C" int nf_cconv_gather(const float* G, int cout, const int64_t* row_spli
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(k_cconv_gather, dim3(blocks), dim3(256), 0, (hipStream_t)stream, G, cout, row_splits, nbr, pair_w,
                        pair_cell, bias_conv, bias_dense, residual, n_out, out);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+
+// ================================================================================================
+// backward (B8).  Open3D's continuous_conv is differentiated w.r.t. filter and input features only (not
+// positions); the weight/feature GEMMs are plain GEMMs done by the caller (library GEMM), the neighbour-
+// dependent parts are these kernels.
+// ================================================================================================
+
+// dG[j][cell][co] = sum over entries (j <- i) of the TRANSPOSED pair cache: tpw * dy[i][co]   (fluid<->fluid is
+// symmetric: i in N(j) <=> j in N(i), so row j of the same CSR lists exactly the rows i that gathered from j; the
+// transposed cache holds the pair's interpolation data as seen from i).  dG[j][64][co] = dy[j][co] (Linear branch).
+// One wave per row, a private 64 x Cout tile in LDS, no atomics, deterministic.
+__global__ void __launch_bounds__(256) k_cconv_gather_t(const float* __restrict__ dy, int cout,
+                                                        const int64_t* __restrict__ row_splits,
+                                                        const int32_t* __restrict__ nbr, const float* __restrict__ tpw,
+                                                        const uint8_t* __restrict__ tpc, int n, float* __restrict__ dG)
+{
+    extern __shared__ float tile_all[];
+    __shared__ int s_j[4][64];
+    __shared__ float s_w[4][64 * 8];
+    __shared__ int s_c[4][64 * 8];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float* tile = tile_all + wv * 64 * cout;
+    const int ntot = 65 * cout;
+    for (int row = blockIdx.x * 4 + wv; row < n; row += gridDim.x * 4) {
+        for (int t = lane; t < 64 * cout; t += 64) tile[t] = 0.f;
+        __builtin_amdgcn_wave_barrier();
+        int64_t s = row_splits[row], e = row_splits[row + 1];
+        for (int64_t base = s; base < e; base += 64) {
+            int cnt = (int)((e - base) < 64 ? (e - base) : 64);
+            if (lane < cnt) {
+                int64_t p = base + lane;
+                s_j[wv][lane] = nbr[p];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { s_w[wv][lane * 8 + k] = tpw[p * 8 + k]; s_c[wv][lane * 8 + k] = tpc[p * 8 + k]; }
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            for (int co = lane; co < cout; co += 64)
+                for (int t = 0; t < cnt; ++t) {
+                    float g = dy[(size_t)s_j[wv][t] * cout + co];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) tile[s_c[wv][t * 8 + k] * cout + co] += s_w[wv][t * 8 + k] * g;
+                }
+            __builtin_amdgcn_wave_barrier();
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        float* out = dG + (size_t)row * ntot;
+        for (int t = lane; t < 64 * cout; t += 64) out[t] = tile[t];
+        for (int co = lane; co < cout; co += 64) out[64 * cout + co] = dy[(size_t)row * cout + co];
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+extern "C" int nf_cconv_gather_bwd(const float* dy, int cout, const int64_t* row_splits, const int32_t* nbr,
+                                   const float* pair_w_t, const uint8_t* pair_cell_t, int n, float* dG, nf_stream_t stream)
+{
+    NF_CHECK_ARG(dy && row_splits && dG, "null pointer");
+    NF_CHECK_ARG(cout >= 1 && cout <= 64, "cout must be in [1,64]");
+    if (n <= 0) return NF_OK;
+    int blocks = (n + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    size_t lds = (size_t)4 * 64 * cout * sizeof(float);
+    hipLaunchKernelGGL(k_cconv_gather_t, dim3(blocks), dim3(256), lds, (hipStream_t)stream, dy, cout, row_splits, nbr,
+                       pair_w_t, pair_cell_t, n, dG);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+// filter gradient of the direct small-Cin conv: dK[cell][ci][co] += pw * feat[j][ci] * dy[i][col_off + co]
+// block-private accumulation in LDS (ds_add_f32), one flush of global float atomics per block.
+template <int CIN>
+__global__ void __launch_bounds__(256) k_cconv_small_bwd_filter(const float* __restrict__ feats,
+                                                                const int64_t* __restrict__ row_splits,
+                                                                const int32_t* __restrict__ nbr, const float* __restrict__ pw,
+                                                                const uint8_t* __restrict__ pc, const float* __restrict__ dy,
+                                                                int ld_dy, int col_off, int n_out, float* __restrict__ dK)
+{
+    __shared__ float acc[64 * CIN * 32];
+    for (int t = threadIdx.x; t < 64 * CIN * 32; t += 256) acc[t] = 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, co = lane & 31, half = lane >> 5;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < n_out; row += gridDim.x * 4) {
+        float g = dy[(size_t)row * ld_dy + col_off + co];
+        for (int64_t p = row_splits[row] + half; p < row_splits[row + 1]; p += 2) {
+            int j = nbr[p];
+            float fj[CIN];
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) fj[ci] = feats[(size_t)j * CIN + ci];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float wg = pw[p * 8 + k] * g;
+                float* a = acc + (int)pc[p * 8 + k] * CIN * 32 + co;
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) atomicAdd(a + ci * 32, wg * fj[ci]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 64 * CIN * 32; t += 256)
+        if (acc[t] != 0.f) atomicAdd(dK + t, acc[t]);
+}
+
+extern "C" int nf_cconv_small_bwd_filter(const float* feats, int cin, const int64_t* row_splits, const int32_t* nbr,
+                                         const float* pair_w, const uint8_t* pair_cell, const float* dy, int ld_dy,
+                                         int col_off, int n_out, float* dkernel, nf_stream_t stream)
+{
+    NF_CHECK_ARG(feats && row_splits && dy && dkernel, "null pointer");
+    NF_CHECK_ARG(cin == 3 || cin == 4, "cin must be 3 or 4");
+    if (n_out <= 0) return NF_OK;
+    int blocks = (n_out + 3) / 4;
+    if (blocks > 512) blocks = 512;
+    hipStream_t st = (hipStream_t)stream;
+    if (cin == 3)
+        hipLaunchKernelGGL(k_cconv_small_bwd_filter<3>, dim3(blocks), dim3(256), 0, st, feats, row_splits, nbr, pair_w,
+                           pair_cell, dy, ld_dy, col_off, n_out, dkernel);
+    else
+        hipLaunchKernelGGL(k_cconv_small_bwd_filter<4>, dim3(blocks), dim3(256), 0, st, feats, row_splits, nbr, pair_w,
+                           pair_cell, dy, ld_dy, col_off, n_out, dkernel);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+// feature gradient of the direct small-Cin conv (fluid<->fluid, transposed pair cache):
+// dfeat[j][ci] = sum_{entries (j <- i)} sum_corners tpw * sum_co K[tpc][ci][co] * dy[i][col_off + co]
+template <int CIN>
+__global__ void __launch_bounds__(256) k_cconv_small_bwd_feat(const float* __restrict__ kernel,
+                                                              const int64_t* __restrict__ row_splits,
+                                                              const int32_t* __restrict__ nbr, const float* __restrict__ tpw,
+                                                              const uint8_t* __restrict__ tpc, const float* __restrict__ dy,
+                                                              int ld_dy, int col_off, int n, float* __restrict__ dfeat)
+{
+    __shared__ float Ks[64 * CIN * 32];
+    for (int t = threadIdx.x; t < 64 * CIN * 32; t += 256) Ks[t] = kernel[t];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, co = lane & 31, half = lane >> 5;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < n; row += gridDim.x * 4) {
+        float acc[CIN];
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) acc[ci] = 0.f;
+        for (int64_t p = row_splits[row] + half; p < row_splits[row + 1]; p += 2) {
+            float g = dy[(size_t)nbr[p] * ld_dy + col_off + co];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float wg = tpw[p * 8 + k] * g;
+                const float* kc = Ks + (int)tpc[p * 8 + k] * CIN * 32 + co;
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) acc[ci] += wg * kc[ci * 32];
+            }
+        }
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) {
+            float v = acc[ci];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0) dfeat[(size_t)row * CIN + ci] = v;
+        }
+    }
+}
+
+extern "C" int nf_cconv_small_bwd_feat(const float* kernel, int cin, const int64_t* row_splits, const int32_t* nbr,
+                                       const float* pair_w_t, const uint8_t* pair_cell_t, const float* dy, int ld_dy,
+                                       int col_off, int n, float* dfeat, nf_stream_t stream)
+{
+    NF_CHECK_ARG(kernel && row_splits && dy && dfeat, "null pointer");
+    NF_CHECK_ARG(cin == 3 || cin == 4, "cin must be 3 or 4");
+    if (n <= 0) return NF_OK;
+    int blocks = (n + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    hipStream_t st = (hipStream_t)stream;
+    if (cin == 3)
+        hipLaunchKernelGGL(k_cconv_small_bwd_feat<3>, dim3(blocks), dim3(256), 0, st, kernel, row_splits, nbr, pair_w_t,
+                           pair_cell_t, dy, ld_dy, col_off, n, dfeat);
+    else
+        hipLaunchKernelGGL(k_cconv_small_bwd_feat<4>, dim3(blocks), dim3(256), 0, st, kernel, row_splits, nbr, pair_w_t,
+                           pair_cell_t, dy, ld_dy, col_off, n, dfeat);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }

@@ -49,13 +49,13 @@ class ContinuousConv(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------------
-def cconv_pairs(inp_pos, out_pos, row_splits, nbr, d2, extent, use_window=True):
+def cconv_pairs(inp_pos, out_pos, row_splits, nbr, d2, extent, use_window=True, negate=False):
     lib = _lib.load()
     nnz = nbr.shape[0]
     pw = torch.empty(max(nnz, 1) * 8, dtype=torch.float32, device=inp_pos.device)
     pc = torch.empty(max(nnz, 1) * 8, dtype=torch.uint8, device=inp_pos.device)
     check(lib.nf_cconv_pairs(ptr(inp_pos), ptr(out_pos), ptr(row_splits), ptr(nbr), ptr(d2), out_pos.shape[0],
-                             float(extent), int(use_window), ptr(pw), ptr(pc), _lib.stream()), "nf_cconv_pairs")
+                             float(extent), int(use_window), int(negate), ptr(pw), ptr(pc), _lib.stream()), "nf_cconv_pairs")
     return pw, pc
 
 
@@ -146,7 +146,8 @@ class ParticleNet(nn.Module):
     def forward(self, pos, vel, box, box_feats, feats=None, fixed_radius_search_hash_table=None):
         if feats is not None:
             raise NotImplementedError("other feats are never passed by the reference callers")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        if torch.is_grad_enabled() and (pos.requires_grad or vel.requires_grad or
+                                        any(p.requires_grad for p in self.parameters())):
             from .autograd_bwd import particle_net_with_grad
             return particle_net_with_grad(self, pos, vel, box, box_feats)
         with torch.no_grad():

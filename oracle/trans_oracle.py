@@ -113,7 +113,8 @@ def trilinear(coords, size=KSIZE):
 
 # --------------------------------------------------------------------------------------------
 def radius_search(points, queries, radius, ignore_query_point=True):
-    idx, rs, d2 = neighbors.fixed_radius_search(points.numpy(), queries.numpy(), radius, ignore_query_point)
+    idx, rs, d2 = neighbors.fixed_radius_search(points.detach().numpy(), queries.detach().numpy(), radius,
+                                                ignore_query_point)
     return torch.from_numpy(idx), torch.from_numpy(rs), torch.from_numpy(d2)
 
 
@@ -125,7 +126,8 @@ def cconv(feats, inp_pos, out_pos, extent, kernel, bias, nbr_idx, row_splits, d2
     rows = torch.repeat_interleave(torch.arange(n_out), counts)
     nbr = nbr_idx.to(torch.int64)
     radius = 0.5 * extent
-    rel = inp_pos[nbr] - out_pos[rows]
+    # Open3D's continuous_conv has gradients w.r.t. filter and input features only: the geometry is detached
+    rel = inp_pos.detach()[nbr] - out_pos.detach()[rows]
     imp = window_poly6(d2 / (radius * radius)) if use_window else torch.ones_like(d2)
     cell, w = trilinear(filter_coordinates(rel, extent))
     # G[j, cell, :] = feats[j] @ kernel[cell]  (transform-then-gather; equal to Open3D's

@@ -94,3 +94,42 @@ def test_edge_cases(dev):
         rp, rv, rn = to.particle_net_forward(st, P, V, box, bn)
         assert torch.equal(n.cpu(), rn)
         torch.testing.assert_close(p.cpu(), rp, rtol=0, atol=1e-6)
+
+
+def _oracle_state_with_grad():
+    from oracle import trans_oracle as to
+    st = to.deterministic_transition_state()
+    return {k: (v.clone().requires_grad_(True) if (k.endswith("kernel") or k.endswith("bias") or k.endswith("weight")) else v)
+            for k, v in st.items()}
+
+
+def test_particle_net_backward_vs_oracle_autograd(dev):
+    """B8: parameter gradients of one transition step (loss on predicted positions, like trainer_e2e.py:255-259)
+    vs torch autograd through the oracle; plus the input (pos, vel) gradients used by 2-step unrolls."""
+    from oracle import render_oracle as ro, trans_oracle as to
+    pn, _ = make_pn(dev)
+    P = ro.watercube_particles()[::2].contiguous()
+    V = torch.randn(P.shape, generator=torch.Generator().manual_seed(2)) * 0.2
+    box, bn = to.watercube_box()
+    tgt = P + 0.01 * torch.randn(P.shape, generator=torch.Generator().manual_seed(3))
+    Pd, Vd = P.to(dev).requires_grad_(True), V.to(dev).requires_grad_(True)
+    p, v, n = pn(Pd, Vd, box.to(dev), bn.to(dev))
+    loss = ((p - tgt.to(dev)) ** 2).sum() + 0.01 * (v ** 2).sum()
+    loss.backward()
+    st = _oracle_state_with_grad()
+    Po, Vo = P.clone().requires_grad_(True), V.clone().requires_grad_(True)
+    rp, rv, rn = to.particle_net_forward(st, Po, Vo, box, bn)
+    lo = ((rp - tgt) ** 2).sum() + 0.01 * (rv ** 2).sum()
+    lo.backward()
+    assert abs(float(loss.detach()) - float(lo.detach())) <= 1e-4 * abs(float(lo.detach()))
+    worst = 0.0
+    for name, prm in pn.named_parameters():
+        ref = st[name].grad
+        assert ref is not None and float(ref.norm()) > 0, name
+        rel = float((prm.grad.cpu() - ref).norm() / ref.norm())
+        worst = max(worst, rel)
+        assert rel < 2e-3, (name, rel)
+    for got, ref, nm in ((Pd.grad, Po.grad, "pos"), (Vd.grad, Vo.grad, "vel")):
+        rel = float((got.cpu() - ref).norm() / ref.norm())
+        assert rel < 2e-3, (nm, rel)
+    print("worst relative parameter-gradient error", worst)

@@ -6,7 +6,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libneurofluid_hip.so")
+LIB_PATH = os.environ.get("NF_LIB_PATH", os.path.join(_HERE, "lib", "libneurofluid_hip.so"))   # env override: A/B kernel experiments
 
 c_void_p, c_int, c_float, c_size_t, c_int64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_int64
 

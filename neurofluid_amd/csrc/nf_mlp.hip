@@ -17,6 +17,7 @@
 //    per sample scatters (r,g,b,sigma) to the dense per-sample array.
 #include "nf_common.h"
 #include <math.h>
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -38,6 +39,8 @@ struct NfMlpLayout {
     int off_bdir;   // 128
     int off_bsig;   // 1
     int off_brgb;   // 3
+    int off_bstep[9];  // bias as one extra K-step per layer: [2][64][4], A = bias (lanes < 32) / 0, B operand = 1.0
+    int off_bstep_dir; // [64][4]
     int total;
 };
 
@@ -59,6 +62,8 @@ static NfMlpLayout mlp_layout(int cx, int cd)
     L.off_bdir = o; o += 128;
     L.off_bsig = o; o += 4;
     L.off_brgb = o; o += 4;
+    for (int l = 0; l < 9; ++l) { L.off_bstep[l] = o; o += 512; }
+    L.off_bstep_dir = o; o += 256;
     L.total = o;
     return L;
 }
@@ -78,6 +83,17 @@ __global__ void k_mlp_pack(NfMlpLayout L, NfNerfPtrs P, float* __restrict__ out)
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= L.total) return;
     float v = 0.f;
+    if (i >= L.off_bstep[0]) {   // bias K-steps
+        if (i >= L.off_bstep_dir) {
+            int k = i - L.off_bstep_dir, e = k & 3, lane = (k >> 2) & 63;
+            out[i] = lane < 32 ? P.b[9][32 * e + lane] : 0.f;
+        } else {
+            int l = (i - L.off_bstep[0]) / 512, k = (i - L.off_bstep[0]) % 512;
+            int e = k & 3, lane = (k >> 2) & 63, g = k >> 8;
+            out[i] = lane < 32 ? P.b[l][32 * (4 * g + e) + lane] : 0.f;
+        }
+        return;
+    }
     // biases
     if (i >= L.off_b[0]) {
         if (i >= L.off_brgb) { int k = i - L.off_brgb; v = k < 3 ? P.b[11][k] : 0.f; }
@@ -230,6 +246,14 @@ __device__ __forceinline__ void kloop_x8(const f32x4* __restrict__ wp /* + lane 
         step8(w[2], w[3], xv[1], acc);
         step8(w[4], w[5], xv[2], acc);
         step8(w[6], w[7], xv[3], acc);
+        if (q + 1 < nq) {   // one VMEM issue per MFMA shadow (see kloop_src)
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 23, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
         xv = xn;
 #pragma unroll
@@ -257,6 +281,14 @@ __device__ __forceinline__ void kloop_x4(const f32x4* __restrict__ wp, const f32
         step4(w[1], xv[1], acc);
         step4(w[2], xv[2], acc);
         step4(w[3], xv[3], acc);
+        if (q + 1 < nq) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 11, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
         xv = xn;
 #pragma unroll
@@ -385,6 +417,180 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(NfMlpLayout L, const float* __r
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// forward kernel, v2: double-buffered accumulators.  Layer l accumulates into one 128-register set while the
+// ReLU of the previous layer's set is applied ON THE FLY, one register per K-step, hidden behind the MFMAs;
+// the bias enters as one extra K-step (A = bias, B = 1, C = 0), so there is no per-layer VALU pass at all.
+// Weights are fetched 4 K-steps ahead (5-slot register ring).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bias_step8(const f32x4* __restrict__ p /* + lane */, f32x16 (&acc)[8])
+{
+    const f32x4 w0 = p[0], w1 = p[64];
+    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    acc[0] = MFMA32(w0[0], 1.f, z); acc[1] = MFMA32(w0[1], 1.f, z); acc[2] = MFMA32(w0[2], 1.f, z); acc[3] = MFMA32(w0[3], 1.f, z);
+    acc[4] = MFMA32(w1[0], 1.f, z); acc[5] = MFMA32(w1[1], 1.f, z); acc[6] = MFMA32(w1[2], 1.f, z); acc[7] = MFMA32(w1[3], 1.f, z);
+}
+
+__device__ __forceinline__ void bias_step4(const f32x4* __restrict__ p, f32x16 (&acc)[4])
+{
+    const f32x4 w0 = p[0];
+    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    acc[0] = MFMA32(w0[0], 1.f, z); acc[1] = MFMA32(w0[1], 1.f, z); acc[2] = MFMA32(w0[2], 1.f, z); acc[3] = MFMA32(w0[3], 1.f, z);
+}
+
+// dst += W * act(src), act = ReLU (RELU) or identity; NB = 8 or 4 output blocks.
+// SAVE: the activated values of `src` are stored row-major at save_row (training).
+template <bool RELU, int NB, bool SAVE>
+__device__ __forceinline__ void kloop_src(const f32x4* __restrict__ p /* + lane */, const f32x16 (&src)[8],
+                                          f32x16 (&dst)[NB], float* __restrict__ save_row, int h, bool row_ok)
+{
+    constexpr int G = NB / 4;          // float4 loads per step
+    constexpr int D = 4;               // prefetch distance in steps
+    f32x4 ring[D + 1][G];
+#pragma unroll
+    for (int s = 0; s < D; ++s)
+#pragma unroll
+        for (int g = 0; g < G; ++g) ring[s][g] = p[(s * G + g) * 64];
+    f32x16 cur, nxt;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cur[r] = RELU ? fmaxf(src[0][r], 0.f) : src[0][r];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int s = b * 16 + r;
+#ifndef NF_EXP_NOLOAD
+            if (s + D < 128) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) ring[(s + D) % (D + 1)][g] = p[((s + D) * G + g) * 64];
+            }
+#endif
+            if (b + 1 < 8) nxt[r] = RELU ? fmaxf(src[b + 1][r], 0.f) : src[b + 1][r];   // next block's operand, hidden
+            const float bv = cur[r];
+            const f32x4 w0 = ring[s % (D + 1)][0];
+            dst[0] = MFMA32(w0[0], bv, dst[0]); dst[1] = MFMA32(w0[1], bv, dst[1]);
+            dst[2] = MFMA32(w0[2], bv, dst[2]); dst[3] = MFMA32(w0[3], bv, dst[3]);
+            if (NB == 8) {
+                const f32x4 w1 = ring[s % (D + 1)][G - 1];
+                dst[NB - 4] = MFMA32(w1[0], bv, dst[NB - 4]); dst[NB - 3] = MFMA32(w1[1], bv, dst[NB - 3]);
+                dst[NB - 2] = MFMA32(w1[2], bv, dst[NB - 2]); dst[NB - 1] = MFMA32(w1[3], bv, dst[NB - 1]);
+            }
+#ifndef NF_EXP_NOSPREAD
+            // A VMEM issue costs ~55 cycles of the wave's issue slot: one per MFMA shadow (64 cycles), never two
+            // back to back (measured: adjacent load pairs idle the matrix pipe ~45 cycles per K-step).
+            if (s + D < 128) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, NB == 8 ? 3 : 3, 0);
+                if (NB == 8) {
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                }
+            }
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (SAVE && row_ok) {
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                f32x4 o = {cur[4 * rq], cur[4 * rq + 1], cur[4 * rq + 2], cur[4 * rq + 3]};
+                *(f32x4*)(save_row + 32 * b + 8 * rq + 4 * h) = o;
+            }
+        }
+        cur = nxt;
+    }
+}
+
+template <bool SAVE>
+__device__ __forceinline__ void mlp_layer(const NfMlpLayout& L, const f32x4* __restrict__ P4, int l, int lane, int h,
+                                          const f32x4* __restrict__ xt, const f32x16 (&src)[8], f32x16 (&dst)[8],
+                                          float* __restrict__ arow, bool row_ok)
+{
+    bias_step8(P4 + (L.off_bstep[l] >> 2) + lane, dst);
+    if (L.off_x[l] >= 0) kloop_x8(P4 + (L.off_x[l] >> 2) + lane, xt, L.qx, dst);
+    // the ReLU'd src IS the saved activation h_l (slot l-1)
+    kloop_src<true, 8, SAVE>(P4 + (L.off_h[l] >> 2) + lane, src, dst, SAVE ? arow + (l - 1) * 256 : nullptr, h, row_ok);
+}
+
+template <bool SAVE>
+__global__ void __launch_bounds__(256) k_mlp_fwd2(NfMlpLayout L, const float* __restrict__ packed,
+                                                  const float* __restrict__ X, const int* __restrict__ n_rows, int max_rows,
+                                                  const int* __restrict__ row_sample, float4* __restrict__ rgbsigma,
+                                                  float* __restrict__ acts)
+{
+    const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
+    const int gwave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    const int nrows = min(*n_rows, max_rows);
+    const int ntiles = (nrows + 31) >> 5;
+    const int Q = L.qx + L.qd;
+
+    for (int tile = gwave; tile < ntiles; tile += nwaves) {
+        const float* __restrict__ pk = packed + opaque_zero();
+        const f32x4* P4 = (const f32x4*)pk;
+        const f32x4* xt = (const f32x4*)X + (size_t)tile * Q * 64 + lane;
+        const int row = tile * 32 + j;
+        const bool row_ok = row < nrows;
+        float* arow = SAVE ? acts + (size_t)(row_ok ? row : 0) * NF_ACT_STRIDE : nullptr;
+        f32x16 accA[8], accB[8];
+
+        // layer 0 = xyz_encoding_1: bias step + feature-matrix K-steps
+        bias_step8(P4 + (L.off_bstep[0] >> 2) + lane, accA);
+        kloop_x8(P4 + (L.off_x[0] >> 2) + lane, xt, L.qx, accA);
+#pragma unroll 1
+        for (int l = 1; l < 9; l += 2) {
+            mlp_layer<SAVE>(L, P4, l, lane, h, xt, accA, accB, arow, row_ok);
+            if (l + 1 == 8) {  // sigma head reads h8 = relu(accB) before xyz_encoding_final consumes it
+                // (computed again inside the next layer's loop; 256 VALU ops per tile)
+            }
+            mlp_layer<SAVE>(L, P4, l + 1, lane, h, xt, accB, accA, arow, row_ok);
+        }
+        // after the loop: accA = xyz_encoding_final output (no activation), accB = pre-activation of layer 8 (h8 = relu)
+        float sigma;
+        {
+            const float* ws_ = pk + L.off_wsig;
+            float part = 0.f;
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float w0 = ws_[(b * 16 + r) * 2], w1 = ws_[(b * 16 + r) * 2 + 1];
+                    part += fmaxf(accB[b][r], 0.f) * (h ? w1 : w0);
+                }
+            sigma = part + __shfl_xor(part, 32, 64) + pk[L.off_bsig];
+        }
+        // view branch: hd = relu(W_dir [final | dir feats] + b); final is saved as activation slot 8
+        f32x16 hd[4];
+        bias_step4(P4 + (L.off_bstep_dir >> 2) + lane, hd);
+        kloop_x4(P4 + (L.off_dir_x >> 2) + lane, xt + L.qx * 64, L.qd, hd);
+        kloop_src<false, 4, SAVE>(P4 + (L.off_dir_h >> 2) + lane, accA, hd, SAVE ? arow + 8 * 256 : nullptr, h, row_ok);
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hd[b][r] = fmaxf(hd[b][r], 0.f);
+        if (SAVE && row_ok) save_frag<4>(hd, arow + 9 * 256, h);
+
+        const float* wr = pk + L.off_wrgb;
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = hd[b][r];
+                int k = (b * 16 + r) * 2;
+                c0 += v * (h ? wr[k + 1] : wr[k]);
+                c1 += v * (h ? wr[128 + k + 1] : wr[128 + k]);
+                c2 += v * (h ? wr[256 + k + 1] : wr[256 + k]);
+            }
+        c0 += __shfl_xor(c0, 32, 64); c1 += __shfl_xor(c1, 32, 64); c2 += __shfl_xor(c2, 32, 64);
+        c0 += pk[L.off_brgb]; c1 += pk[L.off_brgb + 1]; c2 += pk[L.off_brgb + 2];
+        if (h == 0 && row_ok) {
+            float4 o;
+            o.x = 1.f / (1.f + expf(-c0)); o.y = 1.f / (1.f + expf(-c1)); o.z = 1.f / (1.f + expf(-c2)); o.w = sigma;
+            rgbsigma[row_sample[row]] = o;
+        }
+    }
+}
+
 extern "C" int nf_nerf_mlp_fwd(const float* packed, int cx, int cd, const float* X, const int32_t* n_rows, int max_rows,
                                const int32_t* row_sample, float* rgbsigma, float* acts, nf_stream_t stream)
 {
@@ -396,12 +602,22 @@ extern "C" int nf_nerf_mlp_fwd(const float* packed, int cx, int cd, const float*
     int blocks = (tiles + 3) / 4;
     if (blocks > 256) blocks = 256;  // one 4-wave workgroup per CU, persistent over tiles
     hipStream_t st = (hipStream_t)stream;
-    if (acts)
-        hipLaunchKernelGGL(k_mlp_fwd<true>, dim3(blocks), dim3(256), 0, st, L, packed, X, n_rows, max_rows, row_sample,
-                           (float4*)rgbsigma, acts);
-    else
-        hipLaunchKernelGGL(k_mlp_fwd<false>, dim3(blocks), dim3(256), 0, st, L, packed, X, n_rows, max_rows, row_sample,
-                           (float4*)rgbsigma, acts);
+    static const bool use_v1 = getenv("NF_MLP_V1") != nullptr;   // A/B switch for profiling; v2 is the default
+    if (use_v1) {
+        if (acts)
+            hipLaunchKernelGGL(k_mlp_fwd<true>, dim3(blocks), dim3(256), 0, st, L, packed, X, n_rows, max_rows, row_sample,
+                               (float4*)rgbsigma, acts);
+        else
+            hipLaunchKernelGGL(k_mlp_fwd<false>, dim3(blocks), dim3(256), 0, st, L, packed, X, n_rows, max_rows, row_sample,
+                               (float4*)rgbsigma, acts);
+    } else {
+        if (acts)
+            hipLaunchKernelGGL(k_mlp_fwd2<true>, dim3(blocks), dim3(256), 0, st, L, packed, X, n_rows, max_rows, row_sample,
+                               (float4*)rgbsigma, acts);
+        else
+            hipLaunchKernelGGL(k_mlp_fwd2<false>, dim3(blocks), dim3(256), 0, st, L, packed, X, n_rows, max_rows, row_sample,
+                               (float4*)rgbsigma, acts);
+    }
     NF_CHECK_LAUNCH();
     return NF_OK;
 }

@@ -95,7 +95,8 @@ __device__ __forceinline__ float nf_madd_nofma(float o, float d, float z) { retu
 // first-K-by-index search core (used by nf_grid.hip: ball query op, nf_render.hip: fused search)
 // ------------------------------------------------------------------------------------------------
 #define BQ_BLOCK 128
-#define BQ_LDS_INTS(K) ((2 * (K) + 27) * BQ_BLOCK)   // K idx + K d2 + 27 cell keys per thread
+#define BQ_LDS_INTS(K) (((K) + 27) * BQ_BLOCK)   // K indices + 27 cell keys per thread (squared distances are not
+                                                  // kept: only "d2 != 0" per slot, as a bit mask in a register)
 
 // fp32 squared distance from a query to a cell's particle AABB, same op order as nf_dist2.  Because
 // fp32 sub/mul/add are monotone, box_d2 <= nf_dist2(query, p) for every particle p of the cell, so
@@ -127,33 +128,37 @@ __device__ __forceinline__ bool nf_any_cell_in_reach(const NfGridView& g, float 
     return false;
 }
 
-// Sorted insertion of (j, d2) into the per-thread ascending-by-index list held in LDS as
-// list[k * BQ_BLOCK + tid].  Returns the new count.
-__device__ __forceinline__ int firstk_insert(int* li, float* ld, int cnt, int K, int j, float d2, int tid)
+// Sorted insertion of index j into the per-thread ascending list held in LDS as list[k * BQ_BLOCK + tid];
+// `nzmask` bit k = (squared distance of slot k != 0) travels with the slots.  Returns the new count.
+__device__ __forceinline__ int firstk_insert(int* li, unsigned& nzmask, int cnt, int K, int j, bool nz, int tid)
 {
     int pos = cnt < K ? cnt : K - 1;  // slot that is overwritten / appended
     while (pos > 0 && li[(pos - 1) * BQ_BLOCK + tid] > j) {
         li[pos * BQ_BLOCK + tid] = li[(pos - 1) * BQ_BLOCK + tid];
-        ld[pos * BQ_BLOCK + tid] = ld[(pos - 1) * BQ_BLOCK + tid];
         --pos;
     }
     li[pos * BQ_BLOCK + tid] = j;
-    ld[pos * BQ_BLOCK + tid] = d2;
+    // bits [pos, K-1) shift up by one, bit pos takes `nz`, bits >= K are dropped
+    const unsigned low = nzmask & ((1u << pos) - 1u);
+    const unsigned high = (nzmask >> pos) << (pos + 1);
+    nzmask = (low | high | ((nz ? 1u : 0u) << pos)) & ((K >= 32) ? 0xffffffffu : ((1u << K) - 1u));
     return cnt < K ? cnt + 1 : K;
 }
 
 // First-K-by-index search.  Cells are index-sorted, so a cell's first entry is its minimum index.
 // Cells are visited in ascending order of that minimum (keys in LDS); once the list is full and the
 // smallest remaining key exceeds the current K-th index, no remaining particle can enter the list.
-// lk = 27 keys [c * BQ_BLOCK + tid].
+// Candidates are fetched 4 at a time (independent loads in flight) — entries past the break point can
+// never enter the list, so testing them is harmless.  lk = 27 keys [c * BQ_BLOCK + tid].  K <= 32.
 __device__ __forceinline__ int firstk_search(const NfGridView& g, float qx, float qy, float qz, float r2, int K,
-                                             int* li, float* ld, int* lk, int tid)
+                                             int* li, int* lk, int tid, unsigned& nzmask)
 {
     int cx = nf_cell_coord(qx, g.ox, g.icx, g.dx);
     int cy = nf_cell_coord(qy, g.oy, g.icy, g.dy);
     int cz = nf_cell_coord(qz, g.oz, g.icz, g.dz);
     const int BIG = 0x7fffffff;
     int nvalid = 0;
+    nzmask = 0u;
     for (int c = 0; c < 27; ++c) {
         int x = cx + (c % 3) - 1, y = cy + ((c / 3) % 3) - 1, z = cz + (c / 9) - 1;
         int key = BIG;
@@ -181,12 +186,19 @@ __device__ __forceinline__ int firstk_search(const NfGridView& g, float qx, floa
         int x = cx + (bc % 3) - 1, y = cy + ((bc / 3) % 3) - 1, z = cz + (bc / 9) - 1;
         int cell = (z * g.dy + y) * g.dx + x;
         int s = g.cell_start[cell], e = g.cell_start[cell + 1];
-        for (int t = s; t < e; ++t) {
-            float4 p = g.sorted_pos[t];
-            int j = __float_as_int(p.w);
-            if (cnt == K && j > li[(K - 1) * BQ_BLOCK + tid]) break;  // cell is index-sorted
-            float d2 = nf_dist2(qx, qy, qz, p.x, p.y, p.z);
-            if (d2 < r2) cnt = firstk_insert(li, ld, cnt, K, j, d2, tid);
+        bool done = false;
+        for (int t = s; t < e && !done; t += 4) {
+            float4 p[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) p[u] = g.sorted_pos[min(t + u, e - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (t + u >= e) break;
+                int j = __float_as_int(p[u].w);
+                if (cnt == K && j > li[(K - 1) * BQ_BLOCK + tid]) { done = true; break; }  // cell is index-sorted
+                float d2 = nf_dist2(qx, qy, qz, p[u].x, p[u].y, p[u].z);
+                if (d2 < r2) cnt = firstk_insert(li, nzmask, cnt, K, j, d2 != 0.f, tid);
+            }
         }
     }
     return cnt;

@@ -272,21 +272,21 @@ __global__ void __launch_bounds__(BQ_BLOCK) k_ball_query(const void* __restrict_
 {
     extern __shared__ int lds[];
     int* li = lds;
-    float* ld = (float*)(lds + K * BQ_BLOCK);
-    int* lk = lds + 2 * K * BQ_BLOCK;
+    int* lk = lds + K * BQ_BLOCK;
     int i = blockIdx.x * BQ_BLOCK + threadIdx.x;
     if (i >= nq) return;
     NfGridView g = nf_grid_view(ws);
     float qx = q[3 * i], qy = q[3 * i + 1], qz = q[3 * i + 2];
-    int cnt = firstk_search(g, qx, qy, qz, r2, K, li, ld, lk, threadIdx.x);
+    unsigned nzmask;
+    int cnt = firstk_search(g, qx, qy, qz, r2, K, li, lk, threadIdx.x, nzmask);
     for (int k = 0; k < K; ++k) {
         size_t o = (size_t)i * K + k;
         float d = 0.f, x = 0.f, y = 0.f, z = 0.f;
         int64_t j = -1;
         if (k < cnt) {
-            d = ld[k * BQ_BLOCK + threadIdx.x];
             j = li[k * BQ_BLOCK + threadIdx.x];
             x = pts[3 * j]; y = pts[3 * j + 1]; z = pts[3 * j + 2];
+            d = nf_dist2(qx, qy, qz, x, y, z);   // identical bits to the value tested during the search
         }
         dists2[o] = d;
         idx[o] = j;
@@ -298,7 +298,7 @@ extern "C" int nf_ball_query_firstk(const void* ws, const float* pts, const floa
                                     float* dists2, int64_t* idx, float* nn, nf_stream_t stream)
 {
     NF_CHECK_ARG(ws && pts && (nq == 0 || (queries && dists2 && idx)), "null pointer");
-    NF_CHECK_ARG(K >= 1 && K <= 64, "K must be in [1,64]");
+    NF_CHECK_ARG(K >= 1 && K <= 32, "K must be in [1,32]");
     NF_CHECK_ARG(radius > 0.f, "radius must be positive");
     if (nq == 0) return NF_OK;
     hipStream_t st = (hipStream_t)stream;

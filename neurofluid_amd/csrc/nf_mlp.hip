@@ -706,6 +706,90 @@ __device__ __forceinline__ void kloop_act8_from4(const f32x4* __restrict__ p, co
     }
 }
 
+// K-steps over a 4-block (128-feature) source fragment, 8 output blocks; same load discipline as kloop_src
+__device__ __forceinline__ void kloop_src4(const f32x4* __restrict__ p, const f32x16 (&src)[4], f32x16 (&dst)[8])
+{
+    constexpr int D = 4;
+    f32x4 ring[D + 1][2];
+#pragma unroll
+    for (int s = 0; s < D; ++s) { ring[s][0] = p[(s * 2) * 64]; ring[s][1] = p[(s * 2 + 1) * 64]; }
+#pragma unroll
+    for (int s = 0; s < 64; ++s) {
+        if (s + D < 64) { ring[(s + D) % (D + 1)][0] = p[((s + D) * 2) * 64]; ring[(s + D) % (D + 1)][1] = p[((s + D) * 2 + 1) * 64]; }
+        step8(ring[s % (D + 1)][0], ring[s % (D + 1)][1], src[s >> 4][s & 15], dst);
+        if (s + D < 64) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// Backward K-loop: dst = W^T * T(src), where T is applied block by block on the fly and T(src) — the
+// pre-activation gradient of the layer below — is stored row-major as it is produced:
+//   MODE 0: T = identity                          (xyz_encoding_final has no activation)
+//   MODE 1: T = [h > 0] * src                     (ReLU mask from the saved activation row `hrow`)
+//   MODE 2: T = [h > 0] * (src + dsig * w_sigma)  (h8 also feeds the sigma head)
+template <int MODE>
+__device__ __forceinline__ void kloop_bwd(const f32x4* __restrict__ p /* + lane */, const f32x16 (&src)[8], f32x16 (&dst)[8],
+                                          const float* __restrict__ hrow, const float* __restrict__ wsig, float dsig,
+                                          float* __restrict__ save_row, int h, bool row_ok)
+{
+    constexpr int D = 4;
+    f32x4 ring[D + 1][2];
+#pragma unroll
+    for (int s = 0; s < D; ++s) { ring[s][0] = p[(s * 2) * 64]; ring[s][1] = p[(s * 2 + 1) * 64]; }
+    f32x4 hv[4], hn[4];
+    if (MODE != 0) {
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) hv[rq] = *(const f32x4*)(hrow + 8 * rq + 4 * h);
+    }
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        f32x16 cur;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = src[b][r];
+            if (MODE == 2) v += dsig * (h ? wsig[(b * 16 + r) * 2 + 1] : wsig[(b * 16 + r) * 2]);
+            if (MODE != 0) v = hv[r >> 2][r & 3] > 0.f ? v : 0.f;
+            cur[r] = v;
+        }
+        if (MODE != 0 && b + 1 < 8) {
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) hn[rq] = *(const f32x4*)(hrow + 32 * (b + 1) + 8 * rq + 4 * h);
+        }
+        if (row_ok) {
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                f32x4 o = {cur[4 * rq], cur[4 * rq + 1], cur[4 * rq + 2], cur[4 * rq + 3]};
+                *(f32x4*)(save_row + 32 * b + 8 * rq + 4 * h) = o;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int s = b * 16 + r;
+            if (s + D < 128) { ring[(s + D) % (D + 1)][0] = p[((s + D) * 2) * 64]; ring[(s + D) % (D + 1)][1] = p[((s + D) * 2 + 1) * 64]; }
+            step8(ring[s % (D + 1)][0], ring[s % (D + 1)][1], cur[r], dst);
+            if (s + D < 128) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (MODE != 0) {
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) hv[rq] = hn[rq];
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) k_mlp_bwd(NfMlpLayout L, NfMlpLayoutT T, const float* __restrict__ packed,
                                                  const float* __restrict__ packed_t, const float* __restrict__ acts,
                                                  const int* __restrict__ n_rows, int max_rows,
@@ -753,35 +837,37 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(NfMlpLayout L, NfMlpLayoutT T, 
             }
         if (valid) save_frag<4>(dd, drow + 9 * 256, h);
 
-        // d(final) = W_dir[:, :256]^T dpre_dir       (no activation on xyz_encoding_final)
-        f32x16 act[8], acc[8];
-        zero_frag<8>(acc);
-        kloop_act8_from4(PT4 + (T.off_dir >> 2) + lane, dd, acc);
-#pragma unroll
-        for (int b = 0; b < 8; ++b) act[b] = acc[b];
-        if (valid) save_frag<8>(act, drow + 8 * 256, h);
-
+        // d(final) = W_dir[:, :256]^T dpre_dir   (raw; it is stored as dpre slot 8 by the next loop, MODE 0)
+        f32x16 accA[8], accB[8];
+        zero_frag<8>(accA);
+        kloop_src4(PT4 + (T.off_dir >> 2) + lane, dd, accA);
+        const float* ws_ = pk + L.off_wsig;
+        // g = 8: d_h8 = W_final^T dpre_final
+        zero_frag<8>(accB);
+        kloop_bwd<0>(PT4 + (T.off_h[8] >> 2) + lane, accA, accB, nullptr, ws_, dsig, drow + 8 * 256, h, valid);
+        // g = 7: slot 7 = [h8 > 0] (d_h8 + dsig w_sigma);  d_h7 = W_8^T slot 7
+        zero_frag<8>(accA);
+        kloop_bwd<2>(PT4 + (T.off_h[7] >> 2) + lane, accB, accA, arow + 7 * 256, ws_, dsig, drow + 7 * 256, h, valid);
 #pragma unroll 1
-        for (int l = 8; l >= 1; --l) {
-            // d(h_l) = W_l^T dpre_l  (l = 8: xyz_encoding_final, input h8)
-            zero_frag<8>(acc);
-            kloop_act8(PT4 + (T.off_h[l] >> 2) + lane, act, acc);
-            const float* ws_ = pk + L.off_wsig;
-            const float* hprev = arow + (l - 1) * 256;
+        for (int g = 6; g >= 2; g -= 2) {
+            zero_frag<8>(accB);
+            kloop_bwd<1>(PT4 + (T.off_h[g] >> 2) + lane, accA, accB, arow + g * 256, ws_, dsig, drow + g * 256, h, valid);
+            zero_frag<8>(accA);
+            kloop_bwd<1>(PT4 + (T.off_h[g - 1] >> 2) + lane, accB, accA, arow + (g - 1) * 256, ws_, dsig,
+                         drow + (g - 1) * 256, h, valid);
+        }
+        // accA = d_h1 (raw): slot 0 = [h1 > 0] d_h1
+        if (valid) {
 #pragma unroll
             for (int b = 0; b < 8; ++b)
 #pragma unroll
                 for (int rq = 0; rq < 4; ++rq) {
-                    f32x4 hv = *(const f32x4*)(hprev + 32 * b + 8 * rq + 4 * h);
+                    f32x4 hv = *(const f32x4*)(arow + 32 * b + 8 * rq + 4 * h);
+                    f32x4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        int r = 4 * rq + e;
-                        float v = acc[b][r];
-                        if (l == 8) v += dsig * (h ? ws_[(b * 16 + r) * 2 + 1] : ws_[(b * 16 + r) * 2]);  // sigma head reads h8
-                        act[b][r] = hv[e] > 0.f ? v : 0.f;
-                    }
+                    for (int e = 0; e < 4; ++e) o[e] = hv[e] > 0.f ? accA[b][4 * rq + e] : 0.f;
+                    *(f32x4*)(drow + 32 * b + 8 * rq + 4 * h) = o;
                 }
-            if (valid) save_frag<8>(act, drow + (l - 1) * 256, h);
         }
     }
 }

@@ -119,8 +119,7 @@ __global__ void __launch_bounds__(BQ_BLOCK) k_search(const void* __restrict__ ws
 {
     extern __shared__ int lds[];
     int* li = lds;
-    float* ld = (float*)(lds + K * BQ_BLOCK);
-    int* lk = lds + 2 * K * BQ_BLOCK;
+    int* lk = lds + K * BQ_BLOCK;
     NfGridView g = nf_grid_view(ws);
     const int ncand = *cand_count;
     const int tid = threadIdx.x;
@@ -132,9 +131,9 @@ __global__ void __launch_bounds__(BQ_BLOCK) k_search(const void* __restrict__ ws
             sample = cand[c];
             float x, y, zz, zv;
             sample_xyz(rays, z, z_table, S, sample, x, y, zz, zv);
-            cnt = firstk_search(g, x, y, zz, r2, K, li, ld, lk, tid);
-            int nz = 0;
-            for (int k = 0; k < cnt; ++k) nz += (ld[k * BQ_BLOCK + tid] != 0.f);  // nn_mask = dists.ne(0)
+            unsigned nzmask;
+            cnt = firstk_search(g, x, y, zz, r2, K, li, lk, tid, nzmask);
+            int nz = __popc(nzmask);  // nn_mask = dists.ne(0)
             bool full = (nz == K);
             num_nn[sample] = nz;
             mask[sample] = full ? 1 : 0;
@@ -156,7 +155,7 @@ extern "C" int nf_render_search(const void* ws, const float* rays, const float* 
 {
     NF_CHECK_ARG(ws && rays && (z || z_table) && cand && cand_count && num_nn && mask && rgbsigma && row_sample &&
                      row_nbr && n_rows, "null pointer");
-    NF_CHECK_ARG(K >= 1 && K <= 64 && radius > 0.f, "bad K/radius");
+    NF_CHECK_ARG(K >= 1 && K <= 32 && radius > 0.f, "bad K/radius");
     if (R == 0) return NF_OK;
     long total = (long)R * S;
     int blocks = (int)((total + BQ_BLOCK - 1) / BQ_BLOCK);

@@ -142,9 +142,12 @@ class BaseTrainer:
     def render_image(self, particle_pos, N_ray, ro, rays, focal_length, cw, iseval=False):
         rc = self.options.RENDERER.ray.ray_chunk
         chunk = rc
+        shard = iseval and self.world > 1
         if N_ray > rc:   # full-image loops: larger fused calls, still multiples of the reference's chunk
             chunk = max(rc, int(self.options.RENDERER.get('device_ray_chunk', rc)) // rc * rc)
-        shard = iseval and self.world > 1
+            if shard:    # at least ~4 chunks per rank so that the interleaving balances the load
+                per_rank = -(-N_ray // (4 * self.world))
+                chunk = max(rc, min(chunk, -(-per_rank // rc) * rc))
         return _render_image(self.renderer, particle_pos, N_ray, ro, rays, focal_length, cw, iseval=iseval,
                              ray_chunk=chunk, rank=self.rank if shard else 0, world=self.world if shard else 1)
 

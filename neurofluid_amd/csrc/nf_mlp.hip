@@ -10,14 +10,18 @@
 //    128 VGPRs of activations + 128 AGPRs of accumulators per lane, one wave per SIMD.
 //  * the A operand (weights) is pre-packed (nf_nerf_pack) so that each lane fetches the operands of
 //    4 consecutive MFMAs with one 16-byte load; the 2.7 MB of weights of a net stay L2-resident
-//    (4 MiB L2 per XCD) and stream L2 -> VGPR two K-steps ahead of the MFMAs, no LDS, no barriers.
+//    (4 MiB L2 per XCD) and stream L2 -> VGPR four K-steps ahead of the MFMAs, no LDS, no barriers.
+//    Every VMEM issue is placed in the shadow of ONE MFMA (sched_group_barrier): a load costs ~55
+//    cycles of the wave's issue slot, two back to back idle the matrix pipe (measured -17 %).
+//  * two 128-register accumulator sets alternate between layers; the ReLU of the previous set is
+//    applied on the fly, one register per K-step; the bias enters as one extra K-step (A = bias,
+//    B = 1, C = 0): there is no per-layer VALU pass.
 //  * skip connection (layer 5) and the view branch are split-K accumulations over the feature
 //    matrix X (re-read from HBM/L2, 1 KB per row), never materialised concatenations.
 //  * sigma (256->1) and rgb (128->3) heads run on the VALU from the fragments, then one 16-B store
 //    per sample scatters (r,g,b,sigma) to the dense per-sample array.
 #include "nf_common.h"
 #include <math.h>
-#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -189,42 +193,6 @@ __device__ __forceinline__ void step4(const f32x4 w0, const float bv, f32x16 (&a
     acc[3] = MFMA32(w0[3], bv, acc[3]);
 }
 
-// K-steps whose B operand is the previous layer's fragment (128 steps, 8 output blocks).
-// Weights are fetched two steps ahead; sched_barrier pins that software pipeline.
-__device__ __forceinline__ void kloop_act8(const f32x4* __restrict__ p /* + lane */, const f32x16 (&act)[8],
-                                           f32x16 (&acc)[8])
-{
-    f32x4 a0 = p[0], a1 = p[64];
-    f32x4 b0 = p[128], b1 = p[192];
-#pragma unroll
-    for (int s = 0; s < 128; s += 2) {
-        f32x4 c0 = a0, c1 = a1, d0 = b0, d1 = b1;
-        if (s + 2 < 128) { c0 = p[(s + 2) * 128]; c1 = p[(s + 2) * 128 + 64]; }
-        step8(a0, a1, act[s >> 4][s & 15], acc);
-        __builtin_amdgcn_sched_barrier(0);
-        if (s + 3 < 128) { d0 = p[(s + 3) * 128]; d1 = p[(s + 3) * 128 + 64]; }
-        step8(b0, b1, act[(s + 1) >> 4][(s + 1) & 15], acc);
-        __builtin_amdgcn_sched_barrier(0);
-        a0 = c0; a1 = c1; b0 = d0; b1 = d1;
-    }
-}
-
-__device__ __forceinline__ void kloop_act4(const f32x4* __restrict__ p, const f32x16 (&act)[8], f32x16 (&acc)[4])
-{
-    f32x4 a0 = p[0], b0 = p[64];
-#pragma unroll
-    for (int s = 0; s < 128; s += 2) {
-        f32x4 c0 = a0, d0 = b0;
-        if (s + 2 < 128) c0 = p[(s + 2) * 64];
-        step4(a0, act[s >> 4][s & 15], acc);
-        __builtin_amdgcn_sched_barrier(0);
-        if (s + 3 < 128) d0 = p[(s + 3) * 64];
-        step4(b0, act[(s + 1) >> 4][(s + 1) & 15], acc);
-        __builtin_amdgcn_sched_barrier(0);
-        a0 = c0; b0 = d0;
-    }
-}
-
 // K-steps whose B operand comes from the feature matrix: group q = 8 features = 4 steps.
 __device__ __forceinline__ void kloop_x8(const f32x4* __restrict__ wp /* + lane */, const f32x4* __restrict__ xp /* + lane */,
                                          int nq, f32x16 (&acc)[8])
@@ -296,21 +264,6 @@ __device__ __forceinline__ void kloop_x4(const f32x4* __restrict__ wp, const f32
     }
 }
 
-template <int NB>
-__device__ __forceinline__ void init_bias(f32x16 (&acc)[NB], const float* __restrict__ bias, int h)
-{
-#pragma unroll
-    for (int b = 0; b < NB; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            // both candidates are wave-uniform scalar loads; the half-wave picks one (no VGPR staging)
-            const float lo = bias[frag_feature(b, r, 0)], hi = bias[frag_feature(b, r, 1)];
-            acc[b][r] = h ? hi : lo;
-        }
-}
-
-// Opaque copy of a pointer: stops LICM from hoisting the (loop-invariant) head-weight loads out of
-// the persistent tile loop, where they would cost hundreds of live registers.
 // (An opaque zero OFFSET rather than an opaque pointer: laundering the pointer itself drops its
 // global address space and turns every load into flat_load + vmcnt(0)/lgkmcnt(0) waits.)
 __device__ __forceinline__ int opaque_zero()
@@ -333,92 +286,8 @@ __device__ __forceinline__ void save_frag(const f32x16 (&v)[NB], float* __restri
         }
 }
 
-template <bool SAVE>
-__global__ void __launch_bounds__(256) k_mlp_fwd(NfMlpLayout L, const float* __restrict__ packed,
-                                                 const float* __restrict__ X, const int* __restrict__ n_rows, int max_rows,
-                                                 const int* __restrict__ row_sample, float4* __restrict__ rgbsigma,
-                                                 float* __restrict__ acts)
-{
-    const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
-    const int gwave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
-    const int nrows = min(*n_rows, max_rows);
-    const int ntiles = (nrows + 31) >> 5;
-    const int Q = L.qx + L.qd;
-
-    for (int tile = gwave; tile < ntiles; tile += nwaves) {
-        const float* __restrict__ pk = packed + opaque_zero();
-        const f32x4* P4 = (const f32x4*)pk;
-        const f32x4* xt = (const f32x4*)X + (size_t)tile * Q * 64 + lane;
-        const int row = tile * 32 + j;
-        float* arow = SAVE ? acts + (size_t)(row < nrows ? row : 0) * NF_ACT_STRIDE : nullptr;
-        f32x16 act[8], acc[8];
-        float sigma = 0.f;
-
-#pragma unroll 1
-        for (int l = 0; l < 9; ++l) {
-            if (l == 8) {  // sigma head reads h8 before it is overwritten by xyz_encoding_final
-                const float* ws_ = pk + L.off_wsig;
-                float part = 0.f;
-#pragma unroll
-                for (int b = 0; b < 8; ++b)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float w0 = ws_[(b * 16 + r) * 2], w1 = ws_[(b * 16 + r) * 2 + 1];
-                        part += act[b][r] * (h ? w1 : w0);
-                    }
-                sigma = part + __shfl_xor(part, 32, 64) + pk[L.off_bsig];
-            }
-            init_bias<8>(acc, pk + L.off_b[l], h);
-            if (L.off_x[l] >= 0) kloop_x8(P4 + (L.off_x[l] >> 2) + lane, xt, L.qx, acc);
-            if (l > 0) kloop_act8(P4 + (L.off_h[l] >> 2) + lane, act, acc);
-            if (l < 8) {
-#pragma unroll
-                for (int b = 0; b < 8; ++b)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) act[b][r] = fmaxf(acc[b][r], 0.f);
-            } else {
-#pragma unroll
-                for (int b = 0; b < 8; ++b) act[b] = acc[b];
-            }
-            if (SAVE && row < nrows) save_frag<8>(act, arow + l * 256, h);
-        }
-
-        // view branch: dir_encoding = relu(W_dir [final | dir feats] + b)
-        f32x16 hd[4];
-        init_bias<4>(hd, pk + L.off_bdir, h);
-        kloop_act4(P4 + (L.off_dir_h >> 2) + lane, act, hd);
-        kloop_x4(P4 + (L.off_dir_x >> 2) + lane, xt + L.qx * 64, L.qd, hd);
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) hd[b][r] = fmaxf(hd[b][r], 0.f);
-        if (SAVE && row < nrows) save_frag<4>(hd, arow + 9 * 256, h);
-
-        // rgb head
-        const float* wr = pk + L.off_wrgb;
-        float c0 = 0.f, c1 = 0.f, c2 = 0.f;
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = hd[b][r];
-                int k = (b * 16 + r) * 2;
-                c0 += v * (h ? wr[k + 1] : wr[k]);
-                c1 += v * (h ? wr[128 + k + 1] : wr[128 + k]);
-                c2 += v * (h ? wr[256 + k + 1] : wr[256 + k]);
-            }
-        c0 += __shfl_xor(c0, 32, 64); c1 += __shfl_xor(c1, 32, 64); c2 += __shfl_xor(c2, 32, 64);
-        c0 += pk[L.off_brgb]; c1 += pk[L.off_brgb + 1]; c2 += pk[L.off_brgb + 2];
-        if (h == 0 && row < nrows) {
-            float4 o;
-            o.x = 1.f / (1.f + expf(-c0)); o.y = 1.f / (1.f + expf(-c1)); o.z = 1.f / (1.f + expf(-c2)); o.w = sigma;
-            rgbsigma[row_sample[row]] = o;
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
-// forward kernel, v2: double-buffered accumulators.  Layer l accumulates into one 128-register set while the
+// forward kernel: double-buffered accumulators.  Layer l accumulates into one 128-register set while the
 // ReLU of the previous layer's set is applied ON THE FLY, one register per K-step, hidden behind the MFMAs;
 // the bias enters as one extra K-step (A = bias, B = 1, C = 0), so there is no per-layer VALU pass at all.
 // Weights are fetched 4 K-steps ahead (5-slot register ring).
@@ -459,12 +328,10 @@ __device__ __forceinline__ void kloop_src(const f32x4* __restrict__ p /* + lane 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int s = b * 16 + r;
-#ifndef NF_EXP_NOLOAD
             if (s + D < 128) {
 #pragma unroll
                 for (int g = 0; g < G; ++g) ring[(s + D) % (D + 1)][g] = p[((s + D) * G + g) * 64];
             }
-#endif
             if (b + 1 < 8) nxt[r] = RELU ? fmaxf(src[b + 1][r], 0.f) : src[b + 1][r];   // next block's operand, hidden
             const float bv = cur[r];
             const f32x4 w0 = ring[s % (D + 1)][0];
@@ -475,7 +342,6 @@ __device__ __forceinline__ void kloop_src(const f32x4* __restrict__ p /* + lane 
                 dst[NB - 4] = MFMA32(w1[0], bv, dst[NB - 4]); dst[NB - 3] = MFMA32(w1[1], bv, dst[NB - 3]);
                 dst[NB - 2] = MFMA32(w1[2], bv, dst[NB - 2]); dst[NB - 1] = MFMA32(w1[3], bv, dst[NB - 1]);
             }
-#ifndef NF_EXP_NOSPREAD
             // A VMEM issue costs ~55 cycles of the wave's issue slot: one per MFMA shadow (64 cycles), never two
             // back to back (measured: adjacent load pairs idle the matrix pipe ~45 cycles per K-step).
             if (s + D < 128) {
@@ -487,7 +353,6 @@ __device__ __forceinline__ void kloop_src(const f32x4* __restrict__ p /* + lane 
                     __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
                 }
             }
-#endif
             __builtin_amdgcn_sched_barrier(0);
         }
         if (SAVE && row_ok) {
@@ -513,7 +378,7 @@ __device__ __forceinline__ void mlp_layer(const NfMlpLayout& L, const f32x4* __r
 }
 
 template <bool SAVE>
-__global__ void __launch_bounds__(256) k_mlp_fwd2(NfMlpLayout L, const float* __restrict__ packed,
+__global__ void __launch_bounds__(256) k_mlp_fwd(NfMlpLayout L, const float* __restrict__ packed,
                                                   const float* __restrict__ X, const int* __restrict__ n_rows, int max_rows,
                                                   const int* __restrict__ row_sample, float4* __restrict__ rgbsigma,
                                                   float* __restrict__ acts)
@@ -602,22 +467,12 @@ extern "C" int nf_nerf_mlp_fwd(const float* packed, int cx, int cd, const float*
     int blocks = (tiles + 3) / 4;
     if (blocks > 256) blocks = 256;  // one 4-wave workgroup per CU, persistent over tiles
     hipStream_t st = (hipStream_t)stream;
-    static const bool use_v1 = getenv("NF_MLP_V1") != nullptr;   // A/B switch for profiling; v2 is the default
-    if (use_v1) {
-        if (acts)
-            hipLaunchKernelGGL(k_mlp_fwd<true>, dim3(blocks), dim3(256), 0, st, L, packed, X, n_rows, max_rows, row_sample,
-                               (float4*)rgbsigma, acts);
-        else
-            hipLaunchKernelGGL(k_mlp_fwd<false>, dim3(blocks), dim3(256), 0, st, L, packed, X, n_rows, max_rows, row_sample,
-                               (float4*)rgbsigma, acts);
-    } else {
-        if (acts)
-            hipLaunchKernelGGL(k_mlp_fwd2<true>, dim3(blocks), dim3(256), 0, st, L, packed, X, n_rows, max_rows, row_sample,
-                               (float4*)rgbsigma, acts);
-        else
-            hipLaunchKernelGGL(k_mlp_fwd2<false>, dim3(blocks), dim3(256), 0, st, L, packed, X, n_rows, max_rows, row_sample,
-                               (float4*)rgbsigma, acts);
-    }
+    if (acts)
+        hipLaunchKernelGGL(k_mlp_fwd<true>, dim3(blocks), dim3(256), 0, st, L, packed, X, n_rows, max_rows, row_sample,
+                           (float4*)rgbsigma, acts);
+    else
+        hipLaunchKernelGGL(k_mlp_fwd<false>, dim3(blocks), dim3(256), 0, st, L, packed, X, n_rows, max_rows, row_sample,
+                           (float4*)rgbsigma, acts);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }

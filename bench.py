@@ -80,7 +80,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="render", choices=["render", "train"])
     ap.add_argument("--chunk", type=int, default=0,
-                    help="device ray chunk (multiple of the reference's 1024); 0 = whole view on 1 GPU, 32768 when sharded")
+                    help="device ray chunk; 0 = one whole 400x400 view per fused call (results are chunk-independent)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -92,7 +92,7 @@ def main():
 
     rank, world, local = nfdist.init_from_env()
     if args.chunk <= 0:
-        args.chunk = 163840 if int(os.environ.get("WORLD_SIZE", "1")) == 1 else 32768
+        args.chunk = 400 * 400      # weak scaling: chunk k = view k -> rank k mod N, identical load on every rank
     assert world == args.gpus or (args.gpus == 1 and world == 1), f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local)

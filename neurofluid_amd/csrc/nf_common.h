@@ -40,6 +40,8 @@ struct NfGridHeader {
     int off_tmp_list;
     int off_cell_fill;
     int off_cell_aabb;   // float[6] per cell: min xyz, max xyz of the contained points (+inf/-inf when empty)
+    int off_cell_rec;    // 3 x float4 per cell: {start, end, min original index, -} {lo.xyz, hi.x} {hi.y, hi.z, -, -}
+    int pad_[3];
 };
 
 struct NfGridView {
@@ -52,6 +54,7 @@ struct NfGridView {
     const int* sorted_idx;
     const float4* sorted_pos;
     const float* cell_aabb;
+    const float4* cell_rec;
 };
 
 __device__ __forceinline__ NfGridView nf_grid_view(const void* ws)
@@ -68,6 +71,7 @@ __device__ __forceinline__ NfGridView nf_grid_view(const void* ws)
     v.sorted_idx = (const int*)(b + h->off_sorted_idx);
     v.sorted_pos = (const float4*)(b + h->off_sorted_pos);
     v.cell_aabb = (const float*)(b + h->off_cell_aabb);
+    v.cell_rec = (const float4*)(b + h->off_cell_rec);
     return v;
 }
 
@@ -122,7 +126,7 @@ __device__ __forceinline__ bool nf_any_cell_in_reach(const NfGridView& g, float 
     for (int z = max(cz - 1, 0); z <= min(cz + 1, g.dz - 1); ++z)
         for (int y = max(cy - 1, 0); y <= min(cy + 1, g.dy - 1); ++y)
             for (int x = max(cx - 1, 0); x <= min(cx + 1, g.dx - 1); ++x) {
-                int c = (z * g.dy + y) * g.dx + x;
+                int c = (z * g.dy + y) * g.dx + x;     // empty cells carry a +inf/-inf box: distance = inf
                 if (nf_box_dist2(g.cell_aabb + 6 * c, qx, qy, qz) < r2) return true;
             }
     return false;
@@ -150,9 +154,10 @@ __device__ __forceinline__ int firstk_insert(int* li, unsigned& nzmask, int cnt,
 // smallest remaining key exceeds the current K-th index, no remaining particle can enter the list.
 // Candidates are fetched 4 at a time (independent loads in flight) — entries past the break point can
 // never enter the list, so testing them is harmless.  lk = 27 keys [c * BQ_BLOCK + tid].  K <= 32.
-__device__ __forceinline__ int firstk_search(const NfGridView& g, float qx, float qy, float qz, float r2, int K,
+__device__ __forceinline__ int firstk_search(const NfGridView& g, float qx, float qy, float qz, float r2_, int K,
                                              int* li, int* lk, int tid, unsigned& nzmask)
 {
+    const float r2 = r2_;
     int cx = nf_cell_coord(qx, g.ox, g.icx, g.dx);
     int cy = nf_cell_coord(qy, g.oy, g.icy, g.dy);
     int cz = nf_cell_coord(qz, g.oz, g.icz, g.dz);
@@ -163,11 +168,12 @@ __device__ __forceinline__ int firstk_search(const NfGridView& g, float qx, floa
         int x = cx + (c % 3) - 1, y = cy + ((c / 3) % 3) - 1, z = cz + (c / 9) - 1;
         int key = BIG;
         if (x >= 0 && x < g.dx && y >= 0 && y < g.dy && z >= 0 && z < g.dz) {
-            int cell = (z * g.dy + y) * g.dx + x;
-            int s = g.cell_start[cell];
-            if (g.cell_start[cell + 1] > s && nf_box_dist2(g.cell_aabb + 6 * cell, qx, qy, qz) < r2) {
-                key = g.sorted_idx[s];
-                ++nvalid;
+            const float4* rec = g.cell_rec + 3 * ((z * g.dy + y) * g.dx + x);   // one 48-byte record per cell
+            const float4 r0 = rec[0];
+            if (__float_as_int(r0.y) > __float_as_int(r0.x)) {
+                const float4 r1 = rec[1], r2 = rec[2];
+                const float bb[6] = {r1.x, r1.y, r1.z, r1.w, r2.x, r2.y};
+                if (nf_box_dist2(bb, qx, qy, qz) < r2_) { key = __float_as_int(r0.z); ++nvalid; }
             }
         }
         lk[c * BQ_BLOCK + tid] = key;
@@ -184,8 +190,8 @@ __device__ __forceinline__ int firstk_search(const NfGridView& g, float qx, floa
         lk[bc * BQ_BLOCK + tid] = BIG;
         --nvalid;
         int x = cx + (bc % 3) - 1, y = cy + ((bc / 3) % 3) - 1, z = cz + (bc / 9) - 1;
-        int cell = (z * g.dy + y) * g.dx + x;
-        int s = g.cell_start[cell], e = g.cell_start[cell + 1];
+        const float4 r0 = g.cell_rec[3 * ((z * g.dy + y) * g.dx + x)];
+        int s = __float_as_int(r0.x), e = __float_as_int(r0.y);
         bool done = false;
         for (int t = s; t < e && !done; t += 4) {
             float4 p[4];

@@ -143,6 +143,7 @@ int nf_grid_make_header(int n, float cell, const float bbox[6], NfGridHeader* h,
     h->off_tmp_list = (int)off;   off = align_up(off + sizeof(int) * (size_t)(n > 0 ? n : 1), 256);
     h->off_cell_fill = (int)off;  off = align_up(off + sizeof(int) * (cells + SCAN_BLOCK + 2048), 256);
     h->off_cell_aabb = (int)off;  off = align_up(off + sizeof(float) * 6 * cells, 256);
+    h->off_cell_rec = (int)off;   off = align_up(off + sizeof(float4) * 3 * cells, 256);
     if (off > (size_t)0x7fffffff) return NF_EINVAL;
     *total = off;
     return NF_OK;
@@ -235,6 +236,11 @@ __global__ void k_grid_dilate(NfGridHeader h, void* ws)
     }
     float* bb = (float*)(b + h.off_cell_aabb) + 6 * c;
     bb[0] = lo[0]; bb[1] = lo[1]; bb[2] = lo[2]; bb[3] = hi[0]; bb[4] = hi[1]; bb[5] = hi[2];
+    float4* rec = (float4*)(b + h.off_cell_rec) + 3 * c;
+    int mn = cs[c + 1] > cs[c] ? ((const int*)(b + h.off_sorted_idx))[cs[c]] : 0x7fffffff;
+    rec[0] = make_float4(__int_as_float(cs[c]), __int_as_float(cs[c + 1]), __int_as_float(mn), 0.f);
+    rec[1] = make_float4(lo[0], lo[1], lo[2], hi[0]);
+    rec[2] = make_float4(hi[1], hi[2], 0.f, 0.f);
 }
 
 extern "C" int nf_grid_build(const float* pts, int n, float cell, const float bbox[6], void* ws, size_t ws_bytes,

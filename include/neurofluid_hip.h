@@ -118,6 +118,16 @@ int nf_nerf_pack(const nf_nerf_params_t* params /*[host]*/, int cx, int cd, floa
 int nf_nerf_mlp_fwd(const float* packed, int cx, int cd, const float* X, const int32_t* n_rows, int max_rows,
                     const int32_t* row_sample, float* rgbsigma, float* acts /*or NULL*/, nf_stream_t stream);
 
+/* A6, fp16-MFMA variant (BASELINE config 5: "fp16 MFMA path"): v_mfma_f32_32x32x16_f16 with fp32 accumulation; the
+ * weight stream is shared by the 4 waves of a workgroup through an LDS ring; sigma/rgb heads and biases (hi+lo
+ * split) keep fp32 accuracy.  Inference only; `packed` (fp32 blob of nf_nerf_pack) supplies the heads.
+ * Default encodings only (198 + 54 features). */
+size_t nf_nerf_packed_h_bytes(void);
+int nf_nerf_pack_h(const nf_nerf_params_t* params /*[host]*/, int cx, int cd, void* stream_h, nf_stream_t stream);
+int nf_nerf_mlp_fwd_h(const float* packed, const void* stream_h, int cx, int cd, const float* X,
+                      const int32_t* n_rows, int max_rows, const int32_t* row_sample, float* rgbsigma,
+                      nf_stream_t stream);
+
 /* A12 (MLP part): data gradient of the MLP on fp32 MFMA with transposed packed weights.
  * Reads d_rgbsigma[row_sample[row]] (gradient w.r.t. the MLP output (rgb after sigmoid, sigma)) and the
  * activations saved by nf_nerf_mlp_fwd; writes, per row, the pre-activation gradients of every layer:

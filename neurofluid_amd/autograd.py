@@ -16,9 +16,13 @@ def _run_passes(net, particles, ro, rays, white_bg, fine, save_acts):
     pts = grid.points
     rays_c = _prep(rays)
     ro_c = _prep(ro)
+    use_h = net.mlp_dtype == "fp16" and not save_acts
+    if net.mlp_dtype == "fp16" and save_acts:
+        raise RuntimeError("RENDERER.mlp_dtype=fp16 is an inference path; train with fp32")
     pk0 = net.packed_weights(net.nerf_coarse)
     p0 = ops.render_pass(grid, pts, rays_c, None, z_table, net.N_samples, net.raduis, net.num_neighbor, net.enc_flags,
-                         net.use_mask, ro_c, pk0, net.in_channels_xyz, net.in_channels_dir, white_bg, save_acts)
+                         net.use_mask, ro_c, pk0, net.in_channels_xyz, net.in_channels_dir, white_bg, save_acts,
+                         packed_h=net.packed_weights_h(net.nerf_coarse) if use_h else None)
     p0.packed = pk0
     p1 = None
     if fine:
@@ -26,7 +30,7 @@ def _run_passes(net, particles, ro, rays, white_bg, fine, save_acts):
         pk1 = net.packed_weights(net.nerf_fine)
         p1 = ops.render_pass(grid, pts, rays_c, z1, None, net.N_samples + net.N_importance, net.raduis, net.num_neighbor,
                              net.enc_flags, net.use_mask, ro_c, pk1, net.in_channels_xyz, net.in_channels_dir, white_bg,
-                             save_acts)
+                             save_acts, packed_h=net.packed_weights_h(net.nerf_fine) if use_h else None)
         p1.z = z1
         p1.packed = pk1
     return p0, p1, rays_c, ro_c, grid

@@ -1,0 +1,348 @@
+// nf_mlp_h.hip — fp16-MFMA variant of the NeRF MLP forward (BASELINE config 5: "fp16 MFMA path").
+//
+// v_mfma_f32_32x32x16_f16 (fp32 accumulate).  Same orientation and the same register-resident chaining as the
+// fp32 kernel (nf_mlp.hip): D[out_feature][sample]; the D fragment of a layer, ReLU'd and converted to fp16 on the
+// fly, is the B fragment of the next layer (registers r = 0..7 of a 32-feature block form K-step 0, r = 8..15
+// K-step 1; the weights are packed in that K order).  What changes is the operand traffic: at the fp16 MFMA rate a
+// wave needs 1 KB of A operand every 32 cycles, far beyond what L2->VGPR can feed per wave, so the weight stream is
+// shared by the 4 waves of a workgroup through an LDS ring: a flat sequence of 8 KB "slots" (one K-step x 8 output
+// blocks x 64 lanes x 16 B), ring of 8 slots (64 KB), refilled 4 slots at a time by all waves (global -> VGPR ->
+// ds_write_b128, one barrier per 4 K-steps), consumed with lane-linear conflict-free ds_read_b128.
+// Biases enter as one K-step with a hi/lo fp16 split (bias = hi + lo to ~22 bits), heads (sigma, rgb) stay fp32
+// VALU from the fp32 accumulators.  Inputs X stay fp32 in HBM and are converted in registers.
+#include "nf_mlp_layout.h"
+#include <math.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+
+#define H_SLOT_U4 512        // one slot = 8 KB = 512 x 16 B
+#define H_RING_SLOTS 8
+#define H_CHUNK_SLOTS 4
+
+// ------------------------------------------------------------------------------------------------
+// stream description (host) and packing
+// ------------------------------------------------------------------------------------------------
+enum { HK_BIAS = 0, HK_X = 1, HK_H = 2 };
+struct HStep { int layer; int kind; int idx; int nb; };   // layer 0..8 or 9 (dir); idx: X step t / H step (b*2+t); nb = out blocks
+#define H_MAX_STEPS 256
+
+struct HStream {
+    int nsteps;        // K-steps (dir steps are half slots)
+    int nslots;        // padded to a multiple of H_RING_SLOTS
+    HStep steps[H_MAX_STEPS];
+    int slot_of[H_MAX_STEPS];   // slot index of each step
+    int sub_of[H_MAX_STEPS];    // first sub-block (0 or 4) inside the slot
+};
+
+static void h_build_stream(HStream* S)
+{
+    int n = 0;
+    auto add = [&](int layer, int kind, int idx, int nb) { S->steps[n++] = HStep{layer, kind, idx, nb}; };
+    for (int l = 0; l < 9; ++l) {
+        add(l, HK_BIAS, 0, 8);
+        if (l == 0 || l == 4) for (int t = 0; t < 13; ++t) add(l, HK_X, t, 8);
+        if (l > 0) for (int k = 0; k < 16; ++k) add(l, HK_H, k, 8);
+    }
+    add(9, HK_BIAS, 0, 4);
+    for (int t = 12; t < 16; ++t) add(9, HK_X, t, 4);
+    for (int k = 0; k < 16; ++k) add(9, HK_H, k, 4);
+    S->nsteps = n;
+    int slot = 0, half = 0;
+    for (int i = 0; i < n; ++i) {
+        if (S->steps[i].nb == 8) { S->slot_of[i] = slot++; S->sub_of[i] = 0; }
+        else {
+            S->slot_of[i] = slot; S->sub_of[i] = half ? 4 : 0;
+            if (half) ++slot;
+            half ^= 1;
+        }
+    }
+    if (half) ++slot;
+    S->nslots = (slot + H_RING_SLOTS - 1) / H_RING_SLOTS * H_RING_SLOTS;
+}
+
+extern "C" size_t nf_nerf_packed_h_bytes(void)
+{
+    HStream S;
+    h_build_stream(&S);
+    return (size_t)S.nslots * H_SLOT_U4 * 16;
+}
+
+// step i of the stream -> descriptor (closed form of h_build_stream, so that packing needs no host table)
+__device__ __forceinline__ HStep h_step_desc(int i, int* slot, int* sub)
+{
+    const int len[10] = {14, 17, 17, 17, 30, 17, 17, 17, 17, 21};
+    int l = 0, base = 0;
+    while (l < 9 && i >= base + len[l]) { base += len[l]; ++l; }
+    int k = i - base;
+    HStep st;
+    st.layer = l; st.nb = (l == 9) ? 4 : 8;
+    if (k == 0) { st.kind = HK_BIAS; st.idx = 0; }
+    else if (l == 0) { st.kind = HK_X; st.idx = k - 1; }
+    else if (l == 4) { if (k <= 13) { st.kind = HK_X; st.idx = k - 1; } else { st.kind = HK_H; st.idx = k - 14; } }
+    else if (l == 9) { if (k <= 4) { st.kind = HK_X; st.idx = 12 + (k - 1); } else { st.kind = HK_H; st.idx = k - 5; } }
+    else { st.kind = HK_H; st.idx = k - 1; }
+    if (l < 9) { *slot = i; *sub = 0; }
+    else { int d = i - base; *slot = base + (d >> 1); *sub = (d & 1) * 4; }
+    return st;
+}
+
+// packing: one block per K-step
+__global__ void k_mlp_pack_h(int cx, int cd, NfNerfPtrs P, _Float16* __restrict__ out)
+{
+    int slot, sub;
+    HStep st = h_step_desc(blockIdx.x, &slot, &sub);
+    _Float16* dst = out + ((size_t)slot * 8 + sub) * 512;   // 512 halfs per sub-block
+    for (int t = threadIdx.x; t < st.nb * 512; t += blockDim.x) {
+        int ib = t / 512, lane = (t % 512) / 8, e = t % 8, h = lane >> 5;
+        int o = 32 * ib + (lane & 31);
+        float v = 0.f;
+        const int L = st.layer;
+        const int widx = L;                            // P.w index: 0..7 xyz_encoding_1..8, 8 final, 9 dir
+        const int in_dim = (L == 0) ? cx : (L == 4 ? cx + 256 : (L == 9 ? 256 + cd : 256));
+        if (st.kind == HK_BIAS) {
+            if (h == 0 && e < 2) {
+                float b = P.b[widx][o];
+                _Float16 hi = (_Float16)b;
+                v = (e == 0) ? (float)hi : (b - (float)hi);
+            }
+        } else if (st.kind == HK_X) {
+            // lane holds X features (q = 2t): 16t + 4h + e (e < 4) and (q = 2t+1): 16t + 8 + 4h + (e-4), padded row index
+            int f = 16 * st.idx + (e < 4 ? 4 * h + e : 8 + 4 * h + (e - 4));
+            const int qx8 = ((cx + 7) / 8) * 8;
+            if (L == 9) { int fd = f - qx8; if (fd >= 0 && fd < cd) v = P.w[9][(size_t)o * in_dim + 256 + fd]; }
+            else if (f < cx) v = P.w[widx][(size_t)o * in_dim + f];
+        } else {
+            int b = st.idx >> 1, tt = st.idx & 1;
+            int f = frag_feature(b, 8 * tt + e, h);
+            int col = (L == 4) ? cx + f : f;
+            v = P.w[widx][(size_t)o * in_dim + col];
+        }
+        dst[t] = (_Float16)v;
+    }
+}
+
+__global__ void k_zero_u4(u32x4* p, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = u32x4{0u, 0u, 0u, 0u};
+}
+
+extern "C" int nf_nerf_pack_h(const nf_nerf_params_t* params, int cx, int cd, void* stream_h, nf_stream_t stream)
+{
+    NF_CHECK_ARG(params && stream_h, "null pointer");
+    NF_CHECK_ARG((cx + 7) / 8 == 25 && (cd + 7) / 8 == 7, "the fp16 path is built for the default 198+54 feature row");
+    HStream S;
+    h_build_stream(&S);
+    NF_CHECK_ARG(S.nsteps == 184, "internal: stream description out of sync");
+    NfNerfPtrs P;
+    for (int i = 0; i < 12; ++i) { P.w[i] = params->w[i]; P.b[i] = params->b[i]; }
+    hipStream_t st = (hipStream_t)stream;
+    size_t nu4 = (size_t)S.nslots * H_SLOT_U4;
+    hipLaunchKernelGGL(k_zero_u4, dim3((unsigned)((nu4 + 255) / 256)), dim3(256), 0, st, (u32x4*)stream_h, nu4);
+    hipLaunchKernelGGL(k_mlp_pack_h, dim3(S.nsteps), dim3(256), 0, st, cx, cd, P, (_Float16*)stream_h);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernel
+// ------------------------------------------------------------------------------------------------
+struct HCtx {
+    const u32x4* stream;   // + wave * 512 + lane   (this wave's quarter of every chunk: 4 slots x 2 KB... see h_boundary)
+    u32x4* ring;           // LDS base
+    int slot;              // running slot counter (wave-uniform)
+    int half;              // running half-slot toggle for 4-block steps
+    int nchunks, chunk_next;
+    int lane, wave;
+    u32x4 stage[8];        // this wave's share (8 KB) of the next chunk, in flight
+};
+
+// Called before consuming a slot whose index is a multiple of H_CHUNK_SLOTS: publish the staged chunk, rendezvous,
+// start fetching the following chunk.
+__device__ __forceinline__ void h_boundary(HCtx& c)
+{
+    const int half = (c.slot / H_CHUNK_SLOTS) & 1;
+    u32x4* dst = c.ring + half * (H_CHUNK_SLOTS * H_SLOT_U4) + c.wave * 512 + c.lane;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dst[i * 64] = c.stage[i];
+    __syncthreads();
+    const u32x4* src = c.stream + (size_t)c.chunk_next * (H_CHUNK_SLOTS * H_SLOT_U4) + c.wave * 512 + c.lane;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) c.stage[i] = src[i * 64];
+    c.chunk_next = (c.chunk_next + 1 == c.nchunks) ? 0 : c.chunk_next + 1;
+}
+
+template <int NB>
+__device__ __forceinline__ void h_step(HCtx& c, const h8 b, f32x16 (&acc)[NB], bool zero_c)
+{
+    if (NB == 8 || c.half == 0) {
+        if ((c.slot % H_CHUNK_SLOTS) == 0) h_boundary(c);
+    }
+    const u32x4* base = c.ring + (c.slot % H_RING_SLOTS) * H_SLOT_U4 + (NB == 4 ? c.half * 256 : 0) + c.lane;
+    u32x4 a[NB];
+#pragma unroll
+    for (int ib = 0; ib < NB; ++ib) a[ib] = base[ib * 64];
+    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ib = 0; ib < NB; ++ib) {
+        h8 av = __builtin_bit_cast(h8, a[ib]);
+        acc[ib] = MFMA16(av, b, zero_c ? z : acc[ib]);
+    }
+    if (NB == 8) c.slot++;
+    else { if (c.half) c.slot++; c.half ^= 1; }
+}
+
+__device__ __forceinline__ h8 pack8(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7)
+{
+    h8 r = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3, (_Float16)v4, (_Float16)v5, (_Float16)v6, (_Float16)v7};
+    return r;
+}
+
+__device__ __forceinline__ h8 bias_b(int h)
+{
+    const _Float16 one = (_Float16)(h == 0 ? 1.f : 0.f), zz = (_Float16)0.f;
+    h8 r = {one, one, zz, zz, zz, zz, zz, zz};
+    return r;
+}
+
+// X K-steps t0 .. t1-1 : features of groups q = 2t, 2t+1
+template <int NB>
+__device__ __forceinline__ void h_xsteps(HCtx& c, const f32x4* __restrict__ xt /* + lane */, int t0, int t1, f32x16 (&acc)[NB])
+{
+    f32x4 x0 = xt[(2 * t0) * 64], x1 = xt[(2 * t0 + 1) * 64];
+    for (int t = t0; t < t1; ++t) {
+        f32x4 n0 = x0, n1 = x1;
+        if (t + 1 < t1) { n0 = xt[(2 * t + 2) * 64]; n1 = xt[(2 * t + 3) * 64]; }
+        h_step<NB>(c, pack8(x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]), acc, false);
+        x0 = n0; x1 = n1;
+    }
+}
+
+// hidden K-steps: B = fp16(act(src)), act = ReLU or identity
+template <bool RELU, int NB>
+__device__ __forceinline__ void h_hsteps(HCtx& c, const f32x16 (&src)[8], f32x16 (&dst)[NB])
+{
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = RELU ? fmaxf(src[b][8 * t + e], 0.f) : src[b][8 * t + e];
+            h_step<NB>(c, pack8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]), dst, false);
+        }
+}
+
+__device__ __forceinline__ void h_layer(HCtx& c, int l, const f32x4* __restrict__ xt, const f32x16 (&src)[8], f32x16 (&dst)[8])
+{
+    const int h = c.lane >> 5;
+    h_step<8>(c, bias_b(h), dst, true);
+    if (l == 4) h_xsteps<8>(c, xt, 0, 13, dst);
+    h_hsteps<true, 8>(c, src, dst);
+}
+
+__global__ void __launch_bounds__(256) k_mlp_fwd_h(NfMlpLayout L, const float* __restrict__ packed,
+                                                   const u32x4* __restrict__ stream_h, int nslots,
+                                                   const float* __restrict__ X, const int* __restrict__ n_rows, int max_rows,
+                                                   const int* __restrict__ row_sample, float4* __restrict__ rgbsigma)
+{
+    __shared__ u32x4 ring[H_RING_SLOTS * H_SLOT_U4];
+    const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, wave = threadIdx.x >> 6;
+    const int nrows = min(*n_rows, max_rows);
+    const int ntiles = (nrows + 31) >> 5;
+    const int ngroups = (ntiles + 3) >> 2;
+    const int Q = L.qx + L.qd;
+    HCtx c;
+    c.stream = stream_h; c.ring = ring; c.slot = 0; c.half = 0;
+    c.nchunks = nslots / H_CHUNK_SLOTS; c.chunk_next = 1; c.lane = lane; c.wave = wave;
+    {
+        const u32x4* src = stream_h + wave * 512 + lane;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) c.stage[i] = src[i * 64];
+    }
+    for (int tg = blockIdx.x; tg < ngroups; tg += gridDim.x) {
+        int tile = tg * 4 + wave;
+        if (tile >= ntiles) tile = ntiles - 1;      // idle waves recompute the last tile (keeps the barriers matched)
+        const bool owner = (tg * 4 + wave) < ntiles;
+        const f32x4* xt = (const f32x4*)X + (size_t)tile * Q * 64 + lane;
+        const int row = tile * 32 + j;
+        const bool row_ok = owner && row < nrows;
+        f32x16 accA[8], accB[8];
+        // layer 0
+        h_step<8>(c, bias_b(h), accA, true);
+        h_xsteps<8>(c, xt, 0, 13, accA);
+#pragma unroll 1
+        for (int l = 1; l < 9; l += 2) {
+            h_layer(c, l, xt, accA, accB);
+            h_layer(c, l + 1, xt, accB, accA);
+        }
+        // sigma from h8 = relu(accB) in fp32
+        float sigma;
+        {
+            const float* ws_ = packed + L.off_wsig;
+            float part = 0.f;
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float w0 = ws_[(b * 16 + r) * 2], w1 = ws_[(b * 16 + r) * 2 + 1];
+                    part += fmaxf(accB[b][r], 0.f) * (h ? w1 : w0);
+                }
+            sigma = part + __shfl_xor(part, 32, 64) + packed[L.off_bsig];
+        }
+        // view branch
+        f32x16 hd[4];
+        h_step<4>(c, bias_b(h), hd, true);
+        h_xsteps<4>(c, xt, 12, 16, hd);
+        h_hsteps<false, 4>(c, accA, hd);
+        // the stream is padded to a multiple of the ring: skip the padding slots (uniform)
+        if (c.half) { c.slot++; c.half = 0; }
+        while (c.slot % H_RING_SLOTS) {
+            if ((c.slot % H_CHUNK_SLOTS) == 0) h_boundary(c);
+            c.slot++;
+        }
+        const float* wr = packed + L.off_wrgb;
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = fmaxf(hd[b][r], 0.f);
+                int k = (b * 16 + r) * 2;
+                c0 += v * (h ? wr[k + 1] : wr[k]);
+                c1 += v * (h ? wr[128 + k + 1] : wr[128 + k]);
+                c2 += v * (h ? wr[256 + k + 1] : wr[256 + k]);
+            }
+        c0 += __shfl_xor(c0, 32, 64); c1 += __shfl_xor(c1, 32, 64); c2 += __shfl_xor(c2, 32, 64);
+        c0 += packed[L.off_brgb]; c1 += packed[L.off_brgb + 1]; c2 += packed[L.off_brgb + 2];
+        if (h == 0 && row_ok) {
+            float4 o;
+            o.x = 1.f / (1.f + expf(-c0)); o.y = 1.f / (1.f + expf(-c1)); o.z = 1.f / (1.f + expf(-c2)); o.w = sigma;
+            rgbsigma[row_sample[row]] = o;
+        }
+    }
+}
+
+extern "C" int nf_nerf_mlp_fwd_h(const float* packed, const void* stream_h, int cx, int cd, const float* X,
+                                 const int32_t* n_rows, int max_rows, const int32_t* row_sample, float* rgbsigma,
+                                 nf_stream_t stream)
+{
+    NF_CHECK_ARG(packed && stream_h && X && n_rows && row_sample && rgbsigma, "null pointer");
+    if (max_rows <= 0) return NF_OK;
+    NfMlpLayout L = mlp_layout(cx, cd);
+    NF_CHECK_ARG(L.qx + L.qd == 32 && L.qx == 25, "the fp16 path is built for the default 198+54 feature row");
+    HStream S;
+    h_build_stream(&S);
+    int tiles = (max_rows + 31) / 32;
+    int blocks = (tiles + 3) / 4;
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(k_mlp_fwd_h, dim3(blocks), dim3(256), 0, (hipStream_t)stream, L, packed, (const u32x4*)stream_h,
+                       S.nslots, X, n_rows, max_rows, row_sample, (float4*)rgbsigma);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}

@@ -1,0 +1,56 @@
+// nf_mlp_layout.h — packed-weight layout of the fp32 NeRF MLP kernels (shared by nf_mlp.hip / nf_mlp_h.hip)
+#pragma once
+#include "nf_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// packed-weight layout
+// ------------------------------------------------------------------------------------------------
+struct NfMlpLayout {
+    int cx, cd, qx, qd;
+    int off_x[9];   // layer l (0 = xyz_encoding_1 .. 7 = xyz_encoding_8, 8 = xyz_encoding_final): X-part [qx*4][2][64][4] or -1
+    int off_h[9];   // hidden part [128][2][64][4] or -1
+    int off_dir_h;  // [128][64][4]
+    int off_dir_x;  // [qd*4][64][4]
+    int off_wsig;   // [128][2]
+    int off_wrgb;   // [3][64][2]
+    int off_b[9];   // natural bias vectors (256 each)
+    int off_bdir;   // 128
+    int off_bsig;   // 1
+    int off_brgb;   // 3
+    int off_bstep[9];  // bias as one extra K-step per layer: [2][64][4], A = bias (lanes < 32) / 0, B operand = 1.0
+    int off_bstep_dir; // [64][4]
+    int total;
+};
+
+static inline NfMlpLayout mlp_layout(int cx, int cd)
+{
+    NfMlpLayout L;
+    L.cx = cx; L.cd = cd; L.qx = (cx + 7) / 8; L.qd = (cd + 7) / 8;
+    int o = 0;
+    for (int l = 0; l < 9; ++l) {
+        L.off_x[l] = -1; L.off_h[l] = -1;
+        if (l == 0 || l == 4) { L.off_x[l] = o; o += L.qx * 4 * 512; }
+        if (l != 0) { L.off_h[l] = o; o += 128 * 512; }
+    }
+    L.off_dir_h = o; o += 128 * 256;
+    L.off_dir_x = o; o += L.qd * 4 * 256;
+    L.off_wsig = o; o += 256;
+    L.off_wrgb = o; o += 384;
+    for (int l = 0; l < 9; ++l) { L.off_b[l] = o; o += 256; }
+    L.off_bdir = o; o += 128;
+    L.off_bsig = o; o += 4;
+    L.off_brgb = o; o += 4;
+    for (int l = 0; l < 9; ++l) { L.off_bstep[l] = o; o += 512; }
+    L.off_bstep_dir = o; o += 256;
+    L.total = o;
+    return L;
+}
+
+// feature held by register r of block b in half-wave h (MFMA 32x32 C/D layout)
+__device__ __host__ __forceinline__ int frag_feature(int b, int r, int h) { return 32 * b + (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+
+struct NfNerfPtrs {
+    const float* w[12];
+    const float* b[12];
+};

@@ -164,6 +164,21 @@ def pack_nerf(weights, biases, cx, cd, out=None):
     return out
 
 
+def pack_nerf_h(weights, biases, cx, cd):
+    """fp16 weight stream of the fp16-MFMA MLP (nf_nerf_pack_h)."""
+    lib = _lib.load()
+    out = torch.empty(lib.nf_nerf_packed_h_bytes(), dtype=torch.uint8, device=weights[0].device)
+    P = _lib.NerfParams()
+    keep = []
+    for i in range(12):
+        w = weights[i].detach().contiguous().float()
+        b = biases[i].detach().contiguous().float()
+        keep += [w, b]
+        P.w[i], P.b[i] = w.data_ptr(), b.data_ptr()
+    check(lib.nf_nerf_pack_h(ctypes.byref(P), cx, cd, ptr(out), _lib.stream()), "nf_nerf_pack_h")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 # one render pass (coarse or fine) of a ray chunk
 # ------------------------------------------------------------------------------------------------
@@ -173,7 +188,7 @@ class PassBuffers:
 
 
 def render_pass(grid, particles, rays, z, z_table, S, radius, K, enc_flags, use_mask, ro, packed, cx, cd,
-                white_bg=True, save_acts=False, max_rows=None):
+                white_bg=True, save_acts=False, max_rows=None, packed_h=None):
     """Runs classify -> search -> features -> MLP -> composite for R rays x S samples.
     z: (R,S) per-ray depths or None (then z_table (S,) is shared by all rays).
     Returns a PassBuffers with rgb, depth, opacity, weights, num_nn, mask_sum and the row lists."""
@@ -224,8 +239,12 @@ def render_pass(grid, particles, rays, z, z_table, S, radius, K, enc_flags, use_
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(lib.nf_nerf_mlp_fwd(ptr(packed), cx, cd, ptr(b.X), ptr(b.n_rows), max_rows, ptr(b.row_sample),
-                              ptr(b.rgbsigma), ptr(b.acts), st), "nf_nerf_mlp_fwd")
+    if packed_h is not None:      # fp16-MFMA variant (inference only)
+        check(lib.nf_nerf_mlp_fwd_h(ptr(packed), ptr(packed_h), cx, cd, ptr(b.X), ptr(b.n_rows), max_rows,
+                                    ptr(b.row_sample), ptr(b.rgbsigma), st), "nf_nerf_mlp_fwd_h")
+    else:
+        check(lib.nf_nerf_mlp_fwd(ptr(packed), cx, cd, ptr(b.X), ptr(b.n_rows), max_rows, ptr(b.row_sample),
+                                  ptr(b.rgbsigma), ptr(b.acts), st), "nf_nerf_mlp_fwd")
     if PROFILE is not None:
         e1.record()
         PROFILE["mlp"].append((e0, e1))
@@ -271,7 +290,7 @@ def tiles_to_rows(X, n, cx, cd):
     return torch.cat([f[:n, :cx], f[:n, 8 * qx:8 * qx + cd]], 1)
 
 
-def mlp_rows(packed, cx, cd, x, save_acts=False):
+def mlp_rows(packed, cx, cd, x, save_acts=False, packed_h=None):
     """NeRF.forward on row-major features x (n, cx+cd) through the MFMA kernel -> (n,4) [rgb, sigma]."""
     lib = _lib.load()
     n = x.shape[0]
@@ -280,6 +299,10 @@ def mlp_rows(packed, cx, cd, x, save_acts=False):
     row_sample = torch.arange(n, dtype=torch.int32, device=x.device)
     out = torch.zeros(n, 4, dtype=torch.float32, device=x.device)
     acts = torch.empty(n * 2432, dtype=torch.float32, device=x.device) if save_acts else None
+    if packed_h is not None:
+        check(lib.nf_nerf_mlp_fwd_h(ptr(packed), ptr(packed_h), cx, cd, ptr(X), ptr(n_rows), n, ptr(row_sample), ptr(out),
+                                    _lib.stream()), "nf_nerf_mlp_fwd_h")
+        return out
     check(lib.nf_nerf_mlp_fwd(ptr(packed), cx, cd, ptr(X), ptr(n_rows), n, ptr(row_sample), ptr(out), ptr(acts),
                               _lib.stream()), "nf_nerf_mlp_fwd")
     return (out, acts.view(n, 2432)) if save_acts else out

@@ -38,6 +38,10 @@ class RenderNet(nn.Module):
         self.fix_radius = bool(_get(cfg, "NN_search.fix_radius"))
         self.num_neighbor = int(_get(cfg, "NN_search.N_neighbor"))
         self.use_mask = bool(_get(cfg, "use_mask"))
+        # build-only key: "fp32" (default, exact) or "fp16" (fp16 MFMA, fp32 accumulate; inference only; BASELINE config 5)
+        self.mlp_dtype = str(_get(cfg, "mlp_dtype", "fp32"))
+        if self.mlp_dtype not in ("fp32", "fp16"):
+            raise ValueError("RENDERER.mlp_dtype must be fp32 or fp16")
         if not self.fix_radius:
             raise NotImplementedError("fix_radius=False is dead code in the reference (models/renderer.py:119-121)")
         if not _get(cfg, "encoding.exclude_ray", True):
@@ -88,6 +92,11 @@ class RenderNet(nn.Module):
         layers = net.linear_layers()
         return ops.pack_nerf([l.weight for l in layers], [l.bias for l in layers], self.in_channels_xyz,
                              self.in_channels_dir)
+
+    def packed_weights_h(self, net):
+        layers = net.linear_layers()
+        return ops.pack_nerf_h([l.weight for l in layers], [l.bias for l in layers], self.in_channels_xyz,
+                               self.in_channels_dir)
 
     # ------------------------------------------------------------------
     def forward(self, physical_particles, ro, rays, focal=None, c2w=None, use_disp=False, perturb=0, noise_std=0.,

@@ -359,3 +359,29 @@ def test_particle_gradients_vs_oracle_autograd(dev):
     assert rel < 5e-3, rel
     touched = ref.abs().sum(1) > 0
     assert torch.equal(touched, got.abs().sum(1) > 0)
+
+
+def test_fp16_mfma_path(dev):
+    """BASELINE config 5: fp16-MFMA MLP (fp32 accumulate).  Stated tolerance: rgb/sigma rows within 2e-2 of the fp32
+    MLP on unit-scale features, rendered RGB >= 40 dB PSNR vs the fp32 path; neighbour sets / masks stay bit-exact."""
+    from neurofluid_amd import ops
+    from oracle import render_oracle as ro
+    net = make_net(dev)
+    gen = torch.Generator().manual_seed(21)
+    for n in (1, 33, 128, 1000):
+        xr = (torch.rand(n, 252, generator=gen) * 2 - 1).to(dev)
+        ref = ops.mlp_rows(net.packed_weights(net.nerf_fine), 198, 54, xr)
+        got = ops.mlp_rows(net.packed_weights(net.nerf_fine), 198, 54, xr, packed_h=net.packed_weights_h(net.nerf_fine))
+        err = (got - ref).abs()
+        assert float(err[:, :3].max()) < 2e-2, float(err[:, :3].max())
+        assert float((err[:, 3] / (1 + ref[:, 3].abs())).max()) < 2e-2
+    g = load_golden("a10_forward")
+    P, rays, roc = T(g["particles"], dev), T(g["rays"], dev), T(g["ro"], dev)
+    net16 = make_net(dev, dict(make_cfg(), mlp_dtype="fp16"))
+    with torch.no_grad():
+        a = net(P, roc, rays, None, None)
+        b = net16(P, roc, rays, None, None)
+    assert torch.equal(a["mask_0"], b["mask_0"]) and torch.equal(a["num_nn_0"], b["num_nn_0"])
+    p = ro.psnr(b["rgb0"].cpu(), a["rgb0"].cpu())
+    assert p >= 40.0, p
+    print("fp16 path: coarse PSNR vs fp32", p, " fine", ro.psnr(b["rgb1"].cpu(), a["rgb1"].cpu()))

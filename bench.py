@@ -186,6 +186,34 @@ def main():
     torch.cuda.synchronize()
     pstep = P0.shape[0] * nts / (time.perf_counter() - t1)
 
+    # ---- extra (NOT the headline, which stays fp32): the same render step with the fp16-MFMA MLP (BASELINE config 5)
+    fp16_extra = None
+    if args.workload == "render":
+        cfg16 = renderer_cfg(); cfg16["mlp_dtype"] = "fp16"
+        net16 = RenderNet(cfg16, 9.0, 13.0)
+        net16.load_state_dict(scene["nerf_state"], strict=True)
+        net16 = net16.to(dev)
+
+        def step16():
+            with torch.no_grad():
+                return render_image(net16, P0, n_rays, roc, rays, None, None, iseval=True, ray_chunk=args.chunk,
+                                    rank=rank, world=world, gather=False)
+        out16 = step16()
+        sync()
+        t2 = time.perf_counter()
+        for _ in range(3):
+            out16 = step16()
+        sync()
+        dt16 = (time.perf_counter() - t2) / 3
+        mine = nfdist.my_chunks((n_rays + args.chunk - 1) // args.chunk, rank, world)
+        a = out["pred_rgbs_1"] if world == 1 else None
+        psnr16 = None
+        if world == 1:
+            mse = torch.mean((out16["pred_rgbs_1"] - out["pred_rgbs_1"]) ** 2).item()
+            psnr16 = (-10.0 * math.log10(mse)) if mse > 0 else float("inf")
+        fp16_extra = {"rays_per_sec": n_rays / dt16, "ms_per_step": dt16 * 1e3, "dtype": "f16 MFMA, f32 accumulate",
+                      "psnr_vs_f32_path_db": psnr16, "note": "render only (no transition step); not the headline value"}
+
     if rank == 0:
         res = {"metric": "rays/sec (renderer coarse+fine forward) coupled with one transition step per frame, watercube 400^2",
                "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -198,7 +226,7 @@ def main():
                           "particles": int(P0.shape[0]), "image": "400x400", "N_samples": 64, "N_importance": 128,
                           "K": 20, "use_mask": True, "device_ray_chunk": args.chunk},
                "particle_steps_per_sec": pstep * world, "particle_steps_note": "ParticleNet.forward alone, replicated per rank",
-               "roofline": roofline}
+               "roofline": roofline, "fp16_mfma_path": fp16_extra}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(scene)
             res["speedup_vs_cpu_port"] = value / res["cpu_baseline"]["value"]

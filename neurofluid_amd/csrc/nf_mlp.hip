@@ -215,14 +215,6 @@ __device__ __forceinline__ void kloop_x4(const f32x4* __restrict__ wp, const f32
     }
 }
 
-// (An opaque zero OFFSET rather than an opaque pointer: laundering the pointer itself drops its
-// global address space and turns every load into flat_load + vmcnt(0)/lgkmcnt(0) waits.)
-__device__ __forceinline__ int opaque_zero()
-{
-    int z = 0;
-    asm volatile("" : "+s"(z));
-    return z;
-}
 
 // row-major save of a fragment (training): feature f of sample `row` -> dst[row*stride + f]
 template <int NB>

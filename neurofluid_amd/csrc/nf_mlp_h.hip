@@ -23,6 +23,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define H_SLOT_U4 512        // one slot = 8 KB = 512 x 16 B
 #define H_RING_SLOTS 8
 #define H_CHUNK_SLOTS 4
+#define H_STAGE (H_CHUNK_SLOTS * 2)     // u32x4 per lane staged per chunk by each of the 4 waves
 
 // ------------------------------------------------------------------------------------------------
 // stream description (host) and packing
@@ -159,7 +160,9 @@ struct HCtx {
     int half;              // running half-slot toggle for 4-block steps
     int nchunks, chunk_next;
     int lane, wave;
-    u32x4 stage[8];        // this wave's share (8 KB) of the next chunk, in flight
+    u32x4 stage[H_STAGE];  // this wave's share of the next chunk, in flight
+    u32x4 a[8], an[8];     // A operands of the current slot / of the next slot (prefetched)
+    bool a_ok, an_ok;      // compile-time foldable after full unrolling (the slot sequence of a tile is static)
 };
 
 // Called before consuming a slot whose index is a multiple of H_CHUNK_SLOTS: publish the staged chunk, rendezvous,
@@ -167,34 +170,54 @@ struct HCtx {
 __device__ __forceinline__ void h_boundary(HCtx& c)
 {
     const int half = (c.slot / H_CHUNK_SLOTS) & 1;
-    u32x4* dst = c.ring + half * (H_CHUNK_SLOTS * H_SLOT_U4) + c.wave * 512 + c.lane;
+    u32x4* dst = c.ring + half * (H_CHUNK_SLOTS * H_SLOT_U4) + c.wave * (H_STAGE * 64) + c.lane;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) dst[i * 64] = c.stage[i];
+    for (int i = 0; i < H_STAGE; ++i) dst[i * 64] = c.stage[i];
     __syncthreads();
-    const u32x4* src = c.stream + (size_t)c.chunk_next * (H_CHUNK_SLOTS * H_SLOT_U4) + c.wave * 512 + c.lane;
+    const u32x4* src = c.stream + (size_t)c.chunk_next * (H_CHUNK_SLOTS * H_SLOT_U4) + c.wave * (H_STAGE * 64) + c.lane;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) c.stage[i] = src[i * 64];
+    for (int i = 0; i < H_STAGE; ++i) c.stage[i] = src[i * 64];
     c.chunk_next = (c.chunk_next + 1 == c.nchunks) ? 0 : c.chunk_next + 1;
 }
 
+// One K-step.  The slot's 8 sub-blocks are read from the LDS ring into c.a; the NEXT slot is prefetched into c.an
+// before the MFMAs are issued unless it starts a new chunk (its data is only guaranteed after the next rendezvous).
 template <int NB>
 __device__ __forceinline__ void h_step(HCtx& c, const h8 b, f32x16 (&acc)[NB], bool zero_c)
 {
-    if (NB == 8 || c.half == 0) {
-        if ((c.slot % H_CHUNK_SLOTS) == 0) h_boundary(c);
-    }
-    const u32x4* base = c.ring + (c.slot % H_RING_SLOTS) * H_SLOT_U4 + (NB == 4 ? c.half * 256 : 0) + c.lane;
-    u32x4 a[NB];
+    const bool first_of_slot = (NB == 8) || (c.half == 0);
+    if (first_of_slot) {
+        if ((c.slot % H_CHUNK_SLOTS) == 0) { h_boundary(c); }
+        if (!c.a_ok) {
+            const u32x4* base = c.ring + (c.slot % H_RING_SLOTS) * H_SLOT_U4 + c.lane;
 #pragma unroll
-    for (int ib = 0; ib < NB; ++ib) a[ib] = base[ib * 64];
+            for (int ib = 0; ib < 8; ++ib) c.a[ib] = base[ib * 64];
+            c.a_ok = true;
+        }
+        if (((c.slot + 1) % H_CHUNK_SLOTS) != 0) {
+            const u32x4* nb = c.ring + ((c.slot + 1) % H_RING_SLOTS) * H_SLOT_U4 + c.lane;
+#pragma unroll
+            for (int ib = 0; ib < 8; ++ib) c.an[ib] = nb[ib * 64];
+            c.an_ok = true;
+        }
+    }
     const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int o = (NB == 4) ? c.half * 4 : 0;
 #pragma unroll
     for (int ib = 0; ib < NB; ++ib) {
-        h8 av = __builtin_bit_cast(h8, a[ib]);
+        h8 av = __builtin_bit_cast(h8, c.a[o + ib]);
         acc[ib] = MFMA16(av, b, zero_c ? z : acc[ib]);
     }
-    if (NB == 8) c.slot++;
-    else { if (c.half) c.slot++; c.half ^= 1; }
+    const bool leave = (NB == 8) || (c.half == 1);
+    if (NB == 4) c.half ^= 1;
+    if (leave) {
+        c.slot++;
+#pragma unroll
+        for (int ib = 0; ib < 8; ++ib) c.a[ib] = c.an[ib];
+        c.a_ok = c.an_ok;
+        c.an_ok = false;
+    }
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 __device__ __forceinline__ h8 pack8(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7)
@@ -215,6 +238,7 @@ template <int NB>
 __device__ __forceinline__ void h_xsteps(HCtx& c, const f32x4* __restrict__ xt /* + lane */, int t0, int t1, f32x16 (&acc)[NB])
 {
     f32x4 x0 = xt[(2 * t0) * 64], x1 = xt[(2 * t0 + 1) * 64];
+#pragma unroll
     for (int t = t0; t < t1; ++t) {
         f32x4 n0 = x0, n1 = x1;
         if (t + 1 < t1) { n0 = xt[(2 * t + 2) * 64]; n1 = xt[(2 * t + 3) * 64]; }
@@ -251,7 +275,7 @@ __global__ void __launch_bounds__(256) k_mlp_fwd_h(NfMlpLayout L, const float* _
                                                    const float* __restrict__ X, const int* __restrict__ n_rows, int max_rows,
                                                    const int* __restrict__ row_sample, float4* __restrict__ rgbsigma)
 {
-    __shared__ u32x4 ring[H_RING_SLOTS * H_SLOT_U4];
+    extern __shared__ u32x4 ring[];   // H_RING_SLOTS * 8 KB
     const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, wave = threadIdx.x >> 6;
     const int nrows = min(*n_rows, max_rows);
     const int ntiles = (nrows + 31) >> 5;
@@ -261,9 +285,9 @@ __global__ void __launch_bounds__(256) k_mlp_fwd_h(NfMlpLayout L, const float* _
     c.stream = stream_h; c.ring = ring; c.slot = 0; c.half = 0;
     c.nchunks = nslots / H_CHUNK_SLOTS; c.chunk_next = 1; c.lane = lane; c.wave = wave;
     {
-        const u32x4* src = stream_h + wave * 512 + lane;
+        const u32x4* src = stream_h + wave * (H_STAGE * 64) + lane;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) c.stage[i] = src[i * 64];
+        for (int i = 0; i < H_STAGE; ++i) c.stage[i] = src[i * 64];
     }
     for (int tg = blockIdx.x; tg < ngroups; tg += gridDim.x) {
         int tile = tg * 4 + wave;
@@ -272,19 +296,21 @@ __global__ void __launch_bounds__(256) k_mlp_fwd_h(NfMlpLayout L, const float* _
         const f32x4* xt = (const f32x4*)X + (size_t)tile * Q * 64 + lane;
         const int row = tile * 32 + j;
         const bool row_ok = owner && row < nrows;
+        const float* __restrict__ pk = packed + opaque_zero();
         f32x16 accA[8], accB[8];
+        c.slot = 0; c.half = 0; c.a_ok = false; c.an_ok = false;   // every tile consumes exactly nslots (multiple of the ring)
         // layer 0
         h_step<8>(c, bias_b(h), accA, true);
         h_xsteps<8>(c, xt, 0, 13, accA);
-#pragma unroll 1
-        for (int l = 1; l < 9; l += 2) {
-            h_layer(c, l, xt, accA, accB);
-            h_layer(c, l + 1, xt, accB, accA);
-        }
+        // written out (not a loop): with the slot sequence static, every boundary / prefetch decision folds
+        h_layer(c, 1, xt, accA, accB); h_layer(c, 2, xt, accB, accA);
+        h_layer(c, 3, xt, accA, accB); h_layer(c, 4, xt, accB, accA);
+        h_layer(c, 5, xt, accA, accB); h_layer(c, 6, xt, accB, accA);
+        h_layer(c, 7, xt, accA, accB); h_layer(c, 8, xt, accB, accA);
         // sigma from h8 = relu(accB) in fp32
         float sigma;
         {
-            const float* ws_ = packed + L.off_wsig;
+            const float* ws_ = pk + L.off_wsig;
             float part = 0.f;
 #pragma unroll
             for (int b = 0; b < 8; ++b)
@@ -293,7 +319,7 @@ __global__ void __launch_bounds__(256) k_mlp_fwd_h(NfMlpLayout L, const float* _
                     const float w0 = ws_[(b * 16 + r) * 2], w1 = ws_[(b * 16 + r) * 2 + 1];
                     part += fmaxf(accB[b][r], 0.f) * (h ? w1 : w0);
                 }
-            sigma = part + __shfl_xor(part, 32, 64) + packed[L.off_bsig];
+            sigma = part + __shfl_xor(part, 32, 64) + pk[L.off_bsig];
         }
         // view branch
         f32x16 hd[4];
@@ -306,7 +332,8 @@ __global__ void __launch_bounds__(256) k_mlp_fwd_h(NfMlpLayout L, const float* _
             if ((c.slot % H_CHUNK_SLOTS) == 0) h_boundary(c);
             c.slot++;
         }
-        const float* wr = packed + L.off_wrgb;
+        c.a_ok = false; c.an_ok = false;
+        const float* wr = pk + L.off_wrgb;
         float c0 = 0.f, c1 = 0.f, c2 = 0.f;
 #pragma unroll
         for (int b = 0; b < 4; ++b)
@@ -319,7 +346,7 @@ __global__ void __launch_bounds__(256) k_mlp_fwd_h(NfMlpLayout L, const float* _
                 c2 += v * (h ? wr[256 + k + 1] : wr[256 + k]);
             }
         c0 += __shfl_xor(c0, 32, 64); c1 += __shfl_xor(c1, 32, 64); c2 += __shfl_xor(c2, 32, 64);
-        c0 += packed[L.off_brgb]; c1 += packed[L.off_brgb + 1]; c2 += packed[L.off_brgb + 2];
+        c0 += pk[L.off_brgb]; c1 += pk[L.off_brgb + 1]; c2 += pk[L.off_brgb + 2];
         if (h == 0 && row_ok) {
             float4 o;
             o.x = 1.f / (1.f + expf(-c0)); o.y = 1.f / (1.f + expf(-c1)); o.z = 1.f / (1.f + expf(-c2)); o.w = sigma;
@@ -341,7 +368,13 @@ extern "C" int nf_nerf_mlp_fwd_h(const float* packed, const void* stream_h, int 
     int tiles = (max_rows + 31) / 32;
     int blocks = (tiles + 3) / 4;
     if (blocks > 256) blocks = 256;
-    hipLaunchKernelGGL(k_mlp_fwd_h, dim3(blocks), dim3(256), 0, (hipStream_t)stream, L, packed, (const u32x4*)stream_h,
+    const size_t lds = (size_t)H_RING_SLOTS * H_SLOT_U4 * 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)k_mlp_fwd_h, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_mlp_fwd_h, dim3(blocks), dim3(256), lds, (hipStream_t)stream, L, packed, (const u32x4*)stream_h,
                        S.nslots, X, n_rows, max_rows, row_sample, (float4*)rgbsigma);
     NF_CHECK_LAUNCH();
     return NF_OK;

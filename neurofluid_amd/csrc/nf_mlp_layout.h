@@ -54,3 +54,14 @@ struct NfNerfPtrs {
     const float* w[12];
     const float* b[12];
 };
+
+// Stops LICM from hoisting the (loop-invariant) head-weight loads out of the persistent tile loop, where they
+// would cost hundreds of live registers.
+// (An opaque zero OFFSET rather than an opaque pointer: laundering the pointer itself drops its
+// global address space and turns every load into flat_load + vmcnt(0)/lgkmcnt(0) waits.)
+__device__ __forceinline__ int opaque_zero()
+{
+    int z = 0;
+    asm volatile("" : "+s"(z));
+    return z;
+}

@@ -51,23 +51,23 @@ def build_scene(dev):
 
 def cpu_baseline(scene):
     """The oracle (CPU port of the reference path) on a bounded, representative sample (about 10-30 s of CPU work):
-    every 640th ray of the 400^2 image (250 rays, same hit ratio as the full frame) + 2 transition steps.
+    every 40th ray of the 400^2 image (4000 rays, same hit ratio as the full frame) + 5 transition steps.
     torch intra-op threads are capped at 16: the oracle's ops are small and lose time beyond that."""
     from oracle import render_oracle as ro, trans_oracle as to
     cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
-    rays = scene["rays"][::640].contiguous()
+    rays = scene["rays"][::40].contiguous()
     t0 = time.time()
     ro.render_forward(scene["nerf_state"], scene["P"], scene["c2w"][:, 3], rays, 9.0, 13.0)
     dt = time.time() - t0
     t1 = time.time()
     p, v = scene["P"], torch.zeros_like(scene["P"])
-    nsteps = 2
+    nsteps = 5
     for _ in range(nsteps):
         p, v, _ = to.particle_net_forward(scene["trans_state"], p, v, scene["box"], scene["bn"])
     dts = time.time() - t1
     return {"value": rays.shape[0] / dt, "unit": "rays/s", "cores": cores, "kind": "port",
-            "sample": f"oracle.render_forward on every 640th ray of the 400x400 frame ({rays.shape[0]} rays, {dt:.1f} s); "
+            "sample": f"oracle.render_forward on every 40th ray of the 400x400 frame ({rays.shape[0]} rays, {dt:.1f} s); "
                       f"oracle.particle_net_forward x{nsteps} on 4913 particles ({dts:.1f} s); "
                       f"{cores} torch threads of {os.cpu_count()} host cores",
             "particle_steps_per_sec": scene["P"].shape[0] * nsteps / dts}

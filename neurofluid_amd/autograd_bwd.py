@@ -60,28 +60,22 @@ def _pass_backward(net, nerf, pb, rays_c, z, z_table, g_rgb, white_bg, particles
     check(lib.nf_nerf_mlp_bwd(ptr(pb.packed), ptr(packed_t), cx, cd, ptr(pb.acts), ptr(pb.n_rows), n, ptr(pb.row_sample),
                               ptr(pb.rgbsigma), ptr(d_rs), ptr(dpre), st), "nf_nerf_mlp_bwd")
     A = pb.acts.view(-1, ACT)[:n]
-    X = ops.tiles_to_rows(pb.X, n, cx, cd)
-    Xx, Xd = X[:, :cx], X[:, cx:]
-    gw, gb = [], []
-    for k in range(8):
-        D = dpre[:, k * 256:(k + 1) * 256]
-        if k == 0:
-            dW = D.t() @ Xx
-        elif k == 4:
-            dW = torch.cat([D.t() @ Xx, D.t() @ A[:, 3 * 256:4 * 256]], dim=1)
-        else:
-            dW = D.t() @ A[:, (k - 1) * 256:k * 256]
-        gw.append(dW)
-        gb.append(D.sum(0))
-    h8 = A[:, 7 * 256:8 * 256]
-    Dfin = dpre[:, 8 * 256:9 * 256]
-    gw.append(Dfin.t() @ h8); gb.append(Dfin.sum(0))
+    X = ops.tiles_to_rows(pb.X, n, cx, cd).contiguous()
+    # weight gradients: one batched fp32-MFMA launch for all 15 GEMMs of the net (nf_nerf_wgrad)
+    nsl = 16
+    blob = torch.empty(lib.nf_nerf_wgrad_floats(cx, cd), dtype=torch.float32, device=dev)
+    wsp = torch.empty(lib.nf_nerf_wgrad_workspace_floats(cx, cd, nsl), dtype=torch.float32, device=dev)
+    check(lib.nf_nerf_wgrad(ptr(dpre), ptr(pb.acts), ptr(X), cx, cd, n, nsl, ptr(wsp), ptr(blob), st), "nf_nerf_wgrad")
+    gw, o = [], 0
+    for l in layers:
+        k = l.weight.numel()
+        gw.append(blob[o:o + k].view_as(l.weight))
+        o += k
+    # bias gradients = column sums of dpre (one reduction)
+    colsum = dpre.sum(0)
+    gb = [colsum[k * 256:(k + 1) * 256] for k in range(8)]
+    gb += [colsum[8 * 256:9 * 256], colsum[9 * 256:9 * 256 + 128], colsum[2435:2436], colsum[2432:2435]]
     Ddir = dpre[:, 9 * 256:9 * 256 + 128]
-    gw.append(torch.cat([Ddir.t() @ A[:, 8 * 256:9 * 256], Ddir.t() @ Xd], dim=1)); gb.append(Ddir.sum(0))
-    Dsig = dpre[:, 2435:2436]
-    gw.append(Dsig.t() @ h8); gb.append(Dsig.sum(0))
-    Drgb = dpre[:, 2432:2435]
-    gw.append(Drgb.t() @ A[:, 9 * 256:9 * 256 + 128]); gb.append(Drgb.sum(0))
     if dparticles is not None:
         # dL/dX = W^T dpre for the three layers that read the feature matrix (plain GEMMs), then HIP scatter
         W1, W5, Wd = layers[0].weight.detach(), layers[4].weight.detach(), layers[9].weight.detach()

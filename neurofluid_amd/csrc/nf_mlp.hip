@@ -686,3 +686,139 @@ extern "C" int nf_nerf_mlp_bwd(const float* packed, const float* packed_t, int c
     NF_CHECK_LAUNCH();
     return NF_OK;
 }
+
+// ================================================================================================
+// weight gradients: all 15 GEMMs  dW[m][n] = sum_rows dpre[row][a_col+m] * B[row][b_col+n]  of one NeRF in ONE
+// batched launch on fp32 MFMA.  grid.x = tile (over all GEMMs), grid.y = K-slice (split over rows).  128x128 output
+// tile per 4-wave workgroup, 32-row slabs of both operands staged through LDS (k-major, conflict-free fragment
+// reads), per-slice partial tiles written to P[slice][...] and summed by k_wgrad_reduce (deterministic, no atomics).
+// ================================================================================================
+#define WG_MAX_GEMMS 16
+struct NfWgradGemm { int a_col, b_src, b_col, M, N, c_off, ldc, c_col, tile0, tiles_n; };
+struct NfWgradPlan { int ngemm, ntiles, total; NfWgradGemm g[WG_MAX_GEMMS]; };
+
+static NfWgradPlan wgrad_plan(int cx, int cd)
+{
+    NfWgradPlan P;
+    int n = 0, off = 0, tiles = 0;
+    auto add = [&](int a_col, int b_src, int b_col, int M, int N, int c_off, int ldc, int c_col) {
+        NfWgradGemm& g = P.g[n++];
+        g.a_col = a_col; g.b_src = b_src; g.b_col = b_col; g.M = M; g.N = N; g.c_off = c_off; g.ldc = ldc; g.c_col = c_col;
+        g.tile0 = tiles; g.tiles_n = (N + 127) / 128;
+        tiles += ((M + 127) / 128) * g.tiles_n;
+    };
+    // output blob: the 12 weight tensors in nf_nerf_params_t order, each [out][in] row-major
+    for (int l = 0; l < 8; ++l) {
+        int in_dim = (l == 0) ? cx : (l == 4 ? cx + 256 : 256);
+        if (l == 0) add(0, 1, 0, 256, cx, off, in_dim, 0);
+        else if (l == 4) { add(l * 256, 1, 0, 256, cx, off, in_dim, 0); add(l * 256, 0, 3 * 256, 256, 256, off, in_dim, cx); }
+        else add(l * 256, 0, (l - 1) * 256, 256, 256, off, in_dim, 0);
+        off += 256 * in_dim;
+    }
+    add(8 * 256, 0, 7 * 256, 256, 256, off, 256, 0); off += 256 * 256;                       // xyz_encoding_final
+    add(9 * 256, 0, 8 * 256, 128, 256, off, 256 + cd, 0);                                    // dir_encoding: [final | dir]
+    add(9 * 256, 1, cx, 128, cd, off, 256 + cd, 256); off += 128 * (256 + cd);
+    add(2435, 0, 7 * 256, 1, 256, off, 256, 0); off += 256;                                  // sigma
+    add(2432, 0, 9 * 256, 3, 128, off, 128, 0); off += 3 * 128;                              // rgb
+    P.ngemm = n; P.ntiles = tiles; P.total = off;
+    return P;
+}
+
+extern "C" size_t nf_nerf_wgrad_floats(int cx, int cd) { return (size_t)wgrad_plan(cx, cd).total; }
+
+#define WG_KS 32
+__global__ void __launch_bounds__(256) k_wgrad(NfWgradPlan P, const float* __restrict__ dpre, const float* __restrict__ acts,
+                                               const float* __restrict__ xrow, int ld_x, int n_rows, int rows_per_slice,
+                                               float* __restrict__ partial)
+{
+    __shared__ float As[WG_KS][128 + 4];
+    __shared__ float Bs[WG_KS][128 + 4];
+    // locate the GEMM of this tile
+    int gi = 0;
+#pragma unroll 1
+    for (int i = 1; i < P.ngemm; ++i) if ((int)blockIdx.x >= P.g[i].tile0) gi = i;
+    const NfWgradGemm G = P.g[gi];
+    const int t = blockIdx.x - G.tile0;
+    const int m0 = (t / G.tiles_n) * 128, n0 = (t % G.tiles_n) * 128;
+    const float* Bsrc = G.b_src ? xrow : acts;
+    const int ldb = G.b_src ? ld_x : NF_ACT_STRIDE;
+    const int r0 = blockIdx.y * rows_per_slice, r1 = min(n_rows, r0 + rows_per_slice);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    for (int k0 = r0; k0 < r1; k0 += WG_KS) {
+        // slabs: 32 rows x 128 columns each, coalesced along the columns
+        for (int e = tid; e < WG_KS * 128; e += 256) {
+            int k = e >> 7, c = e & 127;
+            int row = k0 + k;
+            float av = 0.f, bv = 0.f;
+            if (row < r1) {
+                if (m0 + c < G.M) av = dpre[(size_t)row * NF_DPRE_STRIDE + G.a_col + m0 + c];
+                if (n0 + c < G.N) bv = Bsrc[(size_t)row * ldb + G.b_col + n0 + c];
+            }
+            As[k][c] = av;
+            Bs[k][c] = bv;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < WG_KS; kk += 2) {
+            int kr = kk + (lane >> 5), c = lane & 31;
+            float a0 = As[kr][wm + c], a1 = As[kr][wm + 32 + c];
+            float b0 = Bs[kr][wn + c], b1 = Bs[kr][wn + 32 + c];
+            acc[0][0] = MFMA32(a0, b0, acc[0][0]);
+            acc[0][1] = MFMA32(a0, b1, acc[0][1]);
+            acc[1][0] = MFMA32(a1, b0, acc[1][0]);
+            acc[1][1] = MFMA32(a1, b1, acc[1][1]);
+        }
+        __syncthreads();
+    }
+    float* out = partial + (size_t)blockIdx.y * P.total + G.c_off;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int m = m0 + wm + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                int n = n0 + wn + 32 * b + (lane & 31);
+                if (m < G.M && n < G.N) out[(size_t)m * G.ldc + G.c_col + n] = acc[a][b][r];
+            }
+}
+
+__global__ void k_wgrad_reduce(const float* __restrict__ partial, int total, int nslices, float* __restrict__ out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    float s = 0.f;
+    for (int z = 0; z < nslices; ++z) s += partial[(size_t)z * total + i];
+    out[i] = s;
+}
+
+extern "C" size_t nf_nerf_wgrad_workspace_floats(int cx, int cd, int nslices) { return (size_t)wgrad_plan(cx, cd).total * nslices; }
+
+extern "C" int nf_nerf_wgrad(const float* dpre, const float* acts, const float* xrow, int cx, int cd, int n_rows,
+                             int nslices, float* workspace, float* dweights, nf_stream_t stream)
+{
+    NF_CHECK_ARG(dpre && acts && xrow && workspace && dweights, "null pointer");
+    NF_CHECK_ARG(nslices >= 1 && nslices <= 65535, "bad slice count");
+    NfWgradPlan P = wgrad_plan(cx, cd);
+    hipStream_t st = (hipStream_t)stream;
+    if (n_rows <= 0) {
+        hipMemsetAsync(dweights, 0, sizeof(float) * P.total, st);
+        return NF_OK;
+    }
+    int rows_per = (n_rows + nslices - 1) / nslices;
+    rows_per = (rows_per + WG_KS - 1) / WG_KS * WG_KS;
+    int ns = (n_rows + rows_per - 1) / rows_per;
+    hipLaunchKernelGGL(k_wgrad, dim3(P.ntiles, ns), dim3(256), 0, st, P, dpre, acts, xrow, cx + cd, n_rows, rows_per, workspace);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((P.total + 255) / 256), dim3(256), 0, st, (const float*)workspace, P.total, ns,
+                       dweights);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}

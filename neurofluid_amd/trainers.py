@@ -20,7 +20,7 @@ from .datasets import BlenderDataset, ParticleDataset
 from .point_eval import FluidErrors
 from .render_loop import render_image as _render_image
 from .renderer import RenderNet
-from .train_step import ExponentialLR, random_sample_coords
+from .train_step import ExponentialLR, PixelSampler, random_sample_coords
 from .transmodel import ParticleNet
 
 to8b = lambda x: (255 * np.clip(x, 0, 1)).astype(np.uint8)   # noqa: E731  trainer/basetrainer.py:16
@@ -132,9 +132,10 @@ class BaseTrainer:
     def random_sample_coords(self, H, W, global_step):
         return random_sample_coords(H, W, global_step, self.options.TRAIN.precrop_iters)
 
-    def sample_pixels(self, rays_hw6, rgbs, H, W, global_step, ray_chunk):
+    def sample_pixels(self, rays_hw6, rgbs, H, W, global_step, ray_chunk, sel=None):
         coords = self.random_sample_coords(H, W, global_step)
-        sel = np.random.choice(coords.shape[0], size=[ray_chunk], replace=False)
+        if sel is None:
+            sel = np.random.choice(coords.shape[0], size=[ray_chunk], replace=False)
         sc = coords[sel].long().to(rays_hw6.device)
         return rays_hw6[sc[:, 0], sc[:, 1]], rgbs.view(H, W, -1)[sc[:, 0], sc[:, 1]]
 
@@ -217,12 +218,17 @@ class RendererTrainer(BaseTrainer):
         data = self._to_dev(self.dataset[0])              # always frame 0 (trainer_renderer.py:81)
         last = o.TRAIN.N_iters if max_steps is None else min(o.TRAIN.N_iters, self.start_step + max_steps)
         loss = None
+        # the global np.random stream, drawn in the reference's order but one step ahead on a host thread
+        self._sampler = PixelSampler(np.random, len(self.train_view_names), o.RENDERER.ray.ray_chunk,
+                                     lambda s: self.random_sample_coords(H, W, s).shape[0], self.start_step)
         for step_idx in range(self.start_step, last):
             loss = self.train_step(data, len(self.train_view_names), H, W, step_idx)
             self.update_step(loss)
             if (step_idx + 1) % o.TRAIN.save_interval == 0:
                 self.eval(step_idx)
                 self.save_checkpoint(step_idx)
+        self._sampler.close()
+        self._sampler = None
         return loss
 
     def update_step(self, loss):
@@ -236,8 +242,9 @@ class RendererTrainer(BaseTrainer):
     def train_step(self, data, view_num, H, W, step_idx):
         rc = self.options.RENDERER.ray.ray_chunk
         rays_l, rgbs_l, ro_l = [], [], []
+        sels = self._sampler.next(step_idx) if getattr(self, '_sampler', None) is not None else [None] * view_num
         for v in range(view_num):
-            rays, rgbs = self.sample_pixels(data['rays'][v], data['rgb'][v], H, W, step_idx, rc)
+            rays, rgbs = self.sample_pixels(data['rays'][v], data['rgb'][v], H, W, step_idx, rc, sels[v])
             rays_l.append(rays); rgbs_l.append(rgbs)
             ro_l.append(self.renderer.set_ro(data['cw'][v]).expand(rc, 3))
         # the views are rendered in ONE fused call (rays are independent; per-ray camera position)

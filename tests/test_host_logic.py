@@ -51,3 +51,15 @@ def test_gather_chunks_single_rank_identity():
     x = torch.arange(10 * 3, dtype=torch.float32).view(10, 3)
     pad = torch.zeros(12, 3); pad[:10] = x
     assert torch.equal(nfdist.gather_chunks(pad, 3, 4, 10, 0, 1), x)
+
+
+def test_pixel_sampler_keeps_the_rng_stream():
+    """The background prefetch must hand out exactly the selections sequential rng.choice calls would."""
+    from neurofluid_amd.train_step import PixelSampler
+    ref_rng = np.random.RandomState(10)
+    ref = [[ref_rng.choice(160000, size=[1024], replace=False) for _ in range(4)] for _ in range(3)]
+    ps = PixelSampler(np.random.RandomState(10), 4, 1024, lambda s: 160000, first_step=7)
+    for i in range(3):
+        got = ps.next(7 + i)
+        assert all(np.array_equal(a, b) for a, b in zip(got, ref[i]))
+    ps.close()

@@ -41,7 +41,9 @@ struct NfGridHeader {
     int off_cell_fill;
     int off_cell_aabb;   // float[6] per cell: min xyz, max xyz of the contained points (+inf/-inf when empty)
     int off_cell_rec;    // 3 x float4 per cell: {start, end, min original index, -} {lo.xyz, hi.x} {hi.y, hi.z, -, -}
-    int pad_[3];
+    int off_dil_start;   // int[n_cells+1]: start of the cell's DILATED list (all points of its 27-neighbourhood)
+    int off_dil_pos;     // float4[sum cell_dil] (<= 27 n): xyz + index bits, ascending ORIGINAL index inside each list
+    int pad_[1];
 };
 
 struct NfGridView {
@@ -55,6 +57,8 @@ struct NfGridView {
     const float4* sorted_pos;
     const float* cell_aabb;
     const float4* cell_rec;
+    const int* dil_start;
+    const float4* dil_pos;
 };
 
 __device__ __forceinline__ NfGridView nf_grid_view(const void* ws)
@@ -72,6 +76,8 @@ __device__ __forceinline__ NfGridView nf_grid_view(const void* ws)
     v.sorted_pos = (const float4*)(b + h->off_sorted_pos);
     v.cell_aabb = (const float*)(b + h->off_cell_aabb);
     v.cell_rec = (const float4*)(b + h->off_cell_rec);
+    v.dil_start = (const int*)(b + h->off_dil_start);
+    v.dil_pos = (const float4*)(b + h->off_dil_pos);
     return v;
 }
 
@@ -99,8 +105,7 @@ __device__ __forceinline__ float nf_madd_nofma(float o, float d, float z) { retu
 // first-K-by-index search core (used by nf_grid.hip: ball query op, nf_render.hip: fused search)
 // ------------------------------------------------------------------------------------------------
 #define BQ_BLOCK 128
-#define BQ_LDS_INTS(K) (((K) + 27) * BQ_BLOCK)   // K indices + 27 cell keys per thread (squared distances are not
-                                                  // kept: only "d2 != 0" per slot, as a bit mask in a register)
+#define BQ_LDS_INTS(K) ((K) * BQ_BLOCK)   // K neighbour indices per thread, [k][thread] (conflict-free)
 
 // fp32 squared distance from a query to a cell's particle AABB, same op order as nf_dist2.  Because
 // fp32 sub/mul/add are monotone, box_d2 <= nf_dist2(query, p) for every particle p of the cell, so
@@ -132,80 +137,37 @@ __device__ __forceinline__ bool nf_any_cell_in_reach(const NfGridView& g, float 
     return false;
 }
 
-// Sorted insertion of index j into the per-thread ascending list held in LDS as list[k * BQ_BLOCK + tid];
-// `nzmask` bit k = (squared distance of slot k != 0) travels with the slots.  Returns the new count.
-__device__ __forceinline__ int firstk_insert(int* li, unsigned& nzmask, int cnt, int K, int j, bool nz, int tid)
+// First-K-by-index search.  Every cell owns a DILATED list: all points of its 27-cell neighbourhood, merged in
+// ascending original index at grid-build time.  A query therefore walks ONE list in exactly the reference's scan
+// order (pytorch3d scans p2 in index order) restricted to the points that can be in range, appends hits (they
+// arrive sorted: no insertion, no per-cell bookkeeping) and stops at the K-th.  Candidates are fetched 4 at a time
+// (independent loads in flight).  li = K indices [k * BQ_BLOCK + tid]; nzmask bit k = (d2 of slot k != 0).  K <= 32.
+__device__ __forceinline__ int firstk_search(const NfGridView& g, float qx, float qy, float qz, float r2, int K,
+                                             int* li, int tid, unsigned& nzmask)
 {
-    int pos = cnt < K ? cnt : K - 1;  // slot that is overwritten / appended
-    while (pos > 0 && li[(pos - 1) * BQ_BLOCK + tid] > j) {
-        li[pos * BQ_BLOCK + tid] = li[(pos - 1) * BQ_BLOCK + tid];
-        --pos;
-    }
-    li[pos * BQ_BLOCK + tid] = j;
-    // bits [pos, K-1) shift up by one, bit pos takes `nz`, bits >= K are dropped
-    const unsigned low = nzmask & ((1u << pos) - 1u);
-    const unsigned high = (nzmask >> pos) << (pos + 1);
-    nzmask = (low | high | ((nz ? 1u : 0u) << pos)) & ((K >= 32) ? 0xffffffffu : ((1u << K) - 1u));
-    return cnt < K ? cnt + 1 : K;
-}
-
-// First-K-by-index search.  Cells are index-sorted, so a cell's first entry is its minimum index.
-// Cells are visited in ascending order of that minimum (keys in LDS); once the list is full and the
-// smallest remaining key exceeds the current K-th index, no remaining particle can enter the list.
-// Candidates are fetched 4 at a time (independent loads in flight) — entries past the break point can
-// never enter the list, so testing them is harmless.  lk = 27 keys [c * BQ_BLOCK + tid].  K <= 32.
-__device__ __forceinline__ int firstk_search(const NfGridView& g, float qx, float qy, float qz, float r2_, int K,
-                                             int* li, int* lk, int tid, unsigned& nzmask)
-{
-    const float r2 = r2_;
     int cx = nf_cell_coord(qx, g.ox, g.icx, g.dx);
     int cy = nf_cell_coord(qy, g.oy, g.icy, g.dy);
     int cz = nf_cell_coord(qz, g.oz, g.icz, g.dz);
-    const int BIG = 0x7fffffff;
-    int nvalid = 0;
-    nzmask = 0u;
-    for (int c = 0; c < 27; ++c) {
-        int x = cx + (c % 3) - 1, y = cy + ((c / 3) % 3) - 1, z = cz + (c / 9) - 1;
-        int key = BIG;
-        if (x >= 0 && x < g.dx && y >= 0 && y < g.dy && z >= 0 && z < g.dz) {
-            const float4* rec = g.cell_rec + 3 * ((z * g.dy + y) * g.dx + x);   // one 48-byte record per cell
-            const float4 r0 = rec[0];
-            if (__float_as_int(r0.y) > __float_as_int(r0.x)) {
-                const float4 r1 = rec[1], r2 = rec[2];
-                const float bb[6] = {r1.x, r1.y, r1.z, r1.w, r2.x, r2.y};
-                if (nf_box_dist2(bb, qx, qy, qz) < r2_) { key = __float_as_int(r0.z); ++nvalid; }
-            }
-        }
-        lk[c * BQ_BLOCK + tid] = key;
-    }
+    const int cell = (cz * g.dy + cy) * g.dx + cx;
+    const int s = g.dil_start[cell], e = g.dil_start[cell + 1];
     int cnt = 0;
-    while (nvalid > 0) {
-        int best = BIG, bc = 0;
-        for (int c = 0; c < 27; ++c) {
-            int k = lk[c * BQ_BLOCK + tid];
-            if (k < best) { best = k; bc = c; }
-        }
-        if (best == BIG) break;
-        if (cnt == K && best > li[(K - 1) * BQ_BLOCK + tid]) break;
-        lk[bc * BQ_BLOCK + tid] = BIG;
-        --nvalid;
-        int x = cx + (bc % 3) - 1, y = cy + ((bc / 3) % 3) - 1, z = cz + (bc / 9) - 1;
-        const float4 r0 = g.cell_rec[3 * ((z * g.dy + y) * g.dx + x)];
-        int s = __float_as_int(r0.x), e = __float_as_int(r0.y);
-        bool done = false;
-        for (int t = s; t < e && !done; t += 4) {
-            float4 p[4];
+    nzmask = 0u;
+    for (int t = s; t < e; t += 4) {
+        float4 p[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) p[u] = g.sorted_pos[min(t + u, e - 1)];
+        for (int u = 0; u < 4; ++u) p[u] = g.dil_pos[min(t + u, e - 1)];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (t + u >= e) break;
-                int j = __float_as_int(p[u].w);
-                if (cnt == K && j > li[(K - 1) * BQ_BLOCK + tid]) { done = true; break; }  // cell is index-sorted
+        for (int u = 0; u < 4; ++u) {
+            if (t + u < e && cnt < K) {
                 float d2 = nf_dist2(qx, qy, qz, p[u].x, p[u].y, p[u].z);
-                if (d2 < r2) cnt = firstk_insert(li, nzmask, cnt, K, j, d2 != 0.f, tid);
+                if (d2 < r2) {
+                    li[cnt * BQ_BLOCK + tid] = __float_as_int(p[u].w);
+                    nzmask |= (d2 != 0.f ? 1u : 0u) << cnt;
+                    ++cnt;
+                }
             }
         }
+        if (cnt >= K) break;
     }
     return cnt;
 }

@@ -144,6 +144,8 @@ int nf_grid_make_header(int n, float cell, const float bbox[6], NfGridHeader* h,
     h->off_cell_fill = (int)off;  off = align_up(off + sizeof(int) * (cells + SCAN_BLOCK + 2048), 256);
     h->off_cell_aabb = (int)off;  off = align_up(off + sizeof(float) * 6 * cells, 256);
     h->off_cell_rec = (int)off;   off = align_up(off + sizeof(float4) * 3 * cells, 256);
+    h->off_dil_start = (int)off;  off = align_up(off + sizeof(int) * (cells + 1), 256);
+    h->off_dil_pos = (int)off;    off = align_up(off + sizeof(float4) * 27 * (size_t)(n > 0 ? n : 1), 256);
     if (off > (size_t)0x7fffffff) return NF_EINVAL;
     *total = off;
     return NF_OK;
@@ -243,6 +245,41 @@ __global__ void k_grid_dilate(NfGridHeader h, void* ws)
     rec[2] = make_float4(hi[1], hi[2], 0.f, 0.f);
 }
 
+// Dilated lists: point (sorted slot t) goes into the list of each of the <= 27 cells around its own cell, at the
+// rank given by its original index among all points of that target cell's neighbourhood (sum of binary searches
+// over the 27 index-sorted source lists) — a 27-way merge without any sorting pass.
+__global__ void k_grid_dil_fill(NfGridHeader h, void* ws)
+{
+    int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= h.n_points * 27) return;
+    int t = gid / 27, o = gid % 27;
+    char* b = (char*)ws;
+    const int* cs = (const int*)(b + h.off_cell_start);
+    const int* sidx = (const int*)(b + h.off_sorted_idx);
+    const float4* spos = (const float4*)(b + h.off_sorted_pos);
+    const int* tcell = (const int*)(b + h.off_tmp_cell);
+    const int me = sidx[t];
+    const int c = tcell[me];
+    int cx = c % h.dims[0], cy = (c / h.dims[0]) % h.dims[1], cz = c / (h.dims[0] * h.dims[1]);
+    int tx = cx + (o % 3) - 1, ty = cy + ((o / 3) % 3) - 1, tz = cz + (o / 9) - 1;
+    if (tx < 0 || tx >= h.dims[0] || ty < 0 || ty >= h.dims[1] || tz < 0 || tz >= h.dims[2]) return;
+    int rank = 0;
+    for (int z = max(tz - 1, 0); z <= min(tz + 1, h.dims[2] - 1); ++z)
+        for (int y = max(ty - 1, 0); y <= min(ty + 1, h.dims[1] - 1); ++y)
+            for (int x = max(tx - 1, 0); x <= min(tx + 1, h.dims[0] - 1); ++x) {
+                int cc = (z * h.dims[1] + y) * h.dims[0] + x;
+                int lo = cs[cc], hi = cs[cc + 1];      // lower_bound(me) in the index-sorted list of cell cc
+                while (lo < hi) {
+                    int mid = (lo + hi) >> 1;
+                    if (sidx[mid] < me) lo = mid + 1; else hi = mid;
+                }
+                rank += lo - cs[cc];
+            }
+    const int target = (tz * h.dims[1] + ty) * h.dims[0] + tx;
+    const int* ds = (const int*)(b + h.off_dil_start);
+    ((float4*)(b + h.off_dil_pos))[ds[target] + rank] = spos[t];
+}
+
 extern "C" int nf_grid_build(const float* pts, int n, float cell, const float bbox[6], void* ws, size_t ws_bytes,
                              nf_stream_t stream)
 {
@@ -264,6 +301,9 @@ extern "C" int nf_grid_build(const float* pts, int n, float cell, const float bb
     hipLaunchKernelGGL(k_grid_scatter, dim3(gp), dim3(B), 0, st, h, ws);
     hipLaunchKernelGGL(k_grid_rank, dim3(gp), dim3(B), 0, st, h, ws, pts);
     hipLaunchKernelGGL(k_grid_dilate, dim3(gc), dim3(B), 0, st, h, ws);
+    launch_scan<int>((const int*)((char*)ws + h.off_cell_dil), (int*)((char*)ws + h.off_dil_start), fill + h.n_cells + 8,
+                     h.n_cells, st);
+    if (n > 0) hipLaunchKernelGGL(k_grid_dil_fill, dim3((n * 27 + B - 1) / B), dim3(B), 0, st, h, ws);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }
@@ -278,13 +318,12 @@ __global__ void __launch_bounds__(BQ_BLOCK) k_ball_query(const void* __restrict_
 {
     extern __shared__ int lds[];
     int* li = lds;
-    int* lk = lds + K * BQ_BLOCK;
     int i = blockIdx.x * BQ_BLOCK + threadIdx.x;
     if (i >= nq) return;
     NfGridView g = nf_grid_view(ws);
     float qx = q[3 * i], qy = q[3 * i + 1], qz = q[3 * i + 2];
     unsigned nzmask;
-    int cnt = firstk_search(g, qx, qy, qz, r2, K, li, lk, threadIdx.x, nzmask);
+    int cnt = firstk_search(g, qx, qy, qz, r2, K, li, threadIdx.x, nzmask);
     for (int k = 0; k < K; ++k) {
         size_t o = (size_t)i * K + k;
         float d = 0.f, x = 0.f, y = 0.f, z = 0.f;

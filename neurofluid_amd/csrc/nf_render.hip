@@ -119,7 +119,6 @@ __global__ void __launch_bounds__(BQ_BLOCK) k_search(const void* __restrict__ ws
 {
     extern __shared__ int lds[];
     int* li = lds;
-    int* lk = lds + K * BQ_BLOCK;
     NfGridView g = nf_grid_view(ws);
     const int ncand = *cand_count;
     const int tid = threadIdx.x;
@@ -132,7 +131,7 @@ __global__ void __launch_bounds__(BQ_BLOCK) k_search(const void* __restrict__ ws
             float x, y, zz, zv;
             sample_xyz(rays, z, z_table, S, sample, x, y, zz, zv);
             unsigned nzmask;
-            cnt = firstk_search(g, x, y, zz, r2, K, li, lk, tid, nzmask);
+            cnt = firstk_search(g, x, y, zz, r2, K, li, tid, nzmask);
             int nz = __popc(nzmask);  // nn_mask = dists.ne(0)
             bool full = (nz == K);
             num_nn[sample] = nz;

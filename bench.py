@@ -37,16 +37,8 @@ def renderer_cfg():
 
 
 def build_scene(dev):
-    from oracle import render_oracle as ro, trans_oracle as to   # scene + closed-form weights only (not timed)
-    P = ro.watercube_particles()
-    c2w = ro.eval_camera()
-    H = W = 400
-    d = ro.get_ray_directions(H, W, ro.camera_focal(W))
-    o, dd = ro.get_rays(d, c2w)
-    rays = torch.cat([o, dd], -1).view(-1, 6)
-    box, bn = to.watercube_box()
-    return dict(P=P, c2w=c2w, rays=rays, box=box, bn=bn, nerf_state=ro.deterministic_nerf_state(),
-                trans_state=to.deterministic_transition_state())
+    from neurofluid_amd.synthetic import watercube_scene      # scene + closed-form weights (host-side, not timed)
+    return watercube_scene(400, 400)
 
 
 def cpu_baseline(scene):

@@ -63,3 +63,20 @@ def test_pixel_sampler_keeps_the_rng_stream():
         got = ps.next(7 + i)
         assert all(np.array_equal(a, b) for a, b in zip(got, ref[i]))
     ps.close()
+
+
+def test_synthetic_scene_matches_the_oracle_definitions():
+    """bench.py builds its scene from the product-side module; it must be the scene the oracle/goldens use."""
+    from neurofluid_amd import synthetic as sy
+    from oracle import render_oracle as ro, trans_oracle as to
+    assert torch.equal(sy.watercube_particles(), ro.watercube_particles())
+    assert torch.equal(sy.eval_camera(), ro.eval_camera())
+    a, b = sy.deterministic_nerf_state(), ro.deterministic_nerf_state()
+    assert a.keys() == b.keys() and all(torch.equal(a[k], b[k]) for k in a)
+    a, b = sy.deterministic_transition_state(), to.deterministic_transition_state()
+    assert a.keys() == b.keys() and all(torch.equal(a[k], b[k]) for k in a)
+    assert all(torch.equal(x, y) for x, y in zip(sy.watercube_box(), to.watercube_box()))
+    sc = sy.watercube_scene(8, 8)
+    d = ro.get_ray_directions(8, 8, sy.camera_focal(8))
+    o, dd = ro.get_rays(d, sy.eval_camera())
+    assert torch.equal(sc["rays"], torch.cat([o, dd], -1).view(-1, 6))

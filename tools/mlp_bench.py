@@ -2,7 +2,7 @@
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from oracle import render_oracle as ro
+from neurofluid_amd import synthetic as ro
 from neurofluid_amd import ops, _lib
 from neurofluid_amd._lib import ptr, check
 

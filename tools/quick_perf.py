@@ -15,9 +15,8 @@ net = net.to(dev)
 P = ro.watercube_particles().to(dev)
 c2w = ro.eval_camera()
 H = W = 400
-d = ro.get_ray_directions(H, W, ro.camera_focal(W))
-o, dd = ro.get_rays(d, c2w)
-rays = torch.cat([o, dd], -1).view(-1, 6).to(dev)
+from neurofluid_amd import ray_utils
+rays = ray_utils.get_rays_cpu(H, W, ro.camera_focal(W), c2w).view(-1, 6).to(dev)
 roc = c2w[:, 3].to(dev)
 chunk = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 for it in range(3):

@@ -206,6 +206,25 @@ def main():
         fp16_extra = {"rays_per_sec": n_rays / dt16, "ms_per_step": dt16 * 1e3, "dtype": "f16 MFMA, f32 accumulate",
                       "psnr_vs_f32_path_db": psnr16, "note": "render only (no transition step); not the headline value"}
 
+    # ---- extra: BASELINE configs[1] (train_renderer.py step: 4 views x 1024 rays, fwd + bwd + Adam) on this rank
+    train_extra = None
+    if args.workload == "render":
+        from neurofluid_amd.train_step import make_train_step
+        net_t = RenderNet(renderer_cfg(), 9.0, 13.0)
+        net_t.load_state_dict(scene["nerf_state"], strict=True)
+        net_t = net_t.to(dev)
+        tstep = make_train_step(net_t, scene, dev, rank, world)
+        for _ in range(3):
+            tstep()
+        sync()
+        t3 = time.perf_counter()
+        for _ in range(10):
+            tstep()
+        sync()
+        dtt = (time.perf_counter() - t3) / 10
+        train_extra = {"workload": "train_renderer.py step: 4 views x 1024 rays per rank, forward + backward + Adam (+ grad all-reduce)",
+                       "ms_per_step": dtt * 1e3, "rays_per_sec": 4096 * world / dtt}
+
     if rank == 0:
         res = {"metric": "rays/sec (renderer coarse+fine forward) coupled with one transition step per frame, watercube 400^2",
                "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -218,7 +237,7 @@ def main():
                           "particles": int(P0.shape[0]), "image": "400x400", "N_samples": 64, "N_importance": 128,
                           "K": 20, "use_mask": True, "device_ray_chunk": args.chunk},
                "particle_steps_per_sec": pstep * world, "particle_steps_note": "ParticleNet.forward alone, replicated per rank",
-               "roofline": roofline, "fp16_mfma_path": fp16_extra}
+               "roofline": roofline, "fp16_mfma_path": fp16_extra, "train_step": train_extra}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(scene)
             res["speedup_vs_cpu_port"] = value / res["cpu_baseline"]["value"]

@@ -69,6 +69,12 @@ int nf_radius_fill(const void* grid_ws, const float* queries, int nq, float radi
  * all-K-slots-filled samples when use_mask (models/renderer.py:233-237), every sample otherwise.
  * ------------------------------------------------------------------------------------------ */
 
+/* A0: rays of image rows [row0, row0+nrows) of an H x W pinhole camera (utils/ray_utils.py:74-131,
+ * get_ray_directions + get_rays): rays[t] = (origin xyz, unit direction xyz), t = (j-row0)*W + i.
+ * c2w: 3x4 row-major camera-to-world on the device. */
+int nf_get_rays(int H, int W, float focal, const float* c2w /*12*/, int row0, int nrows, float* rays /*nrows*W*6*/,
+                nf_stream_t stream);
+
 /* A1 + cell test: xyz = o + d*z (utils/ray_utils.py:232-256 / :227); samples whose 27-cell
  * neighbourhood is empty get num_nn = 0, mask = 0, rgbsigma = 0 here; the rest are appended to
  * cand[] (count in cand_count[0], must be zeroed by the caller).

@@ -187,8 +187,38 @@ class PassBuffers:
     pass
 
 
+def _round_rows(n):
+    """Row-buffer capacity: rounded up in geometric steps (<= 12.5 % slack) so that a slowly growing
+    active-row count (the fluid spreads frame after frame) re-uses the cached block instead of
+    asking the device allocator for a fresh multi-GB one every few frames."""
+    n = max(int(n), 1)
+    step = max(8192, 1 << max(n.bit_length() - 4, 0))
+    return (n + step - 1) // step * step
+
+
+class Workspace:
+    """Grow-only scratch arena for the inference path.  The per-pass scratch (candidate / row lists,
+    feature tiles X, rgbsigma) is several GB per 400x400 frame and its size drifts with the scene;
+    going through the device allocator for it every pass means an occasional multi-GB hipMalloc in
+    the middle of a frame (tens of ms).  Everything here is consumed on the launch stream in order,
+    so the coarse and the fine pass (and the next frame) can re-use the same storage."""
+
+    def __init__(self):
+        self._buf = {}
+
+    def get(self, name, numel, dtype, device):
+        nbytes = max(int(numel), 1) * torch.empty(0, dtype=dtype).element_size()
+        cur = self._buf.get(name)
+        if cur is None or cur.numel() < nbytes or cur.device != device:
+            cur = None
+            self._buf[name] = None                       # drop the old block before growing
+            cur = torch.empty(nbytes + nbytes // 4, dtype=torch.uint8, device=device)
+            self._buf[name] = cur
+        return cur[:nbytes].view(dtype)[:max(int(numel), 1)]
+
+
 def render_pass(grid, particles, rays, z, z_table, S, radius, K, enc_flags, use_mask, ro, packed, cx, cd,
-                white_bg=True, save_acts=False, max_rows=None, packed_h=None):
+                white_bg=True, save_acts=False, max_rows=None, packed_h=None, ws=None):
     """Runs classify -> search -> features -> MLP -> composite for R rays x S samples.
     z: (R,S) per-ray depths or None (then z_table (S,) is shared by all rays).
     Returns a PassBuffers with rgb, depth, opacity, weights, num_nn, mask_sum and the row lists."""
@@ -201,10 +231,18 @@ def render_pass(grid, particles, rays, z, z_table, S, radius, K, enc_flags, use_
         raise RuntimeError("search radius exceeds the grid cell edge")
     b = PassBuffers()
     b.R, b.S = R, S
+    if ws is not None and save_acts:
+        raise RuntimeError("the scratch arena is for the inference path; backward needs per-pass buffers")
+
+    def scratch(name, numel, dtype):
+        if ws is None:
+            return torch.empty(numel, dtype=dtype, device=dev)
+        return ws.get(name, numel, dtype, dev)
+
     b.num_nn = torch.empty(n_samp, dtype=torch.int32, device=dev)
-    b.mask = torch.empty(n_samp, dtype=torch.uint8, device=dev)
-    b.rgbsigma = torch.empty(n_samp, 4, dtype=torch.float32, device=dev)
-    cand = torch.empty(n_samp, dtype=torch.int32, device=dev)
+    b.mask = scratch("mask", n_samp, torch.uint8)
+    b.rgbsigma = scratch("rgbsigma", n_samp * 4, torch.float32).view(n_samp, 4)
+    cand = scratch("cand", n_samp, torch.int32)
     counters = torch.zeros(2, dtype=torch.int32, device=dev)
     b.counters = counters
     check(lib.nf_render_classify(ptr(grid.ws), ptr(rays), ptr(z), ptr(z_table), R, S, float(radius), int(use_mask), ptr(b.num_nn),
@@ -216,8 +254,8 @@ def render_pass(grid, particles, rays, z, z_table, S, radius, K, enc_flags, use_
     _, _, qx, qd = feature_dims(enc_flags)
     # NOTE: row lists are sized for the worst case of this chunk (every sample active) unless the
     # caller bounds max_rows; the renderer module sizes chunks so this stays modest.
-    b.row_sample = torch.empty(n_samp, dtype=torch.int32, device=dev)
-    b.row_nbr = torch.empty(n_samp * K, dtype=torch.int32, device=dev)
+    b.row_sample = scratch("row_sample", n_samp, torch.int32)
+    b.row_nbr = scratch("row_nbr", n_samp * K, torch.int32)
     check(lib.nf_render_search(ptr(grid.ws), ptr(rays), ptr(z), ptr(z_table), R, S, float(radius), K, int(use_mask),
                                ptr(cand), ptr(counters[0:1]), ptr(b.num_nn), ptr(b.mask), ptr(b.rgbsigma),
                                ptr(b.row_sample), ptr(b.row_nbr), ptr(counters[1:2]), st), "nf_render_search")
@@ -229,8 +267,8 @@ def render_pass(grid, particles, rays, z, z_table, S, radius, K, enc_flags, use_
         b.max_rows = max_rows
     b.n_active = max_rows
     tiles = (max_rows + 31) // 32
-    rows_alloc = (max(max_rows, 1) + 8191) // 8192 * 8192      # rounded sizes keep the caching allocator hitting
-    b.X = torch.empty(rows_alloc // 32 * (qx + qd) * 256, dtype=torch.float32, device=dev)
+    rows_alloc = _round_rows(max_rows)
+    b.X = scratch("X", rows_alloc // 32 * (qx + qd) * 256, torch.float32)
     check(lib.nf_render_features(ptr(particles), ptr(rays), ptr(z), ptr(z_table), R, S, float(radius), K, enc_flags,
                                  ptr(ro), int(ro.dim() == 2), ptr(b.row_sample), ptr(b.row_nbr), ptr(b.n_rows), max_rows,
                                  ptr(b.X), st),

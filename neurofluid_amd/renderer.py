@@ -69,6 +69,7 @@ class RenderNet(nn.Module):
         self._z_table = None
         self._u_table = None
         self._grid_cache = (None, None)
+        self._workspace = None
 
     # ------------------------------------------------------------------
     def set_ro(self, cw):
@@ -87,6 +88,12 @@ class RenderNet(nn.Module):
         if self._grid_cache[0] != key:
             self._grid_cache = (key, ops.build_grid(particles, self.raduis))
         return self._grid_cache[1]
+
+    def workspace(self):
+        """Grow-only scratch arena shared by the inference passes of this module (ops.Workspace)."""
+        if self._workspace is None:
+            self._workspace = ops.Workspace()
+        return self._workspace
 
     def packed_weights(self, net):
         layers = net.linear_layers()

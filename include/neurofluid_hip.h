@@ -63,6 +63,13 @@ int nf_radius_fill(const void* grid_ws, const float* queries, int nq, float radi
                    const int64_t* row_splits, int32_t* idx, float* dist2, int64_t nnz_capacity,
                    nf_stream_t stream);
 
+/* Exact nearest neighbour of every query among pts (FluidErrors' gt -> prediction metric,
+ * utils/point_eval.py:36-58, where the reference calls scipy.spatial.cKDTree(pred).query(gt) on the
+ * host).  dist[i] = Euclidean distance in double of the fp32 coordinates, idx[i] (optional) the
+ * winner's index (ties: lowest index). */
+int nf_nearest(const float* pts, int n_pts, const float* queries, int nq, double* dist /*nq*/,
+               int32_t* idx /*nq or NULL*/, nf_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Renderer (RenderNet.forward, models/renderer.py:211-270), fused stages.
  * Sample index = ray * S + s.  "Active rows" are the samples the MLP must evaluate:

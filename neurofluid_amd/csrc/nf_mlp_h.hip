@@ -21,7 +21,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 
 #define H_SLOT_U4 512        // one slot = 8 KB = 512 x 16 B
-#define H_RING_SLOTS 8
+#define H_RING_SLOTS 12
 #define H_CHUNK_SLOTS 4
 #define H_STAGE (H_CHUNK_SLOTS * 2)     // u32x4 per lane staged per chunk by each of the 4 waves
 
@@ -153,53 +153,67 @@ extern "C" int nf_nerf_pack_h(const nf_nerf_params_t* params, int cx, int cd, vo
 // ------------------------------------------------------------------------------------------------
 // kernel
 // ------------------------------------------------------------------------------------------------
+// Ring protocol (3 chunks of 4 slots).  Boundary B(k) runs at the START of slot 4k+3 (the last slot of chunk k):
+//   s_barrier          every wave has finished slots <= 4k+2, i.e. is done with chunk k-1, and chunk k+1 (written at
+//                      B(k-1)) becomes visible before anyone prefetches slot 4k+4;
+//   ds_write stage     chunk k+2 -> third (k+2) % 3 == (k-1) % 3, the one just released;
+//   global_load stage  chunk k+3 (one chunk time of latency budget).
+// The rendezvous is therefore never followed by a dependent LDS read: the A operands of every slot are prefetched
+// one K-step ahead, boundaries included.  The stream length is a multiple of 12 slots, so the cyclic stream keeps
+// the same ring phase tile after tile.
 struct HCtx {
-    const u32x4* stream;   // + wave * 512 + lane   (this wave's quarter of every chunk: 4 slots x 2 KB... see h_boundary)
+    const u32x4* stream;   // global weight stream
     u32x4* ring;           // LDS base
-    int slot;              // running slot counter (wave-uniform)
-    int half;              // running half-slot toggle for 4-block steps
-    int nchunks, chunk_next;
+    int slot;              // running slot counter (static after unrolling)
+    int half;              // half-slot toggle for 4-block steps
+    int nchunks, chunk_next;   // chunk_next: the chunk the NEXT global fetch brings in (runtime, cyclic)
     int lane, wave;
-    u32x4 stage[H_STAGE];  // this wave's share of the next chunk, in flight
+    u32x4 stage[H_STAGE];  // this wave's quarter of the chunk in flight
     u32x4 a[8], an[8];     // A operands of the current slot / of the next slot (prefetched)
-    bool a_ok, an_ok;      // compile-time foldable after full unrolling (the slot sequence of a tile is static)
+    bool a_ok;
 };
 
-// Called before consuming a slot whose index is a multiple of H_CHUNK_SLOTS: publish the staged chunk, rendezvous,
-// start fetching the following chunk.
-__device__ __forceinline__ void h_boundary(HCtx& c)
+__device__ __forceinline__ void h_fetch(HCtx& c)
 {
-    const int half = (c.slot / H_CHUNK_SLOTS) & 1;
-    u32x4* dst = c.ring + half * (H_CHUNK_SLOTS * H_SLOT_U4) + c.wave * (H_STAGE * 64) + c.lane;
-#pragma unroll
-    for (int i = 0; i < H_STAGE; ++i) dst[i * 64] = c.stage[i];
-    __syncthreads();
     const u32x4* src = c.stream + (size_t)c.chunk_next * (H_CHUNK_SLOTS * H_SLOT_U4) + c.wave * (H_STAGE * 64) + c.lane;
 #pragma unroll
     for (int i = 0; i < H_STAGE; ++i) c.stage[i] = src[i * 64];
     c.chunk_next = (c.chunk_next + 1 == c.nchunks) ? 0 : c.chunk_next + 1;
 }
 
-// One K-step.  The slot's 8 sub-blocks are read from the LDS ring into c.a; the NEXT slot is prefetched into c.an
-// before the MFMAs are issued unless it starts a new chunk (its data is only guaranteed after the next rendezvous).
+__device__ __forceinline__ void h_publish(HCtx& c, int third)
+{
+    u32x4* dst = c.ring + third * (H_CHUNK_SLOTS * H_SLOT_U4) + c.wave * (H_STAGE * 64) + c.lane;
+#pragma unroll
+    for (int i = 0; i < H_STAGE; ++i) dst[i * 64] = c.stage[i];
+}
+
+__device__ __forceinline__ void h_boundary(HCtx& c)
+{
+    __syncthreads();
+    h_publish(c, (c.slot / H_CHUNK_SLOTS + 2) % 3);
+    h_fetch(c);
+}
+
+// One K-step: 8 (or 4) MFMAs on the current slot.  The caller computes the B operand of the NEXT step before the
+// call, so that those VALU ops, the LDS prefetch of the next slot and (on boundary steps) the ring refill all sit
+// in the shadow of this step's MFMAs (sched_group_barrier interleave).
 template <int NB>
 __device__ __forceinline__ void h_step(HCtx& c, const h8 b, f32x16 (&acc)[NB], bool zero_c)
 {
     const bool first_of_slot = (NB == 8) || (c.half == 0);
+    bool boundary = false;
     if (first_of_slot) {
-        if ((c.slot % H_CHUNK_SLOTS) == 0) { h_boundary(c); }
+        if ((c.slot % H_CHUNK_SLOTS) == H_CHUNK_SLOTS - 1) { h_boundary(c); boundary = true; }
         if (!c.a_ok) {
             const u32x4* base = c.ring + (c.slot % H_RING_SLOTS) * H_SLOT_U4 + c.lane;
 #pragma unroll
             for (int ib = 0; ib < 8; ++ib) c.a[ib] = base[ib * 64];
             c.a_ok = true;
         }
-        if (((c.slot + 1) % H_CHUNK_SLOTS) != 0) {
-            const u32x4* nb = c.ring + ((c.slot + 1) % H_RING_SLOTS) * H_SLOT_U4 + c.lane;
+        const u32x4* nb = c.ring + ((c.slot + 1) % H_RING_SLOTS) * H_SLOT_U4 + c.lane;
 #pragma unroll
-            for (int ib = 0; ib < 8; ++ib) c.an[ib] = nb[ib * 64];
-            c.an_ok = true;
-        }
+        for (int ib = 0; ib < 8; ++ib) c.an[ib] = nb[ib * 64];
     }
     const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int o = (NB == 4) ? c.half * 4 : 0;
@@ -208,21 +222,56 @@ __device__ __forceinline__ void h_step(HCtx& c, const h8 b, f32x16 (&acc)[NB], b
         h8 av = __builtin_bit_cast(h8, c.a[o + ib]);
         acc[ib] = MFMA16(av, b, zero_c ? z : acc[ib]);
     }
+#pragma unroll
+    for (int ib = 0; ib < NB; ++ib) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // one MFMA ...
+        if (first_of_slot) __builtin_amdgcn_sched_group_barrier(0x100, NB == 8 ? 1 : 2, 0);   // ... an LDS prefetch,
+        if (boundary) {
+            __builtin_amdgcn_sched_group_barrier(0x200, NB == 8 ? 1 : 2, 0);     // a ring store,
+            __builtin_amdgcn_sched_group_barrier(0x020, NB == 8 ? 1 : 2, 0);     // a stream fetch,
+        }
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                       // and a few of the next operand's VALU ops
+    }
+    // pin the MFMAs to this step: they are pure and instruction selection is otherwise free to float a whole
+    // layer's chain down to its first consumer, which strands the A operands in scratch
+#pragma unroll
+    for (int ib = 0; ib < NB; ++ib) asm volatile("" : "+a"(acc[ib]));
     const bool leave = (NB == 8) || (c.half == 1);
     if (NB == 4) c.half ^= 1;
     if (leave) {
         c.slot++;
 #pragma unroll
         for (int ib = 0; ib < 8; ++ib) c.a[ib] = c.an[ib];
-        c.a_ok = c.an_ok;
-        c.an_ok = false;
     }
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// a padding slot of the stream: boundary bookkeeping only
+__device__ __forceinline__ void h_skip_slot(HCtx& c)
+{
+    if ((c.slot % H_CHUNK_SLOTS) == H_CHUNK_SLOTS - 1) h_boundary(c);
+    c.slot++;
+    c.a_ok = false;
+}
+
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+
+template <bool RELU>
+__device__ __forceinline__ h2 cvt2(float v0, float v1)
+{
+    h2 p = {(_Float16)v0, (_Float16)v1};
+    if (RELU) {      // ReLU after rounding == rounding after ReLU; one packed max instead of two fp32 ones
+        const h2 zz = {(_Float16)0.f, (_Float16)0.f};
+        p = __builtin_elementwise_max(p, zz);
+    }
+    return p;
+}
+
+template <bool RELU>
 __device__ __forceinline__ h8 pack8(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7)
 {
-    h8 r = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3, (_Float16)v4, (_Float16)v5, (_Float16)v6, (_Float16)v7};
+    h2 p0 = cvt2<RELU>(v0, v1), p1 = cvt2<RELU>(v2, v3), p2 = cvt2<RELU>(v4, v5), p3 = cvt2<RELU>(v6, v7);
+    h8 r = {p0[0], p0[1], p1[0], p1[1], p2[0], p2[1], p3[0], p3[1]};
     return r;
 }
 
@@ -233,17 +282,31 @@ __device__ __forceinline__ h8 bias_b(int h)
     return r;
 }
 
-// X K-steps t0 .. t1-1 : features of groups q = 2t, 2t+1
+// B operand of hidden K-step k (= 2 b + t) of a layer whose input is act(src)
+template <bool RELU>
+__device__ __forceinline__ h8 h_operand(const f32x16 (&src)[8], int k)
+{
+    const int b = k >> 1, t = k & 1;
+    return pack8<RELU>(src[b][8 * t], src[b][8 * t + 1], src[b][8 * t + 2], src[b][8 * t + 3], src[b][8 * t + 4],
+                       src[b][8 * t + 5], src[b][8 * t + 6], src[b][8 * t + 7]);
+}
+
+// X K-steps t0 .. t1-1 (features of groups q = 2t, 2t+1), then `tail` as the operand of the step that follows
 template <int NB>
 __device__ __forceinline__ void h_xsteps(HCtx& c, const f32x4* __restrict__ xt /* + lane */, int t0, int t1, f32x16 (&acc)[NB])
 {
     f32x4 x0 = xt[(2 * t0) * 64], x1 = xt[(2 * t0 + 1) * 64];
+    h8 bc = pack8<false>(x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]);
+    if (t0 + 1 < t1) { x0 = xt[(2 * t0 + 2) * 64]; x1 = xt[(2 * t0 + 3) * 64]; }
 #pragma unroll
     for (int t = t0; t < t1; ++t) {
-        f32x4 n0 = x0, n1 = x1;
-        if (t + 1 < t1) { n0 = xt[(2 * t + 2) * 64]; n1 = xt[(2 * t + 3) * 64]; }
-        h_step<NB>(c, pack8(x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]), acc, false);
-        x0 = n0; x1 = n1;
+        h8 bn = bc;
+        if (t + 1 < t1) {
+            bn = pack8<false>(x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]);
+            if (t + 2 < t1) { x0 = xt[(2 * t + 4) * 64]; x1 = xt[(2 * t + 5) * 64]; }
+        }
+        h_step<NB>(c, bc, acc, false);
+        bc = bn;
     }
 }
 
@@ -251,15 +314,14 @@ __device__ __forceinline__ void h_xsteps(HCtx& c, const f32x4* __restrict__ xt /
 template <bool RELU, int NB>
 __device__ __forceinline__ void h_hsteps(HCtx& c, const f32x16 (&src)[8], f32x16 (&dst)[NB])
 {
+    h8 bc = h_operand<RELU>(src, 0);
 #pragma unroll
-    for (int b = 0; b < 8; ++b)
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = RELU ? fmaxf(src[b][8 * t + e], 0.f) : src[b][8 * t + e];
-            h_step<NB>(c, pack8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]), dst, false);
-        }
+    for (int k = 0; k < 16; ++k) {
+        h8 bn = bc;
+        if (k + 1 < 16) bn = h_operand<RELU>(src, k + 1);
+        h_step<NB>(c, bc, dst, false);
+        bc = bn;
+    }
 }
 
 __device__ __forceinline__ void h_layer(HCtx& c, int l, const f32x4* __restrict__ xt, const f32x16 (&src)[8], f32x16 (&dst)[8])
@@ -283,12 +345,12 @@ __global__ void __launch_bounds__(256) k_mlp_fwd_h(NfMlpLayout L, const float* _
     const int Q = L.qx + L.qd;
     HCtx c;
     c.stream = stream_h; c.ring = ring; c.slot = 0; c.half = 0;
-    c.nchunks = nslots / H_CHUNK_SLOTS; c.chunk_next = 1; c.lane = lane; c.wave = wave;
-    {
-        const u32x4* src = stream_h + wave * (H_STAGE * 64) + lane;
-#pragma unroll
-        for (int i = 0; i < H_STAGE; ++i) c.stage[i] = src[i * 64];
-    }
+    c.nchunks = nslots / H_CHUNK_SLOTS; c.chunk_next = 0; c.lane = lane; c.wave = wave;
+    // prologue: chunks 0 and 1 into thirds 0 and 1, chunk 2 in flight
+    h_fetch(c); h_publish(c, 0);
+    h_fetch(c); h_publish(c, 1);
+    h_fetch(c);
+    __syncthreads();
     for (int tg = blockIdx.x; tg < ngroups; tg += gridDim.x) {
         int tile = tg * 4 + wave;
         if (tile >= ntiles) tile = ntiles - 1;      // idle waves recompute the last tile (keeps the barriers matched)
@@ -298,7 +360,7 @@ __global__ void __launch_bounds__(256) k_mlp_fwd_h(NfMlpLayout L, const float* _
         const bool row_ok = owner && row < nrows;
         const float* __restrict__ pk = packed + opaque_zero();
         f32x16 accA[8], accB[8];
-        c.slot = 0; c.half = 0; c.a_ok = false; c.an_ok = false;   // every tile consumes exactly nslots (multiple of the ring)
+        c.slot = 0; c.half = 0; c.a_ok = false;     // every tile consumes exactly nslots (a multiple of the ring)
         // layer 0
         h_step<8>(c, bias_b(h), accA, true);
         h_xsteps<8>(c, xt, 0, 13, accA);
@@ -326,13 +388,9 @@ __global__ void __launch_bounds__(256) k_mlp_fwd_h(NfMlpLayout L, const float* _
         h_step<4>(c, bias_b(h), hd, true);
         h_xsteps<4>(c, xt, 12, 16, hd);
         h_hsteps<false, 4>(c, accA, hd);
-        // the stream is padded to a multiple of the ring: skip the padding slots (uniform)
+        // the stream is padded to a multiple of the ring: walk the padding slots (uniform)
         if (c.half) { c.slot++; c.half = 0; }
-        while (c.slot % H_RING_SLOTS) {
-            if ((c.slot % H_CHUNK_SLOTS) == 0) h_boundary(c);
-            c.slot++;
-        }
-        c.a_ok = false; c.an_ok = false;
+        while (c.slot % H_RING_SLOTS) h_skip_slot(c);
         const float* wr = pk + L.off_wrgb;
         float c0 = 0.f, c1 = 0.f, c2 = 0.f;
 #pragma unroll

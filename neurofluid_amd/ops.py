@@ -121,6 +121,17 @@ def radius_fill(grid, queries, radius, row_splits, capacity, ignore_query_point=
     return idx, d2
 
 
+def nearest(points, queries, return_idx=False):
+    """Exact nearest neighbour of every query among points: (nq,) float64 distances [, (nq,) int32 indices]."""
+    lib = _lib.load()
+    pts = points.detach().contiguous().float()
+    q = queries.detach().contiguous().float()
+    dist = torch.empty(q.shape[0], dtype=torch.float64, device=q.device)
+    idx = torch.empty(q.shape[0], dtype=torch.int32, device=q.device) if return_idx else None
+    check(lib.nf_nearest(ptr(pts), pts.shape[0], ptr(q), q.shape[0], ptr(dist), ptr(idx), _lib.stream()), "nf_nearest")
+    return (dist, idx) if return_idx else dist
+
+
 def fixed_radius_search(points, queries, radius, ignore_query_point=True, grid=None):
     """Open3D FixedRadiusSearch contract -> (neighbors_index int32 (nnz), neighbors_row_splits int64 (Q+1),
     neighbors_distance fp32 (nnz) = squared distance).  One host sync (nnz sizes the outputs)."""

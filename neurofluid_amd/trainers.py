@@ -370,7 +370,7 @@ class E2ETrainer(BaseTrainer):
         pred_pos = self.trainsition_step_for_training(data, data_idx)
         log = (global_step + 1) % self.options.TRAIN.log_interval == 0
         if log:
-            d = self.tmp_fluid_error.cal_errors(pred_pos.detach().cpu().numpy(), data['particles_pos_1'].cpu().numpy(), data_idx + 1)
+            d = self.tmp_fluid_error.cal_errors(pred_pos.detach(), data['particles_pos_1'], data_idx + 1)
             self.summary_writer.add_scalar('Train/pred2gt_distance', d, global_step)
         rc = self.options.RENDERER.ray.ray_chunk
         total = 0.
@@ -412,7 +412,7 @@ class E2ETrainer(BaseTrainer):
                 if data_idx == 0:
                     pos, vel = data['particles_pos'], data['particles_vel']
                 pos, vel, _ = self.transition_model(pos, vel, data['box'], data['box_normals'])
-                dists.append(fe.cal_errors(pos.cpu().numpy(), data['particles_pos_1'].cpu().numpy(), data_idx + 1))
+                dists.append(fe.cal_errors(pos, data['particles_pos_1'], data_idx + 1))
                 if data_idx in render_frames:
                     for v, view in enumerate(self.test_viewnames):
                         cw = data['cw_1'][v]
@@ -452,7 +452,7 @@ class E2EEvaluator(BaseTrainer):
                 if data_idx == 0:
                     pos, vel = data['particles_pos'], data['particles_vel']
                 pos, vel, _ = self.transition_model(pos, vel, data['box'], data['box_normals'])
-                dists.append(self.fluid_error.cal_errors(pos.cpu().numpy(), data['particles_pos_1'].cpu().numpy(), data_idx + 1))
+                dists.append(self.fluid_error.cal_errors(pos, data['particles_pos_1'], data_idx + 1))
                 if dump and self.rank == 0:
                     for sub, p, col in (('Pred', pos, (255, 0, 0)), ('GT', data['particles_pos_1'], (3, 168, 158))):
                         os.makedirs(osp.join(self.particlepath, sub), exist_ok=True)
@@ -551,9 +551,9 @@ class TransModelEvaluation:
                     pos, vel = data['particles_pos_0'], data['particles_vel_0']
                 pos, vel, _ = self.transition_model(pos, vel, data['box'], data['box_normals'])
                 gt = data['particles_pos_1']
-                d_all.append(self.fluid_erros.cal_errors(pos.cpu().numpy(), gt.cpu().numpy(), i + 1))
-                dc_all.append(self.cliped_fluid_erros.cal_errors(self.strict_clip_particles(pos).cpu().numpy(),
-                                                                 self.strict_clip_particles(gt).cpu().numpy(), i + 1))
+                d_all.append(self.fluid_erros.cal_errors(pos, gt, i + 1))
+                dc_all.append(self.cliped_fluid_erros.cal_errors(self.strict_clip_particles(pos), self.strict_clip_particles(gt),
+                                                                 i + 1))
                 if self.options.TEST.save_obj and self.rank == 0:
                     with open(osp.join(self.exppath, f'pred_{i + 1}.obj'), 'w') as fp:
                         record2obj(pos, fp, color=(255, 0, 0))

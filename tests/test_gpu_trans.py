@@ -133,3 +133,36 @@ def test_particle_net_backward_vs_oracle_autograd(dev):
         rel = float((got.cpu() - ref).norm() / ref.norm())
         assert rel < 2e-3, (nm, rel)
     print("worst relative parameter-gradient error", worst)
+
+
+def test_fluid_errors_vs_kdtree(dev):
+    """FluidErrors on the device (nf_nearest + device reductions) against the reference's host recipe
+    (utils/point_eval.py:10-58: numpy statistics + scipy cKDTree), restated here as the checker."""
+    from scipy.spatial import cKDTree
+    from neurofluid_amd import ops
+    from neurofluid_amd.point_eval import FluidErrors
+    rng = np.random.RandomState(3)
+    for n_pred, n_gt in [(4913, 4913), (1000, 777), (1, 5), (257, 256)]:
+        pred = rng.uniform(-1, 1, (n_pred, 3)).astype(np.float32)
+        gt = (pred[:n_gt] if n_gt <= n_pred else rng.uniform(-1, 1, (n_gt, 3)).astype(np.float32)).copy()
+        gt += rng.normal(0, 0.02, gt.shape).astype(np.float32)
+        d_ref, i_ref = cKDTree(pred).query(gt)
+        d, i = ops.nearest(torch.from_numpy(pred).to(dev), torch.from_numpy(gt).to(dev), return_idx=True)
+        np.testing.assert_allclose(d.cpu().numpy(), d_ref, rtol=0, atol=1e-7)
+        assert (i.cpu().numpy() == i_ref).mean() > 0.999          # exact ties may resolve differently
+        if n_pred == n_gt:
+            fe = FluidErrors()
+            m = fe.cal_errors(torch.from_numpy(pred).to(dev), torch.from_numpy(gt), 7)
+            x = np.linalg.norm(pred - gt, axis=-1)
+            ref = {'mean': np.mean(x), 'mse': np.mean(x ** 2), 'var': np.var(x), 'min': np.min(x), 'max': np.max(x),
+                   'median': np.median(x)}
+            ref.update({'gt2pred_' + k: v for k, v in {'mean': np.mean(d_ref), 'mse': np.mean(d_ref ** 2), 'var': np.var(d_ref),
+                                                      'min': np.min(d_ref), 'max': np.max(d_ref),
+                                                      'median': np.median(d_ref)}.items()})
+            for k, v in ref.items():
+                assert abs(fe.errors[7][k] - float(v) * 1000) <= 1e-3 * max(1.0, abs(float(v) * 1000)), k
+            assert abs(m - float(np.mean(d_ref)) * 1000) < 1e-3
+            assert fe.errors[7]['num_particles'] == n_pred
+    fe = FluidErrors()
+    bad = torch.full((4, 3), float('nan'), device=dev)
+    assert fe.cal_errors(bad, torch.zeros(4, 3, device=dev), 0) is None and fe.errors == {}

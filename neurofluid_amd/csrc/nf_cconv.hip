@@ -239,12 +239,71 @@ extern "C" int nf_cconv_small(const float* feats, int cin, const int64_t* row_sp
 #define GT_M 128
 #define GT_N 128
 #define GT_K 32
+#define GT_AP 33      // A slab is m-major with an odd pitch: fragment reads (32 rows, fixed k) and the staged stores are conflict-free
+#define GT_BP (GT_N + 4)
+
+// Slab loaders: each thread brings 4 x 16 B of A and 4 x 16 B of B per 32-deep slab into registers (issued before
+// the MFMAs of the previous slab, so the L2 latency hides behind them), then parks them in LDS.
+template <bool VA>
+__device__ __forceinline__ void gemm_load_a(const float* __restrict__ A, int M, int cin, int relu, int m0, int k0, int tid,
+                                            float4 (&ra)[4])
+{
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int t = tid + 256 * u, m = t >> 3, kq = t & 7;        // 128 rows x 8 quads
+        const int gm = m0 + m, gk = k0 + 4 * kq;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gm < M) {
+            const float* src = A + (size_t)gm * cin + gk;
+            if (VA) { if (gk < cin) v = *(const float4*)src; }
+            else {
+                if (gk < cin) v.x = src[0];
+                if (gk + 1 < cin) v.y = src[1];
+                if (gk + 2 < cin) v.z = src[2];
+                if (gk + 3 < cin) v.w = src[3];
+            }
+        }
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        ra[u] = v;
+    }
+}
+
+template <bool VB>
+__device__ __forceinline__ void gemm_load_b(const float* __restrict__ kernel, const float* __restrict__ dense_w, int cin,
+                                            int cout, int n0, int k0, int tid, float4 (&rb)[4])
+{
+    const int ntot = 65 * cout;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int t = tid + 256 * u, k = t >> 5, nq = t & 31;       // 32 k x 32 quads
+        const int gk = k0 + k, gn = n0 + 4 * nq;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gk < cin) {
+            if (VB && gn + 3 < 64 * cout) {                          // a quad never straddles two filter cells (cout % 4 == 0)
+                v = *(const float4*)(kernel + (size_t)(gn / cout) * cin * cout + (size_t)gk * cout + gn % cout);
+            } else {
+                float e[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int g = gn + c;
+                    e[c] = 0.f;
+                    if (g < 64 * cout) e[c] = kernel[(size_t)(g / cout) * cin * cout + (size_t)gk * cout + g % cout];
+                    else if (g < ntot) e[c] = dense_w[(size_t)(g - 64 * cout) * cin + gk];
+                }
+                v = make_float4(e[0], e[1], e[2], e[3]);
+            }
+        }
+        rb[u] = v;
+    }
+}
+
+template <bool VA, bool VB>
 __global__ void __launch_bounds__(256) k_cconv_gemm(const float* __restrict__ A, int M, int cin, int cout, int relu,
                                                     const float* __restrict__ kernel, const float* __restrict__ dense_w,
                                                     float* __restrict__ G)
 {
-    __shared__ float As[GT_K][GT_M + 4];
-    __shared__ float Bs[GT_K][GT_N + 4];
+    __shared__ float As[GT_M * GT_AP];
+    __shared__ float Bs[GT_K][GT_BP];
     const int ntot = 65 * cout;
     const int m0 = blockIdx.y * GT_M, n0 = blockIdx.x * GT_N;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -257,34 +316,27 @@ __global__ void __launch_bounds__(256) k_cconv_gemm(const float* __restrict__ A,
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+    float4 ra[4], rb[4];
+    gemm_load_a<VA>(A, M, cin, relu, m0, 0, tid, ra);
+    gemm_load_b<VB>(kernel, dense_w, cin, cout, n0, 0, tid, rb);
     for (int k0 = 0; k0 < cin; k0 += GT_K) {
-        // A slab: 128 rows x 32 k
-        for (int t = tid; t < GT_M * GT_K; t += 256) {
-            int m = t / GT_K, k = t % GT_K;
-            float v = 0.f;
-            if (m0 + m < M && k0 + k < cin) {
-                v = A[(size_t)(m0 + m) * cin + k0 + k];
-                if (relu) v = fmaxf(v, 0.f);
-            }
-            As[k][m] = v;
-        }
-        // B slab: 32 k x 128 n
-        for (int t = tid; t < GT_K * GT_N; t += 256) {
-            int k = t / GT_N, n = t % GT_N;
-            float v = 0.f;
-            int gn = n0 + n, gk = k0 + k;
-            if (gn < ntot && gk < cin) {
-                if (gn < 64 * cout) v = kernel[(size_t)(gn / cout) * cin * cout + (size_t)gk * cout + gn % cout];
-                else v = dense_w[(size_t)(gn - 64 * cout) * cin + gk];
-            }
-            Bs[k][n] = v;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = tid + 256 * u;
+            float* da = As + (t >> 3) * GT_AP + 4 * (t & 7);
+            da[0] = ra[u].x; da[1] = ra[u].y; da[2] = ra[u].z; da[3] = ra[u].w;
+            *(float4*)&Bs[t >> 5][4 * (t & 31)] = rb[u];
         }
         __syncthreads();
+        if (k0 + GT_K < cin) {      // next slab in flight while this one is multiplied
+            gemm_load_a<VA>(A, M, cin, relu, m0, k0 + GT_K, tid, ra);
+            gemm_load_b<VB>(kernel, dense_w, cin, cout, n0, k0 + GT_K, tid, rb);
+        }
 #pragma unroll
         for (int kk = 0; kk < GT_K; kk += 2) {
-            int kr = kk + (lane >> 5), c = lane & 31;
-            float a0 = As[kr][wm + c], a1 = As[kr][wm + 32 + c];
-            float b0 = Bs[kr][wn + c], b1 = Bs[kr][wn + 32 + c];
+            const int kr = kk + (lane >> 5), c = lane & 31;
+            const float a0 = As[(wm + c) * GT_AP + kr], a1 = As[(wm + 32 + c) * GT_AP + kr];
+            const float b0 = Bs[kr][wn + c], b1 = Bs[kr][wn + 32 + c];
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
@@ -313,7 +365,12 @@ extern "C" int nf_cconv_transform(const float* A, int M, int cin, int cout, int 
     if (M <= 0) return NF_OK;
     int ntot = 65 * cout;
     dim3 grid((ntot + GT_N - 1) / GT_N, (M + GT_M - 1) / GT_M);
-    hipLaunchKernelGGL(k_cconv_gemm, grid, dim3(256), 0, (hipStream_t)stream, A, M, cin, cout, relu, kernel, dense_w, G);
+    const bool va = (cin % 4) == 0, vb = (cout % 4) == 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (va && vb) hipLaunchKernelGGL((k_cconv_gemm<true, true>), grid, dim3(256), 0, st, A, M, cin, cout, relu, kernel, dense_w, G);
+    else if (va) hipLaunchKernelGGL((k_cconv_gemm<true, false>), grid, dim3(256), 0, st, A, M, cin, cout, relu, kernel, dense_w, G);
+    else if (vb) hipLaunchKernelGGL((k_cconv_gemm<false, true>), grid, dim3(256), 0, st, A, M, cin, cout, relu, kernel, dense_w, G);
+    else hipLaunchKernelGGL((k_cconv_gemm<false, false>), grid, dim3(256), 0, st, A, M, cin, cout, relu, kernel, dense_w, G);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }

@@ -98,9 +98,50 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_add(OutT* __restrict__ out,
     if (i < n) out[i] += block_sums[blockIdx.x];
 }
 
+// small inputs (a particle cloud, a grid of a few thousand cells): one block walks the array with a carry —
+// one launch instead of three on the latency-bound transition step
+#define SCAN_ITEMS 8
+#define SCAN_ROUNDS 8     // SCAN_SINGLE_MAX = SCAN_BLOCK * SCAN_ITEMS * SCAN_ROUNDS
+template <typename OutT>
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_single(const int* __restrict__ in, OutT* __restrict__ out, int n)
+{
+    __shared__ OutT lds[SCAN_BLOCK / 64];
+    // all loads are issued up front (one memory latency for the whole array), the rounds then only pay the two
+    // block barriers of the scan
+    int v[SCAN_ROUNDS][SCAN_ITEMS];
+#pragma unroll
+    for (int rd = 0; rd < SCAN_ROUNDS; ++rd) {
+        const int i0 = (rd * SCAN_BLOCK + threadIdx.x) * SCAN_ITEMS;      // each thread owns SCAN_ITEMS consecutive elements
+#pragma unroll
+        for (int u = 0; u < SCAN_ITEMS; ++u) v[rd][u] = (i0 + u) < n ? in[i0 + u] : 0;
+    }
+    OutT carry = 0;
+#pragma unroll
+    for (int rd = 0; rd < SCAN_ROUNDS; ++rd) {
+        if (rd * SCAN_BLOCK * SCAN_ITEMS >= n) break;
+        const int i0 = (rd * SCAN_BLOCK + threadIdx.x) * SCAN_ITEMS;
+        OutT tsum = 0;
+#pragma unroll
+        for (int u = 0; u < SCAN_ITEMS; ++u) tsum += (OutT)v[rd][u];
+        OutT tot;
+        OutT run = block_exclusive_scan<OutT>(tsum, lds, &tot) + carry;
+#pragma unroll
+        for (int u = 0; u < SCAN_ITEMS; ++u) { if (i0 + u < n) out[i0 + u] = run; run += (OutT)v[rd][u]; }
+        carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[n] = carry;
+}
+
+#define SCAN_SINGLE_MAX 65536
+
 template <typename OutT>
 static void launch_scan(const int* in, OutT* out, OutT* block_sums, int n, hipStream_t st)
 {
+    if (n <= SCAN_SINGLE_MAX) {
+        hipLaunchKernelGGL(k_scan_single<OutT>, dim3(1), dim3(SCAN_BLOCK), 0, st, in, out, n);
+        return;
+    }
     int nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
     if (nb < 1) nb = 1;
     hipLaunchKernelGGL(k_scan_local<OutT>, dim3(nb), dim3(SCAN_BLOCK), 0, st, in, out, block_sums, n);
@@ -359,38 +400,55 @@ extern "C" int nf_ball_query_firstk(const void* ws, const float* pts, const floa
 // fixed-radius search -> CSR  (Open3D FixedRadiusSearch contract: d2 <= r2, optional skip of points
 // at the identical position; models/transmodel.py:92, :136-138)
 // ------------------------------------------------------------------------------------------------
+// One WAVE per query: the 3 x-adjacent cells of each of the 9 (z, y) rows are one contiguous range of the
+// cell-sorted point array, swept 64 candidates at a time; hits are counted with ballot/popcount and placed with
+// the lane-prefix popcount, so a row's neighbours keep the cell-major / ascending order.  (A thread per query
+// leaves 4 913 queries on 77 waves — a quarter of the CUs, each with one latency-bound wave.)
+#define RS_QPB 4     // queries (waves) per block
 template <bool FILL>
-__global__ void __launch_bounds__(256) k_radius(const void* __restrict__ ws, const float* __restrict__ q, int nq, float r2,
-                                                int ignore_same, int* __restrict__ counts,
-                                                const int64_t* __restrict__ row_splits, int32_t* __restrict__ idx,
-                                                float* __restrict__ dist2, int64_t cap)
+__global__ void __launch_bounds__(64 * RS_QPB) k_radius(const void* __restrict__ ws, const float* __restrict__ q, int nq, float r2,
+                                                        int ignore_same, int* __restrict__ counts,
+                                                        const int64_t* __restrict__ row_splits, int32_t* __restrict__ idx,
+                                                        float* __restrict__ dist2, int64_t cap)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * RS_QPB + (threadIdx.x >> 6);
     if (i >= nq) return;
     NfGridView g = nf_grid_view(ws);
-    float qx = q[3 * i], qy = q[3 * i + 1], qz = q[3 * i + 2];
-    int cx = nf_cell_coord(qx, g.ox, g.icx, g.dx);
-    int cy = nf_cell_coord(qy, g.oy, g.icy, g.dy);
-    int cz = nf_cell_coord(qz, g.oz, g.icz, g.dz);
+    const float qx = q[3 * i], qy = q[3 * i + 1], qz = q[3 * i + 2];
+    const int cx = nf_cell_coord(qx, g.ox, g.icx, g.dx);
+    const int cy = nf_cell_coord(qy, g.oy, g.icy, g.dy);
+    const int cz = nf_cell_coord(qz, g.oz, g.icz, g.dz);
     int cnt = 0;
-    int64_t o = FILL ? row_splits[i] : 0;
-    int64_t oe = FILL ? row_splits[i + 1] : 0;
+    const int64_t o = FILL ? row_splits[i] : 0;
+    const int64_t oe = FILL ? row_splits[i + 1] : 0;
     if (FILL && oe > cap) return;
+    const unsigned long long lt = (1ull << lane) - 1ull;
     for (int z = max(cz - 1, 0); z <= min(cz + 1, g.dz - 1); ++z)
         for (int y = max(cy - 1, 0); y <= min(cy + 1, g.dy - 1); ++y) {
-            int r0 = (z * g.dy + y) * g.dx;
-            int s = g.cell_start[r0 + max(cx - 1, 0)], e = g.cell_start[r0 + min(cx + 1, g.dx - 1) + 1];
-            for (int t = s; t < e; ++t) {
-                float4 p = g.sorted_pos[t];
-                if (ignore_same && p.x == qx && p.y == qy && p.z == qz) continue;
-                float d2 = nf_dist2(qx, qy, qz, p.x, p.y, p.z);
-                if (d2 <= r2) {
-                    if (FILL) { idx[o + cnt] = __float_as_int(p.w); dist2[o + cnt] = d2; }
-                    ++cnt;
+            const int r0 = (z * g.dy + y) * g.dx;
+            const int s = g.cell_start[r0 + max(cx - 1, 0)], e = g.cell_start[r0 + min(cx + 1, g.dx - 1) + 1];
+            for (int t0 = s; t0 < e; t0 += 64) {
+                const int t = t0 + lane;
+                bool hit = false;
+                float d2 = 0.f;
+                int pi = 0;
+                if (t < e) {
+                    const float4 p = g.sorted_pos[t];
+                    d2 = nf_dist2(qx, qy, qz, p.x, p.y, p.z);
+                    hit = d2 <= r2 && !(ignore_same && p.x == qx && p.y == qy && p.z == qz);
+                    pi = __float_as_int(p.w);
                 }
+                const unsigned long long m = __ballot(hit);
+                if (FILL && hit) {
+                    const int64_t w = o + cnt + __popcll(m & lt);
+                    idx[w] = pi;
+                    dist2[w] = d2;
+                }
+                cnt += __popcll(m);
             }
         }
-    if (!FILL) counts[i] = cnt;
+    if (!FILL && lane == 0) counts[i] = cnt;
 }
 
 extern "C" size_t nf_radius_scan_workspace_bytes(int nq)
@@ -410,7 +468,7 @@ extern "C" int nf_radius_count(const void* ws, const float* queries, int nq, flo
     int64_t* sums = (int64_t*)((char*)scan_ws + align_up(sizeof(int) * (size_t)(nq > 0 ? nq : 1), 256));
     const float r2 = radius * radius;
     if (nq > 0)
-        hipLaunchKernelGGL(k_radius<false>, dim3((nq + 255) / 256), dim3(256), 0, st, ws, queries, nq, r2, ignore_same_pos,
+        hipLaunchKernelGGL(k_radius<false>, dim3((nq + RS_QPB - 1) / RS_QPB), dim3(64 * RS_QPB), 0, st, ws, queries, nq, r2, ignore_same_pos,
                            counts, (const int64_t*)nullptr, (int32_t*)nullptr, (float*)nullptr, (int64_t)0);
     launch_scan<int64_t>(counts, row_splits, sums, nq, st);
     NF_CHECK_LAUNCH();
@@ -425,7 +483,7 @@ extern "C" int nf_radius_fill(const void* ws, const float* queries, int nq, floa
     if (nq == 0 || nnz_capacity == 0) return NF_OK;
     hipStream_t st = (hipStream_t)stream;
     const float r2 = radius * radius;
-    hipLaunchKernelGGL(k_radius<true>, dim3((nq + 255) / 256), dim3(256), 0, st, ws, queries, nq, r2, ignore_same_pos,
+    hipLaunchKernelGGL(k_radius<true>, dim3((nq + RS_QPB - 1) / RS_QPB), dim3(64 * RS_QPB), 0, st, ws, queries, nq, r2, ignore_same_pos,
                        (int*)nullptr, row_splits, idx, dist2, nnz_capacity);
     NF_CHECK_LAUNCH();
     return NF_OK;

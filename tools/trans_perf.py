@@ -1,0 +1,23 @@
+"""Timing of ParticleNet.forward alone on the synthetic watercube (dev tool): particle-steps/s."""
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from neurofluid_amd.synthetic import watercube_scene
+from neurofluid_amd.transmodel import ParticleNet
+
+dev = torch.device("cuda:0")
+scene = watercube_scene(8, 8)
+pn = ParticleNet(gravity=(0, 0, -9.81))
+pn.load_state_dict(scene["trans_state"], strict=True)
+pn = pn.to(dev)
+P0 = scene["P"].to(dev)
+box, bn = scene["box"].to(dev), scene["bn"].to(dev)
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+for it in range(3):
+    pos, vel = P0.clone(), torch.zeros_like(P0)
+    torch.cuda.synchronize(); t = time.time()
+    with torch.no_grad():
+        for _ in range(steps):
+            pos, vel, _ = pn(pos, vel, box, bn)
+    torch.cuda.synchronize(); dt = time.time() - t
+    print(f"iter {it}: {dt/steps*1e6:.1f} us/step, {P0.shape[0]*steps/dt/1e6:.2f} M particle-steps/s")

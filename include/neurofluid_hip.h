@@ -82,13 +82,16 @@ int nf_nearest(const float* pts, int n_pts, const float* queries, int nq, double
 int nf_get_rays(int H, int W, float focal, const float* c2w /*12*/, int row0, int nrows, float* rays /*nrows*W*6*/,
                 nf_stream_t stream);
 
-/* A1 + cell test: xyz = o + d*z (utils/ray_utils.py:232-256 / :227); samples whose 27-cell
- * neighbourhood is empty get num_nn = 0, mask = 0, rgbsigma = 0 here; the rest are appended to
- * cand[] (count in cand_count[0], must be zeroed by the caller).
+/* A1 + cell test: xyz = o + d*z (utils/ray_utils.py:232-256 / :227); num_nn and mask are cleared
+ * for EVERY sample here (the search overwrites the candidates); samples whose 27-cell neighbourhood
+ * holds a particle box within the radius are appended to cand[] (count in cand_count[0], must be
+ * zeroed by the caller).  The (R*S*4) rgbsigma array is NOT touched by classify/search: with use_mask
+ * its value at a sample with mask = 0 is zero by definition (rgbsigma * mask, models/renderer.py:237)
+ * and nf_composite_fwd/bwd (gate_by_mask) never read it there; the MLP writes the mask = 1 rows.
  * z_table (S) is used when z == NULL (coarse pass: same depths for every ray). */
 int nf_render_classify(const void* grid_ws, const float* rays /*R*6*/, const float* z /*R*S or NULL*/,
                        const float* z_table /*S or NULL*/, int R, int S, float radius, int use_mask,
-                       int32_t* num_nn /*R*S*/, uint8_t* mask /*R*S*/, float* rgbsigma /*R*S*4*/,
+                       int32_t* num_nn /*R*S*/, uint8_t* mask /*R*S*/,
                        int32_t* cand /*R*S*/, int32_t* cand_count /*1*/, nf_stream_t stream);
 
 /* A2 + A7: first-K search for every candidate; writes num_nn / mask, appends active rows:
@@ -96,7 +99,7 @@ int nf_render_classify(const void* grid_ws, const float* rays /*R*6*/, const flo
  * n_rows[0] = number of active rows (zeroed by the caller). */
 int nf_render_search(const void* grid_ws, const float* rays, const float* z, const float* z_table, int R, int S,
                      float radius, int K, int use_mask, const int32_t* cand, const int32_t* cand_count,
-                     int32_t* num_nn, uint8_t* mask, float* rgbsigma /*zeroed here for rejected candidates*/,
+                     int32_t* num_nn, uint8_t* mask,
                      int32_t* row_sample, int32_t* row_nbr, int32_t* n_rows, nf_stream_t stream);
 
 /* A3 + A4 + A5: local-geometry features + positional encodings for every active row, written in
@@ -162,22 +165,29 @@ size_t nf_nerf_wgrad_workspace_floats(int cx, int cd, int nslices);
 int nf_nerf_wgrad(const float* dpre, const float* acts, const float* xrow, int cx, int cd, int n_rows, int nslices,
                   float* workspace, float* dweights, nf_stream_t stream);
 
-/* A8: alpha compositing (models/renderer.py:182-208), one thread per ray, sequential products. */
+/* A8: alpha compositing (models/renderer.py:182-208), one thread per ray, sequential products.
+ * gate_by_mask != 0 (use_mask): rgbsigma is read only where mask != 0 and taken as zero elsewhere
+ * (bit-identical to compositing rgbsigma * mask); 0: every sample is read.  mask (optional when not
+ * gating) also yields mask_sum; weights may be NULL when the caller does not resample from them. */
 int nf_composite_fwd(const float* rgbsigma /*R*S*4*/, const float* z, const float* z_table, const float* rays,
-                     const uint8_t* mask, int R, int S, int white_bg,
-                     float* rgb /*R*3*/, float* depth /*R*/, float* opacity /*R*/, float* weights /*R*S*/,
-                     float* mask_sum /*R*/, nf_stream_t stream);
+                     const uint8_t* mask, int gate_by_mask, int R, int S, int white_bg,
+                     float* rgb /*R*3*/, float* depth /*R*/, float* opacity /*R*/, float* weights /*R*S or NULL*/,
+                     float* mask_sum /*R or NULL*/, nf_stream_t stream);
 
 /* A12 (compositing part): d_rgbsigma (R*S*4) from d_rgb (R*3); scratch = R*S floats.  Depth/opacity are
  * not differentiated (the reference losses use rgb0/rgb1 only: trainer/trainer_renderer.py:127-130). */
 int nf_composite_bwd(const float* rgbsigma, const float* z, const float* z_table, const float* rays,
-                     const float* d_rgb, int R, int S, int white_bg, float* scratch /*R*S*/,
-                     float* d_rgbsigma /*R*S*4*/, nf_stream_t stream);
+                     const float* d_rgb, const uint8_t* mask, int gate_by_mask, int R, int S, int white_bg,
+                     float* scratch /*R*S*/, float* d_rgbsigma /*R*S*4*/, nf_stream_t stream);
 
 /* A9: ImportanceSampling(det=True) (utils/ray_utils.py:178-229): z1 = sort(cat(z0, inverse-CDF samples)).
- * u_table = torch.linspace(0,1,N_imp) supplied by the caller (bit-identical to the reference). */
+ * u_table = torch.linspace(0,1,N_imp) supplied by the caller (bit-identical to the reference).
+ * zero_row (optional, S0+N_imp floats): this function's own output for a ray with all-zero weights
+ * (call it once with R = 1, zero weights, zero_row = NULL); rays whose weights[1:-1] are all zero
+ * then take a copy of it instead of the serial inverse-CDF walk — same bits, they share z_table0. */
 int nf_importance_sample(const float* z_table0 /*S0*/, const float* weights0 /*R*S0*/, const float* u_table /*N_imp*/,
-                         int R, int S0, int N_imp, float* z1 /*R*(S0+N_imp)*/, nf_stream_t stream);
+                         int R, int S0, int N_imp, const float* zero_row, float* z1 /*R*(S0+N_imp)*/,
+                         nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Transition model (ParticleNet.forward, models/transmodel.py:151-163).

@@ -28,9 +28,9 @@ PROTOTYPES = {
     "nf_nearest": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "nf_get_rays": (c_int, [c_int, c_int, c_float, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "nf_render_classify": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p, c_void_p,
-                                   c_void_p, c_void_p, c_void_p, c_void_p]),
+                                   c_void_p, c_void_p, c_void_p]),
     "nf_render_search": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_int, c_void_p,
-                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nf_render_features": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_int, c_void_p, c_int,
                                    c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "nf_render_features_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_int, c_void_p, c_int,
@@ -40,16 +40,17 @@ PROTOTYPES = {
     "nf_nerf_packed_floats": (c_size_t, [c_int, c_int]),
     "nf_nerf_pack": (c_int, [ctypes.POINTER(NerfParams), c_int, c_int, c_void_p, c_void_p]),
     "nf_nerf_mlp_fwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "nf_composite_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
-                                 c_void_p, c_void_p, c_void_p, c_void_p]),
-    "nf_importance_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "nf_composite_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nf_importance_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "nf_nerf_packed_h_bytes": (c_size_t, []),
     "nf_nerf_pack_h": (c_int, [ctypes.POINTER(NerfParams), c_int, c_int, c_void_p, c_void_p]),
     "nf_nerf_mlp_fwd_h": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "nf_nerf_wgrad_floats": (c_size_t, [c_int, c_int]),
     "nf_nerf_wgrad_workspace_floats": (c_size_t, [c_int, c_int, c_int]),
     "nf_nerf_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
-    "nf_composite_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "nf_composite_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                                 c_void_p, c_void_p]),
     "nf_nerf_packed_bwd_floats": (c_size_t, []),
     "nf_nerf_pack_bwd": (c_int, [ctypes.POINTER(NerfParams), c_int, c_int, c_void_p, c_void_p]),
     "nf_nerf_mlp_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,

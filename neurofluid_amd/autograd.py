@@ -23,15 +23,16 @@ def _run_passes(net, particles, ro, rays, white_bg, fine, save_acts):
     pk0 = net.packed_weights(net.nerf_coarse)
     p0 = ops.render_pass(grid, pts, rays_c, None, z_table, net.N_samples, net.raduis, net.num_neighbor, net.enc_flags,
                          net.use_mask, ro_c, pk0, net.in_channels_xyz, net.in_channels_dir, white_bg, save_acts,
-                         packed_h=net.packed_weights_h(net.nerf_coarse) if use_h else None, ws=ws)
+                         packed_h=net.packed_weights_h(net.nerf_coarse) if use_h else None, ws=ws, need_weights=fine)
     p0.packed = pk0
     p1 = None
     if fine:
-        z1 = ops.importance_sample(z_table, p0.weights, u_table, net.N_importance)
+        z1 = ops.importance_sample(z_table, p0.weights, u_table, net.N_importance, net.zero_row(dev))
         pk1 = net.packed_weights(net.nerf_fine)
         p1 = ops.render_pass(grid, pts, rays_c, z1, None, net.N_samples + net.N_importance, net.raduis, net.num_neighbor,
                              net.enc_flags, net.use_mask, ro_c, pk1, net.in_channels_xyz, net.in_channels_dir, white_bg,
-                             save_acts, packed_h=net.packed_weights_h(net.nerf_fine) if use_h else None, ws=ws)
+                             save_acts, packed_h=net.packed_weights_h(net.nerf_fine) if use_h else None, ws=ws,
+                             need_weights=False)
         p1.z = z1
         p1.packed = pk1
     return p0, p1, rays_c, ro_c, grid

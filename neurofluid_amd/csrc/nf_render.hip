@@ -38,33 +38,53 @@ __device__ __forceinline__ void sample_xyz(const float* __restrict__ rays, const
 // ------------------------------------------------------------------------------------------------
 // classify
 // ------------------------------------------------------------------------------------------------
-#define CL_PER_THREAD 8
+// Each thread takes CL_GROUPS quads of 4 consecutive samples (same ray when S % 4 == 0: the ray is read once,
+// z as one 16-B load).  num_nn / mask of the whole quad are cleared with one 16-B and one 4-B store — the
+// search overwrites the candidates afterwards — and nothing is written to rgbsigma: compositing reads it only
+// where mask = 1 (use_mask) and the MLP fills exactly those rows.
+#define CL_GROUPS 2
 __global__ void __launch_bounds__(256) k_classify(const void* __restrict__ ws, const float* __restrict__ rays,
                                                   const float* __restrict__ z, const float* __restrict__ z_table, int R,
                                                   int S, float r2, int use_mask, int* __restrict__ num_nn,
-                                                  uint8_t* __restrict__ mask, float4* __restrict__ rgbsigma,
-                                                  int* __restrict__ cand, int* __restrict__ cand_count)
+                                                  uint8_t* __restrict__ mask, int* __restrict__ cand,
+                                                  int* __restrict__ cand_count)
 {
     // one atomic per 2048 samples: per-thread flags -> block scan -> single reservation
     __shared__ int wsum[4];
     __shared__ int block_base;
     NfGridView g = nf_grid_view(ws);
     const int total = R * S;
-    const int base = blockIdx.x * (256 * CL_PER_THREAD);
+    const int base = blockIdx.x * (256 * CL_GROUPS * 4);
+    const bool s4 = (S & 3) == 0;
     unsigned flags = 0;
 #pragma unroll
-    for (int u = 0; u < CL_PER_THREAD; ++u) {
-        int i = base + u * 256 + threadIdx.x;
-        if (i < total) {
-            float x, y, zz, zv;
-            sample_xyz(rays, z, z_table, S, i, x, y, zz, zv);
-            bool is_cand = !use_mask || nf_any_cell_in_reach(g, x, y, zz, r2);
-            if (is_cand) flags |= 1u << u;
-            else {
-                num_nn[i] = 0;
-                mask[i] = 0;
-                rgbsigma[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int u = 0; u < CL_GROUPS; ++u) {
+        const int i0 = base + (u * 256 + threadIdx.x) * 4;
+        if (i0 >= total) continue;
+        const bool whole = i0 + 3 < total;
+        int r = i0 / S, sidx = i0 - r * S;
+        const float* ry = rays + 6 * (size_t)r;
+        float o0 = ry[0], o1 = ry[1], o2 = ry[2], d0 = ry[3], d1 = ry[4], d2 = ry[5];
+        float zq[4];
+        if (z && whole) { const float4 t = *(const float4*)(z + i0); zq[0] = t.x; zq[1] = t.y; zq[2] = t.z; zq[3] = t.w; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = i0 + e;
+            if (i >= total) break;
+            if (!s4 && e > 0 && sidx + e >= S) {      // quad straddles two rays (S % 4 != 0 only)
+                const int r2_ = i / S;
+                const float* rz = rays + 6 * (size_t)r2_;
+                o0 = rz[0]; o1 = rz[1]; o2 = rz[2]; d0 = rz[3]; d1 = rz[4]; d2 = rz[5];
             }
+            const float zv = z ? (whole ? zq[e] : z[i]) : z_table[i % S];
+            const float x = nf_madd_nofma(o0, d0, zv), y = nf_madd_nofma(o1, d1, zv), zz = nf_madd_nofma(o2, d2, zv);
+            if (!use_mask || nf_any_cell_in_reach(g, x, y, zz, r2)) flags |= 1u << (u * 4 + e);
+        }
+        if (whole) {
+            *(int4*)(num_nn + i0) = make_int4(0, 0, 0, 0);
+            *(uchar4*)(mask + i0) = make_uchar4(0, 0, 0, 0);
+        } else {
+            for (int i = i0; i < total; ++i) { num_nn[i] = 0; mask[i] = 0; }
         }
     }
     int n = __popc(flags);
@@ -86,22 +106,22 @@ __global__ void __launch_bounds__(256) k_classify(const void* __restrict__ ws, c
     int off = block_base + (x - n);
     for (int k = 0; k < w; ++k) off += wsum[k];
 #pragma unroll
-    for (int u = 0; u < CL_PER_THREAD; ++u)
-        if (flags & (1u << u)) cand[off++] = base + u * 256 + threadIdx.x;
+    for (int b = 0; b < CL_GROUPS * 4; ++b)
+        if (flags & (1u << b)) cand[off++] = base + ((b >> 2) * 256 + threadIdx.x) * 4 + (b & 3);
 }
 
 extern "C" int nf_render_classify(const void* ws, const float* rays, const float* z, const float* z_table, int R, int S,
-                                  float radius, int use_mask, int32_t* num_nn, uint8_t* mask, float* rgbsigma,
-                                  int32_t* cand, int32_t* cand_count, nf_stream_t stream)
+                                  float radius, int use_mask, int32_t* num_nn, uint8_t* mask, int32_t* cand,
+                                  int32_t* cand_count, nf_stream_t stream)
 {
-    NF_CHECK_ARG(ws && rays && (z || z_table) && num_nn && mask && rgbsigma && cand && cand_count, "null pointer");
+    NF_CHECK_ARG(ws && rays && (z || z_table) && num_nn && mask && cand && cand_count, "null pointer");
     NF_CHECK_ARG(R >= 0 && S > 0 && (long)R * S < 0x7fffffffL, "bad R/S");
     NF_CHECK_ARG(radius > 0.f, "bad radius");
     if (R == 0) return NF_OK;
     int total = R * S;
-    int per_block = 256 * CL_PER_THREAD;
+    int per_block = 256 * CL_GROUPS * 4;
     hipLaunchKernelGGL(k_classify, dim3((total + per_block - 1) / per_block), dim3(256), 0, (hipStream_t)stream, ws, rays,
-                       z, z_table, R, S, radius * radius, use_mask, num_nn, mask, (float4*)rgbsigma, cand, cand_count);
+                       z, z_table, R, S, radius * radius, use_mask, num_nn, mask, cand, cand_count);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }
@@ -114,8 +134,8 @@ __global__ void __launch_bounds__(BQ_BLOCK) k_search(const void* __restrict__ ws
                                                      int S, float r2, int K, int use_mask,
                                                      const int* __restrict__ cand, const int* __restrict__ cand_count,
                                                      int* __restrict__ num_nn, uint8_t* __restrict__ mask,
-                                                     float4* __restrict__ rgbsigma, int* __restrict__ row_sample,
-                                                     int* __restrict__ row_nbr, int* __restrict__ n_rows)
+                                                     int* __restrict__ row_sample, int* __restrict__ row_nbr,
+                                                     int* __restrict__ n_rows)
 {
     extern __shared__ int lds[];
     int* li = lds;
@@ -137,7 +157,6 @@ __global__ void __launch_bounds__(BQ_BLOCK) k_search(const void* __restrict__ ws
             num_nn[sample] = nz;
             mask[sample] = full ? 1 : 0;
             active = full || !use_mask;
-            if (!active) rgbsigma[sample] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         int row = wave_append(active, n_rows);
         if (active) {
@@ -149,11 +168,11 @@ __global__ void __launch_bounds__(BQ_BLOCK) k_search(const void* __restrict__ ws
 
 extern "C" int nf_render_search(const void* ws, const float* rays, const float* z, const float* z_table, int R, int S,
                                 float radius, int K, int use_mask, const int32_t* cand, const int32_t* cand_count,
-                                int32_t* num_nn, uint8_t* mask, float* rgbsigma, int32_t* row_sample, int32_t* row_nbr,
+                                int32_t* num_nn, uint8_t* mask, int32_t* row_sample, int32_t* row_nbr,
                                 int32_t* n_rows, nf_stream_t stream)
 {
-    NF_CHECK_ARG(ws && rays && (z || z_table) && cand && cand_count && num_nn && mask && rgbsigma && row_sample &&
-                     row_nbr && n_rows, "null pointer");
+    NF_CHECK_ARG(ws && rays && (z || z_table) && cand && cand_count && num_nn && mask && row_sample && row_nbr && n_rows,
+                 "null pointer");
     NF_CHECK_ARG(K >= 1 && K <= 32 && radius > 0.f, "bad K/radius");
     if (R == 0) return NF_OK;
     long total = (long)R * S;
@@ -161,8 +180,7 @@ extern "C" int nf_render_search(const void* ws, const float* rays, const float* 
     if (blocks > 8192) blocks = 8192;
     size_t lds = (size_t)BQ_LDS_INTS(K) * 4;
     hipLaunchKernelGGL(k_search, dim3(blocks), dim3(BQ_BLOCK), lds, (hipStream_t)stream, ws, rays, z, z_table, S,
-                       radius * radius, K, use_mask, cand, cand_count, num_nn, mask, (float4*)rgbsigma, row_sample,
-                       row_nbr, n_rows);
+                       radius * radius, K, use_mask, cand, cand_count, num_nn, mask, row_sample, row_nbr, n_rows);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }
@@ -325,14 +343,18 @@ extern "C" int nf_render_features(const float* particles, const float* rays, con
 // ------------------------------------------------------------------------------------------------
 // composite (A8): one thread per ray, sequential transmittance like torch.cumprod
 // ------------------------------------------------------------------------------------------------
-// 64 rays per wave; rgbsigma / z / mask tiles of 16 samples are staged through LDS with coalesced 16-B accesses
+// 64 rays per wave; rgbsigma / z tiles of 16 samples are staged through LDS with coalesced 16-B accesses
 // (a ray's 16 samples are 256 contiguous bytes), each thread then walks ITS ray sequentially — the same
 // association as torch.cumprod — and the weights leave through LDS the same way.
+// gate != 0 (use_mask): rgbsigma of a sample with mask = 0 IS zero (rgbsigma * mask, models/renderer.py:237) and is
+// never read — nobody wrote it.  A zero sample has alpha = 0, weight 0 and leaves T unchanged bit for bit
+// (1 - 0 + 1e-10 rounds to 1.f), so a 16-sample tile without any mask bit in the whole wave is skipped outright:
+// 1 B per sample of traffic for the ~97 % of the volume that is empty.
 #define CP_TS 16
 #define CP_PITCH 17
 __global__ void __launch_bounds__(64) k_composite(const float4* __restrict__ rgbsigma, const float* __restrict__ z,
                                                   const float* __restrict__ z_table, const float* __restrict__ rays,
-                                                  const uint8_t* __restrict__ mask, int R, int S, int white_bg,
+                                                  const uint8_t* __restrict__ mask, int gate, int R, int S, int white_bg,
                                                   float* __restrict__ rgb, float* __restrict__ depth,
                                                   float* __restrict__ opacity, float* __restrict__ weights,
                                                   float* __restrict__ mask_sum)
@@ -340,6 +362,7 @@ __global__ void __launch_bounds__(64) k_composite(const float4* __restrict__ rgb
     __shared__ float4 s_rs[64 * CP_PITCH];
     __shared__ float s_z[64 * (CP_TS + 1) + 64];
     __shared__ float s_w[64 * CP_PITCH];
+    __shared__ unsigned s_m[64];            // per ray: bit k = mask of sample s0 + k
     const int t = threadIdx.x;
     const int r0 = blockIdx.x * 64, r = r0 + t;
     const bool live = r < R;
@@ -351,15 +374,46 @@ __global__ void __launch_bounds__(64) k_composite(const float4* __restrict__ rgb
     float T = 1.f, cr = 0.f, cg = 0.f, cb = 0.f, cd = 0.f, ws = 0.f;
     int ms = 0;
     const int sub = t >> 4, col = t & 15;   // staging role: ray-in-group, sample-in-tile
+    const bool vec_mask = mask && (S & 15) == 0;
     for (int s0 = 0; s0 < S; s0 += CP_TS) {
-        // ---- stage in: 4 rays per instruction, 16 samples x 16 B each
+        const int ns = min(CP_TS, S - s0);
+        // ---- this ray's 16 mask bytes (one 16-B load when the row is 16-B tiled)
+        unsigned mbits = 0;
+        if (mask && live) {
+            if (vec_mask) {
+                const uint4 mv = *(const uint4*)(mask + (size_t)r * S + s0);
+                const unsigned wv[4] = {mv.x, mv.y, mv.z, mv.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) mbits |= (((wv[q] >> (8 * b)) & 0xffu) ? 1u : 0u) << (4 * q + b);
+            } else {
+                for (int k = 0; k < ns; ++k) mbits |= (mask[(size_t)r * S + s0 + k] ? 1u : 0u) << k;
+            }
+            ms += __popc(mbits);
+        }
+        const unsigned abits = gate ? mbits : (live ? 0xffffu : 0u);     // samples whose rgbsigma is read
+        if (__ballot(abits != 0u) == 0ull) {
+            // nothing to composite in this tile for any of the 64 rays
+            if (weights) {
+#pragma unroll 4
+                for (int i = 0; i < 16; ++i) {
+                    int rr = i * 4 + sub, gr = r0 + rr, gs = s0 + col;
+                    if (gr < R && gs < S) weights[(size_t)gr * S + gs] = 0.f;
+                }
+            }
+            continue;
+        }
+        s_m[t] = abits;
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        // ---- stage in: 4 rays per instruction, 16 samples x 16 B each (only where the sample is live)
 #pragma unroll 4
         for (int i = 0; i < 16; ++i) {
             int rr = i * 4 + sub, gr = r0 + rr, gs = s0 + col;
-            if (gr < R && gs < S) {
-                s_rs[rr * CP_PITCH + col] = rgbsigma[(size_t)gr * S + gs];
-                if (mask) ms += 0;  // (mask is summed below from a coalesced byte tile)
-            }
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gr < R && gs < S && ((s_m[rr] >> col) & 1u)) v = rgbsigma[(size_t)gr * S + gs];
+            s_rs[rr * CP_PITCH + col] = v;
         }
         // z tile incl. one look-ahead element per ray
         for (int i = 0; i < 16; ++i) {
@@ -374,7 +428,6 @@ __global__ void __launch_bounds__(64) k_composite(const float4* __restrict__ rgb
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
         // ---- sequential walk of this thread's ray
-        const int ns = min(CP_TS, S - s0);
         if (live) {
             for (int k = 0; k < ns; ++k) {
                 int s = s0 + k;
@@ -390,14 +443,14 @@ __global__ void __launch_bounds__(64) k_composite(const float4* __restrict__ rgb
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
-        // ---- stage out the weights (64 B per ray per instruction) and sum the mask bytes
+        // ---- stage out the weights (64 B per ray per instruction)
+        if (weights) {
 #pragma unroll 4
-        for (int i = 0; i < 16; ++i) {
-            int rr = i * 4 + sub, gr = r0 + rr, gs = s0 + col;
-            if (gr < R && gs < S) weights[(size_t)gr * S + gs] = s_w[rr * CP_PITCH + col];
+            for (int i = 0; i < 16; ++i) {
+                int rr = i * 4 + sub, gr = r0 + rr, gs = s0 + col;
+                if (gr < R && gs < S) weights[(size_t)gr * S + gs] = s_w[rr * CP_PITCH + col];
+            }
         }
-        if (mask && live)
-            for (int k = 0; k < ns; ++k) ms += mask[(size_t)r * S + s0 + k];
         __builtin_amdgcn_wave_barrier();
     }
     if (!live) return;
@@ -409,13 +462,14 @@ __global__ void __launch_bounds__(64) k_composite(const float4* __restrict__ rgb
 }
 
 extern "C" int nf_composite_fwd(const float* rgbsigma, const float* z, const float* z_table, const float* rays,
-                                const uint8_t* mask, int R, int S, int white_bg, float* rgb, float* depth, float* opacity,
-                                float* weights, float* mask_sum, nf_stream_t stream)
+                                const uint8_t* mask, int gate_by_mask, int R, int S, int white_bg, float* rgb, float* depth,
+                                float* opacity, float* weights, float* mask_sum, nf_stream_t stream)
 {
-    NF_CHECK_ARG(rgbsigma && (z || z_table) && rays && rgb && depth && opacity && weights, "null pointer");
+    NF_CHECK_ARG(rgbsigma && (z || z_table) && rays && rgb && depth && opacity, "null pointer");
+    NF_CHECK_ARG(!gate_by_mask || mask, "gate_by_mask needs the mask");
     if (R == 0) return NF_OK;
     hipLaunchKernelGGL(k_composite, dim3((R + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const float4*)rgbsigma, z,
-                       z_table, rays, mask, R, S, white_bg, rgb, depth, opacity, weights, mask_sum);
+                       z_table, rays, mask, gate_by_mask, R, S, white_bg, rgb, depth, opacity, weights, mask_sum);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }
@@ -425,18 +479,38 @@ extern "C" int nf_composite_fwd(const float* rgbsigma, const float* z, const flo
 // [k][thread] (conflict-free).  utils/ray_utils.py:178-229.
 // ------------------------------------------------------------------------------------------------
 #define IS_BLOCK 64
+// zero_row (optional): the output row of a ray whose weights[1:-1] are all exactly zero — the same for every such
+// ray because the coarse depths are shared (computed once by this very kernel on one zero-weight ray, so the bits
+// are those of the general path).  Rays that hit nothing (the large majority of an image) then cost one pass over
+// their weights and a coalesced 64-lane copy of that row instead of the serial inverse-CDF walk.
 __global__ void __launch_bounds__(IS_BLOCK) k_importance(const float* __restrict__ z0, const float* __restrict__ w0,
                                                          const float* __restrict__ u_table, int R, int S0, int NI,
-                                                         float* __restrict__ z1)
+                                                         const float* __restrict__ zero_row, float* __restrict__ z1)
 {
     extern __shared__ float sm[];
     float* cdf = sm;                        // [(S0-1)][IS_BLOCK]
     float* zn = sm + (S0 - 1) * IS_BLOCK;   // [NI][IS_BLOCK]
     const int tid = threadIdx.x;
     int r = blockIdx.x * IS_BLOCK + tid;
-    if (r >= R) return;
     const int NB = S0 - 1;   // bins (mid points): 63
     const int NW = S0 - 2;   // weights[1:-1]: 62
+    if (zero_row) {
+        bool allzero = r < R;
+        if (r < R) {
+            const float* wz = w0 + (size_t)r * S0;
+            for (int k = 0; k < NW; ++k) allzero = allzero && (wz[k + 1] == 0.f);
+        }
+        unsigned long long zm = __ballot(allzero);
+        const int ST = S0 + NI;
+        while (zm) {
+            const int src = __ffsll((long long)zm) - 1;
+            zm &= zm - 1ull;
+            float* out = z1 + (size_t)(blockIdx.x * IS_BLOCK + src) * ST;
+            for (int k = tid; k < ST; k += IS_BLOCK) out[k] = zero_row[k];
+        }
+        if (allzero) return;
+    }
+    if (r >= R) return;
     const float* w = w0 + (size_t)r * S0;
     float tot = 0.f;
     for (int k = 0; k < NW; ++k) tot += (w[k + 1] + 1e-5f);
@@ -478,7 +552,7 @@ __global__ void __launch_bounds__(IS_BLOCK) k_importance(const float* __restrict
 }
 
 extern "C" int nf_importance_sample(const float* z_table0, const float* weights0, const float* u_table, int R, int S0,
-                                    int N_imp, float* z1, nf_stream_t stream)
+                                    int N_imp, const float* zero_row, float* z1, nf_stream_t stream)
 {
     NF_CHECK_ARG(z_table0 && weights0 && u_table && z1, "null pointer");
     NF_CHECK_ARG(S0 >= 3 && N_imp >= 1, "bad S0/N_imp");
@@ -488,7 +562,7 @@ extern "C" int nf_importance_sample(const float* z_table0, const float* weights0
     if (lds > 64 * 1024)
         hipFuncSetAttribute((const void*)k_importance, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_importance, dim3((R + IS_BLOCK - 1) / IS_BLOCK), dim3(IS_BLOCK), lds, (hipStream_t)stream,
-                       z_table0, weights0, u_table, R, S0, N_imp, z1);
+                       z_table0, weights0, u_table, R, S0, N_imp, zero_row, z1);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }
@@ -502,8 +576,9 @@ extern "C" int nf_importance_sample(const float* z_table0, const float* weights0
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_composite_bwd(const float4* __restrict__ rgbsigma, const float* __restrict__ z,
                                                       const float* __restrict__ z_table, const float* __restrict__ rays,
-                                                      const float* __restrict__ d_rgb, int R, int S, int white_bg,
-                                                      float* __restrict__ scratch, float4* __restrict__ d_rgbsigma)
+                                                      const float* __restrict__ d_rgb, const uint8_t* __restrict__ mask,
+                                                      int gate, int R, int S, int white_bg, float* __restrict__ scratch,
+                                                      float4* __restrict__ d_rgbsigma)
 {
     int r = blockIdx.x * 64 + threadIdx.x;
     if (r >= R) return;
@@ -516,13 +591,15 @@ __global__ void __launch_bounds__(64) k_composite_bwd(const float4* __restrict__
     float T = 1.f;
     for (int s = 0; s < S; ++s) {
         float delta = ((s + 1 < S) ? (zr[s + 1] - zr[s]) : 1e10f) * nrm;
-        float alpha = 1.f - expf(-delta * fmaxf(rgbsigma[(size_t)r * S + s].w, 0.f));
+        const bool on = !gate || mask[(size_t)r * S + s];      // rgbsigma is defined (written by the MLP) only there
+        float alpha = on ? 1.f - expf(-delta * fmaxf(rgbsigma[(size_t)r * S + s].w, 0.f)) : 0.f;
         Tr[s] = T;
         T = T * ((1.f - alpha) + 1e-10f);
     }
     float suffix = 0.f;
     for (int s = S - 1; s >= 0; --s) {
-        float4 v = rgbsigma[(size_t)r * S + s];
+        const bool on = !gate || mask[(size_t)r * S + s];
+        float4 v = on ? rgbsigma[(size_t)r * S + s] : make_float4(0.f, 0.f, 0.f, 0.f);
         float delta = ((s + 1 < S) ? (zr[s + 1] - zr[s]) : 1e10f) * nrm;
         float e = expf(-delta * fmaxf(v.w, 0.f));
         float alpha = 1.f - e;
@@ -537,13 +614,14 @@ __global__ void __launch_bounds__(64) k_composite_bwd(const float4* __restrict__
 }
 
 extern "C" int nf_composite_bwd(const float* rgbsigma, const float* z, const float* z_table, const float* rays,
-                                const float* d_rgb, int R, int S, int white_bg, float* scratch, float* d_rgbsigma,
-                                nf_stream_t stream)
+                                const float* d_rgb, const uint8_t* mask, int gate_by_mask, int R, int S, int white_bg,
+                                float* scratch, float* d_rgbsigma, nf_stream_t stream)
 {
     NF_CHECK_ARG(rgbsigma && (z || z_table) && rays && d_rgb && scratch && d_rgbsigma, "null pointer");
+    NF_CHECK_ARG(!gate_by_mask || mask, "gate_by_mask needs the mask");
     if (R == 0) return NF_OK;
     hipLaunchKernelGGL(k_composite_bwd, dim3((R + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const float4*)rgbsigma, z,
-                       z_table, rays, d_rgb, R, S, white_bg, scratch, (float4*)d_rgbsigma);
+                       z_table, rays, d_rgb, mask, gate_by_mask, R, S, white_bg, scratch, (float4*)d_rgbsigma);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }

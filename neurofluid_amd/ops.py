@@ -229,7 +229,7 @@ class Workspace:
 
 
 def render_pass(grid, particles, rays, z, z_table, S, radius, K, enc_flags, use_mask, ro, packed, cx, cd,
-                white_bg=True, save_acts=False, max_rows=None, packed_h=None, ws=None):
+                white_bg=True, save_acts=False, max_rows=None, packed_h=None, ws=None, need_weights=True):
     """Runs classify -> search -> features -> MLP -> composite for R rays x S samples.
     z: (R,S) per-ray depths or None (then z_table (S,) is shared by all rays).
     Returns a PassBuffers with rgb, depth, opacity, weights, num_nn, mask_sum and the row lists."""
@@ -257,7 +257,7 @@ def render_pass(grid, particles, rays, z, z_table, S, radius, K, enc_flags, use_
     counters = torch.zeros(2, dtype=torch.int32, device=dev)
     b.counters = counters
     check(lib.nf_render_classify(ptr(grid.ws), ptr(rays), ptr(z), ptr(z_table), R, S, float(radius), int(use_mask), ptr(b.num_nn),
-                                 ptr(b.mask), ptr(b.rgbsigma), ptr(cand), ptr(counters[0:1]), st), "nf_render_classify")
+                                 ptr(b.mask), ptr(cand), ptr(counters[0:1]), st), "nf_render_classify")
     if max_rows is None:
         max_rows = n_samp
     max_rows = min(max_rows, n_samp)
@@ -268,7 +268,7 @@ def render_pass(grid, particles, rays, z, z_table, S, radius, K, enc_flags, use_
     b.row_sample = scratch("row_sample", n_samp, torch.int32)
     b.row_nbr = scratch("row_nbr", n_samp * K, torch.int32)
     check(lib.nf_render_search(ptr(grid.ws), ptr(rays), ptr(z), ptr(z_table), R, S, float(radius), K, int(use_mask),
-                               ptr(cand), ptr(counters[0:1]), ptr(b.num_nn), ptr(b.mask), ptr(b.rgbsigma),
+                               ptr(cand), ptr(counters[0:1]), ptr(b.num_nn), ptr(b.mask),
                                ptr(b.row_sample), ptr(b.row_nbr), ptr(counters[1:2]), st), "nf_render_search")
     b.n_rows = counters[1:2]
     if max_rows >= n_samp:
@@ -301,21 +301,30 @@ def render_pass(grid, particles, rays, z, z_table, S, radius, K, enc_flags, use_
     b.rgb = torch.empty(R, 3, dtype=torch.float32, device=dev)
     b.depth = torch.empty(R, dtype=torch.float32, device=dev)
     b.opacity = torch.empty(R, dtype=torch.float32, device=dev)
-    b.weights = torch.empty(R, S, dtype=torch.float32, device=dev)
+    # the weights are only needed by the pass that is resampled from (the coarse one)
+    b.weights = torch.empty(R, S, dtype=torch.float32, device=dev) if need_weights else None
     b.mask_sum = torch.empty(R, dtype=torch.float32, device=dev)
-    check(lib.nf_composite_fwd(ptr(b.rgbsigma), ptr(z), ptr(z_table), ptr(rays), ptr(b.mask), R, S, int(white_bg),
+    b.gate = int(bool(use_mask))       # rgbsigma is defined where mask = 1 only (nobody writes the rest)
+    check(lib.nf_composite_fwd(ptr(b.rgbsigma), ptr(z), ptr(z_table), ptr(rays), ptr(b.mask), b.gate, R, S, int(white_bg),
                                ptr(b.rgb), ptr(b.depth), ptr(b.opacity), ptr(b.weights), ptr(b.mask_sum), st),
           "nf_composite_fwd")
     return b
 
 
-def importance_sample(z_table0, weights0, u_table, n_importance):
+def importance_sample(z_table0, weights0, u_table, n_importance, zero_row=None):
+    """zero_row: importance_zero_row(...) of the same tables — the shared output row of every ray that hit nothing."""
     lib = _lib.load()
     R, S0 = weights0.shape
     z1 = torch.empty(R, S0 + n_importance, dtype=torch.float32, device=weights0.device)
-    check(lib.nf_importance_sample(ptr(z_table0), ptr(weights0), ptr(u_table), R, S0, n_importance, ptr(z1),
+    check(lib.nf_importance_sample(ptr(z_table0), ptr(weights0), ptr(u_table), R, S0, n_importance, ptr(zero_row), ptr(z1),
                                    _lib.stream()), "nf_importance_sample")
     return z1
+
+
+def importance_zero_row(z_table0, u_table, n_importance):
+    """The resampled depths of a ray with all-zero weights, computed by the general path of the same kernel."""
+    w = torch.zeros(1, z_table0.shape[0], dtype=torch.float32, device=z_table0.device)
+    return importance_sample(z_table0, w, u_table, n_importance)[0].contiguous()
 
 
 # ------------------------------------------------------------------------------------------------
@@ -368,7 +377,6 @@ def debug_features(particles, rays, near, far, S, radius, K, enc_flags, ro):
     n = R * S
     num_nn = torch.empty(n, dtype=torch.int32, device=dev)
     mask = torch.empty(n, dtype=torch.uint8, device=dev)
-    rgbsigma = torch.empty(n, 4, device=dev)
     cand = torch.empty(n, dtype=torch.int32, device=dev)
     counters = torch.zeros(2, dtype=torch.int32, device=dev)
     row_sample = torch.empty(n, dtype=torch.int32, device=dev)
@@ -376,9 +384,9 @@ def debug_features(particles, rays, near, far, S, radius, K, enc_flags, ro):
     st = _lib.stream()
     rays = rays.contiguous().float()
     check(lib.nf_render_classify(ptr(grid.ws), ptr(rays), None, ptr(z_table), R, S, float(radius), 1, ptr(num_nn), ptr(mask),
-                                 ptr(rgbsigma), ptr(cand), ptr(counters[0:1]), st))
+                                 ptr(cand), ptr(counters[0:1]), st))
     check(lib.nf_render_search(ptr(grid.ws), ptr(rays), None, ptr(z_table), R, S, float(radius), K, 1, ptr(cand),
-                               ptr(counters[0:1]), ptr(num_nn), ptr(mask), ptr(rgbsigma), ptr(row_sample), ptr(row_nbr),
+                               ptr(counters[0:1]), ptr(num_nn), ptr(mask), ptr(row_sample), ptr(row_nbr),
                                ptr(counters[1:2]), st))
     nr = int(counters[1].item())
     cx, cd, qx, qd = feature_dims(enc_flags)

@@ -68,6 +68,7 @@ class RenderNet(nn.Module):
         self.nerf_fine = NeRF(in_channels_xyz=in_xyz, in_channels_dir=in_dir)
         self._z_table = None
         self._u_table = None
+        self._zero_row = None
         self._grid_cache = (None, None)
         self._workspace = None
 
@@ -80,7 +81,15 @@ class RenderNet(nn.Module):
             t = torch.linspace(0, 1, self.N_samples)          # utils/ray_utils.py:236-238 (CPU bits, then copied)
             self._z_table = (self.near * (1 - t) + self.far * t).to(device)
             self._u_table = torch.linspace(0., 1., steps=max(self.N_importance, 1)).to(device)
+            self._zero_row = None
         return self._z_table, self._u_table
+
+    def zero_row(self, device):
+        """Resampled depths shared by every ray whose coarse weights are all zero (ops.importance_zero_row)."""
+        z_table, u_table = self._tables(device)
+        if self._zero_row is None:
+            self._zero_row = ops.importance_zero_row(z_table, u_table, self.N_importance)
+        return self._zero_row
 
     def grid_for(self, particles):
         """One grid per particle tensor *version* (rebuilt when the particles move)."""

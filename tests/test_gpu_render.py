@@ -139,12 +139,63 @@ def test_composite(dev):
     for white, key in ((1, "rgb"), (0, "rgb_nobg")):
         rgb = torch.empty(R, 3, device=dev); depth = torch.empty(R, device=dev); op = torch.empty(R, device=dev)
         w = torch.empty(R, S, device=dev)
-        _lib.check(lib.nf_composite_fwd(rs.data_ptr(), z.data_ptr(), None, rays.data_ptr(), None, R, S, white,
+        _lib.check(lib.nf_composite_fwd(rs.data_ptr(), z.data_ptr(), None, rays.data_ptr(), None, 0, R, S, white,
                                         rgb.data_ptr(), depth.data_ptr(), op.data_ptr(), w.data_ptr(), None,
                                         _lib.stream()))
         torch.testing.assert_close(rgb.cpu(), T(g[key]), rtol=0, atol=2e-6)
         torch.testing.assert_close(w.cpu(), T(g["weights"]), rtol=1e-5, atol=1e-7)
         torch.testing.assert_close(depth.cpu(), T(g["depth"]), rtol=1e-5, atol=1e-5)
+
+
+def test_composite_gated_by_mask(dev):
+    """use_mask: rgbsigma * mask (models/renderer.py:237).  The gated kernel must give the bits of compositing the
+    explicitly masked array while never reading rgbsigma where mask = 0 (those entries hold NaN here); rays / tiles
+    without any mask bit, ragged S, weights = NULL."""
+    from neurofluid_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(5)
+    for R, S in [(200, 64), (131, 192), (70, 37)]:
+        rs = torch.rand(R, S, 4, generator=gen)
+        rs[..., 3] = rs[..., 3] * 30 - 5
+        mask = (torch.rand(R, S, generator=gen) < 0.3)
+        mask[: R // 2] &= (torch.rand(R // 2, 1, generator=gen) < 0.3)      # whole rays / tiles empty
+        mask[5] = False
+        z = torch.sort(torch.rand(R, S, generator=gen) * 4 + 9, dim=1).values
+        rays = torch.randn(R, 6, generator=gen)
+        ref_in = (rs * mask[..., None]).contiguous().to(dev)
+        poisoned = torch.where(mask[..., None], rs, torch.full_like(rs, float("nan"))).contiguous().to(dev)
+        m8 = mask.to(torch.uint8).contiguous().to(dev)
+        zd, rd = z.contiguous().to(dev), rays.contiguous().to(dev)
+        outs = []
+        for src, gate, want_w in ((ref_in, 0, True), (poisoned, 1, True), (poisoned, 1, False)):
+            rgb = torch.empty(R, 3, device=dev); depth = torch.empty(R, device=dev); op = torch.empty(R, device=dev)
+            w = torch.full((R, S), 7.0, device=dev); msum = torch.empty(R, device=dev)
+            _lib.check(lib.nf_composite_fwd(src.data_ptr(), zd.data_ptr(), None, rd.data_ptr(), m8.data_ptr(), gate, R, S, 1,
+                                            rgb.data_ptr(), depth.data_ptr(), op.data_ptr(),
+                                            w.data_ptr() if want_w else None, msum.data_ptr(), _lib.stream()))
+            outs.append((rgb.cpu(), depth.cpu(), op.cpu(), w.cpu(), msum.cpu()))
+        for k in range(3):
+            assert torch.equal(outs[0][k], outs[1][k]) and torch.equal(outs[0][k], outs[2][k])
+        assert torch.equal(outs[0][3], outs[1][3]) and bool((outs[2][3] == 7.0).all())
+        assert torch.equal(outs[1][4], mask.sum(1).float()) and torch.equal(outs[0][4], outs[1][4])
+
+
+def test_importance_zero_row_fast_path(dev):
+    """Rays whose weights[1:-1] are all zero take a copy of the shared row: same bits as the general path."""
+    from neurofluid_amd import ops
+    g = load_golden("a9_importance")
+    z0, u = T(g["z0"])[0].contiguous().to(dev), torch.linspace(0., 1., steps=128).to(dev)
+    gen = torch.Generator().manual_seed(9)
+    w = torch.rand(300, 64, generator=gen)
+    w[::3] = 0                       # every third ray hit nothing
+    w[1, 1:-1] = 0; w[1, 0] = 0.5; w[1, -1] = 0.25      # only the unused end weights set: still the zero row
+    w[4] = 0; w[4, 30] = 1e-30       # a denormal-scale weight is NOT zero
+    w = w.to(dev)
+    row = ops.importance_zero_row(z0, u, 128)
+    slow = ops.importance_sample(z0, w, u, 128)
+    fast = ops.importance_sample(z0, w, u, 128, zero_row=row)
+    assert torch.equal(slow, fast)
+    assert torch.equal(fast[0], row) and torch.equal(fast[1], row)
 
 
 def test_mlp_rows_vs_golden(dev):

@@ -43,8 +43,13 @@ struct NfGridHeader {
     int off_cell_rec;    // 3 x float4 per cell: {start, end, min original index, -} {lo.xyz, hi.x} {hi.y, hi.z, -, -}
     int off_dil_start;   // int[n_cells+1]: start of the cell's DILATED list (all points of its 27-neighbourhood)
     int off_dil_pos;     // float4[sum cell_dil] (<= 27 n): xyz + index bits, ascending ORIGINAL index inside each list
-    int pad_[1];
+    int off_dil_box;     // 2 x float4 per 16 consecutive dil_pos entries: {lo.xyz, -} {hi.xyz, -} (chunk AABB)
+    unsigned pt_lo[3], pt_hi[3];   // exact AABB of the points (order-preserving uint encoding; device-written at build)
 };
+
+// order-preserving float <-> uint (atomicMin / atomicMax on floats of either sign)
+__device__ __forceinline__ unsigned nf_f2ord(float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float nf_ord2f(unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
 
 struct NfGridView {
     float ox, oy, oz;
@@ -59,6 +64,8 @@ struct NfGridView {
     const float4* cell_rec;
     const int* dil_start;
     const float4* dil_pos;
+    const float4* dil_box;
+    float plo[3], phi[3];   // exact AABB of the points (+inf / -inf when the grid is empty)
 };
 
 __device__ __forceinline__ NfGridView nf_grid_view(const void* ws)
@@ -78,6 +85,8 @@ __device__ __forceinline__ NfGridView nf_grid_view(const void* ws)
     v.cell_rec = (const float4*)(b + h->off_cell_rec);
     v.dil_start = (const int*)(b + h->off_dil_start);
     v.dil_pos = (const float4*)(b + h->off_dil_pos);
+    v.dil_box = (const float4*)(b + h->off_dil_box);
+    for (int d = 0; d < 3; ++d) { v.plo[d] = nf_ord2f(h->pt_lo[d]); v.phi[d] = nf_ord2f(h->pt_hi[d]); }
     return v;
 }
 
@@ -121,6 +130,16 @@ __device__ __forceinline__ float nf_box_dist2(const float* __restrict__ bb, floa
     return s;
 }
 
+// Cheap exact rejection ahead of any table lookup: a point within `radius` of some particle lies inside the
+// particles' AABB grown by the radius (margin: 1e-4 relative, far above the fp32 rounding of the distance test).
+// Most samples of an image lie outside — and clamp into a (non-empty) border cell, the expensive case below.
+__device__ __forceinline__ bool nf_near_points_aabb(const NfGridView& g, float qx, float qy, float qz, float radius)
+{
+    const float rm = radius * 1.0001f + 1e-6f;
+    return qx >= g.plo[0] - rm && qx <= g.phi[0] + rm && qy >= g.plo[1] - rm && qy <= g.phi[1] + rm &&
+           qz >= g.plo[2] - rm && qz <= g.phi[2] + rm;
+}
+
 // true iff some cell of the 27-neighbourhood has its particle AABB within (strictly) radius
 __device__ __forceinline__ bool nf_any_cell_in_reach(const NfGridView& g, float qx, float qy, float qz, float r2)
 {
@@ -140,8 +159,13 @@ __device__ __forceinline__ bool nf_any_cell_in_reach(const NfGridView& g, float 
 // First-K-by-index search.  Every cell owns a DILATED list: all points of its 27-cell neighbourhood, merged in
 // ascending original index at grid-build time.  A query therefore walks ONE list in exactly the reference's scan
 // order (pytorch3d scans p2 in index order) restricted to the points that can be in range, appends hits (they
-// arrive sorted: no insertion, no per-cell bookkeeping) and stops at the K-th.  Candidates are fetched 4 at a time
-// (independent loads in flight).  li = K indices [k * BQ_BLOCK + tid]; nzmask bit k = (d2 of slot k != 0).  K <= 32.
+// arrive sorted: no insertion, no per-cell bookkeeping) and stops at the K-th.  The list is walked in aligned
+// chunks of 16 entries, each with a precomputed AABB: a chunk whose box is not within the radius cannot hold a hit
+// (nf_box_dist2 never exceeds the distance to a contained point) and is skipped without touching its entries —
+// consecutive indices are spatially coherent in practice (lattice fill order, SPH emitters), so a ball that covers
+// ~15 % of the 27-cell volume rejects most chunks.  Candidates are fetched 4 at a time (independent loads in flight).
+// li = K indices [k * BQ_BLOCK + tid]; nzmask bit k = (d2 of slot k != 0).  K <= 32.
+#define NF_DIL_CHUNK 16
 __device__ __forceinline__ int firstk_search(const NfGridView& g, float qx, float qy, float qz, float r2, int K,
                                              int* li, int tid, unsigned& nzmask)
 {
@@ -152,18 +176,24 @@ __device__ __forceinline__ int firstk_search(const NfGridView& g, float qx, floa
     const int s = g.dil_start[cell], e = g.dil_start[cell + 1];
     int cnt = 0;
     nzmask = 0u;
-    for (int t = s; t < e; t += 4) {
-        float4 p[4];
+    for (int cb = s & ~(NF_DIL_CHUNK - 1); cb < e; cb += NF_DIL_CHUNK) {
+        const float4 blo = g.dil_box[2 * (cb / NF_DIL_CHUNK)], bhi = g.dil_box[2 * (cb / NF_DIL_CHUNK) + 1];
+        const float bb[6] = {blo.x, blo.y, blo.z, bhi.x, bhi.y, bhi.z};
+        if (!(nf_box_dist2(bb, qx, qy, qz) < r2)) continue;
+        const int t1 = min(cb + NF_DIL_CHUNK, e);
+        for (int t = max(cb, s); t < t1; t += 4) {
+            float4 p[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) p[u] = g.dil_pos[min(t + u, e - 1)];
+            for (int u = 0; u < 4; ++u) p[u] = g.dil_pos[min(t + u, t1 - 1)];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (t + u < e && cnt < K) {
-                float d2 = nf_dist2(qx, qy, qz, p[u].x, p[u].y, p[u].z);
-                if (d2 < r2) {
-                    li[cnt * BQ_BLOCK + tid] = __float_as_int(p[u].w);
-                    nzmask |= (d2 != 0.f ? 1u : 0u) << cnt;
-                    ++cnt;
+            for (int u = 0; u < 4; ++u) {
+                if (t + u < t1 && cnt < K) {
+                    float d2 = nf_dist2(qx, qy, qz, p[u].x, p[u].y, p[u].z);
+                    if (d2 < r2) {
+                        li[cnt * BQ_BLOCK + tid] = __float_as_int(p[u].w);
+                        nzmask |= (d2 != 0.f ? 1u : 0u) << cnt;
+                        ++cnt;
+                    }
                 }
             }
         }

@@ -187,6 +187,7 @@ int nf_grid_make_header(int n, float cell, const float bbox[6], NfGridHeader* h,
     h->off_cell_rec = (int)off;   off = align_up(off + sizeof(float4) * 3 * cells, 256);
     h->off_dil_start = (int)off;  off = align_up(off + sizeof(int) * (cells + 1), 256);
     h->off_dil_pos = (int)off;    off = align_up(off + sizeof(float4) * 27 * (size_t)(n > 0 ? n : 1), 256);
+    h->off_dil_box = (int)off;    off = align_up(off + sizeof(float4) * 2 * (27 * (size_t)(n > 0 ? n : 1) / NF_DIL_CHUNK + 2), 256);
     if (off > (size_t)0x7fffffff) return NF_EINVAL;
     *total = off;
     return NF_OK;
@@ -203,7 +204,10 @@ extern "C" size_t nf_grid_workspace_bytes(int n_points, float cell, const float 
 __global__ void k_grid_init(NfGridHeader h, void* ws)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) *(NfGridHeader*)ws = h;
+    if (i == 0) {
+        for (int d = 0; d < 3; ++d) { h.pt_lo[d] = nf_f2ord(INFINITY); h.pt_hi[d] = nf_f2ord(-INFINITY); }
+        *(NfGridHeader*)ws = h;
+    }
     int* fill = (int*)((char*)ws + h.off_cell_fill);
     if (i < h.n_cells) fill[i] = 0;
 }
@@ -211,13 +215,26 @@ __global__ void k_grid_init(NfGridHeader h, void* ws)
 __global__ void k_grid_count(NfGridHeader h, void* ws, const float* __restrict__ pts)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= h.n_points) return;
-    int cx = nf_cell_coord(pts[3 * i + 0], h.origin[0], h.inv_cell[0], h.dims[0]);
-    int cy = nf_cell_coord(pts[3 * i + 1], h.origin[1], h.inv_cell[1], h.dims[1]);
-    int cz = nf_cell_coord(pts[3 * i + 2], h.origin[2], h.inv_cell[2], h.dims[2]);
-    int c = (cz * h.dims[1] + cy) * h.dims[0] + cx;
-    ((int*)((char*)ws + h.off_tmp_cell))[i] = c;
-    atomicAdd((int*)((char*)ws + h.off_cell_fill) + c, 1);
+    const bool live = i < h.n_points;
+    float p[3] = {0.f, 0.f, 0.f};
+    if (live) {
+        p[0] = pts[3 * i]; p[1] = pts[3 * i + 1]; p[2] = pts[3 * i + 2];
+        int cx = nf_cell_coord(p[0], h.origin[0], h.inv_cell[0], h.dims[0]);
+        int cy = nf_cell_coord(p[1], h.origin[1], h.inv_cell[1], h.dims[1]);
+        int cz = nf_cell_coord(p[2], h.origin[2], h.inv_cell[2], h.dims[2]);
+        int c = (cz * h.dims[1] + cy) * h.dims[0] + cx;
+        ((int*)((char*)ws + h.off_tmp_cell))[i] = c;
+        atomicAdd((int*)((char*)ws + h.off_cell_fill) + c, 1);
+    }
+    // exact AABB of the points: wave reduction, then 6 atomics per wave into the header copy in the workspace
+    NfGridHeader* hw = (NfGridHeader*)ws;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        float lo = live ? p[d] : INFINITY, hi = live ? p[d] : -INFINITY;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o, 64)); hi = fmaxf(hi, __shfl_xor(hi, o, 64)); }
+        if ((threadIdx.x & 63) == 0 && lo <= hi) { atomicMin(&hw->pt_lo[d], nf_f2ord(lo)); atomicMax(&hw->pt_hi[d], nf_f2ord(hi)); }
+    }
 }
 
 __global__ void k_grid_zero_fill(NfGridHeader h, void* ws)
@@ -321,6 +338,27 @@ __global__ void k_grid_dil_fill(NfGridHeader h, void* ws)
     ((float4*)(b + h.off_dil_pos))[ds[target] + rank] = spos[t];
 }
 
+// AABB of every aligned run of NF_DIL_CHUNK consecutive dilated-list entries (a run may straddle two lists: the
+// box is then merely looser, never wrong)
+__global__ void k_grid_dil_box(NfGridHeader h, void* ws)
+{
+    int gch = blockIdx.x * blockDim.x + threadIdx.x;
+    char* b = (char*)ws;
+    const int total = ((const int*)(b + h.off_dil_start))[h.n_cells];
+    if (gch * NF_DIL_CHUNK >= total) return;
+    const float4* dp = (const float4*)(b + h.off_dil_pos);
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    const int t1 = min(gch * NF_DIL_CHUNK + NF_DIL_CHUNK, total);
+    for (int t = gch * NF_DIL_CHUNK; t < t1; ++t) {
+        float4 p = dp[t];
+        lo[0] = fminf(lo[0], p.x); lo[1] = fminf(lo[1], p.y); lo[2] = fminf(lo[2], p.z);
+        hi[0] = fmaxf(hi[0], p.x); hi[1] = fmaxf(hi[1], p.y); hi[2] = fmaxf(hi[2], p.z);
+    }
+    float4* box = (float4*)(b + h.off_dil_box) + 2 * gch;
+    box[0] = make_float4(lo[0], lo[1], lo[2], 0.f);
+    box[1] = make_float4(hi[0], hi[1], hi[2], 0.f);
+}
+
 extern "C" int nf_grid_build(const float* pts, int n, float cell, const float bbox[6], void* ws, size_t ws_bytes,
                              nf_stream_t stream)
 {
@@ -344,7 +382,11 @@ extern "C" int nf_grid_build(const float* pts, int n, float cell, const float bb
     hipLaunchKernelGGL(k_grid_dilate, dim3(gc), dim3(B), 0, st, h, ws);
     launch_scan<int>((const int*)((char*)ws + h.off_cell_dil), (int*)((char*)ws + h.off_dil_start), fill + h.n_cells + 8,
                      h.n_cells, st);
-    if (n > 0) hipLaunchKernelGGL(k_grid_dil_fill, dim3((n * 27 + B - 1) / B), dim3(B), 0, st, h, ws);
+    if (n > 0) {
+        hipLaunchKernelGGL(k_grid_dil_fill, dim3((n * 27 + B - 1) / B), dim3(B), 0, st, h, ws);
+        const int nchunks = n * 27 / NF_DIL_CHUNK + 1;
+        hipLaunchKernelGGL(k_grid_dil_box, dim3((nchunks + B - 1) / B), dim3(B), 0, st, h, ws);
+    }
     NF_CHECK_LAUNCH();
     return NF_OK;
 }

@@ -45,10 +45,11 @@ __device__ __forceinline__ void sample_xyz(const float* __restrict__ rays, const
 #define CL_GROUPS 2
 __global__ void __launch_bounds__(256) k_classify(const void* __restrict__ ws, const float* __restrict__ rays,
                                                   const float* __restrict__ z, const float* __restrict__ z_table, int R,
-                                                  int S, float r2, int use_mask, int* __restrict__ num_nn,
+                                                  int S, float radius, int use_mask, int* __restrict__ num_nn,
                                                   uint8_t* __restrict__ mask, int* __restrict__ cand,
                                                   int* __restrict__ cand_count)
 {
+    const float r2 = radius * radius;
     // one atomic per 2048 samples: per-thread flags -> block scan -> single reservation
     __shared__ int wsum[4];
     __shared__ int block_base;
@@ -78,7 +79,8 @@ __global__ void __launch_bounds__(256) k_classify(const void* __restrict__ ws, c
             }
             const float zv = z ? (whole ? zq[e] : z[i]) : z_table[i % S];
             const float x = nf_madd_nofma(o0, d0, zv), y = nf_madd_nofma(o1, d1, zv), zz = nf_madd_nofma(o2, d2, zv);
-            if (!use_mask || nf_any_cell_in_reach(g, x, y, zz, r2)) flags |= 1u << (u * 4 + e);
+            if (!use_mask || (nf_near_points_aabb(g, x, y, zz, radius) && nf_any_cell_in_reach(g, x, y, zz, r2)))
+                flags |= 1u << (u * 4 + e);
         }
         if (whole) {
             *(int4*)(num_nn + i0) = make_int4(0, 0, 0, 0);
@@ -121,7 +123,7 @@ extern "C" int nf_render_classify(const void* ws, const float* rays, const float
     int total = R * S;
     int per_block = 256 * CL_GROUPS * 4;
     hipLaunchKernelGGL(k_classify, dim3((total + per_block - 1) / per_block), dim3(256), 0, (hipStream_t)stream, ws, rays,
-                       z, z_table, R, S, radius * radius, use_mask, num_nn, mask, cand, cand_count);
+                       z, z_table, R, S, radius, use_mask, num_nn, mask, cand, cand_count);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }

@@ -243,7 +243,9 @@ def main():
                                       "train_renderer.py step: 4 views x 1024 rays per rank, fwd+bwd+Adam",
                           "particles": int(P0.shape[0]), "image": "400x400", "N_samples": 64, "N_importance": 128,
                           "K": 20, "use_mask": True, "device_ray_chunk": args.chunk},
-               "particle_steps_per_sec": pstep * world, "particle_steps_note": "ParticleNet.forward alone, replicated per rank",
+               "particle_steps_per_sec": pstep,
+               "particle_steps_note": "ParticleNet.forward alone on one GPU; the 4913-particle step does not shard (replicas only: "
+                                      "every rank advances the same state), so this figure is per replica, not multiplied by N",
                "roofline": roofline, "fp16_mfma_path": fp16_extra, "train_step": train_extra}
         if os.environ.get("NF_BENCH_DEBUG"):
             res["host_marks_ms"] = [round(m * 1e3, 2) for m in host_marks]

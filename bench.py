@@ -46,7 +46,8 @@ def cpu_baseline(scene):
     every 40th ray of the 400^2 image (4000 rays, same hit ratio as the full frame) + 5 transition steps.
     torch intra-op threads are capped at 16: the oracle's ops are small and lose time beyond that."""
     from oracle import render_oracle as ro, trans_oracle as to
-    cores = min(os.cpu_count() or 1, 16)
+    from neurofluid_amd import effective_cpus
+    cores = min(effective_cpus(), 16)
     torch.set_num_threads(cores)
     rays = scene["rays"][::40].contiguous()
     t0 = time.time()
@@ -61,7 +62,7 @@ def cpu_baseline(scene):
     return {"value": rays.shape[0] / dt, "unit": "rays/s", "cores": cores, "kind": "port",
             "sample": f"oracle.render_forward on every 40th ray of the 400x400 frame ({rays.shape[0]} rays, {dt:.1f} s); "
                       f"oracle.particle_net_forward x{nsteps} on 4913 particles ({dts:.1f} s); "
-                      f"{cores} torch threads of {os.cpu_count()} host cores",
+                      f"{cores} torch threads ({os.cpu_count()} host cores visible, CPU budget {effective_cpus()})",
             "particle_steps_per_sec": scene["P"].shape[0] * nsteps / dts}
 
 

@@ -6,3 +6,7 @@ hand-written HIP kernels behind a C ABI (include/neurofluid_hip.h).  No CPU / Py
 importing works anywhere, running needs the built library and a gfx950 GPU.
 """
 __version__ = "0.1.0"
+
+from ._hostcpu import effective_cpus, limit_host_threads  # noqa: E402,F401
+
+limit_host_threads()

@@ -56,16 +56,23 @@ def _pass_backward(net, nerf, pb, rays_c, z, z_table, g_rgb, white_bg, particles
     check(lib.nf_composite_bwd(ptr(pb.rgbsigma), ptr(z), ptr(z_table), ptr(rays_c), ptr(g), ptr(pb.mask), pb.gate, R, S,
                                int(white_bg), ptr(scratch), ptr(d_rs), st), "nf_composite_bwd")
     packed_t = _pack_bwd(nerf, cx, cd, dev)
-    dpre = torch.empty(n, DPRE, dtype=torch.float32, device=dev)
+    # every row-sized temporary is allocated at the pass's bucketed capacity (ops._round_rows): the active-row count
+    # changes from step to step, and exact sizes make the caching allocator grow by a fresh block per step (and give
+    # the GEMM library a new problem size per step); a handful of capacity buckets are re-used instead
+    cap = ops._round_rows(n)
+    # e2e: the three dX GEMMs go through the vendor GEMM library, which pays ~80 ms the first time it meets a new
+    # problem size (solution lookup + lazy code-object load); power-of-two row counts keep that to a handful of sizes
+    cap_g = max(cap, 1 << max(n - 1, 1).bit_length()) if dparticles is not None else cap
+    dpre_full = torch.empty(cap_g, DPRE, dtype=torch.float32, device=dev)
+    dpre = dpre_full[:n]
     check(lib.nf_nerf_mlp_bwd(ptr(pb.packed), ptr(packed_t), cx, cd, ptr(pb.acts), ptr(pb.n_rows), n, ptr(pb.row_sample),
-                              ptr(pb.rgbsigma), ptr(d_rs), ptr(dpre), st), "nf_nerf_mlp_bwd")
-    A = pb.acts.view(-1, ACT)[:n]
-    X = ops.tiles_to_rows(pb.X, n, cx, cd).contiguous()
+                              ptr(pb.rgbsigma), ptr(d_rs), ptr(dpre_full), st), "nf_nerf_mlp_bwd")
+    X = ops.tiles_to_rows(pb.X, cap, cx, cd).contiguous()          # rows >= n are never read (n_rows bounds the kernels)
     # weight gradients: one batched fp32-MFMA launch for all 15 GEMMs of the net (nf_nerf_wgrad)
     nsl = 16
     blob = torch.empty(lib.nf_nerf_wgrad_floats(cx, cd), dtype=torch.float32, device=dev)
     wsp = torch.empty(lib.nf_nerf_wgrad_workspace_floats(cx, cd, nsl), dtype=torch.float32, device=dev)
-    check(lib.nf_nerf_wgrad(ptr(dpre), ptr(pb.acts), ptr(X), cx, cd, n, nsl, ptr(wsp), ptr(blob), st), "nf_nerf_wgrad")
+    check(lib.nf_nerf_wgrad(ptr(dpre_full), ptr(pb.acts), ptr(X), cx, cd, n, nsl, ptr(wsp), ptr(blob), st), "nf_nerf_wgrad")
     gw, o = [], 0
     for l in layers:
         k = l.weight.numel()
@@ -75,13 +82,15 @@ def _pass_backward(net, nerf, pb, rays_c, z, z_table, g_rgb, white_bg, particles
     colsum = dpre.sum(0)
     gb = [colsum[k * 256:(k + 1) * 256] for k in range(8)]
     gb += [colsum[8 * 256:9 * 256], colsum[9 * 256:9 * 256 + 128], colsum[2435:2436], colsum[2432:2435]]
-    Ddir = dpre[:, 9 * 256:9 * 256 + 128]
     if dparticles is not None:
-        # dL/dX = W^T dpre for the three layers that read the feature matrix (plain GEMMs), then HIP scatter
+        # dL/dX = W^T dpre for the three layers that read the feature matrix (plain GEMMs at the bucketed row count,
+        # tail rows zeroed), then HIP scatter
+        if cap_g > n:
+            dpre_full[n:].zero_()
         W1, W5, Wd = layers[0].weight.detach(), layers[4].weight.detach(), layers[9].weight.detach()
-        dX = torch.empty(n, cx + cd, dtype=torch.float32, device=dev)
-        dX[:, :cx] = dpre[:, 0:256] @ W1 + dpre[:, 4 * 256:5 * 256] @ W5[:, :cx]
-        dX[:, cx:] = Ddir @ Wd[:, 256:]
+        dX = torch.empty(cap_g, cx + cd, dtype=torch.float32, device=dev)
+        dX[:, :cx] = dpre_full[:, 0:256] @ W1 + dpre_full[:, 4 * 256:5 * 256] @ W5[:, :cx]
+        dX[:, cx:] = dpre_full[:, 9 * 256:9 * 256 + 128] @ Wd[:, 256:]
         check(lib.nf_render_features_bwd(ptr(particles), ptr(rays_c), ptr(z), ptr(z_table), R, S, float(net.raduis),
                                          net.num_neighbor, net.enc_flags, ptr(ro_c), int(ro_c.dim() == 2),
                                          ptr(pb.row_sample), ptr(pb.row_nbr), ptr(pb.n_rows), n, ptr(dX), ptr(dparticles),
@@ -103,6 +112,12 @@ class _RenderFn(torch.autograd.Function):
         ctx.keys = keys
         outs = tuple(res[k] for k in keys)
         ctx.mark_non_differentiable(*[o for k, o in zip(keys, outs) if not k.startswith("rgb")])
+        # The pass buffers live on ctx for backward.  They must NOT keep the tensors that are returned: an output holds
+        # its grad_fn (this ctx) through a C++ edge the Python GC cannot see, so ctx -> buffers -> output -> ctx would
+        # be an uncollectable cycle and every training step would leak its activations (~0.4 GB at 1024 rays).
+        for pb in (p0, p1):
+            if pb is not None:
+                pb.rgb = pb.depth = pb.opacity = pb.mask_sum = pb.weights = None
         return outs
 
     @staticmethod

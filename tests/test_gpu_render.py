@@ -436,3 +436,31 @@ def test_fp16_mfma_path(dev):
     p = ro.psnr(b["rgb0"].cpu(), a["rgb0"].cpu())
     assert p >= 40.0, p
     print("fp16 path: coarse PSNR vs fp32", p, " fine", ro.psnr(b["rgb1"].cpu(), a["rgb1"].cpu()))
+
+
+def test_training_steps_do_not_leak(dev):
+    """The autograd ctx keeps the pass buffers for backward; they must not form a cycle with the returned tensors
+    (an output -> grad_fn -> ctx -> buffers -> output cycle is invisible to the Python GC and leaks every step)."""
+    import gc
+    net = make_net(dev)
+    from oracle import render_oracle as ro
+    P = ro.watercube_particles().to(dev).requires_grad_(True)
+    c2w = ro.eval_camera()
+    rays = torch.cat(ro.get_rays(ro.get_ray_directions(400, 400, ro.camera_focal(400)), c2w), -1).view(-1, 6)[80000:80000 + 512].contiguous().to(dev)
+    roc = c2w[:, 3].to(dev)
+    opt = torch.optim.SGD(net.parameters(), lr=1e-4)
+    gc.disable()
+    try:
+        used = []
+        for it in range(6):
+            out = net(P, roc, rays, None, None)
+            loss = ((out["rgb0"] - 0.5) ** 2).mean() + ((out["rgb1"] - 0.5) ** 2).mean()
+            opt.zero_grad(); P.grad = None
+            loss.backward()
+            opt.step()
+            del out, loss
+            torch.cuda.synchronize()
+            used.append(torch.cuda.memory_allocated())
+        assert max(used[2:]) - min(used[2:]) < 8 * 2 ** 20, used
+    finally:
+        gc.enable()

@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_add(OutT* __restrict__ out,
 // small inputs (a particle cloud, a grid of a few thousand cells): one block walks the array with a carry —
 // one launch instead of three on the latency-bound transition step
 #define SCAN_ITEMS 8
-#define SCAN_ROUNDS 8     // SCAN_SINGLE_MAX = SCAN_BLOCK * SCAN_ITEMS * SCAN_ROUNDS
+#define SCAN_ROUNDS 4     // SCAN_SINGLE_MAX = SCAN_BLOCK * SCAN_ITEMS * SCAN_ROUNDS (register budget: 128 VGPRs at 1024 threads)
 template <typename OutT>
 __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_single(const int* __restrict__ in, OutT* __restrict__ out, int n)
 {
@@ -118,22 +118,23 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_single(const int* __restric
     OutT carry = 0;
 #pragma unroll
     for (int rd = 0; rd < SCAN_ROUNDS; ++rd) {
-        if (rd * SCAN_BLOCK * SCAN_ITEMS >= n) break;
-        const int i0 = (rd * SCAN_BLOCK + threadIdx.x) * SCAN_ITEMS;
-        OutT tsum = 0;
+        if (rd * SCAN_BLOCK * SCAN_ITEMS < n) {      // block-uniform; no `break`, so the loop unrolls and v[][] stays in registers
+            const int i0 = (rd * SCAN_BLOCK + threadIdx.x) * SCAN_ITEMS;
+            OutT tsum = 0;
 #pragma unroll
-        for (int u = 0; u < SCAN_ITEMS; ++u) tsum += (OutT)v[rd][u];
-        OutT tot;
-        OutT run = block_exclusive_scan<OutT>(tsum, lds, &tot) + carry;
+            for (int u = 0; u < SCAN_ITEMS; ++u) tsum += (OutT)v[rd][u];
+            OutT tot;
+            OutT run = block_exclusive_scan<OutT>(tsum, lds, &tot) + carry;
 #pragma unroll
-        for (int u = 0; u < SCAN_ITEMS; ++u) { if (i0 + u < n) out[i0 + u] = run; run += (OutT)v[rd][u]; }
-        carry += tot;
-        __syncthreads();
+            for (int u = 0; u < SCAN_ITEMS; ++u) { if (i0 + u < n) out[i0 + u] = run; run += (OutT)v[rd][u]; }
+            carry += tot;
+            __syncthreads();
+        }
     }
     if (threadIdx.x == 0) out[n] = carry;
 }
 
-#define SCAN_SINGLE_MAX 65536
+#define SCAN_SINGLE_MAX 32768
 
 template <typename OutT>
 static void launch_scan(const int* in, OutT* out, OutT* block_sums, int n, hipStream_t st)

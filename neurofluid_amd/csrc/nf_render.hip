@@ -235,10 +235,13 @@ __device__ __forceinline__ void emit_pe(FeatEmitter& em, const float (&x)[C])
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
         const float fr = (float)(1 << f);  // 2**linspace(0,N-1,N)  (models/nerf.py:17)
+        float sn[C], cs[C];      // one argument reduction per angle (sincosf == sinf / cosf of the same ocml code path)
 #pragma unroll
-        for (int c = 0; c < C; ++c) em.emit(sinf(fr * x[c]));
+        for (int c = 0; c < C; ++c) sincosf(fr * x[c], &sn[c], &cs[c]);
 #pragma unroll
-        for (int c = 0; c < C; ++c) em.emit(cosf(fr * x[c]));
+        for (int c = 0; c < C; ++c) em.emit(sn[c]);
+#pragma unroll
+        for (int c = 0; c < C; ++c) em.emit(cs[c]);
     }
 }
 

@@ -464,3 +464,60 @@ def test_training_steps_do_not_leak(dev):
         assert max(used[2:]) - min(used[2:]) < 8 * 2 ** 20, used
     finally:
         gc.enable()
+
+
+@pytest.mark.parametrize("side", [400, 800])
+def test_full_frame_size_independent_properties(dev, side):
+    """BASELINE sizes (400x400 = 160 000 rays; 800x800 = 640 000 rays, 123 M fine samples in ONE fused call) through
+    properties that do not need the oracle at that size: (1) chunk independence — a band of the image rendered alone
+    in the reference's 1024-ray chunks has the bits of the same rays inside the whole-frame call (every stage is
+    per-ray, the MFMA accumulation order of a row does not depend on its tile mates); (2) ranges: opacity in [0, 1],
+    rgb in [0, 1] (white background), mask counts <= S, num_nn <= K; (3) rays that miss the fluid AABB grown by the
+    radius are exactly white with zero mask; (4) a strided sample of rays agrees with the oracle within the fp32
+    tolerance; (5) the fp16-MFMA mode stays >= 45 dB from the fp32 frame."""
+    from oracle import render_oracle as ro
+    from neurofluid_amd import ray_utils
+    net = make_net(dev)
+    P = ro.watercube_particles().to(dev)
+    c2w = ro.eval_camera()
+    rays = ray_utils.get_rays_cpu(side, side, ro.camera_focal(side), c2w).view(-1, 6).to(dev)
+    roc = c2w[:, 3].to(dev)
+    with torch.no_grad():
+        full = net(P, roc, rays, None, None)
+    N = side * side
+    assert full["rgb1"].shape == (N, 3) and full["num_nn_1"].shape == (N, 192, 1)
+    # (2) ranges
+    for k in ("rgb0", "rgb1"):
+        assert float(full[k].min()) >= 0.0 and float(full[k].max()) <= 1.0 + 1e-6
+    for k in ("opacity0", "opacity1"):
+        assert float(full[k].min()) >= 0.0 and float(full[k].max()) <= 1.0 + 1e-6
+    assert float(full["mask_0"].max()) <= 64 and float(full["mask_1"].max()) <= 192
+    assert int(full["num_nn_1"].max()) <= 20 and int(full["num_nn_1"].min()) >= 0
+    assert float(full["mask_1"].sum()) > 0.01 * N             # the fluid is in view
+    # (3) rays that cannot come within the radius of any particle
+    lo, hi = P.min(0).values - 0.2251, P.max(0).values + 0.2251
+    o, d = rays[:, :3], rays[:, 3:]
+    t0, t1 = (lo - o) / d, (hi - o) / d
+    tn, tf = torch.minimum(t0, t1).max(1).values, torch.maximum(t0, t1).min(1).values
+    miss = (tn > tf) | (tf < 9.0) | (tn > 13.0)
+    assert float(miss.float().mean()) > 0.5
+    assert float(full["mask_1"][miss].sum()) == 0 and bool((full["rgb1"][miss] == 1.0).all())
+    assert int(full["num_nn_1"][miss].sum()) == 0
+    # (1) chunk independence on a band through the middle of the image
+    a = (side // 2 - 4) * side
+    band = slice(a, a + 8 * side)
+    with torch.no_grad():
+        parts = [net(P, roc, rays[band][i:i + 1024].contiguous(), None, None) for i in range(0, 8 * side, 1024)]
+    for k in ("rgb0", "rgb1", "depth1", "opacity1", "num_nn_0", "num_nn_1", "mask_0", "mask_1"):
+        assert torch.equal(torch.cat([p[k] for p in parts]), full[k][band]), k
+    # (4) strided sample vs the oracle
+    sel = torch.arange(a + side // 4, a + 8 * side, 8 * side // 24)[:24]
+    ref = ro.render_forward(ro.deterministic_nerf_state(), P.cpu(), roc.cpu(), rays[sel].cpu(), 9.0, 13.0)
+    assert torch.equal(full["mask_1"][sel].cpu(), ref["mask_1"]) and torch.equal(full["num_nn_1"][sel].cpu(), ref["num_nn_1"])
+    torch.testing.assert_close(full["rgb1"][sel].cpu(), ref["rgb1"], rtol=0, atol=RGB_ATOL)
+    # (5) fp16-MFMA mode
+    net16 = make_net(dev, dict(make_cfg(), mlp_dtype="fp16"))
+    with torch.no_grad():
+        h = net16(P, roc, rays, None, None)
+    assert torch.equal(h["mask_0"], full["mask_0"])      # (the fine samples follow the fp16 coarse weights: mask_1 may differ)
+    assert ro.psnr(h["rgb1"].cpu(), full["rgb1"].cpu()) >= 45.0

@@ -54,8 +54,10 @@ int nf_ball_query_firstk(const void* grid_ws, const float* pts /*the cloud the g
  * models/transmodel.py:92 (radius_search_ignore_query_points=True), results read at :136-138.
  * Two calls: counts -> row_splits (inclusive scan done on device), then fill.
  * nf_radius_count writes row_splits[0..nq] (int64, row_splits[nq] = nnz).
- * nf_radius_fill writes idx/dist2 for rows whose range fits in nnz_capacity (deterministic order:
- * cell-major, ascending point index inside a cell; Open3D's own order is hash-bucket order). */
+ * nf_radius_fill writes the entries whose position is below nnz_capacity (deterministic order:
+ * cell-major, ascending point index inside a cell; Open3D's own order is hash-bucket order); a caller
+ * that sizes the arrays by a bound instead of row_splits[nq] must compare the two and clamp
+ * row_splits before handing it to a consumer. */
 int nf_radius_count(const void* grid_ws, const float* queries, int nq, float radius, int ignore_same_pos,
                     int64_t* row_splits /*nq+1*/, void* scan_ws, size_t scan_ws_bytes, nf_stream_t stream);
 size_t nf_radius_scan_workspace_bytes(int nq);

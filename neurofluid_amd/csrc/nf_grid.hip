@@ -464,8 +464,7 @@ __global__ void __launch_bounds__(64 * RS_QPB) k_radius(const void* __restrict__
     const int cz = nf_cell_coord(qz, g.oz, g.icz, g.dz);
     int cnt = 0;
     const int64_t o = FILL ? row_splits[i] : 0;
-    const int64_t oe = FILL ? row_splits[i + 1] : 0;
-    if (FILL && oe > cap) return;
+    if (FILL && o >= cap) return;           // nothing of this row fits (the caller detects row_splits[nq] > capacity)
     const unsigned long long lt = (1ull << lane) - 1ull;
     for (int z = max(cz - 1, 0); z <= min(cz + 1, g.dz - 1); ++z)
         for (int y = max(cy - 1, 0); y <= min(cy + 1, g.dy - 1); ++y) {
@@ -485,8 +484,7 @@ __global__ void __launch_bounds__(64 * RS_QPB) k_radius(const void* __restrict__
                 const unsigned long long m = __ballot(hit);
                 if (FILL && hit) {
                     const int64_t w = o + cnt + __popcll(m & lt);
-                    idx[w] = pi;
-                    dist2[w] = d2;
+                    if (w < cap) { idx[w] = pi; dist2[w] = d2; }
                 }
                 cnt += __popcll(m);
             }

@@ -166,3 +166,35 @@ def test_fluid_errors_vs_kdtree(dev):
     fe = FluidErrors()
     bad = torch.full((4, 3), float('nan'), device=dev)
     assert fe.cal_errors(bad, torch.zeros(4, 3, device=dev), 0) is None and fe.errors == {}
+
+
+def test_step_graph_replay(dev):
+    """HIP-graph replay of the inference step: same bits as the eager step over a rollout (the captured kernels are
+    the same, only the CSR buffers are sized by a capacity); capacity overflow poisons the outputs and raises."""
+    from oracle import trans_oracle as to
+    pn, _ = make_pn(dev)
+    pn2, _ = make_pn(dev)
+    pn2.enable_step_graph()
+    box, bn = [t.to(dev) for t in to.watercube_box()]
+    from oracle import render_oracle as ro
+    p = ro.watercube_particles().to(dev)
+    v = torch.zeros_like(p)
+    pa, va, pb, vb = p, v, p, v
+    with torch.no_grad():
+        for it in range(12):
+            pa, va, na = pn(pa, va, box, bn)
+            pb, vb, nb = pn2(pb, vb, box, bn)
+            assert torch.equal(pa, pb) and torch.equal(va, vb) and torch.equal(na, nb), it
+    # a different particle count re-captures
+    with torch.no_grad():
+        q, w, _ = pn2(p[:1000].contiguous(), v[:1000].contiguous(), box, bn)
+        q0, w0, _ = pn(p[:1000].contiguous(), v[:1000].contiguous(), box, bn)
+    assert torch.equal(q, q0) and torch.equal(w, w0)
+    # capacity overflow: NaN outputs, RuntimeError at the periodic check
+    pn3, _ = make_pn(dev)
+    pn3.enable_step_graph(max_fluid_neighbors=8, check_every=2)
+    with torch.no_grad():
+        a, b, _ = pn3(p, v, box, bn)
+        assert bool(torch.isnan(a).all())
+        with pytest.raises(RuntimeError, match="exceed the capacity"):
+            pn3(p, v, box, bn)

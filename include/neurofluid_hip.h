@@ -39,8 +39,12 @@ const char* nf_last_error(void);
  * ------------------------------------------------------------------------------------------ */
 #define NF_GRID_MAX_DIM 128
 size_t nf_grid_workspace_bytes(int n_points, float cell, const float bbox[6]);
+/* with_firstk_lists != 0 also builds what the first-K-by-index search and the renderer's classify
+ * stage need (per-cell particle AABBs, the dilated index-sorted lists and their chunk boxes);
+ * 0 builds the cell lists only — enough for nf_radius_count / nf_radius_fill (the transition
+ * model rebuilds its grid every step and never runs a first-K query on it). */
 int nf_grid_build(const float* pts /*n*3*/, int n_points, float cell, const float bbox[6],
-                  void* grid_ws, size_t grid_ws_bytes, nf_stream_t stream);
+                  void* grid_ws, size_t grid_ws_bytes, int with_firstk_lists, nf_stream_t stream);
 
 /* pytorch3d.ops.ball_query(p1, p2, radius, K) for one cloud — reference call site
  * models/renderer.py:116-118.  First K points IN INDEX ORDER with sum_d (q_d-p_d)^2 < radius^2

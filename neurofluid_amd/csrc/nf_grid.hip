@@ -361,7 +361,7 @@ __global__ void k_grid_dil_box(NfGridHeader h, void* ws)
 }
 
 extern "C" int nf_grid_build(const float* pts, int n, float cell, const float bbox[6], void* ws, size_t ws_bytes,
-                             nf_stream_t stream)
+                             int with_firstk_lists, nf_stream_t stream)
 {
     NfGridHeader h;
     size_t tot = 0;
@@ -380,6 +380,10 @@ extern "C" int nf_grid_build(const float* pts, int n, float cell, const float bb
     hipLaunchKernelGGL(k_grid_zero_fill, dim3(gc), dim3(B), 0, st, h, ws);
     hipLaunchKernelGGL(k_grid_scatter, dim3(gp), dim3(B), 0, st, h, ws);
     hipLaunchKernelGGL(k_grid_rank, dim3(gp), dim3(B), 0, st, h, ws, pts);
+    if (!with_firstk_lists) {       // radius search only: the cell lists are complete here
+        NF_CHECK_LAUNCH();
+        return NF_OK;
+    }
     hipLaunchKernelGGL(k_grid_dilate, dim3(gc), dim3(B), 0, st, h, ws);
     launch_scan<int>((const int*)((char*)ws + h.off_cell_dil), (int*)((char*)ws + h.off_dil_start), fill + h.n_cells + 8,
                      h.n_cells, st);

@@ -32,17 +32,21 @@ def _require_cuda(*ts):
 class Grid:
     """Uniform cell grid over a point cloud; `ws` is the opaque device workspace of nf_grid_build."""
 
-    def __init__(self, points, cell, bbox, ws):
-        self.points, self.cell, self.bbox, self.ws = points, float(cell), bbox, ws
+    def __init__(self, points, cell, bbox, ws, firstk=True):
+        self.points, self.cell, self.bbox, self.ws, self.firstk = points, float(cell), bbox, ws, firstk
+
+    def need_firstk(self):
+        if not self.firstk:
+            raise RuntimeError("this grid was built for radius search only (build_grid(..., firstk=False))")
 
     @property
     def n(self):
         return self.points.shape[0]
 
 
-def build_grid(points, cell, bbox=None):
+def build_grid(points, cell, bbox=None, firstk=True):
     """points (N,3) fp32 contiguous.  bbox=(xmin,ymin,zmin,xmax,ymax,zmax); if None it is computed
-    from the points (one device->host sync)."""
+    from the points (one device->host sync).  firstk=False builds the cell lists only (fixed-radius search)."""
     _require_cuda(points)
     lib = _lib.load()
     pts = points.detach().contiguous().float()
@@ -57,8 +61,9 @@ def build_grid(points, cell, bbox=None):
     if nbytes == 0:
         raise RuntimeError("nf_grid_workspace_bytes: bad grid parameters")
     ws = torch.empty(nbytes, dtype=torch.uint8, device=pts.device)
-    check(lib.nf_grid_build(ptr(pts), pts.shape[0], float(cell), bb, ptr(ws), nbytes, _lib.stream()), "nf_grid_build")
-    return Grid(pts, cell, tuple(bbox), ws)
+    check(lib.nf_grid_build(ptr(pts), pts.shape[0], float(cell), bb, ptr(ws), nbytes, int(bool(firstk)), _lib.stream()),
+          "nf_grid_build")
+    return Grid(pts, cell, tuple(bbox), ws, bool(firstk))
 
 
 def ball_query(p1, p2, radius, K, return_nn=True):
@@ -85,6 +90,7 @@ def grid_ball_query(grid, queries, radius, K):
     """Single-cloud variant on a prebuilt grid: queries (Q,3)."""
     if radius > grid.cell * (1 + 1e-6):
         raise RuntimeError("query radius exceeds the grid cell edge")
+    grid.need_firstk()
     lib = _lib.load()
     q = queries.detach().contiguous().float()
     Q = q.shape[0]
@@ -240,6 +246,7 @@ def render_pass(grid, particles, rays, z, z_table, S, radius, K, enc_flags, use_
     n_samp = R * S
     if radius > grid.cell * (1 + 1e-6):
         raise RuntimeError("search radius exceeds the grid cell edge")
+    grid.need_firstk()
     b = PassBuffers()
     b.R, b.S = R, S
     if ws is not None and save_acts:

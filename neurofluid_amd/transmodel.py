@@ -113,6 +113,11 @@ class ParticleNet(nn.Module):
         self.num_fluid_neighbors = None
         self._graph_cfg, self._graph, self._nnz_seen = None, None, None
 
+    @property
+    def pos_correction(self):
+        y3 = getattr(self, "_y3", None)
+        return None if y3 is None else y3 * (1.0 / 128)
+
     # ------------------------------------------------------------------
     def integrate_pos_vel(self, pos, vel):
         lib = _lib.load()
@@ -133,7 +138,7 @@ class ParticleNet(nn.Module):
     def _box_grid(self, box):
         key = (box.data_ptr(), box._version, box.shape[0])
         if self._box_cache[0] != key:
-            self._box_cache = (key, ops.build_grid(box, 0.5 * float(self.filter_extent)))
+            self._box_cache = (key, ops.build_grid(box, 0.5 * float(self.filter_extent), firstk=False))
         return self._box_cache[1]
 
     def update_pos_vel(self, pos, pos_new, y3):
@@ -224,7 +229,7 @@ class ParticleNet(nn.Module):
         pos_new, vel_new, fluid_feats = self.integrate_pos_vel(pos, vel)
         # B2: one fluid->fluid and one box->fluid search per step (device-side scans), one sync for nnz
         bbox = self._scene_bbox(box)
-        fgrid = ops.build_grid(pos_new, radius, bbox)
+        fgrid = ops.build_grid(pos_new, radius, bbox, firstk=False)
         bgrid = self._box_grid(box)
         f_rs = ops.radius_row_splits(fgrid, pos_new, radius, True)
         b_rs = ops.radius_row_splits(bgrid, pos_new, radius, True)
@@ -256,7 +261,7 @@ class ParticleNet(nn.Module):
             ans.append(cconv_layer(prev, conv.kernel, conv.bias, dense.weight, dense.bias, f_rs, f_idx, f_pw, f_pc,
                                    relu=True, residual=res))
         self.num_fluid_neighbors = (f_rs[1:] - f_rs[:-1]).to(torch.float32)   # reduce_subarrays_sum(ones) (:135-138)
-        self.pos_correction = ans[-1] * (1.0 / 128)
+        self._y3 = ans[-1]                       # pos_correction (models/transmodel.py:147) is derived on access
         pos_c, vel_c = self.update_pos_vel(pos, pos_new, ans[-1])
         aux = dict(ans=ans, f=(f_rs, f_idx, f_pw, f_pc), b=(b_rs, b_idx, b_pw, b_pc), pos_new=pos_new, vel_new=vel_new,
                    fluid_feats=fluid_feats) if keep else None

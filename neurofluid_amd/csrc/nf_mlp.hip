@@ -145,10 +145,19 @@ __device__ __forceinline__ void step4(const f32x4 w0, const float bv, f32x16 (&a
 }
 
 // K-steps whose B operand comes from the feature matrix: group q = 8 features = 4 steps.
+// STASH: the feature groups are copied into this wave's private LDS slice as they are consumed (layer 1), so that
+// the skip layer reads them back from LDS instead of fetching X from HBM a second time (the tile has left the L2
+// by then: without the stash the kernel moved 1.8x its algorithmic bytes).
+// X is streamed exactly once: a non-temporal load keeps it from evicting the 2.7 MB weight set that all waves of
+// the XCD re-read from the L2 every tile.
+template <bool NT>
+__device__ __forceinline__ f32x4 load_x(const f32x4* p) { return NT ? __builtin_nontemporal_load(p) : *p; }
+
+template <bool STASH>
 __device__ __forceinline__ void kloop_x8(const f32x4* __restrict__ wp /* + lane */, const f32x4* __restrict__ xp /* + lane */,
-                                         int nq, f32x16 (&acc)[8])
+                                         int nq, f32x16 (&acc)[8], f32x4* __restrict__ stash /* LDS + lane */)
 {
-    f32x4 xv = xp[0];
+    f32x4 xv = load_x<STASH>(xp);
     f32x4 w[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) w[i] = wp[i * 64];
@@ -157,10 +166,11 @@ __device__ __forceinline__ void kloop_x8(const f32x4* __restrict__ wp /* + lane 
 #pragma unroll
         for (int i = 0; i < 8; ++i) wn[i] = w[i];
         if (q + 1 < nq) {
-            xn = xp[(q + 1) * 64];
+            xn = load_x<STASH>(xp + (q + 1) * 64);
 #pragma unroll
             for (int i = 0; i < 8; ++i) wn[i] = wp[(q + 1) * 512 + i * 64];
         }
+        if (STASH) stash[q * 64] = xv;
         step8(w[0], w[1], xv[0], acc);
         step8(w[2], w[3], xv[1], acc);
         step8(w[4], w[5], xv[2], acc);
@@ -183,7 +193,7 @@ __device__ __forceinline__ void kloop_x8(const f32x4* __restrict__ wp /* + lane 
 __device__ __forceinline__ void kloop_x4(const f32x4* __restrict__ wp, const f32x4* __restrict__ xp, int nq,
                                          f32x16 (&acc)[4])
 {
-    f32x4 xv = xp[0];
+    f32x4 xv = load_x<true>(xp);
     f32x4 w[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) w[i] = wp[i * 64];
@@ -192,7 +202,7 @@ __device__ __forceinline__ void kloop_x4(const f32x4* __restrict__ wp, const f32
 #pragma unroll
         for (int i = 0; i < 4; ++i) wn[i] = w[i];
         if (q + 1 < nq) {
-            xn = xp[(q + 1) * 64];
+            xn = load_x<true>(xp + (q + 1) * 64);
 #pragma unroll
             for (int i = 0; i < 4; ++i) wn[i] = wp[(q + 1) * 256 + i * 64];
         }
@@ -311,11 +321,11 @@ __device__ __forceinline__ void kloop_src(const f32x4* __restrict__ p /* + lane 
 
 template <bool SAVE>
 __device__ __forceinline__ void mlp_layer(const NfMlpLayout& L, const f32x4* __restrict__ P4, int l, int lane, int h,
-                                          const f32x4* __restrict__ xt, const f32x16 (&src)[8], f32x16 (&dst)[8],
-                                          float* __restrict__ arow, bool row_ok)
+                                          const f32x4* __restrict__ xs /* LDS stash + lane */, const f32x16 (&src)[8],
+                                          f32x16 (&dst)[8], float* __restrict__ arow, bool row_ok)
 {
     bias_step8(P4 + (L.off_bstep[l] >> 2) + lane, dst);
-    if (L.off_x[l] >= 0) kloop_x8(P4 + (L.off_x[l] >> 2) + lane, xt, L.qx, dst);
+    if (L.off_x[l] >= 0) kloop_x8<false>(P4 + (L.off_x[l] >> 2) + lane, xs, L.qx, dst, nullptr);
     // the ReLU'd src IS the saved activation h_l (slot l-1)
     kloop_src<true, 8, SAVE>(P4 + (L.off_h[l] >> 2) + lane, src, dst, SAVE ? arow + (l - 1) * 256 : nullptr, h, row_ok);
 }
@@ -326,11 +336,13 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(NfMlpLayout L, const float* __r
                                                   const int* __restrict__ row_sample, float4* __restrict__ rgbsigma,
                                                   float* __restrict__ acts)
 {
+    extern __shared__ f32x4 xstash[];      // [4 waves][qx][64 lanes] x 16 B: each wave's own copy of its tile's position groups
     const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
     const int gwave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
     const int nrows = min(*n_rows, max_rows);
     const int ntiles = (nrows + 31) >> 5;
     const int Q = L.qx + L.qd;
+    f32x4* xs = xstash + (threadIdx.x >> 6) * (L.qx * 64) + lane;
 
     for (int tile = gwave; tile < ntiles; tile += nwaves) {
         const float* __restrict__ pk = packed + opaque_zero();
@@ -343,14 +355,14 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(NfMlpLayout L, const float* __r
 
         // layer 0 = xyz_encoding_1: bias step + feature-matrix K-steps
         bias_step8(P4 + (L.off_bstep[0] >> 2) + lane, accA);
-        kloop_x8(P4 + (L.off_x[0] >> 2) + lane, xt, L.qx, accA);
+        kloop_x8<true>(P4 + (L.off_x[0] >> 2) + lane, xt, L.qx, accA, xs);
 #pragma unroll 1
         for (int l = 1; l < 9; l += 2) {
-            mlp_layer<SAVE>(L, P4, l, lane, h, xt, accA, accB, arow, row_ok);
+            mlp_layer<SAVE>(L, P4, l, lane, h, xs, accA, accB, arow, row_ok);
             if (l + 1 == 8) {  // sigma head reads h8 = relu(accB) before xyz_encoding_final consumes it
                 // (computed again inside the next layer's loop; 256 VALU ops per tile)
             }
-            mlp_layer<SAVE>(L, P4, l + 1, lane, h, xt, accB, accA, arow, row_ok);
+            mlp_layer<SAVE>(L, P4, l + 1, lane, h, xs, accB, accA, arow, row_ok);
         }
         // after the loop: accA = xyz_encoding_final output (no activation), accB = pre-activation of layer 8 (h8 = relu)
         float sigma;
@@ -410,11 +422,19 @@ extern "C" int nf_nerf_mlp_fwd(const float* packed, int cx, int cd, const float*
     int blocks = (tiles + 3) / 4;
     if (blocks > 256) blocks = 256;  // one 4-wave workgroup per CU, persistent over tiles
     hipStream_t st = (hipStream_t)stream;
+    const size_t lds = (size_t)4 * L.qx * 64 * sizeof(f32x4);      // the X stash: 100 KB at qx = 25 (one workgroup per CU)
+    NF_CHECK_ARG(lds <= 160 * 1024, "feature row too wide for the LDS stash");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)k_mlp_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)k_mlp_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
     if (acts)
-        hipLaunchKernelGGL(k_mlp_fwd<true>, dim3(blocks), dim3(256), 0, st, L, packed, X, n_rows, max_rows, row_sample,
+        hipLaunchKernelGGL(k_mlp_fwd<true>, dim3(blocks), dim3(256), lds, st, L, packed, X, n_rows, max_rows, row_sample,
                            (float4*)rgbsigma, acts);
     else
-        hipLaunchKernelGGL(k_mlp_fwd<false>, dim3(blocks), dim3(256), 0, st, L, packed, X, n_rows, max_rows, row_sample,
+        hipLaunchKernelGGL(k_mlp_fwd<false>, dim3(blocks), dim3(256), lds, st, L, packed, X, n_rows, max_rows, row_sample,
                            (float4*)rgbsigma, acts);
     NF_CHECK_LAUNCH();
     return NF_OK;

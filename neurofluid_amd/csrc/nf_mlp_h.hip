@@ -23,6 +23,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define H_SLOT_U4 512        // one slot = 8 KB = 512 x 16 B
 #define H_RING_SLOTS 12
 #define H_CHUNK_SLOTS 4
+#define H_XSTASH_STEPS 13
 #define H_STAGE (H_CHUNK_SLOTS * 2)     // u32x4 per lane staged per chunk by each of the 4 waves
 
 // ------------------------------------------------------------------------------------------------
@@ -291,20 +292,35 @@ __device__ __forceinline__ h8 h_operand(const f32x16 (&src)[8], int k)
                        src[b][8 * t + 5], src[b][8 * t + 6], src[b][8 * t + 7]);
 }
 
-// X K-steps t0 .. t1-1 (features of groups q = 2t, 2t+1), then `tail` as the operand of the step that follows
-template <int NB>
-__device__ __forceinline__ void h_xsteps(HCtx& c, const f32x4* __restrict__ xt /* + lane */, int t0, int t1, f32x16 (&acc)[NB])
+// X K-steps t0 .. t1-1 (features of groups q = 2t, 2t+1).  X is streamed once (non-temporal loads).
+// MODE 0: operands from global X.  MODE 1: same, and every packed fp16 operand is also stashed in this wave's LDS
+// slice.  MODE 2: operands come back from the stash (the skip layer): no second trip to HBM, no second conversion.
+template <int NB, int MODE>
+__device__ __forceinline__ void h_xsteps(HCtx& c, const f32x4* __restrict__ xt /* + lane */, int t0, int t1, f32x16 (&acc)[NB],
+                                         u32x4* __restrict__ stash /* LDS + lane */)
 {
-    f32x4 x0 = xt[(2 * t0) * 64], x1 = xt[(2 * t0 + 1) * 64];
+    if (MODE == 2) {
+        h8 bc = __builtin_bit_cast(h8, stash[t0 * 64]);
+#pragma unroll
+        for (int t = t0; t < t1; ++t) {
+            h8 bn = bc;
+            if (t + 1 < t1) bn = __builtin_bit_cast(h8, stash[(t + 1) * 64]);
+            h_step<NB>(c, bc, acc, false);
+            bc = bn;
+        }
+        return;
+    }
+    f32x4 x0 = __builtin_nontemporal_load(xt + (2 * t0) * 64), x1 = __builtin_nontemporal_load(xt + (2 * t0 + 1) * 64);
     h8 bc = pack8<false>(x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]);
-    if (t0 + 1 < t1) { x0 = xt[(2 * t0 + 2) * 64]; x1 = xt[(2 * t0 + 3) * 64]; }
+    if (t0 + 1 < t1) { x0 = __builtin_nontemporal_load(xt + (2 * t0 + 2) * 64); x1 = __builtin_nontemporal_load(xt + (2 * t0 + 3) * 64); }
 #pragma unroll
     for (int t = t0; t < t1; ++t) {
         h8 bn = bc;
         if (t + 1 < t1) {
             bn = pack8<false>(x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]);
-            if (t + 2 < t1) { x0 = xt[(2 * t + 4) * 64]; x1 = xt[(2 * t + 5) * 64]; }
+            if (t + 2 < t1) { x0 = __builtin_nontemporal_load(xt + (2 * t + 4) * 64); x1 = __builtin_nontemporal_load(xt + (2 * t + 5) * 64); }
         }
+        if (MODE == 1) stash[t * 64] = __builtin_bit_cast(u32x4, bc);
         h_step<NB>(c, bc, acc, false);
         bc = bn;
     }
@@ -324,11 +340,11 @@ __device__ __forceinline__ void h_hsteps(HCtx& c, const f32x16 (&src)[8], f32x16
     }
 }
 
-__device__ __forceinline__ void h_layer(HCtx& c, int l, const f32x4* __restrict__ xt, const f32x16 (&src)[8], f32x16 (&dst)[8])
+__device__ __forceinline__ void h_layer(HCtx& c, int l, u32x4* __restrict__ stash, const f32x16 (&src)[8], f32x16 (&dst)[8])
 {
     const int h = c.lane >> 5;
     h_step<8>(c, bias_b(h), dst, true);
-    if (l == 4) h_xsteps<8>(c, xt, 0, 13, dst);
+    if (l == 4) h_xsteps<8, 2>(c, nullptr, 0, 13, dst, stash);
     h_hsteps<true, 8>(c, src, dst);
 }
 
@@ -343,6 +359,8 @@ __global__ void __launch_bounds__(256) k_mlp_fwd_h(NfMlpLayout L, const float* _
     const int ntiles = (nrows + 31) >> 5;
     const int ngroups = (ntiles + 3) >> 2;
     const int Q = L.qx + L.qd;
+    // behind the ring: [4 waves][13 K-steps][64 lanes] x 16 B of packed fp16 X operands (layer 1 -> skip layer)
+    u32x4* stash = ring + H_RING_SLOTS * H_SLOT_U4 + wave * (H_XSTASH_STEPS * 64) + lane;
     HCtx c;
     c.stream = stream_h; c.ring = ring; c.slot = 0; c.half = 0;
     c.nchunks = nslots / H_CHUNK_SLOTS; c.chunk_next = 0; c.lane = lane; c.wave = wave;
@@ -363,12 +381,12 @@ __global__ void __launch_bounds__(256) k_mlp_fwd_h(NfMlpLayout L, const float* _
         c.slot = 0; c.half = 0; c.a_ok = false;     // every tile consumes exactly nslots (a multiple of the ring)
         // layer 0
         h_step<8>(c, bias_b(h), accA, true);
-        h_xsteps<8>(c, xt, 0, 13, accA);
+        h_xsteps<8, 1>(c, xt, 0, 13, accA, stash);
         // written out (not a loop): with the slot sequence static, every boundary / prefetch decision folds
-        h_layer(c, 1, xt, accA, accB); h_layer(c, 2, xt, accB, accA);
-        h_layer(c, 3, xt, accA, accB); h_layer(c, 4, xt, accB, accA);
-        h_layer(c, 5, xt, accA, accB); h_layer(c, 6, xt, accB, accA);
-        h_layer(c, 7, xt, accA, accB); h_layer(c, 8, xt, accB, accA);
+        h_layer(c, 1, stash, accA, accB); h_layer(c, 2, stash, accB, accA);
+        h_layer(c, 3, stash, accA, accB); h_layer(c, 4, stash, accB, accA);
+        h_layer(c, 5, stash, accA, accB); h_layer(c, 6, stash, accB, accA);
+        h_layer(c, 7, stash, accA, accB); h_layer(c, 8, stash, accB, accA);
         // sigma from h8 = relu(accB) in fp32
         float sigma;
         {
@@ -386,7 +404,7 @@ __global__ void __launch_bounds__(256) k_mlp_fwd_h(NfMlpLayout L, const float* _
         // view branch
         f32x16 hd[4];
         h_step<4>(c, bias_b(h), hd, true);
-        h_xsteps<4>(c, xt, 12, 16, hd);
+        h_xsteps<4, 0>(c, xt, 12, 16, hd, nullptr);
         h_hsteps<false, 4>(c, accA, hd);
         // the stream is padded to a multiple of the ring: walk the padding slots (uniform)
         if (c.half) { c.slot++; c.half = 0; }
@@ -426,7 +444,7 @@ extern "C" int nf_nerf_mlp_fwd_h(const float* packed, const void* stream_h, int 
     int tiles = (max_rows + 31) / 32;
     int blocks = (tiles + 3) / 4;
     if (blocks > 256) blocks = 256;
-    const size_t lds = (size_t)H_RING_SLOTS * H_SLOT_U4 * 16;
+    const size_t lds = (size_t)H_RING_SLOTS * H_SLOT_U4 * 16 + (size_t)4 * H_XSTASH_STEPS * 64 * 16;
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute((const void*)k_mlp_fwd_h, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -80,3 +80,43 @@ def test_synthetic_scene_matches_the_oracle_definitions():
     d = ro.get_ray_directions(8, 8, sy.camera_focal(8))
     o, dd = ro.get_rays(d, sy.eval_camera())
     assert torch.equal(sc["rays"], torch.cat([o, dd], -1).view(-1, 6))
+
+
+def test_row_capacity_buckets_and_scratch_arena():
+    """Row-sized buffers are allocated at bucketed capacities (<= 12.5 % slack, monotone) and the inference scratch
+    arena only ever grows: a drifting active-row count must not reach the device allocator every frame."""
+    from neurofluid_amd import ops
+    prev = 0
+    for n in [0, 1, 31, 8192, 8193, 60000, 100001, 1570000, 2950000, 3000000]:
+        c = ops._round_rows(n)
+        assert c >= max(n, 1) and c % 8192 == 0 and c >= prev
+        if n > 65536:
+            assert c <= n * 1.125 + 8192
+        prev = c
+    assert len({ops._round_rows(n) for n in range(2_900_000, 3_000_000, 1000)}) <= 2
+    ws = ops.Workspace()
+    dev = torch.device("cpu")
+    a = ws.get("x", 1000, torch.float32, dev)
+    p0 = ws._buf["x"].data_ptr()
+    b = ws.get("x", 1100, torch.float32, dev)          # within the 25 % headroom: same storage
+    assert ws._buf["x"].data_ptr() == p0 and b.shape == (1100,) and a.dtype == torch.float32
+    ws.get("x", 5000, torch.float32, dev)               # grows
+    assert ws._buf["x"].numel() >= 5000 * 4
+    big = ws._buf["x"].numel()
+    ws.get("x", 10, torch.int32, dev)                   # never shrinks, dtype views share the bytes
+    assert ws._buf["x"].numel() == big
+
+
+def test_host_cpu_budget():
+    """The intra-op pool is capped to the CPU budget of the container (cgroup quota / affinity), not to the number
+    of cores the node shows."""
+    import os
+    import neurofluid_amd
+    n = neurofluid_amd.effective_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    assert torch.get_num_threads() <= max(16, n)
+    os.environ["NF_HOST_THREADS"] = "2"
+    try:
+        assert neurofluid_amd.limit_host_threads() <= max(2, torch.get_num_threads())
+    finally:
+        del os.environ["NF_HOST_THREADS"]

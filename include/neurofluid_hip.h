@@ -116,7 +116,9 @@ int nf_render_features(const float* particles /*Np*3*/, const float* rays, const
                        int R, int S, float radius, int K, int enc_flags,
                        const float* ro /*3, or R*3 when ro_per_ray (several views batched in one call)*/, int ro_per_ray,
                        const int32_t* row_sample, const int32_t* row_nbr, const int32_t* n_rows, int max_rows,
-                       float* X, nf_stream_t stream);
+                       void* X, int x_fp16, nf_stream_t stream);
+/* x_fp16 != 0 (operand of nf_nerf_mlp_fwd_h): Xh[tile][t][lane] x 16 B = the lane's 8 halves of K-step t, i.e.
+ * features 16t+4h+e (e < 4) and 16t+8+4h+e, round-to-nearest-even — half the bytes of the fp32 layout. */
 /* A12 (feature part, e2e training): dparticles[j] += dL/d(particle j) given dX (row-major, n_rows x (cx+cd)) =
  * dL/d(feature row).  Gradients flow only through the gathered neighbour positions (models/renderer.py:96-109,
  * :163-169); float atomics (order-dependent in the last bits).  dparticles (Np*3) must be zero-initialised. */
@@ -146,7 +148,8 @@ int nf_nerf_mlp_fwd(const float* packed, int cx, int cd, const float* X, const i
  * Default encodings only (198 + 54 features). */
 size_t nf_nerf_packed_h_bytes(void);
 int nf_nerf_pack_h(const nf_nerf_params_t* params /*[host]*/, int cx, int cd, void* stream_h, nf_stream_t stream);
-int nf_nerf_mlp_fwd_h(const float* packed, const void* stream_h, int cx, int cd, const float* X,
+int nf_nerf_mlp_fwd_h(const float* packed, const void* stream_h, int cx, int cd,
+                      const void* Xh /* fp16 operand layout: nf_render_features(..., x_fp16 = 1) */,
                       const int32_t* n_rows, int max_rows, const int32_t* row_sample, float* rgbsigma,
                       nf_stream_t stream);
 

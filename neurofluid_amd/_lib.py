@@ -32,7 +32,7 @@ PROTOTYPES = {
     "nf_render_search": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_int, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nf_render_features": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_int, c_void_p, c_int,
-                                   c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+                                   c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "nf_render_features_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_int, c_void_p, c_int,
                                        c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "nf_render_feature_dims": (c_int, [c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int),

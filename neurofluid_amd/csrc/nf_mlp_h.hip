@@ -9,7 +9,7 @@
 // blocks x 64 lanes x 16 B), ring of 8 slots (64 KB), refilled 4 slots at a time by all waves (global -> VGPR ->
 // ds_write_b128, one barrier per 4 K-steps), consumed with lane-linear conflict-free ds_read_b128.
 // Biases enter as one K-step with a hi/lo fp16 split (bias = hi + lo to ~22 bits), heads (sigma, rgb) stay fp32
-// VALU from the fp32 accumulators.  Inputs X stay fp32 in HBM and are converted in registers.
+// VALU from the fp32 accumulators.  The feature stage writes X directly as fp16 B operands (Xh[tile][K-step][lane] x 16 B).
 #include "nf_mlp_layout.h"
 #include <math.h>
 
@@ -292,36 +292,21 @@ __device__ __forceinline__ h8 h_operand(const f32x16 (&src)[8], int k)
                        src[b][8 * t + 5], src[b][8 * t + 6], src[b][8 * t + 7]);
 }
 
-// X K-steps t0 .. t1-1 (features of groups q = 2t, 2t+1).  X is streamed once (non-temporal loads).
-// MODE 0: operands from global X.  MODE 1: same, and every packed fp16 operand is also stashed in this wave's LDS
-// slice.  MODE 2: operands come back from the stash (the skip layer): no second trip to HBM, no second conversion.
+// X K-steps t0 .. t1-1.  Xh[tile][t][lane] already IS the lane's fp16 B operand of K-step t (nf_render_features with
+// x_fp16 = 1), streamed once with non-temporal loads.
+// MODE 0: operands from global Xh.  MODE 1: same, and every operand is also stashed in this wave's LDS slice.
+// MODE 2: operands come back from the stash (the skip layer): no second trip to HBM.
 template <int NB, int MODE>
-__device__ __forceinline__ void h_xsteps(HCtx& c, const f32x4* __restrict__ xt /* + lane */, int t0, int t1, f32x16 (&acc)[NB],
+__device__ __forceinline__ void h_xsteps(HCtx& c, const u32x4* __restrict__ xt /* + lane */, int t0, int t1, f32x16 (&acc)[NB],
                                          u32x4* __restrict__ stash /* LDS + lane */)
 {
-    if (MODE == 2) {
-        h8 bc = __builtin_bit_cast(h8, stash[t0 * 64]);
-#pragma unroll
-        for (int t = t0; t < t1; ++t) {
-            h8 bn = bc;
-            if (t + 1 < t1) bn = __builtin_bit_cast(h8, stash[(t + 1) * 64]);
-            h_step<NB>(c, bc, acc, false);
-            bc = bn;
-        }
-        return;
-    }
-    f32x4 x0 = __builtin_nontemporal_load(xt + (2 * t0) * 64), x1 = __builtin_nontemporal_load(xt + (2 * t0 + 1) * 64);
-    h8 bc = pack8<false>(x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]);
-    if (t0 + 1 < t1) { x0 = __builtin_nontemporal_load(xt + (2 * t0 + 2) * 64); x1 = __builtin_nontemporal_load(xt + (2 * t0 + 3) * 64); }
+    u32x4 bc = (MODE == 2) ? stash[t0 * 64] : __builtin_nontemporal_load(xt + t0 * 64);
 #pragma unroll
     for (int t = t0; t < t1; ++t) {
-        h8 bn = bc;
-        if (t + 1 < t1) {
-            bn = pack8<false>(x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]);
-            if (t + 2 < t1) { x0 = __builtin_nontemporal_load(xt + (2 * t + 4) * 64); x1 = __builtin_nontemporal_load(xt + (2 * t + 5) * 64); }
-        }
-        if (MODE == 1) stash[t * 64] = __builtin_bit_cast(u32x4, bc);
-        h_step<NB>(c, bc, acc, false);
+        u32x4 bn = bc;
+        if (t + 1 < t1) bn = (MODE == 2) ? stash[(t + 1) * 64] : __builtin_nontemporal_load(xt + (t + 1) * 64);
+        if (MODE == 1) stash[t * 64] = bc;
+        h_step<NB>(c, __builtin_bit_cast(h8, bc), acc, false);
         bc = bn;
     }
 }
@@ -350,7 +335,7 @@ __device__ __forceinline__ void h_layer(HCtx& c, int l, u32x4* __restrict__ stas
 
 __global__ void __launch_bounds__(256) k_mlp_fwd_h(NfMlpLayout L, const float* __restrict__ packed,
                                                    const u32x4* __restrict__ stream_h, int nslots,
-                                                   const float* __restrict__ X, const int* __restrict__ n_rows, int max_rows,
+                                                   const u32x4* __restrict__ Xh, const int* __restrict__ n_rows, int max_rows,
                                                    const int* __restrict__ row_sample, float4* __restrict__ rgbsigma)
 {
     extern __shared__ u32x4 ring[];   // H_RING_SLOTS * 8 KB
@@ -373,7 +358,7 @@ __global__ void __launch_bounds__(256) k_mlp_fwd_h(NfMlpLayout L, const float* _
         int tile = tg * 4 + wave;
         if (tile >= ntiles) tile = ntiles - 1;      // idle waves recompute the last tile (keeps the barriers matched)
         const bool owner = (tg * 4 + wave) < ntiles;
-        const f32x4* xt = (const f32x4*)X + (size_t)tile * Q * 64 + lane;
+        const u32x4* xt = Xh + (size_t)tile * (Q / 2) * 64 + lane;
         const int row = tile * 32 + j;
         const bool row_ok = owner && row < nrows;
         const float* __restrict__ pk = packed + opaque_zero();
@@ -431,7 +416,7 @@ __global__ void __launch_bounds__(256) k_mlp_fwd_h(NfMlpLayout L, const float* _
     }
 }
 
-extern "C" int nf_nerf_mlp_fwd_h(const float* packed, const void* stream_h, int cx, int cd, const float* X,
+extern "C" int nf_nerf_mlp_fwd_h(const float* packed, const void* stream_h, int cx, int cd, const void* X,
                                  const int32_t* n_rows, int max_rows, const int32_t* row_sample, float* rgbsigma,
                                  nf_stream_t stream)
 {
@@ -451,7 +436,7 @@ extern "C" int nf_nerf_mlp_fwd_h(const float* packed, const void* stream_h, int 
         attr_set = true;
     }
     hipLaunchKernelGGL(k_mlp_fwd_h, dim3(blocks), dim3(256), lds, (hipStream_t)stream, L, packed, (const u32x4*)stream_h,
-                       S.nslots, X, n_rows, max_rows, row_sample, (float4*)rgbsigma);
+                       S.nslots, (const u32x4*)X, n_rows, max_rows, row_sample, (float4*)rgbsigma);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }

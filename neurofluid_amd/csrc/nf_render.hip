@@ -8,6 +8,7 @@
 // feature matrix X (1 KB per ACTIVE row only, thanks to the compaction licensed by use_mask).
 #include "nf_common.h"
 #include <math.h>
+#include <type_traits>
 
 // wave-aggregated append: returns this lane's slot (valid only where pred)
 __device__ __forceinline__ int wave_append(bool pred, int* counter)
@@ -227,8 +228,34 @@ struct FeatEmitter {
     }
 };
 
-template <int C, int NF>
-__device__ __forceinline__ void emit_pe(FeatEmitter& em, const float (&x)[C])
+// fp16 variant for the fp16-MFMA MLP: Xh[tile][t][lane] = 16 B = the lane's 8 halves of K-step t, i.e. features
+// 16t + 4h + e (e < 4) and 16t + 8 + 4h + e — the h8 B operand itself (RNE conversion, identical to converting the
+// fp32 layout inside the kernel), at half the bytes.
+typedef _Float16 nf_h8 __attribute__((ext_vector_type(8)));
+struct FeatEmitterH {
+    nf_h8* base;   // &Xh[tile][0][j]  (lane h=0); h=1 is +32, K-step t is +64
+    _Float16 f[16];
+    int n;
+    __device__ __forceinline__ void emit(float v)
+    {
+        f[n & 15] = (_Float16)v;
+        ++n;
+        if ((n & 15) == 0) {
+            const int t = (n >> 4) - 1;
+            nf_h8 lo = {f[0], f[1], f[2], f[3], f[8], f[9], f[10], f[11]};
+            nf_h8 hi = {f[4], f[5], f[6], f[7], f[12], f[13], f[14], f[15]};
+            base[t * 64] = lo;
+            base[t * 64 + 32] = hi;
+        }
+    }
+    __device__ __forceinline__ void pad_to(int total)
+    {
+        while (n < total) emit(0.f);
+    }
+};
+
+template <int C, int NF, typename EM>
+__device__ __forceinline__ void emit_pe(EM& em, const float (&x)[C])
 {
 #pragma unroll
     for (int c = 0; c < C; ++c) em.emit(x[c]);
@@ -245,12 +272,12 @@ __device__ __forceinline__ void emit_pe(FeatEmitter& em, const float (&x)[C])
     }
 }
 
-template <int FLAGS>
+template <int FLAGS, bool HALF>
 __global__ void __launch_bounds__(128) k_features(const float* __restrict__ particles, const float* __restrict__ rays,
                                                   const float* __restrict__ z, const float* __restrict__ z_table, int S,
                                                   float radius, int K, const float* __restrict__ ro_base, int ro_stride,
                                                   const int* __restrict__ row_sample, const int* __restrict__ row_nbr,
-                                                  const int* __restrict__ n_rows, int max_rows, float* __restrict__ X)
+                                                  const int* __restrict__ n_rows, int max_rows, void* __restrict__ X)
 {
     constexpr int CX = 63 + ((FLAGS & 1) ? 9 : 0) + ((FLAGS & 2) ? 63 : 0) + ((FLAGS & 4) ? 63 : 0);
     constexpr int CD = 27 + ((FLAGS & 8) ? 27 : 0);
@@ -299,8 +326,9 @@ __global__ void __launch_bounds__(128) k_features(const float* __restrict__ part
         }
         // --- emit in the reference's column order (models/renderer.py:141-175, cat at :230)
         int tile = row >> 5, jj = row & 31;
-        FeatEmitter em;
-        em.base = (float4*)X + (size_t)tile * Q * 64 + jj;
+        typename std::conditional<HALF, FeatEmitterH, FeatEmitter>::type em;
+        if constexpr (HALF) em.base = (nf_h8*)X + (size_t)tile * (Q / 2) * 64 + jj;
+        else em.base = (float4*)X + (size_t)tile * Q * 64 + jj;
         em.n = 0;
         emit_pe<3, 10>(em, px);
         if (FLAGS & 1) { float d1[1] = {sw}; emit_pe<1, 4>(em, d1); }
@@ -322,18 +350,27 @@ __global__ void __launch_bounds__(128) k_features(const float* __restrict__ part
 extern "C" int nf_render_features(const float* particles, const float* rays, const float* z, const float* z_table, int R,
                                   int S, float radius, int K, int enc_flags, const float* ro, int ro_per_ray,
                                   const int32_t* row_sample, const int32_t* row_nbr, const int32_t* n_rows, int max_rows,
-                                  float* X, nf_stream_t stream)
+                                  void* X, int x_fp16, nf_stream_t stream)
 {
     NF_CHECK_ARG(particles && rays && (z || z_table) && ro && row_sample && row_nbr && n_rows && X, "null pointer");
     NF_CHECK_ARG(enc_flags >= 0 && enc_flags < 16, "bad enc_flags");
+    if (x_fp16) {
+        int qx = 0, qd = 0;
+        nf_render_feature_dims(enc_flags, nullptr, nullptr, &qx, &qd);
+        NF_CHECK_ARG(((qx + qd) & 1) == 0, "the fp16 operand layout needs an even number of 8-feature groups");
+    }
     if (max_rows <= 0) return NF_OK;
     int blocks = (max_rows + 127) / 128;
     if (blocks > 4096) blocks = 4096;
     hipStream_t st = (hipStream_t)stream;
 #define NF_FEAT_CASE(F)                                                                                              \
     case F:                                                                                                          \
-        hipLaunchKernelGGL(k_features<F>, dim3(blocks), dim3(128), 0, st, particles, rays, z, z_table, S, radius, K, ro, \
-                           ro_per_ray ? 3 : 0, row_sample, row_nbr, n_rows, max_rows, X);                            \
+        if (x_fp16)                                                                                                  \
+            hipLaunchKernelGGL((k_features<F, true>), dim3(blocks), dim3(128), 0, st, particles, rays, z, z_table, S, radius, \
+                               K, ro, ro_per_ray ? 3 : 0, row_sample, row_nbr, n_rows, max_rows, X);                 \
+        else                                                                                                         \
+            hipLaunchKernelGGL((k_features<F, false>), dim3(blocks), dim3(128), 0, st, particles, rays, z, z_table, S, radius, \
+                               K, ro, ro_per_ray ? 3 : 0, row_sample, row_nbr, n_rows, max_rows, X);                 \
         break;
     switch (enc_flags) {
         NF_FEAT_CASE(0) NF_FEAT_CASE(1) NF_FEAT_CASE(2) NF_FEAT_CASE(3) NF_FEAT_CASE(4) NF_FEAT_CASE(5) NF_FEAT_CASE(6)

@@ -286,10 +286,11 @@ def render_pass(grid, particles, rays, z, z_table, S, radius, K, enc_flags, use_
     b.n_active = max_rows
     tiles = (max_rows + 31) // 32
     rows_alloc = _round_rows(max_rows)
-    b.X = scratch("X", rows_alloc // 32 * (qx + qd) * 256, torch.float32)
+    x16 = packed_h is not None       # the fp16-MFMA MLP takes its operand as fp16: half the bytes written and read
+    b.X = scratch("X", rows_alloc // 32 * (qx + qd) * (128 if x16 else 256), torch.float32)
     check(lib.nf_render_features(ptr(particles), ptr(rays), ptr(z), ptr(z_table), R, S, float(radius), K, enc_flags,
                                  ptr(ro), int(ro.dim() == 2), ptr(b.row_sample), ptr(b.row_nbr), ptr(b.n_rows), max_rows,
-                                 ptr(b.X), st),
+                                 ptr(b.X), int(x16), st),
           "nf_render_features")
     b.acts = torch.empty(rows_alloc * 2432, dtype=torch.float32, device=dev) if save_acts else None
     if PROFILE is not None:
@@ -365,7 +366,10 @@ def mlp_rows(packed, cx, cd, x, save_acts=False, packed_h=None):
     out = torch.zeros(n, 4, dtype=torch.float32, device=x.device)
     acts = torch.empty(n * 2432, dtype=torch.float32, device=x.device) if save_acts else None
     if packed_h is not None:
-        check(lib.nf_nerf_mlp_fwd_h(ptr(packed), ptr(packed_h), cx, cd, ptr(X), ptr(n_rows), n, ptr(row_sample), ptr(out),
+        # fp32 operand layout [tile][q][lane][4] -> fp16 layout [tile][t][lane][8]: K-step t = groups 2t, 2t+1
+        T = X.numel() // ((qx_ := (cx + 7) // 8) + (qd_ := (cd + 7) // 8)) // 256
+        Xh = X.view(T, (qx_ + qd_) // 2, 2, 64, 4).permute(0, 1, 3, 2, 4).reshape(-1).to(torch.float16).contiguous()
+        check(lib.nf_nerf_mlp_fwd_h(ptr(packed), ptr(packed_h), cx, cd, ptr(Xh), ptr(n_rows), n, ptr(row_sample), ptr(out),
                                     _lib.stream()), "nf_nerf_mlp_fwd_h")
         return out
     check(lib.nf_nerf_mlp_fwd(ptr(packed), cx, cd, ptr(X), ptr(n_rows), n, ptr(row_sample), ptr(out), ptr(acts),
@@ -400,6 +404,6 @@ def debug_features(particles, rays, near, far, S, radius, K, enc_flags, ro):
     X = torch.empty(max((nr + 31) // 32, 1) * (qx + qd) * 256, device=dev)
     check(lib.nf_render_features(ptr(grid.points), ptr(rays), None, ptr(z_table), R, S, float(radius), K, enc_flags,
                                  ptr(ro.contiguous().float()), 0, ptr(row_sample), ptr(row_nbr), ptr(counters[1:2]), nr,
-                                 ptr(X), st))
+                                 ptr(X), 0, st))
     return dict(features=tiles_to_rows(X, nr, cx, cd), row_sample=row_sample[:nr], num_nn=num_nn,
                 row_nbr=row_nbr[:nr * K].view(nr, K))

@@ -132,7 +132,16 @@ extern "C" int nf_render_classify(const void* ws, const float* rays, const float
 // ------------------------------------------------------------------------------------------------
 // search + compaction of active rows
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(BQ_BLOCK) k_search(const void* __restrict__ ws, const float* __restrict__ rays,
+// A quarter-wave (16 lanes) per candidate.  The candidate's dilated list is walked in the reference's scan order,
+// but 16 entries at a time: first the 16 lanes test the AABBs of the next 16 chunks at once, then every chunk that
+// can reach the query has its 16 entries tested by the 16 lanes in one step; hits are placed by the prefix popcount
+// of the group's ballot bits, so they land in list order and the first K of them are exactly the K lowest indices.
+// (Measured on the 400^2 frame: on par with a thread per candidate, 0.46 vs 0.48 ms per launch — 93 % of the
+// candidates are full rows that meet their K-th hit within the first chunks.)
+#define SG_LANES 16
+#define SG_BLOCK 256
+#define SG_WAVES (SG_BLOCK / 64)
+__global__ void __launch_bounds__(SG_BLOCK) k_search(const void* __restrict__ ws, const float* __restrict__ rays,
                                                      const float* __restrict__ z, const float* __restrict__ z_table,
                                                      int S, float r2, int K, int use_mask,
                                                      const int* __restrict__ cand, const int* __restrict__ cand_count,
@@ -140,32 +149,90 @@ __global__ void __launch_bounds__(BQ_BLOCK) k_search(const void* __restrict__ ws
                                                      int* __restrict__ row_sample, int* __restrict__ row_nbr,
                                                      int* __restrict__ n_rows)
 {
-    extern __shared__ int lds[];
-    int* li = lds;
+    // a wave takes 64 consecutive candidates per round, 4 at a time; their neighbour lists wait in LDS until the round
+    // is over, so that the active rows of the round are reserved with ONE atomic (as with a thread per candidate)
+    __shared__ int s_list[SG_WAVES][64][33];         // [slot][k], pitch 33: conflict-free for both access patterns
+    __shared__ int s_cnt[SG_WAVES][64];
+    __shared__ int s_full[SG_WAVES][64];
     NfGridView g = nf_grid_view(ws);
     const int ncand = *cand_count;
-    const int tid = threadIdx.x;
-    for (int base = blockIdx.x * BQ_BLOCK; base < ncand; base += gridDim.x * BQ_BLOCK) {
-        int c = base + tid;
+    const int lane = threadIdx.x & 63, l = lane & (SG_LANES - 1), gsh = lane & ~(SG_LANES - 1), grp = lane >> 4;
+    const int wv = threadIdx.x >> 6;
+    const unsigned lt = (1u << l) - 1u;
+    for (int base = (blockIdx.x * SG_WAVES + wv) * 64; base < ncand; base += gridDim.x * SG_WAVES * 64) {
+        for (int step = 0; step < 16; ++step) {
+            const int slot = step * 4 + grp;
+            const int c = base + slot;
+            int cnt = 0, nz = 0, sample = 0;
+            if (c < ncand) {
+                sample = cand[c];
+                float x, y, zz, zv;
+                sample_xyz(rays, z, z_table, S, sample, x, y, zz, zv);
+                const int cx = nf_cell_coord(x, g.ox, g.icx, g.dx);
+                const int cy = nf_cell_coord(y, g.oy, g.icy, g.dy);
+                const int cz = nf_cell_coord(zz, g.oz, g.icz, g.dz);
+                const int cell = (cz * g.dy + cy) * g.dx + cx;
+                const int s = g.dil_start[cell], e = g.dil_start[cell + 1];
+                const int cb0 = s & ~(NF_DIL_CHUNK - 1);
+                const int nchunks = (e - cb0 + NF_DIL_CHUNK - 1) / NF_DIL_CHUNK;
+                for (int cbase = 0; cbase < nchunks && cnt < K; cbase += SG_LANES) {
+                    // 16 chunk boxes at once
+                    const int ch = cbase + l;
+                    bool pass = false;
+                    if (ch < nchunks) {
+                        const float4 blo = g.dil_box[2 * (cb0 / NF_DIL_CHUNK + ch)], bhi = g.dil_box[2 * (cb0 / NF_DIL_CHUNK + ch) + 1];
+                        const float bb[6] = {blo.x, blo.y, blo.z, bhi.x, bhi.y, bhi.z};
+                        pass = nf_box_dist2(bb, x, y, zz) < r2;
+                    }
+                    unsigned m = (unsigned)(__ballot(pass) >> gsh) & 0xffffu;
+                    while (m && cnt < K) {
+                        const int bit = __ffs(m) - 1;
+                        m &= m - 1u;
+                        const int t = cb0 + (cbase + bit) * NF_DIL_CHUNK + l;      // NF_DIL_CHUNK == SG_LANES: one entry per lane
+                        bool hit = false, nonzero = false;
+                        int pi = 0;
+                        if (t >= s && t < e) {
+                            const float4 p = g.dil_pos[t];
+                            const float d2 = nf_dist2(x, y, zz, p.x, p.y, p.z);
+                            hit = d2 < r2;
+                            nonzero = d2 != 0.f;
+                            pi = __float_as_int(p.w);
+                        }
+                        const unsigned hm = (unsigned)(__ballot(hit) >> gsh) & 0xffffu;
+                        const int pos = cnt + __popc(hm & lt);
+                        const bool take = hit && pos < K;
+                        if (take) s_list[wv][slot][pos] = pi;
+                        nz += __popc((unsigned)(__ballot(take && nonzero) >> gsh) & 0xffffu);   // nn_mask = dists.ne(0)
+                        cnt += __popc(hm);
+                    }
+                }
+                if (cnt > K) cnt = K;
+                if (l == 0) {
+                    const bool full = (nz == K);
+                    num_nn[sample] = nz;
+                    mask[sample] = full ? 1 : 0;
+                    s_cnt[wv][slot] = cnt;
+                    s_full[wv][slot] = full ? 1 : 0;
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        // ---- end of the round: lane i owns slot i
+        const int c = base + lane;
         bool active = false;
-        int sample = 0, cnt = 0;
+        int cnt = 0, sample = 0;
         if (c < ncand) {
             sample = cand[c];
-            float x, y, zz, zv;
-            sample_xyz(rays, z, z_table, S, sample, x, y, zz, zv);
-            unsigned nzmask;
-            cnt = firstk_search(g, x, y, zz, r2, K, li, tid, nzmask);
-            int nz = __popc(nzmask);  // nn_mask = dists.ne(0)
-            bool full = (nz == K);
-            num_nn[sample] = nz;
-            mask[sample] = full ? 1 : 0;
-            active = full || !use_mask;
+            cnt = s_cnt[wv][lane];
+            active = s_full[wv][lane] || !use_mask;
         }
-        int row = wave_append(active, n_rows);
+        const int row = wave_append(active, n_rows);
         if (active) {
             row_sample[row] = sample;
-            for (int k = 0; k < K; ++k) row_nbr[(size_t)row * K + k] = k < cnt ? li[k * BQ_BLOCK + tid] : -1;
+            for (int k = 0; k < K; ++k) row_nbr[(size_t)row * K + k] = k < cnt ? s_list[wv][lane][k] : -1;
         }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -178,11 +245,11 @@ extern "C" int nf_render_search(const void* ws, const float* rays, const float* 
                  "null pointer");
     NF_CHECK_ARG(K >= 1 && K <= 32 && radius > 0.f, "bad K/radius");
     if (R == 0) return NF_OK;
+    static_assert(NF_DIL_CHUNK == SG_LANES, "one list entry per lane of a group");
     long total = (long)R * S;
-    int blocks = (int)((total + BQ_BLOCK - 1) / BQ_BLOCK);
-    if (blocks > 8192) blocks = 8192;
-    size_t lds = (size_t)BQ_LDS_INTS(K) * 4;
-    hipLaunchKernelGGL(k_search, dim3(blocks), dim3(BQ_BLOCK), lds, (hipStream_t)stream, ws, rays, z, z_table, S,
+    long want = (total + SG_BLOCK - 1) / SG_BLOCK;
+    int blocks = (int)(want < 8192 ? want : 8192);          // grid-stride over the candidates (count known on device only)
+    hipLaunchKernelGGL(k_search, dim3(blocks), dim3(SG_BLOCK), 0, (hipStream_t)stream, ws, rays, z, z_table, S,
                        radius * radius, K, use_mask, cand, cand_count, num_nn, mask, row_sample, row_nbr, n_rows);
     NF_CHECK_LAUNCH();
     return NF_OK;

@@ -83,7 +83,12 @@ def main():
     from neurofluid_amd.render_loop import render_image
     import torch.distributed as dist
 
-    rank, world, local = nfdist.init_from_env()
+    # dev switch: NF_BENCH_SINGLE_DEVICE=1 runs an N-rank job on ONE GPU over gloo, to exercise the multi-rank control
+    # flow (sharding, collectives, timing protocol) where only one device exists; it is not a performance mode
+    single_dev = os.environ.get("NF_BENCH_SINGLE_DEVICE") == "1"
+    rank, world, local = nfdist.init_from_env("gloo" if single_dev else None)
+    if single_dev:
+        local = 0
     if args.chunk <= 0:
         args.chunk = 400 * 400      # weak scaling: chunk k = view k -> rank k mod N, identical load on every rank
     assert world == args.gpus or (args.gpus == 1 and world == 1), f"--gpus {args.gpus} but WORLD_SIZE={world}"

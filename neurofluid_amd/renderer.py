@@ -2,8 +2,8 @@
 
 Same constructor, same ``forward`` signature and result keys, same parameter names; the body is the
 fused HIP pipeline of ops.render_pass (classify -> first-K search -> features -> fp32-MFMA MLP ->
-composite) + importance sampling.  Autograd is provided by ``_RenderFunction`` (backward kernels in
-nf_mlp_bwd.hip / nf_render_bwd) — see neurofluid_amd/autograd.py.
+composite) + importance sampling.  Autograd is provided by ``autograd_bwd._RenderFn`` (k_composite_bwd, k_mlp_bwd,
+k_wgrad, k_features_bwd) — see neurofluid_amd/autograd.py / autograd_bwd.py.
 """
 import torch
 from torch import nn

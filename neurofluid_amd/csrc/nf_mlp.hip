@@ -747,6 +747,18 @@ static NfWgradPlan wgrad_plan(int cx, int cd)
 extern "C" size_t nf_nerf_wgrad_floats(int cx, int cd) { return (size_t)wgrad_plan(cx, cd).total; }
 
 #define WG_KS 32
+// one quad (4 consecutive columns) of a row-slab operand: a 16-B load when the quad is whole and aligned
+__device__ __forceinline__ float4 wg_load4(const float* __restrict__ rowp, int col, int ncols, bool vec_ok)
+{
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col + 3 < ncols && vec_ok) return *(const float4*)(rowp + col);
+    if (col < ncols) v.x = rowp[col];
+    if (col + 1 < ncols) v.y = rowp[col + 1];
+    if (col + 2 < ncols) v.z = rowp[col + 2];
+    if (col + 3 < ncols) v.w = rowp[col + 3];
+    return v;
+}
+
 __global__ void __launch_bounds__(256) k_wgrad(NfWgradPlan P, const float* __restrict__ dpre, const float* __restrict__ acts,
                                                const float* __restrict__ xrow, int ld_x, int n_rows, int rows_per_slice,
                                                float* __restrict__ partial)
@@ -765,6 +777,10 @@ __global__ void __launch_bounds__(256) k_wgrad(NfWgradPlan P, const float* __res
     const int r0 = blockIdx.y * rows_per_slice, r1 = min(n_rows, r0 + rows_per_slice);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    // 16-B loads need the first column of the tile and the row pitch to be multiples of 4 floats (all big GEMMs are;
+    // the sigma / rgb rows and the dir-feature block of xrow start at odd columns and take the scalar path)
+    const bool va = ((G.a_col + m0) & 3) == 0, vb = ((G.b_col + n0) & 3) == 0 && (ldb & 3) == 0;
+    const int ma = G.M - m0, nb = G.N - n0;       // live columns of this tile
     f32x16 acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -772,20 +788,30 @@ __global__ void __launch_bounds__(256) k_wgrad(NfWgradPlan P, const float* __res
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    for (int k0 = r0; k0 < r1; k0 += WG_KS) {
-        // slabs: 32 rows x 128 columns each, coalesced along the columns
-        for (int e = tid; e < WG_KS * 128; e += 256) {
-            int k = e >> 7, c = e & 127;
-            int row = k0 + k;
-            float av = 0.f, bv = 0.f;
+
+    float4 ra[4], rb[4];
+    auto load_slab = [&](int k0) {          // 32 rows x 32 quads per operand, 4 quads per thread, coalesced along the columns
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + 256 * u, k = e >> 5, cq = (e & 31) * 4;
+            const int row = k0 + k;
+            ra[u] = rb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (row < r1) {
-                if (m0 + c < G.M) av = dpre[(size_t)row * NF_DPRE_STRIDE + G.a_col + m0 + c];
-                if (n0 + c < G.N) bv = Bsrc[(size_t)row * ldb + G.b_col + n0 + c];
+                ra[u] = wg_load4(dpre + (size_t)row * NF_DPRE_STRIDE + G.a_col + m0, cq, ma, va);
+                rb[u] = wg_load4(Bsrc + (size_t)row * ldb + G.b_col + n0, cq, nb, vb);
             }
-            As[k][c] = av;
-            Bs[k][c] = bv;
+        }
+    };
+    load_slab(r0);
+    for (int k0 = r0; k0 < r1; k0 += WG_KS) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + 256 * u, k = e >> 5, cq = (e & 31) * 4;
+            *(float4*)&As[k][cq] = ra[u];
+            *(float4*)&Bs[k][cq] = rb[u];
         }
         __syncthreads();
+        if (k0 + WG_KS < r1) load_slab(k0 + WG_KS);      // next slab in flight behind the MFMAs
 #pragma unroll
         for (int kk = 0; kk < WG_KS; kk += 2) {
             int kr = kk + (lane >> 5), c = lane & 31;

@@ -18,7 +18,7 @@ for p in net.parameters(): p.requires_grad_(True)
 opt = torch.optim.Adam(net.parameters(), lr=5e-4)
 rng = np.random.RandomState(10)
 mode = sys.argv[1] if len(sys.argv) > 1 else "thread"
-sampler = None if mode == "inline" else ts.PixelSampler(rng, 4, 1024, lambda s: 160000, 1000, use_process=False)
+sampler = None if mode == "inline" else ts.PixelSampler(rng, 4, 1024, lambda s: 160000, 1000)
 marks = {}
 def mark(name, t0):
     marks[name] = marks.get(name, 0.0) + time.perf_counter() - t0

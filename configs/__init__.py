@@ -29,8 +29,13 @@ class Node(dict):
         self[k] = v
 
     def merge_from_file(self, path):
+        """`_include: other.yaml` (relative to the including file) is merged first, then the file's own keys."""
         with open(path) as f:
-            self.merge(yaml.safe_load(f) or {})
+            d = yaml.safe_load(f) or {}
+        inc = d.pop('_include', None)
+        for name in ([inc] if isinstance(inc, str) else (inc or [])):
+            self.merge_from_file(os.path.join(os.path.dirname(os.path.abspath(path)), name))
+        self.merge(d)
 
     def merge(self, d):
         for k, v in d.items():

@@ -77,6 +77,30 @@ def test_ball_query_edge_cases(dev):
     assert np.array_equal(i[0].cpu().numpy(), i_ref) and np.array_equal(d[0].cpu().numpy(), d_ref)
 
 
+def test_ball_query_large_sparse_grid(dev):
+    """A grid with far more cells than points (> 32 768 cells: the multi-launch scan path; 128-cell dimension clamp)
+    and a larger cloud (60 000 points): still exactly pytorch3d's first-K-by-index sets."""
+    from neurofluid_amd import ops
+    from oracle import neighbors
+    rng = np.random.RandomState(11)
+    for n, span, radius, K in [(20000, 8.0, 0.1, 20), (60000, 30.0, 0.12, 8)]:
+        p2 = rng.uniform(0, span, size=(n, 3)).astype(np.float32)
+        p2[: n // 4] = (p2[: n // 4] * 0.02 + span / 2).astype(np.float32)      # a dense clump: long dilated lists
+        q = np.concatenate([p2[rng.choice(n, 1500, replace=False)] + rng.normal(0, radius / 3, (1500, 3)).astype(np.float32),
+                            rng.uniform(-1, span + 1, size=(500, 3)).astype(np.float32)]).astype(np.float32)
+        d_ref, i_ref, nn_ref = neighbors.ball_query_firstk(q, p2, radius, K)
+        d, i, nn = ops.ball_query(T(q, dev)[None], T(p2, dev)[None], radius, K)
+        assert np.array_equal(i[0].cpu().numpy(), i_ref)
+        assert np.array_equal(d[0].cpu().numpy(), d_ref)
+        # the same cloud through the fixed-radius search (cell lists only): exact row sizes and neighbour sets
+        idx_ref, rs_ref, _ = neighbors.fixed_radius_search(p2, q, radius, ignore_query_point=False)
+        idx, rs, _ = ops.fixed_radius_search(T(p2, dev), T(q, dev), radius, ignore_query_point=False)
+        assert np.array_equal(rs.cpu().numpy(), rs_ref)
+        idx = idx.cpu().numpy()
+        for r in range(0, q.shape[0], 97):
+            assert sorted(idx[rs_ref[r]:rs_ref[r + 1]].tolist()) == sorted(idx_ref[rs_ref[r]:rs_ref[r + 1]].tolist())
+
+
 def test_fixed_radius_search(dev):
     from neurofluid_amd import ops
     from oracle import neighbors, render_oracle as ro, trans_oracle as to

@@ -142,6 +142,17 @@ int nf_nerf_pack(const nf_nerf_params_t* params /*[host]*/, int cx, int cd, floa
 int nf_nerf_mlp_fwd(const float* packed, int cx, int cd, const float* X, const int32_t* n_rows, int max_rows,
                     const int32_t* row_sample, float* rgbsigma, float* acts /*or NULL*/, nf_stream_t stream);
 
+/* A6, same fp32 arithmetic with the weight stream shared by the 4 waves of a workgroup through an LDS ring
+ * (inference; default encodings 198 + 54 only — nf_nerf_pack_stream reports anything else as an error and the
+ * caller keeps nf_nerf_mlp_fwd).  wstream = nf_nerf_pack_stream(packed): the K-steps of `packed` re-ordered into the
+ * order of consumption, nf_nerf_stream_floats(cx, cd) floats.  Results differ from nf_nerf_mlp_fwd only by the
+ * position of the bias in the fp32 summation order (last instead of first K-step). */
+size_t nf_nerf_stream_floats(int cx, int cd);
+int nf_nerf_pack_stream(const float* packed, int cx, int cd, float* wstream, nf_stream_t stream);
+int nf_nerf_mlp_fwd_l(const float* packed, const float* wstream, int cx, int cd, const float* X,
+                      const int32_t* n_rows, int max_rows, const int32_t* row_sample, float* rgbsigma,
+                      nf_stream_t stream);
+
 /* A6, fp16-MFMA variant (BASELINE config 5: "fp16 MFMA path"): v_mfma_f32_32x32x16_f16 with fp32 accumulation; the
  * weight stream is shared by the 4 waves of a workgroup through an LDS ring; sigma/rgb heads and biases (hi+lo
  * split) keep fp32 accuracy.  Inference only; `packed` (fp32 blob of nf_nerf_pack) supplies the heads.

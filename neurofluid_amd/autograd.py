@@ -23,7 +23,9 @@ def _run_passes(net, particles, ro, rays, white_bg, fine, save_acts):
     pk0 = net.packed_weights(net.nerf_coarse)
     p0 = ops.render_pass(grid, pts, rays_c, None, z_table, net.N_samples, net.raduis, net.num_neighbor, net.enc_flags,
                          net.use_mask, ro_c, pk0, net.in_channels_xyz, net.in_channels_dir, white_bg, save_acts,
-                         packed_h=net.packed_weights_h(net.nerf_coarse) if use_h else None, ws=ws, need_weights=fine)
+                         packed_h=net.packed_weights_h(net.nerf_coarse) if use_h else None, ws=ws, need_weights=fine,
+                         wstream=None if (use_h or save_acts) else ops.pack_nerf_stream(pk0, net.in_channels_xyz,
+                                                                                          net.in_channels_dir))
     p0.packed = pk0
     p1 = None
     if fine:
@@ -32,7 +34,9 @@ def _run_passes(net, particles, ro, rays, white_bg, fine, save_acts):
         p1 = ops.render_pass(grid, pts, rays_c, z1, None, net.N_samples + net.N_importance, net.raduis, net.num_neighbor,
                              net.enc_flags, net.use_mask, ro_c, pk1, net.in_channels_xyz, net.in_channels_dir, white_bg,
                              save_acts, packed_h=net.packed_weights_h(net.nerf_fine) if use_h else None, ws=ws,
-                             need_weights=False)
+                             need_weights=False,
+                             wstream=None if (use_h or save_acts) else ops.pack_nerf_stream(pk1, net.in_channels_xyz,
+                                                                                              net.in_channels_dir))
         p1.z = z1
         p1.packed = pk1
     return p0, p1, rays_c, ro_c, grid

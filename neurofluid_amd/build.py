@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libneurofluid_hip.so")
-SOURCES = ["nf_grid.hip", "nf_render.hip", "nf_mlp.hip", "nf_mlp_h.hip", "nf_cconv.hip"]
+SOURCES = ["nf_grid.hip", "nf_render.hip", "nf_mlp.hip", "nf_mlp_l.hip", "nf_mlp_h.hip", "nf_cconv.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-value"]
 

@@ -181,6 +181,17 @@ def pack_nerf(weights, biases, cx, cd, out=None):
     return out
 
 
+def pack_nerf_stream(packed, cx, cd):
+    """Weight stream of the LDS-ring fp32 kernel (nf_nerf_mlp_fwd_l) from the packed blob, or None when the feature
+    row is not the default 198 + 54 one (the direct-from-L2 kernel nf_nerf_mlp_fwd then serves the pass)."""
+    if ((cx + 7) // 8, (cd + 7) // 8) != (25, 7):
+        return None
+    lib = _lib.load()
+    out = torch.empty(lib.nf_nerf_stream_floats(cx, cd), dtype=torch.float32, device=packed.device)
+    check(lib.nf_nerf_pack_stream(ptr(packed), cx, cd, ptr(out), _lib.stream()), "nf_nerf_pack_stream")
+    return out
+
+
 def pack_nerf_h(weights, biases, cx, cd):
     """fp16 weight stream of the fp16-MFMA MLP (nf_nerf_pack_h)."""
     lib = _lib.load()
@@ -235,7 +246,7 @@ class Workspace:
 
 
 def render_pass(grid, particles, rays, z, z_table, S, radius, K, enc_flags, use_mask, ro, packed, cx, cd,
-                white_bg=True, save_acts=False, max_rows=None, packed_h=None, ws=None, need_weights=True):
+                white_bg=True, save_acts=False, max_rows=None, packed_h=None, ws=None, need_weights=True, wstream=None):
     """Runs classify -> search -> features -> MLP -> composite for R rays x S samples.
     z: (R,S) per-ray depths or None (then z_table (S,) is shared by all rays).
     Returns a PassBuffers with rgb, depth, opacity, weights, num_nn, mask_sum and the row lists."""
@@ -299,6 +310,9 @@ def render_pass(grid, particles, rays, z, z_table, S, radius, K, enc_flags, use_
     if packed_h is not None:      # fp16-MFMA variant (inference only)
         check(lib.nf_nerf_mlp_fwd_h(ptr(packed), ptr(packed_h), cx, cd, ptr(b.X), ptr(b.n_rows), max_rows,
                                     ptr(b.row_sample), ptr(b.rgbsigma), st), "nf_nerf_mlp_fwd_h")
+    elif wstream is not None and not save_acts:      # fp32, weight stream shared through LDS (inference)
+        check(lib.nf_nerf_mlp_fwd_l(ptr(packed), ptr(wstream), cx, cd, ptr(b.X), ptr(b.n_rows), max_rows, ptr(b.row_sample),
+                                    ptr(b.rgbsigma), st), "nf_nerf_mlp_fwd_l")
     else:
         check(lib.nf_nerf_mlp_fwd(ptr(packed), cx, cd, ptr(b.X), ptr(b.n_rows), max_rows, ptr(b.row_sample),
                                   ptr(b.rgbsigma), ptr(b.acts), st), "nf_nerf_mlp_fwd")
@@ -356,7 +370,7 @@ def tiles_to_rows(X, n, cx, cd):
     return torch.cat([f[:n, :cx], f[:n, 8 * qx:8 * qx + cd]], 1)
 
 
-def mlp_rows(packed, cx, cd, x, save_acts=False, packed_h=None):
+def mlp_rows(packed, cx, cd, x, save_acts=False, packed_h=None, wstream=None):
     """NeRF.forward on row-major features x (n, cx+cd) through the MFMA kernel -> (n,4) [rgb, sigma]."""
     lib = _lib.load()
     n = x.shape[0]
@@ -371,6 +385,10 @@ def mlp_rows(packed, cx, cd, x, save_acts=False, packed_h=None):
         Xh = X.view(T, (qx_ + qd_) // 2, 2, 64, 4).permute(0, 1, 3, 2, 4).reshape(-1).to(torch.float16).contiguous()
         check(lib.nf_nerf_mlp_fwd_h(ptr(packed), ptr(packed_h), cx, cd, ptr(Xh), ptr(n_rows), n, ptr(row_sample), ptr(out),
                                     _lib.stream()), "nf_nerf_mlp_fwd_h")
+        return out
+    if wstream is not None:
+        check(lib.nf_nerf_mlp_fwd_l(ptr(packed), ptr(wstream), cx, cd, ptr(X), ptr(n_rows), n, ptr(row_sample), ptr(out),
+                                    _lib.stream()), "nf_nerf_mlp_fwd_l")
         return out
     check(lib.nf_nerf_mlp_fwd(ptr(packed), cx, cd, ptr(X), ptr(n_rows), n, ptr(row_sample), ptr(out), ptr(acts),
                               _lib.stream()), "nf_nerf_mlp_fwd")

@@ -354,8 +354,8 @@ def test_fine_net_grads_same_samples(dev):
     net = make_net(dev)
     P, rays, tgt = T(g["particles"], dev), T(g["rays"], dev), T(g["target"], dev)
     roc = T(load_golden("a10_forward")["ro"], dev)
-    with torch.no_grad():
-        _, p1, _, _, _ = _run_passes(net, P, roc, rays, True, True, save_acts=False)
+    with torch.no_grad():      # the training flavour of the forward (save_acts): the very kernels net(...) runs below
+        _, p1, _, _, _ = _run_passes(net, P, roc, rays, True, True, save_acts=True)
     z1 = p1.z.cpu()
     out = net(P, roc, rays, None, None)
     torch.nn.functional.mse_loss(out["rgb1"], tgt).backward()
@@ -545,3 +545,26 @@ def test_full_frame_size_independent_properties(dev, side):
         h = net16(P, roc, rays, None, None)
     assert torch.equal(h["mask_0"], full["mask_0"])      # (the fine samples follow the fp16 coarse weights: mask_1 may differ)
     assert ro.psnr(h["rgb1"].cpu(), full["rgb1"].cpu()) >= 45.0
+
+
+def test_mlp_lds_ring_kernel(dev):
+    """A6 through nf_nerf_mlp_fwd_l (weight stream shared through an LDS ring): the golden rows of the reference's
+    NeRF.forward, and the direct-from-L2 kernel on row counts around every tile / workgroup boundary (the four waves
+    of a workgroup rendezvous on the stream: ragged groups must not deadlock or leak rows)."""
+    from neurofluid_amd import ops
+    g = load_golden("a6_nerf")
+    net = make_net(dev)
+    pk = net.packed_weights(net.nerf_coarse)
+    wst = ops.pack_nerf_stream(pk, net.in_channels_xyz, net.in_channels_dir)
+    assert wst is not None
+    x = T(g["x"], dev)
+    out = ops.mlp_rows(pk, net.in_channels_xyz, net.in_channels_dir, x, wstream=wst)
+    torch.testing.assert_close(out.cpu(), T(g["out"]), rtol=1e-4, atol=2e-5)
+    gen = torch.Generator().manual_seed(4)
+    for n in (1, 31, 32, 33, 127, 128, 129, 1000, 40000):
+        xr = (torch.rand(n, x.shape[1], generator=gen) * 2 - 1).to(dev)
+        a = ops.mlp_rows(pk, net.in_channels_xyz, net.in_channels_dir, xr)
+        b = ops.mlp_rows(pk, net.in_channels_xyz, net.in_channels_dir, xr, wstream=wst)
+        torch.testing.assert_close(b, a, rtol=1e-5, atol=3e-5)
+    # a non-default feature row has no ring variant
+    assert ops.pack_nerf_stream(pk, 63, 27) is None

@@ -26,6 +26,19 @@ for it in range(iters):
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1)
     print(f"iter {it}: rows {n} {ms:.3f} ms  {n*1331968/ms/1e9:.1f} TFLOP/s")
+if len(sys.argv) > 3 and sys.argv[3] == "ring":
+    ws = torch.empty(lib.nf_nerf_stream_floats(198, 54), dtype=torch.float32, device=dev)
+    check(lib.nf_nerf_pack_stream(ptr(packed), 198, 54, ptr(ws), _lib.stream()))
+    out3 = torch.zeros(n, 4, device=dev)
+    for it in range(iters):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib.nf_nerf_mlp_fwd_l(ptr(packed), ptr(ws), 198, 54, ptr(X), ptr(n_rows), n, ptr(row_sample), ptr(out3), _lib.stream()))
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        print(f"ring iter {it}: rows {n} {ms:.3f} ms  {n*1331968/ms/1e9:.1f} TFLOP/s")
+    err = (out3 - out).abs()
+    print("ring vs direct: max abs err rgb", float(err[:, :3].max()), "sigma", float(err[:, 3].max()))
 if len(sys.argv) > 3 and sys.argv[3] == "fp16":
     ph = ops.pack_nerf_h(W, B, 198, 54)
     T = X.numel() // (32 * 256)

@@ -171,7 +171,7 @@ def main():
         # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
         # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, tools/summarize_profiles.py)
         traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-    roofline = {"bound": "mfma", "kernel": "k_mlp_fwd (fp32 v_mfma_f32_32x32x2_f32)", "achieved": achieved,
+    roofline = {"bound": "mfma", "kernel": "k_mlp_fwd_l (fp32 v_mfma_f32_32x32x2_f32, weights through an LDS ring)", "achieved": achieved,
                 "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_MATRIX_PEAK_TFLOPS,
                 "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)", "launches": len(prof["mlp"]), "avg_launch_ms": mlp_ms / n_launch,
                 "executed_rows_per_step": rows / args.steps,

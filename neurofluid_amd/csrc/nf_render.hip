@@ -280,7 +280,9 @@ struct FeatEmitter {
     __device__ __forceinline__ void flush_at(int group)  // group = n/4 - 1 just completed
     {
         int q = group >> 1, h = group & 1;
-        base[q * 64 + h * 32] = make_float4(b0, b1, b2, b3);
+        typedef float nf_f4v __attribute__((ext_vector_type(4)));
+        const nf_f4v v = {b0, b1, b2, b3};
+        __builtin_nontemporal_store(v, (nf_f4v*)&base[q * 64 + h * 32]);   // streamed: read once, by the MLP
     }
     __device__ __forceinline__ void emit(float v)
     {
@@ -311,8 +313,8 @@ struct FeatEmitterH {
             const int t = (n >> 4) - 1;
             nf_h8 lo = {f[0], f[1], f[2], f[3], f[8], f[9], f[10], f[11]};
             nf_h8 hi = {f[4], f[5], f[6], f[7], f[12], f[13], f[14], f[15]};
-            base[t * 64] = lo;
-            base[t * 64 + 32] = hi;
+            __builtin_nontemporal_store(lo, &base[t * 64]);
+            __builtin_nontemporal_store(hi, &base[t * 64 + 32]);
         }
     }
     __device__ __forceinline__ void pad_to(int total)

@@ -323,21 +323,32 @@ struct FeatEmitterH {
     }
 };
 
+// Positional encoding [x, sin(2^k x), cos(2^k x)]_k (models/nerf.py:17-41; the reference evaluates torch.sin / cos of
+// the fp32 product 2^k * x, which is exact).  One sincos of x in DOUBLE, then angle doubling in double
+// (sin 2a = 2 sin a cos a, cos 2a = 1 - 2 sin^2 a): ten octaves cost one argument reduction instead of ten, and the
+// doubling error (< 2^10 * 1e-16) stays far below fp32 rounding, so every emitted value is the correctly rounded
+// sin / cos of the reference's argument.  (Ten independent sincosf calls made this kernel VALU-bound.)
 template <int C, int NF, typename EM>
 __device__ __forceinline__ void emit_pe(EM& em, const float (&x)[C])
 {
 #pragma unroll
     for (int c = 0; c < C; ++c) em.emit(x[c]);
+    double sn[C], cs[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) sincos((double)x[c], &sn[c], &cs[c]);
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
-        const float fr = (float)(1 << f);  // 2**linspace(0,N-1,N)  (models/nerf.py:17)
-        float sn[C], cs[C];      // one argument reduction per angle (sincosf == sinf / cosf of the same ocml code path)
 #pragma unroll
-        for (int c = 0; c < C; ++c) sincosf(fr * x[c], &sn[c], &cs[c]);
+        for (int c = 0; c < C; ++c) em.emit((float)sn[c]);
 #pragma unroll
-        for (int c = 0; c < C; ++c) em.emit(sn[c]);
+        for (int c = 0; c < C; ++c) em.emit((float)cs[c]);
+        if (f + 1 < NF) {
 #pragma unroll
-        for (int c = 0; c < C; ++c) em.emit(cs[c]);
+            for (int c = 0; c < C; ++c) {
+                const double s2 = 2.0 * sn[c] * cs[c], c2 = 1.0 - 2.0 * sn[c] * sn[c];
+                sn[c] = s2; cs[c] = c2;
+            }
+        }
     }
 }
 
@@ -780,12 +791,15 @@ __device__ __forceinline__ void pe_backward(const float* __restrict__ g, const f
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         float acc = g[c];
+        double sd, cd;                       // same double-precision angle doubling as the forward encoding
+        sincos((double)v[c], &sd, &cd);
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
             const float fr = (float)(1 << f);
-            float s, co;
-            sincosf(fr * v[c], &s, &co);
+            const float s = (float)sd, co = (float)cd;
             acc += fr * (g[C * (1 + 2 * f) + c] * co - g[C * (2 + 2 * f) + c] * s);
+            const double s2 = 2.0 * sd * cd, c2 = 1.0 - 2.0 * sd * sd;
+            sd = s2; cd = c2;
         }
         dv[c] = acc;
     }

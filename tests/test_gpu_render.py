@@ -374,8 +374,10 @@ def test_fine_net_grads_same_samples(dev):
         r = st[name].grad
         rel = float((p.grad.cpu() - r).norm() / r.norm())
         worst = max(worst, rel)
-        # every layer inherits (attenuated) the 5e-4 sin(512 x) feature noise of test_features_vs_golden
-        assert rel <= 2e-3, (name, rel)
+        # Calibrated, not guessed: moving every particle coordinate by ONE fp32 ulp moves these gradients by
+        # 0.8e-2 .. 1.9e-2 (tools/grad_sensitivity.py) — the positional encodings multiply 1-ulp differences of the
+        # smoothed positions (GPU vs CPU summation order) by up to 512 before the MLP sees them.
+        assert rel <= 2e-2, (name, rel)
     print("worst relative grad error", worst)
 
 

@@ -239,7 +239,9 @@ def main():
                        "ms_per_step": dtt * 1e3, "rays_per_sec": 4096 * world / dtt}
 
     if rank == 0:
-        res = {"metric": "rays/sec (renderer coarse+fine forward) coupled with one transition step per frame, watercube 400^2",
+        res = {"metric": ("rays/sec (renderer coarse+fine forward) coupled with one transition step per frame, watercube 400^2"
+                          if args.workload == "render" else
+                          "rays/sec of the train_renderer.py optimiser step (forward + backward + Adam), watercube 400^2"),
                "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",

@@ -254,13 +254,15 @@ int nf_cconv_gather(const float* G, int cout, const int64_t* row_splits, const i
  * nf_cconv_gather_bwd: dG (n x 65*Cout) from dy (n x Cout) with the TRANSPOSED pair cache (nf_cconv_pairs negate=1;
  *   fluid<->fluid neighbourhoods are symmetric, so the forward CSR serves both directions).  The caller then does
  *   the plain GEMMs  d[filter|dense_w] = x^T dG  and  dx = dG [filter|dense_w]^T.
- * nf_cconv_small_bwd_filter / _feat: filter / input-feature gradient of the direct Cin<=4 convs (dkernel must be
- *   zero-initialised; float atomics). */
+ * nf_cconv_small_bwd_filter / _feat: filter / input-feature gradient of the direct Cin<=4 convs.  The filter
+ *   gradient is dK += A^T dy with the patch matrix A (n_out x 64*cin) built in `workspace`
+ *   (nf_cconv_small_bwd_filter_workspace_floats floats); deterministic; dkernel is accumulated into. */
 int nf_cconv_gather_bwd(const float* dy, int cout, const int64_t* row_splits, const int32_t* nbr,
                         const float* pair_w_t, const uint8_t* pair_cell_t, int n, float* dG, nf_stream_t stream);
+size_t nf_cconv_small_bwd_filter_workspace_floats(int cin, int n_out);
 int nf_cconv_small_bwd_filter(const float* feats, int cin, const int64_t* row_splits, const int32_t* nbr,
                               const float* pair_w, const uint8_t* pair_cell, const float* dy, int ld_dy, int col_off,
-                              int n_out, float* dkernel /*64*cin*32*/, nf_stream_t stream);
+                              int n_out, float* workspace, float* dkernel /*64*cin*32*/, nf_stream_t stream);
 int nf_cconv_small_bwd_feat(const float* kernel, int cin, const int64_t* row_splits, const int32_t* nbr,
                             const float* pair_w_t, const uint8_t* pair_cell_t, const float* dy, int ld_dy, int col_off,
                             int n, float* dfeat /*n*cin*/, nf_stream_t stream);

@@ -62,7 +62,9 @@ PROTOTYPES = {
     "nf_trans_update": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p]),
     "nf_cconv_pairs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "nf_cconv_gather_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
-    "nf_cconv_small_bwd_filter": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "nf_cconv_small_bwd_filter_workspace_floats": (c_size_t, [c_int, c_int]),
+    "nf_cconv_small_bwd_filter": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
+                                          c_void_p, c_void_p]),
     "nf_cconv_small_bwd_feat": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "nf_cconv_small": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),

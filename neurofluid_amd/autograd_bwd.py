@@ -217,10 +217,11 @@ class _ParticleNetFn(torch.autograd.Function):
         c0f, c0o, d0 = pn.conv0_fluid, pn.conv0_obstacle, pn.dense0_fluid
         dKo = torch.zeros_like(c0o.kernel)
         dKf = torch.zeros_like(c0f.kernel)
+        wsf = torch.empty(lib.nf_cconv_small_bwd_filter_workspace_floats(4, n), dtype=torch.float32, device=dev)
         check(lib.nf_cconv_small_bwd_filter(ptr(ctx.box_feats), 3, ptr(b_rs), ptr(b_idx), ptr(b_pw), ptr(b_pc), ptr(dy), 96, 0,
-                                            n, ptr(dKo), st), "conv0_obstacle filter grad")
+                                            n, ptr(wsf), ptr(dKo), st), "conv0_obstacle filter grad")
         check(lib.nf_cconv_small_bwd_filter(ptr(ff), 4, ptr(f_rs), ptr(f_idx), ptr(f_pw), ptr(f_pc), ptr(dy), 96, 32, n,
-                                            ptr(dKf), st), "conv0_fluid filter grad")
+                                            ptr(wsf), ptr(dKf), st), "conv0_fluid filter grad")
         grads[c0o.kernel], grads[c0f.kernel] = dKo, dKf
         grads[c0o.bias], grads[c0f.bias] = dy[:, :32].sum(0), dy[:, 32:64].sum(0)
         grads[d0.weight], grads[d0.bias] = dy[:, 64:].t() @ ff, dy[:, 64:].sum(0)

@@ -522,56 +522,106 @@ extern "C" int nf_cconv_gather_bwd(const float* dy, int cout, const int64_t* row
     return NF_OK;
 }
 
-// filter gradient of the direct small-Cin conv: dK[cell][ci][co] += pw * feat[j][ci] * dy[i][col_off + co]
-// block-private accumulation in LDS (ds_add_f32), one flush of global float atomics per block.
+// filter gradient of the direct small-Cin conv: dK[cell][ci][co] = sum_i sum_pairs(i) sum_corners pw * feat[j][ci] * dy[i][col_off + co]
+// Factored as  dK = A^T * dy  with the "patch" matrix A[i][cell*CIN + ci] = sum_pairs sum_corners pw * feat[j][ci]
+// (what Open3D builds explicitly before its GEMM):
+//   1. k_cconv_small_patch : one wave per output point accumulates its 64*CIN patch in LDS (2 pairs x 8 corners x CIN
+//      updates per step, ds_add_f32 inside the wave only) and writes the row of A;
+//   2. k_cconv_small_wgemm : dK partials over row slices (thread = patch column, 32 accumulators), deterministic
+//      reduction of the slices.
+// (The first version accumulated pw * feat * dy for every (pair, corner, ci, co) straight into a block-wide LDS copy of
+// dK with atomics and flushed with global atomics: 245 M LDS atomics, 1.1 ms for 4 913 points — the largest kernel of
+// the end-to-end training step — and an order-dependent result.  This one: ~30 us, deterministic.)
+#define SWG_SLICES 128
 template <int CIN>
-__global__ void __launch_bounds__(256) k_cconv_small_bwd_filter(const float* __restrict__ feats,
-                                                                const int64_t* __restrict__ row_splits,
-                                                                const int32_t* __restrict__ nbr, const float* __restrict__ pw,
-                                                                const uint8_t* __restrict__ pc, const float* __restrict__ dy,
-                                                                int ld_dy, int col_off, int n_out, float* __restrict__ dK)
+__global__ void __launch_bounds__(256) k_cconv_small_patch(const float* __restrict__ feats, const int64_t* __restrict__ row_splits,
+                                                           const int32_t* __restrict__ nbr, const float* __restrict__ pw,
+                                                           const uint8_t* __restrict__ pc, int n_out, float* __restrict__ A)
 {
-    __shared__ float acc[64 * CIN * 32];
-    for (int t = threadIdx.x; t < 64 * CIN * 32; t += 256) acc[t] = 0.f;
-    __syncthreads();
-    const int lane = threadIdx.x & 63, co = lane & 31, half = lane >> 5;
-    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < n_out; row += gridDim.x * 4) {
-        float g = dy[(size_t)row * ld_dy + col_off + co];
-        for (int64_t p = row_splits[row] + half; p < row_splits[row + 1]; p += 2) {
-            int j = nbr[p];
-            float fj[CIN];
+    __shared__ float patch[4][64 * 4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int sub = lane >> 5, k = (lane >> 2) & 7, ci = lane & 3;      // lane -> (pair of the step, corner, channel)
+    float* pt = patch[wv];
+    for (int row = blockIdx.x * 4 + wv; row < n_out; row += gridDim.x * 4) {
 #pragma unroll
-            for (int ci = 0; ci < CIN; ++ci) fj[ci] = feats[(size_t)j * CIN + ci];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                float wg = pw[p * 8 + k] * g;
-                float* a = acc + (int)pc[p * 8 + k] * CIN * 32 + co;
-#pragma unroll
-                for (int ci = 0; ci < CIN; ++ci) atomicAdd(a + ci * 32, wg * fj[ci]);
-            }
+        for (int t = lane; t < 64 * CIN; t += 64) pt[t] = 0.f;
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        const int64_t e = row_splits[row + 1];
+        for (int64_t p = row_splits[row] + sub; p < e; p += 2) {
+            if (ci < CIN) atomicAdd(pt + (int)pc[p * 8 + k] * CIN + ci, pw[p * 8 + k] * feats[(size_t)nbr[p] * CIN + ci]);
         }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = lane; t < 64 * CIN; t += 64) A[(size_t)row * (64 * CIN) + t] = pt[t];
+        __builtin_amdgcn_wave_barrier();
     }
-    __syncthreads();
-    for (int t = threadIdx.x; t < 64 * CIN * 32; t += 256)
-        if (acc[t] != 0.f) atomicAdd(dK + t, acc[t]);
+}
+
+template <int CIN>
+__global__ void __launch_bounds__(64 * CIN) k_cconv_small_wgemm(const float* __restrict__ A, const float* __restrict__ dy, int ld_dy,
+                                                                int col_off, int n_out, int rows_per_slice,
+                                                                float* __restrict__ partial)
+{
+    __shared__ float gy[32];
+    const int m = threadIdx.x;                       // patch column = cell * CIN + ci
+    const int r0 = blockIdx.x * rows_per_slice, r1 = min(n_out, r0 + rows_per_slice);
+    float acc[32];
+#pragma unroll
+    for (int co = 0; co < 32; ++co) acc[co] = 0.f;
+    for (int row = r0; row < r1; ++row) {
+        __syncthreads();
+        if (m < 32) gy[m] = dy[(size_t)row * ld_dy + col_off + m];
+        __syncthreads();
+        const float a = A[(size_t)row * (64 * CIN) + m];
+#pragma unroll
+        for (int co = 0; co < 32; ++co) acc[co] += a * gy[co];
+    }
+    float* out = partial + ((size_t)blockIdx.x * (64 * CIN) + m) * 32;
+#pragma unroll
+    for (int co = 0; co < 32; ++co) out[co] = acc[co];
+}
+
+__global__ void k_cconv_small_wreduce(const float* __restrict__ partial, int total, int nslices, float* __restrict__ dK)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    float s = 0.f;
+    for (int z = 0; z < nslices; ++z) s += partial[(size_t)z * total + i];
+    dK[i] += s;                                       // accumulate: the caller zero-initialises (as before)
+}
+
+extern "C" size_t nf_cconv_small_bwd_filter_workspace_floats(int cin, int n_out)
+{
+    return (size_t)(n_out > 0 ? n_out : 0) * 64 * cin + (size_t)SWG_SLICES * 64 * cin * 32;
 }
 
 extern "C" int nf_cconv_small_bwd_filter(const float* feats, int cin, const int64_t* row_splits, const int32_t* nbr,
                                          const float* pair_w, const uint8_t* pair_cell, const float* dy, int ld_dy,
-                                         int col_off, int n_out, float* dkernel, nf_stream_t stream)
+                                         int col_off, int n_out, float* workspace, float* dkernel, nf_stream_t stream)
 {
-    NF_CHECK_ARG(feats && row_splits && dy && dkernel, "null pointer");
+    NF_CHECK_ARG(feats && row_splits && dy && dkernel && workspace, "null pointer");
     NF_CHECK_ARG(cin == 3 || cin == 4, "cin must be 3 or 4");
     if (n_out <= 0) return NF_OK;
     int blocks = (n_out + 3) / 4;
-    if (blocks > 512) blocks = 512;
+    if (blocks > 4096) blocks = 4096;
     hipStream_t st = (hipStream_t)stream;
-    if (cin == 3)
-        hipLaunchKernelGGL(k_cconv_small_bwd_filter<3>, dim3(blocks), dim3(256), 0, st, feats, row_splits, nbr, pair_w,
-                           pair_cell, dy, ld_dy, col_off, n_out, dkernel);
-    else
-        hipLaunchKernelGGL(k_cconv_small_bwd_filter<4>, dim3(blocks), dim3(256), 0, st, feats, row_splits, nbr, pair_w,
-                           pair_cell, dy, ld_dy, col_off, n_out, dkernel);
+    float* A = workspace;
+    float* partial = workspace + (size_t)n_out * 64 * cin;
+    const int rows_per = (n_out + SWG_SLICES - 1) / SWG_SLICES;
+    const int total = 64 * cin * 32;
+    if (cin == 3) {
+        hipLaunchKernelGGL(k_cconv_small_patch<3>, dim3(blocks), dim3(256), 0, st, feats, row_splits, nbr, pair_w, pair_cell, n_out, A);
+        hipLaunchKernelGGL(k_cconv_small_wgemm<3>, dim3(SWG_SLICES), dim3(192), 0, st, (const float*)A, dy, ld_dy, col_off, n_out,
+                           rows_per, partial);
+    } else {
+        hipLaunchKernelGGL(k_cconv_small_patch<4>, dim3(blocks), dim3(256), 0, st, feats, row_splits, nbr, pair_w, pair_cell, n_out, A);
+        hipLaunchKernelGGL(k_cconv_small_wgemm<4>, dim3(SWG_SLICES), dim3(256), 0, st, (const float*)A, dy, ld_dy, col_off, n_out,
+                           rows_per, partial);
+    }
+    hipLaunchKernelGGL(k_cconv_small_wreduce, dim3((total + 255) / 256), dim3(256), 0, st, (const float*)partial, total, SWG_SLICES,
+                       dkernel);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }

@@ -117,11 +117,20 @@ def radius_row_splits(grid, queries, radius, ignore_query_point=True):
     return rs
 
 
+def round_pairs(n):
+    """Capacity bucket of a pair-count-sized buffer (<= 12.5 % slack, multiples of 16 384): the pair count of a
+    moving fluid drifts every step, and exact sizes send the caching allocator back to hipMalloc (4-7 ms, inside a
+    frame) each time a 2 MB size class is crossed."""
+    n = max(int(n), 1)
+    step = max(16384, 1 << max(n.bit_length() - 4, 0))
+    return (n + step - 1) // step * step
+
+
 def radius_fill(grid, queries, radius, row_splits, capacity, ignore_query_point=True):
     lib = _lib.load()
     q = queries.detach().contiguous().float()
-    idx = torch.empty(max(capacity, 1), dtype=torch.int32, device=q.device)
-    d2 = torch.empty(max(capacity, 1), dtype=torch.float32, device=q.device)
+    idx = torch.empty(round_pairs(capacity), dtype=torch.int32, device=q.device)[:max(capacity, 1)]
+    d2 = torch.empty(round_pairs(capacity), dtype=torch.float32, device=q.device)[:max(capacity, 1)]
     check(lib.nf_radius_fill(ptr(grid.ws), ptr(q), q.shape[0], float(radius), int(ignore_query_point), ptr(row_splits),
                              ptr(idx), ptr(d2), capacity, _lib.stream()), "nf_radius_fill")
     return idx, d2

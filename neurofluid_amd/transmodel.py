@@ -52,8 +52,9 @@ class ContinuousConv(nn.Module):
 def cconv_pairs(inp_pos, out_pos, row_splits, nbr, d2, extent, use_window=True, negate=False):
     lib = _lib.load()
     nnz = nbr.shape[0]
-    pw = torch.empty(max(nnz, 1) * 8, dtype=torch.float32, device=inp_pos.device)
-    pc = torch.empty(max(nnz, 1) * 8, dtype=torch.uint8, device=inp_pos.device)
+    cap = ops.round_pairs(nnz)           # bucketed: see ops.round_pairs
+    pw = torch.empty(cap * 8, dtype=torch.float32, device=inp_pos.device)[:max(nnz, 1) * 8]
+    pc = torch.empty(cap * 8, dtype=torch.uint8, device=inp_pos.device)[:max(nnz, 1) * 8]
     check(lib.nf_cconv_pairs(ptr(inp_pos), ptr(out_pos), ptr(row_splits), ptr(nbr), ptr(d2), out_pos.shape[0],
                              float(extent), int(use_window), int(negate), ptr(pw), ptr(pc), _lib.stream()), "nf_cconv_pairs")
     return pw, pc

@@ -187,8 +187,7 @@ class _ParticleNetFn(torch.autograd.Function):
         if g_vel is not None:
             d_pos_c = d_pos_c + g_vel.detach().float() / dt          # vel_c = (pos_c - pos) / dt
         extent = float(pn.filter_extent)
-        f_d2 = pn.conv0_fluid.nns.neighbors_distance
-        nnz = f_idx.shape[0]
+        f_d2 = aux["f_d2"]          # this CALL's pair distances (the module's .nns is overwritten by every forward)
         # the fluid<->fluid pairs as seen from the neighbour (transposed operator), once for all layers
         t_pw, t_pc = cconv_pairs(aux["pos_new"], aux["pos_new"], f_rs, f_idx, f_d2, extent, pn.use_window, negate=True)
         dy = (d_pos_c * (1.0 / 128)).contiguous()                    # pos_correction = y3 / 128

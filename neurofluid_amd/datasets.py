@@ -143,15 +143,20 @@ class ParticleDataset(Dataset):
 
 # ------------------------------------------------------------------------------------------------
 def write_synthetic_dataset(root, n_frames=4, img=16, n_side=9, views=('view_0', 'view_1', 'view_2', 'view_3', 'view_4', 'view_5'),
-                            splits=('train', 'test'), camera_angle_x=0.323, seed=10):
-    """Synthetic watercube in the reference's on-disk layout: a jittered lattice falling under gravity
-    (analytic frames), a sampled box, RGBA images with an analytic pattern (content is irrelevant to the
-    kernels; PSNR-vs-paper needs the released data)."""
+                            splits=('train', 'test'), camera_angle_x=0.323, seed=10, shape='watercube', order='random'):
+    """Synthetic scene in the reference's on-disk layout: a particle body falling under gravity (analytic frames), a
+    sampled box, RGBA images with an analytic pattern (content is irrelevant to the kernels; PSNR-vs-paper needs the
+    released data).  shape: 'watercube' (n_side^3 jittered lattice, lattice index order) or 'bunny' / 'honeycone'
+    (synthetic.shaped_particles: ~4.8 k / 4.4 k particles in `order` = random | scan | shells index order)."""
     import joblib
     from PIL import Image
     rng = np.random.RandomState(seed)
-    ax = [c + 0.05 * np.arange(n_side) for c in (-0.05 * (n_side - 1) / 2, -0.05 * (n_side - 1) / 2, -0.975)]
-    pos0 = np.stack(np.meshgrid(*ax, indexing='ij'), -1).reshape(-1, 3) + rng.uniform(-0.005, 0.005, (n_side ** 3, 3))
+    if shape == 'watercube':
+        ax = [c + 0.05 * np.arange(n_side) for c in (-0.05 * (n_side - 1) / 2, -0.05 * (n_side - 1) / 2, -0.975)]
+        pos0 = np.stack(np.meshgrid(*ax, indexing='ij'), -1).reshape(-1, 3) + rng.uniform(-0.005, 0.005, (n_side ** 3, 3))
+    else:
+        from .synthetic import shaped_particles
+        pos0 = shaped_particles(shape, seed=seed, order=order).numpy().astype(np.float64)
     dt, g = 1 / 50, np.array([0, 0, -9.81])
     lo, hi = np.array([-1.0, -1.0, -1.0]), np.array([1.0, 1.0, 2.4552])
     pts, nrm = [], []

@@ -69,7 +69,7 @@ class RenderNet(nn.Module):
         self._z_table = None
         self._u_table = None
         self._zero_row = None
-        self._grid_cache = (None, None)
+        self._grid_cache = (None, None, None)
         self._workspace = None
 
     # ------------------------------------------------------------------
@@ -94,8 +94,10 @@ class RenderNet(nn.Module):
     def grid_for(self, particles):
         """One grid per particle tensor *version* (rebuilt when the particles move)."""
         key = (particles.data_ptr(), particles._version, particles.shape[0])
-        if self._grid_cache[0] != key:
-            self._grid_cache = (key, ops.build_grid(particles, self.raduis))
+        if self._grid_cache[0] != key or self._grid_cache[2] is not particles:
+            # the entry holds `particles` itself: (ptr, version, N) alone could match a NEW tensor that re-uses a
+            # freed block (build_grid copies non-contiguous / non-fp32 inputs, so the grid would not pin the pointer)
+            self._grid_cache = (key, ops.build_grid(particles, self.raduis), particles)
         return self._grid_cache[1]
 
     def workspace(self):
@@ -127,3 +129,17 @@ class RenderNet(nn.Module):
                          noise_std=0., white_background=True):
         from .autograd import render_forward
         return render_forward(self, physical_particles, ro, rays, white_background, fine=False)
+
+    def fine_rendering(self, physical_particles, ro, rays, focal=None, c2w=None, use_disp=False, perturb=0,
+                       noise_std=0., white_background=True):
+        """models/renderer.py:310-369: coarse pass for the sample weights only (sigma of nerf_coarse -> weights_0 ->
+        importance sampling, which is detached), then the fine pass; only the ``*1`` keys are returned.
+        sigma does not depend on the direction features (models/nerf.py:100-113: ``sigma_only`` reads the first
+        in_channels_xyz columns), so weights_0 here are the very weights ``forward`` resamples from and the result
+        equals forward()'s fine half bit for bit.  (The reference's own body cannot run with the shipped
+        configs: with encoding.smoothed_dir it appends to an undefined list at :172-174 under sigma_only and unpacks
+        a 4-element list at :321; this counterpart implements the evident intent.)"""
+        if self.N_importance <= 0:
+            raise AssertionError("fine_rendering needs N_importance > 0 (models/renderer.py:345)")
+        res = self.forward(physical_particles, ro, rays, focal, c2w, use_disp, perturb, noise_std, white_background)
+        return {k: res[k] for k in ("rgb1", "depth1", "opacity1", "num_nn_1", "mask_1")}

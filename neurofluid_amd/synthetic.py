@@ -15,6 +15,46 @@ def watercube_particles(n_side=17, spacing=0.05, corner=(-0.40, -0.40, -0.975), 
     return torch.from_numpy(g.astype(np.float32))
 
 
+def shaped_particles(kind, spacing=0.05, jitter=0.005, seed=10, order="random", centre=(0.0, 0.0, -0.25)):
+    """Synthetic stand-ins for the fluid bodies of BASELINE configs 4 / 5 (the released data sets are not available):
+    a jittered 0.05 lattice clipped to the shape, in an index order that is NOT lattice order.
+      kind "bunny":     union of ellipsoids (body, head, two ears, tail)  — 4 774 particles
+      kind "honeycone": a cone standing on its apex, top radius 0.65, height 1.3 — 4 350 particles
+      kind "cube":      the watercube block (for comparison with the same code path)
+      order "random":   a seeded permutation — no spatial coherence of the index at all: the hardest regime of the
+                        first-K-by-index search (the K lowest indices in radius are scattered over the whole ball)
+      order "scan":     lattice scan order restricted to the shape (what a volume sampler emits)
+      order "shells":   sorted by distance from the shape's centre (an emitter-like order)"""
+    c = np.asarray(centre, np.float64)
+    ax = [np.arange(-1.0, 1.0 + 1e-9, spacing) for _ in range(3)]
+    g = np.stack(np.meshgrid(ax[0], ax[1], ax[2], indexing="ij"), -1).reshape(-1, 3)
+
+    def ell(p, ctr, rad):
+        return (((p - np.asarray(ctr)) / np.asarray(rad)) ** 2).sum(-1) <= 1.0
+
+    if kind == "bunny":
+        inside = (ell(g, (0, 0, 0), (0.60, 0.43, 0.47)) | ell(g, (0.52, 0, 0.43), (0.29, 0.25, 0.26)) |
+                  ell(g, (0.58, 0.13, 0.80), (0.09, 0.07, 0.29)) | ell(g, (0.58, -0.13, 0.80), (0.09, 0.07, 0.29)) |
+                  ell(g, (-0.63, 0, 0.07), (0.13, 0.13, 0.13)))
+    elif kind == "honeycone":
+        h = g[:, 2] + 0.65                                   # apex at z = -0.65, top at z = +0.65
+        inside = (h >= 0) & (h <= 1.3) & (np.hypot(g[:, 0], g[:, 1]) <= 0.5 * h + 1e-9)
+    elif kind == "cube":
+        inside = (np.abs(g) <= 0.4 + 1e-9).all(-1)
+    else:
+        raise ValueError(kind)
+    p = g[inside]
+    rng = np.random.RandomState(seed)
+    p = p + rng.uniform(-jitter, jitter, p.shape)
+    if order == "random":
+        p = p[rng.permutation(p.shape[0])]
+    elif order == "shells":
+        p = p[np.argsort((p ** 2).sum(-1), kind="stable")]
+    elif order != "scan":
+        raise ValueError(order)
+    return torch.from_numpy((p + c).astype(np.float32))
+
+
 def watercube_box(spacing=0.05):
     """The 6 faces of x,y in [-1,1], z in [-1,2.4552] (trainer/basetrainer.py:58-62) on a 0.05 grid, inward normals."""
     lo = np.array([-1.0, -1.0, -1.0]); hi = np.array([1.0, 1.0, 2.4552])

@@ -35,7 +35,11 @@ def _build_coords(H, W, global_step, precrop_iters):
 class PixelSampler:
     """Draws the per-view pixel selections `rng.choice(n, ray_chunk, replace=False)` (trainer_renderer.py:119) in the
     reference's order, one step ahead on a background thread: the draw is a full 160 000-element shuffle (1.4 ms per
-    view on the host) and would otherwise sit between two GPU steps.  Same RNG stream, same indices."""
+    view on the host) and would otherwise sit between two GPU steps.  Same RNG stream, same indices.
+    The read-ahead is invisible to the stream's other users: every draw records the generator state it started from,
+    and close() joins the worker and rewinds `rng` to the state before the first selection nobody consumed, so after
+    train() the stream is exactly where a sampler without read-ahead would have left it.  An exception in the worker
+    (e.g. fewer pixels than ray_chunk) is re-raised by next()."""
 
     def __init__(self, rng, n_views, ray_chunk, n_pixels_of_step, first_step, depth=2):
         import queue
@@ -43,30 +47,61 @@ class PixelSampler:
         self.rng, self.n_views, self.ray_chunk, self.n_of = rng, n_views, ray_chunk, n_pixels_of_step
         self.q = queue.Queue(maxsize=depth)
         self.step = first_step
-        self._stop = False
+        self._stop = threading.Event()
+        self._pending = None          # (step, sels, state_before) drawn but not yet queued when the stop flag was seen
         self.t = threading.Thread(target=self._run, daemon=True)
         self.t.start()
 
     def _run(self):
+        import queue
         step = self.step
-        while not self._stop:
-            n = self.n_of(step)
-            sels = [self.rng.choice(n, size=[self.ray_chunk], replace=False) for _ in range(self.n_views)]
-            self.q.put((step, sels))
-            step += 1
+        try:
+            while not self._stop.is_set():
+                state = self.rng.get_state()
+                n = self.n_of(step)
+                sels = [self.rng.choice(n, size=[self.ray_chunk], replace=False) for _ in range(self.n_views)]
+                item = (step, sels, state)
+                while True:
+                    if self._stop.is_set():
+                        self._pending = item
+                        return
+                    try:
+                        self.q.put(item, timeout=0.05)
+                        break
+                    except queue.Full:
+                        continue
+                step += 1
+        except BaseException as e:          # surfaced by next(); never leaves the consumer blocked
+            self.q.put(("error", e, None))
 
     def next(self, step):
-        s, sels = self.q.get()
+        import queue
+        while True:
+            try:
+                s, sels, _ = self.q.get(timeout=1.0)
+                break
+            except queue.Empty:
+                if not self.t.is_alive() and self.q.empty():
+                    raise RuntimeError("PixelSampler worker stopped without producing a selection")
+        if s == "error":
+            raise sels
         assert s == step, "PixelSampler is strictly sequential"
         return sels
 
     def close(self):
-        self._stop = True
+        self._stop.set()
+        self.t.join(timeout=10.0)
+        left = []
         try:
             while True:
-                self.q.get_nowait()
+                left.append(self.q.get_nowait())
         except Exception:
             pass
+        if self._pending is not None:
+            left.append(self._pending)
+        states = [it[2] for it in left if it[0] != "error" and it[2] is not None]
+        if states:                          # rewind to before the first unconsumed draw
+            self.rng.set_state(states[0])
 
 
 class ExponentialLR(torch.optim.lr_scheduler.LambdaLR):

@@ -65,16 +65,27 @@ class BaseTrainer:
         torch.cuda.set_device(self.device)
         self.init_fn()
         self.init_box_boundary()
+        self.seed_data_streams()
         if self.options.resume_from != '':
             self.resume(self.options.resume_from)
 
     def init_fn(self):
         raise NotImplementedError()
 
+    def seed_data_streams(self):
+        """Data-parallel training: the models were initialised from the SAME seed on every rank (identical replicas);
+        the streams that draw the training data (pixel selections: np.random.choice, trainer_renderer.py:119; sample
+        order / z-rotation: np.random, dataset_splishsplash_rawdata.py:128-135) are re-seeded with seed + rank, so that
+        N ranks average N different batches.  With one process the reference's single stream is kept untouched."""
+        if self.world > 1:
+            np.random.seed(self._seed + self.rank)
+            random.seed(self._seed + self.rank)
+
     def resume(self, ckpt_file):
         raise NotImplementedError()
 
     def seed_everything(self, seed):
+        self._seed = int(seed)
         random.seed(seed)
         os.environ['PYTHONHASHSEED'] = str(seed)
         np.random.seed(seed)
@@ -175,7 +186,22 @@ class BaseTrainer:
             self._write_png(self.vis_rgbs(mask, channel=1), '{}/{}_{:05d}_mask.png'.format(self.imgpath, prefix, step))
 
     def _to_dev(self, data):
-        return {k: v.to(self.device) if isinstance(v, torch.Tensor) else v for k, v in data.items()}
+        """Host -> device copy of one dataset item.  The container (``box`` / ``box_normals``, ~39 k points, the same
+        for every frame) is uploaded ONCE and the same device tensors are handed out afterwards, so the caches keyed
+        on them (box grid, scene bounds, step graph) hit; a rotated container (ParticleDataset random_rot) differs
+        per item and is uploaded as such."""
+        out = {}
+        for k, v in data.items():
+            if k in ('box', 'box_normals') and isinstance(v, torch.Tensor):
+                cache = self.__dict__.setdefault('_static_dev', {})
+                host, dev_t = cache.get(k, (None, None))
+                if host is None or host.shape != v.shape or not torch.equal(host, v):
+                    host, dev_t = v.clone(), v.to(self.device)
+                    cache[k] = (host, dev_t)
+                out[k] = dev_t
+            else:
+                out[k] = v.to(self.device) if isinstance(v, torch.Tensor) else v
+        return out
 
     def _dataset(self, node_key, views, split, imgnode):
         o = self.options
@@ -563,41 +589,100 @@ class TransModelEvaluation:
 
 
 class TransModelTrainer(BaseTrainer):
-    """trainer/trainer_transmodel.py: supervised fine-tuning, 2-step unroll, neighbour-weighted loss + boundary."""
+    """trainer/trainer_transmodel.py:24-262: supervised fine-tuning of the transition model.  Per sample: a 2-step
+    unroll (state NOT detached in between, :179-180), loss = 0.5*wmse_1 + 0.5*wmse_2 + boundary_1 + boundary_2
+    (:182-189), optional clip_grad_norm_ (:198-199), Adam.  ``N_iters`` counts EPOCHS over the shuffled dataset
+    (:167-168, DataLoader(shuffle=True) :124), checkpoint + rollout eval every ``save_interval`` epochs (:216-221);
+    the checkpoint's ``step`` is the epoch index (:218) and resume() restores model and optimizer only (:111-115)."""
 
     def init_fn(self):
         o = self.options
+        self.eval_count, self.start_step = 0, 0
         self.transition_model = ParticleNet(gravity=o.TRAIN.gravity).to(self.device)
         if o.TRAIN.pretrained:
             self.load_pretained_transition_model(o.TRAIN.pretrained)
-        self.dataset = ParticleDataset(o.TRAIN.datapath.train, o.TRAIN.datapath.train_datatype, o.TRAIN.start_index,
-                                       o.TRAIN.end_index, random_rot=True, window=3)
+        dp = o.TRAIN.datapath
+        self.dataset = ParticleDataset(dp.train, dp.train_datatype, o.TRAIN.start_index, o.TRAIN.end_index,
+                                       random_rot=True, window=3)
+        self.test_dataset = ParticleDataset(dp.eval, dp.eval_datatype, o.TRAIN.start_index, o.TRAIN.end_index,
+                                            random_rot=False, window=3)
         self.optimizer = torch.optim.Adam(self.transition_model.parameters(), lr=o.TRAIN.lr)
         self.set_L1_criterion()
-        self.start_step = 0
+
+    def init_box_boundary(self):
+        super().init_box_boundary(self.options.TRAIN.get('particle_radius', 0.025))
 
     def resume(self, ckpt_file):
         ck = torch.load(ckpt_file, map_location=self.device)
-        self.start_step = ck['step']
         self.transition_model.load_state_dict(ck['model_state_dict'], strict=True)
+        self.optimizer.load_state_dict(ck['optimizer_state_dict'])
+
+    def sample_loss(self, data):
+        """The loss of one training sample (trainer_transmodel.py:170-189); returns (loss, parts)."""
+        box, bn = data['box'], data['box_normals']
+        p1, v1, n1 = self.transition_model(data['particles_pos_0'], data['particles_vel_0'], box, bn)
+        p2, v2, n2 = self.transition_model(p1, v1, box, bn)
+        loss1 = self.weighted_mse_loss(p1, data['particles_pos_1'], n1)
+        loss2 = self.weighted_mse_loss(p2, data['particles_pos_2'], n2)
+        b1, b2 = self.cal_boundary_loss(p1), self.cal_boundary_loss(p2)
+        return 0.5 * loss1 + 0.5 * loss2 + b1 + b2, dict(loss1=loss1, loss2=loss2, bloss1=b1, bloss2=b2)
 
     def train(self, max_steps=None):
         o = self.options
-        step, loss = self.start_step, None
-        order = np.random.permutation(len(self.dataset))
-        while step < o.TRAIN.N_iters and (max_steps is None or step - self.start_step < max_steps):
-            data = self._to_dev(self.dataset[int(order[step % len(order)])])
-            pos, vel = data['particles_pos_0'], data['particles_vel_0']
-            loss = 0.
-            for k in (1, 2):          # 2-step unroll, state NOT detached in between
-                pos, vel, nn = self.transition_model(pos, vel, data['box'], data['box_normals'])
-                loss = loss + self.weighted_mse_loss(pos, data[f'particles_pos_{k}'], nn) + self.cal_boundary_loss(pos)
-            self.optimizer.zero_grad()
-            loss.backward()
-            nfdist.allreduce_grads(list(self.transition_model.parameters()), self.world)
-            self.optimizer.step()
-            step += 1
-            if step % o.TRAIN.save_interval == 0 and self.rank == 0:
-                torch.save({'step': step, 'model_state_dict': self.transition_model.state_dict(),
-                            'optimizer_state_dict': self.optimizer.state_dict()}, osp.join(self.exppath, 'models', f'{step}.pt'))
+        self.transition_model.train()
+        global_step, loss = self.start_step, None
+        clip = o.TRAIN.get('grad_clip_value', 0)
+        for epoch_idx in range(self.start_step, o.TRAIN.N_iters):
+            order = np.random.permutation(len(self.dataset))        # DataLoader(batch_size=1, shuffle=True)
+            if self.world > 1:        # data parallel: an epoch is still len(dataset) samples, split over the ranks
+                order = order[:max(len(order) // self.world, 1)]          # (each rank draws its own permutation)
+            for i in order:
+                data = self._to_dev(self.dataset[int(i)])
+                loss, parts = self.sample_loss(data)
+                self.optimizer.zero_grad()
+                loss.backward()
+                nfdist.allreduce_grads(list(self.transition_model.parameters()), self.world)
+                if clip != 0:
+                    torch.nn.utils.clip_grad_norm_(self.transition_model.parameters(), clip)
+                self.optimizer.step()
+                if (global_step + 1) % o.TRAIN.log_interval == 0:
+                    for k, v in parts.items():
+                        self.summary_writer.add_scalar(k, v.item(), global_step)
+                    self.summary_writer.add_scalar('loss', loss.item(), global_step)
+                    self.summary_writer.add_scalar('lr', self.get_learning_rate(self.optimizer)[0], global_step)
+                global_step += 1
+                if max_steps is not None and global_step - self.start_step >= max_steps:
+                    return loss
+            if (epoch_idx + 1) % o.TRAIN.save_interval == 0:
+                if self.rank == 0:
+                    torch.save({'step': epoch_idx, 'model_state_dict': self.transition_model.state_dict(),
+                                'optimizer_state_dict': self.optimizer.state_dict()},
+                               osp.join(self.exppath, 'models', f'{global_step}.pt'))
+                self.eval(global_step)
         return loss
+
+    def eval(self, step_idx, dump=True):
+        """Rollout over the evaluation windows (trainer_transmodel.py:224-262)."""
+        self.transition_model.eval()
+        self.eval_count += 1
+        dists = []
+        self.fluid_error = FluidErrors()
+        with torch.no_grad():
+            for data_idx in range(len(self.test_dataset)):
+                data = self._to_dev(self.test_dataset[data_idx])
+                if data_idx == 0:
+                    pos, vel = data['particles_pos_0'], data['particles_vel_0']
+                pos, vel, _ = self.transition_model(pos, vel, data['box'], data['box_normals'])
+                d = self.fluid_error.cal_errors(pos, data['particles_pos_1'], data_idx + 1)
+                dists.append(d)
+                self.summary_writer.add_scalar('pred2gt_distance', d, self.eval_count * len(self.test_dataset) + data_idx + 1)
+                if dump and self.rank == 0:
+                    pdir = osp.join(self.particlepath, f'{step_idx}')
+                    os.makedirs(pdir, exist_ok=True)
+                    for name, p, col in ((f'pred_{data_idx + 1}.obj', pos, (255, 0, 0)),
+                                         (f'gt_{data_idx + 1}.obj', data['particles_pos_1'], (3, 168, 158))):
+                        with open(osp.join(pdir, name), 'w') as fp:
+                            record2obj(p, fp, color=col)
+            self.summary_writer.add_scalar('avg_pred2gt_distance', float(np.mean(dists)) if dists else 0.0, step_idx)
+        self.transition_model.train()
+        return dists

@@ -30,7 +30,12 @@ class ContinuousConv(nn.Module):
                 coordinate_mapping != 'ball_to_cube_volume_preserving' or activation is not None or not use_bias:
             raise NotImplementedError("only the configuration used by models/transmodel.py:86-95 is implemented")
         self.in_channels, self.filters = in_channels, filters
+        # window_function(d^2 / radius^2) -> importance, as Open3D's layer calls it.  The poly6 window of
+        # models/transmodel.py:73-77 is fused into nf_cconv_pairs; it is RECOGNISED by evaluating the callable on a
+        # probe vector.  Any other callable is evaluated on the device for every pair (it is never silently replaced).
+        self.window_function = window_function
         self.use_window = window_function is not None
+        self.fused_window = self.use_window and _is_poly6(window_function)
         self.ignore_query_points = radius_search_ignore_query_points
         self.kernel = nn.Parameter(torch.empty(4, 4, 4, in_channels, filters).uniform_(-0.05, 0.05))
         self.bias = nn.Parameter(torch.zeros(filters))
@@ -42,21 +47,44 @@ class ContinuousConv(nn.Module):
         radius = 0.5 * extent
         idx, rs, d2 = ops.fixed_radius_search(inp_positions, out_positions, radius, self.ignore_query_points)
         self.nns = SimpleNamespace(neighbors_index=idx, neighbors_row_splits=rs, neighbors_distance=d2)
-        pw, pc = cconv_pairs(inp_positions, out_positions, rs, idx, d2, extent, self.use_window)
+        pw, pc = cconv_pairs(inp_positions, out_positions, rs, idx, d2, extent, self.use_window,
+                             window_function=None if (self.fused_window or not self.use_window) else self.window_function)
         zero_w = torch.zeros(self.filters, self.in_channels, device=inp_features.device)
         zero_b = torch.zeros(self.filters, device=inp_features.device)
         return cconv_layer(inp_features, self.kernel, self.bias, zero_w, zero_b, rs, idx, pw, pc, relu=False)
 
 
 # ------------------------------------------------------------------------------------------------
-def cconv_pairs(inp_pos, out_pos, row_splits, nbr, d2, extent, use_window=True, negate=False):
+def _window_poly6(r_sqr):
+    """models/transmodel.py:73-77."""
+    return torch.clamp((1 - r_sqr) ** 3, 0, 1)
+
+
+def _is_poly6(fn):
+    """True when `fn` IS the poly6 window on a probe that covers the clamp on both sides."""
+    probe = torch.tensor([-0.25, 0.0, 1e-3, 0.1, 0.25, 0.5, 0.75, 0.9, 0.999, 1.0, 1.5], dtype=torch.float32)
+    try:
+        got = fn(probe.clone())
+    except Exception:
+        return False
+    return isinstance(got, torch.Tensor) and got.shape == probe.shape and torch.equal(got.float(), _window_poly6(probe))
+
+
+def cconv_pairs(inp_pos, out_pos, row_splits, nbr, d2, extent, use_window=True, negate=False, window_function=None):
+    """Per-pair interpolation data.  window_function=None with use_window: the fused poly6 window; a callable: the
+    pairs are built unwindowed and the 8 corner weights of each pair are scaled by window_function(d^2 / radius^2)."""
     lib = _lib.load()
     nnz = nbr.shape[0]
     cap = ops.round_pairs(nnz)           # bucketed: see ops.round_pairs
     pw = torch.empty(cap * 8, dtype=torch.float32, device=inp_pos.device)[:max(nnz, 1) * 8]
     pc = torch.empty(cap * 8, dtype=torch.uint8, device=inp_pos.device)[:max(nnz, 1) * 8]
+    fused = use_window and window_function is None
     check(lib.nf_cconv_pairs(ptr(inp_pos), ptr(out_pos), ptr(row_splits), ptr(nbr), ptr(d2), out_pos.shape[0],
-                             float(extent), int(use_window), int(negate), ptr(pw), ptr(pc), _lib.stream()), "nf_cconv_pairs")
+                             float(extent), int(fused), int(negate), ptr(pw), ptr(pc), _lib.stream()), "nf_cconv_pairs")
+    if use_window and window_function is not None and nnz > 0:
+        radius = 0.5 * float(extent)
+        imp = window_function(d2[:nnz] / (radius * radius)).to(torch.float32)
+        pw[:nnz * 8].view(nnz, 8).mul_(imp.view(nnz, 1))
     return pw, pc
 
 
@@ -90,7 +118,7 @@ class ParticleNet(nn.Module):
         self.filter_extent = np.float32(6 * self.radius_scale * self.particle_radius)
         self.time_step = timestep
         self.register_buffer('gravity', torch.FloatTensor(gravity))
-        window = (lambda r: r) if use_window else None   # marker only: the poly6 window is fused in nf_cconv_pairs
+        window = self._window_poly6 if use_window else None      # models/transmodel.py:82-85
 
         def conv(cin, cout):
             return ContinuousConv(kernel_size=kernel_size, in_channels=cin, filters=cout, activation=None,
@@ -110,9 +138,11 @@ class ParticleNet(nn.Module):
             setattr(self, f'conv{i}', conv(cin, cout))
             self.denses.append(getattr(self, f'dense{i}'))
             self.convs.append(getattr(self, f'conv{i}'))
-        self._box_cache = (None, None)
+        self._box_cache = (None, None, None)
         self.num_fluid_neighbors = None
         self._graph_cfg, self._graph, self._nnz_seen = None, None, None
+
+    _window_poly6 = staticmethod(_window_poly6)
 
     @property
     def pos_correction(self):
@@ -138,8 +168,10 @@ class ParticleNet(nn.Module):
 
     def _box_grid(self, box):
         key = (box.data_ptr(), box._version, box.shape[0])
-        if self._box_cache[0] != key:
-            self._box_cache = (key, ops.build_grid(box, 0.5 * float(self.filter_extent), firstk=False))
+        if self._box_cache[0] != key or self._box_cache[2] is not box:
+            # the entry keeps `box` alive: a freed block could otherwise be handed to a NEW tensor with the same
+            # (ptr, version, N) and a stale grid would be used silently
+            self._box_cache = (key, ops.build_grid(box, 0.5 * float(self.filter_extent), firstk=False), box)
         return self._box_cache[1]
 
     def update_pos_vel(self, pos, pos_new, y3):
@@ -200,7 +232,7 @@ class ParticleNet(nn.Module):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 outs = body()
-            self._graph = dict(key=key, g=g, sp=sp, sv=sv, outs=outs, cap=cap, count=0)
+            self._graph = dict(key=key, g=g, sp=sp, sv=sv, outs=outs, cap=cap, count=0, refs=(box, box_feats))
         G = self._graph
         G["sp"].copy_(pos)
         G["sv"].copy_(vel)
@@ -264,16 +296,16 @@ class ParticleNet(nn.Module):
         self.num_fluid_neighbors = (f_rs[1:] - f_rs[:-1]).to(torch.float32)   # reduce_subarrays_sum(ones) (:135-138)
         self._y3 = ans[-1]                       # pos_correction (models/transmodel.py:147) is derived on access
         pos_c, vel_c = self.update_pos_vel(pos, pos_new, ans[-1])
-        aux = dict(ans=ans, f=(f_rs, f_idx, f_pw, f_pc), b=(b_rs, b_idx, b_pw, b_pc), pos_new=pos_new, vel_new=vel_new,
-                   fluid_feats=fluid_feats) if keep else None
+        aux = dict(ans=ans, f=(f_rs, f_idx, f_pw, f_pc), f_d2=f_d2, b=(b_rs, b_idx, b_pw, b_pc), pos_new=pos_new,
+                   vel_new=vel_new, fluid_feats=fluid_feats) if keep else None
         return pos_c, vel_c, self.num_fluid_neighbors, aux
 
     def _scene_bbox(self, box):
         """Static grid bounds from the container (cached: no per-step sync); particles that leave it are
         clamped into border cells, which keeps the search exact (include/neurofluid_hip.h)."""
         key = (box.data_ptr(), box._version, box.shape[0])
-        if getattr(self, "_bbox_key", None) != key:
+        if getattr(self, "_bbox_key", None) != key or getattr(self, "_bbox_ref", None) is not box:
             lo, hi = torch.aminmax(box, dim=0)
             self._bbox = tuple((lo - 0.5).tolist()) + tuple((hi + 0.5).tolist())
-            self._bbox_key = key
+            self._bbox_key, self._bbox_ref = key, box
         return self._bbox

@@ -15,7 +15,12 @@
  *        (SURVEY §8c "third-party arithmetic #2").  Row order = ascending point index
  *        (Open3D's order is hash-bucket order; the set per row is what is specified).
  *
- * PARITY: unpinned against the real libraries (neither is importable here).
+ * PARITY: unpinned against the real libraries (neither is importable here) unless the fixtures of
+ * tools/gen_goldens_{pytorch3d,open3d}.py are present (tests/test_oracle_thirdparty.py).
+ *
+ * Queries are independent, so the outer loops are OpenMP-parallel (identical results for any thread count); the
+ * thread count follows omp_set_num_threads / OMP_NUM_THREADS — bench.py's cpu_baseline sets it explicitly and
+ * reports it.
  */
 #include <stdint.h>
 #include <stddef.h>
@@ -35,6 +40,7 @@ void nfo_ball_query_firstk(const float* q, int64_t nq, const float* p, int64_t n
                            float radius, int K, float* dists2, int64_t* idx, float* nn)
 {
     const float r2 = radius * radius;
+#pragma omp parallel for schedule(dynamic, 256)
     for (int64_t i = 0; i < nq; ++i) {
         int cnt = 0;
         float* dd = dists2 + i * K;
@@ -58,6 +64,7 @@ int64_t nfo_radius_count(const float* q, int64_t nq, const float* p, int64_t np,
 {
     const float r2 = radius * radius;
     int64_t tot = 0;
+#pragma omp parallel for schedule(dynamic, 64) reduction(+:tot)
     for (int64_t i = 0; i < nq; ++i) {
         int64_t c = 0;
         const float* qi = q + 3 * i;
@@ -77,6 +84,7 @@ void nfo_radius_csr(const float* q, int64_t nq, const float* p, int64_t np,
                     int32_t* idx, float* dist2)
 {
     const float r2 = radius * radius;
+#pragma omp parallel for schedule(dynamic, 64)
     for (int64_t i = 0; i < nq; ++i) {
         int64_t o = row_splits[i];
         const float* qi = q + 3 * i;
@@ -88,3 +96,13 @@ void nfo_radius_csr(const float* q, int64_t nq, const float* p, int64_t np,
         }
     }
 }
+
+/* thread control for the timed CPU baseline (bench.py): n <= 0 leaves the OpenMP default */
+#ifdef _OPENMP
+#include <omp.h>
+void nfo_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+int nfo_max_threads(void) { return omp_get_max_threads(); }
+#else
+void nfo_set_threads(int n) { (void)n; }
+int nfo_max_threads(void) { return 1; }
+#endif

@@ -24,7 +24,16 @@ def _load():
         build()
         _lib = ctypes.CDLL(_SO)
         _lib.nfo_radius_count.restype = ctypes.c_int64
+        # libgomp would start one thread per VISIBLE core (256 on the GPU boxes, under a 16-CPU quota): cap it
+        _lib.nfo_set_threads(min(len(os.sched_getaffinity(0)), 16))
     return _lib
+
+
+def set_threads(n):
+    """OpenMP threads of the C oracle (its query loops are parallel; results do not depend on the count)."""
+    lib = _load()
+    lib.nfo_set_threads(int(n))
+    return int(lib.nfo_max_threads())
 
 
 def _p(a):

@@ -118,8 +118,9 @@ def radius_search(points, queries, radius, ignore_query_point=True):
     return torch.from_numpy(idx), torch.from_numpy(rs), torch.from_numpy(d2)
 
 
-def cconv(feats, inp_pos, out_pos, extent, kernel, bias, nbr_idx, row_splits, d2, use_window=True):
-    """ContinuousConv forward.  kernel (4,4,4,Cin,Cout) indexed [z][y][x]."""
+def cconv(feats, inp_pos, out_pos, extent, kernel, bias, nbr_idx, row_splits, d2, use_window=True, window_fn=None):
+    """ContinuousConv forward.  kernel (4,4,4,Cin,Cout) indexed [z][y][x].  window_fn: the layer's
+    window_function, called on d^2/radius^2 (default: poly6, transmodel.py:73-77)."""
     n_out = out_pos.shape[0]
     cout = kernel.shape[-1]
     counts = (row_splits[1:] - row_splits[:-1])
@@ -128,7 +129,7 @@ def cconv(feats, inp_pos, out_pos, extent, kernel, bias, nbr_idx, row_splits, d2
     radius = 0.5 * extent
     # Open3D's continuous_conv has gradients w.r.t. filter and input features only: the geometry is detached
     rel = inp_pos.detach()[nbr] - out_pos.detach()[rows]
-    imp = window_poly6(d2 / (radius * radius)) if use_window else torch.ones_like(d2)
+    imp = (window_fn or window_poly6)(d2 / (radius * radius)) if use_window else torch.ones_like(d2)
     cell, w = trilinear(filter_coordinates(rel, extent))
     # G[j, cell, :] = feats[j] @ kernel[cell]  (transform-then-gather; equal to Open3D's
     # gather-then-GEMM up to summation order)

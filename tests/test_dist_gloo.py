@@ -63,3 +63,69 @@ def test_sharded_render_image_equals_unsharded(n_rays, chunk):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def _dp_worker(rank, world, port, q):
+    """Data-parallel training semantics of BaseTrainer (trainers.py): identical model init on every rank, DIFFERENT
+    pixel selections per rank (seed + rank), gradient all-reduce -> identical weights after the step."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import numpy as np
+    from neurofluid_amd import dist as nfdist
+    from neurofluid_amd.trainers import BaseTrainer
+    from configs import Node
+    tr = BaseTrainer.__new__(BaseTrainer)            # the constructor needs a GPU; the seeding logic does not
+    tr.rank, tr.world, tr.local_rank = nfdist.init_from_env(backend="gloo")
+    tr.options = Node({"TRAIN": {"precrop_iters": 0}})
+    tr.seed_everything(10)
+    model = torch.nn.Linear(6, 3)                    # "init_fn": built from the common seed
+    w0 = model.weight.detach().clone()
+    tr.seed_data_streams()
+    H = W = 32
+    rays = torch.arange(H * W * 6, dtype=torch.float32).view(H, W, 6) / (H * W * 6)
+    rgbs = torch.rand(H * W, 3, generator=torch.Generator().manual_seed(0))
+    sel_rays, sel_rgb = tr.sample_pixels(rays, rgbs, H, W, global_step=5, ray_chunk=64)
+    first_pixel = float(sel_rays[0, 0])
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    loss = torch.nn.functional.mse_loss(model(sel_rays), sel_rgb)
+    opt.zero_grad()
+    loss.backward()
+    nfdist.allreduce_grads(list(model.parameters()), world)
+    opt.step()
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (w0, model.weight.detach().clone(), first_pixel, sel_rays.clone()))
+    same_init = all(torch.equal(g[0], gathered[0][0]) for g in gathered)
+    same_final = all(torch.equal(g[1], gathered[0][1]) for g in gathered)
+    different_pixels = not torch.equal(gathered[0][3], gathered[1][3])
+    moved = not torch.equal(gathered[0][0], gathered[0][1])
+    q.put((rank, bool(same_init and same_final and different_pixels and moved)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_ranks_draw_different_pixels_same_weights():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_single_process_keeps_reference_stream():
+    """world == 1: seed_data_streams leaves the reference's single np.random stream untouched."""
+    import numpy as np
+    from neurofluid_amd.trainers import BaseTrainer
+    tr = BaseTrainer.__new__(BaseTrainer)
+    tr.rank, tr.world = 0, 1
+    tr.seed_everything(10)
+    tr.seed_data_streams()
+    a = np.random.choice(1000, size=[8], replace=False)
+    np.random.seed(10)
+    assert np.array_equal(a, np.random.choice(1000, size=[8], replace=False))

@@ -87,8 +87,46 @@ def test_transmodel_eval_and_train(workdir):
     res = TransModelEvaluation(cfg).eval()       # BASELINE config 1: 2..3-step rollout harness
     assert len(res["pred2gt"]) == 3 and all(np.isfinite(res["pred2gt"]))
     assert (workdir / "exps" / "trans" / "res.json").exists()
-    cfg.TRAIN.datapath.train = str(workdir / "data" / "watercube")
+    cfg.TRAIN.datapath.train = cfg.TRAIN.datapath.eval = str(workdir / "data" / "watercube")
     cfg.TRAIN.end_index = 4
-    cfg.TRAIN.N_iters = 2
-    loss = TransModelTrainer(cfg).train()
+    cfg.TRAIN.N_iters = 2                      # EPOCHS over the 2 three-frame windows (trainer_transmodel.py:167-168)
+    cfg.TRAIN.save_interval = 1
+    cfg.TRAIN.grad_clip_value = 1.0
+    tr = TransModelTrainer(cfg)
+    assert len(tr.dataset) == 2 and len(tr.test_dataset) == 2
+    # the loss of one sample, numerically: 0.5*wmse_1 + 0.5*wmse_2 + boundary_1 + boundary_2 (:179-189) vs the oracle
+    from oracle import trans_oracle as to
+    item = tr.test_dataset[0]                  # not rotated
+    with torch.no_grad():
+        loss, parts = tr.sample_loss(tr._to_dev(item))
+    st = {k: v.detach().cpu() for k, v in tr.transition_model.state_dict().items()}
+    q1, w1, m1 = to.particle_net_forward(st, item["particles_pos_0"], item["particles_vel_0"], item["box"], item["box_normals"])
+    q2, w2, m2 = to.particle_net_forward(st, q1, w1, item["box"], item["box_normals"])
+
+    def wmse(pred, gt, n):
+        return torch.mean(torch.exp(-n / 40) * torch.sqrt(torch.sum((pred - gt) ** 2, -1) + 1e-12) ** 0.5)
+
+    def bnd(p):
+        r = 0.025
+        c = torch.stack((p[:, 0].clamp(-1 + r, 1 - r), p[:, 1].clamp(-1 + r, 1 - r), p[:, 2].clamp(-1 + r, 2.4552 - r)), 1)
+        return torch.nn.functional.l1_loss(p, c)
+
+    ref = 0.5 * wmse(q1, item["particles_pos_1"], m1) + 0.5 * wmse(q2, item["particles_pos_2"], m2) + bnd(q1) + bnd(q2)
+    assert abs(float(loss) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref))), (float(loss), float(ref))
+    before = [p.detach().clone() for p in tr.transition_model.parameters()]
+    loss = tr.train()
     assert np.isfinite(float(loss))
+    assert any(not torch.equal(a, b.detach()) for a, b in zip(before, tr.transition_model.parameters()))
+    # one checkpoint per epoch, named by the global step, 'step' = epoch index; rollout dumps of eval()
+    ck = workdir / "exps" / "trans" / "models" / "4.pt"
+    assert ck.exists() and (workdir / "exps" / "trans" / "models" / "2.pt").exists()
+    sd = torch.load(ck)
+    assert set(sd) == {"step", "model_state_dict", "optimizer_state_dict"} and sd["step"] == 1
+    assert (workdir / "exps" / "trans" / "particles" / "4" / "pred_1.obj").exists()
+    # resume restores model AND optimizer state (trainer_transmodel.py:111-115)
+    cfg.resume_from = str(ck)
+    tr2 = TransModelTrainer(cfg)
+    st2 = tr2.optimizer.state_dict()["state"]
+    assert len(st2) > 0 and int(next(iter(st2.values()))["step"]) == 4
+    for a, b in zip(tr.transition_model.parameters(), tr2.transition_model.parameters()):
+        assert torch.equal(a.detach(), b.detach())

@@ -34,7 +34,8 @@ def test_continuous_conv_layer(dev):
     for cin, cout, inp, feats in ((16, 64, P, torch.randn(1200, 16, generator=g)),
                                   (8, 3, P, torch.randn(1200, 8, generator=g)),
                                   (5, 32, box, torch.randn(box.shape[0], 5, generator=g))):
-        conv = ContinuousConv(kernel_size=[4, 4, 4], in_channels=cin, filters=cout, window_function=(lambda r: r))
+        conv = ContinuousConv(kernel_size=[4, 4, 4], in_channels=cin, filters=cout, window_function=to.window_poly6)
+        assert conv.fused_window          # the poly6 callable is recognised -> fused into nf_cconv_pairs
         with torch.no_grad():
             conv.kernel.copy_(torch.randn(4, 4, 4, cin, cout, generator=g) * 0.1)
             conv.bias.copy_(torch.randn(cout, generator=g))
@@ -198,3 +199,155 @@ def test_step_graph_replay(dev):
         assert bool(torch.isnan(a).all())
         with pytest.raises(RuntimeError, match="exceed the capacity"):
             pn3(p, v, box, bn)
+
+
+# ------------------------------------------------------------------------------------------------
+# round 2
+# ------------------------------------------------------------------------------------------------
+def test_window_function_is_evaluated_or_fused(dev):
+    """ContinuousConv(window_function=...) (models/transmodel.py:86-95): the poly6 callable is recognised and fused;
+    ANY other callable is evaluated on d^2/radius^2 for every pair; None means no window."""
+    from neurofluid_amd.transmodel import ContinuousConv, ParticleNet
+    from oracle import render_oracle as ro, trans_oracle as to
+    g = torch.Generator().manual_seed(17)
+    P = ro.watercube_particles()[:900].contiguous()
+    feats = torch.randn(900, 6, generator=g)
+    idx, rs, d2 = to.radius_search(P, P, to.FILTER_EXTENT / 2, True)
+    other = lambda r: torch.clamp(1 - r, 0, 1) ** 2          # noqa: E731
+    for wf, fused, use in ((ParticleNet._window_poly6, True, True), (other, False, True), (None, False, False)):
+        conv = ContinuousConv(kernel_size=[4, 4, 4], in_channels=6, filters=16, window_function=wf)
+        assert conv.fused_window == fused and conv.use_window == use
+        with torch.no_grad():
+            conv.kernel.copy_(torch.randn(4, 4, 4, 6, 16, generator=g) * 0.1)
+            conv.bias.copy_(torch.randn(16, generator=g))
+        conv = conv.to(dev)
+        with torch.no_grad():
+            y = conv(feats.to(dev), P.to(dev), P.to(dev), to.FILTER_EXTENT).cpu()
+        ref = to.cconv(feats, P, P, to.FILTER_EXTENT, conv.kernel.detach().cpu(), conv.bias.detach().cpu(), idx, rs, d2,
+                       use_window=use, window_fn=wf)
+        torch.testing.assert_close(y, ref, rtol=1e-4, atol=2e-5)
+    # the three variants must differ from one another, otherwise the window was ignored
+    a = to.cconv(feats, P, P, to.FILTER_EXTENT, conv.kernel.detach().cpu(), conv.bias.detach().cpu(), idx, rs, d2)
+    b = to.cconv(feats, P, P, to.FILTER_EXTENT, conv.kernel.detach().cpu(), conv.bias.detach().cpu(), idx, rs, d2,
+                 window_fn=other)
+    assert float((a - b).abs().max()) > 1e-3
+
+
+def test_two_step_unroll_backward_vs_oracle_autograd(dev):
+    """trainer_transmodel.py:179-189: the model runs TWICE before loss.backward() (state not detached in between).
+    Every call must differentiate with ITS OWN neighbour lists / pair distances (round 1 read the second call's
+    distances from module state while back-propagating the first call).  Loss, parameter gradients and input gradients
+    vs torch autograd through the oracle; the two steps see different pair lists because the particles moved."""
+    from oracle import render_oracle as ro, trans_oracle as to
+    pn, _ = make_pn(dev)
+    P = ro.watercube_particles()[::2].contiguous()
+    V = torch.randn(P.shape, generator=torch.Generator().manual_seed(4)) * 0.5
+    box, bn = to.watercube_box()
+    t1 = P + 0.01 * torch.randn(P.shape, generator=torch.Generator().manual_seed(5))
+    t2 = P + 0.02 * torch.randn(P.shape, generator=torch.Generator().manual_seed(6))
+
+    def wmse(pred, gt, n):
+        imp = torch.exp(-(1 / 40) * n)
+        return torch.mean(imp * torch.sqrt(torch.sum((pred - gt) ** 2, dim=-1) + 1e-12) ** 0.5)
+
+    Pd, Vd = P.to(dev).requires_grad_(True), V.to(dev).requires_grad_(True)
+    p1, v1, n1 = pn(Pd, Vd, box.to(dev), bn.to(dev))
+    nnz1 = int(pn.conv0_fluid.nns.neighbors_row_splits[-1])
+    p2, v2, n2 = pn(p1, v1, box.to(dev), bn.to(dev))
+    nnz2 = int(pn.conv0_fluid.nns.neighbors_row_splits[-1])
+    assert nnz1 != nnz2, "the two unrolled steps must see different pair lists for this test to bite"
+    loss = 0.5 * wmse(p1, t1.to(dev), n1) + 0.5 * wmse(p2, t2.to(dev), n2)
+    loss.backward()
+    st = _oracle_state_with_grad()
+    Po, Vo = P.clone().requires_grad_(True), V.clone().requires_grad_(True)
+    q1, w1, m1 = to.particle_net_forward(st, Po, Vo, box, bn)
+    q2, w2, m2 = to.particle_net_forward(st, q1, w1, box, bn)
+    assert torch.equal(n1.cpu(), m1) and torch.equal(n2.cpu(), m2)
+    lo = 0.5 * wmse(q1, t1, m1) + 0.5 * wmse(q2, t2, m2)
+    lo.backward()
+    assert abs(float(loss.detach()) - float(lo.detach())) <= 1e-5 * abs(float(lo.detach()))
+    worst = 0.0
+    for name, prm in pn.named_parameters():
+        ref = st[name].grad
+        rel = float((prm.grad.cpu() - ref).norm() / ref.norm())
+        worst = max(worst, rel)
+        assert rel < 2e-3, (name, rel)
+    for got, ref, nm in ((Pd.grad, Po.grad, "pos"), (Vd.grad, Vo.grad, "vel")):
+        rel = float((got.cpu() - ref).norm() / ref.norm())
+        assert rel < 2e-3, (nm, rel)
+    print("2-step unroll: worst relative parameter-gradient error", worst, " pairs", nnz1, nnz2)
+
+
+def _rollout(dev, P, frames, reseed_every=None, calibrate=False):
+    """HIP rollout vs oracle rollout from the same initial state; returns per-frame lists
+      free:    mean L2, both sides carrying their own state (eval_transmodel.py:98-99)
+      stepped: mean L2 of ONE step, the oracle stepping from the HIP path's previous state (sampled frames)
+      noise:   (calibrate) mean L2 between the oracle and the SAME oracle started one fp32 ulp away — how much of the
+               free-running difference is the algorithm's own sensitivity (the dynamics amplify rounding noise)."""
+    from oracle import trans_oracle as to
+    pn, st = make_pn(dev)
+    box, bn = to.watercube_box()
+    boxd, bnd = box.to(dev), bn.to(dev)
+    p_h, v_h = P.to(dev), torch.zeros_like(P).to(dev)
+    p_o, v_o = P.clone(), torch.zeros_like(P)
+    if calibrate:
+        up = torch.rand(P.shape, generator=torch.Generator().manual_seed(1)) < 0.5
+        p_n = torch.where(up, torch.nextafter(P, torch.full_like(P, 10.0)), P)
+        v_n = torch.zeros_like(P)
+    free, stepped, noise = [], [], []
+    for f in range(frames):
+        prev = (p_h.cpu(), v_h.cpu())
+        with torch.no_grad():
+            p_h, v_h, n_h = pn(p_h, v_h, boxd, bnd)
+        p_o, v_o, _ = to.particle_net_forward(st, p_o, v_o, box, bn)
+        free.append(float((p_h.cpu() - p_o).norm(dim=-1).mean()))
+        if calibrate:
+            p_n, v_n, _ = to.particle_net_forward(st, p_n, v_n, box, bn)
+            noise.append(float((p_n - p_o).norm(dim=-1).mean()))
+        if reseed_every and (f % reseed_every == 0 or f == frames - 1):
+            p_s, v_s, n_s = to.particle_net_forward(st, prev[0], prev[1], box, bn)
+            assert torch.equal(n_h.cpu(), n_s), f
+            stepped.append(float((p_h.cpu() - p_s).norm(dim=-1).mean()))
+    return free, stepped, noise
+
+
+def test_rollout_50_frames_full_size(dev):
+    """BASELINE config 3 (train_e2e.py watercube, 50-frame rollout, trainer/trainer_e2e.py:161-199): the FULL 4 913-
+    particle cloud rolled out 50 frames, HIP and oracle each carrying their own state; mean L2 per frame <= 1e-4
+    (measured 3.9e-7 at frame 50); one-step error from the HIP state every 10th frame <= 1e-6 (measured < 1e-9)."""
+    from oracle import render_oracle as ro
+    free, stepped, _ = _rollout(dev, ro.watercube_particles(), 50, reseed_every=10)
+    print("50-frame rollout: free-running mean L2 max", max(free), " last", free[-1], " per-step max", max(stepped))
+    assert max(free) <= ROLLOUT_MEAN_L2, max(free)
+    assert max(stepped) <= 1e-6, max(stepped)
+
+
+def test_rollout_60_frames_bunny(dev):
+    """BASELINE config 4's body (bunny, 60 test frames: configs/dataset.yaml), index order = random permutation."""
+    from neurofluid_amd import synthetic
+    free, stepped, _ = _rollout(dev, synthetic.shaped_particles("bunny", order="random"), 60, reseed_every=15)
+    print("bunny 60-frame rollout: free-running mean L2 max", max(free), " per-step max", max(stepped))
+    assert max(free) <= ROLLOUT_MEAN_L2, max(free)
+    assert max(stepped) <= 1e-6, max(stepped)
+
+
+def test_rollout_200_frames_honeycone(dev):
+    """BASELINE config 5 (honeycone, 200-frame rollout), index order = random permutation, all 200 frames free-running
+    on both sides.  What can be asserted over 200 frames, and why: with the closed-form synthetic weights the body
+    falls freely and disperses, and the map amplifies any fp32 rounding difference by ~1.09x per frame (measured), so
+    HIP and oracle — like ANY two fp32 evaluation orders of the reference, its own CPU and CUDA paths included —
+    separate exponentially: 2e-5 at frame 100, 1e-4 around frame 118, 5e-2 at frame 200.  Asserted:
+      (a) mean L2 <= 1e-4 for the first 100 frames (the stated bar, with the full 4 350-particle cloud);
+      (b) over ALL 200 frames the HIP-vs-oracle distance stays below the oracle's own sensitivity to a ONE-ULP
+          perturbation of the initial positions (oracle vs oracle started 1 ulp away) — the implementation is inside the
+          algorithm's noise floor at every frame;
+      (c) the one-step error (oracle stepping from the HIP state) every 20th frame <= 1e-6 (measured <= 3e-9): no drift
+          that the chaotic growth could be hiding."""
+    from neurofluid_amd import synthetic
+    free, stepped, noise = _rollout(dev, synthetic.shaped_particles("honeycone", order="random"), 200, reseed_every=20,
+                                    calibrate=True)
+    print("honeycone 200-frame rollout: free-running mean L2 @50/100/150/200", free[49], free[99], free[149], free[199],
+          " 1-ulp-noise @50/100/150/200", noise[49], noise[99], noise[149], noise[199], " per-step max", max(stepped))
+    assert max(free[:100]) <= ROLLOUT_MEAN_L2, max(free[:100])
+    assert all(f <= max(n, 1e-7) for f, n in zip(free, noise)), max(f / max(n, 1e-7) for f, n in zip(free, noise))
+    assert max(stepped) <= 1e-6, max(stepped)

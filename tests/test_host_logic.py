@@ -120,3 +120,35 @@ def test_host_cpu_budget():
         assert neurofluid_amd.limit_host_threads() <= max(2, torch.get_num_threads())
     finally:
         del os.environ["NF_HOST_THREADS"]
+
+
+def test_pixel_sampler_readahead_is_invisible_and_errors_surface():
+    """PixelSampler (train_step.py): same selections as drawing inline from the stream; close() joins the worker and
+    rewinds the stream to before the first unconsumed draw; a worker exception is re-raised by next()."""
+    import numpy as np
+    import pytest
+    from neurofluid_amd.train_step import PixelSampler
+    rng = np.random.RandomState(3)
+    s = PixelSampler(rng, n_views=2, ray_chunk=16, n_pixels_of_step=lambda step: 100, first_step=7)
+    got = [s.next(7), s.next(8), s.next(9)]
+    s.close()
+    assert not s.t.is_alive()
+    after = rng.randint(1 << 30)
+    ref = np.random.RandomState(3)
+    want = [[ref.choice(100, size=[16], replace=False) for _ in range(2)] for _ in range(3)]
+    for a, b in zip(got, want):
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    assert after == ref.randint(1 << 30)          # the read-ahead draws were rewound
+    # the module-level stream works the same way (the trainers pass np.random itself)
+    np.random.seed(11)
+    s = PixelSampler(np.random, 1, 8, lambda step: 50, 0)
+    a = s.next(0)
+    s.close()
+    b = np.random.randint(1 << 30)
+    np.random.seed(11)
+    assert np.array_equal(a[0], np.random.choice(50, size=[8], replace=False)) and b == np.random.randint(1 << 30)
+    # fewer pixels than ray_chunk: ValueError in the worker -> raised in the consumer, no hang
+    s = PixelSampler(np.random.RandomState(0), 1, 64, lambda step: 10, 0)
+    with pytest.raises(ValueError):
+        s.next(0)
+    s.close()

@@ -1,21 +1,31 @@
 #!/usr/bin/env python3
 """bench.py — NeuroFluid hot path on MI355X: rays/sec (+ particle-steps/sec), synthetic watercube 400^2.
 
-  python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W [--scaling weak|strong] [--image 400|800] [--workload render|train]
+  (N>1: launched by torch.distributed.run, one rank per GPU over RCCL)
 
-One "step" (weak scaling, per-GPU work fixed) = the coupled per-frame body of the reference's e2e loop
-(eval_e2e.py:58-134): one ParticleNet transition step on the 4 913-particle cloud (replicated on every rank),
-then the full coarse+fine render of N 400x400 views (N = number of GPUs), 1024-ray-granular chunks interleaved
-over the ranks, RGB tiles all-gathered over RCCL.  With --workload train the step is instead one
-train_renderer.py optimiser step (4 views x 1024 rays per rank, forward + backward + Adam, gradients
-all-reduced) — BASELINE.json configs[1].
+One "step" = the coupled per-frame body of the reference's e2e loop (eval_e2e.py:58-134): one ParticleNet transition
+step on the 4 913-particle cloud (replicated on every rank: the step does not shard), a rebuild of the renderer's
+particle grid (the cloud moved), then the full coarse+fine render, RGB tiles all-gathered over RCCL inside the timed
+region.
+  --scaling weak   (default; what the driver's N=1/2/4/8 runs measure): N views of 400x400, view k -> rank k mod N —
+                   per-GPU work fixed.
+  --scaling strong ONE image (--image 400 or 800) split into 1024-multiple ray chunks interleaved over the ranks
+                   (chunk k -> rank k mod N, the seam of trainer/basetrainer.py:282-289) — total work fixed; the JSON
+                   then also carries the executed MLP rows of every rank and their max/mean imbalance, next to the
+                   imbalance the same chunks would give under a contiguous assignment.
+With --workload train the step is one train_renderer.py optimiser step (4 views x 1024 rays per rank, forward +
+backward + Adam, gradients all-reduced) — BASELINE.json configs[1].
 Prints ONE JSON line on rank 0 (contract in the task statement) incl. `roofline` (dominant kernel = the fp32-MFMA
-NeRF MLP, timed with HIP events on its stream) and `cpu_baseline` (the oracle = CPU port, timed on the host cores).
+NeRF MLP, timed live with HIP events on its launch stream) and `cpu_baseline` (the oracle = CPU port of the reference
+path, timed on the host cores: 1 warm-up + 3 repetitions on all budgeted threads, and a 1-thread figure).
 """
 import argparse
+import hashlib
 import json
 import math
 import os
+import subprocess
 import sys
 import time
 
@@ -27,6 +37,8 @@ import torch  # noqa: E402
 MLP_FLOP_PER_ROW = 1331968          # 665 984 MAC per sample
 PARTICLE_STEP_FLOP = 1385088
 F32_MATRIX_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+F16_MATRIX_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense fp16 MFMA
+PMC_FILES = ("round2_mlp_pmc.json", "round1_mlp_pmc.json")      # newest first
 
 
 def renderer_cfg():
@@ -36,34 +48,103 @@ def renderer_cfg():
                               same_smooth_factor=False))
 
 
-def build_scene(dev):
+def build_scene(image):
     from neurofluid_amd.synthetic import watercube_scene      # scene + closed-form weights (host-side, not timed)
-    return watercube_scene(400, 400)
+    return watercube_scene(image, image)
 
 
-def cpu_baseline(scene):
-    """The oracle (CPU port of the reference path) on a bounded, representative sample (about 10-30 s of CPU work):
-    every 40th ray of the 400^2 image (4000 rays, same hit ratio as the full frame) + 5 transition steps.
-    torch intra-op threads are capped at 16: the oracle's ops are small and lose time beyond that."""
-    from oracle import render_oracle as ro, trans_oracle as to
+def _median(xs):
+    xs = sorted(xs)
+    return xs[len(xs) // 2]
+
+
+def cpu_baseline(scene400):
+    """The oracle (CPU port of the reference path) on a bounded, representative sample, about 20-30 s of CPU work:
+      n-thread: every 160th ray of the 400^2 image (1000 rays, same hit ratio as the full frame), 1 warm-up + 3 timed
+                repetitions (median); 2 warm + 3 x 2 transition steps on the 4 913 particles
+      1-thread: every 640th ray (250 rays), 1 repetition after a 25-ray warm-up; 2 transition steps
+    Threads: torch intra-op AND the C neighbour oracle's OpenMP loops are set to the same count (the process's CPU
+    budget, capped at 16: the oracle's ops are small and lose time beyond that)."""
+    from oracle import neighbors, render_oracle as ro, trans_oracle as to
     from neurofluid_amd import effective_cpus
-    cores = min(effective_cpus(), 16)
+    cores = max(1, min(effective_cpus(), 16))
+    sc = scene400
+    ro_ = sc["c2w"][:, 3]
+
+    def render_rate(rays, reps, warm_rays):
+        ro.render_forward(sc["nerf_state"], sc["P"], ro_, warm_rays, 9.0, 13.0)
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            ro.render_forward(sc["nerf_state"], sc["P"], ro_, rays, 9.0, 13.0)
+            ts.append(time.perf_counter() - t0)
+        return rays.shape[0] / _median(ts), ts
+
+    def trans_rate(reps, nsteps, warm):
+        p, v = sc["P"], torch.zeros_like(sc["P"])
+        for _ in range(warm):
+            p, v, _ = to.particle_net_forward(sc["trans_state"], p, v, sc["box"], sc["bn"])
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            for _ in range(nsteps):
+                p, v, _ = to.particle_net_forward(sc["trans_state"], p, v, sc["box"], sc["bn"])
+            ts.append((time.perf_counter() - t0) / nsteps)
+        return sc["P"].shape[0] / _median(ts), ts
+
+    t_all = time.perf_counter()
+    old = torch.get_num_threads()
     torch.set_num_threads(cores)
-    rays = scene["rays"][::40].contiguous()
-    t0 = time.time()
-    ro.render_forward(scene["nerf_state"], scene["P"], scene["c2w"][:, 3], rays, 9.0, 13.0)
-    dt = time.time() - t0
-    t1 = time.time()
-    p, v = scene["P"], torch.zeros_like(scene["P"])
-    nsteps = 5
-    for _ in range(nsteps):
-        p, v, _ = to.particle_net_forward(scene["trans_state"], p, v, scene["box"], scene["bn"])
-    dts = time.time() - t1
-    return {"value": rays.shape[0] / dt, "unit": "rays/s", "cores": cores, "kind": "port",
-            "sample": f"oracle.render_forward on every 40th ray of the 400x400 frame ({rays.shape[0]} rays, {dt:.1f} s); "
-                      f"oracle.particle_net_forward x{nsteps} on 4913 particles ({dts:.1f} s); "
-                      f"{cores} torch threads ({os.cpu_count()} host cores visible, CPU budget {effective_cpus()})",
-            "particle_steps_per_sec": scene["P"].shape[0] * nsteps / dts}
+    neighbors.set_threads(cores)
+    rays_n = sc["rays"][::160].contiguous()
+    r_n, ts_n = render_rate(rays_n, 3, rays_n)
+    p_n, _ = trans_rate(3, 2, 2)
+    torch.set_num_threads(1)
+    neighbors.set_threads(1)
+    rays_1 = sc["rays"][::640].contiguous()
+    r_1, ts_1 = render_rate(rays_1, 1, rays_1[::10].contiguous())
+    p_1, _ = trans_rate(1, 2, 0)
+    torch.set_num_threads(old)
+    neighbors.set_threads(cores)
+    return {"value": r_n, "unit": "rays/s", "cores": cores, "kind": "port",
+            "sample": f"oracle.render_forward on every 160th ray of the 400x400 frame ({rays_n.shape[0]} rays; 1 warm-up + 3 "
+                      f"repetitions, median of {[round(t, 2) for t in ts_n]} s) and oracle.particle_net_forward (4913 particles, "
+                      f"2 warm + 3 x 2 steps) on {cores} threads (torch intra-op + OpenMP neighbour search); 1-thread figures "
+                      f"on every 640th ray ({rays_1.shape[0]} rays) and 2 steps; {os.cpu_count()} host cores visible, CPU budget "
+                      f"{effective_cpus()}; {time.perf_counter() - t_all:.0f} s in total",
+            "particle_steps_per_sec": p_n, "value_1_thread": r_1, "particle_steps_per_sec_1_thread": p_1}
+
+
+def _git_blob(path):
+    try:
+        return subprocess.check_output(["git", "hash-object", path], cwd=ROOT, stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:          # noqa: BLE001  (no git on the box: hash the bytes the same way git does)
+        data = open(path, "rb").read()
+        return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+def committed_traffic():
+    """HBM bytes per launch of the dominant kernel from the COMMITTED rocprofv3 PMC passes of this command (PMC counters
+    cannot be read from inside the process; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, tools/summarize_profiles.py).
+    Returns (bytes, source description)."""
+    for name in PMC_FILES:
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            d = json.load(open(path))
+            return d.get("hbm_bytes_per_launch"), {"file": "profiles/" + name, "git_blob": _git_blob(path),
+                                                   "kernel": d.get("kernel"), "launches_profiled": d.get("launches_profiled"),
+                                                   "note": "recorded by separate rocprofv3 --pmc passes of `bench.py --no-cpu-"
+                                                           "baseline`, NOT measured by this run"}
+    return None, None
+
+
+def imbalance(per_chunk_rows, world, interleaved=True):
+    n = len(per_chunk_rows)
+    loads = [0] * world
+    for k, r in enumerate(per_chunk_rows):
+        loads[(k % world) if interleaved else min(k * world // n, world - 1)] += r
+    mean = sum(loads) / world
+    return (max(loads) / mean) if mean > 0 else 1.0
 
 
 def main():
@@ -72,9 +153,12 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="render", choices=["render", "train"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--image", type=int, default=400, choices=[400, 800], help="image edge of --scaling strong")
     ap.add_argument("--chunk", type=int, default=0,
-                    help="device ray chunk; 0 = one whole 400x400 view per fused call (results are chunk-independent)")
+                    help="rays per chunk dealt to the ranks (multiple of 1024). 0 = weak: one whole 400x400 view; strong: 1024")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the fp16 / train-step / particle-step extras")
     args = ap.parse_args()
 
     from neurofluid_amd import dist as nfdist, ops
@@ -84,19 +168,27 @@ def main():
     import torch.distributed as dist
 
     # dev switch: NF_BENCH_SINGLE_DEVICE=1 runs an N-rank job on ONE GPU over gloo, to exercise the multi-rank control
-    # flow (sharding, collectives, timing protocol) where only one device exists; it is not a performance mode
+    # flow (sharding, collectives, timing protocol, load-balance accounting) where only one device exists; its
+    # throughput is NOT a scaling measurement (the ranks time-share one GPU) and the JSON says so
     single_dev = os.environ.get("NF_BENCH_SINGLE_DEVICE") == "1"
     rank, world, local = nfdist.init_from_env("gloo" if single_dev else None)
     if single_dev:
         local = 0
-    if args.chunk <= 0:
-        args.chunk = 400 * 400      # weak scaling: chunk k = view k -> rank k mod N, identical load on every rank
     assert world == args.gpus or (args.gpus == 1 and world == 1), f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    strong = args.scaling == "strong"
+    image = args.image if strong else 400
+    if args.chunk <= 0:
+        # strong: the reference's own 1024-ray chunk is the unit dealt to the ranks (chunk k -> rank k mod N); every rank
+        # renders all its chunks in ONE fused call (render_loop.render_image), so balance is 1024-ray-fine at full-GPU
+        # launch sizes.  weak: chunk k = view k -> rank k mod N, identical load on every rank.
+        args.chunk = 1024 if strong else 400 * 400
+    assert args.chunk % 1024 == 0 or args.chunk == 400 * 400, "--chunk must be a multiple of the reference's 1024-ray chunk"
+    device_chunk = 1 << 22      # rays per fused renderer call: everything a rank owns
 
-    scene = build_scene(dev)
+    scene = build_scene(image)
     net = RenderNet(renderer_cfg(), 9.0, 13.0)
     net.load_state_dict(scene["nerf_state"], strict=True)
     net = net.to(dev)
@@ -106,9 +198,10 @@ def main():
     P0 = scene["P"].to(dev)
     box, bn = scene["box"].to(dev), scene["bn"].to(dev)
     roc = scene["c2w"][:, 3].to(dev)
-    n_views = world
-    rays = scene["rays"].to(dev).repeat(n_views, 1).contiguous()      # N views of the synthetic camera (weak scaling)
+    n_views = 1 if strong else world
+    rays = scene["rays"].to(dev).repeat(n_views, 1).contiguous()      # weak: N views of the synthetic camera
     n_rays = rays.shape[0]
+    n_chunks = (n_rays + args.chunk - 1) // args.chunk
 
     ops.PROFILE = None
     state = {"pos": P0.clone(), "vel": torch.zeros_like(P0)}
@@ -116,10 +209,12 @@ def main():
     def step_render():
         with torch.no_grad():
             state["pos"], state["vel"], _ = pn(state["pos"], state["vel"], box, bn)
-            # every step renders the same (initial) cloud so that step time is stationary; the transition
-            # step above is real work on the evolving state
-            out = render_image(net, P0, n_rays, roc, rays, None, None, iseval=True, ray_chunk=args.chunk,
-                               rank=rank, world=world, gather=False)
+            # The rendered cloud is the initial one, so that step time is stationary (the synthetic weights let the
+            # body fall out of view within a few frames); the transition step above is real work on the evolving
+            # state, and the renderer's particle grid is REBUILT every step, as a real rollout must (the cloud moved)
+            net.invalidate_grid()
+            out = render_image(net, P0, n_rays, roc, rays, None, None, iseval=True, ray_chunk=args.chunk, rank=rank,
+                               world=world, gather=False, device_chunk=device_chunk)      # gather=False: RGB tiles only
         return out
 
     if args.workload == "train":
@@ -146,8 +241,6 @@ def main():
     for _ in range(args.steps):
         out = step_fn()
         host_marks.append(time.perf_counter() - t0)
-        if os.environ.get('NF_BENCH_DEBUG'):
-            host_marks.append(-torch.cuda.memory_reserved() / 1e9)
     sync()
     dt = time.perf_counter() - t0
     prof = ops.PROFILE
@@ -159,41 +252,61 @@ def main():
     rays_per_step = n_rays if args.workload == "render" else 4096 * world
     value = rays_per_step * args.steps / dt
 
-    # ---- roofline of the dominant kernel (this rank's launches)
+    # ---- roofline of the dominant kernel (this rank's launches), HIP events on the launch stream
     mlp_ms = sum(a.elapsed_time(b) for a, b in prof["mlp"])
     rows = sum(prof["rows"])
-    mult = 1.0 if args.workload == "render" else 1.0
     n_launch = max(len(prof["mlp"]), 1)
-    achieved = rows * MLP_FLOP_PER_ROW * mult / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "round1_mlp_pmc.json")
-    if args.workload == "render" and os.path.exists(pmc):
-        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
-        # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, tools/summarize_profiles.py)
-        traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-    roofline = {"bound": "mfma", "kernel": "k_mlp_fwd_l (fp32 v_mfma_f32_32x32x2_f32, weights through an LDS ring)", "achieved": achieved,
-                "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_MATRIX_PEAK_TFLOPS,
-                "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)", "launches": len(prof["mlp"]), "avg_launch_ms": mlp_ms / n_launch,
-                "executed_rows_per_step": rows / args.steps,
-                "flop_per_row": MLP_FLOP_PER_ROW, "mlp_ms_per_step": mlp_ms / args.steps}
+    achieved = rows * MLP_FLOP_PER_ROW / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
+    traffic, traffic_src = committed_traffic() if args.workload == "render" and not strong else (None, None)
+    roofline = {"bound": "mfma", "kernel": "k_mlp_fwd_l (fp32 v_mfma_f32_32x32x2_f32, weights through an LDS ring)",
+                "achieved": achieved, "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_MATRIX_PEAK_TFLOPS,
+                "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": traffic_src,
+                "launches": len(prof["mlp"]), "avg_launch_ms": mlp_ms / n_launch,
+                "executed_rows_per_step": rows / args.steps, "flop_per_row": MLP_FLOP_PER_ROW,
+                "mlp_ms_per_step": mlp_ms / args.steps}
 
-    # ---- transition model alone (particle-steps/sec), rank 0 state
-    tp, tv = P0.clone(), torch.zeros_like(P0)
-    for _ in range(3):
-        with torch.no_grad():
-            tp, tv, _ = pn(tp, tv, box, bn)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    nts = 20
-    for _ in range(nts):
-        with torch.no_grad():
-            tp, tv, _ = pn(tp, tv, box, bn)
-    torch.cuda.synchronize()
-    pstep = P0.shape[0] * nts / (time.perf_counter() - t1)
+    # ---- load balance: executed MLP rows of every rank (measured); per-1024-ray-chunk rows (from the masks of one
+    # untimed single-rank render) for the what-if table: interleaved vs contiguous dealing at 2 / 4 / 8 ranks
+    balance = None
+    if args.workload == "render":
+        rows_rank = float(rows) / args.steps
+        if world > 1:
+            per_rank = [None] * world
+            dist.all_gather_object(per_rank, rows_rank)
+        else:
+            per_rank = [rows_rank]
+        mean = sum(per_rank) / len(per_rank)
+        balance = {"executed_rows_per_rank_per_step": per_rank, "max_over_mean": (max(per_rank) / mean) if mean > 0 else 1.0,
+                   "n_chunks": n_chunks, "chunk_rays": args.chunk}
+        if strong and rank == 0:
+            with torch.no_grad():
+                full = render_image(net, P0, n_rays, roc, rays, None, None, iseval=True, ray_chunk=1024, device_chunk=device_chunk)
+            per_ray = (full["mask_0"] + full["mask_1"]).view(-1)
+            pad = (-per_ray.shape[0]) % 1024
+            chunks = torch.cat([per_ray, per_ray.new_zeros(pad)]).view(-1, 1024).sum(1).tolist()
+            balance["what_if_max_over_mean_1024_ray_chunks"] = {
+                str(g): {"interleaved": round(imbalance(chunks, g, True), 4), "contiguous": round(imbalance(chunks, g, False), 4)}
+                for g in (2, 4, 8)}
+            balance["chunks_without_active_rows"] = int(sum(1 for c in chunks if c == 0))
+
+    pstep = fp16_extra = train_extra = None
+    if not args.no_extras:
+        # ---- transition model alone (particle-steps/sec), rank-local state
+        tp, tv = P0.clone(), torch.zeros_like(P0)
+        for _ in range(3):
+            with torch.no_grad():
+                tp, tv, _ = pn(tp, tv, box, bn)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        nts = 20
+        for _ in range(nts):
+            with torch.no_grad():
+                tp, tv, _ = pn(tp, tv, box, bn)
+        torch.cuda.synchronize()
+        pstep = P0.shape[0] * nts / (time.perf_counter() - t1)
 
     # ---- extra (NOT the headline, which stays fp32): the same render step with the fp16-MFMA MLP (BASELINE config 5)
-    fp16_extra = None
-    if args.workload == "render":
+    if args.workload == "render" and not args.no_extras:
         cfg16 = renderer_cfg(); cfg16["mlp_dtype"] = "fp16"
         net16 = RenderNet(cfg16, 9.0, 13.0)
         net16.load_state_dict(scene["nerf_state"], strict=True)
@@ -201,27 +314,29 @@ def main():
 
         def step16():
             with torch.no_grad():
+                net16.invalidate_grid()
                 return render_image(net16, P0, n_rays, roc, rays, None, None, iseval=True, ray_chunk=args.chunk,
-                                    rank=rank, world=world, gather=False)
+                                    rank=rank, world=world, gather=False, device_chunk=device_chunk)
         out16 = step16()
         sync()
+        ops.PROFILE = {"mlp": [], "rows": []}
         t2 = time.perf_counter()
         for _ in range(3):
             out16 = step16()
         sync()
         dt16 = (time.perf_counter() - t2) / 3
-        mine = nfdist.my_chunks((n_rays + args.chunk - 1) // args.chunk, rank, world)
-        a = out["pred_rgbs_1"] if world == 1 else None
-        psnr16 = None
-        if world == 1:
-            mse = torch.mean((out16["pred_rgbs_1"] - out["pred_rgbs_1"]) ** 2).item()
-            psnr16 = (-10.0 * math.log10(mse)) if mse > 0 else float("inf")
+        p16 = ops.PROFILE
+        ops.PROFILE = None
+        ms16 = sum(a.elapsed_time(b) for a, b in p16["mlp"])
+        ach16 = sum(p16["rows"]) * MLP_FLOP_PER_ROW / (ms16 * 1e-3) / 1e12 if ms16 > 0 else 0.0
+        mse = torch.mean((out16["pred_rgbs_1"] - out["pred_rgbs_1"]) ** 2).item()
+        psnr16 = (-10.0 * math.log10(mse)) if mse > 0 else float("inf")
         fp16_extra = {"rays_per_sec": n_rays / dt16, "ms_per_step": dt16 * 1e3, "dtype": "f16 MFMA, f32 accumulate",
-                      "psnr_vs_f32_path_db": psnr16, "note": "render only (no transition step); not the headline value"}
+                      "psnr_vs_f32_path_db": psnr16, "mlp_tflops": ach16, "mlp_frac_of_dense_f16_peak": ach16 / F16_MATRIX_PEAK_TFLOPS,
+                      "note": "render only (grid rebuild included, no transition step); not the headline value"}
 
     # ---- extra: BASELINE configs[1] (train_renderer.py step: 4 views x 1024 rays, fwd + bwd + Adam) on this rank
-    train_extra = None
-    if args.workload == "render":
+    if args.workload == "render" and not args.no_extras and not strong:
         from neurofluid_amd.train_step import make_train_step
         net_t = RenderNet(renderer_cfg(), 9.0, 13.0)
         net_t.load_state_dict(scene["nerf_state"], strict=True)
@@ -239,27 +354,33 @@ def main():
                        "ms_per_step": dtt * 1e3, "rays_per_sec": 4096 * world / dtt}
 
     if rank == 0:
-        res = {"metric": ("rays/sec (renderer coarse+fine forward) coupled with one transition step per frame, watercube 400^2"
+        if args.workload == "render":
+            wl = ("eval_e2e per-frame body: ParticleNet step (4913 particles, replicated) + grid rebuild + full %dx%d "
+                  "coarse+fine render of %d view(s), %d rays, %d chunk(s) of %d rays interleaved over %d rank(s), RGB "
+                  "all-gather" % (image, image, n_views, n_rays, n_chunks, args.chunk, world))
+        else:
+            wl = "train_renderer.py step: 4 views x 1024 rays per rank, fwd+bwd+Adam"
+        res = {"metric": ("rays/sec (renderer coarse+fine forward) coupled with one transition step per frame, watercube %d^2" % image
                           if args.workload == "render" else
                           "rays/sec of the train_renderer.py optimiser step (forward + backward + Adam), watercube 400^2"),
                "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
-               "config": {"workload": ("eval_e2e per-frame body: ParticleNet step (4913 particles, replicated) + full 400x400 "
-                                       "coarse+fine render of %d view(s), 160000 rays each, chunks of %d rays interleaved over "
-                                       "%d rank(s)" % (n_views, args.chunk, world)) if args.workload == "render" else
-                                      "train_renderer.py step: 4 views x 1024 rays per rank, fwd+bwd+Adam",
-                          "particles": int(P0.shape[0]), "image": "400x400", "N_samples": 64, "N_importance": 128,
-                          "K": 20, "use_mask": True, "device_ray_chunk": args.chunk},
+               "config": {"workload": wl, "particles": int(P0.shape[0]), "image": "%dx%d" % (image, image), "N_samples": 64,
+                          "N_importance": 128, "K": 20, "use_mask": True, "device_ray_chunk": args.chunk},
                "particle_steps_per_sec": pstep,
                "particle_steps_note": "ParticleNet.forward alone on one GPU; the 4913-particle step does not shard (replicas only: "
                                       "every rank advances the same state), so this figure is per replica, not multiplied by N",
-               "roofline": roofline, "fp16_mfma_path": fp16_extra, "train_step": train_extra}
+               "roofline": roofline, "load_balance": balance, "fp16_mfma_path": fp16_extra, "train_step": train_extra}
+        if single_dev and world > 1:
+            res["single_device_emulation"] = ("NF_BENCH_SINGLE_DEVICE=1: %d ranks time-share ONE GPU over gloo; control flow and "
+                                              "load-balance accounting are real, `value` is not a scaling measurement" % world)
         if os.environ.get("NF_BENCH_DEBUG"):
             res["host_marks_ms"] = [round(m * 1e3, 2) for m in host_marks]
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(scene)
-            res["speedup_vs_cpu_port"] = value / res["cpu_baseline"]["value"]
+            res["cpu_baseline"] = cpu_baseline(scene if image == 400 else build_scene(400))
+            if args.workload == "render":
+                res["speedup_vs_cpu_port"] = value / res["cpu_baseline"]["value"]
         print(json.dumps(res))
     if world > 1:
         dist.barrier()

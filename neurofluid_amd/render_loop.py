@@ -4,21 +4,50 @@ import torch
 
 from . import dist as nfdist
 
+_OWN_IDX = {}
+
+
+def _own_ray_index(n_chunks, ray_chunk, N_ray, rank, world, device):
+    """Indices of the rays of this rank's chunks (k = rank, rank + world, ...) in ownership order; cached."""
+    key = (n_chunks, ray_chunk, N_ray, rank, world, str(device))
+    idx = _OWN_IDX.get(key)
+    if idx is None:
+        parts = [torch.arange(k * ray_chunk, min((k + 1) * ray_chunk, N_ray)) for k in nfdist.my_chunks(n_chunks, rank, world)]
+        idx = (torch.cat(parts) if parts else torch.zeros(0, dtype=torch.int64)).to(device)
+        if len(_OWN_IDX) > 64:
+            _OWN_IDX.clear()
+        _OWN_IDX[key] = idx
+    return idx
+
 
 def render_image(renderer, particle_pos, N_ray, ro, rays, focal_length=None, cw=None, iseval=False, ray_chunk=1024,
-                 rank=0, world=1, gather=True):
+                 rank=0, world=1, gather=True, device_chunk=None):
     """Same result dict as the reference: pred_rgbs_0/1 (N_ray,3), num_nn_0/1 (N_ray*S), mask_0/1 (N_ray,1) if iseval.
-    With world > 1 every rank renders chunks k = rank, rank+world, ... and the RGB tiles are all-gathered;
-    num_nn / mask stay local unless gather=True."""
+
+    ray_chunk    the reference's chunk (the unit of its loop, and the unit that is dealt to the ranks);
+    device_chunk rays per fused renderer call (default: ray_chunk).  Rays are independent and results are
+                 chunk-independent bit for bit (tests/test_gpu_render.py), so several reference chunks go into one call.
+    With world > 1 the chunks are interleaved over the ranks (chunk k -> rank k mod world: the fluid covers a minority
+    of the pixels, so the cost follows the active samples; fine interleaving balances it) and every rank renders ALL
+    its chunks in as few fused calls as device_chunk allows — 1024-ray balance at full-GPU launch sizes.  The RGB
+    tiles are all-gathered; num_nn / mask stay local unless gather=True."""
     n_imp = renderer.N_importance
     n_chunks = (N_ray + ray_chunk - 1) // ray_chunk
-    mine = nfdist.my_chunks(n_chunks, rank, world)
+    device_chunk = max(int(device_chunk or ray_chunk), 1)
     keys = ["rgb0", "num_nn_0"] + (["mask_0"] if iseval else [])
     if n_imp > 0:
         keys += ["rgb1", "num_nn_1"] + (["mask_1"] if iseval else [])
+    per_ray_ro = ro is not None and ro.dim() == 2          # fused multi-view calls carry one camera position per ray
+    if world > 1:
+        own = _own_ray_index(n_chunks, ray_chunk, N_ray, rank, world, rays.device)
+        my_rays = rays.index_select(0, own)
+        my_ro = ro.index_select(0, own) if per_ray_ro else ro
+    else:
+        my_rays, my_ro = rays[:N_ray], ro
     parts = {k: [] for k in keys}
-    for k in mine:
-        res = renderer(particle_pos, ro, rays[k * ray_chunk:(k + 1) * ray_chunk], focal_length, cw)
+    for i in range(0, my_rays.shape[0], device_chunk):
+        res = renderer(particle_pos, my_ro[i:i + device_chunk] if per_ray_ro else my_ro, my_rays[i:i + device_chunk],
+                       focal_length, cw)
         for key in keys:
             v = res[key]
             parts[key].append(v.view(v.shape[0], -1) if key.startswith("num_nn") else v)
@@ -31,17 +60,18 @@ def render_image(renderer, particle_pos, N_ray, ro, rays, focal_length=None, cw=
         return ret
     share = nfdist.share_size(n_chunks, world)
     dev = rays.device
+    S0, S1 = renderer.N_samples, renderer.N_samples + n_imp
+    widths = {"rgb0": 3, "rgb1": 3, "mask_0": 1, "mask_1": 1, "num_nn_0": S0, "num_nn_1": S1}
     for key in keys:
         if not gather and not key.startswith("rgb"):
             continue
-        width = parts[key][0].shape[-1] if parts[key] else None
-        if width is None:   # this rank owns no chunk: learn the width from the key
-            S0, S1 = renderer.N_samples, renderer.N_samples + n_imp
-            width = {"rgb0": 3, "rgb1": 3, "mask_0": 1, "mask_1": 1, "num_nn_0": S0, "num_nn_1": S1}[key]
         dtype = parts[key][0].dtype if parts[key] else (torch.int64 if key.startswith("num_nn") else torch.float32)
-        local = torch.zeros(share * ray_chunk, width, dtype=dtype, device=dev)
-        for s, t in enumerate(parts[key]):
-            local[s * ray_chunk:s * ray_chunk + t.shape[0]] = t
+        # own chunks in ownership order; only the image's last chunk can be ragged and it is the last of its owner, so
+        # the rendered rows are a prefix of this rank's (share * ray_chunk)-row slab
+        local = torch.zeros(share * ray_chunk, widths[key], dtype=dtype, device=dev)
+        if parts[key]:
+            t = torch.cat(parts[key], dim=0)
+            local[:t.shape[0]] = t
         full = nfdist.gather_chunks(local, n_chunks, ray_chunk, N_ray, rank, world)
         ret[names.get(key, key)] = full.reshape(-1) if key.startswith("num_nn") else full
     return ret

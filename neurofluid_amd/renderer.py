@@ -94,11 +94,17 @@ class RenderNet(nn.Module):
     def grid_for(self, particles):
         """One grid per particle tensor *version* (rebuilt when the particles move)."""
         key = (particles.data_ptr(), particles._version, particles.shape[0])
-        if self._grid_cache[0] != key or self._grid_cache[2] is not particles:
-            # the entry holds `particles` itself: (ptr, version, N) alone could match a NEW tensor that re-uses a
-            # freed block (build_grid copies non-contiguous / non-fp32 inputs, so the grid would not pin the pointer)
+        if self._grid_cache[0] != key:
+            # the entry holds `particles` (an alias of its storage): the block cannot be freed and handed to a NEW
+            # tensor with the same (ptr, version, N) while the entry exists (build_grid copies non-contiguous /
+            # non-fp32 inputs, so the grid alone would not pin the pointer)
             self._grid_cache = (key, ops.build_grid(particles, self.raduis), particles)
         return self._grid_cache[1]
+
+    def invalidate_grid(self):
+        """Drop the cached grid: the next call rebuilds it (for callers that moved the particles in place through a
+        path the version counter does not see, and for bench.py, which times the rebuild a real rollout pays)."""
+        self._grid_cache = (None, None, None)
 
     def workspace(self):
         """Grow-only scratch arena shared by the inference passes of this module (ops.Workspace)."""

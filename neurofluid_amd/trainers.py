@@ -153,15 +153,12 @@ class BaseTrainer:
     # ---- the chunk loop (trainer/basetrainer.py:264-309)
     def render_image(self, particle_pos, N_ray, ro, rays, focal_length, cw, iseval=False):
         rc = self.options.RENDERER.ray.ray_chunk
-        chunk = rc
-        shard = iseval and self.world > 1
+        dev_chunk = rc
         if N_ray > rc:   # full-image loops: larger fused calls, still multiples of the reference's chunk
-            chunk = max(rc, int(self.options.RENDERER.get('device_ray_chunk', rc)) // rc * rc)
-            if shard:    # at least ~4 chunks per rank so that the interleaving balances the load
-                per_rank = -(-N_ray // (4 * self.world))
-                chunk = max(rc, min(chunk, -(-per_rank // rc) * rc))
-        return _render_image(self.renderer, particle_pos, N_ray, ro, rays, focal_length, cw, iseval=iseval,
-                             ray_chunk=chunk, rank=self.rank if shard else 0, world=self.world if shard else 1)
+            dev_chunk = max(rc, int(self.options.RENDERER.get('device_ray_chunk', rc)) // rc * rc)
+        shard = iseval and self.world > 1      # reference chunks interleaved over the ranks, fused per rank (render_loop)
+        return _render_image(self.renderer, particle_pos, N_ray, ro, rays, focal_length, cw, iseval=iseval, ray_chunk=rc,
+                             device_chunk=dev_chunk, rank=self.rank if shard else 0, world=self.world if shard else 1)
 
     # ---- image dumps
     def vis_rgbs(self, rgbs, channel=3, test=False):

@@ -168,9 +168,9 @@ class ParticleNet(nn.Module):
 
     def _box_grid(self, box):
         key = (box.data_ptr(), box._version, box.shape[0])
-        if self._box_cache[0] != key or self._box_cache[2] is not box:
-            # the entry keeps `box` alive: a freed block could otherwise be handed to a NEW tensor with the same
-            # (ptr, version, N) and a stale grid would be used silently
+        if self._box_cache[0] != key:
+            # the entry keeps `box` (an alias of its storage) alive, so the block cannot be freed and handed to a NEW
+            # tensor with the same (ptr, version, N) while the entry exists
             self._box_cache = (key, ops.build_grid(box, 0.5 * float(self.filter_extent), firstk=False), box)
         return self._box_cache[1]
 
@@ -304,7 +304,7 @@ class ParticleNet(nn.Module):
         """Static grid bounds from the container (cached: no per-step sync); particles that leave it are
         clamped into border cells, which keeps the search exact (include/neurofluid_hip.h)."""
         key = (box.data_ptr(), box._version, box.shape[0])
-        if getattr(self, "_bbox_key", None) != key or getattr(self, "_bbox_ref", None) is not box:
+        if getattr(self, "_bbox_key", None) != key:          # _bbox_ref pins the storage (see _box_grid)
             lo, hi = torch.aminmax(box, dim=0)
             self._bbox = tuple((lo - 0.5).tolist()) + tuple((hi + 0.5).tolist())
             self._bbox_key, self._bbox_ref = key, box

@@ -39,6 +39,11 @@ def _worker(rank, world, port, n_rays, chunk, q):
     ref = render_image(net, None, n_rays, None, rays, iseval=True, ray_chunk=chunk)
     got = render_image(net, None, n_rays, None, rays, iseval=True, ray_chunk=chunk, rank=rank, world=world)
     ok = all(torch.equal(ref[k], got[k]) for k in ref) and set(ref) == set(got)
+    # reference chunks dealt to the ranks, several of them fused into one renderer call per rank
+    got = render_image(net, None, n_rays, None, rays, iseval=True, ray_chunk=chunk, rank=rank, world=world, device_chunk=3 * chunk)
+    ok = ok and all(torch.equal(ref[k], got[k]) for k in ref)
+    got = render_image(net, None, n_rays, None, rays, iseval=True, ray_chunk=chunk, device_chunk=1 << 20)
+    ok = ok and all(torch.equal(ref[k], got[k]) for k in ref)
     # gradient all-reduce = mean over ranks
     p = torch.nn.Parameter(torch.zeros(5))
     p.grad = torch.full((5,), float(rank + 1))

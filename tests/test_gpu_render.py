@@ -670,10 +670,56 @@ def test_fine_pass_particle_gradients_vs_oracle_autograd(dev):
     assert float(ref.abs().max()) > 1e-6 and int((ref.abs().sum(1) > 0).sum()) > 200
     rel = float((got - ref).norm() / ref.norm())
     print("dL/dpos through both passes: relative error", rel, " touched particles", int((ref.abs().sum(1) > 0).sum()))
-    # same calibration as test_fine_net_grads_same_samples: the encodings amplify 1-ulp differences of the smoothed
-    # positions by up to 512; the coarse-only check of round 1 passes at 5e-3
-    assert rel < 1e-2, rel
+    # Calibrated, not guessed (tools/dpos_sensitivity.py, oracle only): moving every particle coordinate by ONE fp32 ulp
+    # moves the ORACLE's own dL/dpos on this very batch by 1.0e-2 .. 1.4e-2 (the encodings multiply 1-ulp differences of
+    # the smoothed positions by up to 512 before the MLP sees them); HIP vs oracle measures 1.07e-2, i.e. inside the
+    # noise floor of the algorithm.  The bar is 2x that floor; the TIGHT check of the scatter kernel itself, which has
+    # no such amplification, is test_features_backward_kernel_vs_oracle_autograd below (1e-4).
+    assert rel < 3e-2, rel
     assert torch.equal(ref.abs().sum(1) > 0, got.abs().sum(1) > 0)
+
+
+def test_features_backward_kernel_vs_oracle_autograd(dev):
+    """A12, the particle-gradient kernel in isolation and TIGHT: nf_render_features_bwd scatters a GIVEN dL/d(feature
+    row) to the particle positions, for the coarse AND the fine pass (192 samples per ray, HIP-sampled depths), vs torch
+    autograd through the oracle's embedding_local_geometry with the same upstream gradient.  With dX given, the only
+    rounding noise is in the local geometry itself (no MLP, no 512x amplification through the forward): 1e-4."""
+    from neurofluid_amd import _lib
+    from neurofluid_amd._lib import check, ptr
+    from neurofluid_amd.autograd import _run_passes
+    from oracle import render_oracle as ro
+    net = make_net(dev)
+    rays, roc = _fluid_rays(64)
+    P0 = ro.watercube_particles()
+    lib = _lib.load()
+    with torch.no_grad():
+        p0, p1, rays_c, ro_c, grid = _run_passes(net, P0.to(dev), roc.to(dev), rays.to(dev), True, True, save_acts=True)
+    z_table, _ = net._tables(dev)
+    R = rays.shape[0]
+    for pb, z, zt, S in ((p0, None, z_table, 64), (p1, p1.z, None, 192)):
+        n = int(pb.n_rows.item())
+        assert n > 500
+        dX = torch.randn(n, 252, generator=torch.Generator().manual_seed(S)).to(dev)
+        dP = torch.zeros(P0.shape, device=dev)
+        check(lib.nf_render_features_bwd(ptr(grid.points), ptr(rays_c), ptr(z), ptr(zt), R, S, float(net.raduis),
+                                         net.num_neighbor, net.enc_flags, ptr(ro_c), 0, ptr(pb.row_sample), ptr(pb.row_nbr),
+                                         ptr(pb.n_rows), n, ptr(dX), ptr(dP), _lib.stream()), "nf_render_features_bwd")
+        Pc = P0.clone().requires_grad_(True)
+        zz = (z_table.cpu()[None].expand(R, 64) if z is None else z.cpu())
+        xyz = rays[:, None, :3] + rays[:, None, 3:] * zz[:, :, None]
+        if z is None:
+            _, xyz = ro.coarse_sample_ray(9.0, 13.0, rays, 64)          # the reference's own expression (no FMA)
+        dists, idx, _ = ro.search(xyz, Pc.detach(), 0.225, 20)
+        nn = torch.where((idx >= 0).unsqueeze(-1), Pc[idx.clamp(min=0)], torch.zeros(1))
+        feats, _ = ro.embedding_local_geometry(dists, nn, 0.225, xyz, rays, roc)
+        rows = pb.row_sample[:n].cpu().long()
+        assert bool(torch.all(dists.view(-1, 20)[rows] != 0))             # the active rows are the full-K samples
+        (feats[rows] * dX.cpu()).sum().backward()
+        ref = Pc.grad
+        rel = float((dP.cpu() - ref).norm() / ref.norm())
+        print(f"features backward, S={S}: {n} rows, relative error {rel:.2e}")
+        assert rel < 1e-4, (S, rel)
+        assert torch.equal(ref.abs().sum(1) > 0, dP.cpu().abs().sum(1) > 0)
 
 
 def test_fine_rendering_entry_point(dev):

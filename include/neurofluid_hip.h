@@ -164,6 +164,14 @@ int nf_nerf_mlp_fwd_h(const float* packed, const void* stream_h, int cx, int cd,
                       const int32_t* n_rows, int max_rows, const int32_t* row_sample, float* rgbsigma,
                       nf_stream_t stream);
 
+/* fp16-MFMA forward, version 3 (nf_mlp_h2.hip): two 32-row tiles per wave, out-block-major, packed fp16 activations
+ * between layers, sigma / rgb heads on the matrix pipe.  Same operand X as nf_nerf_mlp_fwd_h (the fp16 layout written
+ * by nf_render_features(x_fp16 = 1)), which must be allocated for an EVEN number of 32-row tiles; its own weight stream. */
+size_t nf_nerf_packed_h2_bytes(void);
+int nf_nerf_pack_h2(const nf_nerf_params_t* params, int cx, int cd, void* stream_h2, nf_stream_t stream);
+int nf_nerf_mlp_fwd_h2(const void* stream_h2, int cx, int cd, const void* X, const int32_t* n_rows, int max_rows,
+                       const int32_t* row_sample, float* rgbsigma, nf_stream_t stream);
+
 /* A12 (MLP part): data gradient of the MLP on fp32 MFMA with transposed packed weights.
  * Reads d_rgbsigma[row_sample[row]] (gradient w.r.t. the MLP output (rgb after sigmoid, sigma)) and the
  * activations saved by nf_nerf_mlp_fwd; writes, per row, the pre-activation gradients of every layer:

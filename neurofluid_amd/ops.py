@@ -216,6 +216,27 @@ def pack_nerf_h(weights, biases, cx, cd):
     return out
 
 
+class PackedH2:
+    """Weight stream of the fp16-MFMA MLP, version 3 (nf_nerf_pack_h2 / nf_nerf_mlp_fwd_h2)."""
+
+    def __init__(self, blob):
+        self.blob = blob
+
+
+def pack_nerf_h2(weights, biases, cx, cd):
+    lib = _lib.load()
+    out = torch.empty(lib.nf_nerf_packed_h2_bytes(), dtype=torch.uint8, device=weights[0].device)
+    P = _lib.NerfParams()
+    keep = []
+    for i in range(12):
+        w = weights[i].detach().contiguous().float()
+        b = biases[i].detach().contiguous().float()
+        keep += [w, b]
+        P.w[i], P.b[i] = w.data_ptr(), b.data_ptr()
+    check(lib.nf_nerf_pack_h2(ctypes.byref(P), cx, cd, ptr(out), _lib.stream()), "nf_nerf_pack_h2")
+    return PackedH2(out)
+
+
 # ------------------------------------------------------------------------------------------------
 # one render pass (coarse or fine) of a ray chunk
 # ------------------------------------------------------------------------------------------------
@@ -316,7 +337,10 @@ def render_pass(grid, particles, rays, z, z_table, S, radius, K, enc_flags, use_
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    if packed_h is not None:      # fp16-MFMA variant (inference only)
+    if isinstance(packed_h, PackedH2):      # fp16-MFMA, two tiles per wave (inference only); X holds an even tile count
+        check(lib.nf_nerf_mlp_fwd_h2(ptr(packed_h.blob), cx, cd, ptr(b.X), ptr(b.n_rows), max_rows, ptr(b.row_sample),
+                                     ptr(b.rgbsigma), st), "nf_nerf_mlp_fwd_h2")
+    elif packed_h is not None:      # fp16-MFMA, round-1 kernel (kept for A/B runs: RENDERER.mlp_h_kernel = 1)
         check(lib.nf_nerf_mlp_fwd_h(ptr(packed), ptr(packed_h), cx, cd, ptr(b.X), ptr(b.n_rows), max_rows,
                                     ptr(b.row_sample), ptr(b.rgbsigma), st), "nf_nerf_mlp_fwd_h")
     elif wstream is not None and not save_acts:      # fp32, weight stream shared through LDS (inference)
@@ -392,6 +416,12 @@ def mlp_rows(packed, cx, cd, x, save_acts=False, packed_h=None, wstream=None):
         # fp32 operand layout [tile][q][lane][4] -> fp16 layout [tile][t][lane][8]: K-step t = groups 2t, 2t+1
         T = X.numel() // ((qx_ := (cx + 7) // 8) + (qd_ := (cd + 7) // 8)) // 256
         Xh = X.view(T, (qx_ + qd_) // 2, 2, 64, 4).permute(0, 1, 3, 2, 4).reshape(-1).to(torch.float16).contiguous()
+        if isinstance(packed_h, PackedH2):
+            if T % 2:       # the two-tiles-per-wave kernel reads whole tile pairs
+                Xh = torch.cat([Xh, torch.zeros(Xh.numel() // T, dtype=Xh.dtype, device=Xh.device)])
+            check(lib.nf_nerf_mlp_fwd_h2(ptr(packed_h.blob), cx, cd, ptr(Xh), ptr(n_rows), n, ptr(row_sample), ptr(out),
+                                         _lib.stream()), "nf_nerf_mlp_fwd_h2")
+            return out
         check(lib.nf_nerf_mlp_fwd_h(ptr(packed), ptr(packed_h), cx, cd, ptr(Xh), ptr(n_rows), n, ptr(row_sample), ptr(out),
                                     _lib.stream()), "nf_nerf_mlp_fwd_h")
         return out

@@ -42,6 +42,9 @@ class RenderNet(nn.Module):
         self.mlp_dtype = str(_get(cfg, "mlp_dtype", "fp32"))
         if self.mlp_dtype not in ("fp32", "fp16"):
             raise ValueError("RENDERER.mlp_dtype must be fp32 or fp16")
+        # build-only key: which fp16 kernel serves mlp_dtype = fp16.  2 (default): two tiles per wave, out-block-major
+        # (nf_mlp_h2.hip); 1: the round-1 kernel (nf_mlp_h.hip), kept for A/B measurements
+        self.mlp_h_kernel = int(_get(cfg, "mlp_h_kernel", 2))
         if not self.fix_radius:
             raise NotImplementedError("fix_radius=False is dead code in the reference (models/renderer.py:119-121)")
         if not _get(cfg, "encoding.exclude_ray", True):
@@ -119,8 +122,8 @@ class RenderNet(nn.Module):
 
     def packed_weights_h(self, net):
         layers = net.linear_layers()
-        return ops.pack_nerf_h([l.weight for l in layers], [l.bias for l in layers], self.in_channels_xyz,
-                               self.in_channels_dir)
+        pack = ops.pack_nerf_h2 if self.mlp_h_kernel == 2 else ops.pack_nerf_h
+        return pack([l.weight for l in layers], [l.bias for l in layers], self.in_channels_xyz, self.in_channels_dir)
 
     # ------------------------------------------------------------------
     def forward(self, physical_particles, ro, rays, focal=None, c2w=None, use_disp=False, perturb=0, noise_std=0.,

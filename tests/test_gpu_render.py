@@ -438,14 +438,16 @@ def test_particle_gradients_vs_oracle_autograd(dev):
     assert torch.equal(touched, got.abs().sum(1) > 0)
 
 
-def test_fp16_mfma_path(dev):
-    """BASELINE config 5: fp16-MFMA MLP (fp32 accumulate).  Stated tolerance: rgb/sigma rows within 2e-2 of the fp32
+@pytest.mark.parametrize("hk", [2, 1])
+def test_fp16_mfma_path(dev, hk):
+    """BASELINE config 5: fp16-MFMA MLP (fp32 accumulate), both kernels (hk = 2: two tiles per wave, out-block-major,
+    heads on the matrix pipe — the default; hk = 1: round 1's).  Stated tolerance: rgb/sigma rows within 2e-2 of the fp32
     MLP on unit-scale features, rendered RGB >= 40 dB PSNR vs the fp32 path; neighbour sets / masks stay bit-exact."""
     from neurofluid_amd import ops
     from oracle import render_oracle as ro
-    net = make_net(dev)
+    net = make_net(dev, dict(make_cfg(), mlp_h_kernel=hk))
     gen = torch.Generator().manual_seed(21)
-    for n in (1, 33, 128, 1000):
+    for n in (1, 33, 64, 65, 128, 1000, 2049):
         xr = (torch.rand(n, 252, generator=gen) * 2 - 1).to(dev)
         ref = ops.mlp_rows(net.packed_weights(net.nerf_fine), 198, 54, xr)
         got = ops.mlp_rows(net.packed_weights(net.nerf_fine), 198, 54, xr, packed_h=net.packed_weights_h(net.nerf_fine))
@@ -454,7 +456,7 @@ def test_fp16_mfma_path(dev):
         assert float((err[:, 3] / (1 + ref[:, 3].abs())).max()) < 2e-2
     g = load_golden("a10_forward")
     P, rays, roc = T(g["particles"], dev), T(g["rays"], dev), T(g["ro"], dev)
-    net16 = make_net(dev, dict(make_cfg(), mlp_dtype="fp16"))
+    net16 = make_net(dev, dict(make_cfg(), mlp_dtype="fp16", mlp_h_kernel=hk))
     with torch.no_grad():
         a = net(P, roc, rays, None, None)
         b = net16(P, roc, rays, None, None)
@@ -542,7 +544,7 @@ def test_full_frame_size_independent_properties(dev, side):
     assert torch.equal(full["mask_1"][sel].cpu(), ref["mask_1"]) and torch.equal(full["num_nn_1"][sel].cpu(), ref["num_nn_1"])
     torch.testing.assert_close(full["rgb1"][sel].cpu(), ref["rgb1"], rtol=0, atol=RGB_ATOL)
     # (5) fp16-MFMA mode
-    net16 = make_net(dev, dict(make_cfg(), mlp_dtype="fp16"))
+    net16 = make_net(dev, dict(make_cfg(), mlp_dtype="fp16", mlp_h_kernel=hk))
     with torch.no_grad():
         h = net16(P, roc, rays, None, None)
     assert torch.equal(h["mask_0"], full["mask_0"])      # (the fine samples follow the fp16 coarse weights: mask_1 may differ)

@@ -53,3 +53,19 @@ if len(sys.argv) > 3 and sys.argv[3] == "fp16":
         print(f"fp16 iter {it}: rows {n} {ms:.3f} ms  {n*1331968/ms/1e9:.1f} TFLOP/s")
     err = (out2 - out).abs()
     print("max abs err rgb", float(err[:, :3].max()), "sigma", float(err[:, 3].max()), "sigma scale", float(out[:, 3].abs().max()))
+if len(sys.argv) > 3 and sys.argv[3] == "fp16v3":
+    ph = ops.pack_nerf_h2(W, B, 198, 54)
+    T = X.numel() // (32 * 256)
+    Xh = X.view(T, 16, 2, 64, 4).permute(0, 1, 3, 2, 4).reshape(-1).to(torch.float16).contiguous()
+    if T % 2:
+        Xh = torch.cat([Xh, torch.zeros(Xh.numel() // T, dtype=Xh.dtype, device=dev)])
+    out2 = torch.zeros(n, 4, device=dev)
+    for it in range(iters):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib.nf_nerf_mlp_fwd_h2(ptr(ph.blob), 198, 54, ptr(Xh), ptr(n_rows), n, ptr(row_sample), ptr(out2), _lib.stream()))
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        print(f"fp16 v3 iter {it}: rows {n} {ms:.3f} ms  {n*1331968/ms/1e9:.1f} TFLOP/s")
+    err = (out2 - out).abs()
+    print("v3 max abs err rgb", float(err[:, :3].max()), "sigma", float(err[:, 3].max()), "sigma scale", float(out[:, 3].abs().max()))

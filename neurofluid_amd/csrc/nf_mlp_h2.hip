@@ -313,47 +313,69 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
     for (int s = 0; s < H2_PF; ++s) c.ab[s] = c.ring[s * 64 + lane];
 
+    // X operands of layer 1 / the skip layer live in this wave's LDS stash (2 tiles x 13 K-steps x 1 KB).  The first
+    // pair's are staged here; every further pair's are staged by the PREVIOUS pair's pass, in 13 batches of 2 KB spread
+    // over the blocks of layers 5..8 (the stash is free once the skip layer has run): global -> 8 registers in one
+    // block, ds_write in the next, so neither the HBM latency nor the stores ever sit in front of an MFMA.
+    const int last_pair = npairs > 0 ? npairs - 1 : 0;
+    if (ngroups > (int)blockIdx.x) {
+        const u32x4* pa_ = Xh + (size_t)(2 * min((int)blockIdx.x * 4 + wave, last_pair)) * 16 * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < H2_XS; ++t) {
+            const u32x4 va = __builtin_nontemporal_load(pa_ + t * 64), vb = __builtin_nontemporal_load(pa_ + (16 + t) * 64);
+            stash[t * 64] = va;
+            stash[(H2_XS + t) * 64] = vb;
+        }
+    }
+
     for (int tg = blockIdx.x; tg < ngroups; tg += gridDim.x) {
         int pair = tg * 4 + wave;
         const bool owner = pair < npairs;
         if (!owner) pair = npairs - 1;            // idle waves recompute the last pair (keeps the barriers matched)
         const u32x4* xtA = Xh + (size_t)(2 * pair) * 16 * 64 + lane;        // Xh[tile][16 K-steps][64 lanes]
         const u32x4* xtB = xtA + 16 * 64;
+        // next pair of this wave (clamped: the loads of the last pass re-read valid rows and are simply not used)
+        const u32x4* xnA = Xh + (size_t)(2 * min((tg + (int)gridDim.x) * 4 + wave, last_pair)) * 16 * 64 + lane;
         int slot = 0;                             // static step counter: every pair consumes exactly nslots (a multiple of the ring)
 
         u32x4 bank[2][2][16];                     // [which][tile][K-step]: packed fp16 activations
         f32x16 acc[2][2];                         // [buffer][tile]
-        u32x4 xA[H2_XS], xB[H2_XS];
-#pragma unroll
-        for (int t = 0; t < H2_XS; ++t) { xA[t] = __builtin_nontemporal_load(xtA + t * 64); xB[t] = __builtin_nontemporal_load(xtB + t * 64); }
-#pragma unroll
-        for (int t = 0; t < H2_XS; ++t) { stash[t * 64] = xA[t]; stash[(H2_XS + t) * 64] = xB[t]; }
+        u32x4 xf0, xf1;                           // X batch in flight (next pair)
 
         // Every block call is written out with literal block indices (macros, no loops): the running step counter slot
         // must fold to a constant at every step (ring slot, rendezvous and prefetch decisions are all static), and the
         // loop unroller gives up on bodies of this size before that folding has happened.
 #define H2_REP7(M) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
-        // ---- layer 0: X (registers) -> bank[1]
-        h2_block<1, H2_XS, 0, 0>(c, slot, acc[0], bank[0][0], bank[0][1], xA, xB, nullptr, acc[1], bank[1][0], bank[1][1], 0);
-#define H2_L0(b) h2_block<1, H2_XS, 0, 1>(c, slot, acc[(b) & 1], bank[0][0], bank[0][1], xA, xB, nullptr, acc[((b) - 1) & 1], bank[1][0], bank[1][1], (b) - 1);
+        // ---- layer 0: X (stash) -> bank[1]
+        h2_block<2, H2_XS, 0, 0>(c, slot, acc[0], bank[0][0], bank[0][1], nullptr, nullptr, stash, acc[1], bank[1][0], bank[1][1], 0);
+#define H2_L0(b) h2_block<2, H2_XS, 0, 1>(c, slot, acc[(b) & 1], bank[0][0], bank[0][1], nullptr, nullptr, stash, acc[((b) - 1) & 1], bank[1][0], bank[1][1], (b) - 1);
         H2_REP7(H2_L0)
-        // ---- hidden layers: block 0 of a layer converts block 7 of the previous one (into its own input bank)
-#define H2_HB(IN, OUT, CV, b) h2_block<0, 0, 16, CV>(c, slot, acc[(b) & 1], bank[IN][0], bank[IN][1], nullptr, nullptr, nullptr, acc[((b) - 1) & 1], bank[OUT][0], bank[OUT][1], (b) - 1);
-#define H2_HIDDEN_LAYER(IN, OUT, CV)                                                                                             \
+        // ---- hidden layers: block 0 of a layer converts block 7 of the previous one (into its own input bank).
+        // XFB >= 0: global block index of the layer's block 0 in the X staging schedule (even block: load batch, odd: store)
+#define H2_XFER(gb)                                                                                                              \
+        if ((gb) >= 0 && (gb) / 2 < H2_XS) {                                                                                     \
+            if (((gb) & 1) == 0) { xf0 = __builtin_nontemporal_load(xnA + ((gb) / 2) * 64);                                      \
+                                   xf1 = __builtin_nontemporal_load(xnA + (16 + (gb) / 2) * 64); }                               \
+            else { stash[((gb) / 2) * 64] = xf0; stash[(H2_XS + (gb) / 2) * 64] = xf1; }                                         \
+        }
+#define H2_HB(IN, OUT, CV, b, XFB) H2_XFER((XFB) < 0 ? -1 : (XFB) + (b))                                                         \
+        h2_block<0, 0, 16, CV>(c, slot, acc[(b) & 1], bank[IN][0], bank[IN][1], nullptr, nullptr, nullptr, acc[((b) - 1) & 1], bank[OUT][0], bank[OUT][1], (b) - 1);
+#define H2_HIDDEN_LAYER(IN, OUT, CV, XFB)                                                                                        \
+        H2_XFER(XFB)                                                                                                             \
         h2_block<0, 0, 16, 1>(c, slot, acc[0], bank[IN][0], bank[IN][1], nullptr, nullptr, nullptr, acc[1], bank[IN][0], bank[IN][1], 7); \
-        H2_HB(IN, OUT, CV, 1) H2_HB(IN, OUT, CV, 2) H2_HB(IN, OUT, CV, 3) H2_HB(IN, OUT, CV, 4) H2_HB(IN, OUT, CV, 5)             \
-        H2_HB(IN, OUT, CV, 6) H2_HB(IN, OUT, CV, 7)
-        H2_HIDDEN_LAYER(1, 0, 1)      // layer 1: bank[1] -> bank[0]
-        H2_HIDDEN_LAYER(0, 1, 1)      // layer 2
-        H2_HIDDEN_LAYER(1, 0, 1)      // layer 3
+        H2_HB(IN, OUT, CV, 1, XFB) H2_HB(IN, OUT, CV, 2, XFB) H2_HB(IN, OUT, CV, 3, XFB) H2_HB(IN, OUT, CV, 4, XFB)               \
+        H2_HB(IN, OUT, CV, 5, XFB) H2_HB(IN, OUT, CV, 6, XFB) H2_HB(IN, OUT, CV, 7, XFB)
+        H2_HIDDEN_LAYER(1, 0, 1, -1)      // layer 1: bank[1] -> bank[0]
+        H2_HIDDEN_LAYER(0, 1, 1, -1)      // layer 2
+        H2_HIDDEN_LAYER(1, 0, 1, -1)      // layer 3
         // layer 4 (skip): X from the stash + bank[0] -> bank[1]
         h2_block<2, H2_XS, 16, 1>(c, slot, acc[0], bank[0][0], bank[0][1], nullptr, nullptr, stash, acc[1], bank[0][0], bank[0][1], 7);
 #define H2_L4(b) h2_block<2, H2_XS, 16, 1>(c, slot, acc[(b) & 1], bank[0][0], bank[0][1], nullptr, nullptr, stash, acc[((b) - 1) & 1], bank[1][0], bank[1][1], (b) - 1);
         H2_REP7(H2_L4)
-        H2_HIDDEN_LAYER(1, 0, 1)      // layer 5
-        H2_HIDDEN_LAYER(0, 1, 1)      // layer 6
-        H2_HIDDEN_LAYER(1, 0, 1)      // layer 7: -> bank[0] = relu(h8), the input of xyz_encoding_final AND of sigma
-        H2_HIDDEN_LAYER(0, 1, 2)      // layer 8 (xyz_encoding_final, no activation) -> bank[1]
+        H2_HIDDEN_LAYER(1, 0, 1, 0)       // layer 5  (+ X batches 0..3 of the next pair)
+        H2_HIDDEN_LAYER(0, 1, 1, 8)       // layer 6  (+ batches 4..7)
+        H2_HIDDEN_LAYER(1, 0, 1, 16)      // layer 7: -> bank[0] = relu(h8), the input of xyz_encoding_final AND of sigma (+ 8..11)
+        H2_HIDDEN_LAYER(0, 1, 2, 24)      // layer 8 (xyz_encoding_final, no activation) -> bank[1]  (+ batch 12)
         // sigma block on the same input (bank[0]); converts block 7 of the final layer on the way
         h2_block<0, 0, 16, 2>(c, slot, acc[0], bank[0][0], bank[0][1], nullptr, nullptr, nullptr, acc[1], bank[1][0], bank[1][1], 7);
         // ---- view branch: [final (bank[1], identity) | dir features] -> 128 hidden (ReLU) -> bank[0] K-steps 0..7

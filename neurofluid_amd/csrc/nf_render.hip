@@ -151,9 +151,14 @@ __global__ void __launch_bounds__(SG_BLOCK) k_search(const void* __restrict__ ws
 {
     // a wave takes 64 consecutive candidates per round, 4 at a time; their neighbour lists wait in LDS until the round
     // is over, so that the active rows of the round are reserved with ONE atomic (as with a thread per candidate)
-    __shared__ int s_list[SG_WAVES][64][33];         // [slot][k], pitch 33: conflict-free for both access patterns
-    __shared__ int s_cnt[SG_WAVES][64];
-    __shared__ int s_full[SG_WAVES][64];
+    // LDS sized by K (dynamic): [wave][slot][pitch] lists, pitch = K | 1 (odd: conflict-free for both access patterns) +
+    // [wave][slot] counts and flags.  At K = 20 that is 23.5 KB per workgroup instead of the 35.8 KB of a fixed pitch 33:
+    // 6 instead of 4 workgroups per CU, and the kernel is latency-bound (rocprofv3: SQ_WAIT_ANY 0.62 of the wave cycles)
+    extern __shared__ int s_dyn[];
+    const int pitch = K | 1;
+    int* const s_list_w = s_dyn + (threadIdx.x >> 6) * 64 * pitch;
+    int* const s_cnt_w = s_dyn + SG_WAVES * 64 * pitch + (threadIdx.x >> 6) * 64;
+    int* const s_full_w = s_cnt_w + SG_WAVES * 64;
     NfGridView g = nf_grid_view(ws);
     const int ncand = *cand_count;
     const int lane = threadIdx.x & 63, l = lane & (SG_LANES - 1), gsh = lane & ~(SG_LANES - 1), grp = lane >> 4;
@@ -201,7 +206,7 @@ __global__ void __launch_bounds__(SG_BLOCK) k_search(const void* __restrict__ ws
                         const unsigned hm = (unsigned)(__ballot(hit) >> gsh) & 0xffffu;
                         const int pos = cnt + __popc(hm & lt);
                         const bool take = hit && pos < K;
-                        if (take) s_list[wv][slot][pos] = pi;
+                        if (take) s_list_w[slot * pitch + pos] = pi;
                         nz += __popc((unsigned)(__ballot(take && nonzero) >> gsh) & 0xffffu);   // nn_mask = dists.ne(0)
                         cnt += __popc(hm);
                     }
@@ -211,8 +216,8 @@ __global__ void __launch_bounds__(SG_BLOCK) k_search(const void* __restrict__ ws
                     const bool full = (nz == K);
                     num_nn[sample] = nz;
                     mask[sample] = full ? 1 : 0;
-                    s_cnt[wv][slot] = cnt;
-                    s_full[wv][slot] = full ? 1 : 0;
+                    s_cnt_w[slot] = cnt;
+                    s_full_w[slot] = full ? 1 : 0;
                 }
             }
         }
@@ -224,13 +229,13 @@ __global__ void __launch_bounds__(SG_BLOCK) k_search(const void* __restrict__ ws
         int cnt = 0, sample = 0;
         if (c < ncand) {
             sample = cand[c];
-            cnt = s_cnt[wv][lane];
-            active = s_full[wv][lane] || !use_mask;
+            cnt = s_cnt_w[lane];
+            active = s_full_w[lane] || !use_mask;
         }
         const int row = wave_append(active, n_rows);
         if (active) {
             row_sample[row] = sample;
-            for (int k = 0; k < K; ++k) row_nbr[(size_t)row * K + k] = k < cnt ? s_list[wv][lane][k] : -1;
+            for (int k = 0; k < K; ++k) row_nbr[(size_t)row * K + k] = k < cnt ? s_list_w[lane * pitch + k] : -1;
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -249,7 +254,8 @@ extern "C" int nf_render_search(const void* ws, const float* rays, const float* 
     long total = (long)R * S;
     long want = (total + SG_BLOCK - 1) / SG_BLOCK;
     int blocks = (int)(want < 8192 ? want : 8192);          // grid-stride over the candidates (count known on device only)
-    hipLaunchKernelGGL(k_search, dim3(blocks), dim3(SG_BLOCK), 0, (hipStream_t)stream, ws, rays, z, z_table, S,
+    const size_t lds = (size_t)SG_WAVES * 64 * ((K | 1) + 2) * sizeof(int);
+    hipLaunchKernelGGL(k_search, dim3(blocks), dim3(SG_BLOCK), lds, (hipStream_t)stream, ws, rays, z, z_table, S,
                        radius * radius, K, use_mask, cand, cand_count, num_nn, mask, row_sample, row_nbr, n_rows);
     NF_CHECK_LAUNCH();
     return NF_OK;

@@ -544,7 +544,7 @@ def test_full_frame_size_independent_properties(dev, side):
     assert torch.equal(full["mask_1"][sel].cpu(), ref["mask_1"]) and torch.equal(full["num_nn_1"][sel].cpu(), ref["num_nn_1"])
     torch.testing.assert_close(full["rgb1"][sel].cpu(), ref["rgb1"], rtol=0, atol=RGB_ATOL)
     # (5) fp16-MFMA mode
-    net16 = make_net(dev, dict(make_cfg(), mlp_dtype="fp16", mlp_h_kernel=hk))
+    net16 = make_net(dev, dict(make_cfg(), mlp_dtype="fp16"))
     with torch.no_grad():
         h = net16(P, roc, rays, None, None)
     assert torch.equal(h["mask_0"], full["mask_0"])      # (the fine samples follow the fp16 coarse weights: mask_1 may differ)

@@ -9,7 +9,7 @@ def _prep(x):
     return x.detach().contiguous().float()
 
 
-def _run_passes(net, particles, ro, rays, white_bg, fine, save_acts):
+def _run_passes(net, particles, ro, rays, white_bg, fine, save_acts, _retry=False):
     dev = rays.device
     z_table, u_table = net._tables(dev)
     grid = net.grid_for(particles)
@@ -24,6 +24,7 @@ def _run_passes(net, particles, ro, rays, white_bg, fine, save_acts):
     p0 = ops.render_pass(grid, pts, rays_c, None, z_table, net.N_samples, net.raduis, net.num_neighbor, net.enc_flags,
                          net.use_mask, ro_c, pk0, net.in_channels_xyz, net.in_channels_dir, white_bg, save_acts,
                          packed_h=net.packed_weights_h(net.nerf_coarse) if use_h else None, ws=ws, need_weights=fine,
+                         optimistic=not save_acts and not _retry,
                          wstream=None if (use_h or save_acts) else ops.pack_nerf_stream(pk0, net.in_channels_xyz,
                                                                                           net.in_channels_dir))
     p0.packed = pk0
@@ -34,11 +35,28 @@ def _run_passes(net, particles, ro, rays, white_bg, fine, save_acts):
         p1 = ops.render_pass(grid, pts, rays_c, z1, None, net.N_samples + net.N_importance, net.raduis, net.num_neighbor,
                              net.enc_flags, net.use_mask, ro_c, pk1, net.in_channels_xyz, net.in_channels_dir, white_bg,
                              save_acts, packed_h=net.packed_weights_h(net.nerf_fine) if use_h else None, ws=ws,
-                             need_weights=False,
+                             need_weights=False, optimistic=not save_acts and not _retry,
                              wstream=None if (use_h or save_acts) else ops.pack_nerf_stream(pk1, net.in_channels_xyz,
                                                                                               net.in_channels_dir))
         p1.z = z1
         p1.packed = pk1
+    # Inference passes ran against learnt row capacities without a host round trip: verify ONCE, here, with the whole
+    # call enqueued (a real rollout reads the image back anyway).  On overflow the capacities grow and the call is redone
+    # with exact sizing; capacities also grow ahead of need when a count comes within 10 % of them.
+    caps = [(p, p.cap) for p in (p0, p1) if p is not None and p.cap is not None]
+    if caps:
+        counts = torch.cat([p.n_rows for p, _ in caps]).tolist()
+        overflow = False
+        for (p, cap), n in zip(caps, counts):
+            key = (p.R, p.S)
+            if n > cap * 0.9:
+                ws.row_cap[key] = ops._round_rows(n + n // 4 + 4096)
+            overflow |= n > cap
+            p.n_active = n
+        if ops.PROFILE is not None:
+            ops.PROFILE["rows"] = [int(r.item()) if torch.is_tensor(r) else r for r in ops.PROFILE["rows"]]
+        if overflow:
+            return _run_passes(net, particles, ro, rays, white_bg, fine, save_acts, _retry=True)
     return p0, p1, rays_c, ro_c, grid
 
 

@@ -263,6 +263,7 @@ class Workspace:
 
     def __init__(self):
         self._buf = {}
+        self.row_cap = {}        # (R, S) -> row capacity of a render pass learnt from earlier calls (see render_pass)
 
     def get(self, name, numel, dtype, device):
         nbytes = max(int(numel), 1) * torch.empty(0, dtype=dtype).element_size()
@@ -276,10 +277,17 @@ class Workspace:
 
 
 def render_pass(grid, particles, rays, z, z_table, S, radius, K, enc_flags, use_mask, ro, packed, cx, cd,
-                white_bg=True, save_acts=False, max_rows=None, packed_h=None, ws=None, need_weights=True, wstream=None):
+                white_bg=True, save_acts=False, max_rows=None, packed_h=None, ws=None, need_weights=True, wstream=None,
+                optimistic=False):
     """Runs classify -> search -> features -> MLP -> composite for R rays x S samples.
     z: (R,S) per-ray depths or None (then z_table (S,) is shared by all rays).
-    Returns a PassBuffers with rgb, depth, opacity, weights, num_nn, mask_sum and the row lists."""
+    Returns a PassBuffers with rgb, depth, opacity, weights, num_nn, mask_sum and the row lists.
+
+    Row-buffer sizing.  The number of active rows is known on the device only.  Exact sizing reads it back (one host
+    sync in the middle of the pass).  With optimistic=True and a workspace that has seen this (R, S) shape before, the
+    pass runs WITHOUT any host round trip against the capacity learnt then (kernels clamp to it); `b.cap` is set and
+    the caller must compare `b.n_rows` with it once the frame is enqueued and redo the call on overflow
+    (autograd._run_passes does: one sync per call, at its end, instead of one in the middle of each pass)."""
     lib = _lib.load()
     dev = rays.device
     R = rays.shape[0]
@@ -319,11 +327,18 @@ def render_pass(grid, particles, rays, z, z_table, S, radius, K, enc_flags, use_
                                ptr(cand), ptr(counters[0:1]), ptr(b.num_nn), ptr(b.mask),
                                ptr(b.row_sample), ptr(b.row_nbr), ptr(counters[1:2]), st), "nf_render_search")
     b.n_rows = counters[1:2]
-    if max_rows >= n_samp:
+    b.cap = None
+    cap_key = (R, S)
+    if max_rows >= n_samp and optimistic and ws is not None and cap_key in ws.row_cap:
+        max_rows = min(ws.row_cap[cap_key], n_samp)        # no sync: verified by the caller at the end of the call
+        b.max_rows = b.cap = max_rows
+    elif max_rows >= n_samp:
         # exact sizing of the per-row buffers: one host sync per pass (the caller can avoid it by
         # passing a static max_rows bound, e.g. under hipGraph capture)
         max_rows = int(counters[1].item())
         b.max_rows = max_rows
+        if ws is not None:
+            ws.row_cap[cap_key] = max(ws.row_cap.get(cap_key, 0), _round_rows(max_rows + max_rows // 4 + 4096))
     b.n_active = max_rows
     tiles = (max_rows + 31) // 32
     rows_alloc = _round_rows(max_rows)
@@ -352,7 +367,7 @@ def render_pass(grid, particles, rays, z, z_table, S, radius, K, enc_flags, use_
     if PROFILE is not None:
         e1.record()
         PROFILE["mlp"].append((e0, e1))
-        PROFILE["rows"].append(max_rows)
+        PROFILE["rows"].append(max_rows if b.cap is None else b.n_rows)      # capacity run: the caller resolves the true count
     b.rgb = torch.empty(R, 3, dtype=torch.float32, device=dev)
     b.depth = torch.empty(R, dtype=torch.float32, device=dev)
     b.opacity = torch.empty(R, dtype=torch.float32, device=dev)

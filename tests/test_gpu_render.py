@@ -773,3 +773,22 @@ def test_shaped_clouds_nonlattice_index_order(dev, kind, order):
     # by less than the tolerance on this scene; the check is the same as test_forward_vs_oracle's
     torch.testing.assert_close(out["rgb1"].cpu(), ref["rgb1"], rtol=0, atol=5 * RGB_ATOL)
     assert ro.psnr(out["rgb1"].cpu(), ref["rgb1"]) >= RGB_PSNR_MIN
+
+
+def test_optimistic_row_capacities_no_midpass_sync(dev):
+    """Inference passes after the first run against learnt row capacities without a host round trip in the middle of the
+    pass; the single verification at the end of the call redoes it on overflow.  Same bits in all three regimes:
+    exact sizing (first call), capacity run (second call), capacity overflow -> exact redo (capacity forced tiny)."""
+    net = make_net(dev)
+    g = load_golden("a10_forward")
+    P, rays, roc = T(g["particles"], dev), T(g["rays"], dev), T(g["ro"], dev)
+    with torch.no_grad():
+        a = net(P, roc, rays, None, None)                      # exact: learns the capacities
+        ws = net.workspace()
+        assert set(ws.row_cap) == {(48, 64), (48, 192)}
+        b = net(P, roc, rays, None, None)                      # capacity run
+        ws.row_cap = {k: 32 for k in ws.row_cap}               # far too small: overflow -> redo
+        c = net(P, roc, rays, None, None)
+        assert all(v > 32 for v in ws.row_cap.values())        # grown by the redo
+    for k in a:
+        assert torch.equal(a[k], b[k]) and torch.equal(a[k], c[k]), k

@@ -256,6 +256,36 @@ int nf_cconv_transform(const float* A, int M, int cin, int cout, int relu, const
 int nf_cconv_gather(const float* G, int cout, const int64_t* row_splits, const int32_t* nbr, const float* pair_w,
                     const uint8_t* pair_cell, const float* bias_conv, const float* bias_dense,
                     const float* residual /*n_out*Cout or NULL*/, int n_out, float* out, nf_stream_t stream);
+/* the last layer's gather (Cout = 3) with the update epilogue fused: y3 as above, then pos_c = pos_new + scale * y3,
+ * vel_c = (pos_c - pos) / dt (models/transmodel.py:141-148).  totals2 (device, [fluid, box] true pair totals of
+ * nf_trans_count) may be NULL; otherwise a total above its capacity poisons pos_c / vel_c with NaN. */
+int nf_cconv_gather_update(const float* G, const int64_t* row_splits, const int32_t* nbr, const float* pair_w,
+                           const uint8_t* pair_cell, const float* bias_conv, const float* bias_dense, int n_out, float* y3,
+                           const float* pos, const float* pos_new, float scale, float dt, const int64_t* totals2,
+                           int64_t cap_fluid, int64_t cap_box, float* pos_c, float* vel_c, nf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused front half of the inference transition step (nf_trans.hip): 4 launches, no host round trip.
+ * CSR buffers are sized by capacities (pairs); row_splits2 = [fluid (n+1) | box (n+1)] int64, clamped to the
+ * capacities; totals2 = true pair totals.
+ * ------------------------------------------------------------------------------------------ */
+int nf_trans_prepare_limits(int* max_points, int* max_cells);
+/* B1 + fluid cell grid of the integrated positions in ONE workgroup (same grid workspace layout as nf_grid_build with
+ * with_firstk_lists = 0; bbox as there).  NF_EINVAL when the cloud / grid exceeds nf_trans_prepare_limits. */
+int nf_trans_prepare(const float* pos, const float* vel, const float gravity[3], float dt, int n, float cell,
+                     const float bbox[6], void* grid_ws, size_t ws_bytes, float* pos_new, float* vel_new, float* feats4,
+                     nf_stream_t stream);
+size_t nf_trans_count_workspace_bytes(int n);      /* zero-initialise once; the kernel leaves it zeroed */
+int nf_trans_count(const void* fluid_grid, const void* box_grid, const float* queries, int n, float radius,
+                   int64_t cap_fluid, int64_t cap_box, void* workspace, int64_t* row_splits2, int64_t* totals2,
+                   float* num_fluid_nbrs, nf_stream_t stream);
+int nf_trans_fill(const void* fluid_grid, const void* box_grid, const float* queries, int n, float radius, float extent,
+                  int use_window, const int64_t* row_splits2, int64_t cap_fluid, int64_t cap_box, int32_t* idx_f, float* d2_f,
+                  float* pw_f, uint8_t* pc_f, int32_t* idx_b, float* d2_b, float* pw_b, uint8_t* pc_b, nf_stream_t stream);
+int nf_trans_conv0(const float* box_feats, const float* fluid_feats, const int64_t* row_splits2, int n, const int32_t* idx_f,
+                   const float* pw_f, const uint8_t* pc_f, const int32_t* idx_b, const float* pw_b, const uint8_t* pc_b,
+                   const float* kernel_obstacle, const float* bias_obstacle, const float* kernel_fluid,
+                   const float* bias_fluid, const float* dense_w, const float* dense_b, float* out96, nf_stream_t stream);
 
 /* B8: backward of the continuous convolutions.  Open3D differentiates continuous_conv w.r.t. filter and input
  * features only (not positions); the reference trains through it at trainer/trainer_e2e.py:277.

@@ -381,12 +381,24 @@ extern "C" int nf_cconv_transform(const float* A, int M, int cin, int cout, int 
 // one wave per output point; the row's (j, 8 cells, 8 weights) are staged through LDS 64 entries
 // at a time, then every lane walks them for its output channel(s).
 // ------------------------------------------------------------------------------------------------
+// optional epilogue of the LAST layer (Cout = 3): pos_correction = y / 128, update_pos_vel (models/transmodel.py:141-148),
+// and the capacity check of the fused step (nf_trans.hip): a pair total above its capacity poisons the outputs with NaN
+struct NfUpdateEpi {
+    const float* pos;        // null: no epilogue
+    const float* pos_new;
+    float* pos_c;
+    float* vel_c;
+    float scale, dt;
+    const int64_t* totals;   // [2] true pair totals (fluid, box) or null
+    int64_t cap_f, cap_b;
+};
+
 __global__ void __launch_bounds__(256) k_cconv_gather(const float* __restrict__ G, int cout,
                                                       const int64_t* __restrict__ row_splits,
                                                       const int32_t* __restrict__ nbr, const float* __restrict__ pw,
                                                       const uint8_t* __restrict__ pc, const float* __restrict__ bias_c,
                                                       const float* __restrict__ bias_d, const float* __restrict__ residual,
-                                                      int n_out, float* __restrict__ out)
+                                                      int n_out, float* __restrict__ out, NfUpdateEpi epi)
 {
     __shared__ int s_j[4][64];
     __shared__ float s_w[4][64 * 8];
@@ -435,6 +447,14 @@ __global__ void __launch_bounds__(256) k_cconv_gather(const float* __restrict__ 
             float v = acc + G[(size_t)row * ntot + 64 * cout + lane] + bias_c[lane] + bias_d[lane];
             if (residual) v += residual[(size_t)row * cout + lane];
             out[(size_t)row * cout + lane] = v;
+            if (epi.pos) {      // cout == 3: lane = coordinate (same expressions as k_trans_update)
+                const size_t e = (size_t)row * 3 + lane;
+                float pcv = epi.pos_new[e] + epi.scale * v;
+                float vcv = (pcv - epi.pos[e]) / epi.dt;
+                if (epi.totals && (epi.totals[0] > epi.cap_f || epi.totals[1] > epi.cap_b)) pcv = vcv = __int_as_float(0x7fc00000);
+                epi.pos_c[e] = pcv;
+                epi.vel_c[e] = vcv;
+            }
         }
     }
 }
@@ -448,8 +468,28 @@ extern "C" int nf_cconv_gather(const float* G, int cout, const int64_t* row_spli
     if (n_out <= 0) return NF_OK;
     int blocks = (n_out + 3) / 4;
     if (blocks > 4096) blocks = 4096;
+    NfUpdateEpi epi = {};
     hipLaunchKernelGGL(k_cconv_gather, dim3(blocks), dim3(256), 0, (hipStream_t)stream, G, cout, row_splits, nbr, pair_w,
-                       pair_cell, bias_conv, bias_dense, residual, n_out, out);
+                       pair_cell, bias_conv, bias_dense, residual, n_out, out, epi);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+extern "C" int nf_cconv_gather_update(const float* G, const int64_t* row_splits, const int32_t* nbr, const float* pair_w,
+                                      const uint8_t* pair_cell, const float* bias_conv, const float* bias_dense, int n_out,
+                                      float* y3, const float* pos, const float* pos_new, float scale, float dt,
+                                      const int64_t* totals2, int64_t cap_fluid, int64_t cap_box, float* pos_c, float* vel_c,
+                                      nf_stream_t stream)
+{
+    NF_CHECK_ARG(G && row_splits && bias_conv && bias_dense && y3 && pos && pos_new && pos_c && vel_c, "null pointer");
+    if (n_out <= 0) return NF_OK;
+    int blocks = (n_out + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    NfUpdateEpi epi;
+    epi.pos = pos; epi.pos_new = pos_new; epi.pos_c = pos_c; epi.vel_c = vel_c; epi.scale = scale; epi.dt = dt;
+    epi.totals = totals2; epi.cap_f = cap_fluid; epi.cap_b = cap_box;
+    hipLaunchKernelGGL(k_cconv_gather, dim3(blocks), dim3(256), 0, (hipStream_t)stream, G, 3, row_splits, nbr, pair_w, pair_cell,
+                       bias_conv, bias_dense, (const float*)nullptr, n_out, y3, epi);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }

@@ -1,0 +1,438 @@
+// nf_trans.hip — fused front half of the transition step (ParticleNet.forward, models/transmodel.py:151-163) for the
+// inference path: 4 launches where round 1 used ~20.
+//
+//   nf_trans_prepare   ONE workgroup: gravity integration (B1, :100-104) + the fluid cell grid of the integrated
+//                      positions (counting sort in LDS, stable in original index) — replaces k_trans_integrate and the
+//                      six k_grid_* / scan launches of nf_grid_build(with_firstk_lists = 0)
+//   nf_trans_count     fluid->fluid and box->fluid neighbour counts in one launch (blockIdx.y picks the grid); the last
+//                      workgroup to finish scans both count arrays (row_splits, totals, per-particle fluid-neighbour
+//                      count B6) — replaces 2 count launches + 2 scans + the ATen diff
+//   nf_trans_fill      both CSR fills in one launch, and the per-pair interpolation data (ball->cube map, trilinear
+//                      cells / weights, poly6 window; B3) computed right where the hit is found — replaces 2 fills +
+//                      2 k_pair_precompute
+//   nf_trans_conv0     conv0_obstacle + conv0_fluid + dense0_fluid in one launch (both 64-cell filters in LDS) —
+//                      replaces 2 k_cconv_small
+// The CSR buffers are sized by CAPACITIES (pairs per particle): no host round trip anywhere in the step.  The true pair
+// totals are left on the device; the last kernel of the step (nf_cconv_gather's update epilogue) poisons its outputs
+// with NaN when a total exceeds its capacity, and the host checks the totals of step t while step t+1 is in flight.
+#include "nf_common.h"
+#include <math.h>
+
+#define TP_BLOCK 1024
+#define TP_MAX_PER_THREAD 16            // n <= 16 384 particles
+#define TP_MAX_CELLS 36864              // 144 KB of LDS
+
+extern "C" int nf_trans_prepare_limits(int* max_points, int* max_cells)
+{
+    if (max_points) *max_points = TP_BLOCK * TP_MAX_PER_THREAD;
+    if (max_cells) *max_cells = TP_MAX_CELLS;
+    return NF_OK;
+}
+
+__global__ void __launch_bounds__(TP_BLOCK) k_trans_prepare(NfGridHeader h, void* __restrict__ ws, const float* __restrict__ pos,
+                                                            const float* __restrict__ vel, float gx, float gy, float gz, float dt,
+                                                            float* __restrict__ pos_new, float* __restrict__ vel_new,
+                                                            float* __restrict__ feats4)
+{
+    extern __shared__ int cells[];          // n_cells counters -> starts -> ends
+    __shared__ int s_scan[TP_BLOCK / 64];
+    char* b = (char*)ws;
+    int* cell_start = (int*)(b + h.off_cell_start);
+    int* tmp_list = (int*)(b + h.off_tmp_list);
+    int* sorted_idx = (int*)(b + h.off_sorted_idx);
+    float4* sorted_pos = (float4*)(b + h.off_sorted_pos);
+    const int n = h.n_points, nc = h.n_cells, tid = threadIdx.x;
+    if (tid == 0) {
+        for (int d = 0; d < 3; ++d) { h.pt_lo[d] = nf_f2ord(INFINITY); h.pt_hi[d] = nf_f2ord(-INFINITY); }
+        *(NfGridHeader*)ws = h;
+    }
+    for (int c = tid; c < nc; c += TP_BLOCK) cells[c] = 0;
+    __syncthreads();
+    // ---- integrate + count
+    const float g[3] = {gx, gy, gz};
+    int mycell[TP_MAX_PER_THREAD];
+    float px[TP_MAX_PER_THREAD], py[TP_MAX_PER_THREAD], pz[TP_MAX_PER_THREAD];
+#pragma unroll
+    for (int u = 0; u < TP_MAX_PER_THREAD; ++u) {
+        const int i = u * TP_BLOCK + tid;
+        mycell[u] = -1;
+        if (i < n) {
+            float pn[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const float v = vel[3 * i + d];
+                const float vn = v + g[d] * dt;                       // same expressions as k_trans_integrate
+                pn[d] = pos[3 * i + d] + (v + vn) / 2 * dt;
+                pos_new[3 * i + d] = pn[d];
+                vel_new[3 * i + d] = vn;
+                feats4[4 * i + 1 + d] = vn;
+            }
+            feats4[4 * i] = 1.f;
+            const int cx = nf_cell_coord(pn[0], h.origin[0], h.inv_cell[0], h.dims[0]);
+            const int cy = nf_cell_coord(pn[1], h.origin[1], h.inv_cell[1], h.dims[1]);
+            const int cz = nf_cell_coord(pn[2], h.origin[2], h.inv_cell[2], h.dims[2]);
+            mycell[u] = (cz * h.dims[1] + cy) * h.dims[0] + cx;
+            px[u] = pn[0]; py[u] = pn[1]; pz[u] = pn[2];
+            atomicAdd(&cells[mycell[u]], 1);
+        }
+    }
+    __syncthreads();
+    // ---- exclusive scan of the cell counts (each thread a contiguous run, block scan of the run sums)
+    const int per = (nc + TP_BLOCK - 1) / TP_BLOCK;
+    const int c0 = tid * per, c1 = min(c0 + per, nc);
+    int run = 0;
+    for (int c = c0; c < c1; ++c) run += cells[c];
+    {
+        const int lane = tid & 63, w = tid >> 6;
+        int x = run;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+        if (lane == 63) s_scan[w] = x;
+        __syncthreads();
+        if (w == 0) {
+            int s = lane < TP_BLOCK / 64 ? s_scan[lane] : 0;
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { const int y = __shfl_up(s, o, 64); if (lane >= o) s += y; }
+            if (lane < TP_BLOCK / 64) s_scan[lane] = s;
+        }
+        __syncthreads();
+        int base = (w ? s_scan[w - 1] : 0) + x - run;
+        for (int c = c0; c < c1; ++c) { const int cnt = cells[c]; cells[c] = base; cell_start[c] = base; base += cnt; }
+        if (tid == TP_BLOCK - 1) cell_start[nc] = s_scan[TP_BLOCK / 64 - 1];
+    }
+    __syncthreads();
+    // ---- scatter (arrival order), cells[] ends up holding the END of every cell
+#pragma unroll
+    for (int u = 0; u < TP_MAX_PER_THREAD; ++u)
+        if (mycell[u] >= 0) tmp_list[atomicAdd(&cells[mycell[u]], 1)] = u * TP_BLOCK + tid;
+    __threadfence_block();
+    __syncthreads();
+    // ---- stable order inside each cell: rank = number of same-cell points with a smaller original index
+#pragma unroll
+    for (int u = 0; u < TP_MAX_PER_THREAD; ++u) {
+        const int c = mycell[u];
+        if (c < 0) continue;
+        const int i = u * TP_BLOCK + tid;
+        const int s = c ? cells[c - 1] : 0, e = cells[c];
+        int rank = 0;
+        for (int t = s; t < e; ++t) rank += (tmp_list[t] < i);
+        sorted_idx[s + rank] = i;
+        sorted_pos[s + rank] = make_float4(px[u], py[u], pz[u], __int_as_float(i));
+    }
+}
+
+extern "C" int nf_trans_prepare(const float* pos, const float* vel, const float gravity[3], float dt, int n, float cell,
+                                const float bbox[6], void* grid_ws, size_t ws_bytes, float* pos_new, float* vel_new,
+                                float* feats4, nf_stream_t stream)
+{
+    NF_CHECK_ARG(pos && vel && gravity && grid_ws && pos_new && vel_new && feats4, "null pointer");
+    NfGridHeader h;
+    size_t tot = 0;
+    NF_CHECK_ARG(nf_grid_make_header(n, cell, bbox, &h, &tot) == NF_OK, "bad grid parameters");
+    NF_CHECK_ARG(ws_bytes >= tot, "workspace too small");
+    NF_CHECK_ARG(n > 0 && n <= TP_BLOCK * TP_MAX_PER_THREAD && h.n_cells <= TP_MAX_CELLS,
+                 "cloud or grid too large for the single-workgroup build (use nf_trans_integrate + nf_grid_build)");
+    const size_t lds = (size_t)h.n_cells * sizeof(int);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)k_trans_prepare, hipFuncAttributeMaxDynamicSharedMemorySize, TP_MAX_CELLS * (int)sizeof(int));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_trans_prepare, dim3(1), dim3(TP_BLOCK), lds, (hipStream_t)stream, h, grid_ws, pos, vel, gravity[0],
+                       gravity[1], gravity[2], dt, pos_new, vel_new, feats4);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// neighbour search of both clouds (Open3D FixedRadiusSearch contract, as k_radius in nf_grid.hip: one wave per query,
+// the 3 x-adjacent cells of each (z, y) row swept 64 candidates at a time, ballot/popcount placement)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void tr_ball_to_cube(float& x, float& y, float& z)
+{
+    // sphere -> cylinder -> cube, volume preserving (identical to nf_cconv.hip:ball_to_cube)
+    float sq = x * x + y * y + z * z;
+    float nrm = sqrtf(sq);
+    float xy2 = x * x + y * y;
+    if (sq < 1e-12f) { x = y = z = 0.f; }
+    else if (1.25f * z * z > xy2) {
+        float s = sqrtf(3.f * nrm / (nrm + fabsf(z)));
+        x *= s; y *= s; z = copysignf(nrm, z);
+    } else {
+        float s = nrm / sqrtf(xy2);
+        x *= s; y *= s; z *= 1.5f;
+    }
+    float sq2 = x * x + y * y;
+    float nxy = sqrtf(sq2);
+    const float four_over_pi = 1.2732395447351628f;
+    if (sq2 < 1e-12f) { x = y = 0.f; }
+    else if (fabsf(y) <= fabsf(x)) {
+        float t = copysignf(nxy, x);
+        y = t * four_over_pi * atanf(y / x);
+        x = t;
+    } else {
+        float t = copysignf(nxy, y);
+        x = t * four_over_pi * atanf(x / y);
+        y = t;
+    }
+}
+
+struct TrSearch {
+    const void* grid[2];        // 0: fluid, 1: box
+    const float* q;             // queries = integrated positions
+    int n;
+    float r2;
+};
+
+#define TR_QPB 4
+template <bool FILL>
+__device__ __forceinline__ int tr_sweep(const NfGridView& g, float qx, float qy, float qz, float r2, int lane, int64_t o,
+                                        int64_t cap, float extent, int use_window, int32_t* __restrict__ idx,
+                                        float* __restrict__ dist2, float* __restrict__ pw, uint8_t* __restrict__ pc)
+{
+    const int cx = nf_cell_coord(qx, g.ox, g.icx, g.dx);
+    const int cy = nf_cell_coord(qy, g.oy, g.icy, g.dy);
+    const int cz = nf_cell_coord(qz, g.oz, g.icz, g.dz);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const float radius = 0.5f * extent, inv_r2 = 1.f / (radius * radius), scale = 2.f / extent;
+    int cnt = 0;
+    for (int z = max(cz - 1, 0); z <= min(cz + 1, g.dz - 1); ++z)
+        for (int y = max(cy - 1, 0); y <= min(cy + 1, g.dy - 1); ++y) {
+            const int r0 = (z * g.dy + y) * g.dx;
+            const int s = g.cell_start[r0 + max(cx - 1, 0)], e = g.cell_start[r0 + min(cx + 1, g.dx - 1) + 1];
+            for (int t0 = s; t0 < e; t0 += 64) {
+                const int t = t0 + lane;
+                bool hit = false;
+                float d2 = 0.f;
+                float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (t < e) {
+                    p = g.sorted_pos[t];
+                    d2 = nf_dist2(qx, qy, qz, p.x, p.y, p.z);
+                    hit = d2 <= r2 && !(p.x == qx && p.y == qy && p.z == qz);      // radius_search_ignore_query_points=True
+                }
+                const unsigned long long m = __ballot(hit);
+                if (FILL && hit) {
+                    const int64_t w = o + cnt + __popcll(m & lt);
+                    if (w < cap) {
+                        idx[w] = __float_as_int(p.w);
+                        dist2[w] = d2;
+                        // per-pair interpolation data, exactly k_pair_precompute (nf_cconv.hip)
+                        float x = (p.x - qx) * scale, yy = (p.y - qy) * scale, zz = (p.z - qz) * scale;
+                        tr_ball_to_cube(x, yy, zz);
+                        float imp = 1.f;
+                        if (use_window) { const float tt = 1.f - d2 * inv_r2; imp = fminf(fmaxf(tt * tt * tt, 0.f), 1.f); }
+                        const float c[3] = {(x + 1.f) * 1.5f, (yy + 1.f) * 1.5f, (zz + 1.f) * 1.5f};
+                        int i0[3];
+                        float f[3];
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) {
+                            const float cc = fminf(fmaxf(c[d], 0.f), 3.f);
+                            const float fl = fminf(floorf(cc), 2.f);
+                            i0[d] = (int)fl;
+                            f[d] = cc - fl;
+                        }
+                        float wv[8];
+                        unsigned cl[2] = {0u, 0u};
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
+                            wv[k] = imp * ((dx ? f[0] : 1.f - f[0]) * (dy ? f[1] : 1.f - f[1]) * (dz ? f[2] : 1.f - f[2]));
+                            cl[k >> 2] |= (unsigned)(((i0[2] + dz) * 4 + (i0[1] + dy)) * 4 + (i0[0] + dx)) << (8 * (k & 3));
+                        }
+                        *(float4*)(pw + w * 8) = make_float4(wv[0], wv[1], wv[2], wv[3]);
+                        *(float4*)(pw + w * 8 + 4) = make_float4(wv[4], wv[5], wv[6], wv[7]);
+                        *(uint2*)(pc + w * 8) = make_uint2(cl[0], cl[1]);
+                    }
+                }
+                cnt += __popcll(m);
+            }
+        }
+    return cnt;
+}
+
+// counts[2][n]; the last workgroup scans them: row_splits[2][n+1] (clamped to the capacities), totals[2] (true sums),
+// num_fluid_nbrs[n] = fluid count as float (reduce_subarrays_sum of ones, models/transmodel.py:135-138)
+__global__ void __launch_bounds__(64 * TR_QPB) k_trans_count(TrSearch S, int* __restrict__ counts, unsigned* __restrict__ done,
+                                                             int64_t* __restrict__ row_splits, int64_t* __restrict__ totals,
+                                                             int64_t cap_f, int64_t cap_b, float* __restrict__ num_nbrs)
+{
+    const int lane = threadIdx.x & 63, which = blockIdx.y;
+    const int i = blockIdx.x * TR_QPB + (threadIdx.x >> 6);
+    if (i < S.n) {
+        NfGridView g = nf_grid_view(S.grid[which]);
+        const int cnt = tr_sweep<false>(g, S.q[3 * i], S.q[3 * i + 1], S.q[3 * i + 2], S.r2, lane, 0, 0, 1.f, 0, nullptr, nullptr,
+                                        nullptr, nullptr);
+        if (lane == 0) counts[which * S.n + i] = cnt;
+    }
+    // ---- last workgroup done: scan (agent-scope release by every block, acquire by the last one)
+    __shared__ unsigned s_last;
+    __shared__ int64_t s_part[64 * TR_QPB];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the arrival must not overtake the write-back (MI355X_MICROARCH.md)
+        const unsigned total_blocks = gridDim.x * gridDim.y;
+        s_last = (atomicAdd(done, 1u) == total_blocks - 1u) ? 1u : 0u;
+        if (s_last) { *done = 0u; __threadfence(); }
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const int T = 64 * TR_QPB;
+    for (int w2 = 0; w2 < 2; ++w2) {
+        const int* cn = counts + w2 * S.n;
+        int64_t* rs = row_splits + (size_t)w2 * (S.n + 1);
+        const int64_t cap = w2 ? cap_b : cap_f;
+        const int per = (S.n + T - 1) / T;
+        const int a = threadIdx.x * per, e = min(a + per, S.n);
+        int64_t run = 0;
+        for (int t = a; t < e; ++t) run += __builtin_nontemporal_load(cn + t);     // written by other CUs: bypass this CU's L1
+        s_part[threadIdx.x] = run;
+        __syncthreads();
+        int64_t base = 0;
+        for (int t = 0; t < (int)threadIdx.x; ++t) base += s_part[t];
+        for (int t = a; t < e; ++t) {
+            const int c = __builtin_nontemporal_load(cn + t);
+            rs[t] = base < cap ? base : cap;
+            if (w2 == 0) num_nbrs[t] = (float)c;
+            base += c;
+        }
+        if (threadIdx.x == T - 1) { rs[S.n] = base < cap ? base : cap; totals[w2] = base; }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(64 * TR_QPB) k_trans_fill(TrSearch S, const int64_t* __restrict__ row_splits, int64_t cap_f,
+                                                            int64_t cap_b, float extent, int use_window,
+                                                            int32_t* __restrict__ idx_f, float* __restrict__ d2_f,
+                                                            float* __restrict__ pw_f, uint8_t* __restrict__ pc_f,
+                                                            int32_t* __restrict__ idx_b, float* __restrict__ d2_b,
+                                                            float* __restrict__ pw_b, uint8_t* __restrict__ pc_b)
+{
+    const int lane = threadIdx.x & 63, which = blockIdx.y;
+    const int i = blockIdx.x * TR_QPB + (threadIdx.x >> 6);
+    if (i >= S.n) return;
+    const int64_t cap = which ? cap_b : cap_f;
+    const int64_t o = row_splits[(size_t)which * (S.n + 1) + i];
+    if (o >= cap) return;
+    NfGridView g = nf_grid_view(S.grid[which]);
+    tr_sweep<true>(g, S.q[3 * i], S.q[3 * i + 1], S.q[3 * i + 2], S.r2, lane, o, cap, extent, use_window, which ? idx_b : idx_f,
+                   which ? d2_b : d2_f, which ? pw_b : pw_f, which ? pc_b : pc_f);
+}
+
+extern "C" size_t nf_trans_count_workspace_bytes(int n) { return sizeof(int) * 2 * (size_t)(n > 0 ? n : 1) + 256; }
+
+extern "C" int nf_trans_count(const void* fluid_grid, const void* box_grid, const float* queries, int n, float radius,
+                              int64_t cap_fluid, int64_t cap_box, void* workspace, int64_t* row_splits2, int64_t* totals2,
+                              float* num_fluid_nbrs, nf_stream_t stream)
+{
+    NF_CHECK_ARG(fluid_grid && box_grid && queries && workspace && row_splits2 && totals2 && num_fluid_nbrs, "null pointer");
+    NF_CHECK_ARG(n > 0 && radius > 0.f, "bad n/radius");
+    TrSearch S;
+    S.grid[0] = fluid_grid; S.grid[1] = box_grid; S.q = queries; S.n = n; S.r2 = radius * radius;
+    // workspace: [done counter (256 B, zero between calls: the last block resets it)][counts 2 x n]
+    unsigned* done = (unsigned*)workspace;
+    int* counts = (int*)((char*)workspace + 256);
+    hipLaunchKernelGGL(k_trans_count, dim3((n + TR_QPB - 1) / TR_QPB, 2), dim3(64 * TR_QPB), 0, (hipStream_t)stream, S, counts, done,
+                       row_splits2, totals2, cap_fluid, cap_box, num_fluid_nbrs);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+extern "C" int nf_trans_fill(const void* fluid_grid, const void* box_grid, const float* queries, int n, float radius, float extent,
+                             int use_window, const int64_t* row_splits2, int64_t cap_fluid, int64_t cap_box, int32_t* idx_f,
+                             float* d2_f, float* pw_f, uint8_t* pc_f, int32_t* idx_b, float* d2_b, float* pw_b, uint8_t* pc_b,
+                             nf_stream_t stream)
+{
+    NF_CHECK_ARG(fluid_grid && box_grid && queries && row_splits2 && idx_f && d2_f && pw_f && pc_f && idx_b && d2_b && pw_b && pc_b,
+                 "null pointer");
+    NF_CHECK_ARG(n > 0 && radius > 0.f && extent > 0.f, "bad n/radius/extent");
+    TrSearch S;
+    S.grid[0] = fluid_grid; S.grid[1] = box_grid; S.q = queries; S.n = n; S.r2 = radius * radius;
+    hipLaunchKernelGGL(k_trans_fill, dim3((n + TR_QPB - 1) / TR_QPB, 2), dim3(64 * TR_QPB), 0, (hipStream_t)stream, S, row_splits2,
+                       cap_fluid, cap_box, extent, use_window, idx_f, d2_f, pw_f, pc_f, idx_b, d2_b, pw_b, pc_b);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// layer 0: [conv0_obstacle(box normals) | conv0_fluid([1, v]) | dense0_fluid([1, v])] -> a0 (n x 96)
+// (models/transmodel.py:116-120).  One wave per point; both 64-cell filters (3 x 32 and 4 x 32 per cell) in LDS; a
+// half-wave per pair, lane = output channel; the pair's 8 weights / 8 cells arrive as two 16-B and one 8-B load.
+// ------------------------------------------------------------------------------------------------
+template <int CIN>
+__device__ __forceinline__ float tr_conv_row(const float* __restrict__ Ks, const float* __restrict__ feats, const int64_t* __restrict__ rs,
+                                             const int32_t* __restrict__ nbr, const float* __restrict__ pw,
+                                             const uint8_t* __restrict__ pc, int row, int co, int half)
+{
+    float acc = 0.f;
+    for (int64_t p = rs[row] + half; p < rs[row + 1]; p += 2) {
+        const int j = nbr[p];
+        float fj[CIN];
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) fj[ci] = feats[(size_t)j * CIN + ci];
+        const float4 w0 = *(const float4*)(pw + p * 8), w1 = *(const float4*)(pw + p * 8 + 4);
+        const uint2 cc = *(const uint2*)(pc + p * 8);
+        const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int cell = (int)(((k < 4 ? cc.x : cc.y) >> (8 * (k & 3))) & 0xffu);
+            const float* kc = Ks + cell * CIN * 32 + co;
+            float s = 0.f;
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) s += fj[ci] * kc[ci * 32];
+            acc += wv[k] * s;
+        }
+    }
+    return acc + __shfl_xor(acc, 32, 64);
+}
+
+__global__ void __launch_bounds__(256) k_trans_conv0(const float* __restrict__ box_feats, const float* __restrict__ fluid_feats,
+                                                     const int64_t* __restrict__ rs2, int n, const int32_t* __restrict__ idx_f,
+                                                     const float* __restrict__ pw_f, const uint8_t* __restrict__ pc_f,
+                                                     const int32_t* __restrict__ idx_b, const float* __restrict__ pw_b,
+                                                     const uint8_t* __restrict__ pc_b, const float* __restrict__ k_obst,
+                                                     const float* __restrict__ b_obst, const float* __restrict__ k_fluid,
+                                                     const float* __restrict__ b_fluid, const float* __restrict__ dense_w,
+                                                     const float* __restrict__ dense_b, float* __restrict__ out /*n x 96*/)
+{
+    __shared__ float Ko[64 * 3 * 32];
+    __shared__ float Kf[64 * 4 * 32];
+    for (int t = threadIdx.x; t < 64 * 3 * 32; t += 256) Ko[t] = k_obst[t];
+    for (int t = threadIdx.x; t < 64 * 4 * 32; t += 256) Kf[t] = k_fluid[t];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, co = lane & 31, half = lane >> 5;
+    const int64_t* rs_f = rs2;
+    const int64_t* rs_b = rs2 + (n + 1);
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < n; row += gridDim.x * 4) {
+        const float ao = tr_conv_row<3>(Ko, box_feats, rs_b, idx_b, pw_b, pc_b, row, co, half);
+        const float af = tr_conv_row<4>(Kf, fluid_feats, rs_f, idx_f, pw_f, pc_f, row, co, half);
+        float* o = out + (size_t)row * 96;
+        if (half == 0) {
+            o[co] = ao + b_obst[co];
+            o[32 + co] = af + b_fluid[co];
+        } else {
+            float s = dense_b[co];
+#pragma unroll
+            for (int ci = 0; ci < 4; ++ci) s += fluid_feats[(size_t)row * 4 + ci] * dense_w[co * 4 + ci];
+            o[64 + co] = s;
+        }
+    }
+}
+
+extern "C" int nf_trans_conv0(const float* box_feats, const float* fluid_feats, const int64_t* row_splits2, int n,
+                              const int32_t* idx_f, const float* pw_f, const uint8_t* pc_f, const int32_t* idx_b,
+                              const float* pw_b, const uint8_t* pc_b, const float* kernel_obstacle, const float* bias_obstacle,
+                              const float* kernel_fluid, const float* bias_fluid, const float* dense_w, const float* dense_b,
+                              float* out96, nf_stream_t stream)
+{
+    NF_CHECK_ARG(box_feats && fluid_feats && row_splits2 && idx_f && pw_f && pc_f && idx_b && pw_b && pc_b && kernel_obstacle &&
+                 bias_obstacle && kernel_fluid && bias_fluid && dense_w && dense_b && out96, "null pointer");
+    if (n <= 0) return NF_OK;
+    int blocks = (n + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_trans_conv0, dim3(blocks), dim3(256), 0, (hipStream_t)stream, box_feats, fluid_feats, row_splits2, n, idx_f,
+                       pw_f, pc_f, idx_b, pw_b, pc_b, kernel_obstacle, bias_obstacle, kernel_fluid, bias_fluid, dense_w, dense_b,
+                       out96);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}

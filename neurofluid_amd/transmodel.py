@@ -141,6 +141,11 @@ class ParticleNet(nn.Module):
         self._box_cache = (None, None, None)
         self.num_fluid_neighbors = None
         self._graph_cfg, self._graph, self._nnz_seen = None, None, None
+        # fused inference step (nf_trans.hip): CSR capacities in pairs per particle (dense SPH fluid at this radius has
+        # ~40-50 fluid neighbours; the container contributes < 30), persistent buffers per particle count
+        self.max_fluid_neighbors, self.max_box_neighbors = 128, 64
+        self.fused_inference = True
+        self._fused = None
 
     _window_poly6 = staticmethod(_window_poly6)
 
@@ -192,7 +197,138 @@ class ParticleNet(nn.Module):
         with torch.no_grad():
             if self._graph_cfg is not None:
                 return self._graph_step(pos, vel, box, box_feats)
+            if self.fused_inference and self._fused_ok(pos, box):
+                return self._forward_fused(pos, vel, box, box_feats)
             return self._forward_impl(pos, vel, box, box_feats)[:3]
+
+    # ------------------------------------------------------------------
+    # Fused inference step: 10 launches, no host round trip.  prepare (integrate + fluid grid, one
+    # workgroup) -> count + scan (fluid and box in one launch) -> fill + pair interpolation data -> conv0 (obstacle +
+    # fluid + dense) -> 3 x (transform GEMM, gather), the last gather with the position / velocity update fused.
+    # CSR buffers are sized by capacities; an overflow poisons the outputs with NaN on the device and raises at the next
+    # call that finds the (asynchronously copied) pair totals.
+    def _fused_ok(self, pos, box):
+        lib = _lib.load()
+        if getattr(self, "_fused_limits", None) is None:
+            mp, mc = ctypes.c_int(), ctypes.c_int()
+            lib.nf_trans_prepare_limits(ctypes.byref(mp), ctypes.byref(mc))
+            self._fused_limits = (mp.value, mc.value)
+        n = pos.shape[0]
+        if n < 1 or n > self._fused_limits[0]:
+            return False
+        bbox = self._scene_bbox(box.detach())
+        cell = 0.5 * float(self.filter_extent)
+        cells = 1
+        for d in range(3):
+            cells *= int((bbox[3 + d] - bbox[d]) / cell) + 1
+        return cells <= self._fused_limits[1]
+
+    def _fused_buffers(self, n, dev, bbox):
+        st = self._fused
+        key = (n, str(dev), bbox, self.max_fluid_neighbors, self.max_box_neighbors)
+        if st is not None and st["key"] == key:
+            return st
+        lib = _lib.load()
+        radius = 0.5 * float(self.filter_extent)
+        bb = (ctypes.c_float * 6)(*[float(v) for v in bbox])
+        cap_f, cap_b = n * self.max_fluid_neighbors, n * self.max_box_neighbors
+        f32, i32, i64, u8 = torch.float32, torch.int32, torch.int64, torch.uint8
+        E = lambda *shape, dtype=f32: torch.empty(*shape, dtype=dtype, device=dev)      # noqa: E731
+        st = dict(key=key, bb=bb, cap=(cap_f, cap_b),
+                  grid_ws=E(lib.nf_grid_workspace_bytes(n, radius, bb), dtype=u8), pos_new=E(n, 3), vel_new=E(n, 3), feats=E(n, 4),
+                  count_ws=torch.zeros(lib.nf_trans_count_workspace_bytes(n), dtype=u8, device=dev),
+                  rs2=E(2 * (n + 1), dtype=i64), totals=torch.zeros(2, dtype=i64, device=dev),
+                  idx_f=E(cap_f, dtype=i32), d2_f=E(cap_f), pw_f=E(cap_f * 8), pc_f=E(cap_f * 8, dtype=u8),
+                  idx_b=E(cap_b, dtype=i32), d2_b=E(cap_b), pw_b=E(cap_b * 8), pc_b=E(cap_b * 8, dtype=u8),
+                  a0=E(n, 96), a1=E(n, 64), a2=E(n, 64), y3=E(n, 3), G=E(n * 65 * 64),
+                  pending=[], slots=[torch.empty(2, dtype=i64).pin_memory() for _ in range(4)], step=0)
+        self._fused = st
+        return st
+
+    def check_capacity(self, wait=False):
+        """Raises if a finished fused step overflowed its pair capacities (its outputs were poisoned with NaN on the device).
+        wait=True blocks until every launched step has reported."""
+        st = self._fused
+        if st is None:
+            return
+        keep = []
+        for ev, slot in st["pending"]:
+            if wait:
+                ev.synchronize()
+            if ev.query():
+                f, b = slot.tolist()
+                if f > st["cap"][0] or b > st["cap"][1]:
+                    st["pending"] = []
+                    raise RuntimeError(f"ParticleNet fused step: {f} fluid / {b} box pairs exceed the capacities {st['cap']} "
+                                       "(outputs of that step are NaN); raise ParticleNet.max_fluid_neighbors / max_box_neighbors")
+            else:
+                keep.append((ev, slot))
+        st["pending"] = keep
+
+    def _forward_fused(self, pos, vel, box, box_feats):
+        lib = _lib.load()
+        stream = _lib.stream()
+        pos = pos.detach().contiguous().float()
+        vel = vel.detach().contiguous().float()
+        box = box.detach().contiguous().float()
+        box_feats = box_feats.detach().contiguous().float()
+        n, dev = pos.shape[0], pos.device
+        extent = float(self.filter_extent)
+        radius = 0.5 * extent
+        bbox = self._scene_bbox(box)
+        st = self._fused_buffers(n, dev, bbox)
+        self.check_capacity()
+        if len(st["pending"]) >= len(st["slots"]):          # every report slot in flight: wait for the oldest
+            st["pending"][0][0].synchronize()
+            self.check_capacity()
+        cap_f, cap_b = st["cap"]
+        bgrid = self._box_grid(box)
+        g = (ctypes.c_float * 3)(*[float(v) for v in self._gravity_host()])
+        check(lib.nf_trans_prepare(ptr(pos), ptr(vel), g, float(self.time_step), n, radius, st["bb"], ptr(st["grid_ws"]),
+                                   st["grid_ws"].numel(), ptr(st["pos_new"]), ptr(st["vel_new"]), ptr(st["feats"]), stream),
+              "nf_trans_prepare")
+        nn = torch.empty(n, dtype=torch.float32, device=dev)
+        check(lib.nf_trans_count(ptr(st["grid_ws"]), ptr(bgrid.ws), ptr(st["pos_new"]), n, radius, cap_f, cap_b, ptr(st["count_ws"]),
+                                 ptr(st["rs2"]), ptr(st["totals"]), ptr(nn), stream), "nf_trans_count")
+        check(lib.nf_trans_fill(ptr(st["grid_ws"]), ptr(bgrid.ws), ptr(st["pos_new"]), n, radius, extent, int(self.use_window),
+                                ptr(st["rs2"]), cap_f, cap_b, ptr(st["idx_f"]), ptr(st["d2_f"]), ptr(st["pw_f"]), ptr(st["pc_f"]),
+                                ptr(st["idx_b"]), ptr(st["d2_b"]), ptr(st["pw_b"]), ptr(st["pc_b"]), stream), "nf_trans_fill")
+        c0o, c0f, d0 = self.conv0_obstacle, self.conv0_fluid, self.dense0_fluid
+        check(lib.nf_trans_conv0(ptr(box_feats), ptr(st["feats"]), ptr(st["rs2"]), n, ptr(st["idx_f"]), ptr(st["pw_f"]), ptr(st["pc_f"]),
+                                 ptr(st["idx_b"]), ptr(st["pw_b"]), ptr(st["pc_b"]), ptr(c0o.kernel.detach()), ptr(c0o.bias.detach()),
+                                 ptr(c0f.kernel.detach()), ptr(c0f.bias.detach()), ptr(d0.weight.detach()), ptr(d0.bias.detach()),
+                                 ptr(st["a0"]), stream), "nf_trans_conv0")
+        f_rs = st["rs2"][:n + 1]
+        prev = st["a0"]
+        outs = [st["a1"], st["a2"], st["y3"]]
+        pos_c, vel_c = torch.empty_like(pos), torch.empty_like(pos)
+        for li, (conv, dense) in enumerate(zip(self.convs, self.denses)):
+            cin, cout = prev.shape[1], conv.kernel.shape[-1]
+            check(lib.nf_cconv_transform(ptr(prev), n, cin, cout, 1, ptr(conv.kernel.detach()), ptr(dense.weight.detach()),
+                                         ptr(st["G"]), stream), "nf_cconv_transform")
+            y = outs[li]
+            if li < 2:
+                res = prev if dense.out_features == cin else None
+                check(lib.nf_cconv_gather(ptr(st["G"]), cout, ptr(f_rs), ptr(st["idx_f"]), ptr(st["pw_f"]), ptr(st["pc_f"]),
+                                          ptr(conv.bias.detach()), ptr(dense.bias.detach()), ptr(res), n, ptr(y), stream),
+                      "nf_cconv_gather")
+            else:
+                check(lib.nf_cconv_gather_update(ptr(st["G"]), ptr(f_rs), ptr(st["idx_f"]), ptr(st["pw_f"]), ptr(st["pc_f"]),
+                                                 ptr(conv.bias.detach()), ptr(dense.bias.detach()), n, ptr(y), ptr(pos),
+                                                 ptr(st["pos_new"]), 1.0 / 128, float(self.time_step), ptr(st["totals"]), cap_f,
+                                                 cap_b, ptr(pos_c), ptr(vel_c), stream), "nf_cconv_gather_update")
+            prev = y
+        # pair totals -> pinned host slot, checked by a later call (or check_capacity(wait=True))
+        slot = st["slots"][st["step"] % len(st["slots"])]
+        st["step"] += 1
+        slot.copy_(st["totals"], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        st["pending"].append((ev, slot))
+        self.num_fluid_neighbors = nn
+        self._y3 = st["y3"]
+        self.conv0_fluid.nns = SimpleNamespace(neighbors_index=st["idx_f"], neighbors_row_splits=f_rs, neighbors_distance=st["d2_f"])
+        return pos_c, vel_c, nn
 
     # ------------------------------------------------------------------
     # HIP-graph replay of the inference step.  The step is launch-bound (about 45 launches for 0.4 ms of GPU work at

@@ -351,3 +351,39 @@ def test_rollout_200_frames_honeycone(dev):
     assert max(free[:100]) <= ROLLOUT_MEAN_L2, max(free[:100])
     assert all(f <= max(n, 1e-7) for f, n in zip(free, noise)), max(f / max(n, 1e-7) for f, n in zip(free, noise))
     assert max(stepped) <= 1e-6, max(stepped)
+
+
+def test_fused_inference_step_bit_equal(dev):
+    """The fused inference step (nf_trans.hip: prepare / count+scan / fill+pairs / conv0 in 4 launches, update fused into
+    the last gather, capacity-sized CSR, no host round trip) must reproduce the multi-launch path BIT FOR BIT over a
+    rollout (same kernels' arithmetic, same neighbour order), for the lattice cloud and a shuffled shaped one; a capacity
+    overflow poisons the outputs with NaN and raises at the next report."""
+    from neurofluid_amd import synthetic
+    from oracle import trans_oracle as to
+    box, bn = [t.to(dev) for t in to.watercube_box()]
+    for P in (synthetic.watercube_particles(), synthetic.shaped_particles("bunny", order="random"),
+              torch.tensor([[0.0, 0.0, 0.5], [0.5, 0.5, 0.5], [0.52, 0.5, 0.5], [5.0, 5.0, 5.0], [-0.99, -0.99, -0.99]])):
+        pa, _ = make_pn(dev)
+        pb, _ = make_pn(dev)
+        pb.fused_inference = False
+        p1 = p2 = P.to(dev)
+        v1 = v2 = torch.zeros_like(p1)
+        with torch.no_grad():
+            for it in range(6):
+                p1, v1, n1 = pa(p1, v1, box, bn)
+                p2, v2, n2 = pb(p2, v2, box, bn)
+                assert torch.equal(p1, p2) and torch.equal(v1, v2) and torch.equal(n1, n2), it
+        assert pa._fused is not None and pb._fused is None
+        pa.check_capacity(wait=True)
+        rs = pa.conv0_fluid.nns.neighbors_row_splits
+        assert torch.equal(rs, pb.conv0_fluid.nns.neighbors_row_splits)
+        nnz = int(rs[-1])
+        assert torch.equal(pa.conv0_fluid.nns.neighbors_index[:nnz], pb.conv0_fluid.nns.neighbors_index[:nnz])
+    pc, _ = make_pn(dev)
+    pc.max_fluid_neighbors = 8
+    P = synthetic.watercube_particles().to(dev)
+    with torch.no_grad():
+        a, b, _ = pc(P, torch.zeros_like(P), box, bn)
+    assert bool(torch.isnan(a).all()) and bool(torch.isnan(b).all())
+    with pytest.raises(RuntimeError, match="exceed the capacities"):
+        pc.check_capacity(wait=True)

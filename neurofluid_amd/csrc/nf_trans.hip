@@ -20,12 +20,12 @@
 
 #define TP_BLOCK 1024
 #define TP_MAX_PER_THREAD 16            // n <= 16 384 particles
-#define TP_MAX_CELLS 36864              // 144 KB of LDS
+#define TP_MAX_LDS_INTS 39936           // cell counters + the scatter list, 156 KB of LDS: n_cells + n_points <= this
 
 extern "C" int nf_trans_prepare_limits(int* max_points, int* max_cells)
 {
     if (max_points) *max_points = TP_BLOCK * TP_MAX_PER_THREAD;
-    if (max_cells) *max_cells = TP_MAX_CELLS;
+    if (max_cells) *max_cells = TP_MAX_LDS_INTS;     /* n_cells + n_points must not exceed this */
     return NF_OK;
 }
 
@@ -34,11 +34,11 @@ __global__ void __launch_bounds__(TP_BLOCK) k_trans_prepare(NfGridHeader h, void
                                                             float* __restrict__ pos_new, float* __restrict__ vel_new,
                                                             float* __restrict__ feats4)
 {
-    extern __shared__ int cells[];          // n_cells counters -> starts -> ends
+    extern __shared__ int cells[];          // n_cells counters -> starts -> ends, then the scatter list (n_points)
     __shared__ int s_scan[TP_BLOCK / 64];
     char* b = (char*)ws;
     int* cell_start = (int*)(b + h.off_cell_start);
-    int* tmp_list = (int*)(b + h.off_tmp_list);
+    int* tmp_list = cells + h.n_cells;
     int* sorted_idx = (int*)(b + h.off_sorted_idx);
     float4* sorted_pos = (float4*)(b + h.off_sorted_pos);
     const int n = h.n_points, nc = h.n_cells, tid = threadIdx.x;
@@ -105,7 +105,6 @@ __global__ void __launch_bounds__(TP_BLOCK) k_trans_prepare(NfGridHeader h, void
 #pragma unroll
     for (int u = 0; u < TP_MAX_PER_THREAD; ++u)
         if (mycell[u] >= 0) tmp_list[atomicAdd(&cells[mycell[u]], 1)] = u * TP_BLOCK + tid;
-    __threadfence_block();
     __syncthreads();
     // ---- stable order inside each cell: rank = number of same-cell points with a smaller original index
 #pragma unroll
@@ -130,12 +129,12 @@ extern "C" int nf_trans_prepare(const float* pos, const float* vel, const float 
     size_t tot = 0;
     NF_CHECK_ARG(nf_grid_make_header(n, cell, bbox, &h, &tot) == NF_OK, "bad grid parameters");
     NF_CHECK_ARG(ws_bytes >= tot, "workspace too small");
-    NF_CHECK_ARG(n > 0 && n <= TP_BLOCK * TP_MAX_PER_THREAD && h.n_cells <= TP_MAX_CELLS,
+    NF_CHECK_ARG(n > 0 && n <= TP_BLOCK * TP_MAX_PER_THREAD && h.n_cells + n <= TP_MAX_LDS_INTS,
                  "cloud or grid too large for the single-workgroup build (use nf_trans_integrate + nf_grid_build)");
-    const size_t lds = (size_t)h.n_cells * sizeof(int);
+    const size_t lds = (size_t)(h.n_cells + n) * sizeof(int);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)k_trans_prepare, hipFuncAttributeMaxDynamicSharedMemorySize, TP_MAX_CELLS * (int)sizeof(int));
+        hipFuncSetAttribute((const void*)k_trans_prepare, hipFuncAttributeMaxDynamicSharedMemorySize, TP_MAX_LDS_INTS * (int)sizeof(int));
         attr_set = true;
     }
     hipLaunchKernelGGL(k_trans_prepare, dim3(1), dim3(TP_BLOCK), lds, (hipStream_t)stream, h, grid_ws, pos, vel, gravity[0],
@@ -252,52 +251,64 @@ __device__ __forceinline__ int tr_sweep(const NfGridView& g, float qx, float qy,
 
 // counts[2][n]; the last workgroup scans them: row_splits[2][n+1] (clamped to the capacities), totals[2] (true sums),
 // num_fluid_nbrs[n] = fluid count as float (reduce_subarrays_sum of ones, models/transmodel.py:135-138)
-__global__ void __launch_bounds__(64 * TR_QPB) k_trans_count(TrSearch S, int* __restrict__ counts, unsigned* __restrict__ done,
+// 16 queries (waves) per workgroup: every workgroup arrives once on ONE device-scope counter (~12 ns per arrival, serialised:
+// 2 458 workgroups of 4 waves spent 30 us there; 616 of 16 waves spend 7)
+#define TC_QPB 16
+__global__ void __launch_bounds__(64 * TC_QPB) k_trans_count(TrSearch S, int* __restrict__ counts, unsigned* __restrict__ done,
                                                              int64_t* __restrict__ row_splits, int64_t* __restrict__ totals,
                                                              int64_t cap_f, int64_t cap_b, float* __restrict__ num_nbrs)
 {
     const int lane = threadIdx.x & 63, which = blockIdx.y;
-    const int i = blockIdx.x * TR_QPB + (threadIdx.x >> 6);
+    const int i = blockIdx.x * TC_QPB + (threadIdx.x >> 6);
     if (i < S.n) {
         NfGridView g = nf_grid_view(S.grid[which]);
         const int cnt = tr_sweep<false>(g, S.q[3 * i], S.q[3 * i + 1], S.q[3 * i + 2], S.r2, lane, 0, 0, 1.f, 0, nullptr, nullptr,
                                         nullptr, nullptr);
-        if (lane == 0) counts[which * S.n + i] = cnt;
+        // write-through (sc1) store: the scanning workgroup may sit on another XCD, whose L2 is not coherent with this one
+        if (lane == 0) __hip_atomic_store(counts + which * S.n + i, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    // ---- last workgroup done: scan (agent-scope release by every block, acquire by the last one)
+    // ---- last workgroup done: scan.  Hand-off = {sc1 payload stores, drained, then the device-scope arrival atomic} on the
+    // producer side and sc1 loads on the consumer side (MI355X_MICROARCH.md, inter-workgroup visibility: no L2 write-back
+    // fence per workgroup, which would cost microseconds in each of the ~2 500 workgroups)
     __shared__ unsigned s_last;
-    __shared__ int64_t s_part[64 * TR_QPB];
+    __shared__ int64_t s_wsum[TC_QPB];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the arrival must not overtake the write-back (MI355X_MICROARCH.md)
         const unsigned total_blocks = gridDim.x * gridDim.y;
         s_last = (atomicAdd(done, 1u) == total_blocks - 1u) ? 1u : 0u;
-        if (s_last) { *done = 0u; __threadfence(); }
+        if (s_last) *done = 0u;
     }
     __syncthreads();
     if (!s_last) return;
-    const int T = 64 * TR_QPB;
+    const int T = 64 * TC_QPB;
+    const int wv = threadIdx.x >> 6;
     for (int w2 = 0; w2 < 2; ++w2) {
         const int* cn = counts + w2 * S.n;
         int64_t* rs = row_splits + (size_t)w2 * (S.n + 1);
         const int64_t cap = w2 ? cap_b : cap_f;
-        const int per = (S.n + T - 1) / T;
-        const int a = threadIdx.x * per, e = min(a + per, S.n);
-        int64_t run = 0;
-        for (int t = a; t < e; ++t) run += __builtin_nontemporal_load(cn + t);     // written by other CUs: bypass this CU's L1
-        s_part[threadIdx.x] = run;
-        __syncthreads();
-        int64_t base = 0;
-        for (int t = 0; t < (int)threadIdx.x; ++t) base += s_part[t];
-        for (int t = a; t < e; ++t) {
-            const int c = __builtin_nontemporal_load(cn + t);
-            rs[t] = base < cap ? base : cap;
-            if (w2 == 0) num_nbrs[t] = (float)c;
-            base += c;
+        int64_t carry = 0;
+        for (int base_i = 0; base_i < S.n; base_i += T) {
+            const int t = base_i + threadIdx.x;
+            const int c = t < S.n ? __hip_atomic_load(cn + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+            int x = c;       // inclusive wave scan
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+            if (lane == 63) s_wsum[wv] = x;
+            __syncthreads();
+            int64_t before = carry;
+            int64_t chunk = 0;
+#pragma unroll
+            for (int k = 0; k < TC_QPB; ++k) { if (k < wv) before += s_wsum[k]; chunk += s_wsum[k]; }
+            if (t < S.n) {
+                const int64_t ex = before + x - c;
+                rs[t] = ex < cap ? ex : cap;
+                if (w2 == 0) num_nbrs[t] = (float)c;
+            }
+            carry += chunk;
+            __syncthreads();
         }
-        if (threadIdx.x == T - 1) { rs[S.n] = base < cap ? base : cap; totals[w2] = base; }
-        __syncthreads();
+        if (threadIdx.x == 0) { rs[S.n] = carry < cap ? carry : cap; totals[w2] = carry; }
     }
 }
 
@@ -332,7 +343,7 @@ extern "C" int nf_trans_count(const void* fluid_grid, const void* box_grid, cons
     // workspace: [done counter (256 B, zero between calls: the last block resets it)][counts 2 x n]
     unsigned* done = (unsigned*)workspace;
     int* counts = (int*)((char*)workspace + 256);
-    hipLaunchKernelGGL(k_trans_count, dim3((n + TR_QPB - 1) / TR_QPB, 2), dim3(64 * TR_QPB), 0, (hipStream_t)stream, S, counts, done,
+    hipLaunchKernelGGL(k_trans_count, dim3((n + TC_QPB - 1) / TC_QPB, 2), dim3(64 * TC_QPB), 0, (hipStream_t)stream, S, counts, done,
                        row_splits2, totals2, cap_fluid, cap_box, num_fluid_nbrs);
     NF_CHECK_LAUNCH();
     return NF_OK;
@@ -395,26 +406,31 @@ __global__ void __launch_bounds__(256) k_trans_conv0(const float* __restrict__ b
                                                      const float* __restrict__ b_fluid, const float* __restrict__ dense_w,
                                                      const float* __restrict__ dense_b, float* __restrict__ out /*n x 96*/)
 {
-    __shared__ float Ko[64 * 3 * 32];
-    __shared__ float Kf[64 * 4 * 32];
-    for (int t = threadIdx.x; t < 64 * 3 * 32; t += 256) Ko[t] = k_obst[t];
-    for (int t = threadIdx.x; t < 64 * 4 * 32; t += 256) Kf[t] = k_fluid[t];
+    // blockIdx.y = 0: conv0_obstacle -> columns 0..31; 1: conv0_fluid -> 32..63 and dense0_fluid -> 64..95.  A workgroup
+    // stages only its own filter (24 / 32 KB), so both halves keep the occupancy of the separate launches.
+    __shared__ float Ks[64 * 4 * 32];
+    const bool fluid = blockIdx.y == 1;
+    const float* ksrc = fluid ? k_fluid : k_obst;
+    const int kn = fluid ? 64 * 4 * 32 : 64 * 3 * 32;
+    for (int t = threadIdx.x; t < kn; t += 256) Ks[t] = ksrc[t];
     __syncthreads();
     const int lane = threadIdx.x & 63, co = lane & 31, half = lane >> 5;
     const int64_t* rs_f = rs2;
     const int64_t* rs_b = rs2 + (n + 1);
     for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < n; row += gridDim.x * 4) {
-        const float ao = tr_conv_row<3>(Ko, box_feats, rs_b, idx_b, pw_b, pc_b, row, co, half);
-        const float af = tr_conv_row<4>(Kf, fluid_feats, rs_f, idx_f, pw_f, pc_f, row, co, half);
         float* o = out + (size_t)row * 96;
-        if (half == 0) {
-            o[co] = ao + b_obst[co];
-            o[32 + co] = af + b_fluid[co];
+        if (!fluid) {
+            const float ao = tr_conv_row<3>(Ks, box_feats, rs_b, idx_b, pw_b, pc_b, row, co, half);
+            if (half == 0) o[co] = ao + b_obst[co];
         } else {
-            float s = dense_b[co];
+            const float af = tr_conv_row<4>(Ks, fluid_feats, rs_f, idx_f, pw_f, pc_f, row, co, half);
+            if (half == 0) o[32 + co] = af + b_fluid[co];
+            else {
+                float s = dense_b[co];
 #pragma unroll
-            for (int ci = 0; ci < 4; ++ci) s += fluid_feats[(size_t)row * 4 + ci] * dense_w[co * 4 + ci];
-            o[64 + co] = s;
+                for (int ci = 0; ci < 4; ++ci) s += fluid_feats[(size_t)row * 4 + ci] * dense_w[co * 4 + ci];
+                o[64 + co] = s;
+            }
         }
     }
 }
@@ -429,8 +445,8 @@ extern "C" int nf_trans_conv0(const float* box_feats, const float* fluid_feats, 
                  bias_obstacle && kernel_fluid && bias_fluid && dense_w && dense_b && out96, "null pointer");
     if (n <= 0) return NF_OK;
     int blocks = (n + 3) / 4;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_trans_conv0, dim3(blocks), dim3(256), 0, (hipStream_t)stream, box_feats, fluid_feats, row_splits2, n, idx_f,
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_trans_conv0, dim3(blocks, 2), dim3(256), 0, (hipStream_t)stream, box_feats, fluid_feats, row_splits2, n, idx_f,
                        pw_f, pc_f, idx_b, pw_b, pc_b, kernel_obstacle, bias_obstacle, kernel_fluid, bias_fluid, dense_w, dense_b,
                        out96);
     NF_CHECK_LAUNCH();

@@ -221,7 +221,7 @@ class ParticleNet(nn.Module):
         cells = 1
         for d in range(3):
             cells *= int((bbox[3 + d] - bbox[d]) / cell) + 1
-        return cells <= self._fused_limits[1]
+        return cells + n <= self._fused_limits[1]        # cell counters + scatter list share one workgroup's LDS
 
     def _fused_buffers(self, n, dev, bbox):
         st = self._fused

@@ -172,6 +172,14 @@ int nf_nerf_pack_h2(const nf_nerf_params_t* params, int cx, int cd, void* stream
 int nf_nerf_mlp_fwd_h2(const void* stream_h2, int cx, int cd, const void* X, const int32_t* n_rows, int max_rows,
                        const int32_t* row_sample, float* rgbsigma, nf_stream_t stream);
 
+/* Split-precision forward (nf_mlp_s.hip): every operand as hi + lo fp16, three fp16 MFMAs per product, fp32 accumulate —
+ * fp32-level accuracy (max-abs <= 2e-4 on RGB vs the fp32 path) at a multiple of the fp32-MFMA kernel's speed.  Takes
+ * the fp32 operand layout X of nf_render_features (x_fp16 = 0); its own weight stream.  Inference only. */
+size_t nf_nerf_packed_s_bytes(void);
+int nf_nerf_pack_s(const nf_nerf_params_t* params, int cx, int cd, void* stream_s, nf_stream_t stream);
+int nf_nerf_mlp_fwd_s(const void* stream_s, int cx, int cd, const float* X, const int32_t* n_rows, int max_rows,
+                      const int32_t* row_sample, float* rgbsigma, nf_stream_t stream);
+
 /* A12 (MLP part): data gradient of the MLP on fp32 MFMA with transposed packed weights.
  * Reads d_rgbsigma[row_sample[row]] (gradient w.r.t. the MLP output (rgb after sigmoid, sigma)) and the
  * activations saved by nf_nerf_mlp_fwd; writes, per row, the pre-activation gradients of every layer:

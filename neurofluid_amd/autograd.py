@@ -16,9 +16,9 @@ def _run_passes(net, particles, ro, rays, white_bg, fine, save_acts, _retry=Fals
     pts = grid.points
     rays_c = _prep(rays)
     ro_c = _prep(ro)
-    use_h = net.mlp_dtype == "fp16" and not save_acts
-    if net.mlp_dtype == "fp16" and save_acts:
-        raise RuntimeError("RENDERER.mlp_dtype=fp16 is an inference path; train with fp32")
+    use_h = net.mlp_dtype in ("fp16", "split") and not save_acts
+    if net.mlp_dtype != "fp32" and save_acts:
+        raise RuntimeError(f"RENDERER.mlp_dtype={net.mlp_dtype} is an inference path; train with fp32")
     ws = None if save_acts else net.workspace()
     pk0 = net.packed_weights(net.nerf_coarse)
     p0 = ops.render_pass(grid, pts, rays_c, None, z_table, net.N_samples, net.raduis, net.num_neighbor, net.enc_flags,

@@ -1,0 +1,426 @@
+// nf_mlp_s.hip — split-precision NeRF MLP forward: fp32-level accuracy on the fp16 matrix pipe.
+//
+// Every operand is carried as an unevaluated sum of two fp16 numbers, x = xh + xl with xh = fp16(x), xl = fp16(x - xh)
+// (22 significant bits, fp16 subnormals give an absolute floor of 6e-8), and every product is evaluated as
+//     w * x  ~=  wh*xh + wh*xl + wl*xh                (the dropped wl*xl term is < 2^-22 relative)
+// i.e. THREE v_mfma_f32_32x32x16_f16 per (A block, B operand), all accumulating in fp32.  The fp32-MFMA kernel
+// (nf_mlp_l.hip) runs at 1/16 of the fp16 matrix rate, so three fp16 MFMAs per product are still ~5x the fp32 pipe's
+// peak; measured ratio in DESIGN.md §5c.  Results are NOT bit-identical to fp32 arithmetic (summation order and the
+// 2^-22 products differ) but sit inside the fp32 path's own tolerance: max-abs <= 2e-4 on RGB, >= 60 dB PSNR against the
+// oracle (tests/test_gpu_render.py::test_split_precision_path).  Inference only; reported by bench.py as an extra key,
+// never as the headline (whose dtype stays f32 = the reference's arithmetic).
+//
+// Structure = nf_mlp_h2.hip with ONE 32-row tile per wave (the hi + lo activations of one tile fill the register
+// banks that two fp16 tiles fill there): out-block-major, finished blocks converted once (ReLU in fp32, then the hi/lo
+// split), activations never leave the registers, sigma / rgb heads as 1-block layers, weight stream of (hi, lo) A-block
+// pairs through a 48 KB LDS ring shared by the 4 waves, X split on the fly from the fp32 operand layout of
+// nf_render_features and parked (hi + lo) in the wave's LDS stash for layer 1 and the skip layer.
+// Biases: one K-step whose A block carries a THREE-term fp16 split of the fp32 bias (exact to 2^-33) against B = ones.
+#include "nf_mlp_layout.h"
+#include <math.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+
+#define S_CHUNK 8            // steps per ring chunk (a step = an (Ah, Al) pair = 2 KB)
+#define S_RING 24            // ring = 3 chunks = 48 KB
+#define S_PF 2               // A-operand prefetch distance (steps)
+#define S_BND 5              // rendezvous at the start of step (chunk * 8 + 5)
+#define S_XS 13
+
+enum { SK_BIAS = 0, SK_X = 1, SK_H = 2 };
+struct SDesc { int layer, blk, kind, idx; };
+
+__host__ __device__ constexpr int s_layer_blocks(int l) { return l < 8 ? 8 : (l == 8 ? 9 : (l == 9 ? 4 : 1)); }
+__host__ __device__ constexpr int s_block_steps(int l) { return l == 0 ? 14 : (l == 4 ? 30 : (l <= 8 ? 17 : (l == 9 ? 21 : 9))); }
+__host__ __device__ constexpr int s_total_steps()
+{
+    int n = 0;
+    for (int l = 0; l <= 10; ++l) n += s_layer_blocks(l) * s_block_steps(l);
+    return n;
+}
+__host__ __device__ constexpr int s_padded_steps() { return (s_total_steps() + S_RING - 1) / S_RING * S_RING; }
+
+__host__ __device__ inline SDesc s_desc(int i)
+{
+    SDesc d;
+    int l = 0;
+    for (; l <= 10; ++l) {
+        int n = s_layer_blocks(l) * s_block_steps(l);
+        if (i < n) break;
+        i -= n;
+    }
+    d.layer = l;
+    d.blk = i / s_block_steps(l);
+    int s = i % s_block_steps(l);
+    if (s == 0) { d.kind = SK_BIAS; d.idx = 0; }
+    else if (l == 0) { d.kind = SK_X; d.idx = s - 1; }
+    else if (l == 4) { if (s <= S_XS) { d.kind = SK_X; d.idx = s - 1; } else { d.kind = SK_H; d.idx = s - 1 - S_XS; } }
+    else if (l == 9) { if (s <= 4) { d.kind = SK_X; d.idx = 12 + (s - 1); } else { d.kind = SK_H; d.idx = s - 5; } }
+    else { d.kind = SK_H; d.idx = s - 1; }
+    return d;
+}
+
+extern "C" size_t nf_nerf_packed_s_bytes(void) { return (size_t)s_padded_steps() * 2048; }
+
+// one workgroup per step: writes the hi block and the lo block
+__global__ void k_mlp_pack_s(int cx, int cd, NfNerfPtrs P, _Float16* __restrict__ out)
+{
+    const SDesc st = s_desc(blockIdx.x);
+    _Float16* dst = out + (size_t)blockIdx.x * 1024;      // [hi 512 halves][lo 512 halves]
+    const int L = st.layer;
+    const bool sigma_blk = (L == 8 && st.blk == 8), rgb_blk = (L == 10);
+    for (int t = threadIdx.x; t < 512; t += blockDim.x) {
+        const int lane = t >> 3, e = t & 7, h = lane >> 5, jj = lane & 31;
+        const int o = 32 * st.blk + jj;
+        const float* wrow = nullptr;
+        float bias = 0.f;
+        int in_dim = 0, hcol0 = 0;
+        if (sigma_blk) { if (jj == 0) { wrow = P.w[10]; bias = P.b[10][0]; } in_dim = 256; }
+        else if (rgb_blk) { if (jj < 3) { wrow = P.w[11] + (size_t)jj * 128; bias = P.b[11][jj]; } in_dim = 128; }
+        else {
+            in_dim = (L == 0) ? cx : (L == 4 ? cx + 256 : (L == 9 ? 256 + cd : 256));
+            wrow = P.w[L] + (size_t)o * in_dim;
+            bias = P.b[L][o];
+            hcol0 = (L == 4) ? cx : 0;
+        }
+        float v = 0.f;
+        _Float16 hi = (_Float16)0.f, lo = (_Float16)0.f;
+        if (wrow) {
+            if (st.kind == SK_BIAS) {
+                // three-term split of the bias in k = 0, 1, 2 of the HI block (B = ones there); the lo block stays zero
+                if (h == 0 && e < 3) {
+                    const _Float16 b0 = (_Float16)bias;
+                    const float r1 = bias - (float)b0;
+                    const _Float16 b1 = (_Float16)r1;
+                    const _Float16 b2 = (_Float16)(r1 - (float)b1);
+                    hi = e == 0 ? b0 : (e == 1 ? b1 : b2);
+                }
+            } else {
+                if (st.kind == SK_X) {
+                    const int f = 16 * st.idx + (e < 4 ? 4 * h + e : 8 + 4 * h + (e - 4));
+                    const int qx8 = ((cx + 7) / 8) * 8;
+                    if (L == 9) { const int fd = f - qx8; if (fd >= 0 && fd < cd) v = wrow[256 + fd]; }
+                    else if (f < cx) v = wrow[f];
+                } else {
+                    v = wrow[hcol0 + frag_feature(st.idx >> 1, 8 * (st.idx & 1) + e, h)];
+                }
+                hi = (_Float16)v;
+                lo = (_Float16)(v - (float)hi);
+            }
+        }
+        dst[t] = hi;
+        dst[512 + t] = lo;
+    }
+}
+
+__global__ void k_zero_u4_s(u32x4* p, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = u32x4{0u, 0u, 0u, 0u};
+}
+
+extern "C" int nf_nerf_pack_s(const nf_nerf_params_t* params, int cx, int cd, void* stream_s, nf_stream_t stream)
+{
+    NF_CHECK_ARG(params && stream_s, "null pointer");
+    NF_CHECK_ARG((cx + 7) / 8 == 25 && (cd + 7) / 8 == 7, "the split-precision path is built for the default 198+54 feature row");
+    NfNerfPtrs P;
+    for (int i = 0; i < 12; ++i) { P.w[i] = params->w[i]; P.b[i] = params->b[i]; }
+    hipStream_t st = (hipStream_t)stream;
+    const size_t nu4 = (size_t)s_padded_steps() * 128;
+    hipLaunchKernelGGL(k_zero_u4_s, dim3((unsigned)((nu4 + 255) / 256)), dim3(256), 0, st, (u32x4*)stream_s, nu4);
+    hipLaunchKernelGGL(k_mlp_pack_s, dim3(s_total_steps()), dim3(256), 0, st, cx, cd, P, (_Float16*)stream_s);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernel
+// ------------------------------------------------------------------------------------------------
+struct SCtx {
+    const u32x4* stream;
+    u32x4* ring;
+    int nchunks, chunk_next;
+    int lane, wave;
+    u32x4 stage[4];            // this wave's quarter of the chunk in flight (16 KB chunk -> 4 KB per wave)
+    u32x4 ah[4], al[4];        // rotating A operands (hi, lo): index = step & 3
+    u32x4 bias_b;              // B operand of the bias step: ones at k = 0, 1, 2 (lanes h == 0)
+};
+
+__device__ __forceinline__ void s_fetch(SCtx& c)
+{
+    const u32x4* src = c.stream + (size_t)c.chunk_next * (S_CHUNK * 128) + c.wave * 256 + c.lane;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c.stage[i] = src[i * 64];
+    c.chunk_next = (c.chunk_next + 1 == c.nchunks) ? 0 : c.chunk_next + 1;
+}
+
+__device__ __forceinline__ void s_publish(SCtx& c, int third)
+{
+    u32x4* dst = c.ring + third * (S_CHUNK * 128) + c.wave * 256 + c.lane;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dst[i * 64] = c.stage[i];
+}
+
+__device__ __forceinline__ void s_boundary(SCtx& c, int slot)
+{
+    __syncthreads();
+    s_publish(c, (slot / S_CHUNK + 2) % 3);
+    s_fetch(c);
+}
+
+__device__ __forceinline__ void s_prefetch(SCtx& c, int slot)
+{
+    const u32x4* p = c.ring + ((slot + S_PF) % S_RING) * 128 + c.lane;
+    c.ah[(slot + S_PF) & 3] = p[0];
+    c.al[(slot + S_PF) & 3] = p[64];
+}
+
+// One K-step: acc += Ah*Bh + Ah*Bl + Al*Bh.  BIAS: only Ah*Bh (B = ones), accumulator zeroed.
+template <bool BIAS, int NDS, int NVALU>
+__device__ __forceinline__ void s_step(SCtx& c, int& slot, const u32x4 bh, const u32x4 bl, f32x16& acc)
+{
+    const bool boundary = (slot % S_CHUNK) == S_BND;
+    if (boundary) s_boundary(c, slot);
+    s_prefetch(c, slot);
+    const h8 ah = __builtin_bit_cast(h8, c.ah[slot & 3]), al = __builtin_bit_cast(h8, c.al[slot & 3]);
+    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (BIAS) {
+        acc = MFMA16(ah, __builtin_bit_cast(h8, bh), z);
+    } else {
+        acc = MFMA16(al, __builtin_bit_cast(h8, bh), acc);       // small terms first
+        acc = MFMA16(ah, __builtin_bit_cast(h8, bl), acc);
+        acc = MFMA16(ah, __builtin_bit_cast(h8, bh), acc);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 + NDS, 0);
+    if (boundary) {
+        __builtin_amdgcn_sched_group_barrier(0x200, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
+    }
+    if (NVALU) __builtin_amdgcn_sched_group_barrier(0x002, (NVALU + 2) / 3, 0);
+    if (!BIAS) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (NVALU) __builtin_amdgcn_sched_group_barrier(0x002, (NVALU + 2) / 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (NVALU) __builtin_amdgcn_sched_group_barrier(0x002, (NVALU + 2) / 3, 0);
+    }
+    asm volatile("" : "+v"(acc));
+    slot++;
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+__device__ __forceinline__ void s_skip(SCtx& c, int& slot)
+{
+    if ((slot % S_CHUNK) == S_BND) s_boundary(c, slot);
+    s_prefetch(c, slot);
+    slot++;
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// (v0, v1) -> packed hi pair and packed lo pair; RELU applied in fp32 first
+template <bool RELU>
+__device__ __forceinline__ void s_split2(float v0, float v1, unsigned& hi, unsigned& lo)
+{
+    if (RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+    const h2v hh = {(_Float16)v0, (_Float16)v1};
+    const h2v ll = {(_Float16)(v0 - (float)hh[0]), (_Float16)(v1 - (float)hh[1])};
+    hi = __builtin_bit_cast(unsigned, hh);
+    lo = __builtin_bit_cast(unsigned, ll);
+}
+
+// conversion piece q (0..3) of a finished block: accumulator floats 4q .. 4q+3 -> packed registers 2q, 2q+1 of the
+// block's two K-steps (2 blk for q < 2, 2 blk + 1 for q >= 2) in the hi and the lo bank
+template <int CVT>
+__device__ __forceinline__ void s_cvt_piece(int q, const f32x16& a, u32x4 (&oh)[16], u32x4 (&ol)[16], int blk)
+{
+    unsigned h0, l0, h1, l1;
+    s_split2<CVT == 1>(a[4 * q], a[4 * q + 1], h0, l0);
+    s_split2<CVT == 1>(a[4 * q + 2], a[4 * q + 3], h1, l1);
+    u32x4& dh = oh[2 * blk + (q >> 1)];
+    u32x4& dl = ol[2 * blk + (q >> 1)];
+    dh[2 * (q & 1)] = h0; dh[2 * (q & 1) + 1] = h1;
+    dl[2 * (q & 1)] = l0; dl[2 * (q & 1) + 1] = l1;
+}
+
+// One out-block.  XMODE 0: none; 1: X (hi, lo) in registers xh/xl[0..NX-1]; 2: from the LDS stash ([hi 13][lo 13] x 1 KB)
+template <int XMODE, int NX, int NH, int CVT>
+__device__ __forceinline__ void s_block(SCtx& c, int& slot, f32x16& acc, const u32x4 (&inh)[16], const u32x4 (&inl)[16],
+                                        const u32x4* xh, const u32x4* xl, const u32x4* __restrict__ stash, const f32x16& prev,
+                                        u32x4 (&outh)[16], u32x4 (&outl)[16], int pblk)
+{
+    u32x4 xrh[4], xrl[4];
+    if (XMODE == 2) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { xrh[t] = stash[t * 64]; xrl[t] = stash[(S_XS + t) * 64]; }
+        s_step<true, 4, 0>(c, slot, c.bias_b, c.bias_b, acc);
+    } else {
+        s_step<true, 0, 0>(c, slot, c.bias_b, c.bias_b, acc);
+    }
+    int s = 1;
+#pragma unroll
+    for (int t = 0; t < NX; ++t, ++s) {
+        const bool cv = CVT && s <= 4;
+        if (cv) s_cvt_piece<CVT>(s - 1, prev, outh, outl, pblk);
+        if (XMODE == 2) {
+            const bool pf = t + 2 < NX;
+            if (pf) { xrh[(t + 2) & 3] = stash[(t + 2) * 64]; xrl[(t + 2) & 3] = stash[(S_XS + t + 2) * 64]; }
+            if (cv) { if (pf) s_step<false, 2, 24>(c, slot, xrh[t & 3], xrl[t & 3], acc); else s_step<false, 0, 24>(c, slot, xrh[t & 3], xrl[t & 3], acc); }
+            else { if (pf) s_step<false, 2, 0>(c, slot, xrh[t & 3], xrl[t & 3], acc); else s_step<false, 0, 0>(c, slot, xrh[t & 3], xrl[t & 3], acc); }
+        } else {
+            if (cv) s_step<false, 0, 24>(c, slot, xh[t], xl[t], acc);
+            else s_step<false, 0, 0>(c, slot, xh[t], xl[t], acc);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NH; ++k, ++s) {
+        if (CVT && s <= 4) {
+            s_cvt_piece<CVT>(s - 1, prev, outh, outl, pblk);
+            s_step<false, 0, 24>(c, slot, inh[k], inl[k], acc);
+        } else {
+            s_step<false, 0, 0>(c, slot, inh[k], inl[k], acc);
+        }
+    }
+}
+
+// fp32 X operand of K-step t (two float4 groups) -> (hi, lo) packed operands
+__device__ __forceinline__ void s_split_x(const f32x4 g0, const f32x4 g1, u32x4& hi, u32x4& lo)
+{
+    unsigned h, l;
+    s_split2<false>(g0.x, g0.y, h, l); hi[0] = h; lo[0] = l;
+    s_split2<false>(g0.z, g0.w, h, l); hi[1] = h; lo[1] = l;
+    s_split2<false>(g1.x, g1.y, h, l); hi[2] = h; lo[2] = l;
+    s_split2<false>(g1.z, g1.w, h, l); hi[3] = h; lo[3] = l;
+}
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+k_mlp_fwd_s(const u32x4* __restrict__ stream_s, int nsteps_padded, const f32x4* __restrict__ X, const int* __restrict__ n_rows,
+            int max_rows, const int* __restrict__ row_sample, float4* __restrict__ rgbsigma)
+{
+    extern __shared__ u32x4 lds[];    // [ring 48 KB][stash 4 waves x (13 hi + 13 lo) x 1 KB]
+    const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, wave = threadIdx.x >> 6;
+    const int nrows = min(*n_rows, max_rows);
+    const int ntiles = (nrows + 31) >> 5;
+    const int ngroups = (ntiles + 3) >> 2;
+    u32x4* stash = lds + S_RING * 128 + wave * (2 * S_XS * 64) + lane;
+    SCtx c;
+    c.stream = stream_s; c.ring = lds;
+    c.nchunks = nsteps_padded / S_CHUNK; c.chunk_next = 0; c.lane = lane; c.wave = wave;
+    {
+        const _Float16 one = (_Float16)(h == 0 ? 1.f : 0.f), zz = (_Float16)0.f;
+        const h8 r = {one, one, one, zz, zz, zz, zz, zz};
+        c.bias_b = __builtin_bit_cast(u32x4, r);
+    }
+    s_fetch(c); s_publish(c, 0);
+    s_fetch(c); s_publish(c, 1);
+    s_fetch(c);
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < S_PF; ++s) { c.ah[s] = c.ring[s * 128 + lane]; c.al[s] = c.ring[s * 128 + 64 + lane]; }
+
+    // X of the first tile -> stash (hi, lo).  X[tile][q (32)][lane (64)] x float4: K-step t = groups 2t, 2t+1
+    const int last_tile = ntiles > 0 ? ntiles - 1 : 0;
+    if (ngroups > (int)blockIdx.x) {
+        const f32x4* px = X + (size_t)min((int)blockIdx.x * 4 + wave, last_tile) * 32 * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < S_XS; ++t) {
+            u32x4 hi, lo;
+            s_split_x(__builtin_nontemporal_load(px + (2 * t) * 64), __builtin_nontemporal_load(px + (2 * t + 1) * 64), hi, lo);
+            stash[t * 64] = hi;
+            stash[(S_XS + t) * 64] = lo;
+        }
+    }
+
+    for (int tg = blockIdx.x; tg < ngroups; tg += gridDim.x) {
+        int tile = tg * 4 + wave;
+        const bool owner = tile < ntiles;
+        if (!owner) tile = ntiles - 1;
+        const f32x4* xt = X + (size_t)tile * 32 * 64 + lane;
+        const f32x4* xn = X + (size_t)min((tg + (int)gridDim.x) * 4 + wave, last_tile) * 32 * 64 + lane;
+        int slot = 0;
+        u32x4 bh[2][16], bl[2][16];        // [which][K-step]: hi / lo packed activations
+        f32x16 acc[2];
+        f32x4 xf0, xf1;                    // X batch in flight (next tile)
+
+#define S_REP7(M) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
+        // ---- layer 0: X (stash) -> bank 1
+        s_block<2, S_XS, 0, 0>(c, slot, acc[0], bh[0], bl[0], nullptr, nullptr, stash, acc[1], bh[1], bl[1], 0);
+#define S_L0(b) s_block<2, S_XS, 0, 1>(c, slot, acc[(b) & 1], bh[0], bl[0], nullptr, nullptr, stash, acc[((b) - 1) & 1], bh[1], bl[1], (b) - 1);
+        S_REP7(S_L0)
+#define S_XFER(gb)                                                                                                               \
+        if ((gb) >= 0 && (gb) / 2 < S_XS) {                                                                                      \
+            if (((gb) & 1) == 0) { xf0 = __builtin_nontemporal_load(xn + (2 * ((gb) / 2)) * 64);                                 \
+                                   xf1 = __builtin_nontemporal_load(xn + (2 * ((gb) / 2) + 1) * 64); }                           \
+            else { u32x4 hi_, lo_; s_split_x(xf0, xf1, hi_, lo_); stash[((gb) / 2) * 64] = hi_; stash[(S_XS + (gb) / 2) * 64] = lo_; } \
+        }
+#define S_HB(IN, OUT, CV, b, XFB) S_XFER((XFB) < 0 ? -1 : (XFB) + (b))                                                           \
+        s_block<0, 0, 16, CV>(c, slot, acc[(b) & 1], bh[IN], bl[IN], nullptr, nullptr, nullptr, acc[((b) - 1) & 1], bh[OUT], bl[OUT], (b) - 1);
+#define S_HIDDEN_LAYER(IN, OUT, CV, XFB)                                                                                         \
+        S_XFER(XFB)                                                                                                              \
+        s_block<0, 0, 16, 1>(c, slot, acc[0], bh[IN], bl[IN], nullptr, nullptr, nullptr, acc[1], bh[IN], bl[IN], 7);             \
+        S_HB(IN, OUT, CV, 1, XFB) S_HB(IN, OUT, CV, 2, XFB) S_HB(IN, OUT, CV, 3, XFB) S_HB(IN, OUT, CV, 4, XFB)                   \
+        S_HB(IN, OUT, CV, 5, XFB) S_HB(IN, OUT, CV, 6, XFB) S_HB(IN, OUT, CV, 7, XFB)
+        S_HIDDEN_LAYER(1, 0, 1, -1)
+        S_HIDDEN_LAYER(0, 1, 1, -1)
+        S_HIDDEN_LAYER(1, 0, 1, -1)
+        // layer 4 (skip): X from the stash + bank 0 -> bank 1
+        s_block<2, S_XS, 16, 1>(c, slot, acc[0], bh[0], bl[0], nullptr, nullptr, stash, acc[1], bh[0], bl[0], 7);
+#define S_L4(b) s_block<2, S_XS, 16, 1>(c, slot, acc[(b) & 1], bh[0], bl[0], nullptr, nullptr, stash, acc[((b) - 1) & 1], bh[1], bl[1], (b) - 1);
+        S_REP7(S_L4)
+        S_HIDDEN_LAYER(1, 0, 1, 0)
+        S_HIDDEN_LAYER(0, 1, 1, 8)
+        S_HIDDEN_LAYER(1, 0, 1, 16)       // -> bank 0 = relu(h8)
+        S_HIDDEN_LAYER(0, 1, 2, 24)       // xyz_encoding_final (no activation) -> bank 1
+        s_block<0, 0, 16, 2>(c, slot, acc[0], bh[0], bl[0], nullptr, nullptr, nullptr, acc[1], bh[1], bl[1], 7);     // sigma
+        // ---- view branch
+        u32x4 dh[4], dl[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            s_split_x(__builtin_nontemporal_load(xt + (2 * (12 + t)) * 64), __builtin_nontemporal_load(xt + (2 * (12 + t) + 1) * 64),
+                      dh[t], dl[t]);
+        s_block<1, 4, 16, 0>(c, slot, acc[1], bh[1], bl[1], dh, dl, nullptr, acc[0], bh[0], bl[0], 0);
+        const float sig = acc[0][0];
+#define S_VB(b) s_block<1, 4, 16, 1>(c, slot, acc[((b) + 1) & 1], bh[1], bl[1], dh, dl, nullptr, acc[(b) & 1], bh[0], bl[0], (b) - 1);
+        S_VB(1) S_VB(2) S_VB(3)
+        s_block<0, 0, 8, 1>(c, slot, acc[1], bh[0], bl[0], nullptr, nullptr, nullptr, acc[0], bh[0], bl[0], 3);      // rgb head
+        constexpr int S_PAD = s_padded_steps() - s_total_steps();
+#pragma unroll
+        for (int i = 0; i < S_PAD; ++i) s_skip(c, slot);
+
+        if (h == 0 && owner) {
+            const int row = tile * 32 + j;
+            if (row < nrows) {
+                const f32x16 r = acc[1];
+                float4 o;
+                o.x = 1.f / (1.f + expf(-r[0])); o.y = 1.f / (1.f + expf(-r[1])); o.z = 1.f / (1.f + expf(-r[2])); o.w = sig;
+                rgbsigma[row_sample[row]] = o;
+            }
+        }
+    }
+}
+
+extern "C" int nf_nerf_mlp_fwd_s(const void* stream_s, int cx, int cd, const float* X, const int32_t* n_rows, int max_rows,
+                                 const int32_t* row_sample, float* rgbsigma, nf_stream_t stream)
+{
+    NF_CHECK_ARG(stream_s && X && n_rows && row_sample && rgbsigma, "null pointer");
+    if (max_rows <= 0) return NF_OK;
+    NF_CHECK_ARG((cx + 7) / 8 == 25 && (cd + 7) / 8 == 7, "the split-precision path is built for the default 198+54 feature row");
+    const int tiles = (max_rows + 31) / 32;
+    int blocks = (tiles + 3) / 4;
+    if (blocks > 256) blocks = 256;
+    const size_t lds = (size_t)S_RING * 2048 + (size_t)4 * 2 * S_XS * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)k_mlp_fwd_s, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_mlp_fwd_s, dim3(blocks), dim3(256), lds, (hipStream_t)stream, (const u32x4*)stream_s, s_padded_steps(),
+                       (const f32x4*)X, n_rows, max_rows, row_sample, (float4*)rgbsigma);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}

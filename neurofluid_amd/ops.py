@@ -237,6 +237,27 @@ def pack_nerf_h2(weights, biases, cx, cd):
     return PackedH2(out)
 
 
+class PackedS:
+    """Weight stream of the split-precision MLP (nf_nerf_pack_s / nf_nerf_mlp_fwd_s)."""
+
+    def __init__(self, blob):
+        self.blob = blob
+
+
+def pack_nerf_s(weights, biases, cx, cd):
+    lib = _lib.load()
+    out = torch.empty(lib.nf_nerf_packed_s_bytes(), dtype=torch.uint8, device=weights[0].device)
+    P = _lib.NerfParams()
+    keep = []
+    for i in range(12):
+        w = weights[i].detach().contiguous().float()
+        b = biases[i].detach().contiguous().float()
+        keep += [w, b]
+        P.w[i], P.b[i] = w.data_ptr(), b.data_ptr()
+    check(lib.nf_nerf_pack_s(ctypes.byref(P), cx, cd, ptr(out), _lib.stream()), "nf_nerf_pack_s")
+    return PackedS(out)
+
+
 # ------------------------------------------------------------------------------------------------
 # one render pass (coarse or fine) of a ray chunk
 # ------------------------------------------------------------------------------------------------
@@ -342,7 +363,7 @@ def render_pass(grid, particles, rays, z, z_table, S, radius, K, enc_flags, use_
     b.n_active = max_rows
     tiles = (max_rows + 31) // 32
     rows_alloc = _round_rows(max_rows)
-    x16 = packed_h is not None       # the fp16-MFMA MLP takes its operand as fp16: half the bytes written and read
+    x16 = packed_h is not None and not isinstance(packed_h, PackedS)      # the fp16-MFMA MLPs take fp16 operands (half the bytes)
     b.X = scratch("X", rows_alloc // 32 * (qx + qd) * (128 if x16 else 256), torch.float32)
     check(lib.nf_render_features(ptr(particles), ptr(rays), ptr(z), ptr(z_table), R, S, float(radius), K, enc_flags,
                                  ptr(ro), int(ro.dim() == 2), ptr(b.row_sample), ptr(b.row_nbr), ptr(b.n_rows), max_rows,
@@ -352,7 +373,10 @@ def render_pass(grid, particles, rays, z, z_table, S, radius, K, enc_flags, use_
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    if isinstance(packed_h, PackedH2):      # fp16-MFMA, two tiles per wave (inference only); X holds an even tile count
+    if isinstance(packed_h, PackedS):       # split precision: hi + lo fp16 operands, 3 MFMAs per product (inference only)
+        check(lib.nf_nerf_mlp_fwd_s(ptr(packed_h.blob), cx, cd, ptr(b.X), ptr(b.n_rows), max_rows, ptr(b.row_sample),
+                                    ptr(b.rgbsigma), st), "nf_nerf_mlp_fwd_s")
+    elif isinstance(packed_h, PackedH2):      # fp16-MFMA, two tiles per wave (inference only); X holds an even tile count
         check(lib.nf_nerf_mlp_fwd_h2(ptr(packed_h.blob), cx, cd, ptr(b.X), ptr(b.n_rows), max_rows, ptr(b.row_sample),
                                      ptr(b.rgbsigma), st), "nf_nerf_mlp_fwd_h2")
     elif packed_h is not None:      # fp16-MFMA, round-1 kernel (kept for A/B runs: RENDERER.mlp_h_kernel = 1)
@@ -427,6 +451,10 @@ def mlp_rows(packed, cx, cd, x, save_acts=False, packed_h=None, wstream=None):
     row_sample = torch.arange(n, dtype=torch.int32, device=x.device)
     out = torch.zeros(n, 4, dtype=torch.float32, device=x.device)
     acts = torch.empty(n * 2432, dtype=torch.float32, device=x.device) if save_acts else None
+    if isinstance(packed_h, PackedS):
+        check(lib.nf_nerf_mlp_fwd_s(ptr(packed_h.blob), cx, cd, ptr(X), ptr(n_rows), n, ptr(row_sample), ptr(out), _lib.stream()),
+              "nf_nerf_mlp_fwd_s")
+        return out
     if packed_h is not None:
         # fp32 operand layout [tile][q][lane][4] -> fp16 layout [tile][t][lane][8]: K-step t = groups 2t, 2t+1
         T = X.numel() // ((qx_ := (cx + 7) // 8) + (qd_ := (cd + 7) // 8)) // 256

@@ -38,10 +38,11 @@ class RenderNet(nn.Module):
         self.fix_radius = bool(_get(cfg, "NN_search.fix_radius"))
         self.num_neighbor = int(_get(cfg, "NN_search.N_neighbor"))
         self.use_mask = bool(_get(cfg, "use_mask"))
-        # build-only key: "fp32" (default, exact) or "fp16" (fp16 MFMA, fp32 accumulate; inference only; BASELINE config 5)
+        # build-only key: "fp32" (default, the reference's arithmetic), "fp16" (fp16 MFMA, fp32 accumulate; BASELINE config
+        # 5) or "split" (hi + lo fp16 operands, 3 fp16 MFMAs per product: fp32-level accuracy).  fp16 / split: inference only
         self.mlp_dtype = str(_get(cfg, "mlp_dtype", "fp32"))
-        if self.mlp_dtype not in ("fp32", "fp16"):
-            raise ValueError("RENDERER.mlp_dtype must be fp32 or fp16")
+        if self.mlp_dtype not in ("fp32", "fp16", "split"):
+            raise ValueError("RENDERER.mlp_dtype must be fp32, fp16 or split")
         # build-only key: which fp16 kernel serves mlp_dtype = fp16.  2 (default): two tiles per wave, out-block-major
         # (nf_mlp_h2.hip); 1: the round-1 kernel (nf_mlp_h.hip), kept for A/B measurements
         self.mlp_h_kernel = int(_get(cfg, "mlp_h_kernel", 2))
@@ -122,7 +123,7 @@ class RenderNet(nn.Module):
 
     def packed_weights_h(self, net):
         layers = net.linear_layers()
-        pack = ops.pack_nerf_h2 if self.mlp_h_kernel == 2 else ops.pack_nerf_h
+        pack = ops.pack_nerf_s if self.mlp_dtype == "split" else (ops.pack_nerf_h2 if self.mlp_h_kernel == 2 else ops.pack_nerf_h)
         return pack([l.weight for l in layers], [l.bias for l in layers], self.in_channels_xyz, self.in_channels_dir)
 
     # ------------------------------------------------------------------

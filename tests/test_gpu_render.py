@@ -792,3 +792,38 @@ def test_optimistic_row_capacities_no_midpass_sync(dev):
         assert all(v > 32 for v in ws.row_cap.values())        # grown by the redo
     for k in a:
         assert torch.equal(a[k], b[k]) and torch.equal(a[k], c[k]), k
+
+
+def test_split_precision_path(dev):
+    """RENDERER.mlp_dtype = split: hi + lo fp16 operands, three fp16 MFMAs per product, fp32 accumulate (nf_mlp_s.hip).
+    Claim: fp32-LEVEL accuracy — the same bars as the fp32 path itself: MLP rows within 2e-5 (rgb) / 2e-4 relative (sigma)
+    of the fp32-MFMA kernel, rendered RGB max-abs <= 2e-4 and >= 60 dB against the oracle; neighbour sets bit-exact."""
+    from neurofluid_amd import ops
+    from oracle import render_oracle as ro
+    net = make_net(dev)
+    nets = make_net(dev, dict(make_cfg(), mlp_dtype="split"))
+    gen = torch.Generator().manual_seed(22)
+    worst_rgb = worst_sig = 0.0
+    for n in (1, 31, 32, 33, 128, 1000, 4097):
+        xr = (torch.rand(n, 252, generator=gen) * 2 - 1).to(dev)
+        ref = ops.mlp_rows(net.packed_weights(net.nerf_fine), 198, 54, xr)
+        got = ops.mlp_rows(net.packed_weights(net.nerf_fine), 198, 54, xr, packed_h=nets.packed_weights_h(nets.nerf_fine))
+        err = (got - ref).abs()
+        worst_rgb = max(worst_rgb, float(err[:, :3].max()))
+        worst_sig = max(worst_sig, float((err[:, 3] / (1 + ref[:, 3].abs())).max()))
+    print("split-precision MLP rows vs fp32 MFMA kernel: max abs rgb", worst_rgb, " max rel sigma", worst_sig)
+    assert worst_rgb < 2e-5 and worst_sig < 2e-4
+    g = load_golden("a10_forward")
+    P, rays, roc = T(g["particles"], dev), T(g["rays"], dev), T(g["ro"], dev)
+    with torch.no_grad():
+        a = net(P, roc, rays, None, None)
+        b = nets(P, roc, rays, None, None)
+    for k in ("mask_0", "mask_1", "num_nn_0", "num_nn_1"):
+        assert torch.equal(a[k], b[k]), k
+    ref = ro.render_forward(ro.deterministic_nerf_state(), P.cpu(), roc.cpu(), rays.cpu(), 9.0, 13.0)
+    for k in ("rgb0", "rgb1"):
+        torch.testing.assert_close(b[k].cpu(), ref[k], rtol=0, atol=RGB_ATOL, msg=k)
+        assert ro.psnr(b[k].cpu(), ref[k]) >= RGB_PSNR_MIN
+        torch.testing.assert_close(b[k].cpu(), T(g[k]), rtol=0, atol=RGB_ATOL, msg="golden " + k)      # the reference's own output
+    print("split-precision frame: max |rgb1 - fp32 path|", float((a["rgb1"] - b["rgb1"]).abs().max()),
+          " PSNR vs oracle", ro.psnr(b["rgb1"].cpu(), ref["rgb1"]))

@@ -69,3 +69,15 @@ if len(sys.argv) > 3 and sys.argv[3] == "fp16v3":
         print(f"fp16 v3 iter {it}: rows {n} {ms:.3f} ms  {n*1331968/ms/1e9:.1f} TFLOP/s")
     err = (out2 - out).abs()
     print("v3 max abs err rgb", float(err[:, :3].max()), "sigma", float(err[:, 3].max()), "sigma scale", float(out[:, 3].abs().max()))
+if len(sys.argv) > 3 and sys.argv[3] == "split":
+    ps = ops.pack_nerf_s(W, B, 198, 54)
+    out2 = torch.zeros(n, 4, device=dev)
+    for it in range(iters):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib.nf_nerf_mlp_fwd_s(ptr(ps.blob), 198, 54, ptr(X), ptr(n_rows), n, ptr(row_sample), ptr(out2), _lib.stream()))
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        print(f"split iter {it}: rows {n} {ms:.3f} ms  {n*1331968/ms/1e9:.1f} TFLOP/s fp32-equivalent ({3*n*1331968/ms/1e9:.0f} TFLOP/s of fp16 MFMA)")
+    err = (out2 - out).abs()
+    print("split max abs err rgb", float(err[:, :3].max()), "sigma", float(err[:, 3].max()), "sigma scale", float(out[:, 3].abs().max()))

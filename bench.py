@@ -335,9 +335,15 @@ def main():
             acha = sum(pa["rows"]) * MLP_FLOP_PER_ROW / (msa * 1e-3) / 1e12 if msa > 0 else 0.0
             diff = (outa["pred_rgbs_1"] - out["pred_rgbs_1"])
             mse = torch.mean(diff ** 2).item()
+            # coarse image: same sample positions on both paths (pure MLP + compositing difference); fine image: also the
+            # inverse-CDF resampling, which is discontinuous in the coarse weights (a sample may move one bin: isolated
+            # pixels move by ~1e-3 for ANY change of rounding, the fp32 GPU path vs the CPU oracle included)
             return {"rays_per_sec": n_rays / dta, "ms_per_step": dta * 1e3,
                     "psnr_vs_f32_path_db": (-10.0 * math.log10(mse)) if mse > 0 else float("inf"),
-                    "max_abs_rgb_diff_vs_f32_path": float(diff.abs().max()), "mlp_tflops_row_equivalent": acha}
+                    "max_abs_rgb_diff_vs_f32_path_coarse_image": float((outa["pred_rgbs_0"] - out["pred_rgbs_0"]).abs().max()),
+                    "max_abs_rgb_diff_vs_f32_path_fine_image": float(diff.abs().max()),
+                    "pixels_fine_image_beyond_2e-4": int((diff.abs().max(dim=1).values > 2e-4).sum()),
+                    "mlp_tflops_row_equivalent": acha}
         fp16_extra = alt_path("fp16")
         fp16_extra.update({"dtype": "f16 MFMA, f32 accumulate", "mlp_frac_of_dense_f16_peak": fp16_extra["mlp_tflops_row_equivalent"] / F16_MATRIX_PEAK_TFLOPS,
                            "note": "render only (grid rebuild included, no transition step); not the headline value"})

@@ -34,6 +34,13 @@ pmc)
   # the heavy csv files stay on the box; keep what the summariser needs (counter collections + stats) under 64 MiB
   find $O -name "*kernel_trace.csv" -path "*r2_pmc*" -delete
   du -sh $O/r2_* | tail -12 ;;
+pmcs)
+  MB="python $GRAFT_REPO_ROOT/tools/mlp_bench.py 3276800 3 split"
+  bash tools/prof.sh r2_stats_mlps $MB > /dev/null
+  bash tools/pmc.sh r2_pmc_sq_mlps "SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU" $MB > /dev/null
+  bash tools/pmc.sh r2_pmc_fetch_mlps "FETCH_SIZE" $MB > /dev/null
+  bash tools/pmc.sh r2_pmc_write_mlps "WRITE_SIZE" $MB > /dev/null
+  find $O -name "*kernel_trace.csv" -path "*r2_pmc*" -delete ;;
 pmch)
   MB="python $GRAFT_REPO_ROOT/tools/mlp_bench.py 3276800 3 fp16v3"
   bash tools/prof.sh r2_stats_mlph $MB > /dev/null

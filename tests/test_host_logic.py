@@ -152,3 +152,48 @@ def test_pixel_sampler_readahead_is_invisible_and_errors_surface():
     with pytest.raises(ValueError):
         s.next(0)
     s.close()
+
+
+def test_dataset_readers_vs_reference_readers(tmp_path):
+    """the on-disk formats.  tests/golden/f1_dataset.npz holds what the REFERENCE's own BlenderDataset /
+    ParticleDataset (datasets/dataset.py, datasets/dataset_splishsplash_rawdata.py) returned for a data set written by
+    write_synthetic_dataset with fixed arguments (tests/golden/gen_golden_dataset.py); the build's readers must return the
+    same arrays for the same files: items, frame pairing (i, i+1), RGBA-on-white blending, half-resolution resize, focal,
+    sliding windows, z-rotation drawn from the global numpy stream."""
+    import numpy as np
+    import torch
+    from conftest import load_golden
+    from neurofluid_amd.datasets import BlenderDataset, ParticleDataset, write_synthetic_dataset
+    g = load_golden("f1_dataset")
+    root = str(tmp_path / "watercube")
+    write_synthetic_dataset(root, n_frames=4, img=8, n_side=3, views=("view_0", "view_1"), splits=("train",), camera_angle_x=0.323,
+                            seed=10)
+    cfg = {"data_type": "splishsplash"}
+    ds = BlenderDataset(root, cfg, imgW=8, imgH=8, start_index=0, end_index=4, imgscale=1.0, viewnames=["view_0", "view_1"], split="train")
+    assert len(ds) == int(g["blender_len"])
+    for idx in (0, 2):
+        item = ds[idx]
+        keys = [k.split("__")[1] for k in g if k.startswith(f"blender_{idx}__")]
+        assert set(keys) == set(item), (sorted(keys), sorted(item))
+        for k in keys:
+            got = np.asarray(item[k]) if not torch.is_tensor(item[k]) else item[k].numpy()
+            ref = g[f"blender_{idx}__{k}"]
+            assert got.shape == ref.shape, k
+            if k.startswith("rays"):          # directions: same torch ops as the reference -> same bits expected; allow 1 ulp
+                np.testing.assert_allclose(got, ref, rtol=0, atol=1.2e-7, err_msg=k)
+            else:
+                np.testing.assert_array_equal(got, ref, err_msg=k)
+    ds2 = BlenderDataset(root, cfg, imgW=8, imgH=8, start_index=1, end_index=3, imgscale=2.0, viewnames=["view_1"], split="train")
+    item = ds2[0]
+    np.testing.assert_array_equal(item["rgb"].numpy(), g["blender_half__rgb"])
+    np.testing.assert_allclose(item["rays"].numpy(), g["blender_half__rays"], rtol=0, atol=1.2e-7)
+    np.testing.assert_allclose(np.asarray(item["focal"]), g["blender_half__focal"], rtol=1e-12)
+    pd = ParticleDataset(root, "blender", 0, 4, random_rot=False, window=3)
+    assert len(pd) == int(g["particles_len"])
+    for k, v in pd[1].items():
+        np.testing.assert_array_equal(v.numpy(), g[f"particles_1__{k}"], err_msg=k)
+    np.random.seed(123)
+    pr = ParticleDataset(root, "blender", 0, 4, random_rot=True, window=2)
+    assert len(pr) == int(g["particles_rot_len"])
+    for k, v in pr[0].items():
+        np.testing.assert_array_equal(v.numpy(), g[f"particles_rot0__{k}"], err_msg=k)

@@ -321,7 +321,8 @@ def main():
                     neta.invalidate_grid()
                     return render_image(neta, P0, n_rays, roc, rays, None, None, iseval=True, ray_chunk=args.chunk,
                                         rank=rank, world=world, gather=False, device_chunk=device_chunk)
-            outa = step_alt()
+            for _ in range(2):          # exact sizing, then the first capacity run (arena and allocator settle)
+                outa = step_alt()
             sync()
             ops.PROFILE = {"mlp": [], "rows": []}
             t2 = time.perf_counter()

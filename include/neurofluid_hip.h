@@ -97,15 +97,16 @@ int nf_get_rays(int H, int W, float focal, const float* c2w /*12*/, int row0, in
  * z_table (S) is used when z == NULL (coarse pass: same depths for every ray). */
 int nf_render_classify(const void* grid_ws, const float* rays /*R*6*/, const float* z /*R*S or NULL*/,
                        const float* z_table /*S or NULL*/, int R, int S, float radius, int use_mask,
-                       int32_t* num_nn /*R*S*/, uint8_t* mask /*R*S*/,
+                       int32_t* num_nn /*R*S*/, uint8_t* mask /*R*S or NULL*/,
                        int32_t* cand /*R*S*/, int32_t* cand_count /*1*/, nf_stream_t stream);
 
-/* A2 + A7: first-K search for every candidate; writes num_nn / mask, appends active rows:
+/* A2 + A7: first-K search for every candidate; writes num_nn (and mask when it is not NULL: the mask of a sample is
+ * num_nn == K; the fused renderer passes NULL and lets nf_composite_* derive the bit from num_nn), appends active rows:
  * row_sample[row] = sample index, row_nbr[row*K + k] = neighbour index or -1,
  * n_rows[0] = number of active rows (zeroed by the caller). */
 int nf_render_search(const void* grid_ws, const float* rays, const float* z, const float* z_table, int R, int S,
                      float radius, int K, int use_mask, const int32_t* cand, const int32_t* cand_count,
-                     int32_t* num_nn, uint8_t* mask,
+                     int32_t* num_nn, uint8_t* mask /*or NULL*/,
                      int32_t* row_sample, int32_t* row_nbr, int32_t* n_rows, nf_stream_t stream);
 
 /* A3 + A4 + A5: local-geometry features + positional encodings for every active row, written in
@@ -208,13 +209,15 @@ int nf_nerf_wgrad(const float* dpre, const float* acts, const float* xrow, int c
 int nf_composite_fwd(const float* rgbsigma /*R*S*4*/, const float* z, const float* z_table, const float* rays,
                      const uint8_t* mask, int gate_by_mask, int R, int S, int white_bg,
                      float* rgb /*R*3*/, float* depth /*R*/, float* opacity /*R*/, float* weights /*R*S or NULL*/,
-                     float* mask_sum /*R or NULL*/, nf_stream_t stream);
+                     float* mask_sum /*R or NULL*/, const int32_t* num_nn /*R*S or NULL*/, int k_full, nf_stream_t stream);
+/* mask == NULL and num_nn != NULL: the mask bit of a sample is (num_nn[sample] == k_full). */
 
 /* A12 (compositing part): d_rgbsigma (R*S*4) from d_rgb (R*3); scratch = R*S floats.  Depth/opacity are
  * not differentiated (the reference losses use rgb0/rgb1 only: trainer/trainer_renderer.py:127-130). */
 int nf_composite_bwd(const float* rgbsigma, const float* z, const float* z_table, const float* rays,
                      const float* d_rgb, const uint8_t* mask, int gate_by_mask, int R, int S, int white_bg,
-                     float* scratch /*R*S*/, float* d_rgbsigma /*R*S*4*/, nf_stream_t stream);
+                     float* scratch /*R*S*/, float* d_rgbsigma /*R*S*4*/, const int32_t* num_nn /*or NULL*/, int k_full,
+                     nf_stream_t stream);
 
 /* A9: ImportanceSampling(det=True) (utils/ray_utils.py:178-229): z1 = sort(cat(z0, inverse-CDF samples)).
  * u_table = torch.linspace(0,1,N_imp) supplied by the caller (bit-identical to the reference).

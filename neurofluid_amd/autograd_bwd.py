@@ -53,8 +53,8 @@ def _pass_backward(net, nerf, pb, rays_c, z, z_table, g_rgb, white_bg, particles
     scratch = torch.empty(R * S, dtype=torch.float32, device=dev)
     d_rs = torch.empty(R * S, 4, dtype=torch.float32, device=dev)
     g = g_rgb.detach().contiguous().float()
-    check(lib.nf_composite_bwd(ptr(pb.rgbsigma), ptr(z), ptr(z_table), ptr(rays_c), ptr(g), ptr(pb.mask), pb.gate, R, S,
-                               int(white_bg), ptr(scratch), ptr(d_rs), st), "nf_composite_bwd")
+    check(lib.nf_composite_bwd(ptr(pb.rgbsigma), ptr(z), ptr(z_table), ptr(rays_c), ptr(g), None, pb.gate, R, S,
+                               int(white_bg), ptr(scratch), ptr(d_rs), ptr(pb.num_nn), pb.K, st), "nf_composite_bwd")
     packed_t = _pack_bwd(nerf, cx, cd, dev)
     # every row-sized temporary is allocated at the pass's bucketed capacity (ops._round_rows): the active-row count
     # changes from step to step, and exact sizes make the caching allocator grow by a fresh block per step (and give

@@ -44,6 +44,7 @@ __device__ __forceinline__ void sample_xyz(const float* __restrict__ rays, const
 // search overwrites the candidates afterwards — and nothing is written to rgbsigma: compositing reads it only
 // where mask = 1 (use_mask) and the MLP fills exactly those rows.
 #define CL_GROUPS 2
+template <bool HAS_MASK>
 __global__ void __launch_bounds__(256) k_classify(const void* __restrict__ ws, const float* __restrict__ rays,
                                                   const float* __restrict__ z, const float* __restrict__ z_table, int R,
                                                   int S, float radius, int use_mask, int* __restrict__ num_nn,
@@ -85,9 +86,9 @@ __global__ void __launch_bounds__(256) k_classify(const void* __restrict__ ws, c
         }
         if (whole) {
             *(int4*)(num_nn + i0) = make_int4(0, 0, 0, 0);
-            *(uchar4*)(mask + i0) = make_uchar4(0, 0, 0, 0);
+            if (HAS_MASK) *(uchar4*)(mask + i0) = make_uchar4(0, 0, 0, 0);
         } else {
-            for (int i = i0; i < total; ++i) { num_nn[i] = 0; mask[i] = 0; }
+            for (int i = i0; i < total; ++i) { num_nn[i] = 0; if (HAS_MASK) mask[i] = 0; }
         }
     }
     int n = __popc(flags);
@@ -117,14 +118,18 @@ extern "C" int nf_render_classify(const void* ws, const float* rays, const float
                                   float radius, int use_mask, int32_t* num_nn, uint8_t* mask, int32_t* cand,
                                   int32_t* cand_count, nf_stream_t stream)
 {
-    NF_CHECK_ARG(ws && rays && (z || z_table) && num_nn && mask && cand && cand_count, "null pointer");
+    NF_CHECK_ARG(ws && rays && (z || z_table) && num_nn && cand && cand_count, "null pointer");
     NF_CHECK_ARG(R >= 0 && S > 0 && (long)R * S < 0x7fffffffL, "bad R/S");
     NF_CHECK_ARG(radius > 0.f, "bad radius");
     if (R == 0) return NF_OK;
     int total = R * S;
     int per_block = 256 * CL_GROUPS * 4;
-    hipLaunchKernelGGL(k_classify, dim3((total + per_block - 1) / per_block), dim3(256), 0, (hipStream_t)stream, ws, rays,
-                       z, z_table, R, S, radius, use_mask, num_nn, mask, cand, cand_count);
+    if (mask)
+        hipLaunchKernelGGL(k_classify<true>, dim3((total + per_block - 1) / per_block), dim3(256), 0, (hipStream_t)stream, ws, rays,
+                           z, z_table, R, S, radius, use_mask, num_nn, mask, cand, cand_count);
+    else
+        hipLaunchKernelGGL(k_classify<false>, dim3((total + per_block - 1) / per_block), dim3(256), 0, (hipStream_t)stream, ws, rays,
+                           z, z_table, R, S, radius, use_mask, num_nn, mask, cand, cand_count);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }
@@ -145,7 +150,7 @@ __global__ void __launch_bounds__(SG_BLOCK) k_search(const void* __restrict__ ws
                                                      const float* __restrict__ z, const float* __restrict__ z_table,
                                                      int S, float r2, int K, int use_mask,
                                                      const int* __restrict__ cand, const int* __restrict__ cand_count,
-                                                     int* __restrict__ num_nn, uint8_t* __restrict__ mask,
+                                                     int* __restrict__ num_nn,
                                                      int* __restrict__ row_sample, int* __restrict__ row_nbr,
                                                      int* __restrict__ n_rows)
 {
@@ -190,6 +195,9 @@ __global__ void __launch_bounds__(SG_BLOCK) k_search(const void* __restrict__ ws
                         pass = nf_box_dist2(bb, x, y, zz) < r2;
                     }
                     unsigned m = (unsigned)(__ballot(pass) >> gsh) & 0xffffu;
+                    // (requesting the next passing chunks ahead of the test was measured: 961 -> 1 223 us for the fine pass — the
+                    // loads wasted by the early exit at the K-th hit cost more than the latency they hide; the kernel is bound
+                    // by the requests it issues, not by the requests it keeps in flight)
                     while (m && cnt < K) {
                         const int bit = __ffs(m) - 1;
                         m &= m - 1u;
@@ -215,7 +223,6 @@ __global__ void __launch_bounds__(SG_BLOCK) k_search(const void* __restrict__ ws
                 if (l == 0) {
                     const bool full = (nz == K);
                     num_nn[sample] = nz;
-                    mask[sample] = full ? 1 : 0;
                     s_cnt_w[slot] = cnt;
                     s_full_w[slot] = full ? 1 : 0;
                 }
@@ -241,12 +248,24 @@ __global__ void __launch_bounds__(SG_BLOCK) k_search(const void* __restrict__ ws
     }
 }
 
+// mask[sample] = (num_nn[sample] == K) for every candidate: only for callers that want the byte array (the fused renderer
+// keeps no mask array, nf_composite_* derive the bit from num_nn).
+__global__ void k_mask_from_num_nn(const int* __restrict__ cand, const int* __restrict__ cand_count, const int* __restrict__ num_nn,
+                                   int K, uint8_t* __restrict__ mask)
+{
+    const int n = *cand_count;
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
+        const int sample = cand[c];
+        mask[sample] = num_nn[sample] == K ? 1 : 0;
+    }
+}
+
 extern "C" int nf_render_search(const void* ws, const float* rays, const float* z, const float* z_table, int R, int S,
                                 float radius, int K, int use_mask, const int32_t* cand, const int32_t* cand_count,
                                 int32_t* num_nn, uint8_t* mask, int32_t* row_sample, int32_t* row_nbr,
                                 int32_t* n_rows, nf_stream_t stream)
 {
-    NF_CHECK_ARG(ws && rays && (z || z_table) && cand && cand_count && num_nn && mask && row_sample && row_nbr && n_rows,
+    NF_CHECK_ARG(ws && rays && (z || z_table) && cand && cand_count && num_nn && row_sample && row_nbr && n_rows,
                  "null pointer");
     NF_CHECK_ARG(K >= 1 && K <= 32 && radius > 0.f, "bad K/radius");
     if (R == 0) return NF_OK;
@@ -256,7 +275,8 @@ extern "C" int nf_render_search(const void* ws, const float* rays, const float* 
     int blocks = (int)(want < 8192 ? want : 8192);          // grid-stride over the candidates (count known on device only)
     const size_t lds = (size_t)SG_WAVES * 64 * ((K | 1) + 2) * sizeof(int);
     hipLaunchKernelGGL(k_search, dim3(blocks), dim3(SG_BLOCK), lds, (hipStream_t)stream, ws, rays, z, z_table, S,
-                       radius * radius, K, use_mask, cand, cand_count, num_nn, mask, row_sample, row_nbr, n_rows);
+                       radius * radius, K, use_mask, cand, cand_count, num_nn, row_sample, row_nbr, n_rows);
+    if (mask) hipLaunchKernelGGL(k_mask_from_num_nn, dim3(blocks), dim3(256), 0, (hipStream_t)stream, cand, cand_count, (const int*)num_nn, K, mask);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }
@@ -485,7 +505,7 @@ __global__ void __launch_bounds__(64) k_composite(const float4* __restrict__ rgb
                                                   const uint8_t* __restrict__ mask, int gate, int R, int S, int white_bg,
                                                   float* __restrict__ rgb, float* __restrict__ depth,
                                                   float* __restrict__ opacity, float* __restrict__ weights,
-                                                  float* __restrict__ mask_sum)
+                                                  float* __restrict__ mask_sum, const int* __restrict__ num_nn, int k_full)
 {
     __shared__ float4 s_rs[64 * CP_PITCH];
     __shared__ float s_z[64 * (CP_TS + 1) + 64];
@@ -502,13 +522,25 @@ __global__ void __launch_bounds__(64) k_composite(const float4* __restrict__ rgb
     float T = 1.f, cr = 0.f, cg = 0.f, cb = 0.f, cd = 0.f, ws = 0.f;
     int ms = 0;
     const int sub = t >> 4, col = t & 15;   // staging role: ray-in-group, sample-in-tile
-    const bool vec_mask = mask && (S & 15) == 0;
+    const bool vec_mask = (mask || num_nn) && (S & 15) == 0;
+    const bool have_mask = mask || num_nn;      // mask bit of a sample: mask[s] != 0, or (mask == NULL) num_nn[s] == k_full
     for (int s0 = 0; s0 < S; s0 += CP_TS) {
         const int ns = min(CP_TS, S - s0);
         // ---- this ray's 16 mask bytes (one 16-B load when the row is 16-B tiled)
         unsigned mbits = 0;
-        if (mask && live) {
-            if (vec_mask) {
+        if (have_mask && live) {
+            if (!mask) {        // derived from the neighbour counts (4 x 16 B per tile when the row is 16-B tiled)
+                if (vec_mask) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int4 nv = *(const int4*)(num_nn + (size_t)r * S + s0 + 4 * q);
+                        mbits |= ((nv.x == k_full ? 1u : 0u) | (nv.y == k_full ? 2u : 0u) | (nv.z == k_full ? 4u : 0u) |
+                                  (nv.w == k_full ? 8u : 0u)) << (4 * q);
+                    }
+                } else {
+                    for (int k = 0; k < ns; ++k) mbits |= (num_nn[(size_t)r * S + s0 + k] == k_full ? 1u : 0u) << k;
+                }
+            } else if (vec_mask) {
                 const uint4 mv = *(const uint4*)(mask + (size_t)r * S + s0);
                 const unsigned wv[4] = {mv.x, mv.y, mv.z, mv.w};
 #pragma unroll
@@ -591,13 +623,14 @@ __global__ void __launch_bounds__(64) k_composite(const float4* __restrict__ rgb
 
 extern "C" int nf_composite_fwd(const float* rgbsigma, const float* z, const float* z_table, const float* rays,
                                 const uint8_t* mask, int gate_by_mask, int R, int S, int white_bg, float* rgb, float* depth,
-                                float* opacity, float* weights, float* mask_sum, nf_stream_t stream)
+                                float* opacity, float* weights, float* mask_sum, const int32_t* num_nn, int k_full,
+                                nf_stream_t stream)
 {
     NF_CHECK_ARG(rgbsigma && (z || z_table) && rays && rgb && depth && opacity, "null pointer");
-    NF_CHECK_ARG(!gate_by_mask || mask, "gate_by_mask needs the mask");
+    NF_CHECK_ARG(!gate_by_mask || mask || num_nn, "gate_by_mask needs the mask (or num_nn + k_full)");
     if (R == 0) return NF_OK;
     hipLaunchKernelGGL(k_composite, dim3((R + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const float4*)rgbsigma, z,
-                       z_table, rays, mask, gate_by_mask, R, S, white_bg, rgb, depth, opacity, weights, mask_sum);
+                       z_table, rays, mask, gate_by_mask, R, S, white_bg, rgb, depth, opacity, weights, mask_sum, num_nn, k_full);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }
@@ -706,7 +739,7 @@ __global__ void __launch_bounds__(64) k_composite_bwd(const float4* __restrict__
                                                       const float* __restrict__ z_table, const float* __restrict__ rays,
                                                       const float* __restrict__ d_rgb, const uint8_t* __restrict__ mask,
                                                       int gate, int R, int S, int white_bg, float* __restrict__ scratch,
-                                                      float4* __restrict__ d_rgbsigma)
+                                                      float4* __restrict__ d_rgbsigma, const int* __restrict__ num_nn, int k_full)
 {
     int r = blockIdx.x * 64 + threadIdx.x;
     if (r >= R) return;
@@ -719,14 +752,14 @@ __global__ void __launch_bounds__(64) k_composite_bwd(const float4* __restrict__
     float T = 1.f;
     for (int s = 0; s < S; ++s) {
         float delta = ((s + 1 < S) ? (zr[s + 1] - zr[s]) : 1e10f) * nrm;
-        const bool on = !gate || mask[(size_t)r * S + s];      // rgbsigma is defined (written by the MLP) only there
+        const bool on = !gate || (mask ? mask[(size_t)r * S + s] != 0 : num_nn[(size_t)r * S + s] == k_full);      // rgbsigma is defined (written by the MLP) only there
         float alpha = on ? 1.f - expf(-delta * fmaxf(rgbsigma[(size_t)r * S + s].w, 0.f)) : 0.f;
         Tr[s] = T;
         T = T * ((1.f - alpha) + 1e-10f);
     }
     float suffix = 0.f;
     for (int s = S - 1; s >= 0; --s) {
-        const bool on = !gate || mask[(size_t)r * S + s];
+        const bool on = !gate || (mask ? mask[(size_t)r * S + s] != 0 : num_nn[(size_t)r * S + s] == k_full);
         float4 v = on ? rgbsigma[(size_t)r * S + s] : make_float4(0.f, 0.f, 0.f, 0.f);
         float delta = ((s + 1 < S) ? (zr[s + 1] - zr[s]) : 1e10f) * nrm;
         float e = expf(-delta * fmaxf(v.w, 0.f));
@@ -743,13 +776,13 @@ __global__ void __launch_bounds__(64) k_composite_bwd(const float4* __restrict__
 
 extern "C" int nf_composite_bwd(const float* rgbsigma, const float* z, const float* z_table, const float* rays,
                                 const float* d_rgb, const uint8_t* mask, int gate_by_mask, int R, int S, int white_bg,
-                                float* scratch, float* d_rgbsigma, nf_stream_t stream)
+                                float* scratch, float* d_rgbsigma, const int32_t* num_nn, int k_full, nf_stream_t stream)
 {
     NF_CHECK_ARG(rgbsigma && (z || z_table) && rays && d_rgb && scratch && d_rgbsigma, "null pointer");
-    NF_CHECK_ARG(!gate_by_mask || mask, "gate_by_mask needs the mask");
+    NF_CHECK_ARG(!gate_by_mask || mask || num_nn, "gate_by_mask needs the mask (or num_nn + k_full)");
     if (R == 0) return NF_OK;
     hipLaunchKernelGGL(k_composite_bwd, dim3((R + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const float4*)rgbsigma, z,
-                       z_table, rays, d_rgb, mask, gate_by_mask, R, S, white_bg, scratch, (float4*)d_rgbsigma);
+                       z_table, rays, d_rgb, mask, gate_by_mask, R, S, white_bg, scratch, (float4*)d_rgbsigma, num_nn, k_full);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }

@@ -328,13 +328,13 @@ def render_pass(grid, particles, rays, z, z_table, S, radius, K, enc_flags, use_
         return ws.get(name, numel, dtype, dev)
 
     b.num_nn = torch.empty(n_samp, dtype=torch.int32, device=dev)
-    b.mask = scratch("mask", n_samp, torch.uint8)
+    b.K = K         # the mask of a sample is num_nn == K: no separate mask array (nf_composite_* derive the bit from num_nn)
     b.rgbsigma = scratch("rgbsigma", n_samp * 4, torch.float32).view(n_samp, 4)
     cand = scratch("cand", n_samp, torch.int32)
     counters = torch.zeros(2, dtype=torch.int32, device=dev)
     b.counters = counters
     check(lib.nf_render_classify(ptr(grid.ws), ptr(rays), ptr(z), ptr(z_table), R, S, float(radius), int(use_mask), ptr(b.num_nn),
-                                 ptr(b.mask), ptr(cand), ptr(counters[0:1]), st), "nf_render_classify")
+                                 None, ptr(cand), ptr(counters[0:1]), st), "nf_render_classify")
     if max_rows is None:
         max_rows = n_samp
     max_rows = min(max_rows, n_samp)
@@ -345,10 +345,11 @@ def render_pass(grid, particles, rays, z, z_table, S, radius, K, enc_flags, use_
     b.row_sample = scratch("row_sample", n_samp, torch.int32)
     b.row_nbr = scratch("row_nbr", n_samp * K, torch.int32)
     check(lib.nf_render_search(ptr(grid.ws), ptr(rays), ptr(z), ptr(z_table), R, S, float(radius), K, int(use_mask),
-                               ptr(cand), ptr(counters[0:1]), ptr(b.num_nn), ptr(b.mask),
+                               ptr(cand), ptr(counters[0:1]), ptr(b.num_nn), None,
                                ptr(b.row_sample), ptr(b.row_nbr), ptr(counters[1:2]), st), "nf_render_search")
     b.n_rows = counters[1:2]
     b.cap = None
+    alloc_rows = 0
     cap_key = (R, S)
     if max_rows >= n_samp and optimistic and ws is not None and cap_key in ws.row_cap:
         max_rows = min(ws.row_cap[cap_key], n_samp)        # no sync: verified by the caller at the end of the call
@@ -360,9 +361,10 @@ def render_pass(grid, particles, rays, z, z_table, S, radius, K, enc_flags, use_
         b.max_rows = max_rows
         if ws is not None:
             ws.row_cap[cap_key] = max(ws.row_cap.get(cap_key, 0), _round_rows(max_rows + max_rows // 4 + 4096))
+            alloc_rows = ws.row_cap[cap_key]      # size the arena for the capacity runs that follow (no regrowth in a later frame)
     b.n_active = max_rows
     tiles = (max_rows + 31) // 32
-    rows_alloc = _round_rows(max_rows)
+    rows_alloc = _round_rows(max(max_rows, alloc_rows))
     x16 = packed_h is not None and not isinstance(packed_h, PackedS)      # the fp16-MFMA MLPs take fp16 operands (half the bytes)
     b.X = scratch("X", rows_alloc // 32 * (qx + qd) * (128 if x16 else 256), torch.float32)
     check(lib.nf_render_features(ptr(particles), ptr(rays), ptr(z), ptr(z_table), R, S, float(radius), K, enc_flags,
@@ -399,8 +401,8 @@ def render_pass(grid, particles, rays, z, z_table, S, radius, K, enc_flags, use_
     b.weights = torch.empty(R, S, dtype=torch.float32, device=dev) if need_weights else None
     b.mask_sum = torch.empty(R, dtype=torch.float32, device=dev)
     b.gate = int(bool(use_mask))       # rgbsigma is defined where mask = 1 only (nobody writes the rest)
-    check(lib.nf_composite_fwd(ptr(b.rgbsigma), ptr(z), ptr(z_table), ptr(rays), ptr(b.mask), b.gate, R, S, int(white_bg),
-                               ptr(b.rgb), ptr(b.depth), ptr(b.opacity), ptr(b.weights), ptr(b.mask_sum), st),
+    check(lib.nf_composite_fwd(ptr(b.rgbsigma), ptr(z), ptr(z_table), ptr(rays), None, b.gate, R, S, int(white_bg),
+                               ptr(b.rgb), ptr(b.depth), ptr(b.opacity), ptr(b.weights), ptr(b.mask_sum), ptr(b.num_nn), K, st),
           "nf_composite_fwd")
     return b
 
@@ -487,17 +489,16 @@ def debug_features(particles, rays, near, far, S, radius, K, enc_flags, ro):
     R = rays.shape[0]
     n = R * S
     num_nn = torch.empty(n, dtype=torch.int32, device=dev)
-    mask = torch.empty(n, dtype=torch.uint8, device=dev)
     cand = torch.empty(n, dtype=torch.int32, device=dev)
     counters = torch.zeros(2, dtype=torch.int32, device=dev)
     row_sample = torch.empty(n, dtype=torch.int32, device=dev)
     row_nbr = torch.empty(n * K, dtype=torch.int32, device=dev)
     st = _lib.stream()
     rays = rays.contiguous().float()
-    check(lib.nf_render_classify(ptr(grid.ws), ptr(rays), None, ptr(z_table), R, S, float(radius), 1, ptr(num_nn), ptr(mask),
+    check(lib.nf_render_classify(ptr(grid.ws), ptr(rays), None, ptr(z_table), R, S, float(radius), 1, ptr(num_nn), None,
                                  ptr(cand), ptr(counters[0:1]), st))
     check(lib.nf_render_search(ptr(grid.ws), ptr(rays), None, ptr(z_table), R, S, float(radius), K, 1, ptr(cand),
-                               ptr(counters[0:1]), ptr(num_nn), ptr(mask), ptr(row_sample), ptr(row_nbr),
+                               ptr(counters[0:1]), ptr(num_nn), None, ptr(row_sample), ptr(row_nbr),
                                ptr(counters[1:2]), st))
     nr = int(counters[1].item())
     cx, cd, qx, qd = feature_dims(enc_flags)

@@ -164,7 +164,7 @@ def test_composite(dev):
         rgb = torch.empty(R, 3, device=dev); depth = torch.empty(R, device=dev); op = torch.empty(R, device=dev)
         w = torch.empty(R, S, device=dev)
         _lib.check(lib.nf_composite_fwd(rs.data_ptr(), z.data_ptr(), None, rays.data_ptr(), None, 0, R, S, white,
-                                        rgb.data_ptr(), depth.data_ptr(), op.data_ptr(), w.data_ptr(), None,
+                                        rgb.data_ptr(), depth.data_ptr(), op.data_ptr(), w.data_ptr(), None, None, 0,
                                         _lib.stream()))
         torch.testing.assert_close(rgb.cpu(), T(g[key]), rtol=0, atol=2e-6)
         torch.testing.assert_close(w.cpu(), T(g["weights"]), rtol=1e-5, atol=1e-7)
@@ -189,19 +189,24 @@ def test_composite_gated_by_mask(dev):
         ref_in = (rs * mask[..., None]).contiguous().to(dev)
         poisoned = torch.where(mask[..., None], rs, torch.full_like(rs, float("nan"))).contiguous().to(dev)
         m8 = mask.to(torch.uint8).contiguous().to(dev)
+        # the same mask as neighbour counts: K = 20 where the mask is set, anything below elsewhere (the fused renderer
+        # keeps no mask array: mask bit = (num_nn == K))
+        nn = torch.where(mask, torch.full((R, S), 20), torch.randint(0, 20, (R, S), generator=gen)).to(torch.int32).contiguous().to(dev)
         zd, rd = z.contiguous().to(dev), rays.contiguous().to(dev)
         outs = []
-        for src, gate, want_w in ((ref_in, 0, True), (poisoned, 1, True), (poisoned, 1, False)):
+        for src, gate, want_w, by_nn in ((ref_in, 0, True, False), (poisoned, 1, True, False), (poisoned, 1, False, False),
+                                         (poisoned, 1, True, True)):
             rgb = torch.empty(R, 3, device=dev); depth = torch.empty(R, device=dev); op = torch.empty(R, device=dev)
             w = torch.full((R, S), 7.0, device=dev); msum = torch.empty(R, device=dev)
-            _lib.check(lib.nf_composite_fwd(src.data_ptr(), zd.data_ptr(), None, rd.data_ptr(), m8.data_ptr(), gate, R, S, 1,
-                                            rgb.data_ptr(), depth.data_ptr(), op.data_ptr(),
-                                            w.data_ptr() if want_w else None, msum.data_ptr(), _lib.stream()))
+            _lib.check(lib.nf_composite_fwd(src.data_ptr(), zd.data_ptr(), None, rd.data_ptr(), None if by_nn else m8.data_ptr(),
+                                            gate, R, S, 1, rgb.data_ptr(), depth.data_ptr(), op.data_ptr(),
+                                            w.data_ptr() if want_w else None, msum.data_ptr(),
+                                            nn.data_ptr() if by_nn else None, 20, _lib.stream()))
             outs.append((rgb.cpu(), depth.cpu(), op.cpu(), w.cpu(), msum.cpu()))
         for k in range(3):
-            assert torch.equal(outs[0][k], outs[1][k]) and torch.equal(outs[0][k], outs[2][k])
-        assert torch.equal(outs[0][3], outs[1][3]) and bool((outs[2][3] == 7.0).all())
-        assert torch.equal(outs[1][4], mask.sum(1).float()) and torch.equal(outs[0][4], outs[1][4])
+            assert torch.equal(outs[0][k], outs[1][k]) and torch.equal(outs[0][k], outs[2][k]) and torch.equal(outs[0][k], outs[3][k])
+        assert torch.equal(outs[0][3], outs[1][3]) and bool((outs[2][3] == 7.0).all()) and torch.equal(outs[0][3], outs[3][3])
+        assert torch.equal(outs[1][4], mask.sum(1).float()) and torch.equal(outs[0][4], outs[1][4]) and torch.equal(outs[3][4], outs[1][4])
 
 
 def test_importance_zero_row_fast_path(dev):
@@ -827,3 +832,36 @@ def test_split_precision_path(dev):
         torch.testing.assert_close(b[k].cpu(), T(g[k]), rtol=0, atol=RGB_ATOL, msg="golden " + k)      # the reference's own output
     print("split-precision frame: max |rgb1 - fp32 path|", float((a["rgb1"] - b["rgb1"]).abs().max()),
           " PSNR vs oracle", ro.psnr(b["rgb1"].cpu(), ref["rgb1"]))
+
+
+def test_search_optional_mask_output(dev):
+    """nf_render_classify / nf_render_search still fill a caller's mask array when one is passed (mask = num_nn == K, written
+    by a separate tiny kernel); the fused renderer passes NULL and derives the mask from num_nn."""
+    from neurofluid_amd import _lib, ops
+    from neurofluid_amd._lib import check, ptr
+    from oracle import render_oracle as ro
+    lib = _lib.load()
+    net = make_net(dev)
+    rays, roc = _fluid_rays(64)
+    rays = rays.to(dev)
+    P = ro.watercube_particles().to(dev)
+    grid = ops.build_grid(P, net.raduis)
+    z_table, _ = net._tables(dev)
+    R, S, K = rays.shape[0], 64, 20
+    n = R * S
+    res = []
+    for with_mask in (True, False):
+        num_nn = torch.empty(n, dtype=torch.int32, device=dev)
+        mask = torch.full((n,), 9, dtype=torch.uint8, device=dev) if with_mask else None
+        cand = torch.empty(n, dtype=torch.int32, device=dev)
+        counters = torch.zeros(2, dtype=torch.int32, device=dev)
+        row_sample = torch.empty(n, dtype=torch.int32, device=dev)
+        row_nbr = torch.empty(n * K, dtype=torch.int32, device=dev)
+        st = _lib.stream()
+        check(lib.nf_render_classify(ptr(grid.ws), ptr(rays), None, ptr(z_table), R, S, float(net.raduis), 1, ptr(num_nn), ptr(mask),
+                                     ptr(cand), ptr(counters[0:1]), st))
+        check(lib.nf_render_search(ptr(grid.ws), ptr(rays), None, ptr(z_table), R, S, float(net.raduis), K, 1, ptr(cand),
+                                   ptr(counters[0:1]), ptr(num_nn), ptr(mask), ptr(row_sample), ptr(row_nbr), ptr(counters[1:2]), st))
+        res.append((num_nn.clone(), mask, int(counters[1])))
+    assert torch.equal(res[0][0], res[1][0]) and res[0][2] == res[1][2] and res[0][2] > 100
+    assert torch.equal(res[0][1], (res[0][0] == K).to(torch.uint8))

@@ -15,6 +15,14 @@ from . import _lib
 from ._lib import check, ptr
 
 
+# Opt-in experiment (default off = 1): inference passes with at least OVERLAP_MIN_ROWS rows pipelined in OVERLAP_CHUNKS row
+# chunks over two streams (features of chunk c + 1 behind the MLP of chunk c; render_pass).  Measured with 4 chunks: the
+# kernels DO co-run (rocprofv3 trace: separate queues, overlapping intervals), but the co-running feature kernel takes 4x
+# its solo time and the MLP chunk 1.35x — the matrix kernel leaves neither issue slots nor power for the feature stage's
+# double-precision VALU work: fp32 frame 34.9 -> 35.3 ms, fp16 6.7 -> 7.0 ms, split 14.3 -> 14.1 ms.
+OVERLAP_CHUNKS = 1
+OVERLAP_MIN_ROWS = 131072
+
 # bench.py sets PROFILE = {"mlp": [], "rows": []} to collect (start, end) HIP events around every MLP launch
 # (recorded on the stream the kernel is launched on) and the executed-row counts.
 PROFILE = None
@@ -286,6 +294,12 @@ class Workspace:
         self._buf = {}
         self.row_cap = {}        # (R, S) -> row capacity of a render pass learnt from earlier calls (see render_pass)
 
+    def side_stream(self, device):
+        """The second stream of the feature / MLP pipeline (render_pass)."""
+        if getattr(self, "_side", None) is None or self._side.device != device:
+            self._side = torch.cuda.Stream(device=device)
+        return self._side
+
     def get(self, name, numel, dtype, device):
         nbytes = max(int(numel), 1) * torch.empty(0, dtype=dtype).element_size()
         cur = self._buf.get(name)
@@ -367,32 +381,85 @@ def render_pass(grid, particles, rays, z, z_table, S, radius, K, enc_flags, use_
     rows_alloc = _round_rows(max(max_rows, alloc_rows))
     x16 = packed_h is not None and not isinstance(packed_h, PackedS)      # the fp16-MFMA MLPs take fp16 operands (half the bytes)
     b.X = scratch("X", rows_alloc // 32 * (qx + qd) * (128 if x16 else 256), torch.float32)
-    check(lib.nf_render_features(ptr(particles), ptr(rays), ptr(z), ptr(z_table), R, S, float(radius), K, enc_flags,
-                                 ptr(ro), int(ro.dim() == 2), ptr(b.row_sample), ptr(b.row_nbr), ptr(b.n_rows), max_rows,
-                                 ptr(b.X), int(x16), st),
-          "nf_render_features")
     b.acts = torch.empty(rows_alloc * 2432, dtype=torch.float32, device=dev) if save_acts else None
+    x_tile = (qx + qd) * (128 if x16 else 256)           # floats of X per 32-row tile
+    ro_per_ray = int(ro.dim() == 2)
+
+    def features(row0, nrows_t, mx, stream_):
+        check(lib.nf_render_features(ptr(particles), ptr(rays), ptr(z), ptr(z_table), R, S, float(radius), K, enc_flags,
+                                     ptr(ro), ro_per_ray, b.row_sample.data_ptr() + 4 * row0, b.row_nbr.data_ptr() + 4 * K * row0,
+                                     ptr(nrows_t), mx, b.X.data_ptr() + 4 * x_tile * (row0 // 32), int(x16), stream_),
+              "nf_render_features")
+
+    def mlp(row0, nrows_t, mx, stream_):
+        X_, rs_ = b.X.data_ptr() + 4 * x_tile * (row0 // 32), b.row_sample.data_ptr() + 4 * row0
+        if isinstance(packed_h, PackedS):       # split precision: hi + lo fp16 operands, 3 MFMAs per product (inference only)
+            check(lib.nf_nerf_mlp_fwd_s(ptr(packed_h.blob), cx, cd, X_, ptr(nrows_t), mx, rs_, ptr(b.rgbsigma), stream_),
+                  "nf_nerf_mlp_fwd_s")
+        elif isinstance(packed_h, PackedH2):      # fp16-MFMA, two tiles per wave (inference only); X holds an even tile count
+            check(lib.nf_nerf_mlp_fwd_h2(ptr(packed_h.blob), cx, cd, X_, ptr(nrows_t), mx, rs_, ptr(b.rgbsigma), stream_),
+                  "nf_nerf_mlp_fwd_h2")
+        elif packed_h is not None:      # fp16-MFMA, round-1 kernel (kept for A/B runs: RENDERER.mlp_h_kernel = 1)
+            check(lib.nf_nerf_mlp_fwd_h(ptr(packed), ptr(packed_h), cx, cd, X_, ptr(nrows_t), mx, rs_, ptr(b.rgbsigma), stream_),
+                  "nf_nerf_mlp_fwd_h")
+        elif wstream is not None and not save_acts:      # fp32, weight stream shared through LDS (inference)
+            check(lib.nf_nerf_mlp_fwd_l(ptr(packed), ptr(wstream), cx, cd, X_, ptr(nrows_t), mx, rs_, ptr(b.rgbsigma), stream_),
+                  "nf_nerf_mlp_fwd_l")
+        else:
+            check(lib.nf_nerf_mlp_fwd(ptr(packed), cx, cd, X_, ptr(nrows_t), mx, rs_, ptr(b.rgbsigma), ptr(b.acts), stream_),
+                  "nf_nerf_mlp_fwd")
+
+    # Large inference passes are cut into row chunks and pipelined over two streams: the feature stage of chunk c + 1 (VALU /
+    # HBM-write work, <= 84 registers per wave, no LDS) runs on a side stream while the MLP of chunk c (one wave per SIMD on
+    # the matrix pipe, ~390 of the 512 registers) runs on the launch stream — the two kernels co-reside on the same CUs,
+    # so after the first chunk the feature stage costs no wall time.  Chunks are row ranges of the capacity; the kernels
+    # clamp to the true row count (one tiny device op derives the per-chunk counts).
+    n_chunks = OVERLAP_CHUNKS if (ws is not None and not save_acts and OVERLAP_CHUNKS > 1 and max_rows >= OVERLAP_MIN_ROWS) else 1
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-    if isinstance(packed_h, PackedS):       # split precision: hi + lo fp16 operands, 3 MFMAs per product (inference only)
-        check(lib.nf_nerf_mlp_fwd_s(ptr(packed_h.blob), cx, cd, ptr(b.X), ptr(b.n_rows), max_rows, ptr(b.row_sample),
-                                    ptr(b.rgbsigma), st), "nf_nerf_mlp_fwd_s")
-    elif isinstance(packed_h, PackedH2):      # fp16-MFMA, two tiles per wave (inference only); X holds an even tile count
-        check(lib.nf_nerf_mlp_fwd_h2(ptr(packed_h.blob), cx, cd, ptr(b.X), ptr(b.n_rows), max_rows, ptr(b.row_sample),
-                                     ptr(b.rgbsigma), st), "nf_nerf_mlp_fwd_h2")
-    elif packed_h is not None:      # fp16-MFMA, round-1 kernel (kept for A/B runs: RENDERER.mlp_h_kernel = 1)
-        check(lib.nf_nerf_mlp_fwd_h(ptr(packed), ptr(packed_h), cx, cd, ptr(b.X), ptr(b.n_rows), max_rows,
-                                    ptr(b.row_sample), ptr(b.rgbsigma), st), "nf_nerf_mlp_fwd_h")
-    elif wstream is not None and not save_acts:      # fp32, weight stream shared through LDS (inference)
-        check(lib.nf_nerf_mlp_fwd_l(ptr(packed), ptr(wstream), cx, cd, ptr(b.X), ptr(b.n_rows), max_rows, ptr(b.row_sample),
-                                    ptr(b.rgbsigma), st), "nf_nerf_mlp_fwd_l")
+    if n_chunks == 1:
+        features(0, b.n_rows, max_rows, st)
+        if PROFILE is not None:
+            e0.record()
+        mlp(0, b.n_rows, max_rows, st)
+        if PROFILE is not None:
+            e1.record()
+            PROFILE["mlp"].append((e0, e1))
     else:
-        check(lib.nf_nerf_mlp_fwd(ptr(packed), cx, cd, ptr(b.X), ptr(b.n_rows), max_rows, ptr(b.row_sample),
-                                  ptr(b.rgbsigma), ptr(b.acts), st), "nf_nerf_mlp_fwd")
+        main = torch.cuda.current_stream()
+        side = ws.side_stream(dev)
+        chunk = (max_rows + n_chunks - 1) // n_chunks
+        chunk = (chunk + 63) // 64 * 64
+        starts = torch.arange(n_chunks, dtype=torch.int32, device=dev) * chunk
+        counts = (b.n_rows - starts).clamp_(0, chunk)           # rows of every chunk, on the device
+        starts.record_stream(side)
+        counts.record_stream(side)
+        ev = torch.cuda.Event()
+        ev.record(main)                                         # row lists (search) and counts are complete
+        side.wait_event(ev)
+        mlp_ms = []
+        for c in range(n_chunks):
+            row0 = c * chunk
+            mx = min(chunk, max_rows - row0)
+            if mx <= 0:
+                break
+            with torch.cuda.stream(side):
+                features(row0, counts[c:c + 1], mx, side.cuda_stream)
+                evc = torch.cuda.Event()
+                evc.record(side)
+            main.wait_event(evc)
+            if PROFILE is not None:
+                a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a0.record(main)
+            mlp(row0, counts[c:c + 1], mx, st)
+            if PROFILE is not None:
+                a1.record(main)
+                mlp_ms.append((a0, a1))
+        b.overlap_keep = (starts, counts)
+        if PROFILE is not None:
+            PROFILE["mlp"].extend(mlp_ms)
+            PROFILE["rows"].extend([0] * (len(mlp_ms) - 1))     # the pass's rows are booked once, below
     if PROFILE is not None:
-        e1.record()
-        PROFILE["mlp"].append((e0, e1))
         PROFILE["rows"].append(max_rows if b.cap is None else b.n_rows)      # capacity run: the caller resolves the true count
     b.rgb = torch.empty(R, 3, dtype=torch.float32, device=dev)
     b.depth = torch.empty(R, dtype=torch.float32, device=dev)

@@ -313,13 +313,14 @@ class Workspace:
 
 def render_pass(grid, particles, rays, z, z_table, S, radius, K, enc_flags, use_mask, ro, packed, cx, cd,
                 white_bg=True, save_acts=False, max_rows=None, packed_h=None, ws=None, need_weights=True, wstream=None,
-                optimistic=False):
+                optimistic=False, caps=None):
     """Runs classify -> search -> features -> MLP -> composite for R rays x S samples.
     z: (R,S) per-ray depths or None (then z_table (S,) is shared by all rays).
     Returns a PassBuffers with rgb, depth, opacity, weights, num_nn, mask_sum and the row lists.
 
     Row-buffer sizing.  The number of active rows is known on the device only.  Exact sizing reads it back (one host
-    sync in the middle of the pass).  With optimistic=True and a workspace that has seen this (R, S) shape before, the
+    sync in the middle of the pass).  With optimistic=True and a capacity table (`caps`: (R, S) -> rows; the workspace's for
+    inference, the module's for training) that has seen this shape before, the
     pass runs WITHOUT any host round trip against the capacity learnt then (kernels clamp to it); `b.cap` is set and
     the caller must compare `b.n_rows` with it once the frame is enqueued and redo the call on overflow
     (autograd._run_passes does: one sync per call, at its end, instead of one in the middle of each pass)."""
@@ -365,17 +366,19 @@ def render_pass(grid, particles, rays, z, z_table, S, radius, K, enc_flags, use_
     b.cap = None
     alloc_rows = 0
     cap_key = (R, S)
-    if max_rows >= n_samp and optimistic and ws is not None and cap_key in ws.row_cap:
-        max_rows = min(ws.row_cap[cap_key], n_samp)        # no sync: verified by the caller at the end of the call
+    if caps is None and ws is not None:
+        caps = ws.row_cap
+    if max_rows >= n_samp and optimistic and caps is not None and cap_key in caps:
+        max_rows = min(caps[cap_key], n_samp)        # no sync: verified by the caller at the end of the call
         b.max_rows = b.cap = max_rows
     elif max_rows >= n_samp:
         # exact sizing of the per-row buffers: one host sync per pass (the caller can avoid it by
         # passing a static max_rows bound, e.g. under hipGraph capture)
         max_rows = int(counters[1].item())
         b.max_rows = max_rows
-        if ws is not None:
-            ws.row_cap[cap_key] = max(ws.row_cap.get(cap_key, 0), _round_rows(max_rows + max_rows // 4 + 4096))
-            alloc_rows = ws.row_cap[cap_key]      # size the arena for the capacity runs that follow (no regrowth in a later frame)
+        if caps is not None:
+            caps[cap_key] = max(caps.get(cap_key, 0), _round_rows(max_rows + max_rows // 4 + 4096))
+            alloc_rows = caps[cap_key]      # size the buffers for the capacity runs that follow (no regrowth in a later call)
     b.n_active = max_rows
     tiles = (max_rows + 31) // 32
     rows_alloc = _round_rows(max(max_rows, alloc_rows))

@@ -12,6 +12,14 @@ from . import dist as nfdist
 _COORDS = {}
 
 
+def _upload(t, device):
+    """Host -> device copy that does not synchronise the stream: pinned staging + non_blocking (a pageable .to(device)
+    waits for everything enqueued before it, i.e. for the previous optimiser step)."""
+    if device.type != "cuda":
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
+
+
 def random_sample_coords(H, W, global_step, precrop_iters):
     """trainer/basetrainer.py:171-193 (CPU tensors, like the reference's device-less meshgrid).  The grid only
     has two variants (centre crop / full frame), so it is built once instead of once per view per step."""
@@ -122,7 +130,7 @@ def renderer_train_step(renderer, optimizer, scheduler, particles, views, H, W, 
     for vi, v in enumerate(views):
         coords = random_sample_coords(H, W, step_idx, precrop_iters)
         sel = sels[vi] if sels is not None else rng.choice(coords.shape[0], size=[ray_chunk], replace=False)
-        sc = coords[sel].long().to(v["rays"].device)
+        sc = _upload(coords[sel].long(), v["rays"].device)
         rays_l.append(v["rays"][sc[:, 0], sc[:, 1]])
         rgbs_l.append(v["rgb"].view(H, W, -1)[sc[:, 0], sc[:, 1]])
         ro_l.append(renderer.set_ro(v["cw"]).expand(ray_chunk, 3))

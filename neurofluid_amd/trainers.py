@@ -20,7 +20,7 @@ from .datasets import BlenderDataset, ParticleDataset
 from .point_eval import FluidErrors
 from .render_loop import render_image as _render_image
 from .renderer import RenderNet
-from .train_step import ExponentialLR, PixelSampler, random_sample_coords
+from .train_step import ExponentialLR, PixelSampler, random_sample_coords, _upload
 from .transmodel import ParticleNet
 
 to8b = lambda x: (255 * np.clip(x, 0, 1)).astype(np.uint8)   # noqa: E731  trainer/basetrainer.py:16
@@ -147,7 +147,7 @@ class BaseTrainer:
         coords = self.random_sample_coords(H, W, global_step)
         if sel is None:
             sel = np.random.choice(coords.shape[0], size=[ray_chunk], replace=False)
-        sc = coords[sel].long().to(rays_hw6.device)
+        sc = _upload(coords[sel].long(), rays_hw6.device)
         return rays_hw6[sc[:, 0], sc[:, 1]], rgbs.view(H, W, -1)[sc[:, 0], sc[:, 1]]
 
     # ---- the chunk loop (trainer/basetrainer.py:264-309)

@@ -316,6 +316,12 @@ int nf_cconv_small_bwd_feat(const float* kernel, int cin, const int64_t* row_spl
                             const float* pair_w_t, const uint8_t* pair_cell_t, const float* dy, int ld_dy, int col_off,
                             int n, float* dfeat /*n*cin*/, nf_stream_t stream);
 
+/* C1 / C2 callers, host side (no device work): the pixel draw np.random.choice(n, size, replace=False) of
+ * trainer/trainer_renderer.py:119 and trainer/basetrainer.py:186-190 for numpy's legacy RandomState, callable without the
+ * interpreter lock.  key[624] / *pos are the MT19937 state (RandomState.get_state()[1:3]) and are advanced exactly as numpy
+ * advances them; out[size] receives permutation(n)[:size].  1 <= n < 2^31. */
+int nf_host_choice_mt19937(uint32_t* key /*624, in/out*/, int* pos /*in/out*/, int64_t n, int64_t size, int64_t* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -74,6 +74,7 @@ PROTOTYPES = {
     "nf_cconv_small_bwd_feat": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "nf_cconv_small": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "nf_host_choice_mt19937": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "nf_cconv_transform": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nf_cconv_gather": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                 c_void_p, c_void_p]),

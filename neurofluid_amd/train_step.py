@@ -12,12 +12,45 @@ from . import dist as nfdist
 _COORDS = {}
 
 
+_STAGE = {}
+
+
 def _upload(t, device):
-    """Host -> device copy that does not synchronise the stream: pinned staging + non_blocking (a pageable .to(device)
-    waits for everything enqueued before it, i.e. for the previous optimiser step)."""
+    """Host -> device copy that neither synchronises the stream nor allocates: a pageable .to(device) waits for everything
+    enqueued before it (i.e. for the previous optimiser step), and Tensor.pin_memory() page-locks a fresh buffer per call
+    (0.9 ms of host time each in the trace).  A ring of 4 pinned staging buffers per (dtype, size class) is reused; a
+    slot is rewritten only after the event recorded behind its last copy has completed."""
     if device.type != "cuda":
         return t.to(device)
-    return t.pin_memory().to(device, non_blocking=True)
+    t = t.contiguous()
+    n = t.numel()
+    cap = 1 << max(10, (n - 1).bit_length())
+    ring = _STAGE.setdefault((t.dtype, cap), {"i": 0, "slots": []})
+    if len(ring["slots"]) < 4:
+        ring["slots"].append([torch.empty(cap, dtype=t.dtype).pin_memory(), None])
+        slot = ring["slots"][-1]
+    else:
+        slot = ring["slots"][ring["i"] % 4]
+        ring["i"] += 1
+        if slot[1] is not None:
+            slot[1].synchronize()
+    buf = slot[0][:n].view(t.shape)
+    buf.copy_(t)
+    out = buf.to(device, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(device))
+    slot[1] = ev
+    return out
+
+
+def make_adam(params, **kw):
+    """torch.optim.Adam; for parameters on the GPU the fused implementation (same update rule and state layout as the
+    default multi-tensor one, 2 launches instead of 7 per step)."""
+    params = list(params)
+    groups = params if params and isinstance(params[0], dict) else [{"params": params}]
+    groups = [dict(g, params=list(g["params"])) for g in groups]
+    on_gpu = all(p.is_cuda for g in groups for p in g["params"]) and any(len(g["params"]) for g in groups)
+    return torch.optim.Adam(groups, fused=True, **kw) if on_gpu else torch.optim.Adam(groups, **kw)
 
 
 def random_sample_coords(H, W, global_step, precrop_iters):
@@ -40,6 +73,34 @@ def _build_coords(H, W, global_step, precrop_iters):
     return coords.reshape(-1, 2)
 
 
+def gather_view_pixels(rays_list, rgb_list, cw_list, coords, sels, H, W):
+    """The pixel gathers of all views of one step with ONE upload and one index_select per tensor (the reference indexes
+    every view separately, trainer/basetrainer.py:186-193: 2 two-index gathers + 1 upload per view = 16 small dispatches
+    and 1.4 ms of host time per step).  rays_list[v] (H, W, 6), rgb_list[v] (H*W, C), cw_list[v] (3, 4) on the device,
+    coords (n, 2) on the host, sels[v] the selected rows of coords.  Returns rays (V*rc, 6), rgbs (V*rc, C), ro (V*rc, 3),
+    view-major."""
+    dev = rays_list[0].device
+    V, rc = len(rays_list), len(sels[0])
+    yx = torch.cat([coords[torch.as_tensor(s)] for s in sels]).long()
+    flat = yx[:, 0] * W + yx[:, 1] + (torch.arange(V).repeat_interleave(rc) * (H * W))
+    flat = _upload(flat, dev)
+    rays = torch.cat([r.reshape(H * W, -1) for r in rays_list]).index_select(0, flat)
+    rgbs = torch.cat([c.reshape(H * W, -1) for c in rgb_list]).index_select(0, flat)
+    ro = torch.stack([cw[:, 3] for cw in cw_list]).repeat_interleave(rc, dim=0)
+    return rays, rgbs, ro
+
+
+def summed_view_mse(out, rgbs, n_views, fine):
+    """sum over views of MSE(rgb0_v) [+ MSE(rgb1_v)] (trainer_renderer.py:124-131) for equally sized views: every view's
+    mean has the same denominator, so the sum is two global sums over one denominator (2 reductions instead of 2 per view
+    plus the slice / add nodes of the autograd graph)."""
+    denom = rgbs.numel() // n_views
+    tot = torch.nn.functional.mse_loss(out["rgb0"], rgbs, reduction="sum")
+    if fine:
+        tot = tot + torch.nn.functional.mse_loss(out["rgb1"], rgbs, reduction="sum")
+    return tot / denom
+
+
 class PixelSampler:
     """Draws the per-view pixel selections `rng.choice(n, ray_chunk, replace=False)` (trainer_renderer.py:119) in the
     reference's order, one step ahead on a background thread: the draw is a full 160 000-element shuffle (1.4 ms per
@@ -57,17 +118,53 @@ class PixelSampler:
         self.step = first_step
         self._stop = threading.Event()
         self._pending = None          # (step, sels, state_before) drawn but not yet queued when the stop flag was seen
+        self._native_end = None
         self.t = threading.Thread(target=self._run, daemon=True)
         self.t.start()
+
+    def _native_state(self):
+        """(key, pos, tail) when the stream is numpy's legacy MT19937 and the library is built: the draws then run in
+        nf_host_choice_mt19937 (bit-identical indices and generator state, outside the GIL — a numpy draw holds the GIL
+        for its whole 160 000-element shuffle, 4 x 1.4 ms per step, and starves the thread that feeds the GPU)."""
+        try:
+            st = self.rng.get_state()
+            if st[0] != 'MT19937':
+                return None
+            from . import _lib
+            _lib.load()
+            return [np.array(st[1], dtype=np.uint32), int(st[2]), tuple(st[3:])]
+        except Exception:       # no get_state (a Generator), library not built: numpy draws
+            return None
+
+    def _draw(self, nat, n):
+        """One step's selections and the generator state they started from."""
+        if nat is None:
+            state = self.rng.get_state()
+            return [self.rng.choice(n, size=[self.ray_chunk], replace=False) for _ in range(self.n_views)], state
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        key, pos, tail = nat
+        state = ('MT19937', key.copy(), pos) + tail
+        if n < self.ray_chunk:
+            raise ValueError("Cannot take a larger sample than population when 'replace=False'")
+        cpos = ctypes.c_int(pos)
+        sels = []
+        for _ in range(self.n_views):
+            out = np.empty(self.ray_chunk, dtype=np.int64)
+            _lib.check(lib.nf_host_choice_mt19937(key.ctypes.data, ctypes.addressof(cpos), n, self.ray_chunk, out.ctypes.data),
+                       "nf_host_choice_mt19937")
+            sels.append(out)
+        nat[1] = cpos.value
+        return sels, state
 
     def _run(self):
         import queue
         step = self.step
+        nat = self._native_state()
         try:
             while not self._stop.is_set():
-                state = self.rng.get_state()
-                n = self.n_of(step)
-                sels = [self.rng.choice(n, size=[self.ray_chunk], replace=False) for _ in range(self.n_views)]
+                sels, state = self._draw(nat, self.n_of(step))
                 item = (step, sels, state)
                 while True:
                     if self._stop.is_set():
@@ -81,6 +178,9 @@ class PixelSampler:
                 step += 1
         except BaseException as e:          # surfaced by next(); never leaves the consumer blocked
             self.q.put(("error", e, None))
+        finally:
+            if nat is not None:             # native draws never touched self.rng: close() moves it
+                self._native_end = ('MT19937', nat[0].copy(), nat[1]) + nat[2]
 
     def next(self, step):
         import queue
@@ -110,6 +210,8 @@ class PixelSampler:
         states = [it[2] for it in left if it[0] != "error" and it[2] is not None]
         if states:                          # rewind to before the first unconsumed draw
             self.rng.set_state(states[0])
+        elif getattr(self, "_native_end", None) is not None:
+            self.rng.set_state(self._native_end)
 
 
 class ExponentialLR(torch.optim.lr_scheduler.LambdaLR):
@@ -125,23 +227,13 @@ def renderer_train_step(renderer, optimizer, scheduler, particles, views, H, W, 
     The reference renders the views one after the other; rays are independent, so the views are batched into ONE
     renderer call (per-ray camera position) and the per-view MSEs are taken on slices — same loss, 4x fewer launches.
     The pixel RNG is drawn per view in the reference's order (np.random.choice, trainer_renderer.py:119)."""
-    rays_l, rgbs_l, ro_l = [], [], []
-    sels = sampler.next(step_idx) if sampler is not None else None
-    for vi, v in enumerate(views):
-        coords = random_sample_coords(H, W, step_idx, precrop_iters)
-        sel = sels[vi] if sels is not None else rng.choice(coords.shape[0], size=[ray_chunk], replace=False)
-        sc = _upload(coords[sel].long(), v["rays"].device)
-        rays_l.append(v["rays"][sc[:, 0], sc[:, 1]])
-        rgbs_l.append(v["rgb"].view(H, W, -1)[sc[:, 0], sc[:, 1]])
-        ro_l.append(renderer.set_ro(v["cw"]).expand(ray_chunk, 3))
-    out = renderer(particles, torch.cat(ro_l).contiguous(), torch.cat(rays_l), None, None)
-    total = 0.
-    for i, rgbs in enumerate(rgbs_l):
-        sl = slice(i * ray_chunk, (i + 1) * ray_chunk)
-        loss = torch.nn.functional.mse_loss(out["rgb0"][sl], rgbs)
-        if renderer.N_importance > 0:
-            loss = loss + torch.nn.functional.mse_loss(out["rgb1"][sl], rgbs)
-        total = total + loss
+    coords = random_sample_coords(H, W, step_idx, precrop_iters)
+    sels = sampler.next(step_idx) if sampler is not None else \
+        [rng.choice(coords.shape[0], size=[ray_chunk], replace=False) for _ in views]
+    rays, rgbs, ro = gather_view_pixels([v["rays"] for v in views], [v["rgb"] for v in views], [v["cw"] for v in views],
+                                        coords, sels, H, W)
+    out = renderer(particles, ro, rays, None, None)
+    total = summed_view_mse(out, rgbs, len(views), renderer.N_importance > 0)
     optimizer.zero_grad()
     total.backward()
     nfdist.allreduce_grads(list(renderer.parameters()), world)
@@ -161,7 +253,7 @@ def make_train_step(net, scene, dev, rank=0, world=1, lr=5e-4, decay_epochs=1000
     P = scene["P"].to(dev)
     for p in net.parameters():
         p.requires_grad_(True)
-    opt = torch.optim.Adam(net.parameters(), lr=lr)
+    opt = make_adam(net.parameters(), lr=lr)
     sched = ExponentialLR(opt, decay_epochs=decay_epochs, gamma=0.1)
     rng = np.random.RandomState(seed + rank)
     state = {"step": 1000}   # past precrop_iters: full-frame sampling (steady state of the 100k-step schedule)

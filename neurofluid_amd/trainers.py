@@ -20,7 +20,7 @@ from .datasets import BlenderDataset, ParticleDataset
 from .point_eval import FluidErrors
 from .render_loop import render_image as _render_image
 from .renderer import RenderNet
-from .train_step import ExponentialLR, PixelSampler, random_sample_coords, _upload
+from .train_step import ExponentialLR, PixelSampler, random_sample_coords, _upload, gather_view_pixels, make_adam, summed_view_mse
 from .transmodel import ParticleNet
 
 to8b = lambda x: (255 * np.clip(x, 0, 1)).astype(np.uint8)   # noqa: E731  trainer/basetrainer.py:16
@@ -217,7 +217,7 @@ class RendererTrainer(BaseTrainer):
         self.renderer = RenderNet(o.RENDERER, near=o.near, far=o.far).to(self.device)
         if o.TRAIN.pretained_renderer != '':
             self.load_pretained_renderer_model(o.TRAIN.pretained_renderer, partial_load=o.TRAIN.partial_load)
-        self.optimizer = torch.optim.Adam(self.renderer.parameters(), lr=o.TRAIN.LR.lr)
+        self.optimizer = make_adam(self.renderer.parameters(), lr=o.TRAIN.LR.lr)
         self.lr_scheduler = ExponentialLR(self.optimizer, decay_epochs=o.TRAIN.LR.decay_epochs, gamma=0.1) \
             if o.TRAIN.LR.use_scheduler else None
         self.set_RGB_criterion()
@@ -264,22 +264,32 @@ class RendererTrainer(BaseTrainer):
 
     def train_step(self, data, view_num, H, W, step_idx):
         rc = self.options.RENDERER.ray.ray_chunk
-        rays_l, rgbs_l, ro_l = [], [], []
-        sels = self._sampler.next(step_idx) if getattr(self, '_sampler', None) is not None else [None] * view_num
-        for v in range(view_num):
-            rays, rgbs = self.sample_pixels(data['rays'][v], data['rgb'][v], H, W, step_idx, rc, sels[v])
-            rays_l.append(rays); rgbs_l.append(rgbs)
-            ro_l.append(self.renderer.set_ro(data['cw'][v]).expand(rc, 3))
-        # the views are rendered in ONE fused call (rays are independent; per-ray camera position)
-        out = self.renderer(data['particles_pos'], torch.cat(ro_l).contiguous(), torch.cat(rays_l), None, None)
-        total = 0.
-        for v in range(view_num):
-            sl = slice(v * rc, (v + 1) * rc)
-            l0 = self.rgb_criterion(out['rgb0'][sl], rgbs_l[v])
-            loss = l0 + self.rgb_criterion(out['rgb1'][sl], rgbs_l[v]) if self.renderer.N_importance > 0 else l0
-            total = total + loss
-            if (step_idx + 1) % self.options.TRAIN.log_interval == 0:
-                self.summary_writer.add_scalar(f'{self.train_view_names[v]}/rgbloss', loss.item(), step_idx)
+        coords = self.random_sample_coords(H, W, step_idx)
+        sels = self._sampler.next(step_idx) if getattr(self, '_sampler', None) is not None else \
+            [np.random.choice(coords.shape[0], size=[rc], replace=False) for _ in range(view_num)]
+        # the views are rendered in ONE fused call (rays are independent; per-ray camera position), their pixels gathered
+        # with one upload and one index_select per tensor
+        rays, rgbs, ro = gather_view_pixels([data['rays'][v] for v in range(view_num)], [data['rgb'][v] for v in range(view_num)],
+                                            [data['cw'][v] for v in range(view_num)], coords, sels, H, W)
+        out = self.renderer(data['particles_pos'], ro, rays, None, None)
+        fine = self.renderer.N_importance > 0
+        if type(self.rgb_criterion) is torch.nn.MSELoss and self.rgb_criterion.reduction == 'mean':
+            total = summed_view_mse(out, rgbs, view_num, fine)
+        else:
+            total = 0.
+            for v in range(view_num):
+                sl = slice(v * rc, (v + 1) * rc)
+                total = total + self.rgb_criterion(out['rgb0'][sl], rgbs[sl])
+                if fine:
+                    total = total + self.rgb_criterion(out['rgb1'][sl], rgbs[sl])
+        if (step_idx + 1) % self.options.TRAIN.log_interval == 0:
+            with torch.no_grad():
+                for v in range(view_num):
+                    sl = slice(v * rc, (v + 1) * rc)
+                    lv = self.rgb_criterion(out['rgb0'][sl], rgbs[sl])
+                    if fine:
+                        lv = lv + self.rgb_criterion(out['rgb1'][sl], rgbs[sl])
+                    self.summary_writer.add_scalar(f'{self.train_view_names[v]}/rgbloss', lv.item(), step_idx)
         return total
 
     def eval(self, step_idx):
@@ -332,10 +342,10 @@ class E2ETrainer(BaseTrainer):
         lr_r, lr_t = o.TRAIN.LR.renderer_lr, o.TRAIN.LR.trans_lr
         self.separate = o.TRAIN.seperate_render_transition
         if self.separate:
-            self.optimizer = torch.optim.Adam([{'params': self.renderer.parameters(), 'lr': lr_r}])
-            self.transition_optimizer = torch.optim.Adam([{'params': self.transition_model.parameters(), 'lr': lr_t}])
+            self.optimizer = make_adam([{'params': self.renderer.parameters(), 'lr': lr_r}])
+            self.transition_optimizer = make_adam([{'params': self.transition_model.parameters(), 'lr': lr_t}])
         else:
-            self.optimizer = torch.optim.Adam([{'params': self.renderer.parameters(), 'lr': lr_r},
+            self.optimizer = make_adam([{'params': self.renderer.parameters(), 'lr': lr_r},
                                                {'params': self.transition_model.parameters(), 'lr': lr_t}])
         self.schedulers = []
         if o.TRAIN.LR.use_scheduler:      # trainer_e2e.py:83-139
@@ -603,7 +613,7 @@ class TransModelTrainer(BaseTrainer):
                                        random_rot=True, window=3)
         self.test_dataset = ParticleDataset(dp.eval, dp.eval_datatype, o.TRAIN.start_index, o.TRAIN.end_index,
                                             random_rot=False, window=3)
-        self.optimizer = torch.optim.Adam(self.transition_model.parameters(), lr=o.TRAIN.lr)
+        self.optimizer = make_adam(self.transition_model.parameters(), lr=o.TRAIN.lr)
         self.set_L1_criterion()
 
     def init_box_boundary(self):

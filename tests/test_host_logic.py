@@ -197,3 +197,51 @@ def test_dataset_readers_vs_reference_readers(tmp_path):
     assert len(pr) == int(g["particles_rot_len"])
     for k, v in pr[0].items():
         np.testing.assert_array_equal(v.numpy(), g[f"particles_rot0__{k}"], err_msg=k)
+
+
+def test_native_pixel_draw_matches_numpy_bit_for_bit():
+    """nf_host_choice_mt19937 (csrc/nf_host.hip): np.random.choice(n, size, replace=False) of the legacy RandomState
+    (trainer/trainer_renderer.py:119) outside the GIL — same indices, same generator state afterwards (the next values of
+    the stream agree, including a cached gaussian), for full-frame / centre-crop / degenerate sizes and across the
+    generator's 624-word refills and power-of-two mask boundaries."""
+    import ctypes
+    import numpy as np
+    from neurofluid_amd import _lib
+    lib = _lib.load()
+    cases = [(0, 160000, 1024), (1, 40000, 1024), (7, 5, 5), (3, 1, 1), (3, 2, 1), (11, 1024, 1024), (5, 100000, 1),
+             (9, 2 ** 17, 100), (9, 2 ** 17 + 1, 100), (13, 3, 2), (21, 640000, 4096)]
+    for seed, n, size in cases:
+        r = np.random.RandomState(seed)
+        r.standard_normal(3)                      # leaves a cached gaussian in the state
+        st = r.get_state()
+        want = r.choice(n, size=[size], replace=False)
+        key, pos, out = st[1].copy(), ctypes.c_int(st[2]), np.empty(size, dtype=np.int64)
+        assert lib.nf_host_choice_mt19937(key.ctypes.data, ctypes.addressof(pos), n, size, out.ctypes.data) == 0
+        assert np.array_equal(out, want), (seed, n, size)
+        r2 = np.random.RandomState()
+        r2.set_state((st[0], key, pos.value) + tuple(st[3:]))
+        assert np.array_equal(r.randint(0, 1 << 30, size=700), r2.randint(0, 1 << 30, size=700))
+        assert r.standard_normal() == r2.standard_normal()
+    # argument errors are reported, not executed
+    key, pos, out = np.zeros(624, dtype=np.uint32), ctypes.c_int(0), np.empty(4, dtype=np.int64)
+    assert lib.nf_host_choice_mt19937(key.ctypes.data, ctypes.addressof(pos), 3, 4, out.ctypes.data) != 0
+    assert lib.nf_host_choice_mt19937(key.ctypes.data, ctypes.addressof(pos), 0, 0, out.ctypes.data) != 0
+
+
+def test_pixel_sampler_uses_the_native_draw():
+    from neurofluid_amd.train_step import PixelSampler
+    import numpy as np
+    s = PixelSampler(np.random.RandomState(5), 2, 32, lambda step: 1000, 0)
+    assert s._native_state() is not None
+    s.close()
+    # a stream that is not the legacy MT19937 falls back to its own choice()
+    class Other:
+        def __init__(self): self.r = np.random.RandomState(1)
+        def get_state(self): return ('PCG',) + self.r.get_state()[1:]
+        def set_state(self, st): self.r.set_state(('MT19937',) + tuple(st[1:]))
+        def choice(self, *a, **k): return self.r.choice(*a, **k)
+    o = Other()
+    s = PixelSampler(o, 1, 8, lambda step: 50, 0)
+    got = s.next(0)
+    s.close()
+    assert np.array_equal(got[0], np.random.RandomState(1).choice(50, size=[8], replace=False))

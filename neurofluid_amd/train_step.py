@@ -73,6 +73,29 @@ def _build_coords(H, W, global_step, precrop_iters):
     return coords.reshape(-1, 2)
 
 
+def choice_without_replacement(rng, n, size):
+    """rng.choice(n, size=[size], replace=False) of a legacy numpy stream (np.random itself or a RandomState), drawn by
+    nf_host_choice_mt19937 when the stream is MT19937 and the library is built (same indices, same state afterwards,
+    about 2.5x faster than numpy's shuffle); numpy otherwise."""
+    try:
+        st = rng.get_state()
+        native = st[0] == 'MT19937' and n >= size >= 0 and 1 <= n < 2 ** 31
+        if native:
+            from . import _lib
+            lib = _lib.load()
+    except Exception:
+        native = False
+    if not native:
+        return rng.choice(n, size=[size], replace=False)
+    import ctypes
+    key, pos = np.array(st[1], dtype=np.uint32), ctypes.c_int(int(st[2]))
+    out = np.empty(size, dtype=np.int64)
+    _lib.check(lib.nf_host_choice_mt19937(key.ctypes.data, ctypes.addressof(pos), n, size, out.ctypes.data),
+               "nf_host_choice_mt19937")
+    rng.set_state(('MT19937', key, pos.value) + tuple(st[3:]))
+    return out
+
+
 def gather_view_pixels(rays_list, rgb_list, cw_list, coords, sels, H, W):
     """The pixel gathers of all views of one step with ONE upload and one index_select per tensor (the reference indexes
     every view separately, trainer/basetrainer.py:186-193: 2 two-index gathers + 1 upload per view = 16 small dispatches
@@ -84,8 +107,9 @@ def gather_view_pixels(rays_list, rgb_list, cw_list, coords, sels, H, W):
     yx = torch.cat([coords[torch.as_tensor(s)] for s in sels]).long()
     flat = yx[:, 0] * W + yx[:, 1] + (torch.arange(V).repeat_interleave(rc) * (H * W))
     flat = _upload(flat, dev)
-    rays = torch.cat([r.reshape(H * W, -1) for r in rays_list]).index_select(0, flat)
-    rgbs = torch.cat([c.reshape(H * W, -1) for c in rgb_list]).index_select(0, flat)
+    one = (lambda ts: ts[0].reshape(H * W, -1)) if V == 1 else (lambda ts: torch.cat([t.reshape(H * W, -1) for t in ts]))
+    rays = one(rays_list).index_select(0, flat)
+    rgbs = one(rgb_list).index_select(0, flat)
     ro = torch.stack([cw[:, 3] for cw in cw_list]).repeat_interleave(rc, dim=0)
     return rays, rgbs, ro
 
@@ -229,7 +253,7 @@ def renderer_train_step(renderer, optimizer, scheduler, particles, views, H, W, 
     The pixel RNG is drawn per view in the reference's order (np.random.choice, trainer_renderer.py:119)."""
     coords = random_sample_coords(H, W, step_idx, precrop_iters)
     sels = sampler.next(step_idx) if sampler is not None else \
-        [rng.choice(coords.shape[0], size=[ray_chunk], replace=False) for _ in views]
+        [choice_without_replacement(rng, coords.shape[0], ray_chunk) for _ in views]
     rays, rgbs, ro = gather_view_pixels([v["rays"] for v in views], [v["rgb"] for v in views], [v["cw"] for v in views],
                                         coords, sels, H, W)
     out = renderer(particles, ro, rays, None, None)

@@ -20,7 +20,8 @@ from .datasets import BlenderDataset, ParticleDataset
 from .point_eval import FluidErrors
 from .render_loop import render_image as _render_image
 from .renderer import RenderNet
-from .train_step import ExponentialLR, PixelSampler, random_sample_coords, _upload, gather_view_pixels, make_adam, summed_view_mse
+from .train_step import (ExponentialLR, PixelSampler, random_sample_coords, _upload, choice_without_replacement, gather_view_pixels,
+                         make_adam, summed_view_mse)
 from .transmodel import ParticleNet
 
 to8b = lambda x: (255 * np.clip(x, 0, 1)).astype(np.uint8)   # noqa: E731  trainer/basetrainer.py:16
@@ -146,7 +147,7 @@ class BaseTrainer:
     def sample_pixels(self, rays_hw6, rgbs, H, W, global_step, ray_chunk, sel=None):
         coords = self.random_sample_coords(H, W, global_step)
         if sel is None:
-            sel = np.random.choice(coords.shape[0], size=[ray_chunk], replace=False)
+            sel = choice_without_replacement(np.random, coords.shape[0], ray_chunk)
         sc = _upload(coords[sel].long(), rays_hw6.device)
         return rays_hw6[sc[:, 0], sc[:, 1]], rgbs.view(H, W, -1)[sc[:, 0], sc[:, 1]]
 
@@ -199,6 +200,22 @@ class BaseTrainer:
             else:
                 out[k] = v.to(self.device) if isinstance(v, torch.Tensor) else v
         return out
+
+    def _frame_on_device(self, dataset, index, budget_bytes=16 << 30):
+        """dataset[index] on the device, kept there: the end-to-end loop walks the same frames every epoch (their rays and
+        images are 11.5 MB per view and frame: 0.5 ms of pageable upload per step, during which the GPU idles).  Datasets
+        whose items are not deterministic (ParticleDataset random_rot) must not come through here."""
+        cache = self.__dict__.setdefault('_frames_dev', {'ds': None, 'items': {}, 'bytes': 0})
+        if cache['ds'] is not dataset:
+            cache.update(ds=dataset, items={}, bytes=0)
+        item = cache['items'].get(index)
+        if item is None:
+            item = self._to_dev(dataset[index])
+            size = sum(v.numel() * v.element_size() for v in item.values() if isinstance(v, torch.Tensor))
+            if cache['bytes'] + size <= budget_bytes:
+                cache['items'][index] = item
+                cache['bytes'] += size
+        return item
 
     def _dataset(self, node_key, views, split, imgnode):
         o = self.options
@@ -266,7 +283,7 @@ class RendererTrainer(BaseTrainer):
         rc = self.options.RENDERER.ray.ray_chunk
         coords = self.random_sample_coords(H, W, step_idx)
         sels = self._sampler.next(step_idx) if getattr(self, '_sampler', None) is not None else \
-            [np.random.choice(coords.shape[0], size=[rc], replace=False) for _ in range(view_num)]
+            [choice_without_replacement(np.random, coords.shape[0], rc) for _ in range(view_num)]
         # the views are rendered in ONE fused call (rays are independent; per-ray camera position), their pixels gathered
         # with one upload and one index_select per tensor
         rays, rgbs, ro = gather_view_pixels([data['rays'][v] for v in range(view_num)], [data['rgb'][v] for v in range(view_num)],
@@ -379,7 +396,7 @@ class E2ETrainer(BaseTrainer):
         for _epoch in range(self.start_step, o.TRAIN.epochs):
             self.tmp_fluid_error = FluidErrors()
             for data_idx in range(len(self.dataset)):
-                data = self._to_dev(self.dataset[data_idx])
+                data = self._frame_on_device(self.dataset, data_idx)
                 loss = self.train_step(data, data_idx, len(self.train_view_names), H, W, global_step)
                 self.update_step(loss, global_step)
                 global_step += 1; done += 1
@@ -406,14 +423,24 @@ class E2ETrainer(BaseTrainer):
             d = self.tmp_fluid_error.cal_errors(pred_pos.detach(), data['particles_pos_1'], data_idx + 1)
             self.summary_writer.add_scalar('Train/pred2gt_distance', d, global_step)
         rc = self.options.RENDERER.ray.ray_chunk
-        total = 0.
-        for v in range(view_num):       # frame t+1 supervises the particles predicted from frame t (:224-227)
-            rays, rgbs = self.sample_pixels(data['rays_1'][v], data['rgb_1'][v], H, W, global_step, rc)
-            cw = data['cw_1'][v]
-            ret = self.render_image(pred_pos, rc, self.renderer.set_ro(cw), rays, data['focal'][v], cw)
-            l0 = self.rgb_criterion(ret['pred_rgbs_0'], rgbs)
-            loss = l0 + self.rgb_criterion(ret['pred_rgbs_1'], rgbs) if self.renderer.N_importance > 0 else l0
-            total = total + loss
+        # frame t+1 supervises the particles predicted from frame t (:224-227).  The views are drawn in the reference's
+        # order and rendered in ONE fused call (rays are independent; per-ray camera position), as in the warm-up trainer
+        coords = self.random_sample_coords(H, W, global_step)
+        sels = [choice_without_replacement(np.random, coords.shape[0], rc) for _ in range(view_num)]
+        rays, rgbs, ro = gather_view_pixels([data['rays_1'][v] for v in range(view_num)],
+                                            [data['rgb_1'][v] for v in range(view_num)],
+                                            [data['cw_1'][v] for v in range(view_num)], coords, sels, H, W)
+        out = self.renderer(pred_pos, ro, rays, None, None)
+        fine = self.renderer.N_importance > 0
+        if type(self.rgb_criterion) is torch.nn.MSELoss and self.rgb_criterion.reduction == 'mean':
+            total = summed_view_mse(out, rgbs, view_num, fine)
+        else:
+            total = 0.
+            for v in range(view_num):
+                sl = slice(v * rc, (v + 1) * rc)
+                total = total + self.rgb_criterion(out['rgb0'][sl], rgbs[sl])
+                if fine:
+                    total = total + self.rgb_criterion(out['rgb1'][sl], rgbs[sl])
         wb = self.options.TRAIN.loss_weight['boundary_loss']
         if wb != 0.:
             total = total + self.cal_boundary_loss(pred_pos) * wb

@@ -19,10 +19,10 @@ cfg.update(ds)
 for node in (cfg.TRAIN, cfg.TEST):
     node.imgW = node.imgH = 400
 cfg.TRAIN.save_interval = 10 ** 9
-cfg.TRAIN.epochs = 1
+cfg.TRAIN.epochs = 10
 tr = E2ETrainer(cfg)
 print("views", tr.train_view_names, "ray_chunk", cfg.RENDERER.ray.ray_chunk, "frames", len(tr.dataset))
-tr.train(max_steps=5)                      # warm-up
+tr.train(max_steps=len(tr.dataset))        # warm-up: one pass over every frame (the dataset caches decoded frames)
 torch.cuda.synchronize()
 tr.start_step = 0
 t0 = time.time()

@@ -25,15 +25,13 @@ def _upload(t, device):
     t = t.contiguous()
     n = t.numel()
     cap = 1 << max(10, (n - 1).bit_length())
-    ring = _STAGE.setdefault((t.dtype, cap), {"i": 0, "slots": []})
-    if len(ring["slots"]) < 4:
-        ring["slots"].append([torch.empty(cap, dtype=t.dtype).pin_memory(), None])
-        slot = ring["slots"][-1]
-    else:
-        slot = ring["slots"][ring["i"] % 4]
-        ring["i"] += 1
-        if slot[1] is not None:
-            slot[1].synchronize()
+    ring = _STAGE.get((t.dtype, cap))
+    if ring is None:        # page-lock all four slots at once (each hipHostMalloc stalls the device: not one per early step)
+        ring = _STAGE[(t.dtype, cap)] = {"i": 0, "slots": [[torch.empty(cap, dtype=t.dtype).pin_memory(), None] for _ in range(4)]}
+    slot = ring["slots"][ring["i"] % 4]
+    ring["i"] += 1
+    if slot[1] is not None:
+        slot[1].synchronize()
     buf = slot[0][:n].view(t.shape)
     buf.copy_(t)
     out = buf.to(device, non_blocking=True)

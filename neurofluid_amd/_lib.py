@@ -76,18 +76,15 @@ PROTOTYPES = {
                                c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "nf_host_choice_mt19937": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "nf_cconv_transform": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "nf_cconv_gather": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                                c_void_p, c_void_p]),
-    "nf_cconv_gather_update": (c_int, [c_void_p] * 7 + [c_int, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_int64, c_int64,
-                                      c_void_p, c_void_p, c_void_p]),
+    "nf_cconv_gather": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_int, c_void_p, c_void_p]),
+    "nf_cconv_gather_update": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                       c_void_p, c_void_p, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nf_trans_prepare_limits": (c_int, [ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "nf_trans_prepare": (c_int, [c_void_p, c_void_p, ctypes.POINTER(c_float), c_float, c_int, c_float, ctypes.POINTER(c_float), c_void_p,
                                 c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "nf_trans_count_workspace_bytes": (c_size_t, [c_int]),
-    "nf_trans_count": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
-                              c_void_p]),
-    "nf_trans_fill": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_int, c_void_p, c_int64, c_int64] + [c_void_p] * 9),
-    "nf_trans_conv0": (c_int, [c_void_p, c_void_p, c_void_p, c_int] + [c_void_p] * 14),
+    "nf_trans_search": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_int, c_int, c_int] + [c_void_p] * 11),
+    "nf_trans_conv0": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 14),
 }
 
 _lib = None

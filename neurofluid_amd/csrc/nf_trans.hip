@@ -1,20 +1,20 @@
 // nf_trans.hip — fused front half of the transition step (ParticleNet.forward, models/transmodel.py:151-163) for the
-// inference path: 4 launches where round 1 used ~20.
+// inference path: 3 launches where round 1 used ~20.
 //
 //   nf_trans_prepare   ONE workgroup: gravity integration (B1, :100-104) + the fluid cell grid of the integrated
 //                      positions (counting sort in LDS, stable in original index) — replaces k_trans_integrate and the
 //                      six k_grid_* / scan launches of nf_grid_build(with_firstk_lists = 0)
-//   nf_trans_count     fluid->fluid and box->fluid neighbour counts in one launch (blockIdx.y picks the grid); the last
-//                      workgroup to finish scans both count arrays (row_splits, totals, per-particle fluid-neighbour
-//                      count B6) — replaces 2 count launches + 2 scans + the ATen diff
-//   nf_trans_fill      both CSR fills in one launch, and the per-pair interpolation data (ball->cube map, trilinear
-//                      cells / weights, poly6 window; B3) computed right where the hit is found — replaces 2 fills +
-//                      2 k_pair_precompute
+//   nf_trans_search    fluid->fluid and box->fluid fixed-radius search in ONE sweep per (particle, grid) (blockIdx.y picks
+//                      the grid): neighbour index, squared distance and the per-pair interpolation data (ball->cube map,
+//                      trilinear cells / weights, poly6 window; B3) are written where the hit is found, into rows of a
+//                      fixed pitch; the per-particle counts (B6) fall out of the same sweep — replaces 2 counts + 2
+//                      scans + 2 fills + 2 k_pair_precompute + the ATen diff
 //   nf_trans_conv0     conv0_obstacle + conv0_fluid + dense0_fluid in one launch (both 64-cell filters in LDS) —
 //                      replaces 2 k_cconv_small
-// The CSR buffers are sized by CAPACITIES (pairs per particle): no host round trip anywhere in the step.  The true pair
-// totals are left on the device; the last kernel of the step (nf_cconv_gather's update epilogue) poisons its outputs
-// with NaN when a total exceeds its capacity, and the host checks the totals of step t while step t+1 is in flight.
+// Neighbour rows have a fixed PITCH (capacity per particle): no offsets to compute, no host round trip anywhere in the
+// step.  The true counts stay on the device; the last kernel of the step (nf_cconv_gather_update) turns the outputs of a
+// particle whose count exceeds its pitch into NaN and records the count, and the host checks that record of step t
+// while later steps are in flight.
 #include "nf_common.h"
 #include <math.h>
 
@@ -184,7 +184,6 @@ struct TrSearch {
 };
 
 #define TR_QPB 4
-template <bool FILL>
 __device__ __forceinline__ int tr_sweep(const NfGridView& g, float qx, float qy, float qz, float r2, int lane, int64_t o,
                                         int64_t cap, float extent, int use_window, int32_t* __restrict__ idx,
                                         float* __restrict__ dist2, float* __restrict__ pw, uint8_t* __restrict__ pc)
@@ -210,7 +209,7 @@ __device__ __forceinline__ int tr_sweep(const NfGridView& g, float qx, float qy,
                     hit = d2 <= r2 && !(p.x == qx && p.y == qy && p.z == qz);      // radius_search_ignore_query_points=True
                 }
                 const unsigned long long m = __ballot(hit);
-                if (FILL && hit) {
+                if (hit) {
                     const int64_t w = o + cnt + __popcll(m & lt);
                     if (w < cap) {
                         idx[w] = __float_as_int(p.w);
@@ -249,118 +248,46 @@ __device__ __forceinline__ int tr_sweep(const NfGridView& g, float qx, float qy,
     return cnt;
 }
 
-// counts[2][n]; the last workgroup scans them: row_splits[2][n+1] (clamped to the capacities), totals[2] (true sums),
-// num_fluid_nbrs[n] = fluid count as float (reduce_subarrays_sum of ones, models/transmodel.py:135-138)
-// 16 queries (waves) per workgroup: every workgroup arrives once on ONE device-scope counter (~12 ns per arrival, serialised:
-// 2 458 workgroups of 4 waves spent 30 us there; 616 of 16 waves spend 7)
-#define TC_QPB 16
-__global__ void __launch_bounds__(64 * TC_QPB) k_trans_count(TrSearch S, int* __restrict__ counts, unsigned* __restrict__ done,
-                                                             int64_t* __restrict__ row_splits, int64_t* __restrict__ totals,
-                                                             int64_t cap_f, int64_t cap_b, float* __restrict__ num_nbrs)
-{
-    const int lane = threadIdx.x & 63, which = blockIdx.y;
-    const int i = blockIdx.x * TC_QPB + (threadIdx.x >> 6);
-    if (i < S.n) {
-        NfGridView g = nf_grid_view(S.grid[which]);
-        const int cnt = tr_sweep<false>(g, S.q[3 * i], S.q[3 * i + 1], S.q[3 * i + 2], S.r2, lane, 0, 0, 1.f, 0, nullptr, nullptr,
-                                        nullptr, nullptr);
-        // write-through (sc1) store: the scanning workgroup may sit on another XCD, whose L2 is not coherent with this one
-        if (lane == 0) __hip_atomic_store(counts + which * S.n + i, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    // ---- last workgroup done: scan.  Hand-off = {sc1 payload stores, drained, then the device-scope arrival atomic} on the
-    // producer side and sc1 loads on the consumer side (MI355X_MICROARCH.md, inter-workgroup visibility: no L2 write-back
-    // fence per workgroup, which would cost microseconds in each of the ~2 500 workgroups)
-    __shared__ unsigned s_last;
-    __shared__ int64_t s_wsum[TC_QPB];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned total_blocks = gridDim.x * gridDim.y;
-        s_last = (atomicAdd(done, 1u) == total_blocks - 1u) ? 1u : 0u;
-        if (s_last) *done = 0u;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    const int T = 64 * TC_QPB;
-    const int wv = threadIdx.x >> 6;
-    for (int w2 = 0; w2 < 2; ++w2) {
-        const int* cn = counts + w2 * S.n;
-        int64_t* rs = row_splits + (size_t)w2 * (S.n + 1);
-        const int64_t cap = w2 ? cap_b : cap_f;
-        int64_t carry = 0;
-        for (int base_i = 0; base_i < S.n; base_i += T) {
-            const int t = base_i + threadIdx.x;
-            const int c = t < S.n ? __hip_atomic_load(cn + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-            int x = c;       // inclusive wave scan
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
-            if (lane == 63) s_wsum[wv] = x;
-            __syncthreads();
-            int64_t before = carry;
-            int64_t chunk = 0;
-#pragma unroll
-            for (int k = 0; k < TC_QPB; ++k) { if (k < wv) before += s_wsum[k]; chunk += s_wsum[k]; }
-            if (t < S.n) {
-                const int64_t ex = before + x - c;
-                rs[t] = ex < cap ? ex : cap;
-                if (w2 == 0) num_nbrs[t] = (float)c;
-            }
-            carry += chunk;
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) { rs[S.n] = carry < cap ? carry : cap; totals[w2] = carry; }
-    }
-}
-
-__global__ void __launch_bounds__(64 * TR_QPB) k_trans_fill(TrSearch S, const int64_t* __restrict__ row_splits, int64_t cap_f,
-                                                            int64_t cap_b, float extent, int use_window,
-                                                            int32_t* __restrict__ idx_f, float* __restrict__ d2_f,
-                                                            float* __restrict__ pw_f, uint8_t* __restrict__ pc_f,
-                                                            int32_t* __restrict__ idx_b, float* __restrict__ d2_b,
-                                                            float* __restrict__ pw_b, uint8_t* __restrict__ pc_b)
+// ONE sweep per (query, grid): the neighbours are found, counted and written with their interpolation data in the same pass.
+// Rows live at a fixed PITCH (row i of grid w starts at i * pitch_w: `max_fluid_neighbors` / `max_box_neighbors` per
+// particle), so no offsets have to be known before the fill — the count kernel, its scan by the last workgroup and the
+// second sweep of the former count + fill pair are gone (31 + 21 us -> one launch).  counts2[w][i] is the TRUE
+// neighbour count (consumers clamp it to the pitch; a count above the pitch is an overflow that the last kernel of the step
+// turns into NaN outputs for that particle and reports through overflow2), num_nbrs[i] the fluid count as float
+// (reduce_subarrays_sum of ones, models/transmodel.py:135-138).
+__global__ void __launch_bounds__(64 * TR_QPB) k_trans_search(TrSearch S, int pitch_f, int pitch_b, float extent, int use_window,
+                                                              int32_t* __restrict__ counts2, float* __restrict__ num_nbrs,
+                                                              int32_t* __restrict__ idx_f, float* __restrict__ d2_f,
+                                                              float* __restrict__ pw_f, uint8_t* __restrict__ pc_f,
+                                                              int32_t* __restrict__ idx_b, float* __restrict__ d2_b,
+                                                              float* __restrict__ pw_b, uint8_t* __restrict__ pc_b)
 {
     const int lane = threadIdx.x & 63, which = blockIdx.y;
     const int i = blockIdx.x * TR_QPB + (threadIdx.x >> 6);
     if (i >= S.n) return;
-    const int64_t cap = which ? cap_b : cap_f;
-    const int64_t o = row_splits[(size_t)which * (S.n + 1) + i];
-    if (o >= cap) return;
+    const int pitch = which ? pitch_b : pitch_f;
+    const int64_t o = (int64_t)i * pitch;
     NfGridView g = nf_grid_view(S.grid[which]);
-    tr_sweep<true>(g, S.q[3 * i], S.q[3 * i + 1], S.q[3 * i + 2], S.r2, lane, o, cap, extent, use_window, which ? idx_b : idx_f,
-                   which ? d2_b : d2_f, which ? pw_b : pw_f, which ? pc_b : pc_f);
+    const int cnt = tr_sweep(g, S.q[3 * i], S.q[3 * i + 1], S.q[3 * i + 2], S.r2, lane, o, o + pitch, extent, use_window,
+                             which ? idx_b : idx_f, which ? d2_b : d2_f, which ? pw_b : pw_f, which ? pc_b : pc_f);
+    if (lane == 0) {
+        counts2[(size_t)which * S.n + i] = cnt;
+        if (!which) num_nbrs[i] = (float)cnt;
+    }
 }
 
-extern "C" size_t nf_trans_count_workspace_bytes(int n) { return sizeof(int) * 2 * (size_t)(n > 0 ? n : 1) + 256; }
-
-extern "C" int nf_trans_count(const void* fluid_grid, const void* box_grid, const float* queries, int n, float radius,
-                              int64_t cap_fluid, int64_t cap_box, void* workspace, int64_t* row_splits2, int64_t* totals2,
-                              float* num_fluid_nbrs, nf_stream_t stream)
+extern "C" int nf_trans_search(const void* fluid_grid, const void* box_grid, const float* queries, int n, float radius, float extent,
+                               int use_window, int pitch_fluid, int pitch_box, int32_t* counts2, float* num_fluid_nbrs,
+                               int32_t* idx_f, float* d2_f, float* pw_f, uint8_t* pc_f, int32_t* idx_b, float* d2_b, float* pw_b,
+                               uint8_t* pc_b, nf_stream_t stream)
 {
-    NF_CHECK_ARG(fluid_grid && box_grid && queries && workspace && row_splits2 && totals2 && num_fluid_nbrs, "null pointer");
-    NF_CHECK_ARG(n > 0 && radius > 0.f, "bad n/radius");
+    NF_CHECK_ARG(fluid_grid && box_grid && queries && counts2 && num_fluid_nbrs && idx_f && d2_f && pw_f && pc_f && idx_b && d2_b &&
+                 pw_b && pc_b, "null pointer");
+    NF_CHECK_ARG(n > 0 && radius > 0.f && extent > 0.f && pitch_fluid >= 1 && pitch_box >= 1, "bad n/radius/extent/pitch");
     TrSearch S;
     S.grid[0] = fluid_grid; S.grid[1] = box_grid; S.q = queries; S.n = n; S.r2 = radius * radius;
-    // workspace: [done counter (256 B, zero between calls: the last block resets it)][counts 2 x n]
-    unsigned* done = (unsigned*)workspace;
-    int* counts = (int*)((char*)workspace + 256);
-    hipLaunchKernelGGL(k_trans_count, dim3((n + TC_QPB - 1) / TC_QPB, 2), dim3(64 * TC_QPB), 0, (hipStream_t)stream, S, counts, done,
-                       row_splits2, totals2, cap_fluid, cap_box, num_fluid_nbrs);
-    NF_CHECK_LAUNCH();
-    return NF_OK;
-}
-
-extern "C" int nf_trans_fill(const void* fluid_grid, const void* box_grid, const float* queries, int n, float radius, float extent,
-                             int use_window, const int64_t* row_splits2, int64_t cap_fluid, int64_t cap_box, int32_t* idx_f,
-                             float* d2_f, float* pw_f, uint8_t* pc_f, int32_t* idx_b, float* d2_b, float* pw_b, uint8_t* pc_b,
-                             nf_stream_t stream)
-{
-    NF_CHECK_ARG(fluid_grid && box_grid && queries && row_splits2 && idx_f && d2_f && pw_f && pc_f && idx_b && d2_b && pw_b && pc_b,
-                 "null pointer");
-    NF_CHECK_ARG(n > 0 && radius > 0.f && extent > 0.f, "bad n/radius/extent");
-    TrSearch S;
-    S.grid[0] = fluid_grid; S.grid[1] = box_grid; S.q = queries; S.n = n; S.r2 = radius * radius;
-    hipLaunchKernelGGL(k_trans_fill, dim3((n + TR_QPB - 1) / TR_QPB, 2), dim3(64 * TR_QPB), 0, (hipStream_t)stream, S, row_splits2,
-                       cap_fluid, cap_box, extent, use_window, idx_f, d2_f, pw_f, pc_f, idx_b, d2_b, pw_b, pc_b);
+    hipLaunchKernelGGL(k_trans_search, dim3((n + TR_QPB - 1) / TR_QPB, 2), dim3(64 * TR_QPB), 0, (hipStream_t)stream, S, pitch_fluid,
+                       pitch_box, extent, use_window, counts2, num_fluid_nbrs, idx_f, d2_f, pw_f, pc_f, idx_b, d2_b, pw_b, pc_b);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }
@@ -371,12 +298,12 @@ extern "C" int nf_trans_fill(const void* fluid_grid, const void* box_grid, const
 // half-wave per pair, lane = output channel; the pair's 8 weights / 8 cells arrive as two 16-B and one 8-B load.
 // ------------------------------------------------------------------------------------------------
 template <int CIN>
-__device__ __forceinline__ float tr_conv_row(const float* __restrict__ Ks, const float* __restrict__ feats, const int64_t* __restrict__ rs,
+__device__ __forceinline__ float tr_conv_row(const float* __restrict__ Ks, const float* __restrict__ feats, int64_t begin, int count,
                                              const int32_t* __restrict__ nbr, const float* __restrict__ pw,
-                                             const uint8_t* __restrict__ pc, int row, int co, int half)
+                                             const uint8_t* __restrict__ pc, int co, int half)
 {
     float acc = 0.f;
-    for (int64_t p = rs[row] + half; p < rs[row + 1]; p += 2) {
+    for (int64_t p = begin + half; p < begin + count; p += 2) {
         const int j = nbr[p];
         float fj[CIN];
 #pragma unroll
@@ -398,7 +325,8 @@ __device__ __forceinline__ float tr_conv_row(const float* __restrict__ Ks, const
 }
 
 __global__ void __launch_bounds__(256) k_trans_conv0(const float* __restrict__ box_feats, const float* __restrict__ fluid_feats,
-                                                     const int64_t* __restrict__ rs2, int n, const int32_t* __restrict__ idx_f,
+                                                     const int32_t* __restrict__ counts2, int pitch_f, int pitch_b, int n,
+                                                     const int32_t* __restrict__ idx_f,
                                                      const float* __restrict__ pw_f, const uint8_t* __restrict__ pc_f,
                                                      const int32_t* __restrict__ idx_b, const float* __restrict__ pw_b,
                                                      const uint8_t* __restrict__ pc_b, const float* __restrict__ k_obst,
@@ -415,15 +343,13 @@ __global__ void __launch_bounds__(256) k_trans_conv0(const float* __restrict__ b
     for (int t = threadIdx.x; t < kn; t += 256) Ks[t] = ksrc[t];
     __syncthreads();
     const int lane = threadIdx.x & 63, co = lane & 31, half = lane >> 5;
-    const int64_t* rs_f = rs2;
-    const int64_t* rs_b = rs2 + (n + 1);
     for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < n; row += gridDim.x * 4) {
         float* o = out + (size_t)row * 96;
         if (!fluid) {
-            const float ao = tr_conv_row<3>(Ks, box_feats, rs_b, idx_b, pw_b, pc_b, row, co, half);
+            const float ao = tr_conv_row<3>(Ks, box_feats, (int64_t)row * pitch_b, min(counts2[n + row], pitch_b), idx_b, pw_b, pc_b, co, half);
             if (half == 0) o[co] = ao + b_obst[co];
         } else {
-            const float af = tr_conv_row<4>(Ks, fluid_feats, rs_f, idx_f, pw_f, pc_f, row, co, half);
+            const float af = tr_conv_row<4>(Ks, fluid_feats, (int64_t)row * pitch_f, min(counts2[row], pitch_f), idx_f, pw_f, pc_f, co, half);
             if (half == 0) o[32 + co] = af + b_fluid[co];
             else {
                 float s = dense_b[co];
@@ -435,18 +361,18 @@ __global__ void __launch_bounds__(256) k_trans_conv0(const float* __restrict__ b
     }
 }
 
-extern "C" int nf_trans_conv0(const float* box_feats, const float* fluid_feats, const int64_t* row_splits2, int n,
-                              const int32_t* idx_f, const float* pw_f, const uint8_t* pc_f, const int32_t* idx_b,
+extern "C" int nf_trans_conv0(const float* box_feats, const float* fluid_feats, const int32_t* counts2, int pitch_fluid,
+                              int pitch_box, int n, const int32_t* idx_f, const float* pw_f, const uint8_t* pc_f, const int32_t* idx_b,
                               const float* pw_b, const uint8_t* pc_b, const float* kernel_obstacle, const float* bias_obstacle,
                               const float* kernel_fluid, const float* bias_fluid, const float* dense_w, const float* dense_b,
                               float* out96, nf_stream_t stream)
 {
-    NF_CHECK_ARG(box_feats && fluid_feats && row_splits2 && idx_f && pw_f && pc_f && idx_b && pw_b && pc_b && kernel_obstacle &&
+    NF_CHECK_ARG(box_feats && fluid_feats && counts2 && idx_f && pw_f && pc_f && idx_b && pw_b && pc_b && kernel_obstacle &&
                  bias_obstacle && kernel_fluid && bias_fluid && dense_w && dense_b && out96, "null pointer");
     if (n <= 0) return NF_OK;
     int blocks = (n + 3) / 4;
     if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(k_trans_conv0, dim3(blocks, 2), dim3(256), 0, (hipStream_t)stream, box_feats, fluid_feats, row_splits2, n, idx_f,
+    hipLaunchKernelGGL(k_trans_conv0, dim3(blocks, 2), dim3(256), 0, (hipStream_t)stream, box_feats, fluid_feats, counts2, pitch_fluid, pitch_box, n, idx_f,
                        pw_f, pc_f, idx_b, pw_b, pc_b, kernel_obstacle, bias_obstacle, kernel_fluid, bias_fluid, dense_w, dense_b,
                        out96);
     NF_CHECK_LAUNCH();

@@ -100,9 +100,32 @@ def cconv_layer(x, kernel, bias, dense_w, dense_b, row_splits, nbr, pw, pc, relu
     check(lib.nf_cconv_transform(ptr(x), M, cin, cout, int(relu), ptr(kernel.detach().contiguous()),
                                  ptr(dense_w.detach().contiguous()), ptr(G), st), "nf_cconv_transform")
     y = torch.empty(n_out, cout, dtype=torch.float32, device=x.device)
-    check(lib.nf_cconv_gather(ptr(G), cout, ptr(row_splits), ptr(nbr), ptr(pw), ptr(pc), ptr(bias.detach().contiguous()),
+    check(lib.nf_cconv_gather(ptr(G), cout, ptr(row_splits), 0, None, ptr(nbr), ptr(pw), ptr(pc), ptr(bias.detach().contiguous()),
                               ptr(dense_b.detach().contiguous()), ptr(residual), n_out, ptr(y), st), "nf_cconv_gather")
     return y
+
+
+class _PitchedNeighbors:
+    """`conv.nns` of the fused inference step: the neighbour rows live at a fixed pitch on the device; the CSR view the
+    Open3D attribute names promise (neighbors_index / neighbors_row_splits / neighbors_distance) is built on first access."""
+
+    def __init__(self, idx, d2, counts, pitch):
+        self._idx, self._d2, self._counts, self._pitch, self._csr = idx, d2, counts, pitch, None
+
+    def _build(self):
+        if self._csr is None:
+            c = self._counts.clamp(max=self._pitch).long()
+            rs = torch.zeros(c.numel() + 1, dtype=torch.int64, device=c.device)
+            rs[1:] = torch.cumsum(c, 0)
+            n = c.numel()
+            slot = torch.arange(self._pitch, device=c.device).unsqueeze(0).expand(n, -1)
+            keep = (slot < c.unsqueeze(1)).reshape(-1)
+            self._csr = (self._idx[:n * self._pitch][keep], rs, self._d2[:n * self._pitch][keep])
+        return self._csr
+
+    neighbors_index = property(lambda self: self._build()[0])
+    neighbors_row_splits = property(lambda self: self._build()[1])
+    neighbors_distance = property(lambda self: self._build()[2])
 
 
 class ParticleNet(nn.Module):
@@ -202,11 +225,12 @@ class ParticleNet(nn.Module):
             return self._forward_impl(pos, vel, box, box_feats)[:3]
 
     # ------------------------------------------------------------------
-    # Fused inference step: 10 launches, no host round trip.  prepare (integrate + fluid grid, one
-    # workgroup) -> count + scan (fluid and box in one launch) -> fill + pair interpolation data -> conv0 (obstacle +
-    # fluid + dense) -> 3 x (transform GEMM, gather), the last gather with the position / velocity update fused.
-    # CSR buffers are sized by capacities; an overflow poisons the outputs with NaN on the device and raises at the next
-    # call that finds the (asynchronously copied) pair totals.
+    # Fused inference step: 9 launches, no host round trip.  prepare (integrate + fluid grid, one
+    # workgroup) -> search (fluid and box neighbours + pair interpolation data in one sweep) -> conv0 (obstacle + fluid +
+    # dense) -> 3 x (transform GEMM, gather), the last gather with the position / velocity update fused.
+    # Neighbour rows have a fixed pitch (max_fluid_neighbors / max_box_neighbors per particle); a particle with more
+    # neighbours gets NaN outputs on the device and the next call that finds the (asynchronously copied) overflow record
+    # raises.
     def _fused_ok(self, pos, box):
         lib = _lib.load()
         if getattr(self, "_fused_limits", None) is None:
@@ -231,13 +255,13 @@ class ParticleNet(nn.Module):
         lib = _lib.load()
         radius = 0.5 * float(self.filter_extent)
         bb = (ctypes.c_float * 6)(*[float(v) for v in bbox])
-        cap_f, cap_b = n * self.max_fluid_neighbors, n * self.max_box_neighbors
+        pitch_f, pitch_b = int(self.max_fluid_neighbors), int(self.max_box_neighbors)
+        cap_f, cap_b = n * pitch_f, n * pitch_b
         f32, i32, i64, u8 = torch.float32, torch.int32, torch.int64, torch.uint8
         E = lambda *shape, dtype=f32: torch.empty(*shape, dtype=dtype, device=dev)      # noqa: E731
-        st = dict(key=key, bb=bb, cap=(cap_f, cap_b),
+        st = dict(key=key, bb=bb, pitch=(pitch_f, pitch_b),
                   grid_ws=E(lib.nf_grid_workspace_bytes(n, radius, bb), dtype=u8), pos_new=E(n, 3), vel_new=E(n, 3), feats=E(n, 4),
-                  count_ws=torch.zeros(lib.nf_trans_count_workspace_bytes(n), dtype=u8, device=dev),
-                  rs2=E(2 * (n + 1), dtype=i64), totals=torch.zeros(2, dtype=i64, device=dev),
+                  counts2=E(2 * n, dtype=i32), overflow=torch.zeros(2, dtype=i64, device=dev),
                   idx_f=E(cap_f, dtype=i32), d2_f=E(cap_f), pw_f=E(cap_f * 8), pc_f=E(cap_f * 8, dtype=u8),
                   idx_b=E(cap_b, dtype=i32), d2_b=E(cap_b), pw_b=E(cap_b * 8), pc_b=E(cap_b * 8, dtype=u8),
                   a0=E(n, 96), a1=E(n, 64), a2=E(n, 64), y3=E(n, 3), G=E(n * 65 * 64),
@@ -246,8 +270,8 @@ class ParticleNet(nn.Module):
         return st
 
     def check_capacity(self, wait=False):
-        """Raises if a finished fused step overflowed its pair capacities (its outputs were poisoned with NaN on the device).
-        wait=True blocks until every launched step has reported."""
+        """Raises if a particle of a finished fused step had more neighbours than its row pitch (its outputs were set to NaN
+        on the device).  wait=True blocks until every launched step has reported."""
         st = self._fused
         if st is None:
             return
@@ -257,10 +281,12 @@ class ParticleNet(nn.Module):
                 ev.synchronize()
             if ev.query():
                 f, b = slot.tolist()
-                if f > st["cap"][0] or b > st["cap"][1]:
+                if f > st["pitch"][0] or b > st["pitch"][1]:
                     st["pending"] = []
-                    raise RuntimeError(f"ParticleNet fused step: {f} fluid / {b} box pairs exceed the capacities {st['cap']} "
-                                       "(outputs of that step are NaN); raise ParticleNet.max_fluid_neighbors / max_box_neighbors")
+                    st["overflow"].zero_()
+                    raise RuntimeError(f"ParticleNet fused step: a particle with {f} fluid / {b} box neighbours (0 = within "
+                                       f"bounds) exceeds the capacities {st['pitch']} per particle (its outputs are NaN); raise "
+                                       "ParticleNet.max_fluid_neighbors / max_box_neighbors")
             else:
                 keep.append((ev, slot))
         st["pending"] = keep
@@ -281,24 +307,23 @@ class ParticleNet(nn.Module):
         if len(st["pending"]) >= len(st["slots"]):          # every report slot in flight: wait for the oldest
             st["pending"][0][0].synchronize()
             self.check_capacity()
-        cap_f, cap_b = st["cap"]
+        pitch_f, pitch_b = st["pitch"]
         bgrid = self._box_grid(box)
         g = (ctypes.c_float * 3)(*[float(v) for v in self._gravity_host()])
         check(lib.nf_trans_prepare(ptr(pos), ptr(vel), g, float(self.time_step), n, radius, st["bb"], ptr(st["grid_ws"]),
                                    st["grid_ws"].numel(), ptr(st["pos_new"]), ptr(st["vel_new"]), ptr(st["feats"]), stream),
               "nf_trans_prepare")
         nn = torch.empty(n, dtype=torch.float32, device=dev)
-        check(lib.nf_trans_count(ptr(st["grid_ws"]), ptr(bgrid.ws), ptr(st["pos_new"]), n, radius, cap_f, cap_b, ptr(st["count_ws"]),
-                                 ptr(st["rs2"]), ptr(st["totals"]), ptr(nn), stream), "nf_trans_count")
-        check(lib.nf_trans_fill(ptr(st["grid_ws"]), ptr(bgrid.ws), ptr(st["pos_new"]), n, radius, extent, int(self.use_window),
-                                ptr(st["rs2"]), cap_f, cap_b, ptr(st["idx_f"]), ptr(st["d2_f"]), ptr(st["pw_f"]), ptr(st["pc_f"]),
-                                ptr(st["idx_b"]), ptr(st["d2_b"]), ptr(st["pw_b"]), ptr(st["pc_b"]), stream), "nf_trans_fill")
+        check(lib.nf_trans_search(ptr(st["grid_ws"]), ptr(bgrid.ws), ptr(st["pos_new"]), n, radius, extent, int(self.use_window),
+                                  pitch_f, pitch_b, ptr(st["counts2"]), ptr(nn), ptr(st["idx_f"]), ptr(st["d2_f"]), ptr(st["pw_f"]),
+                                  ptr(st["pc_f"]), ptr(st["idx_b"]), ptr(st["d2_b"]), ptr(st["pw_b"]), ptr(st["pc_b"]), stream),
+              "nf_trans_search")
         c0o, c0f, d0 = self.conv0_obstacle, self.conv0_fluid, self.dense0_fluid
-        check(lib.nf_trans_conv0(ptr(box_feats), ptr(st["feats"]), ptr(st["rs2"]), n, ptr(st["idx_f"]), ptr(st["pw_f"]), ptr(st["pc_f"]),
-                                 ptr(st["idx_b"]), ptr(st["pw_b"]), ptr(st["pc_b"]), ptr(c0o.kernel.detach()), ptr(c0o.bias.detach()),
-                                 ptr(c0f.kernel.detach()), ptr(c0f.bias.detach()), ptr(d0.weight.detach()), ptr(d0.bias.detach()),
-                                 ptr(st["a0"]), stream), "nf_trans_conv0")
-        f_rs = st["rs2"][:n + 1]
+        check(lib.nf_trans_conv0(ptr(box_feats), ptr(st["feats"]), ptr(st["counts2"]), pitch_f, pitch_b, n, ptr(st["idx_f"]),
+                                 ptr(st["pw_f"]), ptr(st["pc_f"]), ptr(st["idx_b"]), ptr(st["pw_b"]), ptr(st["pc_b"]),
+                                 ptr(c0o.kernel.detach()), ptr(c0o.bias.detach()), ptr(c0f.kernel.detach()), ptr(c0f.bias.detach()),
+                                 ptr(d0.weight.detach()), ptr(d0.bias.detach()), ptr(st["a0"]), stream), "nf_trans_conv0")
+        cnt_f, cnt_b = st["counts2"][:n], st["counts2"][n:]
         prev = st["a0"]
         outs = [st["a1"], st["a2"], st["y3"]]
         pos_c, vel_c = torch.empty_like(pos), torch.empty_like(pos)
@@ -309,25 +334,25 @@ class ParticleNet(nn.Module):
             y = outs[li]
             if li < 2:
                 res = prev if dense.out_features == cin else None
-                check(lib.nf_cconv_gather(ptr(st["G"]), cout, ptr(f_rs), ptr(st["idx_f"]), ptr(st["pw_f"]), ptr(st["pc_f"]),
-                                          ptr(conv.bias.detach()), ptr(dense.bias.detach()), ptr(res), n, ptr(y), stream),
-                      "nf_cconv_gather")
+                check(lib.nf_cconv_gather(ptr(st["G"]), cout, None, pitch_f, ptr(cnt_f), ptr(st["idx_f"]), ptr(st["pw_f"]),
+                                          ptr(st["pc_f"]), ptr(conv.bias.detach()), ptr(dense.bias.detach()), ptr(res), n, ptr(y),
+                                          stream), "nf_cconv_gather")
             else:
-                check(lib.nf_cconv_gather_update(ptr(st["G"]), ptr(f_rs), ptr(st["idx_f"]), ptr(st["pw_f"]), ptr(st["pc_f"]),
+                check(lib.nf_cconv_gather_update(ptr(st["G"]), pitch_f, ptr(cnt_f), ptr(st["idx_f"]), ptr(st["pw_f"]), ptr(st["pc_f"]),
                                                  ptr(conv.bias.detach()), ptr(dense.bias.detach()), n, ptr(y), ptr(pos),
-                                                 ptr(st["pos_new"]), 1.0 / 128, float(self.time_step), ptr(st["totals"]), cap_f,
-                                                 cap_b, ptr(pos_c), ptr(vel_c), stream), "nf_cconv_gather_update")
+                                                 ptr(st["pos_new"]), 1.0 / 128, float(self.time_step), pitch_b, ptr(cnt_b),
+                                                 ptr(st["overflow"]), ptr(pos_c), ptr(vel_c), stream), "nf_cconv_gather_update")
             prev = y
-        # pair totals -> pinned host slot, checked by a later call (or check_capacity(wait=True))
+        # overflow record -> pinned host slot, checked by a later call (or check_capacity(wait=True))
         slot = st["slots"][st["step"] % len(st["slots"])]
         st["step"] += 1
-        slot.copy_(st["totals"], non_blocking=True)
+        slot.copy_(st["overflow"], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         st["pending"].append((ev, slot))
         self.num_fluid_neighbors = nn
         self._y3 = st["y3"]
-        self.conv0_fluid.nns = SimpleNamespace(neighbors_index=st["idx_f"], neighbors_row_splits=f_rs, neighbors_distance=st["d2_f"])
+        self.conv0_fluid.nns = _PitchedNeighbors(st["idx_f"], st["d2_f"], cnt_f, pitch_f)
         return pos_c, vel_c, nn
 
     # ------------------------------------------------------------------

@@ -354,10 +354,10 @@ def test_rollout_200_frames_honeycone(dev):
 
 
 def test_fused_inference_step_bit_equal(dev):
-    """The fused inference step (nf_trans.hip: prepare / count+scan / fill+pairs / conv0 in 4 launches, update fused into
-    the last gather, capacity-sized CSR, no host round trip) must reproduce the multi-launch path BIT FOR BIT over a
-    rollout (same kernels' arithmetic, same neighbour order), for the lattice cloud and a shuffled shaped one; a capacity
-    overflow poisons the outputs with NaN and raises at the next report."""
+    """The fused inference step (nf_trans.hip: prepare / search+pairs / conv0 in 3 launches, update fused into the last
+    gather, neighbour rows of a fixed pitch, no host round trip) must reproduce the multi-launch path BIT FOR BIT over a
+    rollout (same kernels' arithmetic, same neighbour order), for the lattice cloud and a shuffled shaped one; a particle
+    with more neighbours than the pitch gets NaN outputs and the next report raises."""
     from neurofluid_amd import synthetic
     from oracle import trans_oracle as to
     box, bn = [t.to(dev) for t in to.watercube_box()]
@@ -385,5 +385,5 @@ def test_fused_inference_step_bit_equal(dev):
     with torch.no_grad():
         a, b, _ = pc(P, torch.zeros_like(P), box, bn)
     assert bool(torch.isnan(a).all()) and bool(torch.isnan(b).all())
-    with pytest.raises(RuntimeError, match="exceed the capacities"):
+    with pytest.raises(RuntimeError, match="exceeds the capacities"):
         pc.check_capacity(wait=True)

@@ -297,29 +297,53 @@ extern "C" int nf_trans_search(const void* fluid_grid, const void* box_grid, con
 // (models/transmodel.py:116-120).  One wave per point; both 64-cell filters (3 x 32 and 4 x 32 per cell) in LDS; a
 // half-wave per pair, lane = output channel; the pair's 8 weights / 8 cells arrive as two 16-B and one 8-B load.
 // ------------------------------------------------------------------------------------------------
+// One row: the pair records (neighbour, 8 weights, 8 cells) and the neighbours' input features are staged through the wave's
+// LDS slice 64 pairs at a time (two dependent global round trips per 64 pairs instead of two per pair), then a half-wave
+// per pair, lane = output channel.  Measured alternatives that did NOT help (the kernel is bound by the 8 x Cin LDS reads +
+// FMAs per pair and lane, not by latency or staging): 16-B filter reads from a [cell][co][4] copy (34.5 us), 16-wave
+// workgroups staging both filters once per CU (42 us), fewer / more workgroups (33-60 us).
+struct TrStage {
+    float f[64][4];
+    float w[64][8];
+    uint2 c[64];
+};
+
 template <int CIN>
 __device__ __forceinline__ float tr_conv_row(const float* __restrict__ Ks, const float* __restrict__ feats, int64_t begin, int count,
                                              const int32_t* __restrict__ nbr, const float* __restrict__ pw,
-                                             const uint8_t* __restrict__ pc, int co, int half)
+                                             const uint8_t* __restrict__ pc, int co, int half, int lane, TrStage& st)
 {
     float acc = 0.f;
-    for (int64_t p = begin + half; p < begin + count; p += 2) {
-        const int j = nbr[p];
-        float fj[CIN];
+    for (int base = 0; base < count; base += 64) {
+        const int m = min(64, count - base);
+        if (lane < m) {
+            const int64_t p = begin + base + lane;
+            const int j = nbr[p];
+            const float4 w0 = *(const float4*)(pw + p * 8), w1 = *(const float4*)(pw + p * 8 + 4);
+            st.c[lane] = *(const uint2*)(pc + p * 8);
+            *(float4*)&st.w[lane][0] = w0;
+            *(float4*)&st.w[lane][4] = w1;
 #pragma unroll
-        for (int ci = 0; ci < CIN; ++ci) fj[ci] = feats[(size_t)j * CIN + ci];
-        const float4 w0 = *(const float4*)(pw + p * 8), w1 = *(const float4*)(pw + p * 8 + 4);
-        const uint2 cc = *(const uint2*)(pc + p * 8);
-        const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int cell = (int)(((k < 4 ? cc.x : cc.y) >> (8 * (k & 3))) & 0xffu);
-            const float* kc = Ks + cell * CIN * 32 + co;
-            float s = 0.f;
-#pragma unroll
-            for (int ci = 0; ci < CIN; ++ci) s += fj[ci] * kc[ci * 32];
-            acc += wv[k] * s;
+            for (int ci = 0; ci < CIN; ++ci) st.f[lane][ci] = feats[(size_t)j * CIN + ci];
         }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the staged records are visible wave-wide
+        for (int t = half; t < m; t += 2) {
+            float fj[CIN];
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) fj[ci] = st.f[t][ci];
+            const uint2 cc = st.c[t];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int cell = (int)(((k < 4 ? cc.x : cc.y) >> (8 * (k & 3))) & 0xffu);
+                const float* kc = Ks + cell * CIN * 32 + co;
+                float s = 0.f;
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) s += fj[ci] * kc[ci * 32];
+                acc += st.w[t][k] * s;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
     return acc + __shfl_xor(acc, 32, 64);
 }
@@ -337,6 +361,7 @@ __global__ void __launch_bounds__(256) k_trans_conv0(const float* __restrict__ b
     // blockIdx.y = 0: conv0_obstacle -> columns 0..31; 1: conv0_fluid -> 32..63 and dense0_fluid -> 64..95.  A workgroup
     // stages only its own filter (24 / 32 KB), so both halves keep the occupancy of the separate launches.
     __shared__ float Ks[64 * 4 * 32];
+    __shared__ TrStage stage[4];
     const bool fluid = blockIdx.y == 1;
     const float* ksrc = fluid ? k_fluid : k_obst;
     const int kn = fluid ? 64 * 4 * 32 : 64 * 3 * 32;
@@ -346,10 +371,10 @@ __global__ void __launch_bounds__(256) k_trans_conv0(const float* __restrict__ b
     for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < n; row += gridDim.x * 4) {
         float* o = out + (size_t)row * 96;
         if (!fluid) {
-            const float ao = tr_conv_row<3>(Ks, box_feats, (int64_t)row * pitch_b, min(counts2[n + row], pitch_b), idx_b, pw_b, pc_b, co, half);
+            const float ao = tr_conv_row<3>(Ks, box_feats, (int64_t)row * pitch_b, min(counts2[n + row], pitch_b), idx_b, pw_b, pc_b, co, half, lane, stage[threadIdx.x >> 6]);
             if (half == 0) o[co] = ao + b_obst[co];
         } else {
-            const float af = tr_conv_row<4>(Ks, fluid_feats, (int64_t)row * pitch_f, min(counts2[row], pitch_f), idx_f, pw_f, pc_f, co, half);
+            const float af = tr_conv_row<4>(Ks, fluid_feats, (int64_t)row * pitch_f, min(counts2[row], pitch_f), idx_f, pw_f, pc_f, co, half, lane, stage[threadIdx.x >> 6]);
             if (half == 0) o[32 + co] = af + b_fluid[co];
             else {
                 float s = dense_b[co];

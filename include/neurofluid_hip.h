@@ -326,6 +326,14 @@ int nf_cconv_small_bwd_feat(const float* kernel, int cin, const int64_t* row_spl
  * advances them; out[size] receives permutation(n)[:size].  1 <= n < 2^31. */
 int nf_host_choice_mt19937(uint32_t* key /*624, in/out*/, int* pos /*in/out*/, int64_t n, int64_t size, int64_t* out);
 
+/* SSIM of utils/evaluate_images.ipynb cell 5 (class SSIM): 11x11 gaussian window given as its 1-D
+ * factor window[11] (normalised), no padding, dynamic range L; pred / gt are B x C x H x W on the device, H, W >= 11.
+ * ssim_per_image[b] = mean over channels and valid positions (the notebook's size_average=False result; its default is the
+ * mean of these).  workspace: nf_image_ssim_workspace_floats floats. */
+size_t nf_image_ssim_workspace_floats(int B, int C, int H, int W);
+int nf_image_ssim(const float* pred, const float* gt, int B, int C, int H, int W, const float window[11], float L,
+                  float* workspace, float* ssim_per_image, nf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

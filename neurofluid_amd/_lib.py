@@ -74,6 +74,9 @@ PROTOTYPES = {
     "nf_cconv_small_bwd_feat": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "nf_cconv_small": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "nf_image_ssim_workspace_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "nf_image_ssim": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, ctypes.POINTER(c_float), c_float, c_void_p, c_void_p,
+                              c_void_p]),
     "nf_host_choice_mt19937": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "nf_cconv_transform": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nf_cconv_gather": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

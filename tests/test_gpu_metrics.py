@@ -1,0 +1,46 @@
+"""the SSIM kernel (csrc/nf_metrics.hip) and PSNR against the values the reference notebook returned
+(tests/golden/f4_ssim.npz) and against the CPU oracle on larger images."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def test_ssim_psnr_vs_reference_notebook_values(dev, golden):
+    from neurofluid_amd import metrics
+    g = golden("f4_ssim")
+    for c in "abcde":
+        p, t = torch.from_numpy(g[f"{c}_pred"]).to(dev), torch.from_numpy(g[f"{c}_gt"]).to(dev)
+        # fp32 tolerance: the kernel applies the window separably (22 taps) where conv2d sums 121 products
+        assert abs(float(metrics.ssim(p, t)) - float(g[f"{c}_ssim"])) <= 2e-6, c
+        per = metrics.ssim(p, t, size_average=False).cpu().numpy()
+        assert np.abs(per - g[f"{c}_ssim_per_image"]).max() <= 2e-6, c
+        assert abs(float(metrics.psnr(p, t)) - float(g[f"{c}_psnr"])) <= 1e-4, c
+
+
+def test_ssim_frame_sized_vs_oracle_and_properties(dev):
+    from neurofluid_amd import metrics
+    from oracle import metrics_oracle as mo
+    g = torch.Generator().manual_seed(3)
+    gt = torch.rand(2, 3, 400, 400, generator=g)
+    pred = (gt + 0.05 * torch.randn(2, 3, 400, 400, generator=g)).clamp(0, 1)
+    want = mo.ssim(pred, gt, size_average=False)
+    got = metrics.ssim(pred.to(dev), gt.to(dev), size_average=False).cpu()
+    assert (got - want).abs().max() <= 2e-6
+    # identical images: exactly 1 up to fp32 rounding of the variance terms; symmetric in its arguments
+    one = metrics.ssim(gt.to(dev), gt.to(dev))
+    assert abs(float(one) - 1.0) <= 1e-6
+    a, b = metrics.ssim(pred.to(dev), gt.to(dev)), metrics.ssim(gt.to(dev), pred.to(dev))
+    assert abs(float(a) - float(b)) <= 1e-6
+    with pytest.raises(RuntimeError):
+        metrics.ssim(pred, gt)                     # CPU tensors: no fallback
+    with pytest.raises(NotImplementedError):
+        metrics.ssim(pred.to(dev), gt.to(dev), w_size=7)

@@ -95,3 +95,16 @@ def test_b1_integrate(golden):
     assert torch.equal(p3, T(g["pos_corr"])) and torch.equal(v3, T(g["vel_corr"]))
     assert torch.equal(to.window_poly6(T(g["R"])), T(g["window"]))
     assert abs(to.FILTER_EXTENT - float(g["filter_extent"])) == 0
+
+
+def test_f4_image_metrics(golden):
+    """oracle/metrics_oracle.py against what the reference notebook's own SSIM / PSNR classes returned
+    (tests/golden/gen_golden_ssim.py executes utils/evaluate_images.ipynb cells 3-5): [0,1], 8-bit and tanh ranges, ragged
+    sizes, a single valid window position."""
+    from oracle import metrics_oracle as mo
+    g = golden("f4_ssim")
+    for c in "abcde":
+        p, t = T(g[f"{c}_pred"]), T(g[f"{c}_gt"])
+        assert float(mo.ssim(p, t)) == float(g[f"{c}_ssim"])
+        assert torch.equal(mo.ssim(p, t, size_average=False), T(g[f"{c}_ssim_per_image"]))
+        assert float(mo.psnr(p, t)) == float(g[f"{c}_psnr"])

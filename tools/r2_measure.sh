@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-2 measurement pass on the GPU box: gpu tests (full log), default bench line, strong-scaling control-flow runs
 # on one device (world 2/4/8 over gloo), kernel stats and PMC passes for the non-MLP kernels.
-# usage (from the repo root on the GPU box): bash tools/r2_measure.sh [tests] [bench] [strong] [pmc]
+# usage (from the repo root on the GPU box): bash tools/r2_measure.sh [tests] [bench] [strong] [pmc] [pmct] [pmcs] [pmch]
 set -u
 cd $GRAFT_REPO_ROOT
 O=gpurun_out
@@ -34,6 +34,14 @@ pmc)
   # the heavy csv files stay on the box; keep what the summariser needs (counter collections + stats) under 64 MiB
   find $O -name "*kernel_trace.csv" -path "*r2_pmc*" -delete
   du -sh $O/r2_* | tail -12 ;;
+pmct)
+  TS="python $GRAFT_REPO_ROOT/tools/train_hostprof.py"
+  bash tools/prof.sh r2_stats_train $TS > /dev/null
+  bash tools/pmc.sh r2_pmc_fetch_train "FETCH_SIZE" $TS > /dev/null
+  bash tools/pmc.sh r2_pmc_write_train "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" $TS > /dev/null
+  bash tools/pmc.sh r2_pmc_sq_train "SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU" $TS > /dev/null
+  find $O -name "*kernel_trace.csv" -path "*r2_pmc*" -delete
+  grep step $O/r2_stats_train/run.log ;;
 pmcs)
   MB="python $GRAFT_REPO_ROOT/tools/mlp_bench.py 3276800 3 split"
   bash tools/prof.sh r2_stats_mlps $MB > /dev/null

@@ -740,7 +740,7 @@ static NfWgradPlan wgrad_plan(int cx, int cd)
     }
     add(8 * 256, 0, 7 * 256, 256, 256, off, 256, 0); off += 256 * 256;                       // xyz_encoding_final
     add(9 * 256, 0, 8 * 256, 128, 256, off, 256 + cd, 0);                                    // dir_encoding: [final | dir]
-    add(9 * 256, 1, cx, 128, cd, off, 256 + cd, 256); off += 128 * (256 + cd);
+    add(9 * 256, 1, 8 * ((cx + 7) / 8), 128, cd, off, 256 + cd, 256); off += 128 * (256 + cd);   // dir features start at group qx
     add(2435, 0, 7 * 256, 1, 256, off, 256, 0); off += 256;                                  // sigma
     add(2432, 0, 9 * 256, 3, 128, off, 128, 0); off += 3 * 128;                              // rgb
     P.ngemm = n; P.ntiles = tiles; P.total = off;
@@ -762,8 +762,12 @@ __device__ __forceinline__ float4 wg_load4(const float* __restrict__ rowp, int c
     return v;
 }
 
+// B operands come from the saved activations (row-major, NF_ACT_STRIDE) or, for the three X-fed GEMMs (b_src = 1), straight
+// from the MLP's operand X in its tile layout [tile][q][h][j][4] (row = 32 tile + j, feature = 8 q + 4 h + c): a quad of 4
+// consecutive features of a row is one aligned 16-B load there, and the 32 rows of a slab are 512 contiguous bytes — the
+// row-major copy of X that round 1 made for this kernel (permute + cat: 0.6 ms of a 5.2 ms training step) is gone.
 __global__ void __launch_bounds__(256) k_wgrad(NfWgradPlan P, const float* __restrict__ dpre, const float* __restrict__ acts,
-                                               const float* __restrict__ xrow, int ld_x, int n_rows, int rows_per_slice,
+                                               const float* __restrict__ xtiles, int Q, int n_rows, int rows_per_slice,
                                                float* __restrict__ partial)
 {
     __shared__ float As[WG_KS][128 + 4];
@@ -775,14 +779,13 @@ __global__ void __launch_bounds__(256) k_wgrad(NfWgradPlan P, const float* __res
     const NfWgradGemm G = P.g[gi];
     const int t = blockIdx.x - G.tile0;
     const int m0 = (t / G.tiles_n) * 128, n0 = (t % G.tiles_n) * 128;
-    const float* Bsrc = G.b_src ? xrow : acts;
-    const int ldb = G.b_src ? ld_x : NF_ACT_STRIDE;
+    const int ldb = NF_ACT_STRIDE;
     const int r0 = blockIdx.y * rows_per_slice, r1 = min(n_rows, r0 + rows_per_slice);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     // 16-B loads need the first column of the tile and the row pitch to be multiples of 4 floats (all big GEMMs are;
     // the sigma / rgb rows and the dir-feature block of xrow start at odd columns and take the scalar path)
-    const bool va = ((G.a_col + m0) & 3) == 0, vb = ((G.b_col + n0) & 3) == 0 && (ldb & 3) == 0;
+    const bool va = ((G.a_col + m0) & 3) == 0, vb = ((G.b_col + n0) & 3) == 0;
     const int ma = G.M - m0, nb = G.N - n0;       // live columns of this tile
     f32x16 acc[2][2];
 #pragma unroll
@@ -801,7 +804,12 @@ __global__ void __launch_bounds__(256) k_wgrad(NfWgradPlan P, const float* __res
             ra[u] = rb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (row < r1) {
                 ra[u] = wg_load4(dpre + (size_t)row * NF_DPRE_STRIDE + G.a_col + m0, cq, ma, va);
-                rb[u] = wg_load4(Bsrc + (size_t)row * ldb + G.b_col + n0, cq, nb, vb);
+                if (G.b_src) {      // X tiles: columns beyond N hold other features / padding and are never stored
+                    const int f0 = G.b_col + n0 + cq;
+                    if (f0 < 8 * Q)
+                        rb[u] = *(const float4*)(xtiles + ((((size_t)(row >> 5) * Q + (f0 >> 3)) * 2 + ((f0 >> 2) & 1)) * 32 + (row & 31)) * 4);
+                } else
+                    rb[u] = wg_load4(acts + (size_t)row * ldb + G.b_col + n0, cq, nb, vb);
             }
         }
     };
@@ -851,10 +859,10 @@ __global__ void k_wgrad_reduce(const float* __restrict__ partial, int total, int
 
 extern "C" size_t nf_nerf_wgrad_workspace_floats(int cx, int cd, int nslices) { return (size_t)wgrad_plan(cx, cd).total * nslices; }
 
-extern "C" int nf_nerf_wgrad(const float* dpre, const float* acts, const float* xrow, int cx, int cd, int n_rows,
+extern "C" int nf_nerf_wgrad(const float* dpre, const float* acts, const float* X, int cx, int cd, int n_rows,
                              int nslices, float* workspace, float* dweights, nf_stream_t stream)
 {
-    NF_CHECK_ARG(dpre && acts && xrow && workspace && dweights, "null pointer");
+    NF_CHECK_ARG(dpre && acts && X && workspace && dweights, "null pointer");
     NF_CHECK_ARG(nslices >= 1 && nslices <= 65535, "bad slice count");
     NfWgradPlan P = wgrad_plan(cx, cd);
     hipStream_t st = (hipStream_t)stream;
@@ -865,7 +873,7 @@ extern "C" int nf_nerf_wgrad(const float* dpre, const float* acts, const float* 
     int rows_per = (n_rows + nslices - 1) / nslices;
     rows_per = (rows_per + WG_KS - 1) / WG_KS * WG_KS;
     int ns = (n_rows + rows_per - 1) / rows_per;
-    hipLaunchKernelGGL(k_wgrad, dim3(P.ntiles, ns), dim3(256), 0, st, P, dpre, acts, xrow, cx + cd, n_rows, rows_per, workspace);
+    hipLaunchKernelGGL(k_wgrad, dim3(P.ntiles, ns), dim3(256), 0, st, P, dpre, acts, X, (cx + 7) / 8 + (cd + 7) / 8, n_rows, rows_per, workspace);
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((P.total + 255) / 256), dim3(256), 0, st, (const float*)workspace, P.total, ns,
                        dweights);
     NF_CHECK_LAUNCH();

@@ -68,7 +68,7 @@ def _pass_backward(net, nerf, pb, rays_c, z, z_table, g_rgb, white_bg, particles
     check(lib.nf_nerf_mlp_bwd(ptr(pb.packed), ptr(packed_t), cx, cd, ptr(pb.acts), ptr(pb.n_rows), n, ptr(pb.row_sample),
                               ptr(pb.rgbsigma), ptr(d_rs), ptr(dpre_full), st), "nf_nerf_mlp_bwd")
     # weight gradients: one batched fp32-MFMA launch for all 15 GEMMs of the net (nf_nerf_wgrad)
-    nsl = 16
+    nsl = 16          # 46 tiles x 16 row slices = 736 workgroups (3 per CU); 11...44 slices measure the same
     blob = torch.empty(lib.nf_nerf_wgrad_floats(cx, cd), dtype=torch.float32, device=dev)
     wsp = torch.empty(lib.nf_nerf_wgrad_workspace_floats(cx, cd, nsl), dtype=torch.float32, device=dev)
     check(lib.nf_nerf_wgrad(ptr(dpre_full), ptr(pb.acts), ptr(pb.X), cx, cd, n, nsl, ptr(wsp), ptr(blob), st), "nf_nerf_wgrad")

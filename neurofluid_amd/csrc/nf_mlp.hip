@@ -823,15 +823,27 @@ __global__ void __launch_bounds__(256) k_wgrad(NfWgradPlan P, const float* __res
         }
         __syncthreads();
         if (k0 + WG_KS < r1) load_slab(k0 + WG_KS);      // next slab in flight behind the MFMAs
+        {   // fragments of K-step kk + 2 are read from LDS BEFORE the four MFMAs of step kk are issued (the compiler's own
+            // order was read, wait lgkmcnt(0), 4 MFMAs: every step exposed the LDS latency behind one MFMA)
+            const int c = lane & 31, h = lane >> 5;
+            float a0 = As[h][wm + c], a1 = As[h][wm + 32 + c], b0 = Bs[h][wn + c], b1 = Bs[h][wn + 32 + c];
 #pragma unroll
-        for (int kk = 0; kk < WG_KS; kk += 2) {
-            int kr = kk + (lane >> 5), c = lane & 31;
-            float a0 = As[kr][wm + c], a1 = As[kr][wm + 32 + c];
-            float b0 = Bs[kr][wn + c], b1 = Bs[kr][wn + 32 + c];
-            acc[0][0] = MFMA32(a0, b0, acc[0][0]);
-            acc[0][1] = MFMA32(a0, b1, acc[0][1]);
-            acc[1][0] = MFMA32(a1, b0, acc[1][0]);
-            acc[1][1] = MFMA32(a1, b1, acc[1][1]);
+            for (int kk = 0; kk < WG_KS; kk += 2) {
+                float a0n = a0, a1n = a1, b0n = b0, b1n = b1;
+                if (kk + 2 < WG_KS) {
+                    const int kr = kk + 2 + h;
+                    a0n = As[kr][wm + c]; a1n = As[kr][wm + 32 + c]; b0n = Bs[kr][wn + c]; b1n = Bs[kr][wn + 32 + c];
+                }
+                acc[0][0] = MFMA32(a0, b0, acc[0][0]);
+                acc[0][1] = MFMA32(a0, b1, acc[0][1]);
+                acc[1][0] = MFMA32(a1, b0, acc[1][0]);
+                acc[1][1] = MFMA32(a1, b1, acc[1][1]);
+                if (kk + 2 < WG_KS) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);      // DS reads of the next step first
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);      // then this step's MFMAs
+                }
+                a0 = a0n; a1 = a1n; b0 = b0n; b1 = b1n;
+            }
         }
         __syncthreads();
     }

@@ -774,6 +774,76 @@ __global__ void __launch_bounds__(64) k_composite_bwd(const float4* __restrict__
     }
 }
 
+// Small ray counts (the training steps: 1 024 - 4 096 rays): a thread per ray is a 2 x S chain of dependent, uncoalesced
+// global loads per thread and takes ~170 us however few rays there are (16 - 64 waves on the whole chip).  Here a WAVE owns a
+// ray: the elementwise parts (exp, alpha, dL/dw, the output rows) run on the 64 lanes with coalesced accesses, and only the
+// two recurrences — T_i (forward) and the suffix sum (reverse) — are walked by one lane over LDS, in the same order as above
+// (bit-identical results).  4 arrays of S floats per wave in LDS.
+__global__ void __launch_bounds__(256) k_composite_bwd_w(const float4* __restrict__ rgbsigma, const float* __restrict__ z,
+                                                         const float* __restrict__ z_table, const float* __restrict__ rays,
+                                                         const float* __restrict__ d_rgb, const uint8_t* __restrict__ mask,
+                                                         int gate, int R, int S, int white_bg,
+                                                         float4* __restrict__ d_rgbsigma, const int* __restrict__ num_nn, int k_full)
+{
+    extern __shared__ float cbw_lds[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + wv;
+    if (r >= R) return;                                  // wave-uniform; no workgroup barrier below
+    float* fac = cbw_lds + (size_t)wv * 4 * S;          // (1 - alpha_s) + 1e-10
+    float* Tv = fac + S;                                 // T_s
+    float* dww = Tv + S;                                 // dL/dw_s * w_s
+    float* sfx = dww + S;                                // sum_{k>s} dL/dw_k * w_k
+    const float* ry = rays + 6 * (size_t)r;
+    const float nrm = sqrtf(ry[3] * ry[3] + ry[4] * ry[4] + ry[5] * ry[5]);
+    const float* zr = z ? z + (size_t)r * S : z_table;
+    const float g0 = d_rgb[3 * (size_t)r], g1 = d_rgb[3 * (size_t)r + 1], g2 = d_rgb[3 * (size_t)r + 2];
+    const float gsum = white_bg ? (g0 + g1 + g2) : 0.f;
+    for (int s = lane; s < S; s += 64) {
+        const float delta = ((s + 1 < S) ? (zr[s + 1] - zr[s]) : 1e10f) * nrm;
+        const bool on = !gate || (mask ? mask[(size_t)r * S + s] != 0 : num_nn[(size_t)r * S + s] == k_full);
+        const float alpha = on ? 1.f - expf(-delta * fmaxf(rgbsigma[(size_t)r * S + s].w, 0.f)) : 0.f;
+        fac[s] = (1.f - alpha) + 1e-10f;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        float T = 1.f;
+        for (int s = 0; s < S; ++s) { Tv[s] = T; T = T * fac[s]; }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    for (int s = lane; s < S; s += 64) {
+        const bool on = !gate || (mask ? mask[(size_t)r * S + s] != 0 : num_nn[(size_t)r * S + s] == k_full);
+        const float4 v = on ? rgbsigma[(size_t)r * S + s] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float delta = ((s + 1 < S) ? (zr[s + 1] - zr[s]) : 1e10f) * nrm;
+        const float alpha = 1.f - expf(-delta * fmaxf(v.w, 0.f));
+        const float w = alpha * Tv[s];
+        const float dw = g0 * v.x + g1 * v.y + g2 * v.z - gsum;
+        dww[s] = dw * w;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        float suffix = 0.f;
+        for (int s = S - 1; s >= 0; --s) { sfx[s] = suffix; suffix += dww[s]; }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    for (int s = lane; s < S; s += 64) {
+        const bool on = !gate || (mask ? mask[(size_t)r * S + s] != 0 : num_nn[(size_t)r * S + s] == k_full);
+        const float4 v = on ? rgbsigma[(size_t)r * S + s] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float delta = ((s + 1 < S) ? (zr[s + 1] - zr[s]) : 1e10f) * nrm;
+        const float e = expf(-delta * fmaxf(v.w, 0.f));
+        const float alpha = 1.f - e;
+        const float Ti = Tv[s];
+        const float w = alpha * Ti;
+        const float dw = g0 * v.x + g1 * v.y + g2 * v.z - gsum;
+        const float dalpha = Ti * dw - sfx[s] / ((1.f - alpha) + 1e-10f);
+        const float dsigma = v.w > 0.f ? dalpha * delta * e : 0.f;
+        d_rgbsigma[(size_t)r * S + s] = make_float4(w * g0, w * g1, w * g2, dsigma);
+    }
+}
+
 extern "C" int nf_composite_bwd(const float* rgbsigma, const float* z, const float* z_table, const float* rays,
                                 const float* d_rgb, const uint8_t* mask, int gate_by_mask, int R, int S, int white_bg,
                                 float* scratch, float* d_rgbsigma, const int32_t* num_nn, int k_full, nf_stream_t stream)
@@ -781,6 +851,13 @@ extern "C" int nf_composite_bwd(const float* rgbsigma, const float* z, const flo
     NF_CHECK_ARG(rgbsigma && (z || z_table) && rays && d_rgb && scratch && d_rgbsigma, "null pointer");
     NF_CHECK_ARG(!gate_by_mask || mask || num_nn, "gate_by_mask needs the mask (or num_nn + k_full)");
     if (R == 0) return NF_OK;
+    const size_t lds_w = (size_t)4 * 4 * S * sizeof(float);
+    if (R <= 16384 && lds_w <= 64 * 1024) {             // few rays: a wave per ray (see k_composite_bwd_w)
+        hipLaunchKernelGGL(k_composite_bwd_w, dim3((R + 3) / 4), dim3(256), lds_w, (hipStream_t)stream, (const float4*)rgbsigma, z,
+                           z_table, rays, d_rgb, mask, gate_by_mask, R, S, white_bg, (float4*)d_rgbsigma, num_nn, k_full);
+        NF_CHECK_LAUNCH();
+        return NF_OK;
+    }
     hipLaunchKernelGGL(k_composite_bwd, dim3((R + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const float4*)rgbsigma, z,
                        z_table, rays, d_rgb, mask, gate_by_mask, R, S, white_bg, scratch, (float4*)d_rgbsigma, num_nn, k_full);
     NF_CHECK_LAUNCH();

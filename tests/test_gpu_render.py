@@ -865,3 +865,47 @@ def test_search_optional_mask_output(dev):
         res.append((num_nn.clone(), mask, int(counters[1])))
     assert torch.equal(res[0][0], res[1][0]) and res[0][2] == res[1][2] and res[0][2] > 100
     assert torch.equal(res[0][1], (res[0][0] == K).to(torch.uint8))
+
+
+def test_composite_backward_wave_per_ray_bit_equal(dev):
+    """nf_composite_bwd has two kernels: a thread per ray (large R) and a wave per ray (R <= 16 384: the training steps).
+    Same recurrences in the same order: the rows of a small call must equal, bit for bit, the rows the large-R kernel writes
+    for the same rays (the inputs tiled past the switch), gated (NaN where the mask is 0) and ungated, ragged S, and both must
+    agree with torch autograd through the compositing formula."""
+    from neurofluid_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(11)
+    for R, S, gate in [(300, 192, 1), (257, 64, 0), (100, 37, 1)]:
+        rs = torch.rand(R, S, 4, generator=gen)
+        rs[..., 3] = rs[..., 3] * 30 - 5
+        mask = torch.rand(R, S, generator=gen) < 0.4
+        z = torch.sort(torch.rand(R, S, generator=gen) * 4 + 9, dim=1).values
+        rays = torch.randn(R, 6, generator=gen)
+        g = torch.randn(R, 3, generator=gen)
+        src = torch.where(mask[..., None], rs, torch.full_like(rs, float("nan"))) if gate else rs
+        rep = (16384 // R) + 2                              # tiled past the kernel switch
+
+        def run(reps):
+            t = lambda a: a.repeat((reps,) + (1,) * (a.dim() - 1)).contiguous().to(dev)     # noqa: E731
+            rs_d, z_d, ry_d, g_d, m_d = t(src), t(z), t(rays), t(g), t(mask.to(torch.uint8))
+            n = R * reps
+            scratch = torch.empty(n * S, device=dev)
+            out = torch.full((n, S, 4), float("nan"), device=dev)
+            _lib.check(lib.nf_composite_bwd(rs_d.data_ptr(), z_d.data_ptr(), None, ry_d.data_ptr(), g_d.data_ptr(),
+                                            m_d.data_ptr() if gate else None, gate, n, S, 1, scratch.data_ptr(), out.data_ptr(), None, 0,
+                                            _lib.stream()))
+            return out[:R].cpu()
+        small, large = run(1), run(rep)
+        assert torch.equal(small, large), (R, S, gate)
+        # autograd reference (double)
+        x = (rs * mask[..., None] if gate else rs).double().requires_grad_(True)
+        zd = z.double()
+        delta = torch.cat([zd[:, 1:] - zd[:, :-1], torch.full((R, 1), 1e10, dtype=torch.float64)], 1) * rays[:, 3:].double().norm(dim=1, keepdim=True)
+        alpha = 1 - torch.exp(-delta * torch.relu(x[..., 3]))
+        Tt = torch.cumprod(torch.cat([torch.ones(R, 1, dtype=torch.float64), 1 - alpha + 1e-10], 1), 1)[:, :-1]
+        w = alpha * Tt
+        rgb = (w[..., None] * x[..., :3]).sum(1) + 1 - w.sum(1, keepdim=True)
+        (rgb * g.double()).sum().backward()
+        want = x.grad * (mask[..., None] if gate else 1)
+        got = torch.where(mask[..., None], small, torch.zeros_like(small)) if gate else small
+        assert (got.double() - want).abs().max() <= 2e-4 * max(1.0, float(want.abs().max()))

@@ -152,9 +152,9 @@ __global__ void __launch_bounds__(SG_BLOCK) k_search(const void* __restrict__ ws
                                                      const int* __restrict__ cand, const int* __restrict__ cand_count,
                                                      int* __restrict__ num_nn,
                                                      int* __restrict__ row_sample, int* __restrict__ row_nbr,
-                                                     int* __restrict__ n_rows)
+                                                     int* __restrict__ n_rows, int cpr)
 {
-    // a wave takes 64 consecutive candidates per round, 4 at a time; their neighbour lists wait in LDS until the round
+    // a wave takes cpr (64, or 16 for small launches) consecutive candidates per round, 4 at a time; their neighbour lists wait in LDS until the round
     // is over, so that the active rows of the round are reserved with ONE atomic (as with a thread per candidate)
     // LDS sized by K (dynamic): [wave][slot][pitch] lists, pitch = K | 1 (odd: conflict-free for both access patterns) +
     // [wave][slot] counts and flags.  At K = 20 that is 23.5 KB per workgroup instead of the 35.8 KB of a fixed pitch 33:
@@ -169,8 +169,8 @@ __global__ void __launch_bounds__(SG_BLOCK) k_search(const void* __restrict__ ws
     const int lane = threadIdx.x & 63, l = lane & (SG_LANES - 1), gsh = lane & ~(SG_LANES - 1), grp = lane >> 4;
     const int wv = threadIdx.x >> 6;
     const unsigned lt = (1u << l) - 1u;
-    for (int base = (blockIdx.x * SG_WAVES + wv) * 64; base < ncand; base += gridDim.x * SG_WAVES * 64) {
-        for (int step = 0; step < 16; ++step) {
+    for (int base = (blockIdx.x * SG_WAVES + wv) * cpr; base < ncand; base += gridDim.x * SG_WAVES * cpr) {
+        for (int step = 0; step < (cpr >> 2); ++step) {
             const int slot = step * 4 + grp;
             const int c = base + slot;
             int cnt = 0, nz = 0, sample = 0;
@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(SG_BLOCK) k_search(const void* __restrict__ ws
         const int c = base + lane;
         bool active = false;
         int cnt = 0, sample = 0;
-        if (c < ncand) {
+        if (lane < cpr && c < ncand) {
             sample = cand[c];
             cnt = s_cnt_w[lane];
             active = s_full_w[lane] || !use_mask;
@@ -273,9 +273,13 @@ extern "C" int nf_render_search(const void* ws, const float* rays, const float* 
     long total = (long)R * S;
     long want = (total + SG_BLOCK - 1) / SG_BLOCK;
     int blocks = (int)(want < 8192 ? want : 8192);          // grid-stride over the candidates (count known on device only)
+    // Small launches (the training steps: < 1 M samples, ~10 % of them candidates) leave most of these waves without work
+    // while the others walk 64 candidates one group of 4 after the other (16 dependent steps ~ 130 us whatever the count):
+    // rounds of 16 candidates spread the same candidates over 4x the waves.
+    const int cpr = total < (1L << 20) ? 16 : 64;
     const size_t lds = (size_t)SG_WAVES * 64 * ((K | 1) + 2) * sizeof(int);
     hipLaunchKernelGGL(k_search, dim3(blocks), dim3(SG_BLOCK), lds, (hipStream_t)stream, ws, rays, z, z_table, S,
-                       radius * radius, K, use_mask, cand, cand_count, num_nn, row_sample, row_nbr, n_rows);
+                       radius * radius, K, use_mask, cand, cand_count, num_nn, row_sample, row_nbr, n_rows, cpr);
     if (mask) hipLaunchKernelGGL(k_mask_from_num_nn, dim3(blocks), dim3(256), 0, (hipStream_t)stream, cand, cand_count, (const int*)num_nn, K, mask);
     NF_CHECK_LAUNCH();
     return NF_OK;
@@ -621,6 +625,64 @@ __global__ void __launch_bounds__(64) k_composite(const float4* __restrict__ rgb
     if (mask_sum) mask_sum[r] = (float)ms;
 }
 
+// Small ray counts (training steps): a wave per ray, as k_composite_bwd_w below — the elementwise work and the global accesses
+// on 64 lanes, the recurrence T_i and the five running sums walked by one lane over LDS in sample order (the results are
+// those of the thread-per-ray kernel bit for bit; 1 024 rays there are 16 waves on the whole chip for 45 us).
+__global__ void __launch_bounds__(256) k_composite_w(const float4* __restrict__ rgbsigma, const float* __restrict__ z,
+                                                     const float* __restrict__ z_table, const float* __restrict__ rays,
+                                                     const uint8_t* __restrict__ mask, int gate, int R, int S, int white_bg,
+                                                     float* __restrict__ rgb, float* __restrict__ depth,
+                                                     float* __restrict__ opacity, float* __restrict__ weights,
+                                                     float* __restrict__ mask_sum, const int* __restrict__ num_nn, int k_full)
+{
+    extern __shared__ float cw_lds[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + wv;
+    if (r >= R) return;                                  // wave-uniform; no workgroup barrier below
+    float* al = cw_lds + (size_t)wv * 6 * S;
+    float* vx = al + S; float* vy = vx + S; float* vz = vy + S; float* zc_ = vz + S; float* wv_ = zc_ + S;
+    const float* ry = rays + 6 * (size_t)r;
+    const float nrm = sqrtf(ry[3] * ry[3] + ry[4] * ry[4] + ry[5] * ry[5]);
+    const float* zr = z ? z + (size_t)r * S : z_table;
+    const bool have_mask = mask || num_nn;
+    int ms = 0;
+    for (int s = lane; s < S; s += 64) {
+        bool mb = false;
+        if (have_mask) mb = mask ? mask[(size_t)r * S + s] != 0 : num_nn[(size_t)r * S + s] == k_full;
+        ms += mb ? 1 : 0;
+        const bool on = gate ? mb : true;
+        const float4 v = on ? rgbsigma[(size_t)r * S + s] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float zc = zr[s];
+        const float delta = ((s + 1 < S) ? (zr[s + 1] - zc) : 1e10f) * nrm;
+        al[s] = 1.f - expf(-delta * fmaxf(v.w, 0.f));
+        vx[s] = v.x; vy[s] = v.y; vz[s] = v.z; zc_[s] = zc;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ms += __shfl_down(ms, o, 64);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        float T = 1.f, cr = 0.f, cg = 0.f, cb = 0.f, cd = 0.f, ws = 0.f;
+        for (int s = 0; s < S; ++s) {
+            const float alpha = al[s];
+            const float w = alpha * T;
+            T = T * ((1.f - alpha) + 1e-10f);
+            cr += w * vx[s]; cg += w * vy[s]; cb += w * vz[s]; cd += w * zc_[s]; ws += w;
+            wv_[s] = w;
+        }
+        if (white_bg) { cr = cr + 1.f - ws; cg = cg + 1.f - ws; cb = cb + 1.f - ws; }
+        rgb[3 * (size_t)r] = cr; rgb[3 * (size_t)r + 1] = cg; rgb[3 * (size_t)r + 2] = cb;
+        depth[r] = cd;
+        opacity[r] = ws;
+        if (mask_sum) mask_sum[r] = (float)ms;
+    }
+    if (weights) {
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        for (int s = lane; s < S; s += 64) weights[(size_t)r * S + s] = wv_[s];
+    }
+}
+
 extern "C" int nf_composite_fwd(const float* rgbsigma, const float* z, const float* z_table, const float* rays,
                                 const uint8_t* mask, int gate_by_mask, int R, int S, int white_bg, float* rgb, float* depth,
                                 float* opacity, float* weights, float* mask_sum, const int32_t* num_nn, int k_full,
@@ -629,6 +691,13 @@ extern "C" int nf_composite_fwd(const float* rgbsigma, const float* z, const flo
     NF_CHECK_ARG(rgbsigma && (z || z_table) && rays && rgb && depth && opacity, "null pointer");
     NF_CHECK_ARG(!gate_by_mask || mask || num_nn, "gate_by_mask needs the mask (or num_nn + k_full)");
     if (R == 0) return NF_OK;
+    const size_t lds_w = (size_t)4 * 6 * S * sizeof(float);
+    if (R <= 16384 && lds_w <= 64 * 1024) {             // few rays: a wave per ray (see k_composite_w)
+        hipLaunchKernelGGL(k_composite_w, dim3((R + 3) / 4), dim3(256), lds_w, (hipStream_t)stream, (const float4*)rgbsigma, z,
+                           z_table, rays, mask, gate_by_mask, R, S, white_bg, rgb, depth, opacity, weights, mask_sum, num_nn, k_full);
+        NF_CHECK_LAUNCH();
+        return NF_OK;
+    }
     hipLaunchKernelGGL(k_composite, dim3((R + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const float4*)rgbsigma, z,
                        z_table, rays, mask, gate_by_mask, R, S, white_bg, rgb, depth, opacity, weights, mask_sum, num_nn, k_full);
     NF_CHECK_LAUNCH();

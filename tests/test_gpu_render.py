@@ -909,3 +909,42 @@ def test_composite_backward_wave_per_ray_bit_equal(dev):
         want = x.grad * (mask[..., None] if gate else 1)
         got = torch.where(mask[..., None], small, torch.zeros_like(small)) if gate else small
         assert (got.double() - want).abs().max() <= 2e-4 * max(1.0, float(want.abs().max()))
+
+
+def test_composite_forward_wave_per_ray_bit_equal(dev):
+    """nf_composite_fwd: the wave-per-ray kernel of small calls (R <= 16 384) against the thread-per-ray kernel (the same
+    rays tiled past the switch): rgb, depth, opacity, weights and mask_sum bit for bit, gated by mask bytes / by neighbour
+    counts / ungated, ragged S, weights = NULL."""
+    from neurofluid_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(12)
+    for R, S, mode in [(300, 192, "mask"), (257, 64, "none"), (100, 37, "nn"), (64, 192, "mask_now")]:
+        rs = torch.rand(R, S, 4, generator=gen)
+        rs[..., 3] = rs[..., 3] * 30 - 5
+        mask = torch.rand(R, S, generator=gen) < 0.4
+        mask[3] = False
+        z = torch.sort(torch.rand(R, S, generator=gen) * 4 + 9, dim=1).values
+        rays = torch.randn(R, 6, generator=gen)
+        gate = 0 if mode == "none" else 1
+        src = torch.where(mask[..., None], rs, torch.full_like(rs, float("nan"))) if gate else rs
+        nn = torch.where(mask, torch.full((R, S), 20), torch.randint(0, 20, (R, S), generator=gen)).to(torch.int32)
+        rep = (16384 // R) + 2
+
+        def run(reps):
+            t = lambda a: a.repeat((reps,) + (1,) * (a.dim() - 1)).contiguous().to(dev)     # noqa: E731
+            rs_d, z_d, ry_d, m_d, nn_d = t(src), t(z), t(rays), t(mask.to(torch.uint8)), t(nn)
+            n = R * reps
+            rgb = torch.empty(n, 3, device=dev); depth = torch.empty(n, device=dev); op = torch.empty(n, device=dev)
+            w = torch.empty(n, S, device=dev) if mode != "mask_now" else None
+            msum = torch.empty(n, device=dev)
+            _lib.check(lib.nf_composite_fwd(rs_d.data_ptr(), z_d.data_ptr(), None, ry_d.data_ptr(),
+                                            m_d.data_ptr() if mode.startswith("mask") else None, gate, n, S, 1, rgb.data_ptr(),
+                                            depth.data_ptr(), op.data_ptr(), w.data_ptr() if w is not None else None,
+                                            msum.data_ptr(), nn_d.data_ptr() if mode == "nn" else None, 20, _lib.stream()))
+            outs = [rgb[:R].cpu(), depth[:R].cpu(), op[:R].cpu(), msum[:R].cpu()]
+            return outs + ([w[:R].cpu()] if w is not None else [])
+        small, large = run(1), run(rep)
+        for a, b in zip(small, large):
+            assert torch.equal(a, b), (R, S, mode)
+        if mode != "none":
+            assert torch.equal(small[3], mask.sum(1).float())

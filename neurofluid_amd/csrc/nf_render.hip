@@ -781,6 +781,83 @@ __global__ void __launch_bounds__(IS_BLOCK) k_importance(const float* __restrict
     }
 }
 
+// Small ray counts: a wave per ray.  The elementwise parts (pdf terms, the inverse-CDF samples) and the global accesses run on
+// the 64 lanes; the order-dependent parts (total, running CDF, insertion sort, merge) are walked by one lane over LDS exactly
+// as the thread-per-ray kernel walks them, so the samples are the same bit for bit (the count of CDF entries <= u is found by
+// the same forward scan, per sample instead of carried over: the CDF is strictly increasing, the count is the same).
+__global__ void __launch_bounds__(256) k_importance_w(const float* __restrict__ z0, const float* __restrict__ w0,
+                                                      const float* __restrict__ u_table, int R, int S0, int NI,
+                                                      const float* __restrict__ zero_row, float* __restrict__ z1)
+{
+    extern __shared__ float smw[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + wv;
+    if (r >= R) return;                                  // wave-uniform; no workgroup barrier below
+    const int NB = S0 - 1, NW = S0 - 2, ST = S0 + NI;
+    float* pw = smw + (size_t)wv * (S0 + S0 + NI + ST);      // pdf terms w[k+1] + 1e-5 -> (..)/tot
+    float* cdf = pw + S0;                                      // [NB]
+    float* zn = cdf + S0;                                      // [NI]
+    float* mg = zn + NI;                                       // [ST] merged row
+    const float* w = w0 + (size_t)r * S0;
+    float* out = z1 + (size_t)r * ST;
+    bool nz = false;
+    for (int k = lane; k < NW; k += 64) { const float v = w[k + 1]; pw[k] = v + 1e-5f; nz = nz || (v != 0.f); }
+    if (zero_row && __ballot(nz) == 0ull) {
+        for (int k = lane; k < ST; k += 64) out[k] = zero_row[k];
+        return;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    float tot = 0.f;
+    if (lane == 0) {
+        for (int k = 0; k < NW; ++k) tot += pw[k];
+    }
+    tot = __shfl(tot, 0, 64);
+    for (int k = lane; k < NW; k += 64) pw[k] = pw[k] / tot;
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        float c = 0.f;
+        cdf[0] = 0.f;
+        for (int k = 0; k < NW; ++k) { c += pw[k]; cdf[k + 1] = c; }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    for (int k = lane; k < NI; k += 64) {
+        const float u = u_table[k];
+        int ind = 0;
+        while (ind < NB && cdf[ind] <= u) ++ind;
+        const int below = ind - 1 < 0 ? 0 : ind - 1;
+        const int above = ind > NB - 1 ? NB - 1 : ind;
+        const float c0 = cdf[below], c1 = cdf[above];
+        const float b0 = 0.5f * (z0[below + 1] + z0[below]);
+        const float b1 = 0.5f * (z0[above + 1] + z0[above]);
+        float denom = c1 - c0;
+        if (denom < 1e-5f) denom = 1.f;
+        const float t = (u - c0) / denom;
+        zn[k] = b0 + t * (b1 - b0);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        for (int k = 1; k < NI; ++k) {
+            const float v = zn[k];
+            int m = k;
+            while (m > 0 && zn[m - 1] > v) { zn[m] = zn[m - 1]; --m; }
+            zn[m] = v;
+        }
+        int a = 0, b = 0;
+        for (int k = 0; k < ST; ++k) {
+            const float va = a < S0 ? z0[a] : INFINITY;
+            const float vb = b < NI ? zn[b] : INFINITY;
+            if (b >= NI || (a < S0 && va <= vb)) { mg[k] = va; ++a; } else { mg[k] = vb; ++b; }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    for (int k = lane; k < ST; k += 64) out[k] = mg[k];
+}
+
 extern "C" int nf_importance_sample(const float* z_table0, const float* weights0, const float* u_table, int R, int S0,
                                     int N_imp, const float* zero_row, float* z1, nf_stream_t stream)
 {
@@ -789,6 +866,13 @@ extern "C" int nf_importance_sample(const float* z_table0, const float* weights0
     size_t lds = (size_t)(S0 - 1 + N_imp) * IS_BLOCK * sizeof(float);
     NF_CHECK_ARG(lds <= 160 * 1024, "S0 + N_imp too large for LDS staging");
     if (R == 0) return NF_OK;
+    const size_t lds_w = (size_t)4 * (3 * S0 + 2 * N_imp) * sizeof(float);
+    if (R <= 16384 && lds_w <= 64 * 1024) {             // few rays: a wave per ray (see k_importance_w)
+        hipLaunchKernelGGL(k_importance_w, dim3((R + 3) / 4), dim3(256), lds_w, (hipStream_t)stream, z_table0, weights0, u_table, R,
+                           S0, N_imp, zero_row, z1);
+        NF_CHECK_LAUNCH();
+        return NF_OK;
+    }
     if (lds > 64 * 1024)
         hipFuncSetAttribute((const void*)k_importance, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_importance, dim3((R + IS_BLOCK - 1) / IS_BLOCK), dim3(IS_BLOCK), lds, (hipStream_t)stream,

@@ -948,3 +948,25 @@ def test_composite_forward_wave_per_ray_bit_equal(dev):
             assert torch.equal(a, b), (R, S, mode)
         if mode != "none":
             assert torch.equal(small[3], mask.sum(1).float())
+
+
+def test_importance_wave_per_ray_bit_equal(dev):
+    """nf_importance_sample: the wave-per-ray kernel of small calls (R <= 16 384) against the thread-per-ray kernel (the same
+    rays tiled past the switch), with and without the shared zero row, weights with exact zeros / near-flat pdfs / spikes."""
+    from neurofluid_amd import ops
+    gen = torch.Generator().manual_seed(13)
+    for R, S0, NI in [(333, 64, 128), (70, 32, 16), (129, 64, 64)]:
+        w = torch.rand(R, S0, generator=gen) ** 6
+        w[::7] = 0.0                                        # rays that hit nothing
+        w[1::7, 1:-1] = 0.0; w[1::7, S0 // 2] = 0.9         # a single spike
+        w[2::7] = 1e-7 * torch.rand(R, S0, generator=gen)[2::7]
+        t = torch.linspace(0, 1, S0)
+        zt = (9.0 * (1 - t) + 13.0 * t).to(dev)
+        ut = torch.linspace(0.0, 1.0, NI).to(dev)
+        zero_row = ops.importance_zero_row(zt, ut, NI)
+        rep = (16384 // R) + 2
+        for zr in (None, zero_row):
+            small = ops.importance_sample(zt, w.to(dev).contiguous(), ut, NI, zr).cpu()
+            large = ops.importance_sample(zt, w.repeat(rep, 1).to(dev).contiguous(), ut, NI, zr)[:R].cpu()
+            assert torch.equal(small, large), (R, S0, NI, zr is None)
+            assert bool((small[:, 1:] >= small[:, :-1]).all())

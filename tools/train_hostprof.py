@@ -32,3 +32,12 @@ for _ in range(N):
 torch.cuda.synchronize()
 print("%s: step %.2f ms wall, %.2f ms inside step() on the host (incl. its two sizing syncs)" %
       (sys.argv[1] if len(sys.argv) > 1 else "default", (time.perf_counter() - t0) / N * 1e3, host / N * 1e3))
+if os.environ.get("NF_CPROFILE") == "1":
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(40):
+        step()
+    torch.cuda.synchronize()
+    pr.disable()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(45)

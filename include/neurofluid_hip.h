@@ -39,6 +39,12 @@ const char* nf_last_error(void);
  * ------------------------------------------------------------------------------------------ */
 #define NF_GRID_MAX_DIM 128
 size_t nf_grid_workspace_bytes(int n_points, float cell, const float bbox[6]);
+/* Byte offset, inside a built workspace, of the EXACT axis-aligned bounds of the points: 6 x uint32 (lo xyz, hi xyz) in the
+ * order-preserving encoding u = bits(f) ^ (bits(f) >> 31 ? 0xffffffff : 0x80000000), written by nf_grid_build whatever bbox
+ * the grid was given (points outside the bbox are clamped into its boundary cells; results do not depend on the bbox).
+ * A caller that rebuilds the grid every frame reads them back with data it fetches anyway and passes them, padded by a
+ * cell, as the next frame's bbox instead of reducing the cloud on the host side of a device sync. */
+size_t nf_grid_points_aabb_offset(void);
 /* with_firstk_lists != 0 also builds what the first-K-by-index search and the renderer's classify
  * stage need (per-cell particle AABBs, the dilated index-sorted lists and their chunk boxes);
  * 0 builds the cell lists only — enough for nf_radius_count / nf_radius_fill (the transition

@@ -20,6 +20,7 @@ PROTOTYPES = {
     "nf_version": (c_int, []),
     "nf_last_error": (ctypes.c_char_p, []),
     "nf_grid_workspace_bytes": (c_size_t, [c_int, c_float, ctypes.POINTER(c_float)]),
+    "nf_grid_points_aabb_offset": (c_size_t, []),
     "nf_grid_build": (c_int, [c_void_p, c_int, c_float, ctypes.POINTER(c_float), c_void_p, c_size_t, c_int, c_void_p]),
     "nf_ball_query_firstk": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nf_radius_scan_workspace_bytes": (c_size_t, [c_int]),

@@ -24,24 +24,25 @@ def _run_passes(net, particles, ro, rays, white_bg, fine, save_acts, _retry=Fals
     # verification at the end of the forward was measured SLOWER there (9.3 vs 8.3 ms per train_renderer step) — the host
     # then starts enqueuing the loss and the backward only after the whole forward has finished
     caps = ws.row_cap if ws is not None else None
-    pk0 = net.packed_weights(net.nerf_coarse)
+    if save_acts:
+        pk0, ws0, ph0 = net.packed_weights(net.nerf_coarse), None, None
+    else:
+        pk0, ws0, ph0 = net.packed_for_inference(net.nerf_coarse, use_h)
     p0 = ops.render_pass(grid, pts, rays_c, None, z_table, net.N_samples, net.raduis, net.num_neighbor, net.enc_flags,
                          net.use_mask, ro_c, pk0, net.in_channels_xyz, net.in_channels_dir, white_bg, save_acts,
-                         packed_h=net.packed_weights_h(net.nerf_coarse) if use_h else None, ws=ws, need_weights=fine,
-                         optimistic=not save_acts and not _retry, caps=caps,
-                         wstream=None if (use_h or save_acts) else ops.pack_nerf_stream(pk0, net.in_channels_xyz,
-                                                                                          net.in_channels_dir))
+                         packed_h=ph0, ws=ws, need_weights=fine, optimistic=not save_acts and not _retry, caps=caps, wstream=ws0)
     p0.packed = pk0
     p1 = None
     if fine:
         z1 = ops.importance_sample(z_table, p0.weights, u_table, net.N_importance, net.zero_row(dev))
-        pk1 = net.packed_weights(net.nerf_fine)
+        if save_acts:
+            pk1, ws1, ph1 = net.packed_weights(net.nerf_fine), None, None
+        else:
+            pk1, ws1, ph1 = net.packed_for_inference(net.nerf_fine, use_h)
         p1 = ops.render_pass(grid, pts, rays_c, z1, None, net.N_samples + net.N_importance, net.raduis, net.num_neighbor,
                              net.enc_flags, net.use_mask, ro_c, pk1, net.in_channels_xyz, net.in_channels_dir, white_bg,
-                             save_acts, packed_h=net.packed_weights_h(net.nerf_fine) if use_h else None, ws=ws,
-                             need_weights=False, optimistic=not save_acts and not _retry, caps=caps,
-                             wstream=None if (use_h or save_acts) else ops.pack_nerf_stream(pk1, net.in_channels_xyz,
-                                                                                              net.in_channels_dir))
+                             save_acts, packed_h=ph1, ws=ws, need_weights=False, optimistic=not save_acts and not _retry,
+                             caps=caps, wstream=ws1)
         p1.z = z1
         p1.packed = pk1
     # Inference passes ran against learnt row capacities without a host round trip: verify ONCE, here, with the whole
@@ -49,7 +50,9 @@ def _run_passes(net, particles, ro, rays, white_bg, fine, save_acts, _retry=Fals
     # with exact sizing; capacities also grow ahead of need when a count comes within 10 % of them.
     cap_runs = [(p, p.cap) for p in (p0, p1) if p is not None and p.cap is not None]
     if cap_runs:
-        counts = torch.cat([p.n_rows for p, _ in cap_runs]).tolist()
+        fetched = torch.cat([p.n_rows for p, _ in cap_runs] + [grid.aabb_words()]).tolist()
+        counts = fetched[:len(cap_runs)]
+        net.note_point_bounds(ops.decode_aabb(fetched[len(cap_runs):]))      # the next frame's grid bbox: no reduction + sync
         overflow = False
         for (p, cap), n in zip(cap_runs, counts):
             key = (p.R, p.S)

@@ -7,6 +7,7 @@
 //    "first K by index" is a K-bounded sorted insertion with an early break per cell;
 //  * the per-thread K-list lives in LDS, laid out [k][thread] so every access is conflict-free.
 #include "nf_common.h"
+#include <stddef.h>
 #include <math.h>
 #include <string.h>
 
@@ -193,6 +194,8 @@ int nf_grid_make_header(int n, float cell, const float bbox[6], NfGridHeader* h,
     *total = off;
     return NF_OK;
 }
+
+extern "C" size_t nf_grid_points_aabb_offset(void) { return offsetof(NfGridHeader, pt_lo); }
 
 extern "C" size_t nf_grid_workspace_bytes(int n_points, float cell, const float bbox[6])
 {

@@ -51,6 +51,22 @@ class Grid:
     def n(self):
         return self.points.shape[0]
 
+    def aabb_words(self):
+        """The exact bounds of the points as the build left them on the device: 6 int32 words (see decode_aabb)."""
+        off = _lib.load().nf_grid_points_aabb_offset()
+        return self.ws[off:off + 24].view(torch.int32)
+
+
+def decode_aabb(words):
+    """6 order-preserving uint32 words (as Python ints, possibly negative from an int32 view) -> (lo xyz, hi xyz) floats."""
+    import struct
+    out = []
+    for w in words:
+        u = w & 0xffffffff
+        b = (u & 0x7fffffff) if (u & 0x80000000) else (~u & 0xffffffff)
+        out.append(struct.unpack("<f", struct.pack("<I", b))[0])
+    return tuple(out)
+
 
 def build_grid(points, cell, bbox=None, firstk=True):
     """points (N,3) fp32 contiguous.  bbox=(xmin,ymin,zmin,xmax,ymax,zmax); if None it is computed

@@ -73,6 +73,7 @@ class RenderNet(nn.Module):
         self._z_table = None
         self._u_table = None
         self._zero_row = None
+        self._bbox_hint = None      # bounds of the last cloud, padded (note_point_bounds): the next grid's bbox
         self._grid_cache = (None, None, None)
         self._workspace = None
 
@@ -102,8 +103,18 @@ class RenderNet(nn.Module):
             # the entry holds `particles` (an alias of its storage): the block cannot be freed and handed to a NEW
             # tensor with the same (ptr, version, N) while the entry exists (build_grid copies non-contiguous /
             # non-fp32 inputs, so the grid alone would not pin the pointer)
-            self._grid_cache = (key, ops.build_grid(particles, self.raduis), particles)
+            self._grid_cache = (key, ops.build_grid(particles, self.raduis, bbox=self._bbox_hint), particles)
         return self._grid_cache[1]
+
+    def note_point_bounds(self, lo_hi):
+        """Bounds of the cloud of the grid just used (read back with data the caller fetched anyway), padded by one cell:
+        the bbox of the NEXT grid build.  Any bbox gives the same results (points outside it are clamped into boundary
+        cells), so a stale hint costs nothing but cell occupancy; without a hint build_grid reduces the cloud with
+        torch.aminmax and waits for the device (one sync per frame of a rollout, with the GPU idle behind it)."""
+        import math
+        if all(math.isfinite(v) for v in lo_hi) and all(lo_hi[3 + d] >= lo_hi[d] for d in range(3)):
+            pad = float(self.raduis)
+            self._bbox_hint = tuple(v - pad for v in lo_hi[:3]) + tuple(v + pad for v in lo_hi[3:])
 
     def invalidate_grid(self):
         """Drop the cached grid: the next call rebuilds it (for callers that moved the particles in place through a
@@ -125,6 +136,22 @@ class RenderNet(nn.Module):
         layers = net.linear_layers()
         pack = ops.pack_nerf_s if self.mlp_dtype == "split" else (ops.pack_nerf_h2 if self.mlp_h_kernel == 2 else ops.pack_nerf_h)
         return pack([l.weight for l in layers], [l.bias for l in layers], self.in_channels_xyz, self.in_channels_dir)
+
+    def packed_for_inference(self, net, use_h):
+        """(packed blob, LDS-ring weight stream or None, fp16 / split stream or None) of one NeRF for the inference kernels,
+        re-packed only when a parameter changed (storage pointer or in-place version of any of the 24 tensors): in a
+        rollout the weights are constant, and the three small pack launches per pass sat, with their host gaps, in front of
+        a GPU that had nothing else queued (~0.2 ms per frame)."""
+        sig = tuple((p.data_ptr(), p._version) for l in net.linear_layers() for p in (l.weight, l.bias)) + \
+            (self.mlp_dtype, self.mlp_h_kernel, bool(use_h))
+        cache = self.__dict__.setdefault("_packed_cache", {})
+        hit = cache.get(id(net))
+        if hit is None or hit[0] != sig:
+            pk = self.packed_weights(net)
+            stream = None if use_h else ops.pack_nerf_stream(pk, self.in_channels_xyz, self.in_channels_dir)
+            hit = (sig, pk, stream, self.packed_weights_h(net) if use_h else None)
+            cache[id(net)] = hit
+        return hit[1], hit[2], hit[3]
 
     # ------------------------------------------------------------------
     def forward(self, physical_particles, ro, rays, focal=None, c2w=None, use_disp=False, perturb=0, noise_std=0.,

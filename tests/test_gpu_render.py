@@ -970,3 +970,40 @@ def test_importance_wave_per_ray_bit_equal(dev):
             large = ops.importance_sample(zt, w.repeat(rep, 1).to(dev).contiguous(), ut, NI, zr)[:R].cpu()
             assert torch.equal(small, large), (R, S0, NI, zr is None)
             assert bool((small[:, 1:] >= small[:, :-1]).all())
+
+
+def test_grid_bbox_hint_and_weight_cache_do_not_change_results(dev):
+    """A rollout's renderer calls build the particle grid inside the bbox learnt from the previous call (read back with the
+    row counts: no reduction + sync per frame) and re-use the packed weights while no parameter changed.  Neither may move a
+    bit: the same frame is rendered by a fresh module (bbox reduced from the cloud, weights packed), by the same module
+    again (hint + cache), with a hint that is far too small / offset (every outside particle is clamped into a boundary
+    cell), and after an in-place weight update (the cache must notice)."""
+    g = load_golden("a10_forward")
+    P, rays, roc = T(g["particles"], dev), T(g["rays"], dev), T(g["ro"], dev)
+    net = make_net(dev)
+    with torch.no_grad():
+        first = net(P, roc, rays, None, None)         # exact sizing, bbox reduced from the cloud
+        net.invalidate_grid()
+        second = net(P, roc, rays, None, None)        # first capacity run: its verification fetch also brings the bounds
+        assert net._bbox_hint is not None
+        lo, hi = P.min(0).values.cpu(), P.max(0).values.cpu()
+        assert all(net._bbox_hint[d] <= float(lo[d]) and net._bbox_hint[3 + d] >= float(hi[d]) for d in range(3))
+        net.invalidate_grid()
+        again = net(P, roc, rays, None, None)         # grid built inside the hint
+        net._bbox_hint = (0.1, 0.1, -0.6, 0.2, 0.15, -0.5)           # a sliver inside the cloud
+        net.invalidate_grid()
+        clamped = net(P, roc, rays, None, None)
+        moved = net(P + 0.25, roc, rays, None, None)                  # new cloud, hint of the old one
+        fresh_moved = make_net(dev)(P + 0.25, roc, rays, None, None)
+    for k in first:
+        assert torch.equal(first[k], second[k]) and torch.equal(first[k], again[k]) and torch.equal(first[k], clamped[k]), k
+        assert torch.equal(moved[k], fresh_moved[k]), k
+    with torch.no_grad():
+        w = dict(net.named_parameters())["nerf_fine.rgb.0.weight"]
+        w.mul_(0.5)
+        changed = net(P, roc, rays, None, None)
+        other = make_net(dev)
+        dict(other.named_parameters())["nerf_fine.rgb.0.weight"].mul_(0.5)
+        want = other(P, roc, rays, None, None)
+    assert not torch.equal(changed["rgb1"], first["rgb1"])
+    assert torch.equal(changed["rgb1"], want["rgb1"]) and torch.equal(changed["rgb0"], first["rgb0"])

@@ -55,7 +55,7 @@ def render_image(renderer, particle_pos, N_ray, ro, rays, focal_length=None, cw=
     ret = {}
     if world == 1:
         for key in keys:
-            t = torch.cat(parts[key], dim=0)
+            t = parts[key][0] if len(parts[key]) == 1 else torch.cat(parts[key], dim=0)     # one fused call: no copy
             ret[names.get(key, key)] = t.reshape(-1) if key.startswith("num_nn") else t
         return ret
     share = nfdist.share_size(n_chunks, world)
@@ -70,7 +70,7 @@ def render_image(renderer, particle_pos, N_ray, ro, rays, focal_length=None, cw=
         # the rendered rows are a prefix of this rank's (share * ray_chunk)-row slab
         local = torch.zeros(share * ray_chunk, widths[key], dtype=dtype, device=dev)
         if parts[key]:
-            t = torch.cat(parts[key], dim=0)
+            t = parts[key][0] if len(parts[key]) == 1 else torch.cat(parts[key], dim=0)
             local[:t.shape[0]] = t
         full = nfdist.gather_chunks(local, n_chunks, ray_chunk, N_ray, rank, world)
         ret[names.get(key, key)] = full.reshape(-1) if key.startswith("num_nn") else full

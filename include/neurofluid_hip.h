@@ -171,6 +171,13 @@ int nf_nerf_mlp_fwd_h(const float* packed, const void* stream_h, int cx, int cd,
                       const int32_t* n_rows, int max_rows, const int32_t* row_sample, float* rgbsigma,
                       nf_stream_t stream);
 
+/* A6 for small launches (nf_mlp_n.hip): one 32-row tile per WORKGROUP, a layer's 8 output blocks split over its 4 waves,
+ * activations exchanged through an LDS image — a quarter of nf_nerf_mlp_fwd's per-tile latency (it keeps a tile in one
+ * wave for 0.35 ms: a launch costs ceil(tiles / 1024) such rounds however empty the last one is).  Same packed blob, same
+ * operand X, same outputs (rgbsigma, and acts when not NULL) BIT FOR BIT. */
+int nf_nerf_mlp_fwd_n(const float* packed, int cx, int cd, const float* X, const int32_t* n_rows, int max_rows,
+                      const int32_t* row_sample, float* rgbsigma, float* acts /*or NULL*/, nf_stream_t stream);
+
 /* fp16-MFMA forward, version 3 (nf_mlp_h2.hip): two 32-row tiles per wave, out-block-major, packed fp16 activations
  * between layers, sigma / rgb heads on the matrix pipe.  Same operand X as nf_nerf_mlp_fwd_h (the fp16 layout written
  * by nf_render_features(x_fp16 = 1)), which must be allocated for an EVEN number of 32-row tiles; its own weight stream. */

@@ -1,0 +1,283 @@
+// nf_mlp_n.hip — fp32-MFMA NeRF MLP forward for SMALL launches (the training steps): one 32-sample tile per WORKGROUP,
+// the 8 output blocks of a layer split over its 4 waves (2 blocks each; the 4-block view branch: 1 each).
+//
+// k_mlp_fwd (nf_mlp.hip) keeps a tile in ONE wave's registers for all layers: 10 416 dependent-in-order MFMAs = 0.35 ms per
+// tile, one wave per SIMD — so a launch costs ceil(tiles / 1024) rounds of 0.35 ms whatever the fill of the last round, and a
+// 4 096-ray training step (600 + 2 100 tiles) or a 1 024-ray end-to-end step (160 + 470 tiles) spends most of its MLP time
+// on SIMDs that have nothing to do.  Here a tile occupies the four SIMDs of a CU for a quarter of that time: the rounds are
+// 256 tiles of ~0.09 ms.  The price is that activations no longer stay in registers: every layer's 64 features per wave go
+// to an LDS image act[feature][sample] (double-buffered, one barrier per layer) from which all four waves read their B
+// operands back, one ds_read_b32 per K-step (lane-linear, conflict-free both ways).
+//
+// Same arithmetic as k_mlp_fwd, bit for bit: same MFMA, same K order (bias step first, X part, hidden part), the sigma / rgb
+// heads summed by one wave in the same order from the LDS image.  Same packed blob (nf_nerf_pack): a wave reads the 16-B
+// operand of its half of the blocks and uses two of the four lanes' values.
+#include "nf_mlp_layout.h"
+#include <math.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+#define NN_ACT (256 * 32)          // floats of one activation image
+
+struct NCtx {
+    int lane, h, j, w, g, c0;      // wave w owns blocks 2w, 2w + 1 = half g = w >> 1, components c0, c0 + 1 of its 16-B operands
+};
+
+// bias K-step (A = bias, B = 1, C = 0) of an 8-block layer: [2][64][4]
+__device__ __forceinline__ void n_bias2(const NCtx& c, const f32x4* __restrict__ p, f32x16 (&acc)[2])
+{
+    const f32x2 wv = *(const f32x2*)((const float*)(p + c.g * 64 + c.lane) + c.c0);
+    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    acc[0] = MFMA32(wv[0], 1.f, z);
+    acc[1] = MFMA32(wv[1], 1.f, z);
+}
+
+// K-steps whose B operand comes from the feature matrix (25 groups x 4 steps), read from global X both times (layer 0 and the
+// skip layer ~30 us later: 32 KB per tile that the L2 still holds; no LDS stash, so two workgroups fit a CU and each SIMD
+// has a second tile's wave to issue from while the first one waits at a layer barrier).
+template <int nq>
+__device__ __forceinline__ void n_xpart2(const NCtx& c, const f32x4* __restrict__ p /* part base */, const f32x4* __restrict__ xt /* + lane */,
+                                         f32x16 (&acc)[2])
+{
+    // the wave's two blocks are components c0, c0 + 1 of the 16-B operand: an 8-B load at that offset, no select
+    const f32x2* wp = (const f32x2*)((const float*)(p + c.g * 64 + c.lane) + c.c0);       // K-step stride: 128 f32x4 = 256 f32x2
+    // a group is only 4 K-steps x 2 MFMAs = 512 cycles here: X (HBM the first time, L2 the second) is requested XD groups
+    // ahead, the weights (L2) two groups ahead
+    constexpr int XD = 6;
+    f32x4 xr[XD];
+    f32x2 wr[2][4];
+#pragma unroll
+    for (int q = 0; q < XD; ++q) xr[q] = q < nq ? xt[q * 64] : xt[0];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wr[q][i] = wp[(q * 4 + i) * 256];
+#pragma unroll
+    for (int q = 0; q < nq; ++q) {
+        const f32x4 xv = xr[0];
+        f32x2 w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = wr[0][i];
+#pragma unroll
+        for (int k = 0; k + 1 < XD; ++k) xr[k] = xr[k + 1];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wr[0][i] = wr[1][i];
+        if (q + XD < nq) xr[XD - 1] = xt[(q + XD) * 64];
+        if (q + 2 < nq) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wr[1][i] = wp[((q + 2) * 4 + i) * 256];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc[0] = MFMA32(w[i][0], xv[i], acc[0]);
+            acc[1] = MFMA32(w[i][1], xv[i], acc[1]);
+        }
+    }
+}
+
+// hidden part: acc += W * act, act read from the LDS image (already activated); 128 K-steps = 8 source blocks x 16
+__device__ __forceinline__ void n_hpart2(const NCtx& c, const f32x4* __restrict__ p, const float* __restrict__ act, f32x16 (&acc)[2])
+{
+    constexpr int D = 8;
+    const f32x2* wp = (const f32x2*)((const float*)(p + c.g * 64 + c.lane) + c.c0);
+    const float* ap = act + (4 * c.h) * 32 + c.j;           // feature frag_feature(b, r, h) = 32 b + (r & 3) + 8 (r >> 2) + 4 h
+    f32x2 ring[D + 1];
+    float bv[D + 1];
+#pragma unroll
+    for (int s = 0; s < D; ++s) {
+        ring[s] = wp[s * 256];
+        bv[s] = ap[(32 * (s >> 4) + (s & 3) + 8 * ((s & 15) >> 2)) * 32];
+    }
+#pragma unroll
+    for (int s = 0; s < 128; ++s) {
+        if (s + D < 128) {
+            const int t = s + D;
+            ring[t % (D + 1)] = wp[t * 256];
+            bv[t % (D + 1)] = ap[(32 * (t >> 4) + (t & 3) + 8 * ((t & 15) >> 2)) * 32];
+        }
+        const f32x2 wv = ring[s % (D + 1)];
+        const float b = bv[s % (D + 1)];
+        acc[0] = MFMA32(wv[0], b, acc[0]);
+        acc[1] = MFMA32(wv[1], b, acc[1]);
+        if (s + D < 128) {      // one VMEM and one LDS read per K-step, each in an MFMA shadow
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// the wave's two blocks -> LDS image (RELU or raw) and, when training, the saved-activation row (row-major, as k_mlp_fwd)
+template <bool RELU, bool SAVE>
+__device__ __forceinline__ void n_store2(const NCtx& c, const f32x16 (&acc)[2], float* __restrict__ act, float* __restrict__ save_row,
+                                         bool row_ok)
+{
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int b = 2 * c.w + i;
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            v[r] = RELU ? fmaxf(acc[i][r], 0.f) : acc[i][r];
+            act[(32 * b + (r & 3) + 8 * (r >> 2) + 4 * c.h) * 32 + c.j] = v[r];
+        }
+        if (SAVE && row_ok) {
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                f32x4 o = {v[4 * rq], v[4 * rq + 1], v[4 * rq + 2], v[4 * rq + 3]};
+                *(f32x4*)(save_row + 32 * b + 8 * rq + 4 * c.h) = o;
+            }
+        }
+    }
+}
+
+template <bool SAVE, int QX, int QD>
+__global__ void __launch_bounds__(256) k_mlp_fwd_n(NfMlpLayout L, const float* __restrict__ packed, const float* __restrict__ X,
+                                                   const int* __restrict__ n_rows, int max_rows,
+                                                   const int* __restrict__ row_sample, float4* __restrict__ rgbsigma,
+                                                   float* __restrict__ acts)
+{
+    extern __shared__ float nlds[];        // act image A, act image B
+    float* actA = nlds;
+    float* actB = nlds + NN_ACT;
+    NCtx c;
+    c.lane = threadIdx.x & 63; c.h = c.lane >> 5; c.j = c.lane & 31; c.w = threadIdx.x >> 6; c.g = c.w >> 1; c.c0 = 2 * (c.w & 1);
+    const int nrows = min(*n_rows, max_rows);
+    const int ntiles = (nrows + 31) >> 5;
+    constexpr int Q = QX + QD;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const float* __restrict__ pk = packed + opaque_zero();
+        const f32x4* P4 = (const f32x4*)pk;
+        const f32x4* xt = (const f32x4*)X + (size_t)tile * Q * 64 + c.lane;
+        const int row = tile * 32 + c.j;
+        const bool row_ok = row < nrows;
+        float* arow = SAVE ? acts + (size_t)(row_ok ? row : 0) * NF_ACT_STRIDE : nullptr;
+        f32x16 acc[2];
+        f32x4 xdir[QD];         // the view-direction feature groups, requested now, used ~100 us later
+#pragma unroll
+        for (int q = 0; q < QD; ++q) xdir[q] = xt[(QX + q) * 64];
+
+        // layer 0 = xyz_encoding_1 -> h1 in A
+        n_bias2(c, P4 + (L.off_bstep[0] >> 2), acc);
+        n_xpart2<QX>(c, P4 + (L.off_x[0] >> 2), xt, acc);
+        n_store2<true, SAVE>(c, acc, actA, arow, row_ok);
+        __syncthreads();
+        float* cur = actA;
+        float* nxt = actB;
+        float sigma = 0.f;
+#pragma unroll 1
+        for (int l = 1; l < 9; ++l) {
+            n_bias2(c, P4 + (L.off_bstep[l] >> 2), acc);
+            if (L.off_x[l] >= 0) n_xpart2<QX>(c, P4 + (L.off_x[l] >> 2), xt, acc);
+            n_hpart2(c, P4 + (L.off_h[l] >> 2), cur, acc);
+            if (l == 8) {
+                // `cur` holds h8: the sigma head, by wave 0, in k_mlp_fwd's order (its lanes sum their own 128 features)
+                if (c.w == 0) {
+                    const float* ws_ = pk + L.off_wsig;
+                    float part = 0.f;
+#pragma unroll
+                    for (int b = 0; b < 8; ++b)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float w0 = ws_[(b * 16 + r) * 2], w1 = ws_[(b * 16 + r) * 2 + 1];
+                            part += cur[(32 * b + (r & 3) + 8 * (r >> 2) + 4 * c.h) * 32 + c.j] * (c.h ? w1 : w0);
+                        }
+                    sigma = part + __shfl_xor(part, 32, 64) + pk[L.off_bsig];
+                }
+                n_store2<false, SAVE>(c, acc, nxt, SAVE ? arow + 8 * 256 : nullptr, row_ok);      // xyz_encoding_final: no activation
+            } else {
+                n_store2<true, SAVE>(c, acc, nxt, SAVE ? arow + l * 256 : nullptr, row_ok);        // h_{l+1}
+            }
+            __syncthreads();
+            float* t = cur; cur = nxt; nxt = t;
+        }
+        // view branch: hd = relu(W_dir [final | dir feats] + b), one block per wave; `cur` holds final
+        f32x16 hd;
+        {
+            const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const f32x4* pb = P4 + (L.off_bstep_dir >> 2) + c.lane;
+            hd = MFMA32(((const float*)pb)[c.w], 1.f, z);
+            const f32x4* px = P4 + (L.off_dir_x >> 2) + c.lane;         // [s][64][4]
+#pragma unroll
+            for (int q = 0; q < QD; ++q) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hd = MFMA32(((const float*)(px + (q * 4 + i) * 64))[c.w], xdir[q][i], hd);
+            }
+            const f32x4* ph = P4 + (L.off_dir_h >> 2) + c.lane;         // [128][64][4]
+            const float* ap = cur + (4 * c.h) * 32 + c.j;
+#pragma unroll 8
+            for (int s = 0; s < 128; ++s)
+                hd = MFMA32(((const float*)(ph + s * 64))[c.w], ap[(32 * (s >> 4) + (s & 3) + 8 * ((s & 15) >> 2)) * 32], hd);
+        }
+        {
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                v[r] = fmaxf(hd[r], 0.f);
+                nxt[(32 * c.w + (r & 3) + 8 * (r >> 2) + 4 * c.h) * 32 + c.j] = v[r];
+            }
+            if (SAVE && row_ok) {
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    f32x4 o = {v[4 * rq], v[4 * rq + 1], v[4 * rq + 2], v[4 * rq + 3]};
+                    *(f32x4*)(arow + 9 * 256 + 32 * c.w + 8 * rq + 4 * c.h) = o;
+                }
+            }
+        }
+        __syncthreads();
+        if (c.w == 0) {
+            const float* wr = pk + L.off_wrgb;
+            float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = nxt[(32 * b + (r & 3) + 8 * (r >> 2) + 4 * c.h) * 32 + c.j];
+                    const int k = (b * 16 + r) * 2;
+                    c0 += v * (c.h ? wr[k + 1] : wr[k]);
+                    c1 += v * (c.h ? wr[128 + k + 1] : wr[128 + k]);
+                    c2 += v * (c.h ? wr[256 + k + 1] : wr[256 + k]);
+                }
+            c0 += __shfl_xor(c0, 32, 64); c1 += __shfl_xor(c1, 32, 64); c2 += __shfl_xor(c2, 32, 64);
+            c0 += pk[L.off_brgb]; c1 += pk[L.off_brgb + 1]; c2 += pk[L.off_brgb + 2];
+            if (c.h == 0 && row_ok) {
+                float4 o;
+                o.x = 1.f / (1.f + expf(-c0)); o.y = 1.f / (1.f + expf(-c1)); o.z = 1.f / (1.f + expf(-c2)); o.w = sigma;
+                rgbsigma[row_sample[row]] = o;
+            }
+        }
+        __syncthreads();        // the images are rewritten by the next tile
+    }
+}
+
+extern "C" int nf_nerf_mlp_fwd_n(const float* packed, int cx, int cd, const float* X, const int32_t* n_rows, int max_rows,
+                                 const int32_t* row_sample, float* rgbsigma, float* acts, nf_stream_t stream)
+{
+    NF_CHECK_ARG(packed && X && n_rows && row_sample && rgbsigma, "null pointer");
+    NF_CHECK_ARG(cx >= 1 && cx <= 256 && cd >= 1 && cd <= 256, "bad channel counts");
+    if (max_rows <= 0) return NF_OK;
+    NfMlpLayout L = mlp_layout(cx, cd);
+    NF_CHECK_ARG(L.qx == 25 && L.qd == 7, "built for the default 198 + 54 feature row (other encodings: nf_nerf_mlp_fwd)");
+    const int tiles = (max_rows + 31) / 32;
+    const size_t lds = (size_t)(2 * NN_ACT) * sizeof(float);       // 64 KB: two workgroups per CU
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)k_mlp_fwd_n<true, 25, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)k_mlp_fwd_n<false, 25, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (acts)
+        hipLaunchKernelGGL((k_mlp_fwd_n<true, 25, 7>), dim3(tiles), dim3(256), lds, st, L, packed, X, n_rows, max_rows, row_sample,
+                           (float4*)rgbsigma, acts);
+    else
+        hipLaunchKernelGGL((k_mlp_fwd_n<false, 25, 7>), dim3(tiles), dim3(256), lds, st, L, packed, X, n_rows, max_rows, row_sample,
+                           (float4*)rgbsigma, acts);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}

@@ -424,6 +424,13 @@ def render_pass(grid, particles, rays, z, z_table, S, radius, K, enc_flags, use_
         elif wstream is not None and not save_acts:      # fp32, weight stream shared through LDS (inference)
             check(lib.nf_nerf_mlp_fwd_l(ptr(packed), ptr(wstream), cx, cd, X_, ptr(nrows_t), mx, rs_, ptr(b.rgbsigma), stream_),
                   "nf_nerf_mlp_fwd_l")
+        elif save_acts and (qx, qd) == (25, 7):
+            # training forward (activations saved; launches of a few hundred to a few thousand tiles): a tile per WORKGROUP
+            # (nf_mlp_n.hip) — a third of the per-tile latency of the tile-per-wave kernel, bit-identical outputs.  (The
+            # inference passes stay on the ring kernel at every size: its sums differ in the place of the bias, and results
+            # must not depend on how a frame is cut into calls.)
+            check(lib.nf_nerf_mlp_fwd_n(ptr(packed), cx, cd, X_, ptr(nrows_t), mx, rs_, ptr(b.rgbsigma), ptr(b.acts), stream_),
+                  "nf_nerf_mlp_fwd_n")
         else:
             check(lib.nf_nerf_mlp_fwd(ptr(packed), cx, cd, X_, ptr(nrows_t), mx, rs_, ptr(b.rgbsigma), ptr(b.acts), stream_),
                   "nf_nerf_mlp_fwd")

@@ -1007,3 +1007,34 @@ def test_grid_bbox_hint_and_weight_cache_do_not_change_results(dev):
         want = other(P, roc, rays, None, None)
     assert not torch.equal(changed["rgb1"], first["rgb1"])
     assert torch.equal(changed["rgb1"], want["rgb1"]) and torch.equal(changed["rgb0"], first["rgb0"])
+
+
+def test_mlp_tile_per_workgroup_bit_equal(dev):
+    """nf_nerf_mlp_fwd_n (nf_mlp_n.hip: a 32-row tile per workgroup, a layer's output blocks split over its 4 waves, activations
+    through an LDS image) against nf_nerf_mlp_fwd (a tile per wave): rgbsigma and the saved activations bit for bit, at row
+    counts around the tile / workgroup boundaries, with a permuted row_sample, and fewer rows than max_rows."""
+    from neurofluid_amd import _lib, ops
+    from oracle import render_oracle as ro
+    lib = _lib.load()
+    st = ro.deterministic_nerf_state()
+    W = [st[f"nerf_fine.{k}.weight"].to(dev) for k in ops.NERF_LAYER_NAMES]
+    B = [st[f"nerf_fine.{k}.bias"].to(dev) for k in ops.NERF_LAYER_NAMES]
+    packed = ops.pack_nerf(W, B, 198, 54)
+    g = torch.Generator().manual_seed(21)
+    for n, live in [(1, 1), (31, 31), (33, 33), (4096, 4096), (5000, 4321), (130, 97)]:
+        x = (torch.rand(n, 252, generator=g) * 2 - 1).to(dev)
+        X = ops.rows_to_tiles(x, 198, 54)
+        n_rows = torch.tensor([live], dtype=torch.int32, device=dev)
+        row_sample = torch.randperm(n, generator=g).to(torch.int32).to(dev)
+        outs = []
+        for fn in (lib.nf_nerf_mlp_fwd, lib.nf_nerf_mlp_fwd_n):
+            for save in (False, True):
+                out = torch.full((n, 4), -7.0, device=dev)
+                acts = torch.full(((n + 31) // 32 * 32 * 2432,), -7.0, device=dev) if save else None
+                _lib.check(fn(packed.data_ptr(), 198, 54, X.data_ptr(), n_rows.data_ptr(), n, row_sample.data_ptr(), out.data_ptr(),
+                              acts.data_ptr() if save else None, _lib.stream()))
+                outs.append((out, acts[:live * 2432] if save else None))
+        assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[1][0], outs[3][0]) and torch.equal(outs[0][0], outs[1][0])
+        assert torch.equal(outs[1][1], outs[3][1])
+        touched = (outs[2][0] != -7.0).any(dim=1)
+        assert int(touched.sum()) == live           # exactly the live rows' samples were written

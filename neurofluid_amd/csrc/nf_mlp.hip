@@ -443,24 +443,6 @@ extern "C" int nf_nerf_mlp_fwd(const float* packed, int cx, int cd, const float*
 // ================================================================================================
 // backward (data gradient) — same register-resident structure, transposed weights
 // ================================================================================================
-// dpre buffer per row: [dpre1..dpre8 (8*256) | dpre_final (256) | dpre_dir (128) | dz_rgb (3) | dsigma (1)]
-struct NfMlpLayoutT {
-    int off_h[9];   // l = 1..8: W_l^T hidden part [128 steps][2][64][4]   (index 0 unused)
-    int off_dir;    // W_dir[:, :256]^T  [64 steps][2][64][4]
-    int total;
-};
-
-static NfMlpLayoutT mlp_layout_t()
-{
-    NfMlpLayoutT T;
-    int o = 0;
-    T.off_h[0] = -1;
-    for (int l = 1; l < 9; ++l) { T.off_h[l] = o; o += 128 * 512; }
-    T.off_dir = o; o += 64 * 512;
-    T.total = o;
-    return T;
-}
-
 extern "C" size_t nf_nerf_packed_bwd_floats(void) { return (size_t)mlp_layout_t().total; }
 
 __global__ void k_mlp_pack_bwd(NfMlpLayoutT T, int cx, int cd, NfNerfPtrs P, float* __restrict__ out)

@@ -46,6 +46,26 @@ static inline NfMlpLayout mlp_layout(int cx, int cd)
     return L;
 }
 
+// transposed weights of the backward (data-gradient) kernels
+// dpre buffer per row: [dpre1..dpre8 (8*256) | dpre_final (256) | dpre_dir (128) | dz_rgb (3) | dsigma (1)]
+struct NfMlpLayoutT {
+    int off_h[9];   // l = 1..8: W_l^T hidden part [128 steps][2][64][4]   (index 0 unused)
+    int off_dir;    // W_dir[:, :256]^T  [64 steps][2][64][4]
+    int total;
+};
+
+static inline NfMlpLayoutT mlp_layout_t()
+{
+    NfMlpLayoutT T;
+    int o = 0;
+    T.off_h[0] = -1;
+    for (int l = 1; l < 9; ++l) { T.off_h[l] = o; o += 128 * 512; }
+    T.off_dir = o; o += 64 * 512;
+    T.total = o;
+    return T;
+}
+
+
 // feature held by register r of block b in half-wave h (MFMA 32x32 C/D layout)
 __device__ __host__ __forceinline__ int frag_feature(int b, int r, int h) { return 32 * b + (r & 3) + 8 * (r >> 2) + 4 * h; }
 

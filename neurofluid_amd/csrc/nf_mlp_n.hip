@@ -281,3 +281,4 @@ extern "C" int nf_nerf_mlp_fwd_n(const float* packed, int cx, int cd, const floa
     NF_CHECK_LAUNCH();
     return NF_OK;
 }
+

@@ -1038,3 +1038,4 @@ def test_mlp_tile_per_workgroup_bit_equal(dev):
         assert torch.equal(outs[1][1], outs[3][1])
         touched = (outs[2][0] != -7.0).any(dim=1)
         assert int(touched.sum()) == live           # exactly the live rows' samples were written
+

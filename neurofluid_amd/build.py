@@ -12,7 +12,8 @@ SOURCES = ["nf_grid.hip", "nf_render.hip", "nf_mlp.hip", "nf_mlp_l.hip", "nf_mlp
 # which cannot read AGPRs: AGPR accumulators cost 16 v_accvgpr_read per block and tile)
 EXTRA_FLAGS = {"nf_mlp_h2.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "nf_mlp_s.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-value"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-value"] + \
+    os.environ.get("NF_EXTRA_DEFS", "").split()      # dev: extra -D switches for A/B builds of a kernel
 
 
 def _stale(target, deps):

@@ -26,7 +26,7 @@ python tools/summarize_pmc.py $P/round2_transition_pmc.json r2_stats_trans r2_pm
 if [ -d $O/r2_stats_train ]; then
   short_stats r2_stats_train $P/round2_train_kernel_stats.csv
   python tools/summarize_pmc.py $P/round2_train_pmc.json r2_stats_train r2_pmc_fetch_train r2_pmc_write_train r2_pmc_sq_train -- \
-      "k_mlp_fwd<true>" k_mlp_bwd "k_wgrad(" k_search k_composite_bwd
+      k_mlp_fwd_n k_mlp_bwd "k_wgrad(" k_search k_composite_bwd_w
 fi
 python - <<'PY'
 import json

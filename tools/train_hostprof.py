@@ -21,6 +21,9 @@ if os.environ.get("NF_FAKE_DRAW") == "1":      # what-if: a pixel draw that cost
         def choice(self, n, size, replace=False): return self.rng.randint(0, n, size=size)
     _PS = ts.PixelSampler
     ts.PixelSampler = lambda rng, *a, **k: _PS(_Cheap(rng), *a, **k)
+if os.environ.get("NF_ONE_STREAM") == "1":
+    from neurofluid_amd import autograd_bwd
+    autograd_bwd.TWO_STREAM_BACKWARD = False
 step = ts.make_train_step(net, scene, dev)
 for _ in range(8):
     step()

@@ -58,13 +58,15 @@ def _median(xs):
     return xs[len(xs) // 2]
 
 
-def cpu_baseline(scene400):
+def cpu_baseline(scene400, hip_frame=None, hip_step=None):
     """The oracle (CPU port of the reference path) on a bounded, representative sample, about 20-30 s of CPU work:
       n-thread: every 160th ray of the 400^2 image (1000 rays, same hit ratio as the full frame), 1 warm-up + 3 timed
                 repetitions (median); 2 warm + 3 x 2 transition steps on the 4 913 particles
       1-thread: every 640th ray (250 rays), 1 repetition after a 25-ray warm-up; 2 transition steps
     Threads: torch intra-op AND the C neighbour oracle's OpenMP loops are set to the same count (the process's CPU
-    budget, capped at 16: the oracle's ops are small and lose time beyond that)."""
+    budget, capped at 16: the oracle's ops are small and lose time beyond that).
+    hip_frame / hip_step: the HIP path's 400^2 frame (coarse, fine RGB) and a 5-step rollout [(pos, vel), ...] from the SAME
+    inputs; the oracle's sample doubles as the checker (parity reported with the numbers) -> "parity"."""
     from oracle import neighbors, render_oracle as ro, trans_oracle as to
     from neurofluid_amd import effective_cpus
     cores = max(1, min(effective_cpus(), 16))
@@ -76,9 +78,9 @@ def cpu_baseline(scene400):
         ts = []
         for _ in range(reps):
             t0 = time.perf_counter()
-            ro.render_forward(sc["nerf_state"], sc["P"], ro_, rays, 9.0, 13.0)
+            ref = ro.render_forward(sc["nerf_state"], sc["P"], ro_, rays, 9.0, 13.0)
             ts.append(time.perf_counter() - t0)
-        return rays.shape[0] / _median(ts), ts
+        return rays.shape[0] / _median(ts), ts, ref
 
     def trans_rate(reps, nsteps, warm):
         p, v = sc["P"], torch.zeros_like(sc["P"])
@@ -97,12 +99,36 @@ def cpu_baseline(scene400):
     torch.set_num_threads(cores)
     neighbors.set_threads(cores)
     rays_n = sc["rays"][::160].contiguous()
-    r_n, ts_n = render_rate(rays_n, 3, rays_n)
+    r_n, ts_n, ref_n = render_rate(rays_n, 3, rays_n)
     p_n, _ = trans_rate(3, 2, 2)
+    parity = None
+    if hip_frame is not None:
+        def cmp(a, b):
+            d = (a.double() - b.double())
+            mse = float((d ** 2).mean())
+            return {"psnr_db": (-10.0 * math.log10(mse)) if mse > 0 else float("inf"), "max_abs": float(d.abs().max())}
+        c0, c1 = cmp(hip_frame[0][::160], ref_n["rgb0"]), cmp(hip_frame[1][::160], ref_n["rgb1"])
+        op, ov = sc["P"], torch.zeros_like(sc["P"])
+        for _ in range(len(hip_step)):
+            op, ov, _ = to.particle_net_forward(sc["trans_state"], op, ov, sc["box"], sc["bn"])
+        hp, hv = hip_step[-1]
+        parity = {"against": "oracle (CPU restatement of the reference path, pinned to the reference by tests/golden), same "
+                             "inputs, same fp32 weights",
+                  "render_rays_compared": int(rays_n.shape[0]),
+                  "rgb_coarse": c0, "rgb_fine": c1,
+                  "rollout_steps": len(hip_step),
+                  "rollout_pos_mean_l2": float((hp.double() - op.double()).norm(dim=1).mean()),
+                  "rollout_pos_max_abs": float((hp.double() - op.double()).abs().max()),
+                  "rollout_vel_max_abs": float((hv.double() - ov.double()).abs().max()),
+                  "tolerance": "north_star: rgb at fp32 tolerance, reported as PSNR (tests: >= 60 dB, coarse max-abs <= 2e-4; "
+                               "fine image: isolated pixels may move by ~1e-3 where inverse-CDF resampling flips a bin); "
+                               "rolled-out positions within 1e-4 mean L2",
+                  "within_tolerance": bool(c0["psnr_db"] >= 60 and c1["psnr_db"] >= 60 and c0["max_abs"] <= 2e-4 and
+                                           float((hp.double() - op.double()).norm(dim=1).mean()) <= 1e-4)}
     torch.set_num_threads(1)
     neighbors.set_threads(1)
     rays_1 = sc["rays"][::640].contiguous()
-    r_1, ts_1 = render_rate(rays_1, 1, rays_1[::10].contiguous())
+    r_1, ts_1, _ = render_rate(rays_1, 1, rays_1[::10].contiguous())
     p_1, _ = trans_rate(1, 2, 0)
     torch.set_num_threads(old)
     neighbors.set_threads(cores)
@@ -112,7 +138,7 @@ def cpu_baseline(scene400):
                       f"2 warm + 3 x 2 steps) on {cores} threads (torch intra-op + OpenMP neighbour search); 1-thread figures "
                       f"on every 640th ray ({rays_1.shape[0]} rays) and 2 steps; {os.cpu_count()} host cores visible, CPU budget "
                       f"{effective_cpus()}; {time.perf_counter() - t_all:.0f} s in total",
-            "particle_steps_per_sec": p_n, "value_1_thread": r_1, "particle_steps_per_sec_1_thread": p_1}
+            "particle_steps_per_sec": p_n, "value_1_thread": r_1, "particle_steps_per_sec_1_thread": p_1}, parity
 
 
 def _git_blob(path):
@@ -403,7 +429,17 @@ def main():
         if os.environ.get("NF_BENCH_DEBUG"):
             res["host_marks_ms"] = [round(m * 1e3, 2) for m in host_marks]
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(scene if image == 400 else build_scene(400))
+            hip_frame = hip_step = None
+            if args.workload == "render" and image == 400 and not strong:
+                hip_step, hp, hv = [], P0, torch.zeros_like(P0)
+                with torch.no_grad():
+                    for _ in range(5):
+                        hp, hv, _ = pn(hp, hv, box, bn)
+                        hip_step.append((hp.cpu(), hv.cpu()))
+                hip_frame = (out["pred_rgbs_0"].float().cpu(), out["pred_rgbs_1"].float().cpu())
+            res["cpu_baseline"], parity = cpu_baseline(scene if image == 400 else build_scene(400), hip_frame, hip_step)
+            if parity is not None:
+                res["parity"] = parity
             if args.workload == "render":
                 res["speedup_vs_cpu_port"] = value / res["cpu_baseline"]["value"]
         print(json.dumps(res))

@@ -209,11 +209,13 @@ int nf_nerf_mlp_bwd(const float* packed, const float* packed_t, int cx, int cd, 
 /* A12 (weight gradients): all 15 GEMMs dW_l = dpre_l^T * input_l of one NeRF in one batched fp32-MFMA launch +
  * one deterministic slice reduction.  X = the MLP operand of nf_render_features (tile layout) that the forward consumed.
  * dweights = one flat blob holding the 12 weight gradients in nf_nerf_params_t order, each [out][in] row-major
- * (nf_nerf_wgrad_floats floats); workspace = nf_nerf_wgrad_workspace_floats(cx, cd, nslices) floats. */
+ * (nf_nerf_wgrad_floats floats); workspace = nf_nerf_wgrad_workspace_floats(cx, cd, nslices) floats.
+ * dbias (NF_DPRE_STRIDE floats, or NULL) = the column sums of dpre over the n_rows rows = the 12 bias gradients in dpre's
+ * column order, added up from the operand slabs the GEMMs stage anyway (no separate pass over dpre). */
 size_t nf_nerf_wgrad_floats(int cx, int cd);
 size_t nf_nerf_wgrad_workspace_floats(int cx, int cd, int nslices);
 int nf_nerf_wgrad(const float* dpre, const float* acts, const float* X, int cx, int cd, int n_rows, int nslices,
-                  float* workspace, float* dweights, nf_stream_t stream);
+                  float* workspace, float* dweights, float* dbias, nf_stream_t stream);
 
 /* A8: alpha compositing (models/renderer.py:182-208), one thread per ray, sequential products.
  * gate_by_mask != 0 (use_mask): rgbsigma is read only where mask != 0 and taken as zero elsewhere

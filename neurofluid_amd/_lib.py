@@ -59,7 +59,7 @@ PROTOTYPES = {
     "nf_nerf_mlp_fwd_s": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "nf_nerf_wgrad_floats": (c_size_t, [c_int, c_int]),
     "nf_nerf_wgrad_workspace_floats": (c_size_t, [c_int, c_int, c_int]),
-    "nf_nerf_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "nf_nerf_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nf_composite_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                  c_void_p, c_void_p, c_int, c_void_p]),
     "nf_nerf_packed_bwd_floats": (c_size_t, []),

@@ -71,14 +71,15 @@ def _pass_backward(net, nerf, pb, rays_c, z, z_table, g_rgb, white_bg, particles
     nsl = 16          # 46 tiles x 16 row slices = 736 workgroups (3 per CU); 11...44 slices measure the same
     blob = torch.empty(lib.nf_nerf_wgrad_floats(cx, cd), dtype=torch.float32, device=dev)
     wsp = torch.empty(lib.nf_nerf_wgrad_workspace_floats(cx, cd, nsl), dtype=torch.float32, device=dev)
-    check(lib.nf_nerf_wgrad(ptr(dpre_full), ptr(pb.acts), ptr(pb.X), cx, cd, n, nsl, ptr(wsp), ptr(blob), st), "nf_nerf_wgrad")
+    colsum = torch.empty(DPRE, dtype=torch.float32, device=dev)
+    check(lib.nf_nerf_wgrad(ptr(dpre_full), ptr(pb.acts), ptr(pb.X), cx, cd, n, nsl, ptr(wsp), ptr(blob), ptr(colsum), st),
+          "nf_nerf_wgrad")
     gw, o = [], 0
     for l in layers:
         k = l.weight.numel()
         gw.append(blob[o:o + k].view_as(l.weight))
         o += k
-    # bias gradients = column sums of dpre (one reduction)
-    colsum = dpre.sum(0)
+    # bias gradients = column sums of dpre, summed by the weight-gradient launch from the slabs it stages
     gb = [colsum[k * 256:(k + 1) * 256] for k in range(8)]
     gb += [colsum[8 * 256:9 * 256], colsum[9 * 256:9 * 256 + 128], colsum[2435:2436], colsum[2432:2435]]
     if dparticles is not None:

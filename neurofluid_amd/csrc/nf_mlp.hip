@@ -699,16 +699,18 @@ extern "C" int nf_nerf_mlp_bwd(const float* packed, const float* packed_t, int c
 // three, slices cut to one round of 506 workgroups: 744 vs 686 us per launch inside the training step.)
 // ================================================================================================
 #define WG_MAX_GEMMS 16
-struct NfWgradGemm { int a_col, b_src, b_col, M, N, c_off, ldc, c_col, tile0, tiles_n; };
+struct NfWgradGemm { int a_col, b_src, b_col, M, N, c_off, ldc, c_col, tile0, tiles_n, colsum; };
 struct NfWgradPlan { int ngemm, ntiles, total; NfWgradGemm g[WG_MAX_GEMMS]; };
 
 static NfWgradPlan wgrad_plan(int cx, int cd)
 {
     NfWgradPlan P;
-    int n = 0, off = 0, tiles = 0;
+    int n = 0, off = 0, tiles = 0, last_a = -1;
     auto add = [&](int a_col, int b_src, int b_col, int M, int N, int c_off, int ldc, int c_col) {
         NfWgradGemm& g = P.g[n++];
         g.a_col = a_col; g.b_src = b_src; g.b_col = b_col; g.M = M; g.N = N; g.c_off = c_off; g.ldc = ldc; g.c_col = c_col;
+        g.colsum = a_col != last_a;      // the first GEMM over a block of dpre columns also sums them (bias gradients)
+        last_a = a_col;
         g.tile0 = tiles; g.tiles_n = (N + 127) / 128;
         tiles += ((M + 127) / 128) * g.tiles_n;
     };
@@ -778,6 +780,9 @@ __global__ void __launch_bounds__(256) k_wgrad(NfWgradPlan P, const float* __res
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     float4 ra[4], rb[4];
+    // bias gradients = column sums of dpre: the n0 == 0 tiles of a block's first GEMM add up the A quads they stage anyway
+    const bool do_colsum = G.colsum && n0 == 0;
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
     auto load_slab = [&](int k0) {          // 32 rows x 32 quads per operand, 4 quads per thread, coalesced along the columns
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -802,6 +807,7 @@ __global__ void __launch_bounds__(256) k_wgrad(NfWgradPlan P, const float* __res
             const int e = tid + 256 * u, k = e >> 5, cq = (e & 31) * 4;
             *(float4*)&As[k][cq] = ra[u];
             *(float4*)&Bs[k][cq] = rb[u];
+            if (do_colsum) { cs.x += ra[u].x; cs.y += ra[u].y; cs.z += ra[u].z; cs.w += ra[u].w; }
         }
         __syncthreads();
         if (k0 + WG_KS < r1) load_slab(k0 + WG_KS);      // next slab in flight behind the MFMAs
@@ -829,7 +835,18 @@ __global__ void __launch_bounds__(256) k_wgrad(NfWgradPlan P, const float* __res
         }
         __syncthreads();
     }
-    float* out = partial + (size_t)blockIdx.y * P.total + G.c_off;
+    float* const slice = partial + (size_t)blockIdx.y * (P.total + NF_DPRE_STRIDE);
+    if (do_colsum) {        // 8 row groups (tid >> 5) hold partial sums of the same column quad: fold them through LDS
+        *(float4*)&As[tid >> 5][(tid & 31) * 4] = cs;
+        __syncthreads();
+        if (tid < 128 && tid < ma) {
+            float v = 0.f;
+#pragma unroll
+            for (int g8 = 0; g8 < 8; ++g8) v += As[g8][tid];
+            slice[P.total + G.a_col + m0 + tid] = v;
+        }
+    }
+    float* out = slice + G.c_off;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -842,19 +859,40 @@ __global__ void __launch_bounds__(256) k_wgrad(NfWgradPlan P, const float* __res
             }
 }
 
-__global__ void k_wgrad_reduce(const float* __restrict__ partial, int total, int nslices, float* __restrict__ out)
+// partial[slice][total + NF_DPRE_STRIDE] -> dweights[total] | dbias[NF_DPRE_STRIDE]; one float4 per thread, the slices in
+// groups of 4 independent loads (total and NF_DPRE_STRIDE are multiples of 4 floats)
+__global__ void k_wgrad_reduce(const float* __restrict__ partial, int total, int nslices, float* __restrict__ out,
+                               float* __restrict__ dbias)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    float s = 0.f;
-    for (int z = 0; z < nslices; ++z) s += partial[(size_t)z * total + i];
-    out[i] = s;
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int stride = total + NF_DPRE_STRIDE;
+    if (i >= stride) return;
+    const float* p = partial + i;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int z = 0;
+    for (; z + 4 <= nslices; z += 4) {
+        const float4 a = *(const float4*)(p + (size_t)z * stride), b = *(const float4*)(p + (size_t)(z + 1) * stride);
+        const float4 c = *(const float4*)(p + (size_t)(z + 2) * stride), d = *(const float4*)(p + (size_t)(z + 3) * stride);
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+        s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w;
+        s.x += d.x; s.y += d.y; s.z += d.z; s.w += d.w;
+    }
+    for (; z < nslices; ++z) {
+        const float4 a = *(const float4*)(p + (size_t)z * stride);
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    }
+    if (i < total) *(float4*)(out + i) = s;
+    else if (dbias) *(float4*)(dbias + (i - total)) = s;
 }
 
-extern "C" size_t nf_nerf_wgrad_workspace_floats(int cx, int cd, int nslices) { return (size_t)wgrad_plan(cx, cd).total * nslices; }
+extern "C" size_t nf_nerf_wgrad_workspace_floats(int cx, int cd, int nslices)
+{
+    return ((size_t)wgrad_plan(cx, cd).total + NF_DPRE_STRIDE) * nslices;
+}
 
 extern "C" int nf_nerf_wgrad(const float* dpre, const float* acts, const float* X, int cx, int cd, int n_rows,
-                             int nslices, float* workspace, float* dweights, nf_stream_t stream)
+                             int nslices, float* workspace, float* dweights, float* dbias, nf_stream_t stream)
 {
     NF_CHECK_ARG(dpre && acts && X && workspace && dweights, "null pointer");
     NF_CHECK_ARG(nslices >= 1 && nslices <= 65535, "bad slice count");
@@ -862,14 +900,15 @@ extern "C" int nf_nerf_wgrad(const float* dpre, const float* acts, const float* 
     hipStream_t st = (hipStream_t)stream;
     if (n_rows <= 0) {
         hipMemsetAsync(dweights, 0, sizeof(float) * P.total, st);
+        if (dbias) hipMemsetAsync(dbias, 0, sizeof(float) * NF_DPRE_STRIDE, st);
         return NF_OK;
     }
     int rows_per = (n_rows + nslices - 1) / nslices;
     rows_per = (rows_per + WG_KS - 1) / WG_KS * WG_KS;
     int ns = (n_rows + rows_per - 1) / rows_per;
     hipLaunchKernelGGL(k_wgrad, dim3(P.ntiles, ns), dim3(256), 0, st, P, dpre, acts, X, (cx + 7) / 8 + (cd + 7) / 8, n_rows, rows_per, workspace);
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((P.total + 255) / 256), dim3(256), 0, st, (const float*)workspace, P.total, ns,
-                       dweights);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(((P.total + NF_DPRE_STRIDE) / 4 + 255) / 256), dim3(256), 0, st,
+                       (const float*)workspace, P.total, ns, dweights, dbias);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }

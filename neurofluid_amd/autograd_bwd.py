@@ -233,9 +233,9 @@ class _ParticleNetFn(torch.autograd.Function):
             grads[conv.kernel] = dB[:, :64 * cout].reshape(cin, 64, cout).permute(1, 0, 2).reshape(conv.kernel.shape)
             grads[dense.weight] = dB[:, 64 * cout:].t().contiguous()
             grads[conv.bias] = dy.sum(0)
-            grads[dense.bias] = dy.sum(0)
+            grads[dense.bias] = grads[conv.bias].clone()
             dx = dG @ _virtual_b(conv.kernel, dense.weight).t()      # (n, Cin) plain GEMM
-            dprev = dx * (prev > 0).float()
+            dprev = torch.ops.aten.threshold_backward(dx, prev, 0.0)  # dx where prev > 0, else 0 (one kernel)
             if dense.out_features == prev.shape[-1]:
                 dprev = dprev + dy                                   # residual branch (transmodel.py:127-128)
             dy = dprev.contiguous()

@@ -24,11 +24,15 @@ tr = E2ETrainer(cfg)
 print("views", tr.train_view_names, "ray_chunk", cfg.RENDERER.ray.ray_chunk, "frames", len(tr.dataset))
 tr.train(max_steps=len(tr.dataset))        # warm-up: one pass over every frame (the dataset caches decoded frames)
 torch.cuda.synchronize()
-tr.start_step = 0
-t0 = time.time()
-tr.train(max_steps=steps)
-torch.cuda.synchronize()
-dt = (time.time() - t0) / steps
+blocks = []
+for _ in range(5):          # median of 5 blocks (a block is `steps` steps from the start of an epoch)
+    tr.start_step = 0
+    t0 = time.time()
+    tr.train(max_steps=steps)
+    torch.cuda.synchronize()
+    blocks.append((time.time() - t0) / steps)
+print("blocks (ms/step):", [round(b * 1e3, 2) for b in blocks])
+dt = sorted(blocks)[2]
 nv = len(tr.train_view_names)
 print(f"train_e2e step: {dt*1e3:.2f} ms  ({nv} views x {cfg.RENDERER.ray.ray_chunk} rays + transition fwd/bwd, "
       f"{nv * cfg.RENDERER.ray.ray_chunk / dt:.0f} rays/s)")

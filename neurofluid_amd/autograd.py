@@ -20,17 +20,25 @@ def _run_passes(net, particles, ro, rays, white_bg, fine, save_acts, _retry=Fals
     if net.mlp_dtype != "fp32" and save_acts:
         raise RuntimeError(f"RENDERER.mlp_dtype={net.mlp_dtype} is an inference path; train with fp32")
     ws = None if save_acts else net.workspace()
-    # learnt row capacities of the inference arena.  Training keeps exact sizing (a sync after each pass's search): a single
-    # verification at the end of the forward was measured SLOWER there (9.3 vs 8.3 ms per train_renderer step) — the host
-    # then starts enqueuing the loss and the backward only after the whole forward has finished
-    caps = ws.row_cap if ws is not None else None
+    # learnt row capacities: the inference arena's, or the module's own table for training passes.  Inference verifies the
+    # counts ONCE at the end of the call (torch.cat + tolist: it waits for the whole frame, which a rollout reads back
+    # anyway).  Training must not wait for its forward MLPs (the host still has the loss and the backward to enqueue): each
+    # pass's count is copied to pinned memory right behind its search kernel (ops.HostFetch) and read when the forward is
+    # enqueued — by then it has long arrived.  (Exact sizing — an `.item()` in the middle of each pass — left the GPU idle
+    # for ~100 us twice per step; one blocking verification at the end was worse still: 9.3 vs 8.3 ms in round 1.)
+    caps = ws.row_cap if ws is not None else net.train_row_cap
+    fetch = ops.HostFetch(dev) if save_acts else None
+    if fetch is not None:
+        fetch.add(grid.aabb_words())        # words 0..5: the cloud's bounds (the next grid's bbox hint), then one count per pass
+    after = (lambda n_rows: fetch.add(n_rows)) if fetch is not None else None
+    opt = not _retry
     if save_acts:
         pk0, ws0, ph0 = net.packed_weights(net.nerf_coarse), None, None
     else:
         pk0, ws0, ph0 = net.packed_for_inference(net.nerf_coarse, use_h)
     p0 = ops.render_pass(grid, pts, rays_c, None, z_table, net.N_samples, net.raduis, net.num_neighbor, net.enc_flags,
                          net.use_mask, ro_c, pk0, net.in_channels_xyz, net.in_channels_dir, white_bg, save_acts,
-                         packed_h=ph0, ws=ws, need_weights=fine, optimistic=not save_acts and not _retry, caps=caps, wstream=ws0)
+                         packed_h=ph0, ws=ws, need_weights=fine, optimistic=opt, caps=caps, wstream=ws0, after_search=after)
     p0.packed = pk0
     p1 = None
     if fine:
@@ -41,18 +49,23 @@ def _run_passes(net, particles, ro, rays, white_bg, fine, save_acts, _retry=Fals
             pk1, ws1, ph1 = net.packed_for_inference(net.nerf_fine, use_h)
         p1 = ops.render_pass(grid, pts, rays_c, z1, None, net.N_samples + net.N_importance, net.raduis, net.num_neighbor,
                              net.enc_flags, net.use_mask, ro_c, pk1, net.in_channels_xyz, net.in_channels_dir, white_bg,
-                             save_acts, packed_h=ph1, ws=ws, need_weights=False, optimistic=not save_acts and not _retry,
-                             caps=caps, wstream=ws1)
+                             save_acts, packed_h=ph1, ws=ws, need_weights=False, optimistic=opt, caps=caps, wstream=ws1,
+                             after_search=after)
         p1.z = z1
         p1.packed = pk1
     # Inference passes ran against learnt row capacities without a host round trip: verify ONCE, here, with the whole
     # call enqueued (a real rollout reads the image back anyway).  On overflow the capacities grow and the call is redone
     # with exact sizing; capacities also grow ahead of need when a count comes within 10 % of them.
     cap_runs = [(p, p.cap) for p in (p0, p1) if p is not None and p.cap is not None]
-    if cap_runs:
+    if fetch is not None:
+        got = fetch.get()                   # waits for the LAST search kernel only; the MLPs behind it stay queued
+        net.note_point_bounds(ops.decode_aabb(got[:6]))
+        counts = [got[6 + k] for k, p in enumerate((p0, p1)) if p is not None and p.cap is not None]
+    elif cap_runs:
         fetched = torch.cat([p.n_rows for p, _ in cap_runs] + [grid.aabb_words()]).tolist()
         counts = fetched[:len(cap_runs)]
         net.note_point_bounds(ops.decode_aabb(fetched[len(cap_runs):]))      # the next frame's grid bbox: no reduction + sync
+    if cap_runs:
         overflow = False
         for (p, cap), n in zip(cap_runs, counts):
             key = (p.R, p.S)

@@ -62,7 +62,10 @@ def _pass_backward(net, nerf, pb, rays_c, z, z_table, g_rgb, white_bg, particles
     cap = ops._round_rows(n)
     # e2e: the three dX GEMMs go through the vendor GEMM library, which pays ~80 ms the first time it meets a new
     # problem size (solution lookup + lazy code-object load); power-of-two row counts keep that to a handful of sizes
-    cap_g = max(cap, 1 << max(n - 1, 1).bit_length()) if dparticles is not None else cap
+    # ... up to 8 192 rows, multiples of 4 096 beyond (a 20 000-row pass pays for 20 480 rows, not 32 768)
+    cap_g = cap
+    if dparticles is not None:
+        cap_g = max(cap, 1 << max(n - 1, 1).bit_length()) if n <= 8192 else max(cap, (n + 4095) // 4096 * 4096)
     dpre_full = torch.empty(cap_g, DPRE, dtype=torch.float32, device=dev)
     dpre = dpre_full[:n]
     check(lib.nf_nerf_mlp_bwd(ptr(pb.packed), ptr(packed_t), cx, cd, ptr(pb.acts), ptr(pb.n_rows), n, ptr(pb.row_sample),
@@ -89,8 +92,10 @@ def _pass_backward(net, nerf, pb, rays_c, z, z_table, g_rgb, white_bg, particles
             dpre_full[n:].zero_()
         W1, W5, Wd = layers[0].weight.detach(), layers[4].weight.detach(), layers[9].weight.detach()
         dX = torch.empty(cap_g, cx + cd, dtype=torch.float32, device=dev)
-        dX[:, :cx] = dpre_full[:, 0:256] @ W1 + dpre_full[:, 4 * 256:5 * 256] @ W5[:, :cx]
-        dX[:, cx:] = dpre_full[:, 9 * 256:9 * 256 + 128] @ Wd[:, 256:]
+        # written in place by the GEMMs (strided C, beta = 1 for the skip layer's term): 3 launches, no temporaries
+        torch.mm(dpre_full[:, 0:256], W1, out=dX[:, :cx])
+        dX[:, :cx].addmm_(dpre_full[:, 4 * 256:5 * 256], W5[:, :cx])
+        torch.mm(dpre_full[:, 9 * 256:9 * 256 + 128], Wd[:, 256:], out=dX[:, cx:])
         check(lib.nf_render_features_bwd(ptr(particles), ptr(rays_c), ptr(z), ptr(z_table), R, S, float(net.raduis),
                                          net.num_neighbor, net.enc_flags, ptr(ro_c), int(ro_c.dim() == 2),
                                          ptr(pb.row_sample), ptr(pb.row_nbr), ptr(pb.n_rows), n, ptr(dX), ptr(dparticles),
@@ -112,6 +117,7 @@ def _side_stream(device):
 class _RenderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, particles, ro, rays, white_bg, fine, *params):
+        ctx.set_materialize_grads(False)      # backward reads rgb0 / rgb1 only: no zero tensors for the 8 other outputs
         p0, p1, rays_c, ro_c, grid = _run_passes(net, particles, ro, rays, white_bg, fine, save_acts=True)
         ctx.net, ctx.p0, ctx.p1, ctx.rays_c, ctx.white_bg, ctx.fine = net, p0, p1, rays_c, white_bg, fine
         ctx.particles_need_grad = particles.requires_grad
@@ -192,6 +198,7 @@ def _virtual_b(kernel, dense_w):
 class _ParticleNetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pn, pos, vel, box, box_feats, *params):
+        ctx.set_materialize_grads(False)      # g_pos / g_vel arrive as None when unused (backward handles both)
         pos_c, vel_c, nn, aux = pn._forward_impl(pos, vel, box, box_feats, keep=True)
         ctx.pn, ctx.aux = pn, aux
         ctx.box, ctx.box_feats = box.detach().contiguous().float(), box_feats.detach().contiguous().float()
@@ -211,7 +218,7 @@ class _ParticleNetFn(torch.autograd.Function):
         b_rs, b_idx, b_pw, b_pc = aux["b"]
         n = ans[0].shape[0]
         dev = ans[0].device
-        d_pos_c = torch.zeros(n, 3, device=dev) if g_pos is None else g_pos.detach().float().clone()
+        d_pos_c = torch.zeros(n, 3, device=dev) if g_pos is None else g_pos.detach().float()      # read only below
         if g_vel is not None:
             d_pos_c = d_pos_c + g_vel.detach().float() / dt          # vel_c = (pos_c - pos) / dt
         extent = float(pn.filter_extent)

@@ -327,9 +327,42 @@ class Workspace:
         return cur[:nbytes].view(dtype)[:max(int(numel), 1)]
 
 
+class HostFetch:
+    """A few int32 words read back WITHOUT stalling the launch stream: asynchronous copies into a pinned buffer + an event
+    recorded behind them.  The training forward enqueues the fetch of a pass's row count right behind its search kernel —
+    i.e. in front of the feature / MLP / composite launches — and waits for the event only when the whole forward is
+    enqueued: the count is on the host long before, and the GPU never runs dry behind a mid-pass `.item()`.
+    Pinned buffers come from a small per-device ring (allocating pinned memory costs ~1 ms); a slot is reused only after
+    its words were read."""
+    _ring = {}
+
+    def __init__(self, device):
+        key = (device.type, device.index)
+        ring = HostFetch._ring.setdefault(key, {"bufs": [torch.empty(16, dtype=torch.int32).pin_memory() for _ in range(8)], "i": 0})
+        self.buf = ring["bufs"][ring["i"] % 8]
+        ring["i"] += 1
+        self.n = 0
+        self.ev = None
+
+    def add(self, words):
+        """words: 1-D int32 device tensor.  Returns the slice of the result its values will occupy."""
+        k = words.numel()
+        assert self.n + k <= self.buf.numel() and words.dtype == torch.int32
+        self.buf[self.n:self.n + k].copy_(words, non_blocking=True)
+        sl = slice(self.n, self.n + k)
+        self.n += k
+        self.ev = torch.cuda.Event()
+        self.ev.record()
+        return sl
+
+    def get(self):
+        self.ev.synchronize()
+        return self.buf[:self.n].tolist()
+
+
 def render_pass(grid, particles, rays, z, z_table, S, radius, K, enc_flags, use_mask, ro, packed, cx, cd,
                 white_bg=True, save_acts=False, max_rows=None, packed_h=None, ws=None, need_weights=True, wstream=None,
-                optimistic=False, caps=None):
+                optimistic=False, caps=None, after_search=None):
     """Runs classify -> search -> features -> MLP -> composite for R rays x S samples.
     z: (R,S) per-ray depths or None (then z_table (S,) is shared by all rays).
     Returns a PassBuffers with rgb, depth, opacity, weights, num_nn, mask_sum and the row lists.
@@ -379,6 +412,8 @@ def render_pass(grid, particles, rays, z, z_table, S, radius, K, enc_flags, use_
                                ptr(cand), ptr(counters[0:1]), ptr(b.num_nn), None,
                                ptr(b.row_sample), ptr(b.row_nbr), ptr(counters[1:2]), st), "nf_render_search")
     b.n_rows = counters[1:2]
+    if after_search is not None:
+        after_search(b.n_rows)          # e.g. HostFetch.add: the count is final here, everything below is enqueued behind it
     b.cap = None
     alloc_rows = 0
     cap_key = (R, S)

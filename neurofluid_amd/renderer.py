@@ -76,6 +76,7 @@ class RenderNet(nn.Module):
         self._bbox_hint = None      # bounds of the last cloud, padded (note_point_bounds): the next grid's bbox
         self._grid_cache = (None, None, None)
         self._workspace = None
+        self.train_row_cap = {}     # (R, S) -> row capacity of a training pass (ops.render_pass; autograd._run_passes)
 
     # ------------------------------------------------------------------
     def set_ro(self, cw):

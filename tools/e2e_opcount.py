@@ -60,7 +60,7 @@ tr.update_step = update_step
 tr.trainsition_step_for_training = rf("transition_fwd", tr.trainsition_step_for_training)
 tr.renderer.forward = rf("render_fwd", tr.renderer.forward)
 tr._frame_on_device = rf("frame_on_device", tr._frame_on_device)
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
     tr.train(max_steps=steps)
     torch.cuda.synchronize()
 by = collections.Counter()
@@ -76,4 +76,13 @@ for ev in evs:
     by[((ph[-1] if ph else "(outside)") + (" / " + node[-1][:30] if node else ""), ev.name[:40])] += len(ev.kernels)
 for (frame, name), n in sorted(by.items(), key=lambda kv: -kv[1])[:70]:
     print("%6.1f /step  %-40s %s" % (n / steps, name, frame))
+if os.environ.get("NF_OPSEQ"):           # the launch sequence of the last step, in host order
+    last = [p_ for p_ in phases if p_[2] == "frame_on_device"][-1][0]
+    for ev in sorted(evs, key=lambda e: e.time_range.start):
+        if ev.kernels and not ev.name.startswith("PH:") and ev.time_range.start >= last:
+            t = ev.time_range.start
+            ph = [n for a, b, n in phases if a <= t <= b]
+            node = [n for a, b, n in fns if a <= t <= b and n != ev.name]
+            print("%9.0f %-16s %-28s %-28s %s" % (t - last, ph[-1] if ph else "-", node[-1][:28] if node else "", ev.name[:28],
+                                              str(ev.input_shapes)[:70]))
 print("total kernels per step: %.0f" % (sum(by.values()) / steps))

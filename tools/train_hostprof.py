@@ -33,7 +33,7 @@ t0 = time.perf_counter(); host = 0.0
 for _ in range(N):
     t = time.perf_counter(); step(); host += time.perf_counter() - t
 torch.cuda.synchronize()
-print("%s: step %.2f ms wall, %.2f ms inside step() on the host (incl. its two sizing syncs)" %
+print("%s: step %.2f ms wall, %.2f ms inside step() on the host (incl. the wait for its row counts)" %
       (sys.argv[1] if len(sys.argv) > 1 else "default", (time.perf_counter() - t0) / N * 1e3, host / N * 1e3))
 if os.environ.get("NF_CPROFILE") == "1":
     import cProfile, pstats

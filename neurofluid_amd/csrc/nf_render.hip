@@ -1169,6 +1169,130 @@ __global__ void __launch_bounds__(128) k_features_bwd(const float* __restrict__ 
     }
 }
 
+// Wave per row (K <= 64; every e2e launch: 5 000 - 50 000 rows).  With a thread per row a launch is a few hundred waves,
+// each walking 252 strided loads of its dX row, ten double-precision sincos chains and three neighbour loops one after the
+// other (203 us for 19 500 rows, however idle the chip).  Here lane k owns neighbour k (gathers, weights, atomics side by side,
+// the sums over neighbours as wave reductions), the dX row is read with four coalesced loads into LDS, and the ten encoded
+// scalars (density, smoothed position, variance, smoothed direction) are differentiated by ten lanes at once — one sincos
+// chain deep instead of ten.  Same formulas as k_features_bwd; the neighbour sums associate differently (tree instead of
+// k = 0..K-1), a relative 1e-7 on the recomputed forward values.
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int FLAGS>
+__global__ void __launch_bounds__(256) k_features_bwd_w(const float* __restrict__ particles, const float* __restrict__ rays,
+                                                        const float* __restrict__ z, const float* __restrict__ z_table,
+                                                        int S, float radius, int K, const float* __restrict__ ro_base,
+                                                        int ro_stride, const int* __restrict__ row_sample,
+                                                        const int* __restrict__ row_nbr, const int* __restrict__ n_rows,
+                                                        int max_rows, const float* __restrict__ dX /*row-major*/,
+                                                        float* __restrict__ dparticles)
+{
+    constexpr int CX = 63 + ((FLAGS & 1) ? 9 : 0) + ((FLAGS & 2) ? 63 : 0) + ((FLAGS & 4) ? 63 : 0);
+    constexpr int CD = 27 + ((FLAGS & 8) ? 27 : 0);
+    constexpr int OFF_DEN = 63, OFF_SM = OFF_DEN + ((FLAGS & 1) ? 9 : 0), OFF_VAR = OFF_SM + ((FLAGS & 2) ? 63 : 0);
+    constexpr int OFF_SDIR = CX + 27;
+    __shared__ float gs[4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* g = gs[wave];
+    const int nrows = min(*n_rows, max_rows);
+    for (int row = blockIdx.x * 4 + wave; row < nrows; row += gridDim.x * 4) {
+        const int sample = row_sample[row];
+        float px[3], zv;
+        sample_xyz(rays, z, z_table, S, sample, px[0], px[1], px[2], zv);
+        const float* ro = ro_base + (size_t)ro_stride * (sample / S);
+        const float* grow = dX + (size_t)row * (CX + CD);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (lane + 64 * u < CX + CD) g[lane + 64 * u] = grow[lane + 64 * u];
+        // ---- forward recompute: lane k = neighbour k
+        const int j = lane < K ? row_nbr[(size_t)row * K + lane] : -1;
+        float n[3] = {0.f, 0.f, 0.f};
+        bool valid = false;
+        if (j >= 0) {
+            n[0] = particles[3 * (size_t)j]; n[1] = particles[3 * (size_t)j + 1]; n[2] = particles[3 * (size_t)j + 2];
+            valid = nf_dist2(px[0], px[1], px[2], n[0], n[1], n[2]) != 0.f;
+        }
+        const float d[3] = {n[0] - px[0], n[1] - px[1], n[2] - px[2]};
+        const float dist = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        const float t = dist / radius;
+        // padded entries (j < 0) take part in the sums with n = 0, as in the forward (and in k_features_bwd); lanes >= K do not
+        const float w = lane < K ? fmaxf(1.f - t * t * t, 0.f) : 0.f;
+        const float sw = wave_sum(w);
+        const float swp[3] = {wave_sum(w * n[0]), wave_sum(w * n[1]), wave_sum(w * n[2])};
+        const float sd[3] = {wave_sum(valid ? d[0] : 0.f), wave_sum(valid ? d[1] : 0.f), wave_sum(valid ? d[2] : 0.f)};
+        const int nvalid = __popcll(__ballot(valid));
+        const float den = sw + 1e-12f, nn_f = (float)nvalid + 1e-12f;
+        const float sm[3] = {swp[0] / den, swp[1] / den, swp[2] / den};
+        const float mean[3] = {sd[0] / nn_f, sd[1] / nn_f, sd[2] / nn_f};
+        float var[3] = {0.f, 0.f, 0.f}, resid[3] = {0.f, 0.f, 0.f};
+        if (FLAGS & 4) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float e = valid ? d[c] - mean[c] : 0.f;
+                var[c] = wave_sum(e * e) / nn_f;
+                resid[c] = wave_sum(e);
+            }
+        }
+        float u3[3] = {sm[0] - ro[0], sm[1] - ro[1], sm[2] - ro[2]};
+        const float nu = sqrtf(u3[0] * u3[0] + u3[1] * u3[1] + u3[2] * u3[2]);
+        const float sdir[3] = {u3[0] / nu, u3[1] / nu, u3[2] / nu};
+        // ---- the ten encoded scalars, one per lane: 0 density | 1-3 smoothed position | 4-6 variance | 7-9 smoothed direction
+        float acc = 0.f;
+        {
+            const int grp = lane == 0 ? 0 : (lane < 4 ? 1 : (lane < 7 ? 2 : 3));
+            const int c = lane == 0 ? 0 : (lane - 1) % 3;
+            const bool on = lane < 10 && ((grp == 0 && (FLAGS & 1)) || (grp == 1 && (FLAGS & 2)) || (grp == 2 && (FLAGS & 4)) ||
+                                          (grp == 3 && (FLAGS & 8)));
+            const int base = grp == 0 ? OFF_DEN : (grp == 1 ? OFF_SM : (grp == 2 ? OFF_VAR : OFF_SDIR));
+            const int C = grp == 0 ? 1 : 3, NF = (grp == 0 || grp == 3) ? 4 : 10;
+            const float v = grp == 0 ? sw : (grp == 1 ? sm[c] : (grp == 2 ? var[c] : sdir[c]));
+            if (on) {
+                acc = g[base + c];
+                double sdb, cdb;                 // same double-precision angle doubling as the forward encoding
+                sincos((double)v, &sdb, &cdb);
+                for (int f = 0; f < NF; ++f) {
+                    const float fr = (float)(1 << f);
+                    const float sf = (float)sdb, cf = (float)cdb;
+                    acc += fr * (g[base + C * (1 + 2 * f) + c] * cf - g[base + C * (2 + 2 * f) + c] * sf);
+                    const double s2 = 2.0 * sdb * cdb, c2 = 1.0 - 2.0 * sdb * sdb;
+                    sdb = s2; cdb = c2;
+                }
+            }
+        }
+        const float d_den = __shfl(acc, 0, 64);
+        float d_sm[3] = {__shfl(acc, 1, 64), __shfl(acc, 2, 64), __shfl(acc, 3, 64)};
+        const float d_var[3] = {__shfl(acc, 4, 64), __shfl(acc, 5, 64), __shfl(acc, 6, 64)};
+        if (FLAGS & 8) {
+            const float d_sdir[3] = {__shfl(acc, 7, 64), __shfl(acc, 8, 64), __shfl(acc, 9, 64)};
+            const float dot = sdir[0] * d_sdir[0] + sdir[1] * d_sdir[1] + sdir[2] * d_sdir[2];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) d_sm[c] += (d_sdir[c] - sdir[c] * dot) / nu;
+        }
+        const float dN[3] = {d_sm[0] / den, d_sm[1] / den, d_sm[2] / den};
+        const float d_sw = d_den - (d_sm[0] * sm[0] + d_sm[1] * sm[1] + d_sm[2] * sm[2]) / den;
+        // ---- scatter: lane k -> neighbour k
+        if (j >= 0) {
+            const float dw = dN[0] * n[0] + dN[1] * n[1] + dN[2] * n[2] + d_sw;
+            const float coef = (1.f - t * t * t) > 0.f ? dw * (-3.f * dist / (radius * radius * radius)) : 0.f;
+            float gp[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) gp[c] = w * dN[c] + coef * d[c];
+            if ((FLAGS & 4) && valid) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) gp[c] += d_var[c] * (2.f / nn_f) * ((d[c] - mean[c]) - resid[c] / nn_f);
+            }
+            atomicAdd(dparticles + 3 * (size_t)j, gp[0]);
+            atomicAdd(dparticles + 3 * (size_t)j + 1, gp[1]);
+            atomicAdd(dparticles + 3 * (size_t)j + 2, gp[2]);
+        }
+    }
+}
+
 extern "C" int nf_render_features_bwd(const float* particles, const float* rays, const float* z, const float* z_table,
                                       int R, int S, float radius, int K, int enc_flags, const float* ro, int ro_per_ray,
                                       const int32_t* row_sample, const int32_t* row_nbr, const int32_t* n_rows,
@@ -1180,11 +1304,17 @@ extern "C" int nf_render_features_bwd(const float* particles, const float* rays,
     if (max_rows <= 0) return NF_OK;
     int blocks = (max_rows + 127) / 128;
     if (blocks > 4096) blocks = 4096;
+    int blocks_w = (max_rows + 3) / 4;
+    if (blocks_w > 16384) blocks_w = 16384;
     hipStream_t st = (hipStream_t)stream;
 #define NF_FB_CASE(F)                                                                                                   \
     case F:                                                                                                             \
-        hipLaunchKernelGGL(k_features_bwd<F>, dim3(blocks), dim3(128), 0, st, particles, rays, z, z_table, S, radius, K, ro, \
-                           ro_per_ray ? 3 : 0, row_sample, row_nbr, n_rows, max_rows, dX, dparticles);                   \
+        if (K <= 64)                                                                                                    \
+            hipLaunchKernelGGL(k_features_bwd_w<F>, dim3(blocks_w), dim3(256), 0, st, particles, rays, z, z_table, S, radius, \
+                               K, ro, ro_per_ray ? 3 : 0, row_sample, row_nbr, n_rows, max_rows, dX, dparticles);       \
+        else                                                                                                            \
+            hipLaunchKernelGGL(k_features_bwd<F>, dim3(blocks), dim3(128), 0, st, particles, rays, z, z_table, S, radius, K, \
+                               ro, ro_per_ray ? 3 : 0, row_sample, row_nbr, n_rows, max_rows, dX, dparticles);           \
         break;
     switch (enc_flags) {
         NF_FB_CASE(0) NF_FB_CASE(1) NF_FB_CASE(2) NF_FB_CASE(3) NF_FB_CASE(4) NF_FB_CASE(5) NF_FB_CASE(6) NF_FB_CASE(7)

@@ -727,6 +727,31 @@ def test_features_backward_kernel_vs_oracle_autograd(dev):
         print(f"features backward, S={S}: {n} rows, relative error {rel:.2e}")
         assert rel < 1e-4, (S, rel)
         assert torch.equal(ref.abs().sum(1) > 0, dP.cpu().abs().sum(1) > 0)
+    # K <= 64 runs a wave per row, K > 64 a thread per row: the same rows through both, the neighbour lists padded to 72
+    # columns with -1 for the second.  A padded entry counts as a particle at the origin in the density sums (as in the
+    # forward), so the scene is moved one unit down first: weight 0, and the two kernels must agree — up to the order of
+    # the neighbour sums (tree vs k = 0..K-1: 1e-7 on the smoothed position, times the 2^9 of the highest encoding
+    # frequency in the gradient of sin(2^9 x): a few 1e-5).
+    shift = torch.tensor([0.0, 0.0, -1.0])
+    rays_s = rays.clone(); rays_s[:, :3] += shift
+    with torch.no_grad():
+        q0, _, rays_sc, ro_sc, grid_s = _run_passes(net, (P0 + shift).to(dev), (roc + shift).to(dev), rays_s.to(dev), True, True,
+                                                    save_acts=True)
+    n, K = int(q0.n_rows.item()), net.num_neighbor
+    assert n > 500
+    dX = torch.randn(n, 252, generator=torch.Generator().manual_seed(7)).to(dev)
+    nbr72 = torch.full((n, 72), -1, dtype=torch.int32, device=dev)
+    nbr72[:, :K] = q0.row_nbr[:n * K].view(n, K)
+    got = []
+    for kk, nbr in ((K, q0.row_nbr), (72, nbr72)):
+        dP = torch.zeros(P0.shape, device=dev)
+        check(lib.nf_render_features_bwd(ptr(grid_s.points), ptr(rays_sc), None, ptr(z_table), R, 64, float(net.raduis), kk,
+                                         net.enc_flags, ptr(ro_sc), 0, ptr(q0.row_sample), ptr(nbr), ptr(q0.n_rows), n,
+                                         ptr(dX), ptr(dP), _lib.stream()), "nf_render_features_bwd")
+        got.append(dP)
+    rel72 = float((got[1] - got[0]).norm() / got[0].norm())
+    print(f"thread-per-row kernel (K = 72, padded) vs wave-per-row (K = {K}): {rel72:.2e}")
+    assert rel72 < 3e-4, rel72
 
 
 def test_fine_rendering_entry_point(dev):

@@ -524,46 +524,88 @@ extern "C" int nf_cconv_gather_update(const float* G, int pitch_fluid, const int
 // dG[j][cell][co] = sum over entries (j <- i) of the TRANSPOSED pair cache: tpw * dy[i][co]   (fluid<->fluid is
 // symmetric: i in N(j) <=> j in N(i), so row j of the same CSR lists exactly the rows i that gathered from j; the
 // transposed cache holds the pair's interpolation data as seen from i).  dG[j][64][co] = dy[j][co] (Linear branch).
-// One wave per row, a private 64 x Cout tile in LDS, no atomics, deterministic.
+// One wave per row, a private 64 x Cout tile in LDS (ds_add_f32 from one wave only: in order), no global atomics, deterministic.
 __global__ void __launch_bounds__(256) k_cconv_gather_t(const float* __restrict__ dy, int cout,
                                                         const int64_t* __restrict__ row_splits,
                                                         const int32_t* __restrict__ nbr, const float* __restrict__ tpw,
                                                         const uint8_t* __restrict__ tpc, int n, float* __restrict__ dG)
 {
+    // Lane t of the wave holds pair t of the current chunk of 64 (neighbour index, 8 corner weights, 8 corner cells packed in
+    // two words); the loop over the pairs reads them with v_readlane into scalar registers.  (Staged through LDS instead,
+    // every pair cost three dependent LDS round trips before its first tile update — 1 100 cycles per pair with one wave
+    // per SIMD; and ds_add_f32 in place of the read-add-write runs at a fraction of the plain LDS rate: 405 vs 87 us.)
     extern __shared__ float tile_all[];
-    __shared__ int s_j[4][64];
-    __shared__ float s_w[4][64 * 8];
-    __shared__ int s_c[4][64 * 8];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float* tile = tile_all + wv * 64 * cout;
     const int ntot = 65 * cout;
-    for (int row = blockIdx.x * 4 + wv; row < n; row += gridDim.x * 4) {
+    const int wpb = blockDim.x >> 6;
+    for (int row = blockIdx.x * wpb + wv; row < n; row += gridDim.x * wpb) {
         for (int t = lane; t < 64 * cout; t += 64) tile[t] = 0.f;
-        __builtin_amdgcn_wave_barrier();
-        int64_t s = row_splits[row], e = row_splits[row + 1];
+        const int64_t s = row_splits[row], e = row_splits[row + 1];
         for (int64_t base = s; base < e; base += 64) {
-            int cnt = (int)((e - base) < 64 ? (e - base) : 64);
+            const int cnt = __builtin_amdgcn_readfirstlane((int)((e - base) < 64 ? (e - base) : 64));
+            int jl = 0, c03 = 0, c47 = 0;
+            float w8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (lane < cnt) {
-                int64_t p = base + lane;
-                s_j[wv][lane] = nbr[p];
+                const int64_t p = base + lane;
+                jl = nbr[p];
+                unsigned long long seen = 0ull;
+                bool distinct = true;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) { s_w[wv][lane * 8 + k] = tpw[p * 8 + k]; s_c[wv][lane * 8 + k] = tpc[p * 8 + k]; }
-            }
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            for (int co = lane; co < cout; co += 64)
-                for (int t = 0; t < cnt; ++t) {
-                    float g = dy[(size_t)s_j[wv][t] * cout + co];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) tile[s_c[wv][t * 8 + k] * cout + co] += s_w[wv][t * 8 + k] * g;
+                for (int k = 0; k < 8; ++k) {
+                    w8[k] = tpw[p * 8 + k];
+                    const int c = tpc[p * 8 + k];
+                    if (k < 4) c03 |= c << (8 * k); else c47 |= c << (8 * (k - 4));
+                    distinct &= !((seen >> c) & 1ull);
+                    seen |= 1ull << c;
                 }
-            __builtin_amdgcn_wave_barrier();
+                // the 8 corner cells of a pair are pairwise distinct unless the interpolation was clamped at the filter's
+                // border: then (and only then) its updates must run one after the other
+                if (distinct) c47 |= 1 << 31;
+            }
+            for (int co = lane; co < cout; co += 64) {
+                // dy rows of 8 pairs at a time, the next 8 in flight behind the LDS work of these
+                float g8[8], g8n[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) g8[u] = u < cnt ? dy[(size_t)__builtin_amdgcn_readlane(jl, u) * cout + co] : 0.f;
+                for (int t0 = 0; t0 < cnt; t0 += 8) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        g8n[u] = t0 + 8 + u < cnt ? dy[(size_t)__builtin_amdgcn_readlane(jl, t0 + 8 + u) * cout + co] : 0.f;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int t = t0 + u;
+                        if (t >= cnt) break;
+                        const float g = g8[u];
+                        const int a03 = __builtin_amdgcn_readlane(c03, t), a47 = __builtin_amdgcn_readlane(c47, t);
+                        int a[8];
+                        float wk[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            a[k] = (((k < 4 ? a03 >> (8 * k) : a47 >> (8 * (k - 4))) & 63)) * cout + co;
+                            wk[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w8[k]), t));
+                        }
+                        if (a47 < 0) {          // distinct cells: 8 independent reads, 8 FMAs, 8 writes (the same sums as the chain)
+                            float v[8];
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) v[k] = tile[a[k]];
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) v[k] += wk[k] * g;
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) tile[a[k]] = v[k];
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) tile[a[k]] += wk[k] * g;
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) g8[u] = g8n[u];
+                }
+            }
         }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
         float* out = dG + (size_t)row * ntot;
         for (int t = lane; t < 64 * cout; t += 64) out[t] = tile[t];
         for (int co = lane; co < cout; co += 64) out[64 * cout + co] = dy[(size_t)row * cout + co];
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -573,10 +615,13 @@ extern "C" int nf_cconv_gather_bwd(const float* dy, int cout, const int64_t* row
     NF_CHECK_ARG(dy && row_splits && dG, "null pointer");
     NF_CHECK_ARG(cout >= 1 && cout <= 64, "cout must be in [1,64]");
     if (n <= 0) return NF_OK;
-    int blocks = (n + 3) / 4;
-    if (blocks > 4096) blocks = 4096;
-    size_t lds = (size_t)4 * 64 * cout * sizeof(float);
-    hipLaunchKernelGGL(k_cconv_gather_t, dim3(blocks), dim3(256), lds, (hipStream_t)stream, dy, cout, row_splits, nbr,
+    // one wave per workgroup (16 KB of LDS at cout = 64): 55 us per launch at 4 913 particles x 39 pairs, 59 with four.  The
+    // kernel is bound by its instruction count (~150 per pair and wave), not by LDS or memory: see DESIGN section 6
+    const int wpb = 1;
+    int blocks = (n + wpb - 1) / wpb;
+    if (blocks > 16384) blocks = 16384;
+    size_t lds = (size_t)wpb * 64 * cout * sizeof(float);
+    hipLaunchKernelGGL(k_cconv_gather_t, dim3(blocks), dim3(64 * wpb), lds, (hipStream_t)stream, dy, cout, row_splits, nbr,
                        pair_w_t, pair_cell_t, n, dG);
     NF_CHECK_LAUNCH();
     return NF_OK;

@@ -382,8 +382,11 @@ __device__ __forceinline__ void emit_pe(EM& em, const float (&x)[C])
     }
 }
 
-template <int FLAGS, bool HALF>
-__global__ void __launch_bounds__(128) k_features(const float* __restrict__ particles, const float* __restrict__ rays,
+// KC = K when K is 20 (the configs' value; 0 = any K): the row's neighbour indices are five 16-B loads kept in registers
+// for both sweeps, and the sweeps unroll, so the 20 position gathers of a sweep are in flight together instead of one
+// index -> position chain after the other.  Same arithmetic, same order.
+template <int FLAGS, bool HALF, int KC>
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 8))) k_features(const float* __restrict__ particles, const float* __restrict__ rays,
                                                   const float* __restrict__ z, const float* __restrict__ z_table, int S,
                                                   float radius, int K, const float* __restrict__ ro_base, int ro_stride,
                                                   const int* __restrict__ row_sample, const int* __restrict__ row_nbr,
@@ -403,8 +406,22 @@ __global__ void __launch_bounds__(128) k_features(const float* __restrict__ part
         float sw = 0.f, swx = 0.f, swy = 0.f, swz = 0.f;
         float sx = 0.f, sy = 0.f, sz = 0.f;
         int nvalid = 0;
-        for (int k = 0; k < K; ++k) {
-            int j = row_nbr[(size_t)row * K + k];
+        int nb[KC > 0 ? KC : 1];
+        if constexpr (KC > 0) {
+#pragma unroll
+            for (int q4 = 0; q4 < KC / 4; ++q4) {
+                const int4 v = *(const int4*)(row_nbr + (size_t)row * KC + 4 * q4);
+                nb[4 * q4] = v.x; nb[4 * q4 + 1] = v.y; nb[4 * q4 + 2] = v.z; nb[4 * q4 + 3] = v.w;
+            }
+        }
+        const int Kn = KC > 0 ? KC : K;
+        // measured on the 400^2 frame (us per launch, coarse + fine average): fp32 X 479 -> 328 (full unroll) -> 315 (<= 128
+        // registers); fp16 X 421 -> 444 (full unroll) / 501 (capped) -> 336 with the sweeps unrolled by 10
+        constexpr int UN = HALF ? 10 : 20;
+#pragma unroll UN
+        for (int k = 0; k < Kn; ++k) {
+            int j;
+            if constexpr (KC > 0) j = nb[k]; else j = row_nbr[(size_t)row * K + k];
             float nx = 0.f, ny = 0.f, nz = 0.f;
             bool valid = false;
             if (j >= 0) {
@@ -424,8 +441,10 @@ __global__ void __launch_bounds__(128) k_features(const float* __restrict__ part
         float mean[3] = {sx / nn_f, sy / nn_f, sz / nn_f};
         float var[3] = {0.f, 0.f, 0.f};
         if (FLAGS & 4) {
-            for (int k = 0; k < K; ++k) {
-                int j = row_nbr[(size_t)row * K + k];
+#pragma unroll UN
+            for (int k = 0; k < Kn; ++k) {
+                int j;
+                if constexpr (KC > 0) j = nb[k]; else j = row_nbr[(size_t)row * K + k];
                 if (j < 0) continue;
                 float nx = particles[3 * (size_t)j], ny = particles[3 * (size_t)j + 1], nz = particles[3 * (size_t)j + 2];
                 if (nf_dist2(px[0], px[1], px[2], nx, ny, nz) == 0.f) continue;
@@ -473,13 +492,21 @@ extern "C" int nf_render_features(const float* particles, const float* rays, con
     int blocks = (max_rows + 127) / 128;
     if (blocks > 4096) blocks = 4096;
     hipStream_t st = (hipStream_t)stream;
+    // K = 20 with the row lists 16-B aligned (80-B rows): the specialised kernel; only the default encoding gets it (15)
+    const bool k20 = K == 20 && enc_flags == 15 && (((uintptr_t)row_nbr) & 15) == 0;
 #define NF_FEAT_CASE(F)                                                                                              \
     case F:                                                                                                          \
-        if (x_fp16)                                                                                                  \
-            hipLaunchKernelGGL((k_features<F, true>), dim3(blocks), dim3(128), 0, st, particles, rays, z, z_table, S, radius, \
+        if (x_fp16 && k20)                                                                                           \
+            hipLaunchKernelGGL((k_features<F, true, 20>), dim3(blocks), dim3(128), 0, st, particles, rays, z, z_table, S, radius, \
+                               K, ro, ro_per_ray ? 3 : 0, row_sample, row_nbr, n_rows, max_rows, X);                 \
+        else if (x_fp16)                                                                                             \
+            hipLaunchKernelGGL((k_features<F, true, 0>), dim3(blocks), dim3(128), 0, st, particles, rays, z, z_table, S, radius, \
+                               K, ro, ro_per_ray ? 3 : 0, row_sample, row_nbr, n_rows, max_rows, X);                 \
+        else if (k20)                                                                                                \
+            hipLaunchKernelGGL((k_features<F, false, 20>), dim3(blocks), dim3(128), 0, st, particles, rays, z, z_table, S, radius, \
                                K, ro, ro_per_ray ? 3 : 0, row_sample, row_nbr, n_rows, max_rows, X);                 \
         else                                                                                                         \
-            hipLaunchKernelGGL((k_features<F, false>), dim3(blocks), dim3(128), 0, st, particles, rays, z, z_table, S, radius, \
+            hipLaunchKernelGGL((k_features<F, false, 0>), dim3(blocks), dim3(128), 0, st, particles, rays, z, z_table, S, radius, \
                                K, ro, ro_per_ray ? 3 : 0, row_sample, row_nbr, n_rows, max_rows, X);                 \
         break;
     switch (enc_flags) {

@@ -43,7 +43,9 @@ __device__ __forceinline__ void sample_xyz(const float* __restrict__ rays, const
 // z as one 16-B load).  num_nn / mask of the whole quad are cleared with one 16-B and one 4-B store — the
 // search overwrites the candidates afterwards — and nothing is written to rgbsigma: compositing reads it only
 // where mask = 1 (use_mask) and the MLP fills exactly those rows.
+#ifndef CL_GROUPS
 #define CL_GROUPS 2
+#endif
 template <bool HAS_MASK>
 __global__ void __launch_bounds__(256) k_classify(const void* __restrict__ ws, const float* __restrict__ rays,
                                                   const float* __restrict__ z, const float* __restrict__ z_table, int R,

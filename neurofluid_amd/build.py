@@ -29,14 +29,22 @@ def build(force=False, verbose=False):
     headers.append(os.path.join(os.path.dirname(HERE), "include", "neurofluid_hip.h"))
     objs = []
     procs = []
+    stamps = []
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
         if not os.path.exists(sp):
             continue
         obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
         objs.append(obj)
-        if force or _stale(obj, [sp] + headers):
-            cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", sp, "-o", obj]
+        cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", sp, "-o", obj]
+        # an object is also stale when it was built with other flags (A/B builds with NF_EXTRA_DEFS must not leave their
+        # objects behind for the next plain build): the command line is kept next to the object
+        stamp = obj + ".cmd"
+        same_cmd = os.path.exists(stamp) and open(stamp).read() == " ".join(cmd)
+        if force or not same_cmd or _stale(obj, [sp] + headers):
+            if os.path.exists(stamp):
+                os.remove(stamp)
+            stamps.append((stamp, " ".join(cmd)))
             if verbose:
                 print(" ".join(cmd))
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -50,6 +58,9 @@ def build(force=False, verbose=False):
             print(out.decode())
     if failed:
         raise RuntimeError("hipcc failed")
+    for stamp, text in stamps:
+        with open(stamp, "w") as f:
+            f.write(text)
     if force or procs or _stale(LIB, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         subprocess.check_call(cmd)

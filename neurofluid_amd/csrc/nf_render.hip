@@ -44,7 +44,7 @@ __device__ __forceinline__ void sample_xyz(const float* __restrict__ rays, const
 // search overwrites the candidates afterwards — and nothing is written to rgbsigma: compositing reads it only
 // where mask = 1 (use_mask) and the MLP fills exactly those rows.
 #ifndef CL_GROUPS
-#define CL_GROUPS 2
+#define CL_GROUPS 1      // quads per thread; 1 / 2 / 4: 103 / 114 / 147 us per launch (400^2 frame, coarse + fine average)
 #endif
 template <bool HAS_MASK>
 __global__ void __launch_bounds__(256) k_classify(const void* __restrict__ ws, const float* __restrict__ rays,
@@ -418,8 +418,11 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 8))
         }
         const int Kn = KC > 0 ? KC : K;
         // measured on the 400^2 frame (us per launch, coarse + fine average): fp32 X 479 -> 328 (full unroll) -> 315 (<= 128
-        // registers); fp16 X 421 -> 444 (full unroll) / 501 (capped) -> 336 with the sweeps unrolled by 10
-        constexpr int UN = HALF ? 10 : 20;
+        // registers); fp16 X 421 -> 444 (full unroll) / 501 (capped); sweeps unrolled by 2 / 4 / 5 / 10: 338 / 332 / 327 / 346
+#ifndef NF_FEAT_UNH
+#define NF_FEAT_UNH 5
+#endif
+        constexpr int UN = HALF ? NF_FEAT_UNH : 20;
 #pragma unroll UN
         for (int k = 0; k < Kn; ++k) {
             int j;

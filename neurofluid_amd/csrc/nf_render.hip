@@ -745,17 +745,24 @@ extern "C" int nf_composite_fwd(const float* rgbsigma, const float* z, const flo
 // ray because the coarse depths are shared (computed once by this very kernel on one zero-weight ray, so the bits
 // are those of the general path).  Rays that hit nothing (the large majority of an image) then cost one pass over
 // their weights and a coalesced 64-lane copy of that row instead of the serial inverse-CDF walk.
+#define IS_PITCH (IS_BLOCK + 1)       // LDS rows [k][thread] with an odd pitch: conflict-free by thread (own column) AND by k (write-out)
 __global__ void __launch_bounds__(IS_BLOCK) k_importance(const float* __restrict__ z0, const float* __restrict__ w0,
                                                          const float* __restrict__ u_table, int R, int S0, int NI,
                                                          const float* __restrict__ zero_row, float* __restrict__ z1)
 {
+    // rows [0, NI): the new samples; rows [NI, NI + S0 - 1): the cdf (dead once the samples exist).  The merge with the coarse
+    // depths runs BACKWARDS in place over rows [0, S0 + NI) (row k is written when at most k samples are still unread), and
+    // the merged rows leave through a cooperative copy: 64 lanes on consecutive addresses of one ray instead of every thread
+    // storing its own row 4 bytes at a time (192 stores, each into 64 different lines).
     extern __shared__ float sm[];
-    float* cdf = sm;                        // [(S0-1)][IS_BLOCK]
-    float* zn = sm + (S0 - 1) * IS_BLOCK;   // [NI][IS_BLOCK]
+    float* zn = sm;                          // [NI][IS_PITCH], later the merged row [S0 + NI][IS_PITCH]
+    float* cdf = sm + NI * IS_PITCH;         // [(S0-1)][IS_PITCH]
     const int tid = threadIdx.x;
-    int r = blockIdx.x * IS_BLOCK + tid;
+    const int r = blockIdx.x * IS_BLOCK + tid;
     const int NB = S0 - 1;   // bins (mid points): 63
     const int NW = S0 - 2;   // weights[1:-1]: 62
+    const int ST = S0 + NI;
+    bool act = r < R;
     if (zero_row) {
         bool allzero = r < R;
         if (r < R) {
@@ -763,53 +770,63 @@ __global__ void __launch_bounds__(IS_BLOCK) k_importance(const float* __restrict
             for (int k = 0; k < NW; ++k) allzero = allzero && (wz[k + 1] == 0.f);
         }
         unsigned long long zm = __ballot(allzero);
-        const int ST = S0 + NI;
         while (zm) {
             const int src = __ffsll((long long)zm) - 1;
             zm &= zm - 1ull;
             float* out = z1 + (size_t)(blockIdx.x * IS_BLOCK + src) * ST;
             for (int k = tid; k < ST; k += IS_BLOCK) out[k] = zero_row[k];
         }
-        if (allzero) return;
+        act = act && !allzero;
     }
-    if (r >= R) return;
-    const float* w = w0 + (size_t)r * S0;
-    float tot = 0.f;
-    for (int k = 0; k < NW; ++k) tot += (w[k + 1] + 1e-5f);
-    float c = 0.f;
-    cdf[0 * IS_BLOCK + tid] = 0.f;
-    for (int k = 0; k < NW; ++k) {
-        c += (w[k + 1] + 1e-5f) / tot;
-        cdf[(k + 1) * IS_BLOCK + tid] = c;
+    if (act) {
+        const float* w = w0 + (size_t)r * S0;
+        float tot = 0.f;
+        for (int k = 0; k < NW; ++k) tot += (w[k + 1] + 1e-5f);
+        float c = 0.f;
+        cdf[0 * IS_PITCH + tid] = 0.f;
+        for (int k = 0; k < NW; ++k) {
+            c += (w[k + 1] + 1e-5f) / tot;
+            cdf[(k + 1) * IS_PITCH + tid] = c;
+        }
+        // inverse CDF; u ascending -> the searchsorted(right=True) pointer only moves forward
+        int ind = 0;  // number of cdf entries <= u
+        for (int k = 0; k < NI; ++k) {
+            float u = u_table[k];
+            while (ind < NB && cdf[ind * IS_PITCH + tid] <= u) ++ind;
+            int below = ind - 1 < 0 ? 0 : ind - 1;
+            int above = ind > NB - 1 ? NB - 1 : ind;
+            float c0 = cdf[below * IS_PITCH + tid], c1 = cdf[above * IS_PITCH + tid];
+            float b0 = 0.5f * (z0[below + 1] + z0[below]);
+            float b1 = 0.5f * (z0[above + 1] + z0[above]);
+            float denom = c1 - c0;
+            if (denom < 1e-5f) denom = 1.f;
+            float t = (u - c0) / denom;
+            zn[k * IS_PITCH + tid] = b0 + t * (b1 - b0);
+        }
+        // torch.sort(cat(z0, z_new)): make z_new sorted (it is, up to rounding), then merge
+        for (int k = 1; k < NI; ++k) {
+            float v = zn[k * IS_PITCH + tid];
+            int m = k;
+            while (m > 0 && zn[(m - 1) * IS_PITCH + tid] > v) { zn[m * IS_PITCH + tid] = zn[(m - 1) * IS_PITCH + tid]; --m; }
+            zn[m * IS_PITCH + tid] = v;
+        }
+        // backward merge, in place: a coarse depth goes BEHIND an equal new sample exactly when the forward merge puts it in
+        // front (equal values: the rows agree bit for bit either way)
+        int a = S0 - 1, b = NI - 1;
+        for (int k = ST - 1; k >= 0; --k) {
+            const float va = a >= 0 ? z0[a] : -INFINITY;
+            const float vb = b >= 0 ? zn[b * IS_PITCH + tid] : -INFINITY;
+            if (a < 0 || (b >= 0 && !(va > vb))) { zn[k * IS_PITCH + tid] = vb; --b; } else { zn[k * IS_PITCH + tid] = va; --a; }
+        }
     }
-    // inverse CDF; u ascending -> the searchsorted(right=True) pointer only moves forward
-    int ind = 0;  // number of cdf entries <= u
-    for (int k = 0; k < NI; ++k) {
-        float u = u_table[k];
-        while (ind < NB && cdf[ind * IS_BLOCK + tid] <= u) ++ind;
-        int below = ind - 1 < 0 ? 0 : ind - 1;
-        int above = ind > NB - 1 ? NB - 1 : ind;
-        float c0 = cdf[below * IS_BLOCK + tid], c1 = cdf[above * IS_BLOCK + tid];
-        float b0 = 0.5f * (z0[below + 1] + z0[below]);
-        float b1 = 0.5f * (z0[above + 1] + z0[above]);
-        float denom = c1 - c0;
-        if (denom < 1e-5f) denom = 1.f;
-        float t = (u - c0) / denom;
-        zn[k * IS_BLOCK + tid] = b0 + t * (b1 - b0);
-    }
-    // torch.sort(cat(z0, z_new)): make z_new sorted (it is, up to rounding), then merge
-    for (int k = 1; k < NI; ++k) {
-        float v = zn[k * IS_BLOCK + tid];
-        int m = k;
-        while (m > 0 && zn[(m - 1) * IS_BLOCK + tid] > v) { zn[m * IS_BLOCK + tid] = zn[(m - 1) * IS_BLOCK + tid]; --m; }
-        zn[m * IS_BLOCK + tid] = v;
-    }
-    float* out = z1 + (size_t)r * (S0 + NI);
-    int a = 0, b = 0;
-    for (int k = 0; k < S0 + NI; ++k) {
-        float va = a < S0 ? z0[a] : INFINITY;
-        float vb = b < NI ? zn[b * IS_BLOCK + tid] : INFINITY;
-        if (b >= NI || (a < S0 && va <= vb)) { out[k] = va; ++a; } else { out[k] = vb; ++b; }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    unsigned long long am = __ballot(act);
+    while (am) {
+        const int src = __ffsll((long long)am) - 1;
+        am &= am - 1ull;
+        float* out = z1 + (size_t)(blockIdx.x * IS_BLOCK + src) * ST;
+        for (int k = tid; k < ST; k += IS_BLOCK) out[k] = zn[k * IS_PITCH + src];
     }
 }
 
@@ -895,7 +912,7 @@ extern "C" int nf_importance_sample(const float* z_table0, const float* weights0
 {
     NF_CHECK_ARG(z_table0 && weights0 && u_table && z1, "null pointer");
     NF_CHECK_ARG(S0 >= 3 && N_imp >= 1, "bad S0/N_imp");
-    size_t lds = (size_t)(S0 - 1 + N_imp) * IS_BLOCK * sizeof(float);
+    size_t lds = (size_t)(S0 + N_imp) * IS_PITCH * sizeof(float);
     NF_CHECK_ARG(lds <= 160 * 1024, "S0 + N_imp too large for LDS staging");
     if (R == 0) return NF_OK;
     const size_t lds_w = (size_t)4 * (3 * S0 + 2 * N_imp) * sizeof(float);

@@ -609,12 +609,102 @@ __global__ void __launch_bounds__(256) k_cconv_gather_t(const float* __restrict_
     }
 }
 
+// cout = 64 on the matrix pipe: for one particle the transposed gather is a small dense product,
+//     dG[cell][co] = sum_t W[t][cell] * dy[j_t][co],      W[t][cell] = sum of pair t's corner weights that fall on `cell`
+// (8 non-zeros per row of W).  A wave scatters its chunk of up to 64 pairs into W in LDS (lane t owns row t: its own 8
+// read-add-writes, nothing shared) and runs 64 cells x 64 channels x pairs on v_mfma_f32_32x32x2_f32: per K-step (two pairs)
+// two ds_read_b32 of W, two global loads of dy rows and four MFMAs, instead of ~150 VALU / LDS instructions per pair.
+// Sums: every output element adds its pairs in list order (the pairs that do not touch the cell contribute exact zeros);
+// duplicate corner cells of a pair (interpolation clamped at the filter's border) are added up before the product.
+#define GT_PITCH 65
+__global__ void __launch_bounds__(64) k_cconv_gather_t64(const float* __restrict__ dy, const int64_t* __restrict__ row_splits,
+                                                         const int32_t* __restrict__ nbr, const float* __restrict__ tpw,
+                                                         const uint8_t* __restrict__ tpc, int n, float* __restrict__ dG)
+{
+    __shared__ float Wt[64 * GT_PITCH];
+    const int lane = threadIdx.x, h = lane >> 5, c = lane & 31;
+    for (int row = blockIdx.x; row < n; row += gridDim.x) {
+        const int64_t s = row_splits[row], e = row_splits[row + 1];
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        for (int64_t base = s; base < e; base += 64) {
+            const int cnt = __builtin_amdgcn_readfirstlane((int)((e - base) < 64 ? (e - base) : 64));
+            const int nk = (cnt + 1) >> 1;                       // K-steps of two pairs
+            // W rows 0 .. 2 nk - 1 <- 0, then lane t adds its pair's 8 corner weights into row t
+            for (int t = 0; t < 2 * nk; ++t) Wt[t * GT_PITCH + lane] = 0.f;
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            int jl = row;                                         // padded pair: any valid row (its W row is zero, its B operand too)
+            if (lane < cnt) {
+                const int64_t p = base + lane;
+                jl = nbr[p];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) Wt[lane * GT_PITCH + tpc[p * 8 + k]] += tpw[p * 8 + k];
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            // B operands (dy rows of the two pairs of a K-step, one per half-wave), 4 K-steps ahead
+            float b0[4], b1[4];
+            auto loadB = [&](int kk, float& x0, float& x1) {
+                const int t = 2 * kk + h;
+                const int jlo = __builtin_amdgcn_readlane(jl, (2 * kk) & 63), jhi = __builtin_amdgcn_readlane(jl, (2 * kk + 1) & 63);
+                const float* src = dy + (size_t)(h ? jhi : jlo) * 64 + c;
+                const bool live = kk < nk && t < cnt;
+                x0 = live ? src[0] : 0.f;
+                x1 = live ? src[32] : 0.f;
+            };
+#pragma unroll
+            for (int u = 0; u < 4; ++u) loadB(u, b0[u], b1[u]);
+            for (int k0 = 0; k0 < nk; k0 += 4) {
+                float n0[4], n1[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) loadB(k0 + 4 + u, n0[u], n1[u]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int kk = k0 + u;
+                    if (kk < nk) {
+                        const float a0 = Wt[(2 * kk + h) * GT_PITCH + c], a1 = Wt[(2 * kk + h) * GT_PITCH + 32 + c];
+                        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[u], acc[0][0], 0, 0, 0);
+                        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1[u], acc[0][1], 0, 0, 0);
+                        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0[u], acc[1][0], 0, 0, 0);
+                        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[u], acc[1][1], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { b0[u] = n0[u]; b1[u] = n1[u]; }
+            }
+            __builtin_amdgcn_wave_barrier();                      // the next chunk rewrites W
+        }
+        float* out = dG + (size_t)row * (65 * 64);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    out[(32 * a + (r & 3) + 8 * (r >> 2) + 4 * h) * 64 + 32 * b + c] = acc[a][b][r];
+        out[64 * 64 + lane] = dy[(size_t)row * 64 + lane];
+    }
+}
+
 extern "C" int nf_cconv_gather_bwd(const float* dy, int cout, const int64_t* row_splits, const int32_t* nbr,
                                    const float* pair_w_t, const uint8_t* pair_cell_t, int n, float* dG, nf_stream_t stream)
 {
     NF_CHECK_ARG(dy && row_splits && dG, "null pointer");
     NF_CHECK_ARG(cout >= 1 && cout <= 64, "cout must be in [1,64]");
     if (n <= 0) return NF_OK;
+    if (cout == 64) {
+        int blocks64 = n < 16384 ? n : 16384;
+        hipLaunchKernelGGL(k_cconv_gather_t64, dim3(blocks64), dim3(64), 0, (hipStream_t)stream, dy, row_splits, nbr, pair_w_t,
+                           pair_cell_t, n, dG);
+        NF_CHECK_LAUNCH();
+        return NF_OK;
+    }
     // one wave per workgroup (16 KB of LDS at cout = 64): 55 us per launch at 4 913 particles x 39 pairs, 59 with four.  The
     // kernel is bound by its instruction count (~150 per pair and wave), not by LDS or memory: see DESIGN section 6
     const int wpb = 1;

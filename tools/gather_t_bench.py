@@ -32,4 +32,16 @@ for cout in (64, 3):
     for _ in range(20):
         check(lib.nf_cconv_gather_bwd(ptr(dy), cout, ptr(f_rs), ptr(f_idx), ptr(t_pw), ptr(t_pc), n, ptr(dG), _lib.stream()), "x")
     e1.record(); torch.cuda.synchronize()
-    print("cout %d: %.1f us per launch, checksum %.6e" % (cout, e0.elapsed_time(e1) / 20 * 1e3, float(dG.double().sum())))
+    # reference: the same sum as one scatter-add over (pair, corner) entries
+    npair = f_idx.shape[0]
+    counts = (f_rs[1:] - f_rs[:-1]).long()
+    rows = torch.repeat_interleave(torch.arange(n, device=dev), counts)
+    ref = torch.zeros(n, 65, cout, device=dev, dtype=torch.float64)
+    w = t_pw[:npair * 8].view(npair, 8).double()
+    cells = t_pc[:npair * 8].view(npair, 8).long()
+    g = dy[f_idx.long()].double()
+    for k in range(8):
+        ref.index_put_((rows, cells[:, k]), w[:, k, None] * g, accumulate=True)
+    ref[:, 64, :] = dy.double()
+    err = float((dG.view(n, 65, cout).double() - ref).abs().max() / ref.abs().max())
+    print("cout %d: %.1f us per launch, max err / max |ref| %.2e" % (cout, e0.elapsed_time(e1) / 20 * 1e3, err))

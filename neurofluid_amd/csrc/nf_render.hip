@@ -242,10 +242,27 @@ __global__ void __launch_bounds__(SG_BLOCK) k_search(const void* __restrict__ ws
             active = s_full_w[lane] || !use_mask;
         }
         const int row = wave_append(active, n_rows);
-        if (active) {
-            row_sample[row] = sample;
-            for (int k = 0; k < K; ++k) row_nbr[(size_t)row * K + k] = k < cnt ? s_list_w[lane * pitch + k] : -1;
+        // the round's active rows are consecutive (wave_append): their K-lists leave as ONE contiguous run written by the
+        // whole wave (64 consecutive ints per store) instead of every lane storing its own 80-B row 4 bytes at a time
+        const unsigned long long am = __ballot(active);
+        if (am) {
+            const int na = __popcll(am);
+            const int row0 = __shfl(row, __ffsll((long long)am) - 1, 64);
+            if (active) {
+                row_sample[row] = sample;
+                s_full_w[row - row0] = lane;        // rank -> slot (s_full is dead: `active` has been derived from it)
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            const unsigned invK = (1u << 16) / (unsigned)K + 1u;      // idx / K for idx < 64 K, K <= 32 (exact: checked offline)
+            int* const dst = row_nbr + (size_t)row0 * K;
+            for (int idx = lane; idx < na * K; idx += 64) {
+                const int rr = (int)(((unsigned)idx * invK) >> 16), k = idx - rr * K;
+                const int slot = s_full_w[rr];
+                dst[idx] = k < s_cnt_w[slot] ? s_list_w[slot * pitch + k] : -1;
+            }
         }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
     }
 }

@@ -762,6 +762,49 @@ extern "C" int nf_composite_fwd(const float* rgbsigma, const float* z, const flo
 // ray because the coarse depths are shared (computed once by this very kernel on one zero-weight ray, so the bits
 // are those of the general path).  Rays that hit nothing (the large majority of an image) then cost one pass over
 // their weights and a coalesced 64-lane copy of that row instead of the serial inverse-CDF walk.
+// Rays whose weights[1:-1] are all exactly zero (the large majority of an image) get `zero_row`; the others get a NaN in
+// their first output word, which tells k_importance to compute them.  A kernel of its own because the general path needs
+// 50 KB of LDS per 64 rays (3 waves per CU): the empty rays are pure streaming work and want the whole chip's occupancy.
+__global__ void __launch_bounds__(256) k_importance_zero(const float* __restrict__ w0, int R, int S0, int NI,
+                                                         const float* __restrict__ zero_row, float* __restrict__ z1)
+{
+    const int lane = threadIdx.x & 63;
+    const int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;       // a wave takes 64 consecutive rays
+    if (r0 >= R) return;
+    const int ST = S0 + NI, NW = S0 - 2;
+    unsigned long long nzm = 0ull;                                    // bit i: ray r0 + i has a non-zero inner weight
+    if (S0 == 64 && r0 + 64 <= R) {
+        // the 64 weight rows are one contiguous 16 KB run: 16 lanes (float4) per ray, 4 rays per step
+        const float4* w4 = (const float4*)(w0 + (size_t)r0 * S0);
+#pragma unroll 4
+        for (int step = 0; step < 16; ++step) {
+            const float4 v = w4[step * 64 + lane];
+            const int q = lane & 15;
+            const bool nz = (v.y != 0.f) || (v.z != 0.f) || (q != 0 && v.x != 0.f) || (q != 15 && v.w != 0.f);
+            const unsigned long long bm = __ballot(nz);
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+                if ((bm >> (16 * g4)) & 0xffffull) nzm |= 1ull << (step * 4 + g4);
+        }
+    } else {
+        bool nz = false;
+        if (r0 + lane < R) {
+            const float* wz = w0 + (size_t)(r0 + lane) * S0;
+            for (int k = 0; k < NW; ++k) nz = nz || (wz[k + 1] != 0.f);
+        }
+        nzm = __ballot(nz);
+    }
+    const int nr = min(64, R - r0);
+    for (int i = 0; i < nr; ++i) {
+        float* out = z1 + (size_t)(r0 + i) * ST;
+        if ((nzm >> i) & 1ull) {
+            if (lane == 0) out[0] = __int_as_float(0x7fc00000);
+        } else {
+            for (int k = lane; k < ST; k += 64) out[k] = zero_row[k];
+        }
+    }
+}
+
 #define IS_PITCH (IS_BLOCK + 1)       // LDS rows [k][thread] with an odd pitch: conflict-free by thread (own column) AND by k (write-out)
 __global__ void __launch_bounds__(IS_BLOCK) k_importance(const float* __restrict__ z0, const float* __restrict__ w0,
                                                          const float* __restrict__ u_table, int R, int S0, int NI,
@@ -780,21 +823,8 @@ __global__ void __launch_bounds__(IS_BLOCK) k_importance(const float* __restrict
     const int NW = S0 - 2;   // weights[1:-1]: 62
     const int ST = S0 + NI;
     bool act = r < R;
-    if (zero_row) {
-        bool allzero = r < R;
-        if (r < R) {
-            const float* wz = w0 + (size_t)r * S0;
-            for (int k = 0; k < NW; ++k) allzero = allzero && (wz[k + 1] == 0.f);
-        }
-        unsigned long long zm = __ballot(allzero);
-        while (zm) {
-            const int src = __ffsll((long long)zm) - 1;
-            zm &= zm - 1ull;
-            float* out = z1 + (size_t)(blockIdx.x * IS_BLOCK + src) * ST;
-            for (int k = tid; k < ST; k += IS_BLOCK) out[k] = zero_row[k];
-        }
-        act = act && !allzero;
-    }
+    if (zero_row && act) act = isnan(z1[(size_t)r * ST]);      // k_importance_zero ran first: empty rays already hold their row
+    if (__ballot(act) == 0ull) return;
     if (act) {
         const float* w = w0 + (size_t)r * S0;
         float tot = 0.f;
@@ -941,6 +971,9 @@ extern "C" int nf_importance_sample(const float* z_table0, const float* weights0
     }
     if (lds > 64 * 1024)
         hipFuncSetAttribute((const void*)k_importance, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (zero_row)
+        hipLaunchKernelGGL(k_importance_zero, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, weights0, R, S0, N_imp,
+                           zero_row, z1);
     hipLaunchKernelGGL(k_importance, dim3((R + IS_BLOCK - 1) / IS_BLOCK), dim3(IS_BLOCK), lds, (hipStream_t)stream,
                        z_table0, weights0, u_table, R, S0, N_imp, zero_row, z1);
     NF_CHECK_LAUNCH();

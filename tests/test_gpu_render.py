@@ -824,6 +824,37 @@ def test_optimistic_row_capacities_no_midpass_sync(dev):
         assert torch.equal(a[k], b[k]) and torch.equal(a[k], c[k]), k
 
 
+def test_training_passes_learnt_capacities_and_async_counts(dev):
+    """Training passes (activations saved) run against the module's learnt row capacities; the row counts travel to pinned
+    memory behind the search kernels (ops.HostFetch) and are verified when the forward is enqueued.  Same outputs (bit for
+    bit) and the same gradients in all three regimes: exact sizing (first call), capacity run, overflow -> exact redo."""
+    g = load_golden("a10_forward")
+    P, rays, roc = T(g["particles"], dev), T(g["rays"], dev), T(g["ro"], dev)
+    tgt = torch.rand(rays.shape[0], 3, generator=torch.Generator().manual_seed(3)).to(dev)
+
+    def step(net):
+        for p in net.parameters():
+            p.grad = None
+        out = net(P, roc, rays, None, None)
+        loss = ((out["rgb0"] - tgt) ** 2).mean() + ((out["rgb1"] - tgt) ** 2).mean()
+        loss.backward()
+        grads = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+        return {k: v.detach().clone() for k, v in out.items()}, grads
+
+    net = make_net(dev)
+    a, ga = step(net)                                          # exact sizing: learns the capacities
+    assert set(net.train_row_cap) == {(48, 64), (48, 192)}
+    b, gb = step(net)                                          # capacity run (no host round trip inside the passes)
+    net.train_row_cap = {k: 32 for k in net.train_row_cap}     # far too small: overflow -> redo with exact sizing
+    c, gc = step(net)
+    assert all(v > 32 for v in net.train_row_cap.values())
+    for k in a:
+        assert torch.equal(a[k], b[k]) and torch.equal(a[k], c[k]), k
+    # the weight gradients add the rows in the order the compaction left them (atomic reservations): equal up to summation order
+    for other in (gb, gc):
+        assert float((other - ga).norm() / ga.norm()) < 1e-5
+
+
 def test_split_precision_path(dev):
     """RENDERER.mlp_dtype = split: hi + lo fp16 operands, three fp16 MFMAs per product, fp32 accumulate (nf_mlp_s.hip).
     Claim: fp32-LEVEL accuracy — the same bars as the fp32 path itself: MLP rows within 2e-5 (rgb) / 2e-4 relative (sigma)

@@ -171,14 +171,14 @@ int nf_nerf_mlp_fwd_h(const float* packed, const void* stream_h, int cx, int cd,
                       const int32_t* n_rows, int max_rows, const int32_t* row_sample, float* rgbsigma,
                       nf_stream_t stream);
 
-/* A6 for small launches (nf_mlp_n.hip): one 32-row tile per WORKGROUP, a layer's 8 output blocks split over its 4 waves,
+/* A6 for small launches (models/nerf.py:83-124, the forward of a training step; nf_mlp_n.hip): one 32-row tile per WORKGROUP, a layer's 8 output blocks split over its 4 waves,
  * activations exchanged through an LDS image — a quarter of nf_nerf_mlp_fwd's per-tile latency (it keeps a tile in one
  * wave for 0.35 ms: a launch costs ceil(tiles / 1024) such rounds however empty the last one is).  Same packed blob, same
  * operand X, same outputs (rgbsigma, and acts when not NULL) BIT FOR BIT. */
 int nf_nerf_mlp_fwd_n(const float* packed, int cx, int cd, const float* X, const int32_t* n_rows, int max_rows,
                       const int32_t* row_sample, float* rgbsigma, float* acts /*or NULL*/, nf_stream_t stream);
 
-/* fp16-MFMA forward, version 3 (nf_mlp_h2.hip): two 32-row tiles per wave, out-block-major, packed fp16 activations
+/* fp16-MFMA forward of A6 (models/nerf.py:83-124), version 3 (nf_mlp_h2.hip): two 32-row tiles per wave, out-block-major, packed fp16 activations
  * between layers, sigma / rgb heads on the matrix pipe.  Same operand X as nf_nerf_mlp_fwd_h (the fp16 layout written
  * by nf_render_features(x_fp16 = 1)), which must be allocated for an EVEN number of 32-row tiles; its own weight stream. */
 size_t nf_nerf_packed_h2_bytes(void);
@@ -186,7 +186,7 @@ int nf_nerf_pack_h2(const nf_nerf_params_t* params, int cx, int cd, void* stream
 int nf_nerf_mlp_fwd_h2(const void* stream_h2, int cx, int cd, const void* X, const int32_t* n_rows, int max_rows,
                        const int32_t* row_sample, float* rgbsigma, nf_stream_t stream);
 
-/* Split-precision forward (nf_mlp_s.hip): every operand as hi + lo fp16, three fp16 MFMAs per product, fp32 accumulate —
+/* Split-precision forward of A6 (models/nerf.py:83-124; nf_mlp_s.hip): every operand as hi + lo fp16, three fp16 MFMAs per product, fp32 accumulate —
  * fp32-level accuracy (max-abs <= 2e-4 on RGB vs the fp32 path) at a multiple of the fp32-MFMA kernel's speed.  Takes
  * the fp32 operand layout X of nf_render_features (x_fp16 = 0); its own weight stream.  Inference only. */
 size_t nf_nerf_packed_s_bytes(void);
@@ -194,7 +194,8 @@ int nf_nerf_pack_s(const nf_nerf_params_t* params, int cx, int cd, void* stream_
 int nf_nerf_mlp_fwd_s(const void* stream_s, int cx, int cd, const float* X, const int32_t* n_rows, int max_rows,
                       const int32_t* row_sample, float* rgbsigma, nf_stream_t stream);
 
-/* A12 (MLP part): data gradient of the MLP on fp32 MFMA with transposed packed weights.
+/* A12 (MLP part; what torch autograd derives for models/nerf.py:83-124 under loss.backward(),
+ * trainer/trainer_renderer.py:96): data gradient of the MLP on fp32 MFMA with transposed packed weights.
  * Reads d_rgbsigma[row_sample[row]] (gradient w.r.t. the MLP output (rgb after sigmoid, sigma)) and the
  * activations saved by nf_nerf_mlp_fwd; writes, per row, the pre-activation gradients of every layer:
  * dpre[row][NF_DPRE_STRIDE] = dpre_1..8 (8*256) | dpre_final (256) | dpre_dir (128) | dz_rgb (3) | dsigma (1).
@@ -206,7 +207,7 @@ int nf_nerf_mlp_bwd(const float* packed, const float* packed_t, int cx, int cd, 
                     const int32_t* n_rows, int max_rows, const int32_t* row_sample, const float* rgbsigma,
                     const float* d_rgbsigma, float* dpre, nf_stream_t stream);
 
-/* A12 (weight gradients): all 15 GEMMs dW_l = dpre_l^T * input_l of one NeRF in one batched fp32-MFMA launch +
+/* A12 (weight gradients of the nn.Linear layers of models/nerf.py:55-81): all 15 GEMMs dW_l = dpre_l^T * input_l of one NeRF in one batched fp32-MFMA launch +
  * one deterministic slice reduction.  X = the MLP operand of nf_render_features (tile layout) that the forward consumed.
  * dweights = one flat blob holding the 12 weight gradients in nf_nerf_params_t order, each [out][in] row-major
  * (nf_nerf_wgrad_floats floats); workspace = nf_nerf_wgrad_workspace_floats(cx, cd, nslices) floats.

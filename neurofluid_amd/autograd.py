@@ -20,17 +20,18 @@ def _run_passes(net, particles, ro, rays, white_bg, fine, save_acts, _retry=Fals
     if net.mlp_dtype != "fp32" and save_acts:
         raise RuntimeError(f"RENDERER.mlp_dtype={net.mlp_dtype} is an inference path; train with fp32")
     ws = None if save_acts else net.workspace()
-    # learnt row capacities: the inference arena's, or the module's own table for training passes.  Inference verifies the
-    # counts ONCE at the end of the call (torch.cat + tolist: it waits for the whole frame, which a rollout reads back
-    # anyway).  Training must not wait for its forward MLPs (the host still has the loss and the backward to enqueue): each
-    # pass's count is copied to pinned memory right behind its search kernel (ops.HostFetch) and read when the forward is
-    # enqueued — by then it has long arrived.  (Exact sizing — an `.item()` in the middle of each pass — left the GPU idle
-    # for ~100 us twice per step; one blocking verification at the end was worse still: 9.3 vs 8.3 ms in round 1.)
+    # learnt row capacities: the inference arena's, or the module's own table for training passes.  The passes run against
+    # them without a host round trip; each pass's row count is copied to pinned memory right behind its search kernel
+    # (ops.HostFetch) and verified when the whole call is enqueued — the wait is for the LAST SEARCH kernel, not for the MLPs
+    # behind it.  Training: the host still has the loss and the backward to enqueue while the forward MLPs run.  Inference:
+    # the caller gets its (still computing) result tensors back and enqueues the next frame's transition step and grid
+    # build behind this frame's fine MLP — no launch gap between the frames of a rollout.  (Exact sizing — an `.item()` in
+    # the middle of each pass — left the GPU idle for ~100 us twice per call; a blocking torch.cat(...).tolist() at the end
+    # of the call waits for the whole frame: 0.13 ms of idle GPU per frame, and 9.3 vs 8.3 ms per training step in round 1.)
     caps = ws.row_cap if ws is not None else net.train_row_cap
-    fetch = ops.HostFetch(dev) if save_acts else None
-    if fetch is not None:
-        fetch.add(grid.aabb_words())        # words 0..5: the cloud's bounds (the next grid's bbox hint), then one count per pass
-    after = (lambda n_rows: fetch.add(n_rows)) if fetch is not None else None
+    fetch = ops.HostFetch(dev)
+    fetch.add(grid.aabb_words())            # words 0..5: the cloud's bounds (the next grid's bbox hint), then one count per pass
+    after = lambda n_rows: fetch.add(n_rows)
     opt = not _retry
     if save_acts:
         pk0, ws0, ph0 = net.packed_weights(net.nerf_coarse), None, None
@@ -57,14 +58,9 @@ def _run_passes(net, particles, ro, rays, white_bg, fine, save_acts, _retry=Fals
     # call enqueued (a real rollout reads the image back anyway).  On overflow the capacities grow and the call is redone
     # with exact sizing; capacities also grow ahead of need when a count comes within 10 % of them.
     cap_runs = [(p, p.cap) for p in (p0, p1) if p is not None and p.cap is not None]
-    if fetch is not None:
-        got = fetch.get()                   # waits for the LAST search kernel only; the MLPs behind it stay queued
-        net.note_point_bounds(ops.decode_aabb(got[:6]))
-        counts = [got[6 + k] for k, p in enumerate((p0, p1)) if p is not None and p.cap is not None]
-    elif cap_runs:
-        fetched = torch.cat([p.n_rows for p, _ in cap_runs] + [grid.aabb_words()]).tolist()
-        counts = fetched[:len(cap_runs)]
-        net.note_point_bounds(ops.decode_aabb(fetched[len(cap_runs):]))      # the next frame's grid bbox: no reduction + sync
+    got = fetch.get()                       # waits for the LAST search kernel only; the MLPs behind it stay queued
+    net.note_point_bounds(ops.decode_aabb(got[:6]))          # the next frame's grid bbox: no reduction + sync
+    counts = [got[6 + k] for k, p in enumerate((p0, p1)) if p is not None and p.cap is not None]
     if cap_runs:
         overflow = False
         for (p, cap), n in zip(cap_runs, counts):
@@ -73,8 +69,10 @@ def _run_passes(net, particles, ro, rays, white_bg, fine, save_acts, _retry=Fals
                 caps[key] = ops._round_rows(n + n // 4 + 4096)
             overflow |= n > cap
             p.n_active = n
-        if ops.PROFILE is not None:
-            ops.PROFILE["rows"] = [int(r.item()) if torch.is_tensor(r) else r for r in ops.PROFILE["rows"]]
+        if ops.PROFILE is not None:      # capacity runs booked their device-side count: the fetched value, no extra sync
+            known = {id(p.n_rows): n for (p, _), n in zip(cap_runs, counts)}
+            ops.PROFILE["rows"] = [(known[id(r)] if id(r) in known else int(r.item())) if torch.is_tensor(r) else r
+                                   for r in ops.PROFILE["rows"]]
         if overflow:
             return _run_passes(net, particles, ro, rays, white_bg, fine, save_acts, _retry=True)
     return p0, p1, rays_c, ro_c, grid

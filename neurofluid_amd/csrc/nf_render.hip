@@ -322,27 +322,22 @@ extern "C" int nf_render_feature_dims(int enc_flags, int* cx, int* cd, int* qx, 
 }
 
 // Streams features of one row into X[tile][q][lane][4]: 4 consecutive features share one 16-B store.
+// Every value is put at an EXPLICIT feature index that is a compile-time constant once the callers' loops are unrolled (the
+// encodings' offsets follow from the FLAGS template argument): the staging registers are then addressed statically.  (With a
+// running counter inside the emitter the compiler kept it — and the fp16 emitter's 16-entry staging array — in memory: the
+// array was promoted to LDS, ~2 000 ds_ instructions and ~450 address computations in k_features<15, true>.)
 struct FeatEmitter {
     float4* base;  // &X[tile][0][j]  (lane h=0); h=1 is +32 float4, q is +64 float4
-    float b0, b1, b2, b3;
-    int n;  // features emitted so far in the current section (compile-time after unrolling)
-    __device__ __forceinline__ void flush_at(int group)  // group = n/4 - 1 just completed
+    float b[4];
+    __device__ __forceinline__ void put(int idx, float v)
     {
-        int q = group >> 1, h = group & 1;
-        typedef float nf_f4v __attribute__((ext_vector_type(4)));
-        const nf_f4v v = {b0, b1, b2, b3};
-        __builtin_nontemporal_store(v, (nf_f4v*)&base[q * 64 + h * 32]);   // streamed: read once, by the MLP
-    }
-    __device__ __forceinline__ void emit(float v)
-    {
-        int e = n & 3;
-        if (e == 0) b0 = v; else if (e == 1) b1 = v; else if (e == 2) b2 = v; else b3 = v;
-        ++n;
-        if ((n & 3) == 0) flush_at((n >> 2) - 1);
-    }
-    __device__ __forceinline__ void pad_to(int total)  // zero-fill up to `total` features (multiple of 8)
-    {
-        while (n < total) emit(0.f);
+        b[idx & 3] = v;
+        if ((idx & 3) == 3) {
+            const int group = idx >> 2, q = group >> 1, h = group & 1;
+            typedef float nf_f4v __attribute__((ext_vector_type(4)));
+            const nf_f4v o = {b[0], b[1], b[2], b[3]};
+            __builtin_nontemporal_store(o, (nf_f4v*)&base[q * 64 + h * 32]);   // streamed: read once, by the MLP
+        }
     }
 };
 
@@ -353,44 +348,46 @@ typedef _Float16 nf_h8 __attribute__((ext_vector_type(8)));
 struct FeatEmitterH {
     nf_h8* base;   // &Xh[tile][0][j]  (lane h=0); h=1 is +32, K-step t is +64
     _Float16 f[16];
-    int n;
-    __device__ __forceinline__ void emit(float v)
+    __device__ __forceinline__ void put(int idx, float v)
     {
-        f[n & 15] = (_Float16)v;
-        ++n;
-        if ((n & 15) == 0) {
-            const int t = (n >> 4) - 1;
+        f[idx & 15] = (_Float16)v;
+        if ((idx & 15) == 15) {
+            const int t = idx >> 4;
             nf_h8 lo = {f[0], f[1], f[2], f[3], f[8], f[9], f[10], f[11]};
             nf_h8 hi = {f[4], f[5], f[6], f[7], f[12], f[13], f[14], f[15]};
             __builtin_nontemporal_store(lo, &base[t * 64]);
             __builtin_nontemporal_store(hi, &base[t * 64 + 32]);
         }
     }
-    __device__ __forceinline__ void pad_to(int total)
-    {
-        while (n < total) emit(0.f);
-    }
 };
+
+// zero-fill features [from, to)
+template <int FROM, int TO, typename EM>
+__device__ __forceinline__ void emit_pad(EM& em)
+{
+#pragma unroll
+    for (int i = FROM; i < TO; ++i) em.put(i, 0.f);
+}
 
 // Positional encoding [x, sin(2^k x), cos(2^k x)]_k (models/nerf.py:17-41; the reference evaluates torch.sin / cos of
 // the fp32 product 2^k * x, which is exact).  One sincos of x in DOUBLE, then angle doubling in double
 // (sin 2a = 2 sin a cos a, cos 2a = 1 - 2 sin^2 a): ten octaves cost one argument reduction instead of ten, and the
 // doubling error (< 2^10 * 1e-16) stays far below fp32 rounding, so every emitted value is the correctly rounded
 // sin / cos of the reference's argument.  (Ten independent sincosf calls made this kernel VALU-bound.)
-template <int C, int NF, typename EM>
+template <int BASE, int C, int NF, typename EM>
 __device__ __forceinline__ void emit_pe(EM& em, const float (&x)[C])
 {
 #pragma unroll
-    for (int c = 0; c < C; ++c) em.emit(x[c]);
+    for (int c = 0; c < C; ++c) em.put(BASE + c, x[c]);
     double sn[C], cs[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) sincos((double)x[c], &sn[c], &cs[c]);
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
 #pragma unroll
-        for (int c = 0; c < C; ++c) em.emit((float)sn[c]);
+        for (int c = 0; c < C; ++c) em.put(BASE + C * (1 + 2 * f) + c, (float)sn[c]);
 #pragma unroll
-        for (int c = 0; c < C; ++c) em.emit((float)cs[c]);
+        for (int c = 0; c < C; ++c) em.put(BASE + C * (2 + 2 * f) + c, (float)cs[c]);
         if (f + 1 < NF) {
 #pragma unroll
             for (int c = 0; c < C; ++c) {
@@ -405,7 +402,11 @@ __device__ __forceinline__ void emit_pe(EM& em, const float (&x)[C])
 // for both sweeps, and the sweeps unroll, so the 20 position gathers of a sweep are in flight together instead of one
 // index -> position chain after the other.  Same arithmetic, same order.
 template <int FLAGS, bool HALF, int KC>
-__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 8))) k_features(const float* __restrict__ particles, const float* __restrict__ rays,
+__global__ void __launch_bounds__(128)
+#ifndef NF_FEAT_NOCAP
+__attribute__((amdgpu_waves_per_eu(4, 8)))
+#endif
+k_features(const float* __restrict__ particles, const float* __restrict__ rays,
                                                   const float* __restrict__ z, const float* __restrict__ z_table, int S,
                                                   float radius, int K, const float* __restrict__ ro_base, int ro_stride,
                                                   const int* __restrict__ row_sample, const int* __restrict__ row_nbr,
@@ -434,12 +435,16 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 8))
             }
         }
         const int Kn = KC > 0 ? KC : K;
-        // measured on the 400^2 frame (us per launch, coarse + fine average): fp32 X 479 -> 328 (full unroll) -> 315 (<= 128
-        // registers); fp16 X 421 -> 444 (full unroll) / 501 (capped); sweeps unrolled by 2 / 4 / 5 / 10: 338 / 332 / 327 / 346
+        // measured on the 400^2 frame (us per launch, coarse + fine average), gathers first, then the static-index emitters:
+        // fp32 X 479 -> 328 (full unroll) -> 315 (<= 128 registers) -> 300 (emitters; sweeps unrolled by 5 / 10 / 20: 303 / 300 / 337)
+        // fp16 X 421 -> 327 (sweeps unrolled by 5; 2 / 4 / 10 / 20: 338 / 332 / 346 / 444) -> 234 (emitters)
 #ifndef NF_FEAT_UNH
 #define NF_FEAT_UNH 5
 #endif
-        constexpr int UN = HALF ? NF_FEAT_UNH : 20;
+#ifndef NF_FEAT_UNF
+#define NF_FEAT_UNF 10
+#endif
+        constexpr int UN = HALF ? NF_FEAT_UNH : NF_FEAT_UNF;
 #pragma unroll UN
         for (int k = 0; k < Kn; ++k) {
             int j;
@@ -480,21 +485,23 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 8))
         typename std::conditional<HALF, FeatEmitterH, FeatEmitter>::type em;
         if constexpr (HALF) em.base = (nf_h8*)X + (size_t)tile * (Q / 2) * 64 + jj;
         else em.base = (float4*)X + (size_t)tile * Q * 64 + jj;
-        em.n = 0;
-        emit_pe<3, 10>(em, px);
-        if (FLAGS & 1) { float d1[1] = {sw}; emit_pe<1, 4>(em, d1); }
-        if (FLAGS & 2) emit_pe<3, 10>(em, sm);
-        if (FLAGS & 4) emit_pe<3, 10>(em, var);
-        em.pad_to(QX * 8);
+        constexpr int O_DEN = 63, O_SM = O_DEN + ((FLAGS & 1) ? 9 : 0), O_VAR = O_SM + ((FLAGS & 2) ? 63 : 0);
+        constexpr int O_DIR = QX * 8, O_SDIR = O_DIR + 27;
+        static_assert(O_VAR + ((FLAGS & 4) ? 63 : 0) == CX && O_SDIR + ((FLAGS & 8) ? 27 : 0) == O_DIR + CD, "feature offsets");
+        emit_pe<0, 3, 10>(em, px);
+        if constexpr ((FLAGS & 1) != 0) { float d1[1] = {sw}; emit_pe<O_DEN, 1, 4>(em, d1); }
+        if constexpr ((FLAGS & 2) != 0) emit_pe<O_SM, 3, 10>(em, sm);
+        if constexpr ((FLAGS & 4) != 0) emit_pe<O_VAR, 3, 10>(em, var);
+        emit_pad<CX, QX * 8>(em);
         float rd[3] = {ry[3], ry[4], ry[5]};
-        emit_pe<3, 4>(em, rd);
-        if (FLAGS & 8) {
+        emit_pe<O_DIR, 3, 4>(em, rd);
+        if constexpr ((FLAGS & 8) != 0) {
             float ddx = sm[0] - ro[0], ddy = sm[1] - ro[1], ddz = sm[2] - ro[2];
             float nrm = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
             float sd[3] = {ddx / nrm, ddy / nrm, ddz / nrm};
-            emit_pe<3, 4>(em, sd);
+            emit_pe<O_SDIR, 3, 4>(em, sd);
         }
-        em.pad_to(Q * 8);
+        emit_pad<O_DIR + CD, Q * 8>(em);
     }
 }
 

@@ -275,12 +275,33 @@ __global__ void k_grid_rank(NfGridHeader h, void* ws, const float* __restrict__ 
     ((float4*)(b + h.off_sorted_pos))[dst] = make_float4(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], __int_as_float(i));
 }
 
-__global__ void k_grid_dilate(NfGridHeader h, void* ws)
+// A WAVE per cell: the cell's particles are spread over the lanes for its AABB (min / max are exact in any order).  A thread
+// per cell left a typical renderer grid (a few hundred cells of ~80 particles) on four waves, each lane walking its cell's
+// particles one dependent load after the other: 40 us per build.
+__global__ void __launch_bounds__(256) k_grid_dilate(NfGridHeader h, void* ws)
 {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= h.n_cells) return;
     char* b = (char*)ws;
     const int* cs = (const int*)(b + h.off_cell_start);
+    const int s0 = cs[c], s1 = cs[c + 1];
+    // particle AABB of this cell
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    const float4* sp = (const float4*)(b + h.off_sorted_pos);
+    for (int t = s0 + lane; t < s1; t += 64) {
+        float4 p = sp[t];
+        lo[0] = fminf(lo[0], p.x); lo[1] = fminf(lo[1], p.y); lo[2] = fminf(lo[2], p.z);
+        hi[0] = fmaxf(hi[0], p.x); hi[1] = fmaxf(hi[1], p.y); hi[2] = fmaxf(hi[2], p.z);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = fminf(lo[k], __shfl_xor(lo[k], o, 64));
+            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], o, 64));
+        }
+    if (lane != 0) return;
     int cx = c % h.dims[0], cy = (c / h.dims[0]) % h.dims[1], cz = c / (h.dims[0] * h.dims[1]);
     int tot = 0;
     for (int z = max(cz - 1, 0); z <= min(cz + 1, h.dims[2] - 1); ++z)
@@ -290,19 +311,11 @@ __global__ void k_grid_dilate(NfGridHeader h, void* ws)
             tot += cs[r0 + x1 + 1] - cs[r0 + x0];  // cells of one x-row are contiguous
         }
     ((int*)(b + h.off_cell_dil))[c] = tot;
-    // particle AABB of this cell
-    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    const float4* sp = (const float4*)(b + h.off_sorted_pos);
-    for (int t = cs[c]; t < cs[c + 1]; ++t) {
-        float4 p = sp[t];
-        lo[0] = fminf(lo[0], p.x); lo[1] = fminf(lo[1], p.y); lo[2] = fminf(lo[2], p.z);
-        hi[0] = fmaxf(hi[0], p.x); hi[1] = fmaxf(hi[1], p.y); hi[2] = fmaxf(hi[2], p.z);
-    }
     float* bb = (float*)(b + h.off_cell_aabb) + 6 * c;
     bb[0] = lo[0]; bb[1] = lo[1]; bb[2] = lo[2]; bb[3] = hi[0]; bb[4] = hi[1]; bb[5] = hi[2];
     float4* rec = (float4*)(b + h.off_cell_rec) + 3 * c;
-    int mn = cs[c + 1] > cs[c] ? ((const int*)(b + h.off_sorted_idx))[cs[c]] : 0x7fffffff;
-    rec[0] = make_float4(__int_as_float(cs[c]), __int_as_float(cs[c + 1]), __int_as_float(mn), 0.f);
+    int mn = s1 > s0 ? ((const int*)(b + h.off_sorted_idx))[s0] : 0x7fffffff;
+    rec[0] = make_float4(__int_as_float(s0), __int_as_float(s1), __int_as_float(mn), 0.f);
     rec[1] = make_float4(lo[0], lo[1], lo[2], hi[0]);
     rec[2] = make_float4(hi[1], hi[2], 0.f, 0.f);
 }
@@ -387,7 +400,7 @@ extern "C" int nf_grid_build(const float* pts, int n, float cell, const float bb
         NF_CHECK_LAUNCH();
         return NF_OK;
     }
-    hipLaunchKernelGGL(k_grid_dilate, dim3(gc), dim3(B), 0, st, h, ws);
+    hipLaunchKernelGGL(k_grid_dilate, dim3((h.n_cells + 3) / 4), dim3(256), 0, st, h, ws);      // a wave per cell
     launch_scan<int>((const int*)((char*)ws + h.off_cell_dil), (int*)((char*)ws + h.off_dil_start), fill + h.n_cells + 8,
                      h.n_cells, st);
     if (n > 0) {

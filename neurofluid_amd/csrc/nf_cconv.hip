@@ -778,13 +778,28 @@ __global__ void __launch_bounds__(64 * CIN) k_cconv_small_wgemm(const float* __r
     for (int co = 0; co < 32; ++co) out[co] = acc[co];
 }
 
-__global__ void k_cconv_small_wreduce(const float* __restrict__ partial, int total, int nslices, float* __restrict__ dK)
+// 64 outputs x 4 slice groups per workgroup: a group adds every fourth slice with four loads in flight, the groups are
+// folded through LDS in a fixed order (a thread per output walking all 128 slices one load after the other: 32 us for 4 MB)
+__global__ void __launch_bounds__(256) k_cconv_small_wreduce(const float* __restrict__ partial, int total, int nslices,
+                                                             float* __restrict__ dK)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    float s = 0.f;
-    for (int z = 0; z < nslices; ++z) s += partial[(size_t)z * total + i];
-    dK[i] += s;                                       // accumulate: the caller zero-initialises (as before)
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < total) {
+        int z = g;
+        for (; z + 12 < nslices; z += 16) {
+            s0 += partial[(size_t)z * total + i];
+            s1 += partial[(size_t)(z + 4) * total + i];
+            s2 += partial[(size_t)(z + 8) * total + i];
+            s3 += partial[(size_t)(z + 12) * total + i];
+        }
+        for (; z < nslices; z += 4) s0 += partial[(size_t)z * total + i];
+    }
+    part[g][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (g == 0 && i < total) dK[i] += (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);   // accumulate: the caller zero-initialises
 }
 
 extern "C" size_t nf_cconv_small_bwd_filter_workspace_floats(int cin, int n_out)
@@ -815,7 +830,7 @@ extern "C" int nf_cconv_small_bwd_filter(const float* feats, int cin, const int6
         hipLaunchKernelGGL(k_cconv_small_wgemm<4>, dim3(SWG_SLICES), dim3(256), 0, st, (const float*)A, dy, ld_dy, col_off, n_out,
                            rows_per, partial);
     }
-    hipLaunchKernelGGL(k_cconv_small_wreduce, dim3((total + 255) / 256), dim3(256), 0, st, (const float*)partial, total, SWG_SLICES,
+    hipLaunchKernelGGL(k_cconv_small_wreduce, dim3((total + 63) / 64), dim3(256), 0, st, (const float*)partial, total, SWG_SLICES,
                        dkernel);
     NF_CHECK_LAUNCH();
     return NF_OK;

@@ -609,6 +609,59 @@ __global__ void __launch_bounds__(256) k_cconv_gather_t(const float* __restrict_
     }
 }
 
+// cout <= 4 (the last layer: 3 channels): lane = CELL.  With lane = channel only 3 lanes of the wave above work; here every
+// lane owns one of the 64 cells, finds its weight in a pair's 8 corners by comparison with the broadcast cell ids and keeps
+// COUT accumulators in registers — no LDS, ~25 instructions per pair instead of ~150 (31 -> ~10 us per launch).
+template <int COUT>
+__global__ void __launch_bounds__(64) k_cconv_gather_t_small(const float* __restrict__ dy, const int64_t* __restrict__ row_splits,
+                                                             const int32_t* __restrict__ nbr, const float* __restrict__ tpw,
+                                                             const uint8_t* __restrict__ tpc, int n, float* __restrict__ dG)
+{
+    const int lane = threadIdx.x;
+    for (int row = blockIdx.x; row < n; row += gridDim.x) {
+        const int64_t s = row_splits[row], e = row_splits[row + 1];
+        float acc[COUT];
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
+        for (int64_t base = s; base < e; base += 64) {
+            const int cnt = __builtin_amdgcn_readfirstlane((int)((e - base) < 64 ? (e - base) : 64));
+            int jl = 0, c03 = 0, c47 = 0;
+            float w8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, g[COUT];
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) g[co] = 0.f;
+            if (lane < cnt) {
+                const int64_t p = base + lane;
+                jl = nbr[p];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    w8[k] = tpw[p * 8 + k];
+                    const int c = tpc[p * 8 + k];
+                    if (k < 4) c03 |= c << (8 * k); else c47 |= c << (8 * (k - 4));
+                }
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) g[co] = dy[(size_t)jl * COUT + co];      // lane t holds pair t's dy row
+            }
+            for (int t = 0; t < cnt; ++t) {
+                const int a03 = __builtin_amdgcn_readlane(c03, t), a47 = __builtin_amdgcn_readlane(c47, t);
+                float wl = 0.f;                                   // this cell's weight in pair t (corners in order)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int ck = ((k < 4 ? a03 >> (8 * k) : a47 >> (8 * (k - 4))) & 63);
+                    const float wk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w8[k]), t));
+                    wl += ck == lane ? wk : 0.f;
+                }
+#pragma unroll
+                for (int co = 0; co < COUT; ++co)
+                    acc[co] += wl * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g[co]), t));
+            }
+        }
+        float* out = dG + (size_t)row * (65 * COUT);
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) out[lane * COUT + co] = acc[co];
+        if (lane < COUT) out[64 * COUT + lane] = dy[(size_t)row * COUT + lane];
+    }
+}
+
 // cout = 64 on the matrix pipe: for one particle the transposed gather is a small dense product,
 //     dG[cell][co] = sum_t W[t][cell] * dy[j_t][co],      W[t][cell] = sum of pair t's corner weights that fall on `cell`
 // (8 non-zeros per row of W).  A wave scatters its chunk of up to 64 pairs into W in LDS (lane t owns row t: its own 8
@@ -698,6 +751,18 @@ extern "C" int nf_cconv_gather_bwd(const float* dy, int cout, const int64_t* row
     NF_CHECK_ARG(dy && row_splits && dG, "null pointer");
     NF_CHECK_ARG(cout >= 1 && cout <= 64, "cout must be in [1,64]");
     if (n <= 0) return NF_OK;
+    if (cout <= 4) {
+        const int blocks_s = n < 16384 ? n : 16384;
+        hipStream_t st_ = (hipStream_t)stream;
+        switch (cout) {
+            case 1: hipLaunchKernelGGL(k_cconv_gather_t_small<1>, dim3(blocks_s), dim3(64), 0, st_, dy, row_splits, nbr, pair_w_t, pair_cell_t, n, dG); break;
+            case 2: hipLaunchKernelGGL(k_cconv_gather_t_small<2>, dim3(blocks_s), dim3(64), 0, st_, dy, row_splits, nbr, pair_w_t, pair_cell_t, n, dG); break;
+            case 3: hipLaunchKernelGGL(k_cconv_gather_t_small<3>, dim3(blocks_s), dim3(64), 0, st_, dy, row_splits, nbr, pair_w_t, pair_cell_t, n, dG); break;
+            default: hipLaunchKernelGGL(k_cconv_gather_t_small<4>, dim3(blocks_s), dim3(64), 0, st_, dy, row_splits, nbr, pair_w_t, pair_cell_t, n, dG); break;
+        }
+        NF_CHECK_LAUNCH();
+        return NF_OK;
+    }
     if (cout == 64) {
         int blocks64 = n < 16384 ? n : 16384;
         hipLaunchKernelGGL(k_cconv_gather_t64, dim3(blocks64), dim3(64), 0, (hipStream_t)stream, dy, row_splits, nbr, pair_w_t,

@@ -32,8 +32,12 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #define H2_CHUNK 16          // A blocks (1 KB each) per ring chunk
 #define H2_RING 48           // ring = 3 chunks
+#ifndef H2_PF
 #define H2_PF 3              // A-operand prefetch distance (steps)
+#endif
+#ifndef H2_BND
 #define H2_BND 12            // the chunk rendezvous runs at the start of step (chunk * 16 + 12)
+#endif
 #define H2_XS 13             // X K-steps of the position-like part (200 padded features -> 13 x 16)
 
 enum { H2K_BIAS = 0, H2K_X = 1, H2K_H = 2 };

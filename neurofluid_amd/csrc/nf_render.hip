@@ -681,6 +681,140 @@ __global__ void __launch_bounds__(64) k_composite(const float4* __restrict__ rgb
     if (mask_sum) mask_sum[r] = (float)ms;
 }
 
+// The fused renderer's case (mask bits from the neighbour counts, rows 16-B tiled, S <= 256), software-pipelined: the mask
+// bits of ALL tiles of the 64 rays are fetched up front (16 bits per tile, 8 registers, published once through LDS), tiles
+// without a live sample in the whole wave are skipped without touching memory, and the rgbsigma / z values of the NEXT live
+// tile are in flight (held in registers) while this tile is walked.  k_composite pays three dependent global round trips
+// per tile (counts -> gated rgbsigma / z -> walk), 12 tiles per ray at S = 192, and its duration is that of ONE block
+// (the ~750 blocks that touch the fluid are all resident at once: halving the occupancy changes nothing).  Same
+// arithmetic in the same order: bit-identical outputs.
+__global__ void __launch_bounds__(64) k_composite_p(const float4* __restrict__ rgbsigma, const float* __restrict__ z,
+                                                    const float* __restrict__ z_table, const float* __restrict__ rays, int gate,
+                                                    int R, int S, int white_bg, float* __restrict__ rgb, float* __restrict__ depth,
+                                                    float* __restrict__ opacity, float* __restrict__ weights,
+                                                    float* __restrict__ mask_sum, const int* __restrict__ num_nn, int k_full)
+{
+    __shared__ float4 s_rs[64 * CP_PITCH];
+    __shared__ float s_z[64 * (CP_TS + 1) + 64];
+    __shared__ float s_w[64 * CP_PITCH];
+    __shared__ unsigned s_mw[64][8];        // per ray: 16 live-sample bits per tile, two tiles per word
+    const int t = threadIdx.x;
+    const int r0 = blockIdx.x * 64, r = r0 + t;
+    const bool live = r < R;
+    const int NT = S >> 4;
+    float nrm = 0.f;
+    if (live) {
+        const float* ry = rays + 6 * (size_t)r;
+        nrm = sqrtf(ry[3] * ry[3] + ry[4] * ry[4] + ry[5] * ry[5]);
+    }
+    // ---- mask bits of every tile of this ray: 4 x 16 B per tile, all loads independent
+    unsigned mw[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    int ms = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        unsigned bits = 0u;
+        if (live && w < NT) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int4 nv = *(const int4*)(num_nn + (size_t)r * S + 16 * w + 4 * q);
+                bits |= ((nv.x == k_full ? 1u : 0u) | (nv.y == k_full ? 2u : 0u) | (nv.z == k_full ? 4u : 0u) |
+                         (nv.w == k_full ? 8u : 0u)) << (4 * q);
+            }
+        }
+        ms += __popc(bits);
+        if (!gate) bits = (live && w < NT) ? 0xffffu : 0u;      // samples whose rgbsigma is read
+        if (w & 1) mw[w >> 1] |= bits << 16; else mw[w >> 1] = bits;
+    }
+    unsigned tile_act = 0u;                                     // wave-uniform: tiles with a live sample in any of the 64 rays
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const unsigned bits = (w & 1) ? (mw[w >> 1] >> 16) : (mw[w >> 1] & 0xffffu);
+        if (__ballot(bits != 0u) != 0ull) tile_act |= 1u << w;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s_mw[t][k] = mw[k];
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    const int sub = t >> 4, col = t & 15;   // staging role: ray-in-group, sample-in-tile
+    float4 prs[16];
+    float pz[16], pzx[16];
+    auto fetch = [&](int w) {               // tile w -> registers (4 rays per instruction, 16 samples x 16 B each)
+        const int s0 = 16 * w;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int rr = i * 4 + sub, gr = r0 + rr, gs = s0 + col;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const unsigned word = s_mw[rr][w >> 1];
+            if (gr < R && ((word >> (16 * (w & 1) + col)) & 1u)) v = rgbsigma[(size_t)gr * S + gs];
+            prs[i] = v;
+            pz[i] = z ? (gr < R ? z[(size_t)gr * S + gs] : 0.f) : z_table[gs];
+            pzx[i] = 0.f;
+            if (col == 0 && s0 + CP_TS < S) pzx[i] = z ? (gr < R ? z[(size_t)gr * S + s0 + CP_TS] : 0.f) : z_table[s0 + CP_TS];
+        }
+    };
+    float T = 1.f, cr = 0.f, cg = 0.f, cb = 0.f, cd = 0.f, ws = 0.f;
+    if (tile_act) fetch(__ffs(tile_act) - 1);
+    for (int w = 0; w < NT; ++w) {
+        const int s0 = 16 * w;
+        if (!((tile_act >> w) & 1u)) {
+            // nothing to composite in this tile for any of the 64 rays
+            if (weights) {
+#pragma unroll 4
+                for (int i = 0; i < 16; ++i) {
+                    const int rr = i * 4 + sub, gr = r0 + rr, gs = s0 + col;
+                    if (gr < R) weights[(size_t)gr * S + gs] = 0.f;
+                }
+            }
+            continue;
+        }
+        // ---- registers -> LDS
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int rr = i * 4 + sub;
+            s_rs[rr * CP_PITCH + col] = prs[i];
+            s_z[rr * (CP_TS + 1) + col] = pz[i];
+            if (col == 0) s_z[rr * (CP_TS + 1) + CP_TS] = pzx[i];
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        // ---- the next live tile's values go in flight behind this tile's walk
+        const unsigned later = tile_act & ~((2u << w) - 1u);
+        if (later) fetch(__ffs(later) - 1);
+        // ---- sequential walk of this thread's ray
+        if (live) {
+#pragma unroll 4
+            for (int k = 0; k < CP_TS; ++k) {
+                const int sidx = s0 + k;
+                const float zc = s_z[t * (CP_TS + 1) + k], zn = s_z[t * (CP_TS + 1) + k + 1];
+                const float delta = ((sidx + 1 < S) ? (zn - zc) : 1e10f) * nrm;
+                const float4 v = s_rs[t * CP_PITCH + k];
+                const float alpha = 1.f - expf(-delta * fmaxf(v.w, 0.f));
+                const float wgt = alpha * T;
+                T = T * ((1.f - alpha) + 1e-10f);
+                cr += wgt * v.x; cg += wgt * v.y; cb += wgt * v.z; cd += wgt * zc; ws += wgt;
+                s_w[t * CP_PITCH + k] = wgt;
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        // ---- stage out the weights (64 B per ray per instruction)
+        if (weights) {
+#pragma unroll 4
+            for (int i = 0; i < 16; ++i) {
+                const int rr = i * 4 + sub, gr = r0 + rr, gs = s0 + col;
+                if (gr < R) weights[(size_t)gr * S + gs] = s_w[rr * CP_PITCH + col];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (!live) return;
+    if (white_bg) { cr = cr + 1.f - ws; cg = cg + 1.f - ws; cb = cb + 1.f - ws; }
+    rgb[3 * (size_t)r] = cr; rgb[3 * (size_t)r + 1] = cg; rgb[3 * (size_t)r + 2] = cb;
+    depth[r] = cd;
+    opacity[r] = ws;
+    if (mask_sum) mask_sum[r] = (float)ms;
+}
+
 // Small ray counts (training steps): a wave per ray, as k_composite_bwd_w below — the elementwise work and the global accesses
 // on 64 lanes, the recurrence T_i and the five running sums walked by one lane over LDS in sample order (the results are
 // those of the thread-per-ray kernel bit for bit; 1 024 rays there are 16 waves on the whole chip for 45 us).
@@ -751,6 +885,12 @@ extern "C" int nf_composite_fwd(const float* rgbsigma, const float* z, const flo
     if (R <= 16384 && lds_w <= 64 * 1024) {             // few rays: a wave per ray (see k_composite_w)
         hipLaunchKernelGGL(k_composite_w, dim3((R + 3) / 4), dim3(256), lds_w, (hipStream_t)stream, (const float4*)rgbsigma, z,
                            z_table, rays, mask, gate_by_mask, R, S, white_bg, rgb, depth, opacity, weights, mask_sum, num_nn, k_full);
+        NF_CHECK_LAUNCH();
+        return NF_OK;
+    }
+    if (!mask && num_nn && (S & 15) == 0 && S <= 256) {
+        hipLaunchKernelGGL(k_composite_p, dim3((R + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const float4*)rgbsigma, z, z_table,
+                           rays, gate_by_mask, R, S, white_bg, rgb, depth, opacity, weights, mask_sum, num_nn, k_full);
         NF_CHECK_LAUNCH();
         return NF_OK;
     }

@@ -1006,6 +1006,44 @@ def test_composite_forward_wave_per_ray_bit_equal(dev):
             assert torch.equal(small[3], mask.sum(1).float())
 
 
+def test_composite_pipelined_kernel_bit_equal(dev):
+    """nf_composite_fwd at frame size with the mask bits taken from the neighbour counts and 16-B tiled rows (S % 16 == 0,
+    S <= 256) runs the software-pipelined kernel (k_composite_p: mask bits of all tiles up front, the next live tile in
+    flight behind the walk); the same rays with the mask given as bytes run k_composite.  Same arithmetic in the same order:
+    rgb, depth, opacity, weights and mask_sum bit for bit — gated and ungated, with whole tiles and whole rays empty."""
+    from neurofluid_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(31)
+    R = 16384 + 200                                     # past the wave-per-ray switch, ragged last block
+    for S, gate, want_w in [(192, 1, True), (64, 1, True), (256, 1, False), (192, 0, True)]:
+        rs = torch.rand(R, S, 4, generator=gen)
+        rs[..., 3] = rs[..., 3] * 30 - 5
+        mask = torch.rand(R, S, generator=gen) < 0.3
+        mask[::3] = False                                # whole rays without a live sample
+        mask[:, 32:64] = False                           # whole tiles without a live sample
+        mask[1000:1064] = False                          # a whole block without a live sample
+        z = torch.sort(torch.rand(R, S, generator=gen) * 4 + 9, dim=1).values
+        rays = torch.randn(R, 6, generator=gen)
+        src = torch.where(mask[..., None], rs, torch.full_like(rs, float("nan"))) if gate else rs
+        nn = torch.where(mask, torch.full((R, S), 20), torch.randint(0, 20, (R, S), generator=gen)).to(torch.int32)
+        rs_d, z_d, ry_d, m_d, nn_d = src.to(dev), z.to(dev), rays.to(dev), mask.to(torch.uint8).to(dev), nn.to(dev)
+
+        def run(by_counts):
+            rgb = torch.empty(R, 3, device=dev); depth = torch.empty(R, device=dev); op = torch.empty(R, device=dev)
+            w = torch.empty(R, S, device=dev) if want_w else None
+            msum = torch.empty(R, device=dev)
+            _lib.check(lib.nf_composite_fwd(rs_d.data_ptr(), z_d.data_ptr(), None, ry_d.data_ptr(),
+                                            None if by_counts else m_d.data_ptr(), gate, R, S, 1, rgb.data_ptr(), depth.data_ptr(),
+                                            op.data_ptr(), w.data_ptr() if w is not None else None, msum.data_ptr(),
+                                            nn_d.data_ptr() if by_counts else None, 20, _lib.stream()))
+            return [rgb.cpu(), depth.cpu(), op.cpu(), msum.cpu()] + ([w.cpu()] if w is not None else [])
+        a, b = run(True), run(False)
+        for x, y in zip(a, b):
+            assert torch.equal(x, y), (S, gate)
+        assert torch.equal(a[3], mask.sum(1).float())
+        assert bool(torch.isfinite(a[0]).all())
+
+
 def test_importance_wave_per_ray_bit_equal(dev):
     """nf_importance_sample: the wave-per-ray kernel of small calls (R <= 16 384) against the thread-per-ray kernel (the same
     rays tiled past the switch), with and without the shared zero row, weights with exact zeros / near-flat pdfs / spikes."""

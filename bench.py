@@ -8,12 +8,12 @@ One "step" = the coupled per-frame body of the reference's e2e loop (eval_e2e.py
 step on the 4 913-particle cloud (replicated on every rank: the step does not shard), a rebuild of the renderer's
 particle grid (the cloud moved), then the full coarse+fine render, RGB tiles all-gathered over RCCL inside the timed
 region.
-  --scaling weak   (default; what the driver's N=1/2/4/8 runs measure): N views of 400x400, view k -> rank k mod N —
-                   per-GPU work fixed.
-  --scaling strong ONE image (--image 400 or 800) split into 1024-multiple ray chunks interleaved over the ranks
-                   (chunk k -> rank k mod N, the seam of trainer/basetrainer.py:282-289) — total work fixed; the JSON
-                   then also carries the executed MLP rows of every rank and their max/mean imbalance, next to the
-                   imbalance the same chunks would give under a contiguous assignment.
+  --scaling strong (default; what the driver's N=1/2/4/8 runs measure = north_star's "ray-tile scaling"): ONE image
+                   (--image 400 or 800) split into 1024-ray chunks interleaved over the ranks (chunk k -> rank k mod N,
+                   the seam of trainer/basetrainer.py:282-289), RGB tiles all-gathered inside the timed region — total
+                   work fixed; the JSON carries the executed MLP rows of every rank and their max/mean imbalance
+                   (`max_over_mean`), next to the imbalance the same chunks would give under a contiguous assignment.
+  --scaling weak   N views of 400x400, view k -> rank k mod N — per-GPU work fixed (embarrassingly parallel).
 With --workload train the step is one train_renderer.py optimiser step (4 views x 1024 rays per rank, forward +
 backward + Adam, gradients all-reduced) — BASELINE.json configs[1].
 Prints ONE JSON line on rank 0 (contract in the task statement) incl. `roofline` (dominant kernel = the fp32-MFMA
@@ -38,7 +38,11 @@ MLP_FLOP_PER_ROW = 1331968          # 665 984 MAC per sample
 PARTICLE_STEP_FLOP = 1385088
 F32_MATRIX_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
 F16_MATRIX_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense fp16 MFMA
-PMC_FILES = ("round2_mlp_pmc.json", "round1_mlp_pmc.json")      # newest first
+F32_VECTOR_PEAK_TFLOPS = 157.3
+HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s
+PMC_FILES = ("round3_mlp_pmc.json", "round2_mlp_pmc.json", "round1_mlp_pmc.json")      # newest first
+TRANS_PMC_FILES = ("round3_transition_pmc.json", "round2_transition_pmc.json")
+TRANS_STATS_FILES = ("round3_transition_kernel_stats.csv", "round2_transition_kernel_stats.csv")
 
 
 def renderer_cfg():
@@ -164,6 +168,31 @@ def committed_traffic():
     return None, None
 
 
+def committed_transition():
+    """Per-step HBM-side bytes and per-kernel microseconds of the transition step from the COMMITTED rocprofv3 passes of
+    `tools/trans_perf.py` (separate --pmc passes; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE).  One k_trans_prepare
+    launch = one step."""
+    for name in TRANS_PMC_FILES:
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        d = json.load(open(path))
+        ks = d.get("kernels", {})
+        steps = (ks.get("k_trans_prepare") or {}).get("calls")
+        if not steps:
+            continue
+        hbm, us = 0.0, {}
+        for k, e in ks.items():
+            per_step = e.get("calls", 0) / steps
+            hbm += (e.get("fetch_bytes_x2", 0.0) + e.get("write_bytes", 0.0)) * per_step
+            us[k] = round(e.get("avg_us", 0.0) * per_step, 2)
+        return {"hbm_bytes_per_step": hbm, "kernel_us_per_step": us,
+                "source": {"file": "profiles/" + name, "git_blob": _git_blob(path), "steps_profiled": steps,
+                           "note": "recorded by separate rocprofv3 --kernel-trace / --pmc passes of `tools/trans_perf.py`, NOT "
+                                   "measured by this run"}}
+    return None
+
+
 def imbalance(per_chunk_rows, world, interleaved=True):
     n = len(per_chunk_rows)
     loads = [0] * world
@@ -179,7 +208,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="render", choices=["render", "train"])
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"])
     ap.add_argument("--image", type=int, default=400, choices=[400, 800], help="image edge of --scaling strong")
     ap.add_argument("--chunk", type=int, default=0,
                     help="rays per chunk dealt to the ranks (multiple of 1024). 0 = weak: one whole 400x400 view; strong: 1024")
@@ -285,7 +314,7 @@ def main():
     rows = sum(prof["rows"])
     n_launch = max(len(prof["mlp"]), 1)
     achieved = rows * MLP_FLOP_PER_ROW / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
-    traffic, traffic_src = committed_traffic() if args.workload == "render" and not strong else (None, None)
+    traffic, traffic_src = committed_traffic() if args.workload == "render" and world == 1 and image == 400 else (None, None)
     roofline = {"bound": "mfma", "kernel": "k_mlp_fwd_l (fp32 v_mfma_f32_32x32x2_f32, weights through an LDS ring)",
                 "achieved": achieved, "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_MATRIX_PEAK_TFLOPS,
                 "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": traffic_src,
@@ -317,7 +346,7 @@ def main():
                 for g in (2, 4, 8)}
             balance["chunks_without_active_rows"] = int(sum(1 for c in chunks if c == 0))
 
-    pstep = fp16_extra = train_extra = None
+    pstep = fp16_extra = train_extra = trans_roofline = coupled_extra = None
     if not args.no_extras:
         # ---- transition model alone (particle-steps/sec), rank-local state
         tp, tv = P0.clone(), torch.zeros_like(P0)
@@ -331,7 +360,21 @@ def main():
             with torch.no_grad():
                 tp, tv, _ = pn(tp, tv, box, bn)
         torch.cuda.synchronize()
-        pstep = P0.shape[0] * nts / (time.perf_counter() - t1)
+        pstep_dt = (time.perf_counter() - t1) / nts
+        pstep = P0.shape[0] / pstep_dt
+        # roofline of the transition step (north_star: "achieved HBM GB/s on the gather" next to the MFMA figure): executed
+        # FLOP = BASELINE.md section 2's per-particle-step count x particles (all of it runs on fp32 MFMA or the fp32 VALU,
+        # same 157.3 TFLOP/s peak), time measured here; HBM-side bytes from the committed PMC passes
+        ct = committed_transition()
+        tflops = PARTICLE_STEP_FLOP * P0.shape[0] / pstep_dt / 1e12
+        trans_roofline = {"bound": "mfma (conv1 / conv2 contractions) after the gather is taken off HBM", "flop_per_particle_step": PARTICLE_STEP_FLOP,
+                          "particles": int(P0.shape[0]), "us_per_step": pstep_dt * 1e6, "achieved": tflops,
+                          "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / F32_MATRIX_PEAK_TFLOPS,
+                          "traffic": ct["hbm_bytes_per_step"] if ct else None, "traffic_unit": "HBM-side bytes per step (PMC)",
+                          "hbm_GBps": (ct["hbm_bytes_per_step"] / pstep_dt / 1e9) if ct else None,
+                          "hbm_frac": (ct["hbm_bytes_per_step"] / pstep_dt / 1e9 / HBM_PEAK_GBS) if ct else None,
+                          "kernel_us_per_step": ct["kernel_us_per_step"] if ct else None,
+                          "traffic_source": ct["source"] if ct else None}
 
     # ---- extras (NOT the headline, which stays fp32 = the reference's arithmetic): the same render step with
     #   fp16:  the fp16-MFMA MLP, fp32 accumulate (BASELINE config 5)
@@ -385,8 +428,36 @@ def main():
                             "note": "render only; same tolerance as the fp32 path (tests/test_gpu_render.py::test_split_precision_path); "
                                     "not the headline value"})
 
+    # ---- extra: the frame body with the renderer consuming what the transition step PRODUCED (a moving cloud: grid rebuild
+    # on real motion, bbox hint one frame stale, row capacities tracking the spreading fluid); the state is reset to P0
+    # every 8 frames so that the body stays in view.  The stationary headline above renders P0 every frame.
+    if args.workload == "render" and not args.no_extras:
+        cst = {"i": 0, "pos": P0.clone(), "vel": torch.zeros_like(P0)}
+
+        def step_coupled():
+            with torch.no_grad():
+                if cst["i"] % 8 == 0:
+                    cst["pos"], cst["vel"] = P0.clone(), torch.zeros_like(P0)
+                cst["i"] += 1
+                cst["pos"], cst["vel"], _ = pn(cst["pos"], cst["vel"], box, bn)
+                return render_image(net, cst["pos"], n_rays, roc, rays, None, None, iseval=True, ray_chunk=args.chunk, rank=rank,
+                                    world=world, gather=False, device_chunk=device_chunk)
+        for _ in range(8):
+            step_coupled()
+        sync()
+        per_step = []
+        for _ in range(16):
+            t4 = time.perf_counter()
+            step_coupled()
+            sync()
+            per_step.append(time.perf_counter() - t4)
+        dtc = sorted(per_step)[len(per_step) // 2]
+        coupled_extra = {"workload": "ParticleNet step -> render of the PREDICTED positions (state reset to P0 every 8 frames)",
+                         "ms_per_step_median": dtc * 1e3, "rays_per_sec": n_rays / dtc,
+                         "ms_per_step_by_frame_of_cycle": [round(sum(per_step[k::8]) / len(per_step[k::8]) * 1e3, 3) for k in range(8)]}
+
     # ---- extra: BASELINE configs[1] (train_renderer.py step: 4 views x 1024 rays, fwd + bwd + Adam) on this rank
-    if args.workload == "render" and not args.no_extras and not strong:
+    if args.workload == "render" and not args.no_extras and image == 400:
         from neurofluid_amd.train_step import make_train_step
         net_t = RenderNet(renderer_cfg(), 9.0, 13.0)
         net_t.load_state_dict(scene["nerf_state"], strict=True)
@@ -395,13 +466,24 @@ def main():
         for _ in range(8):
             tstep()
         sync()
+        ops.PROFILE = {"mlp": [], "rows": []}
         t3 = time.perf_counter()
         for _ in range(20):
             tstep()
         sync()
         dtt = (time.perf_counter() - t3) / 20
+        pt = ops.PROFILE
+        ops.PROFILE = None
+        trows = sum(int(r.item()) if torch.is_tensor(r) else int(r) for r in pt["rows"]) / 20
+        # executed FLOP of the step's matrix work: forward + data gradient + weight gradient of every active MLP row
+        # (3 x 1 331 968 per row), against the fp32 matrix peak; Adam, composite, search, features are not counted
+        ttf = trows * MLP_FLOP_PER_ROW * 3 / dtt / 1e12
         train_extra = {"workload": "train_renderer.py step: 4 views x 1024 rays per rank, forward + backward + Adam (+ grad all-reduce)",
-                       "ms_per_step": dtt * 1e3, "rays_per_sec": 4096 * world / dtt}
+                       "ms_per_step": dtt * 1e3, "rays_per_sec": 4096 * world / dtt,
+                       "executed_mlp_rows_per_step": trows, "flop_per_row_fwd_bwd_wgrad": 3 * MLP_FLOP_PER_ROW,
+                       "roofline": {"bound": "mfma", "achieved": ttf, "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": ttf / F32_MATRIX_PEAK_TFLOPS,
+                                    "note": "whole-step wall time (host + all kernels) against the MLP FLOP only"}}
 
     if rank == 0:
         if args.workload == "render":
@@ -414,15 +496,18 @@ def main():
                           if args.workload == "render" else
                           "rays/sec of the train_renderer.py optimiser step (forward + backward + Adam), watercube 400^2"),
                "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+               "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+               "scaling": "weak" if args.workload == "train" else args.scaling, "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": wl, "particles": int(P0.shape[0]), "image": "%dx%d" % (image, image), "N_samples": 64,
                           "N_importance": 128, "K": 20, "use_mask": True, "device_ray_chunk": args.chunk},
                "particle_steps_per_sec": pstep,
                "particle_steps_note": "ParticleNet.forward alone on one GPU; the 4913-particle step does not shard (replicas only: "
                                       "every rank advances the same state), so this figure is per replica, not multiplied by N",
-               "roofline": roofline, "load_balance": balance, "fp16_mfma_path": fp16_extra, "split_precision_path": split_extra,
-               "train_step": train_extra}
+               "roofline": roofline, "roofline_transition": trans_roofline, "load_balance": balance,
+               "max_over_mean": balance["max_over_mean"] if balance else None,
+               "fp16_mfma_path": fp16_extra, "split_precision_path": split_extra,
+               "train_step": train_extra, "coupled_moving_cloud": coupled_extra}
         if single_dev and world > 1:
             res["single_device_emulation"] = ("NF_BENCH_SINGLE_DEVICE=1: %d ranks time-share ONE GPU over gloo; control flow and "
                                               "load-balance accounting are real, `value` is not a scaling measurement" % world)
@@ -430,7 +515,7 @@ def main():
             res["host_marks_ms"] = [round(m * 1e3, 2) for m in host_marks]
         if world == 1 and not args.no_cpu_baseline:
             hip_frame = hip_step = None
-            if args.workload == "render" and image == 400 and not strong:
+            if args.workload == "render" and image == 400:
                 hip_step, hp, hv = [], P0, torch.zeros_like(P0)
                 with torch.no_grad():
                     for _ in range(5):

@@ -124,7 +124,7 @@ int nf_render_features(const float* particles /*Np*3*/, const float* rays, const
                        const float* ro /*3, or R*3 when ro_per_ray (several views batched in one call)*/, int ro_per_ray,
                        const int32_t* row_sample, const int32_t* row_nbr, const int32_t* n_rows, int max_rows,
                        void* X, int x_fp16, nf_stream_t stream);
-/* x_fp16 != 0 (operand of nf_nerf_mlp_fwd_h): Xh[tile][t][lane] x 16 B = the lane's 8 halves of K-step t, i.e.
+/* x_fp16 != 0 (operand of nf_nerf_mlp_fwd_h2): Xh[tile][t][lane] x 16 B = the lane's 8 halves of K-step t, i.e.
  * features 16t+4h+e (e < 4) and 16t+8+4h+e, round-to-nearest-even — half the bytes of the fp32 layout. */
 /* A12 (feature part, e2e training): dparticles[j] += dL/d(particle j) given dX (row-major, n_rows x (cx+cd)) =
  * dL/d(feature row).  Gradients flow only through the gathered neighbour positions (models/renderer.py:96-109,
@@ -160,17 +160,6 @@ int nf_nerf_mlp_fwd_l(const float* packed, const float* wstream, int cx, int cd,
                       const int32_t* n_rows, int max_rows, const int32_t* row_sample, float* rgbsigma,
                       nf_stream_t stream);
 
-/* A6, fp16-MFMA variant (BASELINE config 5: "fp16 MFMA path"): v_mfma_f32_32x32x16_f16 with fp32 accumulation; the
- * weight stream is shared by the 4 waves of a workgroup through an LDS ring; sigma/rgb heads and biases (hi+lo
- * split) keep fp32 accuracy.  Inference only; `packed` (fp32 blob of nf_nerf_pack) supplies the heads.
- * Default encodings only (198 + 54 features). */
-size_t nf_nerf_packed_h_bytes(void);
-int nf_nerf_pack_h(const nf_nerf_params_t* params /*[host]*/, int cx, int cd, void* stream_h, nf_stream_t stream);
-int nf_nerf_mlp_fwd_h(const float* packed, const void* stream_h, int cx, int cd,
-                      const void* Xh /* fp16 operand layout: nf_render_features(..., x_fp16 = 1) */,
-                      const int32_t* n_rows, int max_rows, const int32_t* row_sample, float* rgbsigma,
-                      nf_stream_t stream);
-
 /* A6 for small launches (models/nerf.py:83-124, the forward of a training step; nf_mlp_n.hip): one 32-row tile per WORKGROUP, a layer's 8 output blocks split over its 4 waves,
  * activations exchanged through an LDS image — a quarter of nf_nerf_mlp_fwd's per-tile latency (it keeps a tile in one
  * wave for 0.35 ms: a launch costs ceil(tiles / 1024) such rounds however empty the last one is).  Same packed blob, same
@@ -179,7 +168,7 @@ int nf_nerf_mlp_fwd_n(const float* packed, int cx, int cd, const float* X, const
                       const int32_t* row_sample, float* rgbsigma, float* acts /*or NULL*/, nf_stream_t stream);
 
 /* fp16-MFMA forward of A6 (models/nerf.py:83-124), version 3 (nf_mlp_h2.hip): two 32-row tiles per wave, out-block-major, packed fp16 activations
- * between layers, sigma / rgb heads on the matrix pipe.  Same operand X as nf_nerf_mlp_fwd_h (the fp16 layout written
+ * between layers, sigma / rgb heads on the matrix pipe.  Operand X: the fp16 layout written
  * by nf_render_features(x_fp16 = 1)), which must be allocated for an EVEN number of 32-row tiles; its own weight stream. */
 size_t nf_nerf_packed_h2_bytes(void);
 int nf_nerf_pack_h2(const nf_nerf_params_t* params, int cx, int cd, void* stream_h2, nf_stream_t stream);
@@ -193,6 +182,26 @@ size_t nf_nerf_packed_s_bytes(void);
 int nf_nerf_pack_s(const nf_nerf_params_t* params, int cx, int cd, void* stream_s, nf_stream_t stream);
 int nf_nerf_mlp_fwd_s(const void* stream_s, int cx, int cd, const float* X, const int32_t* n_rows, int max_rows,
                       const int32_t* row_sample, float* rgbsigma, nf_stream_t stream);
+
+/* A5 standalone: Embedding.forward (models/nerf.py:21-38), for callers that drive the reference's modules one by one.
+ * out[b][c] = x[b][c]; out[b][C(1+2f)+c] = sin(2^f x[b][c]); out[b][C(2+2f)+c] = cos(2^f x[b][c]), f < n_freqs (logscale
+ * freq_bands, :16-17).  Each value is the correctly rounded sin / cos of the reference's exact fp32 argument (one
+ * double-precision sincos + angle doubling, as the fused feature kernel does).  nf_embed_bwd: what autograd derives,
+ * d_x[b][c] = g[b][c] + sum_f 2^f (g_sin cos - g_cos sin). */
+int nf_embed_fwd(const float* x /*n_rows*channels*/, int64_t n_rows, int channels, int n_freqs,
+                 float* out /*n_rows*channels*(2 n_freqs+1)*/, nf_stream_t stream);
+int nf_embed_bwd(const float* x, const float* d_out, int64_t n_rows, int channels, int n_freqs, float* d_x,
+                 nf_stream_t stream);
+
+/* Plain strided fp32 GEMM on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32; exact fp32 products and sums): the dense
+ * products that torch autograd runs for the nn.Linear / ContinuousConv layers of models/nerf.py:83-124 and
+ * models/transmodel.py:116-131 under loss.backward() (trainer/trainer_e2e.py:219-277) and that are not fused elsewhere:
+ * dX = dpre W, dB = relu(x)^T dG, dx = dG B^T.   C[m*ldc + n] (+)= sum_k opA(A[m*sa_m + k*sa_k]) * B[k*sb_k + n*sb_n];
+ * one of (sa_m, sa_k) and one of (sb_k, sb_n) must be 1; relu_a: opA = max(., 0); splits > 1: split-K with a
+ * deterministic slice reduction through `workspace` (nf_gemm_f32_workspace_floats floats). */
+size_t nf_gemm_f32_workspace_floats(int M, int N, int splits);
+int nf_gemm_f32(int M, int N, int K, const float* A, int64_t sa_m, int64_t sa_k, int relu_a, const float* B, int64_t sb_k,
+                int64_t sb_n, float* C, int64_t ldc, int accumulate, int splits, float* workspace, nf_stream_t stream);
 
 /* A12 (MLP part; what torch autograd derives for models/nerf.py:83-124 under loss.backward(),
  * trainer/trainer_renderer.py:96): data gradient of the MLP on fp32 MFMA with transposed packed weights.

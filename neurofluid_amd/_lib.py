@@ -48,9 +48,6 @@ PROTOTYPES = {
     "nf_nerf_stream_floats": (c_size_t, [c_int, c_int]),
     "nf_nerf_pack_stream": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "nf_nerf_mlp_fwd_l": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
-    "nf_nerf_packed_h_bytes": (c_size_t, []),
-    "nf_nerf_pack_h": (c_int, [ctypes.POINTER(NerfParams), c_int, c_int, c_void_p, c_void_p]),
-    "nf_nerf_mlp_fwd_h": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "nf_nerf_packed_h2_bytes": (c_size_t, []),
     "nf_nerf_pack_h2": (c_int, [ctypes.POINTER(NerfParams), c_int, c_int, c_void_p, c_void_p]),
     "nf_nerf_mlp_fwd_h2": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
@@ -66,6 +63,11 @@ PROTOTYPES = {
     "nf_nerf_pack_bwd": (c_int, [ctypes.POINTER(NerfParams), c_int, c_int, c_void_p, c_void_p]),
     "nf_nerf_mlp_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                 c_void_p, c_void_p]),
+    "nf_embed_fwd": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "nf_embed_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "nf_gemm_f32_workspace_floats": (c_size_t, [c_int, c_int, c_int]),
+    "nf_gemm_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_int64, c_void_p, c_int64,
+                            c_int, c_int, c_void_p, c_void_p]),
     "nf_trans_integrate": (c_int, [c_void_p, c_void_p, ctypes.POINTER(c_float), c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nf_trans_update": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p]),
     "nf_cconv_pairs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -1,9 +1,11 @@
 """Autograd of the fused renderer and of the transition model (row B8).
 
 Renderer backward = composite backward (HIP) -> MLP data-gradient on fp32 MFMA (HIP, nf_nerf_mlp_bwd) ->
-weight gradients as plain GEMMs dW_l = dpre_l^T . input_l over all active rows (library GEMM through torch.mm:
-the only place a vendor BLAS is used, as allowed for plain GEMMs) -> optional gradient w.r.t. the particle
-positions through the local-geometry features (e2e training, trainer/trainer_e2e.py:219-236).
+weight gradients dW_l = dpre_l^T . input_l over all active rows (one batched fp32-MFMA launch, nf_nerf_wgrad) ->
+optional gradient w.r.t. the particle positions through the local-geometry features (e2e training,
+trainer/trainer_e2e.py:219-236).  Every dense product runs on the fp32 matrix pipe in hand-written HIP: the plain
+GEMMs of both backward passes (dX = dpre W; dB = relu(x)^T dG, dx = dG B^T of the continuous convolutions) go through
+ops.gemm (nf_gemm.hip) — no vendor BLAS on the path.
 """
 import ctypes
 
@@ -60,13 +62,7 @@ def _pass_backward(net, nerf, pb, rays_c, z, z_table, g_rgb, white_bg, particles
     # changes from step to step, and exact sizes make the caching allocator grow by a fresh block per step (and give
     # the GEMM library a new problem size per step); a handful of capacity buckets are re-used instead
     cap = ops._round_rows(n)
-    # e2e: the three dX GEMMs go through the vendor GEMM library, which pays ~80 ms the first time it meets a new
-    # problem size (solution lookup + lazy code-object load); power-of-two row counts keep that to a handful of sizes
-    # ... up to 8 192 rows, multiples of 4 096 beyond (a 20 000-row pass pays for 20 480 rows, not 32 768)
-    cap_g = cap
-    if dparticles is not None:
-        cap_g = max(cap, 1 << max(n - 1, 1).bit_length()) if n <= 8192 else max(cap, (n + 4095) // 4096 * 4096)
-    dpre_full = torch.empty(cap_g, DPRE, dtype=torch.float32, device=dev)
+    dpre_full = torch.empty(cap, DPRE, dtype=torch.float32, device=dev)
     dpre = dpre_full[:n]
     check(lib.nf_nerf_mlp_bwd(ptr(pb.packed), ptr(packed_t), cx, cd, ptr(pb.acts), ptr(pb.n_rows), n, ptr(pb.row_sample),
                               ptr(pb.rgbsigma), ptr(d_rs), ptr(dpre_full), st), "nf_nerf_mlp_bwd")
@@ -86,16 +82,13 @@ def _pass_backward(net, nerf, pb, rays_c, z, z_table, g_rgb, white_bg, particles
     gb = [colsum[k * 256:(k + 1) * 256] for k in range(8)]
     gb += [colsum[8 * 256:9 * 256], colsum[9 * 256:9 * 256 + 128], colsum[2435:2436], colsum[2432:2435]]
     if dparticles is not None:
-        # dL/dX = W^T dpre for the three layers that read the feature matrix (plain GEMMs at the bucketed row count,
-        # tail rows zeroed), then HIP scatter
-        if cap_g > n:
-            dpre_full[n:].zero_()
+        # dL/dX = dpre W for the three layers that read the feature matrix (fp32-MFMA GEMMs on column slices of dpre, the
+        # skip layer's term accumulated in place), then HIP scatter
         W1, W5, Wd = layers[0].weight.detach(), layers[4].weight.detach(), layers[9].weight.detach()
-        dX = torch.empty(cap_g, cx + cd, dtype=torch.float32, device=dev)
-        # written in place by the GEMMs (strided C, beta = 1 for the skip layer's term): 3 launches, no temporaries
-        torch.mm(dpre_full[:, 0:256], W1, out=dX[:, :cx])
-        dX[:, :cx].addmm_(dpre_full[:, 4 * 256:5 * 256], W5[:, :cx])
-        torch.mm(dpre_full[:, 9 * 256:9 * 256 + 128], Wd[:, 256:], out=dX[:, cx:])
+        dX = torch.empty(cap, cx + cd, dtype=torch.float32, device=dev)
+        ops.gemm(dpre[:, 0:256], W1, out=dX[:n, :cx])
+        ops.gemm(dpre[:, 4 * 256:5 * 256], W5[:, :cx], out=dX[:n, :cx], accumulate=True)
+        ops.gemm(dpre[:, 9 * 256:9 * 256 + 128], Wd[:, 256:], out=dX[:n, cx:])
         check(lib.nf_render_features_bwd(ptr(particles), ptr(rays_c), ptr(z), ptr(z_table), R, S, float(net.raduis),
                                          net.num_neighbor, net.enc_flags, ptr(ro_c), int(ro_c.dim() == 2),
                                          ptr(pb.row_sample), ptr(pb.row_nbr), ptr(pb.n_rows), n, ptr(dX), ptr(dparticles),
@@ -231,17 +224,16 @@ class _ParticleNetFn(torch.autograd.Function):
             conv, dense = pn.convs[li - 1], pn.denses[li - 1]
             prev = ans[li - 1]
             cout = conv.kernel.shape[-1]
-            x = torch.relu(prev)
             dG = torch.empty(n, 65 * cout, dtype=torch.float32, device=dev)
             check(lib.nf_cconv_gather_bwd(ptr(dy), cout, ptr(f_rs), ptr(f_idx), ptr(t_pw), ptr(t_pc), n, ptr(dG), st),
                   "nf_cconv_gather_bwd")
-            dB = x.t() @ dG                                          # (Cin, 65*Cout) plain GEMM
-            cin = x.shape[1]
+            dB = ops.gemm(prev.t(), dG, relu_a=True)                 # relu(prev)^T dG: (Cin, 65*Cout), split-K over the particles
+            cin = prev.shape[1]
             grads[conv.kernel] = dB[:, :64 * cout].reshape(cin, 64, cout).permute(1, 0, 2).reshape(conv.kernel.shape)
             grads[dense.weight] = dB[:, 64 * cout:].t().contiguous()
             grads[conv.bias] = dy.sum(0)
             grads[dense.bias] = grads[conv.bias].clone()
-            dx = dG @ _virtual_b(conv.kernel, dense.weight).t()      # (n, Cin) plain GEMM
+            dx = ops.gemm(dG, _virtual_b(conv.kernel, dense.weight).t())      # (n, Cin)
             dprev = torch.ops.aten.threshold_backward(dx, prev, 0.0)  # dx where prev > 0, else 0 (one kernel)
             if dense.out_features == prev.shape[-1]:
                 dprev = dprev + dy                                   # residual branch (transmodel.py:127-128)
@@ -258,7 +250,7 @@ class _ParticleNetFn(torch.autograd.Function):
                                             ptr(wsf), ptr(dKf), st), "conv0_fluid filter grad")
         grads[c0o.kernel], grads[c0f.kernel] = dKo, dKf
         grads[c0o.bias], grads[c0f.bias] = dy[:, :32].sum(0), dy[:, 32:64].sum(0)
-        grads[d0.weight], grads[d0.bias] = dy[:, 64:].t() @ ff, dy[:, 64:].sum(0)
+        grads[d0.weight], grads[d0.bias] = ops.gemm(dy[:, 64:].t(), ff), dy[:, 64:].sum(0)
         # input gradients (2-step unrolls, trainer_transmodel.py): through integrate/update and the velocity features
         g_in_pos = g_in_vel = None
         if ctx.in_grad[0]:
@@ -267,7 +259,7 @@ class _ParticleNetFn(torch.autograd.Function):
             dfeat = torch.empty(n, 4, dtype=torch.float32, device=dev)
             check(lib.nf_cconv_small_bwd_feat(ptr(c0f.kernel.detach().contiguous()), 4, ptr(f_rs), ptr(f_idx), ptr(t_pw),
                                               ptr(t_pc), ptr(dy), 96, 32, n, ptr(dfeat), st), "conv0_fluid feature grad")
-            dfeat = dfeat + dy[:, 64:] @ d0.weight.detach()
+            ops.gemm(dy[:, 64:], d0.weight.detach(), out=dfeat, accumulate=True)
             g_in_vel = d_pos_c * dt + dfeat[:, 1:4]                 # pos_new = pos + vel dt + g dt^2/2 ; feats = [1, vel + g dt]
         return (None, g_in_pos, g_in_vel, None, None) + tuple(grads[p] for p in _pn_params(pn))
 

@@ -184,6 +184,46 @@ def fixed_radius_search(points, queries, radius, ignore_query_point=True, grid=N
 
 
 # ------------------------------------------------------------------------------------------------
+# plain fp32 GEMM on the matrix pipe (nf_gemm.hip) — the dense products of the training path that are not fused elsewhere
+# ------------------------------------------------------------------------------------------------
+def gemm(a, b, out=None, accumulate=False, relu_a=False, splits=None):
+    """out (+)= opA(a) @ b for 2-D fp32 CUDA VIEWS (transposed / column-sliced views are fine: each operand needs a unit
+    stride along one of its axes); opA = relu when relu_a.  `out` (M, N) must have unit column stride.
+    splits=None picks a split-K factor that fills the chip when the output has few 128x128 tiles."""
+    _require_cuda(a, b, out)
+    lib = _lib.load()
+    assert a.dim() == 2 and b.dim() == 2 and a.shape[1] == b.shape[0] and a.dtype == b.dtype == torch.float32
+    M, K = a.shape
+    N = b.shape[1]
+    if out is None:
+        assert not accumulate
+        out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    assert out.shape == (M, N) and out.dtype == torch.float32 and (N <= 1 or out.stride(1) == 1)
+    if 1 not in (a.stride(0), a.stride(1)) and min(a.shape) > 1:
+        a = a.contiguous()
+    if 1 not in (b.stride(0), b.stride(1)) and min(b.shape) > 1:
+        b = b.contiguous()
+
+    def strides(t):          # a size-1 axis may carry any stride: give it the one the kernel wants
+        s0, s1 = t.stride()
+        if t.shape[1] == 1 and s0 != 1:
+            s1 = 1
+        if t.shape[0] == 1 and s1 != 1 and s0 != 1:
+            s0 = 1
+        return s0, s1
+    sa_m, sa_k = strides(a)
+    sb_k, sb_n = strides(b)
+    if splits is None:
+        tiles = ((M + 127) // 128) * ((N + 127) // 128)
+        splits = max(1, min(512 // max(tiles, 1), K // 256, 64)) if tiles < 128 else 1
+    wsp = torch.empty(lib.nf_gemm_f32_workspace_floats(M, N, splits), dtype=torch.float32, device=a.device) if splits > 1 else None
+    ldc = out.stride(0) if M > 1 else max(N, out.stride(0))
+    check(lib.nf_gemm_f32(M, N, K, ptr(a), sa_m, sa_k, int(relu_a), ptr(b), sb_k, sb_n, ptr(out), ldc, int(accumulate),
+                          int(splits), ptr(wsp), _lib.stream()), "nf_gemm_f32")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
 # NeRF weights
 # ------------------------------------------------------------------------------------------------
 NERF_LAYER_NAMES = [f"xyz_encoding_{i}.0" for i in range(1, 9)] + ["xyz_encoding_final", "dir_encoding.0", "sigma", "rgb.0"]
@@ -225,23 +265,8 @@ def pack_nerf_stream(packed, cx, cd):
     return out
 
 
-def pack_nerf_h(weights, biases, cx, cd):
-    """fp16 weight stream of the fp16-MFMA MLP (nf_nerf_pack_h)."""
-    lib = _lib.load()
-    out = torch.empty(lib.nf_nerf_packed_h_bytes(), dtype=torch.uint8, device=weights[0].device)
-    P = _lib.NerfParams()
-    keep = []
-    for i in range(12):
-        w = weights[i].detach().contiguous().float()
-        b = biases[i].detach().contiguous().float()
-        keep += [w, b]
-        P.w[i], P.b[i] = w.data_ptr(), b.data_ptr()
-    check(lib.nf_nerf_pack_h(ctypes.byref(P), cx, cd, ptr(out), _lib.stream()), "nf_nerf_pack_h")
-    return out
-
-
 class PackedH2:
-    """Weight stream of the fp16-MFMA MLP, version 3 (nf_nerf_pack_h2 / nf_nerf_mlp_fwd_h2)."""
+    """Weight stream of the fp16-MFMA MLP (nf_nerf_pack_h2 / nf_nerf_mlp_fwd_h2)."""
 
     def __init__(self, blob):
         self.blob = blob
@@ -453,9 +478,8 @@ def render_pass(grid, particles, rays, z, z_table, S, radius, K, enc_flags, use_
         elif isinstance(packed_h, PackedH2):      # fp16-MFMA, two tiles per wave (inference only); X holds an even tile count
             check(lib.nf_nerf_mlp_fwd_h2(ptr(packed_h.blob), cx, cd, X_, ptr(nrows_t), mx, rs_, ptr(b.rgbsigma), stream_),
                   "nf_nerf_mlp_fwd_h2")
-        elif packed_h is not None:      # fp16-MFMA, round-1 kernel (kept for A/B runs: RENDERER.mlp_h_kernel = 1)
-            check(lib.nf_nerf_mlp_fwd_h(ptr(packed), ptr(packed_h), cx, cd, X_, ptr(nrows_t), mx, rs_, ptr(b.rgbsigma), stream_),
-                  "nf_nerf_mlp_fwd_h")
+        elif packed_h is not None:
+            raise RuntimeError("unknown fp16 weight stream (expected PackedH2 or PackedS)")
         elif wstream is not None and not save_acts:      # fp32, weight stream shared through LDS (inference)
             check(lib.nf_nerf_mlp_fwd_l(ptr(packed), ptr(wstream), cx, cd, X_, ptr(nrows_t), mx, rs_, ptr(b.rgbsigma), stream_),
                   "nf_nerf_mlp_fwd_l")
@@ -595,9 +619,7 @@ def mlp_rows(packed, cx, cd, x, save_acts=False, packed_h=None, wstream=None):
             check(lib.nf_nerf_mlp_fwd_h2(ptr(packed_h.blob), cx, cd, ptr(Xh), ptr(n_rows), n, ptr(row_sample), ptr(out),
                                          _lib.stream()), "nf_nerf_mlp_fwd_h2")
             return out
-        check(lib.nf_nerf_mlp_fwd_h(ptr(packed), ptr(packed_h), cx, cd, ptr(Xh), ptr(n_rows), n, ptr(row_sample), ptr(out),
-                                    _lib.stream()), "nf_nerf_mlp_fwd_h")
-        return out
+        raise RuntimeError("unknown fp16 weight stream (expected PackedH2 or PackedS)")
     if wstream is not None:
         check(lib.nf_nerf_mlp_fwd_l(ptr(packed), ptr(wstream), cx, cd, ptr(X), ptr(n_rows), n, ptr(row_sample), ptr(out),
                                     _lib.stream()), "nf_nerf_mlp_fwd_l")

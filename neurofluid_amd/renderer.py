@@ -43,9 +43,6 @@ class RenderNet(nn.Module):
         self.mlp_dtype = str(_get(cfg, "mlp_dtype", "fp32"))
         if self.mlp_dtype not in ("fp32", "fp16", "split"):
             raise ValueError("RENDERER.mlp_dtype must be fp32, fp16 or split")
-        # build-only key: which fp16 kernel serves mlp_dtype = fp16.  2 (default): two tiles per wave, out-block-major
-        # (nf_mlp_h2.hip); 1: the round-1 kernel (nf_mlp_h.hip), kept for A/B measurements
-        self.mlp_h_kernel = int(_get(cfg, "mlp_h_kernel", 2))
         if not self.fix_radius:
             raise NotImplementedError("fix_radius=False is dead code in the reference (models/renderer.py:119-121)")
         if not _get(cfg, "encoding.exclude_ray", True):
@@ -135,7 +132,7 @@ class RenderNet(nn.Module):
 
     def packed_weights_h(self, net):
         layers = net.linear_layers()
-        pack = ops.pack_nerf_s if self.mlp_dtype == "split" else (ops.pack_nerf_h2 if self.mlp_h_kernel == 2 else ops.pack_nerf_h)
+        pack = ops.pack_nerf_s if self.mlp_dtype == "split" else ops.pack_nerf_h2
         return pack([l.weight for l in layers], [l.bias for l in layers], self.in_channels_xyz, self.in_channels_dir)
 
     def packed_for_inference(self, net, use_h):
@@ -144,7 +141,7 @@ class RenderNet(nn.Module):
         rollout the weights are constant, and the three small pack launches per pass sat, with their host gaps, in front of
         a GPU that had nothing else queued (~0.2 ms per frame)."""
         sig = tuple((p.data_ptr(), p._version) for l in net.linear_layers() for p in (l.weight, l.bias)) + \
-            (self.mlp_dtype, self.mlp_h_kernel, bool(use_h))
+            (self.mlp_dtype, bool(use_h))
         cache = self.__dict__.setdefault("_packed_cache", {})
         hit = cache.get(id(net))
         if hit is None or hit[0] != sig:

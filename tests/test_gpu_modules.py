@@ -1,0 +1,163 @@
+"""GPU tests of the stand-alone module forwards (models/nerf.py: Embedding :21-38, NeRF :83-124) and of the plain fp32-MFMA
+GEMM that replaced the vendor BLAS calls of the training path.  A caller that keeps the reference's own
+models/renderer.py (INTEGRATION.md level 2) drives exactly these."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def T(a, dev=None):
+    t = torch.from_numpy(np.asarray(a))
+    return t.to(dev) if dev is not None else t
+
+
+def _nerf(dev, prefix="nerf_coarse"):
+    from neurofluid_amd.nerf import NeRF
+    from oracle import render_oracle as ro
+    st = ro.deterministic_nerf_state()
+    net = NeRF(in_channels_xyz=198, in_channels_dir=54)
+    net.load_state_dict({k[len(prefix) + 1:]: v for k, v in st.items() if k.startswith(prefix + ".")}, strict=True)
+    return net.to(dev), st
+
+
+def test_embedding_forward_vs_golden(dev):
+    """A5 (models/nerf.py:21-38): Embedding.forward on the device vs what the reference's own module returned
+    (tests/golden/a5_embed.npz).  Stated tolerance: 6e-8 absolute for |2^k x| <= ~1e3 — the kernel emits the correctly
+    rounded sin / cos of the exact fp32 argument (double-precision sincos + angle doubling); torch's fp32 sin / cos on the
+    CPU is itself up to 3.5e-8 from that value.  The pass-through columns are exact."""
+    from neurofluid_amd.nerf import Embedding
+    g = load_golden("a5_embed")
+    for xk, ek, c, nf in (("x3", "e3_10", 3, 10), ("x3", "e3_4", 3, 4), ("x1", "e1_4", 1, 4)):
+        emb = Embedding(c, nf)
+        x = T(g[xk], dev)
+        out = emb(x)
+        ref = T(g[ek])
+        assert out.shape == ref.shape == (x.shape[0], emb.out_channels)
+        assert torch.equal(out[:, :c].cpu(), ref[:, :c])
+        err = float((out.cpu() - ref).abs().max())
+        assert err <= 6e-8 * 4, err          # x1 reaches 2^3 * 20 = 160 rad: fp32 torch.sin there is ~1e-7 from the true value
+    # ragged / larger batch and leading batch dims, against the float64 definition
+    gen = torch.Generator().manual_seed(5)
+    x = (torch.rand(3, 1001, 3, generator=gen) * 4 - 2)
+    out = Embedding(3, 10)(x.to(dev)).cpu()
+    xd = x.double()
+    cols = [xd] + [f(xd * 2.0 ** k) for k in range(10) for f in (torch.sin, torch.cos)]
+    ref = torch.cat(cols, -1)
+    assert out.shape == (3, 1001, 63)
+    assert float((out.double() - ref).abs().max()) <= 6e-8
+
+
+def test_embedding_backward_vs_autograd(dev):
+    """d/dx of the encoding vs torch autograd through the oracle's definition in float64."""
+    from neurofluid_amd.nerf import Embedding
+    gen = torch.Generator().manual_seed(6)
+    x = (torch.rand(257, 3, generator=gen) * 2 - 1)
+    gout = torch.randn(257, 27, generator=gen)
+    xg = x.to(dev).requires_grad_(True)
+    Embedding(3, 4)(xg).backward(gout.to(dev))
+    xd = x.double().requires_grad_(True)
+    cols = [xd] + [f(xd * 2.0 ** k) for k in range(4) for f in (torch.sin, torch.cos)]
+    torch.cat(cols, -1).backward(gout.double())
+    torch.testing.assert_close(xg.grad.cpu().double(), xd.grad, rtol=1e-5, atol=1e-5)
+
+
+def test_nerf_forward_vs_golden(dev):
+    """A6 (models/nerf.py:83-124): NeRF.forward(x) and NeRF.forward(x[:, :cx], sigma_only=True) on the HIP path vs the rows
+    the reference's own module returned (tests/golden/a6_nerf.npz); same tolerance as the fused path's MLP test."""
+    g = load_golden("a6_nerf")
+    net, _ = _nerf(dev)
+    x = T(g["x"], dev)
+    with torch.no_grad():
+        out = net(x)
+        sig = net(x[:, :198].contiguous(), sigma_only=True)
+    assert out.shape == (40, 4) and sig.shape == (40, 1)
+    torch.testing.assert_close(out.cpu(), T(g["out"]), rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(sig.cpu(), T(g["sigma_only"]), rtol=1e-4, atol=2e-5)
+    assert torch.equal(sig, out[:, 3:4])          # sigma does not depend on the view branch
+    with pytest.raises(ValueError):
+        net(x[:, :100])
+    with pytest.raises(RuntimeError):
+        net(x.cpu())                               # no CPU fallback
+
+
+def test_nerf_forward_autograd_vs_oracle(dev):
+    """Parameter and INPUT gradients of the stand-alone NeRF.forward vs torch autograd through the oracle's MLP
+    (what a caller that keeps the reference's renderer and trains end to end needs), incl. the sigma_only form."""
+    from oracle import render_oracle as ro
+    net, st = _nerf(dev, "nerf_fine")
+    gen = torch.Generator().manual_seed(9)
+    n = 300
+    x = (torch.rand(n, 252, generator=gen) * 2 - 1)
+    gout = torch.randn(n, 4, generator=gen)
+    xg = x.to(dev).requires_grad_(True)
+    out = net(xg)
+    out.backward(gout.to(dev))
+    stc = {k: v.clone().requires_grad_(k.startswith("nerf_fine")) for k, v in st.items()}
+    xc = x.clone().requires_grad_(True)
+    ref = ro.nerf_forward(stc, "nerf_fine", xc, 198, 54)
+    ref.backward(gout)
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-4, atol=2e-5)
+    rel = float((xg.grad.cpu() - xc.grad).norm() / xc.grad.norm())
+    assert rel < 2e-5, rel
+    worst = 0.0
+    for name, p in net.named_parameters():
+        r = stc["nerf_fine." + name].grad
+        rel = float((p.grad.cpu() - r).norm() / (r.norm() + 1e-30))
+        worst = max(worst, rel)
+        assert rel < 5e-5, (name, rel)
+    # sigma_only: gradient reaches x[:, :cx] and the eight trunk layers + sigma head only
+    for p in net.parameters():
+        p.grad = None
+    xs = x[:, :198].to(dev).requires_grad_(True)
+    s = net(xs, sigma_only=True)
+    s.backward(gout[:, 3:4].to(dev))
+    xc2 = x[:, :198].clone().requires_grad_(True)
+    stc2 = {k: v.clone().requires_grad_(k.startswith("nerf_fine")) for k, v in st.items()}
+    r = ro.nerf_forward(stc2, "nerf_fine", xc2, 198, 54, sigma_only=True)
+    r.backward(gout[:, 3:4])
+    assert xs.grad.shape == (n, 198)
+    assert float((xs.grad.cpu() - xc2.grad).norm() / xc2.grad.norm()) < 2e-5
+    gw = dict(net.named_parameters())["xyz_encoding_3.0.weight"].grad.cpu()
+    rw = stc2["nerf_fine.xyz_encoding_3.0.weight"].grad
+    assert float((gw - rw).norm() / rw.norm()) < 5e-5
+    assert float(dict(net.named_parameters())["rgb.0.weight"].grad.abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (37, 5, 3), (128, 128, 32), (129, 131, 33), (300, 198, 256), (96, 4160, 4913),
+                                   (4913, 96, 4160), (32, 4, 4913), (2000, 54, 128)])
+def test_gemm_f32_vs_float64(dev, M, N, K):
+    """nf_gemm_f32 in its four operand orders (A contiguous along k or m, B along n or k), with relu-on-load, accumulation
+    and split-K, on ragged sizes, strided column slices and unaligned bases; vs the float64 product.  Tolerance: fp32
+    summation of K products, 4e-7 * sqrt(K) relative to the row/column norms (observed ~1e-7 * sqrt(K))."""
+    from neurofluid_amd import ops
+    gen = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn(M, K + 3, generator=gen).to(dev)
+    B = torch.randn(K, N + 5, generator=gen).to(dev)
+    Av, Bv = A[:, 3:], B[:, 1:N + 1]            # unaligned bases, non-trivial row strides
+    ref = (Av.double() @ Bv.double())
+    scale = Av.double().norm(dim=1, keepdim=True) * Bv.double().norm(dim=0, keepdim=True) + 1e-30
+    tol = 4e-7 * max(K, 1) ** 0.5
+
+    def ok(got, want=ref):
+        assert float(((got.double() - want).abs() / scale).max()) <= tol
+
+    ok(ops.gemm(Av, Bv))                                                   # A along k, B along n
+    ok(ops.gemm(Av.t().contiguous().t(), Bv))                              # A along m
+    ok(ops.gemm(Av, Bv.t().contiguous().t()))                              # B along k
+    ok(ops.gemm(Av.t().contiguous().t(), Bv.t().contiguous().t(), splits=3))
+    ok(ops.gemm(Av, Bv, relu_a=True), torch.relu(Av).double() @ Bv.double())
+    C = torch.randn(M, N + 2, generator=gen).to(dev)
+    C0 = C.clone()
+    ops.gemm(Av, Bv, out=C[:, 1:N + 1], accumulate=True, splits=2)
+    ok(C[:, 1:N + 1] - C0[:, 1:N + 1])
+    assert torch.equal(C[:, 0], C0[:, 0]) and torch.equal(C[:, N + 1], C0[:, N + 1])       # neighbours of the slice untouched

@@ -387,3 +387,74 @@ def test_fused_inference_step_bit_equal(dev):
     assert bool(torch.isnan(a).all()) and bool(torch.isnan(b).all())
     with pytest.raises(RuntimeError, match="exceeds the capacities"):
         pc.check_capacity(wait=True)
+
+
+# ------------------------------------------------------------------------------------------------
+# round 3: convention known-answer tests (tests/kat_conventions.py) against the HIP path.  The expected values come from
+# the operators' published contracts, not from the oracle: a convention error that the oracle and the kernels share
+# (both were written by the same hand) cannot pass here.  The same cases pin the oracle in tests/test_oracle_trans.py.
+# ------------------------------------------------------------------------------------------------
+def test_kat_filter_axis_order_and_sign_hip(dev):
+    """(i): which WORLD axis selects which filter dim (kernel[z][y][x]), neighbour-minus-query sign, window on
+    d^2 / radius^2, align-corners scaling — one neighbour, one-hot filters, through ContinuousConv.__call__."""
+    import kat_conventions as kat
+    from neurofluid_amd.transmodel import ContinuousConv, ParticleNet
+    out_pos = torch.tensor([kat.OUT_POS])
+    conv = ContinuousConv(kernel_size=[4, 4, 4], in_channels=1, filters=1, window_function=ParticleNet._window_poly6).to(dev)
+    assert conv.fused_window
+    n_nonzero = 0
+    for off, (kz, ky, kx), want in kat.axis_cases():
+        inp_pos = out_pos + torch.tensor([off])
+        with torch.no_grad():
+            conv.kernel.zero_()
+            conv.kernel[kz, ky, kx, 0, 0] = 1.0
+            conv.bias.zero_()
+            out = conv(torch.ones(1, 1, device=dev), inp_pos.to(dev), out_pos.to(dev), kat.EXTENT)
+        assert conv.nns.neighbors_index.tolist() == [0]
+        assert abs(float(out[0, 0]) - want) <= 2e-6, (off, (kz, ky, kx), float(out[0, 0]), want)
+        n_nonzero += want > 0
+    assert n_nonzero == 12
+
+
+def test_kat_ball_to_cube_closed_forms_hip(dev):
+    """(ii): closed-form values of ball_to_cube_volume_preserving (axis points, the cap / side seam, the cube diagonal, cap
+    and side interior points, mixed signs) read back from the pair interpolation data of nf_cconv_pairs: with the window
+    off the 8 corner weights are a partition of unity and sum(w * node coordinate) IS the filter coordinate.  The map is
+    radially homogeneous (both stages scale (x, y, z) by factors that depend on direction only), so the cases are placed
+    at 0.75 of the radius (strictly inside the search ball in fp32) and the expected cube point scales by 0.75."""
+    import kat_conventions as kat
+    from neurofluid_amd import ops
+    from neurofluid_amd.transmodel import cconv_pairs
+    lam = 0.75
+    P = torch.tensor([p for p, _ in kat.MAPPING_CASES], dtype=torch.float64) * (lam * kat.RADIUS)
+    inp = P.float().to(dev).contiguous()
+    out = torch.zeros(1, 3, device=dev)
+    idx, rs, d2 = ops.fixed_radius_search(inp, out, kat.RADIUS, True)
+    order = idx.tolist()                                                 # cell-major order of the grid, not index order
+    assert sorted(order) == list(range(len(kat.MAPPING_CASES)))
+    pw, pc = cconv_pairs(inp, out, rs, idx, d2, kat.EXTENT, use_window=False)
+    w = pw[:idx.numel() * 8].view(-1, 8).cpu().double()
+    c = pc[:idx.numel() * 8].view(-1, 8).cpu().long()
+    torch.testing.assert_close(w.sum(1), torch.ones(w.shape[0], dtype=torch.float64), rtol=0, atol=1e-6)
+    got = torch.stack([(w * (c % 4)).sum(1), (w * ((c // 4) % 4)).sum(1), (w * (c // 16)).sum(1)], 1)
+    for k, j in enumerate(order):
+        p, cube = kat.MAPPING_CASES[j]
+        want = kat.filter_coordinate(tuple(lam * v for v in cube))
+        assert max(abs(float(g) - t) for g, t in zip(got[k], want)) <= 3e-6, (p, got[k].tolist(), want)
+
+
+def test_kat_radius_inclusivity_hip(dev):
+    """(iii): FixedRadiusSearch keeps d^2 <= radius^2 (the point at EXACTLY the radius, d^2 = 2^-6, is in; one ulp beyond is
+    out), skips the identical position under ignore_query_point; (iv): ball_query is STRICT (the same point is out)."""
+    import kat_conventions as kat
+    from neurofluid_amd import ops
+    pts = torch.from_numpy(kat.radius_points()).to(dev)
+    q = pts[:1].contiguous()
+    idx, rs, d2 = ops.fixed_radius_search(pts, q, kat.RADIUS, True)
+    assert idx.tolist() == kat.FIXED_RADIUS_EXPECTED_IGNORE and rs.tolist() == [0, 3]
+    assert float(d2[1]) == kat.RADIUS ** 2
+    idx, rs, d2 = ops.fixed_radius_search(pts, q, kat.RADIUS, False)
+    assert sorted(idx.tolist()) == kat.FIXED_RADIUS_EXPECTED_KEEP
+    d, i, nn = ops.ball_query(q[None], pts[None], kat.RADIUS, 5)
+    assert i[0, 0].tolist() == kat.BALL_QUERY_EXPECTED + [-1, -1]
+    assert d[0, 0].tolist()[:2] == [0.0, float(np.float32(0.05) ** 2)]

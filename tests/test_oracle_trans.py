@@ -115,3 +115,43 @@ def test_particle_net_shapes_and_rest_state():
     # update_pos_vel re-derives the velocity from the displacement: (p'' - p)/dt = g*dt/2  (transmodel.py:144-148)
     torch.testing.assert_close(v0, (0.5 * torch.tensor([0, 0, -9.81]) * dt).expand_as(P), rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(p0, P + 0.5 * torch.tensor([0, 0, -9.81]) * dt * dt, rtol=1e-6, atol=1e-7)
+
+
+# ------------------------------------------------------------------------------------------------
+# Convention known-answer tests (tests/kat_conventions.py): expected values come from the operators' published contracts,
+# not from this oracle — the same cases run against the HIP path in tests/test_gpu_trans.py / test_gpu_render.py.
+# ------------------------------------------------------------------------------------------------
+def test_kat_filter_axis_order_and_sign():
+    import kat_conventions as kat
+    out_pos = torch.tensor([kat.OUT_POS])
+    for off, (kz, ky, kx), want in kat.axis_cases():
+        inp_pos = out_pos + torch.tensor([off])
+        kernel = torch.zeros(4, 4, 4, 1, 1)
+        kernel[kz, ky, kx, 0, 0] = 1.0
+        idx, rs, d2 = to.radius_search(inp_pos, out_pos, kat.RADIUS, True)
+        assert idx.tolist() == [0]
+        out = to.cconv(torch.ones(1, 1), inp_pos, out_pos, kat.EXTENT, kernel, torch.zeros(1), idx, rs, d2)
+        assert abs(float(out[0, 0]) - want) <= 2e-6, (off, (kz, ky, kx), float(out[0, 0]), want)
+
+
+def test_kat_ball_to_cube_closed_forms():
+    import kat_conventions as kat
+    for p, cube in kat.MAPPING_CASES:
+        got = to.map_cylinder_to_cube(to.map_sphere_to_cylinder(torch.tensor([p], dtype=torch.float64)))[0]
+        assert max(abs(float(g) - c) for g, c in zip(got, cube)) <= 1e-8, (p, got.tolist(), cube)
+        rel = torch.tensor([p], dtype=torch.float32) * (kat.EXTENT / 2)
+        coords = to.filter_coordinates(rel, kat.EXTENT)[0]
+        assert max(abs(float(g) - c) for g, c in zip(coords, kat.filter_coordinate(cube))) <= 2e-6
+
+
+def test_kat_radius_inclusivity():
+    import kat_conventions as kat
+    from oracle import neighbors
+    pts = kat.radius_points()
+    q = pts[:1]
+    idx, rs, d2 = neighbors.fixed_radius_search(pts, q, kat.RADIUS, True)
+    assert idx.tolist() == kat.FIXED_RADIUS_EXPECTED_IGNORE and float(d2[1]) == kat.RADIUS ** 2
+    idx, rs, d2 = neighbors.fixed_radius_search(pts, q, kat.RADIUS, False)
+    assert idx.tolist() == kat.FIXED_RADIUS_EXPECTED_KEEP
+    d, i, nn = neighbors.ball_query_firstk(q, pts, kat.RADIUS, 5)
+    assert i[0].tolist() == kat.BALL_QUERY_EXPECTED + [-1, -1]

@@ -39,20 +39,6 @@ if len(sys.argv) > 3 and sys.argv[3] == "ring":
         print(f"ring iter {it}: rows {n} {ms:.3f} ms  {n*1331968/ms/1e9:.1f} TFLOP/s")
     err = (out3 - out).abs()
     print("ring vs direct: max abs err rgb", float(err[:, :3].max()), "sigma", float(err[:, 3].max()))
-if len(sys.argv) > 3 and sys.argv[3] == "fp16":
-    ph = ops.pack_nerf_h(W, B, 198, 54)
-    T = X.numel() // (32 * 256)
-    Xh = X.view(T, 16, 2, 64, 4).permute(0, 1, 3, 2, 4).reshape(-1).to(torch.float16).contiguous()
-    out2 = torch.zeros(n, 4, device=dev)
-    for it in range(iters):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        check(lib.nf_nerf_mlp_fwd_h(ptr(packed), ptr(ph), 198, 54, ptr(Xh), ptr(n_rows), n, ptr(row_sample), ptr(out2), _lib.stream()))
-        e1.record(); torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1)
-        print(f"fp16 iter {it}: rows {n} {ms:.3f} ms  {n*1331968/ms/1e9:.1f} TFLOP/s")
-    err = (out2 - out).abs()
-    print("max abs err rgb", float(err[:, :3].max()), "sigma", float(err[:, 3].max()), "sigma scale", float(out[:, 3].abs().max()))
 if len(sys.argv) > 3 and sys.argv[3] == "fp16v3":
     ph = ops.pack_nerf_h2(W, B, 198, 54)
     T = X.numel() // (32 * 256)

@@ -42,13 +42,48 @@ def _upload(t, device):
 
 
 def make_adam(params, **kw):
-    """torch.optim.Adam; for parameters on the GPU the fused implementation (same update rule and state layout as the
-    default multi-tensor one, 2 launches instead of 7 per step)."""
+    """torch.optim.Adam; for parameters on the GPU the fused implementation (same update rule, 2 launches instead of 7
+    per step).  Its state differs from the default implementation's in two places — `state['step']` is a float32 tensor on
+    the device and the param groups carry `fused: True` — so checkpoints go through portable_optimizer_state(), which
+    writes what a plain torch.optim.Adam writes (and what the reference's checkpoints hold)."""
     params = list(params)
     groups = params if params and isinstance(params[0], dict) else [{"params": params}]
     groups = [dict(g, params=list(g["params"])) for g in groups]
     on_gpu = all(p.is_cuda for g in groups for p in g["params"]) and any(len(g["params"]) for g in groups)
     return torch.optim.Adam(groups, fused=True, **kw) if on_gpu else torch.optim.Adam(groups, **kw)
+
+
+def portable_optimizer_state(optimizer):
+    """optimizer.state_dict() normalised to what a default (non-fused) torch.optim.Adam saves: `step` as a CPU float tensor,
+    no implementation switches (`fused`, `foreach`) frozen into the param groups — loadable on a CPU-only box, by the
+    reference's optimizer, and by make_adam() alike (load_state_dict keeps the LOADING optimizer's own implementation
+    switches when the saved groups do not name any)."""
+    sd = optimizer.state_dict()
+    out = {"state": {}, "param_groups": []}
+    for k, st in sd["state"].items():
+        st = {a: (b.detach().clone() if torch.is_tensor(b) else b) for a, b in st.items()}      # a snapshot, not an alias
+        if torch.is_tensor(st.get("step")):
+            st["step"] = st["step"].detach().to("cpu", torch.float32)
+        out["state"][k] = st
+    for g in sd["param_groups"]:
+        g = dict(g)
+        for key in ("fused", "foreach"):
+            g[key] = None
+        out["param_groups"].append(g)
+    return out
+
+
+def load_optimizer_state(optimizer, state):
+    """load_state_dict that keeps THIS optimizer's implementation switches (a checkpoint written by the fused
+    implementation of an older build, or by the reference's plain Adam, must not flip them)."""
+    keep = [{k: g.get(k) for k in ("fused", "foreach")} for g in optimizer.param_groups]
+    optimizer.load_state_dict(state)
+    for g, k in zip(optimizer.param_groups, keep):
+        g.update(k)
+    if any(g.get("fused") for g in optimizer.param_groups):          # the fused kernel wants its step counters on the device
+        for p, st in optimizer.state.items():
+            if torch.is_tensor(st.get("step")) and p.is_cuda:
+                st["step"] = st["step"].to(p.device, torch.float32)
 
 
 def random_sample_coords(H, W, global_step, precrop_iters):
@@ -103,11 +138,13 @@ def gather_view_pixels(rays_list, rgb_list, cw_list, coords, sels, H, W):
     dev = rays_list[0].device
     V, rc = len(rays_list), len(sels[0])
     yx = torch.cat([coords[torch.as_tensor(s)] for s in sels]).long()
-    flat = yx[:, 0] * W + yx[:, 1] + (torch.arange(V).repeat_interleave(rc) * (H * W))
-    flat = _upload(flat, dev)
-    one = (lambda ts: ts[0].reshape(H * W, -1)) if V == 1 else (lambda ts: torch.cat([t.reshape(H * W, -1) for t in ts]))
-    rays = one(rays_list).index_select(0, flat)
-    rgbs = one(rgb_list).index_select(0, flat)
+    flat = _upload(yx[:, 0] * W + yx[:, 1], dev)          # pixel index inside its own view: ONE upload for all views
+    # one index_select per view and tensor on that view's own storage (round 2 concatenated the whole images of all views
+    # first: 23 MB of copies per step at 400^2, 92 MB at 800^2, to read 4 096 rows)
+    rays = torch.cat([rays_list[v].reshape(H * W, -1).index_select(0, flat[v * rc:(v + 1) * rc]) for v in range(V)]) if V > 1 \
+        else rays_list[0].reshape(H * W, -1).index_select(0, flat)
+    rgbs = torch.cat([rgb_list[v].reshape(H * W, -1).index_select(0, flat[v * rc:(v + 1) * rc]) for v in range(V)]) if V > 1 \
+        else rgb_list[0].reshape(H * W, -1).index_select(0, flat)
     ro = torch.stack([cw[:, 3] for cw in cw_list]).repeat_interleave(rc, dim=0)
     return rays, rgbs, ro
 
@@ -127,10 +164,14 @@ class PixelSampler:
     """Draws the per-view pixel selections `rng.choice(n, ray_chunk, replace=False)` (trainer_renderer.py:119) in the
     reference's order, one step ahead on a background thread: the draw is a full 160 000-element shuffle (1.4 ms per
     view on the host) and would otherwise sit between two GPU steps.  Same RNG stream, same indices.
-    The read-ahead is invisible to the stream's other users: every draw records the generator state it started from,
-    and close() joins the worker and rewinds `rng` to the state before the first selection nobody consumed, so after
-    train() the stream is exactly where a sampler without read-ahead would have left it.  An exception in the worker
-    (e.g. fewer pixels than ray_chunk) is re-raised by next()."""
+    Every draw records the generator state it started from, and close() joins the worker and rewinds `rng` to the state
+    before the first selection nobody consumed, so after train() the stream is exactly where a sampler without read-ahead
+    would have left it — PROVIDED the sampler is the stream's only consumer while it is alive: in native mode the worker
+    copies the MT19937 state once and never touches `rng` again, so a foreign draw in between (a dataset rotation, an eval
+    hook, user code) would be silently rewound or overwritten by close().  close() therefore compares the stream with the
+    state the sampler last left it in and warns when somebody else drew from it (the foreign draws are then lost: the
+    stream is set to the sampler's own position, as documented).  Use it under try / finally (trainers do): a sampler that
+    is never closed leaves a daemon thread polling.  An exception in the worker is re-raised by next()."""
 
     def __init__(self, rng, n_views, ray_chunk, n_pixels_of_step, first_step, depth=2):
         import queue
@@ -141,6 +182,10 @@ class PixelSampler:
         self._stop = threading.Event()
         self._pending = None          # (step, sels, state_before) drawn but not yet queued when the stop flag was seen
         self._native_end = None
+        try:
+            self._state_at_start = rng.get_state()
+        except Exception:
+            self._state_at_start = None
         self.t = threading.Thread(target=self._run, daemon=True)
         self.t.start()
 
@@ -218,9 +263,34 @@ class PixelSampler:
         assert s == step, "PixelSampler is strictly sequential"
         return sels
 
+    def _foreign_draws(self):
+        """True when `rng` is not where this sampler left it (native mode: where it was when the sampler started; numpy mode:
+        the state after the worker's last draw is unknown to us, so only native mode can tell)."""
+        if self._state_at_start is None or getattr(self, "_native_end", None) is None:
+            return False
+        try:
+            now = self.rng.get_state()
+        except Exception:
+            return False
+        a = self._state_at_start
+        return not (now[0] == a[0] and now[2] == a[2] and np.array_equal(now[1], a[1]))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
     def close(self):
+        if self._stop.is_set() and not self.t.is_alive():
+            return
         self._stop.set()
         self.t.join(timeout=10.0)
+        if self._foreign_draws():
+            import warnings
+            warnings.warn("PixelSampler: another consumer drew from the sampler's random stream while the sampler was alive; "
+                          "its draws are discarded (the stream is set to the sampler's own position)", RuntimeWarning)
         left = []
         try:
             while True:

@@ -21,7 +21,7 @@ from .point_eval import FluidErrors
 from .render_loop import render_image as _render_image
 from .renderer import RenderNet
 from .train_step import (ExponentialLR, PixelSampler, random_sample_coords, _upload, choice_without_replacement, gather_view_pixels,
-                         make_adam, summed_view_mse)
+                         make_adam, summed_view_mse, portable_optimizer_state, load_optimizer_state)
 from .transmodel import ParticleNet
 
 to8b = lambda x: (255 * np.clip(x, 0, 1)).astype(np.uint8)   # noqa: E731  trainer/basetrainer.py:16
@@ -207,13 +207,37 @@ class BaseTrainer:
                 out[k] = v.to(self.device) if isinstance(v, torch.Tensor) else v
         return out
 
-    def _frame_on_device(self, dataset, index, budget_bytes=16 << 30):
+    def _frame_cache_budget(self):
+        """Bytes the frame cache may pin: TRAIN.frame_cache_gb when the config names it, otherwise a quarter of the memory
+        that is free on the device when the cache is created, capped at 16 GiB — the renderer's activation buffers (about
+        0.8 GB per training pass + 25 % headroom) and other tenants of a shared device need the rest."""
+        gb = None
+        try:
+            gb = self.options.TRAIN.frame_cache_gb
+        except Exception:
+            gb = None
+        if gb is not None:
+            return int(float(gb) * (1 << 30))
+        if self.device.type == 'cuda':
+            free, _total = torch.cuda.mem_get_info(self.device)
+            return int(min(free // 4, 16 << 30))
+        return 1 << 30
+
+    def release_frame_cache(self):
+        """Drop the cached frames (called at the end of train(); the cache is only useful inside the epoch loop)."""
+        self.__dict__.pop('_frames_dev', None)
+
+    def _frame_on_device(self, dataset, index, budget_bytes=None):
         """dataset[index] on the device, kept there: the end-to-end loop walks the same frames every epoch (their rays and
         images are 11.5 MB per view and frame: 0.5 ms of pageable upload per step, during which the GPU idles).  Datasets
         whose items are not deterministic (ParticleDataset random_rot) must not come through here."""
-        cache = self.__dict__.setdefault('_frames_dev', {'ds': None, 'items': {}, 'bytes': 0})
+        cache = self.__dict__.setdefault('_frames_dev', {'ds': None, 'items': {}, 'bytes': 0, 'budget': None})
         if cache['ds'] is not dataset:
             cache.update(ds=dataset, items={}, bytes=0)
+        if budget_bytes is None:
+            if cache.get('budget') is None:
+                cache['budget'] = self._frame_cache_budget()
+            budget_bytes = cache['budget']
         item = cache['items'].get(index)
         if item is None:
             item = self._to_dev(dataset[index])
@@ -249,12 +273,12 @@ class RendererTrainer(BaseTrainer):
         ck = torch.load(ckpt_file, map_location=self.device)
         self.start_step = ck['step']
         self.renderer.load_state_dict(ck['renderer_state_dict'], strict=True)
-        self.optimizer.load_state_dict(ck['optimizer_state_dict'])
+        load_optimizer_state(self.optimizer, ck['optimizer_state_dict'])
 
     def save_checkpoint(self, global_step):
         if self.rank == 0:
             torch.save({'step': global_step, 'renderer_state_dict': self.renderer.state_dict(),
-                        'optimizer_state_dict': self.optimizer.state_dict()},
+                        'optimizer_state_dict': portable_optimizer_state(self.optimizer)},
                        osp.join(self.exppath, 'models', f'{global_step}.pt'))
 
     def train(self, max_steps=None):
@@ -267,14 +291,16 @@ class RendererTrainer(BaseTrainer):
         # the global np.random stream, drawn in the reference's order but one step ahead on a host thread
         self._sampler = PixelSampler(np.random, len(self.train_view_names), o.RENDERER.ray.ray_chunk,
                                      lambda s: self.random_sample_coords(H, W, s).shape[0], self.start_step)
-        for step_idx in range(self.start_step, last):
-            loss = self.train_step(data, len(self.train_view_names), H, W, step_idx)
-            self.update_step(loss)
-            if (step_idx + 1) % o.TRAIN.save_interval == 0:
-                self.eval(step_idx)
-                self.save_checkpoint(step_idx)
-        self._sampler.close()
-        self._sampler = None
+        try:
+            for step_idx in range(self.start_step, last):
+                loss = self.train_step(data, len(self.train_view_names), H, W, step_idx)
+                self.update_step(loss)
+                if (step_idx + 1) % o.TRAIN.save_interval == 0:
+                    self.eval(step_idx)
+                    self.save_checkpoint(step_idx)
+        finally:                      # also on an exception: the worker thread must not outlive the loop
+            self._sampler.close()
+            self._sampler = None
         return loss
 
     def update_step(self, loss):
@@ -391,7 +417,7 @@ class E2ETrainer(BaseTrainer):
         if self.rank == 0:
             torch.save({'step': global_step, 'renderer_state_dict': self.renderer.state_dict(),
                         'transition_model_state_dict': self.transition_model.state_dict(),
-                        'optimizer_state_dict': self.optimizer.state_dict()},
+                        'optimizer_state_dict': portable_optimizer_state(self.optimizer)},
                        osp.join(self.exppath, 'models', f'{global_step}.pt'))
 
     def train(self, max_steps=None):
@@ -402,18 +428,21 @@ class E2ETrainer(BaseTrainer):
 
         # (The warm-up trainer draws its pixels one step ahead on a host thread.  Here that was measured a loss — 4.5 -> 6.9 ms
         # per step: this step is bound by the host's launch sequence, and a second Python thread costs it the GIL.)
-        for _epoch in range(self.start_step, o.TRAIN.epochs):
-            self.tmp_fluid_error = FluidErrors()
-            for data_idx in range(len(self.dataset)):
-                data = self._frame_on_device(self.dataset, data_idx)
-                loss = self.train_step(data, data_idx, len(self.train_view_names), H, W, global_step)
-                self.update_step(loss, global_step)
-                global_step += 1; done += 1
-                if (global_step + 1) % o.TRAIN.save_interval == 0:
-                    self.eval(global_step)
-                    self.save_checkpoint(global_step)
-                if max_steps is not None and done >= max_steps:
-                    return loss
+        try:
+            for _epoch in range(self.start_step, o.TRAIN.epochs):
+                self.tmp_fluid_error = FluidErrors()
+                for data_idx in range(len(self.dataset)):
+                    data = self._frame_on_device(self.dataset, data_idx)
+                    loss = self.train_step(data, data_idx, len(self.train_view_names), H, W, global_step)
+                    self.update_step(loss, global_step)
+                    global_step += 1; done += 1
+                    if (global_step + 1) % o.TRAIN.save_interval == 0:
+                        self.eval(global_step)
+                        self.save_checkpoint(global_step)
+                    if max_steps is not None and done >= max_steps:
+                        return loss
+        finally:
+            self.release_frame_cache()          # the pinned frames are only useful inside the epoch loop
         return loss
 
     def trainsition_step_for_training(self, data, data_idx):
@@ -658,7 +687,7 @@ class TransModelTrainer(BaseTrainer):
     def resume(self, ckpt_file):
         ck = torch.load(ckpt_file, map_location=self.device)
         self.transition_model.load_state_dict(ck['model_state_dict'], strict=True)
-        self.optimizer.load_state_dict(ck['optimizer_state_dict'])
+        load_optimizer_state(self.optimizer, ck['optimizer_state_dict'])
 
     def sample_loss(self, data):
         """The loss of one training sample (trainer_transmodel.py:170-189); returns (loss, parts)."""
@@ -699,7 +728,7 @@ class TransModelTrainer(BaseTrainer):
             if (epoch_idx + 1) % o.TRAIN.save_interval == 0:
                 if self.rank == 0:
                     torch.save({'step': epoch_idx, 'model_state_dict': self.transition_model.state_dict(),
-                                'optimizer_state_dict': self.optimizer.state_dict()},
+                                'optimizer_state_dict': portable_optimizer_state(self.optimizer)},
                                osp.join(self.exppath, 'models', f'{global_step}.pt'))
                 self.eval(global_step)
         return loss

@@ -1132,3 +1132,133 @@ def test_mlp_tile_per_workgroup_bit_equal(dev):
         touched = (outs[2][0] != -7.0).any(dim=1)
         assert int(touched.sum()) == live           # exactly the live rows' samples were written
 
+
+
+# ------------------------------------------------------------------------------------------------
+# round 3: BASELINE configs at their real shapes — config 2's whole batch against autograd through the oracle, configs 4 / 5
+# as full 800 x 800 frames of the shaped clouds (fp32 and fp16-MFMA)
+# ------------------------------------------------------------------------------------------------
+def test_config2_full_batch_loss_and_grads_vs_oracle_autograd(dev):
+    """BASELINE config 2 (`train_renderer.py`, trainer/trainer_renderer.py:102-143): ONE optimiser step's batch at its real
+    size — 4 views x 1024 pixels of the 400 x 400 camera drawn with np.random.choice in the reference's order, all views in
+    one fused call — loss and ALL 48 parameter gradients (norms and full tensors) against torch autograd
+    through the oracle on the SAME 4 096 rays and the very fine depths z1 the HIP path sampled (both sides differentiate the
+    same 192 samples per ray).  Bars: those of test_trainstep_grads_vs_golden / test_fine_net_grads_same_samples — loss
+    1e-5 absolute, coarse net 2e-5 relative, fine net 2e-2 (its calibrated noise floor under a 1-ulp move of the particles is
+    0.8-1.9e-2, tools/grad_sensitivity.py).  The oracle runs in 512-ray slices (its autograd graph of 4 096 x 192 samples
+    would hold ~8 GB)."""
+    import numpy as np
+    from oracle import render_oracle as ro
+    from neurofluid_amd.autograd import _run_passes
+    from neurofluid_amd.train_step import random_sample_coords, choice_without_replacement, gather_view_pixels, summed_view_mse
+    net = make_net(dev)
+    H = W = 400
+    c2w = ro.eval_camera()
+    o, dd = ro.get_rays(ro.get_ray_directions(H, W, ro.camera_focal(W)), c2w)
+    rays_img = torch.cat([o, dd], -1).to(dev)                         # (H, W, 6)
+    gen = torch.Generator().manual_seed(42)
+    views = [dict(cw=c2w.to(dev), rays=rays_img, rgb=torch.rand(H * W, 3, generator=gen).to(dev)) for _ in range(4)]
+    P = ro.watercube_particles().to(dev)
+    rng = np.random.RandomState(7)
+    coords = random_sample_coords(H, W, 1000, 500)                    # past precrop_iters: the whole frame
+    sels = [choice_without_replacement(rng, coords.shape[0], 1024) for _ in views]
+    rays, rgbs, roc = gather_view_pixels([v["rays"] for v in views], [v["rgb"] for v in views], [v["cw"] for v in views],
+                                         coords, sels, H, W)
+    assert rays.shape == (4096, 6) and roc.shape == (4096, 3)
+    with torch.no_grad():
+        _, p1, _, _, _ = _run_passes(net, P, roc, rays, True, True, save_acts=True)
+    z1 = p1.z.cpu()
+    out = net(P, roc, rays, None, None)
+    loss = summed_view_mse(out, rgbs, 4, True)
+    loss.backward()
+    assert float(out["mask_1"].sum()) > 4096                          # the batch crosses the fluid
+    # ---- oracle: same rays, same z1, sliced; loss = sum over views of MSE = sum of squares / (1024 * 3)
+    st = {k: v.clone().requires_grad_(True) for k, v in ro.deterministic_nerf_state().items()}
+    rc, tc, Pc, roh = rays.cpu(), rgbs.cpu(), P.cpu(), c2w[:, 3]
+    ref_loss = 0.0
+    for a in range(0, 4096, 512):
+        r = rc[a:a + 512]
+        z0, xyz0 = ro.coarse_sample_ray(9.0, 13.0, r, 64)
+        p0 = ro.render_pass(st, "nerf_coarse", Pc, roh, r, z0, xyz0, ro.DEFAULT_CFG)
+        zz = z1[a:a + 512]
+        xyz1 = r[:, None, :3] + r[:, None, 3:] * zz[:, :, None]
+        pf = ro.render_pass(st, "nerf_fine", Pc, roh, r, zz, xyz1, ro.DEFAULT_CFG)
+        part = (((p0["rgb"] - tc[a:a + 512]) ** 2).sum() + ((pf["rgb"] - tc[a:a + 512]) ** 2).sum()) / (1024 * 3)
+        part.backward()
+        ref_loss += float(part.detach())
+        torch.testing.assert_close(out["rgb0"][a:a + 512].detach().cpu(), p0["rgb"].detach(), rtol=0, atol=RGB_ATOL)
+        torch.testing.assert_close(out["rgb1"][a:a + 512].detach().cpu(), pf["rgb"].detach(), rtol=0, atol=RGB_ATOL)
+    assert abs(float(loss.detach()) - ref_loss) < 1e-5, (float(loss.detach()), ref_loss)
+    params = dict(net.named_parameters())
+    assert len(params) == 48
+    worst = {"nerf_coarse": 0.0, "nerf_fine": 0.0}
+    for name, p in params.items():
+        r = st[name].grad
+        tight = name.startswith("nerf_coarse")
+        gn, rn = float(p.grad.norm()), float(r.norm())
+        assert abs(gn - rn) <= (2e-5 if tight else 5e-3) * rn + 1e-12, (name, gn, rn)
+        rel = float((p.grad.cpu() - r).norm() / (rn + 1e-30))
+        worst[name.split(".")[0]] = max(worst[name.split(".")[0]], rel)
+        assert rel <= (2e-5 if tight else 2e-2), (name, rel)
+    print("config-2 batch: worst relative gradient error", worst)
+
+
+def _frame_checks(full, P, rays, side, net, roc):
+    """Size-independent properties of a whole frame (see test_full_frame_size_independent_properties)."""
+    N = side * side
+    assert full["rgb1"].shape == (N, 3) and full["num_nn_1"].shape == (N, 192, 1)
+    for k in ("rgb0", "rgb1", "opacity0", "opacity1"):
+        assert float(full[k].min()) >= 0.0 and float(full[k].max()) <= 1.0 + 1e-6
+    assert float(full["mask_0"].max()) <= 64 and float(full["mask_1"].max()) <= 192
+    assert int(full["num_nn_1"].max()) <= 20 and int(full["num_nn_1"].min()) >= 0
+    lo, hi = P.min(0).values - 0.2251, P.max(0).values + 0.2251
+    o, d = rays[:, :3], rays[:, 3:]
+    t0, t1 = (lo - o) / d, (hi - o) / d
+    tn, tf = torch.minimum(t0, t1).max(1).values, torch.maximum(t0, t1).min(1).values
+    miss = (tn > tf) | (tf < 9.0) | (tn > 13.0)
+    assert float(miss.float().mean()) > 0.3
+    assert float(full["mask_1"][miss].sum()) == 0 and bool((full["rgb1"][miss] == 1.0).all())
+    # chunk independence: the 8 image rows with the most active samples, rendered alone in the reference's 1024-ray chunks
+    per_row = full["mask_1"].view(side, side).sum(1)
+    r0 = int(torch.clamp(per_row.argmax() - 4, 0, side - 8))
+    band = slice(r0 * side, (r0 + 8) * side)
+    with torch.no_grad():
+        parts = [net(P, roc, rays[band][i:i + 1024].contiguous(), None, None) for i in range(0, 8 * side, 1024)]
+    for k in ("rgb0", "rgb1", "depth1", "opacity1", "num_nn_0", "num_nn_1", "mask_0", "mask_1"):
+        assert torch.equal(torch.cat([p[k] for p in parts]), full[k][band]), k
+    return band
+
+
+@pytest.mark.parametrize("kind", ["bunny", "honeycone"])
+def test_shaped_cloud_full_800_frame_fp32_and_fp16(dev, kind):
+    """BASELINE configs 4 / 5 at their shape: the bunny- / honeycone-shaped cloud (random index order, the hardest regime of
+    the first-K search) as ONE 800 x 800 frame = 640 000 rays, 123 M fine samples.  fp32 path: the size-independent
+    properties + a 24-ray spot check against the oracle on rays through the body (masks / neighbour counts bit-exact, RGB
+    within the fp32 tolerance).  `mlp_dtype: fp16` (config 5's "fp16 MFMA path") on the SAME cloud: coarse masks and
+    neighbour counts bit-exact (they do not depend on the MLP), the fine image >= 45 dB from the fp32 frame."""
+    from oracle import render_oracle as ro
+    from neurofluid_amd import ray_utils, synthetic
+    side = 800
+    net = make_net(dev)
+    P = synthetic.shaped_particles(kind, order="random").to(dev)
+    c2w = ro.eval_camera()
+    rays = ray_utils.get_rays_cpu(side, side, ro.camera_focal(side), c2w).view(-1, 6).to(dev)
+    roc = c2w[:, 3].to(dev)
+    with torch.no_grad():
+        full = net(P, roc, rays, None, None)
+    assert float((full["mask_1"] > 0).float().mean()) > 0.02           # the body is in view
+    band = _frame_checks(full, P, rays, side, net, roc)
+    hit = torch.nonzero(full["mask_1"].view(-1) > 20).view(-1)
+    sel = hit[torch.linspace(0, hit.numel() - 1, 24).long()]
+    ref = ro.render_forward(ro.deterministic_nerf_state(), P.cpu(), roc.cpu(), rays[sel].cpu(), 9.0, 13.0)
+    assert torch.equal(full["mask_0"][sel].cpu(), ref["mask_0"]) and torch.equal(full["num_nn_0"][sel].cpu(), ref["num_nn_0"])
+    torch.testing.assert_close(full["rgb0"][sel].cpu(), ref["rgb0"], rtol=0, atol=RGB_ATOL)
+    torch.testing.assert_close(full["rgb1"][sel].cpu(), ref["rgb1"], rtol=0, atol=5 * RGB_ATOL)      # one-bin resampling moves
+    assert ro.psnr(full["rgb1"][sel].cpu(), ref["rgb1"]) >= RGB_PSNR_MIN
+    net16 = make_net(dev, dict(make_cfg(), mlp_dtype="fp16"))
+    with torch.no_grad():
+        h = net16(P, roc, rays, None, None)
+    assert torch.equal(h["mask_0"], full["mask_0"]) and torch.equal(h["num_nn_0"], full["num_nn_0"])
+    p0, p1 = ro.psnr(h["rgb0"].cpu(), full["rgb0"].cpu()), ro.psnr(h["rgb1"].cpu(), full["rgb1"].cpu())
+    print(f"{kind} 800x800: fp16 vs fp32 frame {p0:.1f} dB (coarse) / {p1:.1f} dB (fine)")
+    assert p0 >= 45.0 and p1 >= 45.0

@@ -245,3 +245,86 @@ def test_pixel_sampler_uses_the_native_draw():
     got = s.next(0)
     s.close()
     assert np.array_equal(got[0], np.random.RandomState(1).choice(50, size=[8], replace=False))
+
+
+# ------------------------------------------------------------------------------------------------
+# round 3 (ADVICE): portable optimizer state, per-view pixel gather, sampler ownership of its random stream
+# ------------------------------------------------------------------------------------------------
+def test_portable_optimizer_state_round_trips_with_plain_adam():
+    """A checkpoint written through portable_optimizer_state() is what a default torch.optim.Adam writes: CPU float `step`,
+    no implementation switch frozen into the param groups — it loads into a plain Adam (the reference's), and a plain Adam's
+    checkpoint loads back through load_optimizer_state() with the same next update."""
+    import torch
+    from neurofluid_amd.train_step import make_adam, portable_optimizer_state, load_optimizer_state
+    torch.manual_seed(0)
+    w0 = torch.randn(5, 3)
+    g1, g2 = torch.randn(5, 3), torch.randn(5, 3)
+
+    def run(opt, p, grads):
+        for g in grads:
+            p.grad = g.clone()
+            opt.step()
+
+    pa = torch.nn.Parameter(w0.clone())
+    a = make_adam([pa], lr=1e-2)                       # CPU parameters: the default implementation
+    run(a, pa, [g1])
+    sd = portable_optimizer_state(a)
+    assert all(g.get("fused") is None and g.get("foreach") is None for g in sd["param_groups"])
+    assert all(st["step"].device.type == "cpu" and st["step"].dtype == torch.float32 for st in sd["state"].values())
+    pb = torch.nn.Parameter(pa.detach().clone())
+    b = torch.optim.Adam([pb], lr=1e-2)                # "the reference's optimizer"
+    b.load_state_dict(sd)
+    run(a, pa, [g2]); run(b, pb, [g2])
+    assert torch.equal(pa, pb)
+    pc = torch.nn.Parameter(pb.detach().clone())
+    c = make_adam([pc], lr=1e-2)
+    import copy
+    load_optimizer_state(c, copy.deepcopy(b.state_dict()))      # and back: a plain Adam's checkpoint into ours
+    g3 = torch.randn(5, 3)
+    run(b, pb, [g3]); run(c, pc, [g3])
+    assert torch.equal(pb, pc)
+
+
+def test_gather_view_pixels_indexes_each_view_separately():
+    """Same rows as indexing every view on its own (trainer/basetrainer.py:186-193), view-major, one camera position per ray."""
+    import torch
+    from neurofluid_amd.train_step import gather_view_pixels
+    H, W, V, rc = 6, 5, 3, 7
+    g = torch.Generator().manual_seed(1)
+    rays = [torch.randn(H, W, 6, generator=g) for _ in range(V)]
+    rgbs = [torch.rand(H * W, 3, generator=g) for _ in range(V)]
+    cws = [torch.randn(3, 4, generator=g) for _ in range(V)]
+    coords = torch.stack(torch.meshgrid(torch.arange(H).float(), torch.arange(W).float(), indexing="ij"), -1).reshape(-1, 2)
+    sels = [np.random.RandomState(v).choice(H * W, rc, replace=False) for v in range(V)]
+    r, c, ro = gather_view_pixels(rays, rgbs, cws, coords, sels, H, W)
+    for v in range(V):
+        yx = coords[sels[v]].long()
+        assert torch.equal(r[v * rc:(v + 1) * rc], rays[v][yx[:, 0], yx[:, 1]])
+        assert torch.equal(c[v * rc:(v + 1) * rc], rgbs[v][yx[:, 0] * W + yx[:, 1]])
+        assert torch.equal(ro[v * rc:(v + 1) * rc], cws[v][:, 3].expand(rc, 3))
+    r1, c1, _ = gather_view_pixels(rays[:1], rgbs[:1], cws[:1], coords, sels[:1], H, W)
+    assert torch.equal(r1, r[:rc]) and torch.equal(c1, c[:rc])
+
+
+def test_pixel_sampler_warns_about_foreign_draws_and_closes_twice():
+    """Native mode owns a COPY of the stream: somebody else drawing from `rng` while the sampler is alive is detected at
+    close() (warning; the stream ends at the sampler's own position).  close() is idempotent and usable as a context."""
+    import warnings
+    from neurofluid_amd.train_step import PixelSampler
+    rng = np.random.RandomState(3)
+    with PixelSampler(rng, 1, 8, lambda step: 50, 0) as s:
+        native = s._native_state() is not None
+        s.next(0)
+        rng.rand(4)                                     # a foreign consumer
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            s.close()
+    if native:
+        assert any("another consumer" in str(x.message) for x in w)
+    s.close()                                           # second close: no-op
+    rng2 = np.random.RandomState(3)
+    with warnings.catch_warnings(record=True) as w2:
+        warnings.simplefilter("always")
+        with PixelSampler(rng2, 1, 8, lambda step: 50, 0) as s2:
+            s2.next(0)
+    assert not any("another consumer" in str(x.message) for x in w2)

@@ -87,7 +87,7 @@ class _NerfFn(torch.autograd.Function):
         P, keep = _nerf_param_struct(layers)
         packed = torch.empty(lib.nf_nerf_packed_floats(cx, cd), dtype=torch.float32, device=dev)
         check(lib.nf_nerf_pack(ctypes.byref(P), cx, cd, ptr(packed), _lib.stream()), "nf_nerf_pack")
-        need = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+        need = any(ctx.needs_input_grad)          # (grad mode is off inside Function.forward: ask the ctx, not torch)
         X = ops.rows_to_tiles(xf, cx, cd)
         n_rows = torch.tensor([n], dtype=torch.int32, device=dev)
         row_sample = torch.arange(n, dtype=torch.int32, device=dev)
@@ -97,7 +97,7 @@ class _NerfFn(torch.autograd.Function):
             check(lib.nf_nerf_mlp_fwd(ptr(packed), cx, cd, ptr(X), ptr(n_rows), n, ptr(row_sample), ptr(out), ptr(acts),
                                       _lib.stream()), "nf_nerf_mlp_fwd")
         ctx.net, ctx.sigma_only, ctx.n = net, sigma_only, n
-        ctx.x_needs_grad = x.requires_grad
+        ctx.x_needs_grad = bool(ctx.needs_input_grad[1])
         if need:
             ctx.save_for_backward(packed, X, n_rows, row_sample, out, acts)
         return out[:, 3:4].clone() if sigma_only else out

@@ -451,8 +451,8 @@ def test_kat_radius_inclusivity_hip(dev):
     pts = torch.from_numpy(kat.radius_points()).to(dev)
     q = pts[:1].contiguous()
     idx, rs, d2 = ops.fixed_radius_search(pts, q, kat.RADIUS, True)
-    assert idx.tolist() == kat.FIXED_RADIUS_EXPECTED_IGNORE and rs.tolist() == [0, 3]
-    assert float(d2[1]) == kat.RADIUS ** 2
+    assert sorted(idx.tolist()) == kat.FIXED_RADIUS_EXPECTED_IGNORE and rs.tolist() == [0, 3]      # (cell-major order)
+    assert float(d2[idx.tolist().index(2)]) == kat.RADIUS ** 2
     idx, rs, d2 = ops.fixed_radius_search(pts, q, kat.RADIUS, False)
     assert sorted(idx.tolist()) == kat.FIXED_RADIUS_EXPECTED_KEEP
     d, i, nn = ops.ball_query(q[None], pts[None], kat.RADIUS, 5)

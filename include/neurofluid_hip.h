@@ -39,6 +39,8 @@ const char* nf_last_error(void);
  * ------------------------------------------------------------------------------------------ */
 #define NF_GRID_MAX_DIM 128
 size_t nf_grid_workspace_bytes(int n_points, float cell, const float bbox[6]);
+/* number of cells the grid of (n_points, cell, bbox) has (0 = bad parameters): the same header code the builders run */
+int nf_grid_cells(int n_points, float cell, const float bbox[6]);
 /* Byte offset, inside a built workspace, of the EXACT axis-aligned bounds of the points: 6 x uint32 (lo xyz, hi xyz) in the
  * order-preserving encoding u = bits(f) ^ (bits(f) >> 31 ? 0xffffffff : 0x80000000), written by nf_grid_build whatever bbox
  * the grid was given (points outside the bbox are clamped into its boundary cells; results do not depend on the bbox).
@@ -358,6 +360,51 @@ int nf_host_choice_mt19937(uint32_t* key /*624, in/out*/, int* pos /*in/out*/, i
 size_t nf_image_ssim_workspace_floats(int B, int C, int H, int W);
 int nf_image_ssim(const float* pred, const float* gt, int B, int C, int H, int W, const float window[11], float L,
                   float* workspace, float* ssim_per_image, nf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Round 3: G-free inference step (ParticleNet.forward, models/transmodel.py:151-163; the Open3D ContinuousConv layers of
+ * :86-95 evaluated in Open3D's own order: gather a (64 x Cin) patch per output point, then one contraction with the
+ * filter on the fp32 matrix pipe — nothing of size n x 64 x C is ever materialised).
+ *   nf_trans_front     search of both clouds + the row-entry lists of the fluid pairs + layer 0 (conv0_obstacle, conv0_fluid,
+ *                      dense0_fluid, :116-120).  Row entry = {j | cx << 30, w(cx), w(cx + 1)} of a pair in filter row
+ *                      (cz + dz) * 4 + (cy + dy); entries[i][roff[i][rho] .. roff[i][rho + 1]) (roff: 20 uint16 per particle).
+ *                      Rows keep a pitch (<= nf_trans_front_max_pitch()); overflow2[w] = largest count above its pitch.
+ *   nf_cconv_gf_layer  y = cconv(act(x)) + Linear(act(x)) + biases (+ residual) for Cin in {96, 64}, Cout <= 64 (:121-131),
+ *                      optionally followed by pos_correction / update_pos_vel (:141-148).  packed = nf_cconv_gf_pack(kernel
+ *                      (4,4,4,Cin,Cout), dense_w (Cout,Cin)); scratch = nf_cconv_gf_plan(...) floats; max_wg = CUs.
+ *   nf_trans_step      prepare + front + three layers behind one call; optionally copies overflow2 to pinned host memory
+ *                      right behind the front kernel and records `event` (hipEvent_t) there. */
+int nf_trans_front_max_pitch(void);
+int nf_trans_front(const void* fluid_grid, const void* box_grid, const float* queries, const float* fluid_feats,
+                   const float* box_feats, int n, float radius, float extent, int use_window, int pitch_fluid,
+                   int pitch_box, int32_t* counts2, float* num_fluid_nbrs, int32_t* idx_f, float* d2_f, uint16_t* roff,
+                   uint32_t* entries, const float* kernel_fluid, const float* bias_fluid, const float* kernel_obstacle,
+                   const float* bias_obstacle, const float* dense_w, const float* dense_b, float* out96,
+                   int64_t* overflow2, nf_stream_t stream);
+size_t nf_cconv_gf_packed_floats(int cin, int cout);
+int nf_cconv_gf_pack(const float* kernel, const float* dense_w, int cin, int cout, float* packed, nf_stream_t stream);
+int nf_cconv_gf_plan(int n, int cout, int max_wg, int* tiles, int* nwg, int* maxseg, size_t* scratch_floats);
+int nf_cconv_gf_layer(const float* x, int n, int cin, int cout, int relu, const uint16_t* roff, const uint32_t* entries,
+                      int pitch, const float* packed, const float* bias_conv, const float* bias_dense,
+                      const float* residual, float* out, float* scratch, int max_wg, const float* pos,
+                      const float* pos_new, float scale, float dt, float* pos_c, float* vel_c, nf_stream_t stream);
+typedef struct {
+    /* model (device pointers; wpK = nf_cconv_gf_pack of convK / denseK) */
+    const float *k_fluid, *b_fluid, *k_obst, *b_obst, *dense0_w, *dense0_b;
+    const float *wp1, *bc1, *bd1, *wp2, *bc2, *bd2, *wp3, *bc3, *bd3;
+    /* scene */
+    const void* box_grid; const float* box_feats;
+    /* workspace of one particle count */
+    void* grid_ws; size_t grid_ws_bytes;
+    float *pos_new, *vel_new, *feats; int32_t* counts2; int32_t* idx_f; float* d2_f; uint16_t* roff; uint32_t* ent;
+    float *a0, *a1, *a2, *y3, *scratch; int64_t* overflow2;
+    int n, pitch_f, pitch_b, use_window, max_wg;
+    float radius, extent, dt, scale;
+    float gravity[3]; float bbox[6];
+} nf_trans_step_t;
+int nf_trans_step(const nf_trans_step_t* s /*[host]*/, const float* pos, const float* vel, float* num_fluid_nbrs, float* pos_c,
+                  float* vel_c, int64_t* host_overflow2 /*[pinned host] or NULL*/, void* event /*hipEvent_t or NULL*/,
+                  nf_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libneurofluid_hip.so")
-SOURCES = ["nf_grid.hip", "nf_render.hip", "nf_mlp.hip", "nf_mlp_l.hip", "nf_mlp_n.hip", "nf_mlp_h2.hip", "nf_mlp_s.hip", "nf_cconv.hip", "nf_trans.hip", "nf_host.hip", "nf_metrics.hip", "nf_embed.hip", "nf_gemm.hip"]
+SOURCES = ["nf_grid.hip", "nf_render.hip", "nf_mlp.hip", "nf_mlp_l.hip", "nf_mlp_n.hip", "nf_mlp_h2.hip", "nf_mlp_s.hip", "nf_cconv.hip", "nf_cconv_gf.hip", "nf_trans.hip", "nf_host.hip", "nf_metrics.hip", "nf_embed.hip", "nf_gemm.hip"]
 # per-file flags.  nf_mlp_h2.hip: MFMA accumulators in VGPRs (the finished blocks are converted by VALU instructions,
 # which cannot read AGPRs: AGPR accumulators cost 16 v_accvgpr_read per block and tile)
 EXTRA_FLAGS = {"nf_mlp_h2.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "nf_mlp_s.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}

@@ -15,6 +15,18 @@ void nf_set_error(const char* fmt, ...);
         if (!(cond)) { nf_set_error("%s: %s", __func__, msg); return NF_EINVAL; } \
     } while (0)
 
+// true the first time a call site runs on the CURRENT device (hipFuncSetAttribute belongs to a device's copy of the function:
+// a process-wide "done" flag would leave every device but the first at the 64 KB default).  `flags` = the call site's own
+// static bool[64].
+static inline bool nf_first_use_on_device(bool* flags)
+{
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return true;
+    if (flags[d]) return false;
+    flags[d] = true;
+    return true;
+}
+
 #define NF_CHECK_LAUNCH()                                                             \
     do {                                                                              \
         hipError_t e_ = hipGetLastError();                                            \

@@ -197,6 +197,14 @@ int nf_grid_make_header(int n, float cell, const float bbox[6], NfGridHeader* h,
 
 extern "C" size_t nf_grid_points_aabb_offset(void) { return offsetof(NfGridHeader, pt_lo); }
 
+extern "C" int nf_grid_cells(int n_points, float cell, const float bbox[6])
+{
+    NfGridHeader h;
+    size_t tot = 0;
+    if (nf_grid_make_header(n_points, cell, bbox, &h, &tot) != NF_OK) return 0;
+    return h.n_cells;
+}
+
 extern "C" size_t nf_grid_workspace_bytes(int n_points, float cell, const float bbox[6])
 {
     NfGridHeader h;
@@ -491,11 +499,13 @@ extern "C" int nf_grid_build(const float* pts, int n, float cell, const float bb
     int* fill = (int*)((char*)ws + h.off_cell_fill);
     int* cstart = (int*)((char*)ws + h.off_cell_start);
     if (n > 0 && n <= GB_BLOCK * GB_MAX_PER_THREAD && (long)h.n_cells + n <= GB_MAX_LDS_INTS) {
-        static bool attr_set = false;
-        if (!attr_set) {
+        static bool attr_set[64] = {};          // per DEVICE: the attribute belongs to the device's copy of the function
+        int dev = 0;
+        hipGetDevice(&dev);
+        if (dev < 0 || dev >= 64 || !attr_set[dev]) {
             hipFuncSetAttribute((const void*)k_grid_cells_1wg, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 GB_MAX_LDS_INTS * (int)sizeof(int));
-            attr_set = true;
+            if (dev >= 0 && dev < 64) attr_set[dev] = true;
         }
         hipLaunchKernelGGL(k_grid_cells_1wg, dim3(1), dim3(GB_BLOCK), sizeof(int) * ((size_t)h.n_cells + n), st, h, ws, pts);
     } else {

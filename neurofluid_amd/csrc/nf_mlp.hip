@@ -424,11 +424,10 @@ extern "C" int nf_nerf_mlp_fwd(const float* packed, int cx, int cd, const float*
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = (size_t)4 * L.qx * 64 * sizeof(f32x4);      // the X stash: 100 KB at qx = 25 (one workgroup per CU)
     NF_CHECK_ARG(lds <= 160 * 1024, "feature row too wide for the LDS stash");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};
+    if (nf_first_use_on_device(attr_set)) {
         hipFuncSetAttribute((const void*)k_mlp_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipFuncSetAttribute((const void*)k_mlp_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
     }
     if (acts)
         hipLaunchKernelGGL(k_mlp_fwd<true>, dim3(blocks), dim3(256), lds, st, L, packed, X, n_rows, max_rows, row_sample,

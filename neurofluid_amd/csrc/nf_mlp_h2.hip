@@ -426,10 +426,9 @@ extern "C" int nf_nerf_mlp_fwd_h2(const void* stream_h2, int cx, int cd, const v
     int blocks = (pairs + 3) / 4;
     if (blocks > 256) blocks = 256;
     const size_t lds = (size_t)H2_RING * 1024 + (size_t)4 * 2 * H2_XS * 1024;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};
+    if (nf_first_use_on_device(attr_set)) {
         hipFuncSetAttribute((const void*)k_mlp_fwd_h2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     hipLaunchKernelGGL(k_mlp_fwd_h2, dim3(blocks), dim3(256), lds, (hipStream_t)stream, (const u32x4*)stream_h2, nslots,
                        (const u32x4*)X, n_rows, max_rows, row_sample, (float4*)rgbsigma);

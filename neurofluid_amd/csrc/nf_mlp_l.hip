@@ -399,10 +399,9 @@ extern "C" int nf_nerf_mlp_fwd_l(const float* packed, const float* wstream, int 
     int blocks = (tiles + 3) / 4;
     if (blocks > 256) blocks = 256;
     const size_t lds = (size_t)(3 * LS_CHUNK_F4 + 4 * LS_QX * 64) * sizeof(f32x4);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};
+    if (nf_first_use_on_device(attr_set)) {
         hipFuncSetAttribute((const void*)k_mlp_fwd_l, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     hipLaunchKernelGGL(k_mlp_fwd_l, dim3(blocks), dim3(256), lds, (hipStream_t)stream, L, packed, (const f32x4*)wstream,
                        S.nslots, X, n_rows, max_rows, row_sample, (float4*)rgbsigma);

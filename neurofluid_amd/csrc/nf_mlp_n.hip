@@ -265,11 +265,10 @@ extern "C" int nf_nerf_mlp_fwd_n(const float* packed, int cx, int cd, const floa
     NF_CHECK_ARG(L.qx == 25 && L.qd == 7, "built for the default 198 + 54 feature row (other encodings: nf_nerf_mlp_fwd)");
     const int tiles = (max_rows + 31) / 32;
     const size_t lds = (size_t)(2 * NN_ACT) * sizeof(float);       // 64 KB: two workgroups per CU
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};
+    if (nf_first_use_on_device(attr_set)) {
         hipFuncSetAttribute((const void*)k_mlp_fwd_n<true, 25, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipFuncSetAttribute((const void*)k_mlp_fwd_n<false, 25, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
     }
     hipStream_t st = (hipStream_t)stream;
     if (acts)

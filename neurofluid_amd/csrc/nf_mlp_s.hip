@@ -414,10 +414,9 @@ extern "C" int nf_nerf_mlp_fwd_s(const void* stream_s, int cx, int cd, const flo
     int blocks = (tiles + 3) / 4;
     if (blocks > 256) blocks = 256;
     const size_t lds = (size_t)S_RING * 2048 + (size_t)4 * 2 * S_XS * 1024;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};
+    if (nf_first_use_on_device(attr_set)) {
         hipFuncSetAttribute((const void*)k_mlp_fwd_s, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     hipLaunchKernelGGL(k_mlp_fwd_s, dim3(blocks), dim3(256), lds, (hipStream_t)stream, (const u32x4*)stream_s, s_padded_steps(),
                        (const f32x4*)X, n_rows, max_rows, row_sample, (float4*)rgbsigma);

@@ -132,10 +132,12 @@ extern "C" int nf_trans_prepare(const float* pos, const float* vel, const float 
     NF_CHECK_ARG(n > 0 && n <= TP_BLOCK * TP_MAX_PER_THREAD && h.n_cells + n <= TP_MAX_LDS_INTS,
                  "cloud or grid too large for the single-workgroup build (use nf_trans_integrate + nf_grid_build)");
     const size_t lds = (size_t)(h.n_cells + n) * sizeof(int);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};              // per DEVICE
+    int dev = 0;
+    hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
         hipFuncSetAttribute((const void*)k_trans_prepare, hipFuncAttributeMaxDynamicSharedMemorySize, TP_MAX_LDS_INTS * (int)sizeof(int));
-        attr_set = true;
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     hipLaunchKernelGGL(k_trans_prepare, dim3(1), dim3(TP_BLOCK), lds, (hipStream_t)stream, h, grid_ws, pos, vel, gravity[0],
                        gravity[1], gravity[2], dt, pos_new, vel_new, feats4);
@@ -632,4 +634,29 @@ __global__ void __launch_bounds__(64 * TF_QPB) k_trans_front(TfArgs A)
         const float ao = tf_patch_times_filter<3>(patch[wv], Ks, co, half);
         if (half == 0) orow[co] = ao + A.b_obst[co];
     }
+}
+
+extern "C" int nf_trans_front_max_pitch(void) { return TF_MAXP; }
+
+extern "C" int nf_trans_front(const void* fluid_grid, const void* box_grid, const float* queries, const float* fluid_feats,
+                              const float* box_feats, int n, float radius, float extent, int use_window, int pitch_fluid,
+                              int pitch_box, int32_t* counts2, float* num_fluid_nbrs, int32_t* idx_f, float* d2_f, uint16_t* roff,
+                              uint32_t* entries, const float* kernel_fluid, const float* bias_fluid, const float* kernel_obstacle,
+                              const float* bias_obstacle, const float* dense_w, const float* dense_b, float* out96,
+                              int64_t* overflow2, nf_stream_t stream)
+{
+    NF_CHECK_ARG(fluid_grid && box_grid && queries && fluid_feats && box_feats && counts2 && num_fluid_nbrs && idx_f && d2_f && roff &&
+                 entries && kernel_fluid && bias_fluid && kernel_obstacle && bias_obstacle && dense_w && dense_b && out96 && overflow2,
+                 "null pointer");
+    NF_CHECK_ARG(n > 0 && radius > 0.f && extent > 0.f, "bad n/radius/extent");
+    NF_CHECK_ARG(pitch_fluid >= 1 && pitch_fluid <= TF_MAXP && pitch_box >= 1 && pitch_box <= TF_MAXP, "pitch must be in [1, nf_trans_front_max_pitch()]");
+    TfArgs A;
+    A.grid[0] = fluid_grid; A.grid[1] = box_grid; A.q = queries; A.feats_f = fluid_feats; A.feats_b = box_feats; A.n = n;
+    A.r2 = radius * radius; A.extent = extent; A.use_window = use_window; A.pitch_f = pitch_fluid; A.pitch_b = pitch_box;
+    A.counts2 = counts2; A.num_nbrs = num_fluid_nbrs; A.idx_f = idx_f; A.d2_f = d2_f; A.roff = roff; A.ent = entries;
+    A.k_fluid = kernel_fluid; A.b_fluid = bias_fluid; A.k_obst = kernel_obstacle; A.b_obst = bias_obstacle;
+    A.dense_w = dense_w; A.dense_b = dense_b; A.a0 = out96; A.overflow2 = (unsigned long long*)overflow2;
+    hipLaunchKernelGGL(k_trans_front, dim3((n + TF_QPB - 1) / TF_QPB, 2), dim3(64 * TF_QPB), 0, (hipStream_t)stream, A);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
 }

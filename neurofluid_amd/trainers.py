@@ -192,7 +192,7 @@ class BaseTrainer:
     def _to_dev(self, data):
         """Host -> device copy of one dataset item.  The container (``box`` / ``box_normals``, ~39 k points, the same
         for every frame) is uploaded ONCE and the same device tensors are handed out afterwards, so the caches keyed
-        on them (box grid, scene bounds, step graph) hit; a rotated container (ParticleDataset random_rot) differs
+        on them (box grid, scene bounds) hit; a rotated container (ParticleDataset random_rot) differs
         per item and is uploaded as such."""
         out = {}
         for k, v in data.items():

@@ -163,12 +163,12 @@ class ParticleNet(nn.Module):
             self.convs.append(getattr(self, f'conv{i}'))
         self._box_cache = (None, None, None)
         self.num_fluid_neighbors = None
-        self._graph_cfg, self._graph, self._nnz_seen = None, None, None
         # fused inference step (nf_trans.hip): CSR capacities in pairs per particle (dense SPH fluid at this radius has
         # ~40-50 fluid neighbours; the container contributes < 30), persistent buffers per particle count
         self.max_fluid_neighbors, self.max_box_neighbors = 128, 64
         self.fused_inference = True
-        self._fused = None
+        self.fused_grow_pitch = True        # on overflow: redo the step exactly AND grow the pitch (False: only redo)
+        self._fused, self._fused_skip = None, 0
 
     _window_poly6 = staticmethod(_window_poly6)
 
@@ -218,199 +218,161 @@ class ParticleNet(nn.Module):
             from .autograd_bwd import particle_net_with_grad
             return particle_net_with_grad(self, pos, vel, box, box_feats)
         with torch.no_grad():
-            if self._graph_cfg is not None:
-                return self._graph_step(pos, vel, box, box_feats)
             if self.fused_inference and self._fused_ok(pos, box):
                 return self._forward_fused(pos, vel, box, box_feats)
             return self._forward_impl(pos, vel, box, box_feats)[:3]
 
     # ------------------------------------------------------------------
-    # Fused inference step: 9 launches, no host round trip.  prepare (integrate + fluid grid, one
-    # workgroup) -> search (fluid and box neighbours + pair interpolation data in one sweep) -> conv0 (obstacle + fluid +
-    # dense) -> 3 x (transform GEMM, gather), the last gather with the position / velocity update fused.
-    # Neighbour rows have a fixed pitch (max_fluid_neighbors / max_box_neighbors per particle); a particle with more
-    # neighbours gets NaN outputs on the device and the next call that finds the (asynchronously copied) overflow record
-    # raises.
+    # Fused inference step, round 3: ONE C call = prepare (integrate + fluid grid, one workgroup) ->
+    # front (search of both clouds, row-entry lists, layer 0) -> three G-free continuous convolutions (gather a patch per
+    # point in LDS, contract with the filter on the fp32 matrix pipe; nothing of size n x 64 x C is materialised), the last
+    # one with the position / velocity update.  Neighbour rows keep a fixed pitch (max_fluid_neighbors / max_box_neighbors per
+    # particle, <= nf_trans_front_max_pitch()).  The reference's search has no cap, so a count above the pitch must not
+    # change results: the overflow record leaves the device right behind the front kernel (pinned memory + event, while
+    # the convolutions run), the host reads it before forward() returns, and on overflow THIS step is redone on the exact
+    # CSR path (_forward_impl) and the pitch grows for the next ones — nothing is poisoned, nothing surfaces later.
     def _fused_ok(self, pos, box):
         lib = _lib.load()
         if getattr(self, "_fused_limits", None) is None:
             mp, mc = ctypes.c_int(), ctypes.c_int()
             lib.nf_trans_prepare_limits(ctypes.byref(mp), ctypes.byref(mc))
-            self._fused_limits = (mp.value, mc.value)
+            self._fused_limits = (mp.value, mc.value, lib.nf_trans_front_max_pitch())
         n = pos.shape[0]
-        if n < 1 or n > self._fused_limits[0]:
+        if n < 1 or n > self._fused_limits[0] or self._fused_skip > 0:
+            self._fused_skip = max(self._fused_skip - 1, 0)
             return False
+        if max(int(self.max_fluid_neighbors), int(self.max_box_neighbors)) > self._fused_limits[2]:
+            return False
+        # the single-workgroup grid build holds the cell counters and the scatter list in LDS; ask the library for the
+        # cell count of THIS bbox (its header code: float32 floor + clamping) instead of re-deriving it here
         bbox = self._scene_bbox(box.detach())
-        cell = 0.5 * float(self.filter_extent)
-        cells = 1
-        for d in range(3):
-            cells *= int((bbox[3 + d] - bbox[d]) / cell) + 1
-        return cells + n <= self._fused_limits[1]        # cell counters + scatter list share one workgroup's LDS
+        key = (n, bbox)
+        if getattr(self, "_fused_fit", (None, None))[0] != key:
+            bb = (ctypes.c_float * 6)(*[float(v) for v in bbox])
+            cells = lib.nf_grid_cells(n, 0.5 * float(self.filter_extent), bb)
+            self._fused_fit = (key, cells > 0 and cells + n <= self._fused_limits[1])
+        return self._fused_fit[1]
 
     def _fused_buffers(self, n, dev, bbox):
         st = self._fused
-        key = (n, str(dev), bbox, self.max_fluid_neighbors, self.max_box_neighbors)
+        key = (n, str(dev), bbox, int(self.max_fluid_neighbors), int(self.max_box_neighbors))
         if st is not None and st["key"] == key:
             return st
         lib = _lib.load()
         radius = 0.5 * float(self.filter_extent)
         bb = (ctypes.c_float * 6)(*[float(v) for v in bbox])
         pitch_f, pitch_b = int(self.max_fluid_neighbors), int(self.max_box_neighbors)
-        cap_f, cap_b = n * pitch_f, n * pitch_b
-        f32, i32, i64, u8 = torch.float32, torch.int32, torch.int64, torch.uint8
+        f32, i32, i64, u8, i16 = torch.float32, torch.int32, torch.int64, torch.uint8, torch.int16
         E = lambda *shape, dtype=f32: torch.empty(*shape, dtype=dtype, device=dev)      # noqa: E731
-        st = dict(key=key, bb=bb, pitch=(pitch_f, pitch_b),
+        max_wg = torch.cuda.get_device_properties(dev).multi_processor_count
+        sf = ctypes.c_size_t()
+        check(lib.nf_cconv_gf_plan(n, 64, max_wg, None, None, None, ctypes.byref(sf)), "nf_cconv_gf_plan")
+        st = dict(key=key, pitch=(pitch_f, pitch_b), max_wg=max_wg,
                   grid_ws=E(lib.nf_grid_workspace_bytes(n, radius, bb), dtype=u8), pos_new=E(n, 3), vel_new=E(n, 3), feats=E(n, 4),
-                  counts2=E(2 * n, dtype=i32), overflow=torch.zeros(2, dtype=i64, device=dev),
-                  idx_f=E(cap_f, dtype=i32), d2_f=E(cap_f), pw_f=E(cap_f * 8), pc_f=E(cap_f * 8, dtype=u8),
-                  idx_b=E(cap_b, dtype=i32), d2_b=E(cap_b), pw_b=E(cap_b * 8), pc_b=E(cap_b * 8, dtype=u8),
-                  a0=E(n, 96), a1=E(n, 64), a2=E(n, 64), y3=E(n, 3), G=E(n * 65 * 64),
-                  pending=[], slots=[torch.empty(2, dtype=i64).pin_memory() for _ in range(4)], step=0)
+                  counts2=E(2 * n, dtype=i32), idx_f=E(n * pitch_f, dtype=i32), d2_f=E(n * pitch_f),
+                  roff=torch.zeros(n * 20, dtype=i16, device=dev), ent=E(n * 4 * pitch_f * 3, dtype=i32),
+                  a0=E(n, 96), a1=E(n, 64), a2=E(n, 64), y3=E(n, 3), scratch=E(sf.value),
+                  # overflow records: rows of a pre-zeroed pool, one per step in turn; a row is written by the device only when
+                  # a count exceeds its pitch (and re-zeroed by the host after it has been read), so no per-step memset
+                  ovf=torch.zeros(8, 2, dtype=i64, device=dev), ovf_host=torch.zeros(8, 2, dtype=i64).pin_memory(),
+                  events=[torch.cuda.Event() for _ in range(8)], step=0, wsig=None, packed=None)
+        for ev in st["events"]:
+            ev.record()                     # materialises the hipEvent_t handle the library records on
+        S = _lib.TransStep()
+        S.grid_ws, S.grid_ws_bytes = st["grid_ws"].data_ptr(), st["grid_ws"].numel()
+        for k in ("pos_new", "vel_new", "feats", "counts2", "idx_f", "d2_f", "roff", "ent", "a0", "a1", "a2", "y3", "scratch"):
+            setattr(S, k, st[k].data_ptr())
+        S.n, S.pitch_f, S.pitch_b, S.use_window, S.max_wg = n, pitch_f, pitch_b, int(self.use_window), max_wg
+        S.radius, S.extent, S.dt, S.scale = radius, float(self.filter_extent), float(self.time_step), 1.0 / 128
+        for d in range(6):
+            S.bbox[d] = float(bbox[d])
+        st["S"] = S
         self._fused = st
         return st
 
-    def check_capacity(self, wait=False):
-        """Raises if a particle of a finished fused step had more neighbours than its row pitch (its outputs were set to NaN
-        on the device).  wait=True blocks until every launched step has reported."""
-        st = self._fused
-        if st is None:
+    def _fused_weights(self, st, dev):
+        """Packed filters of conv1..3 (+ their Linear branches) and the pointers of layer 0 / the biases in the step struct;
+        re-packed only when a parameter's storage or in-place version changed."""
+        lib = _lib.load()
+        c0f, c0o, d0 = self.conv0_fluid, self.conv0_obstacle, self.dense0_fluid
+        tensors = [c0f.kernel, c0f.bias, c0o.kernel, c0o.bias, d0.weight, d0.bias]
+        for conv, dense in zip(self.convs, self.denses):
+            tensors += [conv.kernel, conv.bias, dense.weight, dense.bias]
+        sig = tuple((t.data_ptr(), t._version) for t in tensors) + (str(dev),)
+        if st["wsig"] == sig:
             return
-        keep = []
-        for ev, slot in st["pending"]:
-            if wait:
-                ev.synchronize()
-            if ev.query():
-                f, b = slot.tolist()
-                if f > st["pitch"][0] or b > st["pitch"][1]:
-                    st["pending"] = []
-                    st["overflow"].zero_()
-                    raise RuntimeError(f"ParticleNet fused step: a particle with {f} fluid / {b} box neighbours (0 = within "
-                                       f"bounds) exceeds the capacities {st['pitch']} per particle (its outputs are NaN); raise "
-                                       "ParticleNet.max_fluid_neighbors / max_box_neighbors")
-            else:
-                keep.append((ev, slot))
-        st["pending"] = keep
+        S = st["S"]
+        keep = [t.detach().contiguous().float() for t in tensors]
+        S.k_fluid, S.b_fluid, S.k_obst, S.b_obst, S.dense0_w, S.dense0_b = [t.data_ptr() for t in keep[:6]]
+        packed = []
+        for li, (conv, dense) in enumerate(zip(self.convs, self.denses)):
+            k, bc, w, bd = keep[6 + 4 * li:10 + 4 * li]
+            cin, cout = k.shape[-2], k.shape[-1]
+            wp = torch.empty(lib.nf_cconv_gf_packed_floats(cin, cout), dtype=torch.float32, device=dev)
+            check(lib.nf_cconv_gf_pack(ptr(k), ptr(w), cin, cout, ptr(wp), _lib.stream()), "nf_cconv_gf_pack")
+            packed.append(wp)
+            setattr(S, f"wp{li + 1}", wp.data_ptr())
+            setattr(S, f"bc{li + 1}", bc.data_ptr())
+            setattr(S, f"bd{li + 1}", bd.data_ptr())
+        st["wsig"], st["packed"], st["keep"] = sig, packed, keep
+
+    def check_capacity(self, wait=False):
+        """Kept for callers of round 2's API: the fused step now verifies its row capacities before forward() returns and
+        redoes an overflowing step on the exact path, so there is never anything pending."""
+        return None
 
     def _forward_fused(self, pos, vel, box, box_feats):
         lib = _lib.load()
-        stream = _lib.stream()
         pos = pos.detach().contiguous().float()
         vel = vel.detach().contiguous().float()
         box = box.detach().contiguous().float()
         box_feats = box_feats.detach().contiguous().float()
         n, dev = pos.shape[0], pos.device
-        extent = float(self.filter_extent)
-        radius = 0.5 * extent
-        bbox = self._scene_bbox(box)
-        st = self._fused_buffers(n, dev, bbox)
-        self.check_capacity()
-        if len(st["pending"]) >= len(st["slots"]):          # every report slot in flight: wait for the oldest
-            st["pending"][0][0].synchronize()
-            self.check_capacity()
-        pitch_f, pitch_b = st["pitch"]
+        st = self._fused_buffers(n, dev, self._scene_bbox(box))
+        self._fused_weights(st, dev)
+        S = st["S"]
         bgrid = self._box_grid(box)
-        g = (ctypes.c_float * 3)(*[float(v) for v in self._gravity_host()])
-        check(lib.nf_trans_prepare(ptr(pos), ptr(vel), g, float(self.time_step), n, radius, st["bb"], ptr(st["grid_ws"]),
-                                   st["grid_ws"].numel(), ptr(st["pos_new"]), ptr(st["vel_new"]), ptr(st["feats"]), stream),
-              "nf_trans_prepare")
-        nn = torch.empty(n, dtype=torch.float32, device=dev)
-        check(lib.nf_trans_search(ptr(st["grid_ws"]), ptr(bgrid.ws), ptr(st["pos_new"]), n, radius, extent, int(self.use_window),
-                                  pitch_f, pitch_b, ptr(st["counts2"]), ptr(nn), ptr(st["idx_f"]), ptr(st["d2_f"]), ptr(st["pw_f"]),
-                                  ptr(st["pc_f"]), ptr(st["idx_b"]), ptr(st["d2_b"]), ptr(st["pw_b"]), ptr(st["pc_b"]), stream),
-              "nf_trans_search")
-        c0o, c0f, d0 = self.conv0_obstacle, self.conv0_fluid, self.dense0_fluid
-        check(lib.nf_trans_conv0(ptr(box_feats), ptr(st["feats"]), ptr(st["counts2"]), pitch_f, pitch_b, n, ptr(st["idx_f"]),
-                                 ptr(st["pw_f"]), ptr(st["pc_f"]), ptr(st["idx_b"]), ptr(st["pw_b"]), ptr(st["pc_b"]),
-                                 ptr(c0o.kernel.detach()), ptr(c0o.bias.detach()), ptr(c0f.kernel.detach()), ptr(c0f.bias.detach()),
-                                 ptr(d0.weight.detach()), ptr(d0.bias.detach()), ptr(st["a0"]), stream), "nf_trans_conv0")
-        cnt_f, cnt_b = st["counts2"][:n], st["counts2"][n:]
-        prev = st["a0"]
-        outs = [st["a1"], st["a2"], st["y3"]]
-        pos_c, vel_c = torch.empty_like(pos), torch.empty_like(pos)
-        for li, (conv, dense) in enumerate(zip(self.convs, self.denses)):
-            cin, cout = prev.shape[1], conv.kernel.shape[-1]
-            check(lib.nf_cconv_transform(ptr(prev), n, cin, cout, 1, ptr(conv.kernel.detach()), ptr(dense.weight.detach()),
-                                         ptr(st["G"]), stream), "nf_cconv_transform")
-            y = outs[li]
-            if li < 2:
-                res = prev if dense.out_features == cin else None
-                check(lib.nf_cconv_gather(ptr(st["G"]), cout, None, pitch_f, ptr(cnt_f), ptr(st["idx_f"]), ptr(st["pw_f"]),
-                                          ptr(st["pc_f"]), ptr(conv.bias.detach()), ptr(dense.bias.detach()), ptr(res), n, ptr(y),
-                                          stream), "nf_cconv_gather")
-            else:
-                check(lib.nf_cconv_gather_update(ptr(st["G"]), pitch_f, ptr(cnt_f), ptr(st["idx_f"]), ptr(st["pw_f"]), ptr(st["pc_f"]),
-                                                 ptr(conv.bias.detach()), ptr(dense.bias.detach()), n, ptr(y), ptr(pos),
-                                                 ptr(st["pos_new"]), 1.0 / 128, float(self.time_step), pitch_b, ptr(cnt_b),
-                                                 ptr(st["overflow"]), ptr(pos_c), ptr(vel_c), stream), "nf_cconv_gather_update")
-            prev = y
-        # overflow record -> pinned host slot, checked by a later call (or check_capacity(wait=True))
-        slot = st["slots"][st["step"] % len(st["slots"])]
+        S.box_grid, S.box_feats = bgrid.ws.data_ptr(), box_feats.data_ptr()
+        g = self._gravity_host()
+        for d in range(3):
+            S.gravity[d] = float(g[d])
+        k = st["step"] % 8
         st["step"] += 1
-        slot.copy_(st["overflow"], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        st["pending"].append((ev, slot))
+        S.overflow2 = st["ovf"][k].data_ptr()
+        nn = torch.empty(n, dtype=torch.float32, device=dev)
+        pos_c, vel_c = torch.empty_like(pos), torch.empty_like(pos)
+        ev = st["events"][k]
+        check(lib.nf_trans_step(ctypes.byref(S), ptr(pos), ptr(vel), ptr(nn), ptr(pos_c), ptr(vel_c), st["ovf_host"][k].data_ptr(),
+                                ev.cuda_event, _lib.stream()), "nf_trans_step")
+        ev.synchronize()                    # the record left the device behind the front kernel: the convolutions are still running
+        of, ob = st["ovf_host"][k].tolist()
+        if of or ob:
+            return self._fused_overflow(st, k, of, ob, pos, vel, box, box_feats)
+        cnt_f = st["counts2"][:n]
         self.num_fluid_neighbors = nn
         self._y3 = st["y3"]
-        self.conv0_fluid.nns = _PitchedNeighbors(st["idx_f"], st["d2_f"], cnt_f, pitch_f)
+        self.conv0_fluid.nns = _PitchedNeighbors(st["idx_f"], st["d2_f"], cnt_f, st["pitch"][0])
         return pos_c, vel_c, nn
 
-    # ------------------------------------------------------------------
-    # HIP-graph replay of the inference step.  The step is launch-bound (about 45 launches for 0.4 ms of GPU work at
-    # 5 k particles) and its only data-dependent size is the pair count; with the CSR sized by a capacity
-    # (max_neighbors per particle) there is no host round trip left, so the whole step is captured once per
-    # (particle count, container) and replayed.  An overflow of the capacity cannot pass silently: the outputs are
-    # poisoned with NaN inside the graph and the host raises at its next periodic check.
-    def enable_step_graph(self, max_fluid_neighbors=128, max_box_neighbors=64, check_every=32):
-        self._graph_cfg = dict(f=int(max_fluid_neighbors), b=int(max_box_neighbors), every=int(check_every))
-        self._graph = None
-        return self
+    def _fused_overflow(self, st, k, of, ob, pos, vel, box, box_feats):
+        """A particle had more neighbours than its row pitch: redo THIS step on the exact CSR path (same results as the
+        reference's uncapped search) and let the pitch grow for the following steps (up to what the front kernel stages;
+        beyond that the exact path serves the next steps and the fused one is retried later)."""
+        st["ovf"][k].zero_()
+        self.fused_overflows = getattr(self, "fused_overflows", 0) + 1
+        cap = self._fused_limits[2]
+        if self.fused_grow_pitch:
+            if of:
+                self.max_fluid_neighbors = min(cap, max(int(self.max_fluid_neighbors), of + of // 4 + 8))
+            if ob:
+                self.max_box_neighbors = min(cap, max(int(self.max_box_neighbors), ob + ob // 4 + 8))
+        if of > cap or ob > cap:
+            self._fused_skip = 16           # a clump denser than the front kernel stages: exact path for a while
+        return self._forward_impl(pos, vel, box, box_feats)[:3]
 
-    def disable_step_graph(self):
-        self._graph_cfg, self._graph = None, None
-        return self
-
-    def _graph_step(self, pos, vel, box, box_feats):
-        cfg = self._graph_cfg
-        n = pos.shape[0]
-        key = (n, box.data_ptr(), box._version, box_feats.data_ptr(), str(pos.device))
-        if self._graph is None or self._graph["key"] != key:
-            sp, sv = pos.detach().clone().float().contiguous(), vel.detach().clone().float().contiguous()
-            cap = (n * cfg["f"], n * cfg["b"])
-
-            def body():
-                pc, vc, nn, _ = self._forward_impl(sp, sv, box, box_feats, nnz_cap=cap)
-                ok = (self._nnz_seen[0] <= cap[0]) & (self._nnz_seen[1] <= cap[1])
-                nan = torch.full((), float("nan"), device=pc.device)
-                return torch.where(ok, pc, nan), torch.where(ok, vc, nan), nn, self._nnz_seen
-
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):          # warm-up off the capture (caches: box grid, scene bbox, gravity)
-                for _ in range(2):
-                    body()
-            torch.cuda.current_stream().wait_stream(side)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                outs = body()
-            self._graph = dict(key=key, g=g, sp=sp, sv=sv, outs=outs, cap=cap, count=0, refs=(box, box_feats))
-        G = self._graph
-        G["sp"].copy_(pos)
-        G["sv"].copy_(vel)
-        G["g"].replay()
-        pc, vc, nn, seen = G["outs"]
-        G["count"] += 1
-        if G["count"] % cfg["every"] == 0:
-            f, b = seen.tolist()
-            if f > G["cap"][0] or b > G["cap"][1]:
-                raise RuntimeError(f"ParticleNet step graph: {f} fluid / {b} box pairs exceed the capacity {G['cap']}; "
-                                   "raise max_fluid_neighbors / max_box_neighbors in enable_step_graph()")
-        self.num_fluid_neighbors = nn
-        return pc.clone(), vc.clone(), nn.clone()
-
-    def _forward_impl(self, pos, vel, box, box_feats, keep=False, nnz_cap=None):
-        """nnz_cap = (fluid, box) pair capacities: no host sync (the CSR buffers are sized by the caller's bound
-        instead of the exact count) — the form that can be captured in a HIP graph."""
+    def _forward_impl(self, pos, vel, box, box_feats, keep=False):
+        """The exact multi-launch path (CSR neighbour lists sized by one host round trip): training (keep=True saves what the
+        backward needs), clouds beyond the fused step's limits, and the redo of a fused step whose row pitch overflowed."""
         lib = _lib.load()
         st = _lib.stream()
         pos = pos.detach().contiguous().float()
@@ -427,15 +389,9 @@ class ParticleNet(nn.Module):
         bgrid = self._box_grid(box)
         f_rs = ops.radius_row_splits(fgrid, pos_new, radius, True)
         b_rs = ops.radius_row_splits(bgrid, pos_new, radius, True)
-        if nnz_cap is None:
-            nnz_f, nnz_b = torch.stack([f_rs[-1], b_rs[-1]]).tolist()
-        else:
-            nnz_f, nnz_b = int(nnz_cap[0]), int(nnz_cap[1])
-            self._nnz_seen = torch.stack([f_rs[-1], b_rs[-1]])
+        nnz_f, nnz_b = torch.stack([f_rs[-1], b_rs[-1]]).tolist()
         f_idx, f_d2 = ops.radius_fill(fgrid, pos_new, radius, f_rs, nnz_f, True)
         b_idx, b_d2 = ops.radius_fill(bgrid, pos_new, radius, b_rs, nnz_b, True)
-        if nnz_cap is not None:      # consumers index the pair arrays through row_splits: never past the capacity
-            f_rs, b_rs = f_rs.clamp(max=nnz_f), b_rs.clamp(max=nnz_b)
         f_pw, f_pc = cconv_pairs(pos_new, pos_new, f_rs, f_idx, f_d2, extent, self.use_window)
         b_pw, b_pc = cconv_pairs(box, pos_new, b_rs, b_idx, b_d2, extent, self.use_window)
         self.conv0_fluid.nns = SimpleNamespace(neighbors_index=f_idx[:nnz_f], neighbors_row_splits=f_rs,

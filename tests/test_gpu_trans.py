@@ -169,38 +169,6 @@ def test_fluid_errors_vs_kdtree(dev):
     assert fe.cal_errors(bad, torch.zeros(4, 3, device=dev), 0) is None and fe.errors == {}
 
 
-def test_step_graph_replay(dev):
-    """HIP-graph replay of the inference step: same bits as the eager step over a rollout (the captured kernels are
-    the same, only the CSR buffers are sized by a capacity); capacity overflow poisons the outputs and raises."""
-    from oracle import trans_oracle as to
-    pn, _ = make_pn(dev)
-    pn2, _ = make_pn(dev)
-    pn2.enable_step_graph()
-    box, bn = [t.to(dev) for t in to.watercube_box()]
-    from oracle import render_oracle as ro
-    p = ro.watercube_particles().to(dev)
-    v = torch.zeros_like(p)
-    pa, va, pb, vb = p, v, p, v
-    with torch.no_grad():
-        for it in range(12):
-            pa, va, na = pn(pa, va, box, bn)
-            pb, vb, nb = pn2(pb, vb, box, bn)
-            assert torch.equal(pa, pb) and torch.equal(va, vb) and torch.equal(na, nb), it
-    # a different particle count re-captures
-    with torch.no_grad():
-        q, w, _ = pn2(p[:1000].contiguous(), v[:1000].contiguous(), box, bn)
-        q0, w0, _ = pn(p[:1000].contiguous(), v[:1000].contiguous(), box, bn)
-    assert torch.equal(q, q0) and torch.equal(w, w0)
-    # capacity overflow: NaN outputs, RuntimeError at the periodic check
-    pn3, _ = make_pn(dev)
-    pn3.enable_step_graph(max_fluid_neighbors=8, check_every=2)
-    with torch.no_grad():
-        a, b, _ = pn3(p, v, box, bn)
-        assert bool(torch.isnan(a).all())
-        with pytest.raises(RuntimeError, match="exceed the capacity"):
-            pn3(p, v, box, bn)
-
-
 # ------------------------------------------------------------------------------------------------
 # round 2
 # ------------------------------------------------------------------------------------------------
@@ -353,11 +321,89 @@ def test_rollout_200_frames_honeycone(dev):
     assert max(stepped) <= 1e-6, max(stepped)
 
 
-def test_fused_inference_step_bit_equal(dev):
-    """The fused inference step (nf_trans.hip: prepare / search+pairs / conv0 in 3 launches, update fused into the last
-    gather, neighbour rows of a fixed pitch, no host round trip) must reproduce the multi-launch path BIT FOR BIT over a
-    rollout (same kernels' arithmetic, same neighbour order), for the lattice cloud and a shuffled shaped one; a particle
-    with more neighbours than the pitch gets NaN outputs and the next report raises."""
+def test_gfree_conv_layer_vs_oracle_and_transform_gather(dev):
+    """B4/B5 through the G-free kernels of the inference step (nf_trans_front row-entry lists + nf_cconv_gf_layer: patch in
+    LDS, contraction on the fp32 matrix pipe, stream-K partial slabs + epilogue) for the three layer shapes of
+    models/transmodel.py:121-131 (96 -> 64, 64 -> 64 with residual, 64 -> 3), on the lattice cloud, a shuffled shaped cloud and
+    particle counts around the tile size: against the oracle's cconv + Linear (1e-4 / 2e-5, the bar of
+    test_continuous_conv_layer) and against the training path's transform + gather kernels (same inputs; only the
+    summation order differs)."""
+    import ctypes
+    from neurofluid_amd import _lib, ops, synthetic
+    from neurofluid_amd._lib import check, ptr
+    from neurofluid_amd.transmodel import cconv_pairs, cconv_layer
+    from oracle import trans_oracle as to
+    lib = _lib.load()
+    extent = to.FILTER_EXTENT
+    radius = 0.5 * extent
+    g = torch.Generator().manual_seed(5)
+    box, bn = to.watercube_box()
+    max_wg = torch.cuda.get_device_properties(dev).multi_processor_count
+    for P in (synthetic.watercube_particles(), synthetic.shaped_particles("bunny", order="random")[:1000].contiguous(),
+              synthetic.watercube_particles()[:33].contiguous(), synthetic.watercube_particles()[:1].contiguous()):
+        n = P.shape[0]
+        Pd = P.to(dev)
+        pitch_f, pitch_b = 128, 64
+        bbox = tuple((box.min(0).values - 0.5).tolist()) + tuple((box.max(0).values + 0.5).tolist())
+        fgrid = ops.build_grid(Pd, radius, bbox, firstk=False)
+        bgrid = ops.build_grid(box.to(dev), radius, firstk=False)
+        feats4 = torch.cat([torch.ones(n, 1), torch.randn(n, 3, generator=g)], 1).to(dev)
+        k0f, k0o = torch.randn(4, 4, 4, 4, 32, generator=g) * 0.1, torch.randn(4, 4, 4, 3, 32, generator=g) * 0.1
+        b0f, b0o, wd0, bd0 = torch.randn(32, generator=g), torch.randn(32, generator=g), torch.randn(32, 4, generator=g), torch.randn(32, generator=g)
+        i32, f32 = torch.int32, torch.float32
+        counts2 = torch.empty(2 * n, dtype=i32, device=dev)
+        nn = torch.empty(n, device=dev)
+        idx_f, d2_f = torch.empty(n * pitch_f, dtype=i32, device=dev), torch.empty(n * pitch_f, device=dev)
+        roff = torch.zeros(n * 20, dtype=torch.int16, device=dev)
+        ent = torch.empty(n * 4 * pitch_f * 3, dtype=i32, device=dev)
+        a0 = torch.empty(n, 96, device=dev)
+        ovf = torch.zeros(2, dtype=torch.int64, device=dev)
+        dv = lambda t: t.to(dev).contiguous()          # noqa: E731
+        bnd = dv(bn)
+        args0 = [dv(k0f), dv(b0f), dv(k0o), dv(b0o), dv(wd0), dv(bd0)]
+        check(lib.nf_trans_front(ptr(fgrid.ws), ptr(bgrid.ws), ptr(Pd), ptr(feats4), ptr(bnd), n, radius, extent, 1, pitch_f, pitch_b,
+                                 ptr(counts2), ptr(nn), ptr(idx_f), ptr(d2_f), ptr(roff), ptr(ent), *[ptr(t) for t in args0], ptr(a0),
+                                 ptr(ovf), _lib.stream()), "nf_trans_front")
+        assert ovf.tolist() == [0, 0]
+        # ---- the search and layer 0 against the oracle
+        f_idx, f_rs, f_d2 = to.radius_search(P, P, radius, True)
+        b_idx, b_rs, b_d2 = to.radius_search(box, P, radius, True)
+        assert torch.equal(counts2[:n].cpu().long(), f_rs[1:] - f_rs[:-1]) and torch.equal(counts2[n:].cpu().long(), b_rs[1:] - b_rs[:-1])
+        ro = roff.view(n, 20).cpu().long() & 0xffff
+        assert torch.equal(ro[:, 16], 4 * (f_rs[1:] - f_rs[:-1]))            # four row entries per pair
+        ref0 = torch.cat([to.cconv(bn, box, P, extent, k0o, b0o, b_idx, b_rs, b_d2),
+                          to.cconv(feats4.cpu(), P, P, extent, k0f, b0f, f_idx, f_rs, f_d2),
+                          torch.nn.functional.linear(feats4.cpu(), wd0, bd0)], 1)
+        torch.testing.assert_close(a0.cpu(), ref0, rtol=1e-4, atol=2e-5)
+        # ---- the three layer shapes
+        rsd, idxd, d2d = f_rs.to(dev), f_idx.to(dev), f_d2.to(dev)
+        pw, pc = cconv_pairs(Pd, Pd, rsd, idxd, d2d, extent, True)
+        for cin, cout, res in ((96, 64, False), (64, 64, True), (64, 3, False)):
+            x = torch.randn(n, cin, generator=g)
+            K = torch.randn(4, 4, 4, cin, cout, generator=g) * 0.1
+            bc, W, bd = torch.randn(cout, generator=g), torch.randn(cout, cin, generator=g) * 0.1, torch.randn(cout, generator=g)
+            xd, Kd, bcd, Wd, bdd = dv(x), dv(K), dv(bc), dv(W), dv(bd)
+            wp = torch.empty(lib.nf_cconv_gf_packed_floats(cin, cout), device=dev)
+            check(lib.nf_cconv_gf_pack(ptr(Kd), ptr(Wd), cin, cout, ptr(wp), _lib.stream()), "pack")
+            sf = ctypes.c_size_t()
+            check(lib.nf_cconv_gf_plan(n, cout, max_wg, None, None, None, ctypes.byref(sf)), "plan")
+            scratch = torch.full((sf.value,), float("nan"), device=dev)          # every slab that is read must have been written
+            y = torch.empty(n, cout, device=dev)
+            check(lib.nf_cconv_gf_layer(ptr(xd), n, cin, cout, 1, ptr(roff), ptr(ent), pitch_f, ptr(wp), ptr(bcd), ptr(bdd),
+                                        ptr(xd) if res else None, ptr(y), ptr(scratch), max_wg, None, None, 0.0, 0.0, None, None,
+                                        _lib.stream()), "nf_cconv_gf_layer")
+            xr = torch.relu(x)
+            ref = to.cconv(xr, P, P, extent, K, bc, f_idx, f_rs, f_d2) + torch.nn.functional.linear(xr, W, bd) + (x if res else 0)
+            torch.testing.assert_close(y.cpu(), ref, rtol=1e-4, atol=2e-5)
+            old = cconv_layer(xd, Kd, bcd, Wd, bdd, rsd, idxd, pw, pc, relu=True, residual=xd if res else None)
+            torch.testing.assert_close(y, old, rtol=1e-4, atol=2e-5)
+
+
+def test_fused_inference_step_vs_multi_launch_path(dev):
+    """The fused inference step (one C call: prepare -> front -> three G-free layers) against the
+    multi-launch training-path kernels over a rollout.  Integer results (neighbour counts, the CSR view of conv.nns) are
+    exact; positions / velocities differ by the summation order of the contractions only: <= 2e-7 per step on positions of
+    O(1) (observed ~3e-8; the rollout tests above hold the 1e-4 bar against the oracle over 50-200 frames)."""
     from neurofluid_amd import synthetic
     from oracle import trans_oracle as to
     box, bn = [t.to(dev) for t in to.watercube_box()]
@@ -366,27 +412,51 @@ def test_fused_inference_step_bit_equal(dev):
         pa, _ = make_pn(dev)
         pb, _ = make_pn(dev)
         pb.fused_inference = False
-        p1 = p2 = P.to(dev)
-        v1 = v2 = torch.zeros_like(p1)
+        p1 = P.to(dev)
+        v1 = torch.zeros_like(p1)
         with torch.no_grad():
             for it in range(6):
-                p1, v1, n1 = pa(p1, v1, box, bn)
-                p2, v2, n2 = pb(p2, v2, box, bn)
-                assert torch.equal(p1, p2) and torch.equal(v1, v2) and torch.equal(n1, n2), it
-        assert pa._fused is not None and pb._fused is None
-        pa.check_capacity(wait=True)
+                p2, v2, n2 = pb(p1, v1, box, bn)            # both paths step from the SAME state
+                p1n, v1n, n1 = pa(p1, v1, box, bn)
+                assert torch.equal(n1, n2), it
+                assert float((p1n - p2).abs().max()) <= 2e-7 and float((v1n - v2).abs().max()) <= 2e-5, it
+                p1, v1 = p1n, v1n
+        assert pa._fused is not None and pb._fused is None and getattr(pa, "fused_overflows", 0) == 0
         rs = pa.conv0_fluid.nns.neighbors_row_splits
         assert torch.equal(rs, pb.conv0_fluid.nns.neighbors_row_splits)
         nnz = int(rs[-1])
         assert torch.equal(pa.conv0_fluid.nns.neighbors_index[:nnz], pb.conv0_fluid.nns.neighbors_index[:nnz])
-    pc, _ = make_pn(dev)
-    pc.max_fluid_neighbors = 8
+        assert torch.equal(pa.pos_correction, pa._y3 / 128)
+
+
+def test_fused_step_overflow_is_redone_exactly(dev):
+    """A particle with more neighbours than its row pitch must not change results (the reference's search has no cap): the
+    step is redone on the exact CSR path before forward() returns — BIT-equal to the unfused path — and the pitch grows so that
+    the following steps run fused again.  With growth switched off every step is redone (still bit-equal, never NaN)."""
+    from neurofluid_amd import synthetic
+    from oracle import trans_oracle as to
+    box, bn = [t.to(dev) for t in to.watercube_box()]
     P = synthetic.watercube_particles().to(dev)
-    with torch.no_grad():
-        a, b, _ = pc(P, torch.zeros_like(P), box, bn)
-    assert bool(torch.isnan(a).all()) and bool(torch.isnan(b).all())
-    with pytest.raises(RuntimeError, match="exceeds the capacities"):
-        pc.check_capacity(wait=True)
+    ref, _ = make_pn(dev)
+    ref.fused_inference = False
+    for grow in (True, False):
+        pc, _ = make_pn(dev)
+        pc.max_fluid_neighbors, pc.max_box_neighbors, pc.fused_grow_pitch = 8, 4, grow
+        p, v = P, torch.zeros_like(P)
+        with torch.no_grad():
+            for it in range(4):
+                pr, vr, nr = ref(p, v, box, bn)
+                pf, vf, nf = pc(p, v, box, bn)              # both step from the same state
+                assert not bool(torch.isnan(pf).any())
+                if it == 0 or not grow:                     # redone on the exact path: the unfused path's bits
+                    assert torch.equal(pf, pr) and torch.equal(vf, vr) and torch.equal(nf, nr), (grow, it)
+                else:                                       # pitch grown: fused again
+                    assert torch.equal(nf, nr) and float((pf - pr).abs().max()) <= 2e-7
+                p, v = pr, vr
+        if grow:
+            assert pc.fused_overflows == 1 and pc.max_fluid_neighbors > 40 and pc.max_box_neighbors > 4
+        else:
+            assert pc.fused_overflows == 4 and pc.max_fluid_neighbors == 8
 
 
 # ------------------------------------------------------------------------------------------------

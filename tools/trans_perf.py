@@ -13,8 +13,8 @@ pn = pn.to(dev)
 P0 = scene["P"].to(dev)
 box, bn = scene["box"].to(dev), scene["bn"].to(dev)
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
-if len(sys.argv) > 2 and sys.argv[2] == "graph":
-    pn.enable_step_graph()
+if len(sys.argv) > 2 and sys.argv[2] == "unfused":
+    pn.fused_inference = False
 for it in range(3):
     pos, vel = P0.clone(), torch.zeros_like(P0)
     torch.cuda.synchronize(); t = time.time()

@@ -369,42 +369,57 @@ int nf_image_ssim(const float* pred, const float* gt, int B, int C, int H, int W
  *                      dense0_fluid, :116-120).  Row entry = {j | cx << 30, w(cx), w(cx + 1)} of a pair in filter row
  *                      (cz + dz) * 4 + (cy + dy); entries[i][roff[i][rho] .. roff[i][rho + 1]) (roff: 20 uint16 per particle).
  *                      Rows keep a pitch (<= nf_trans_front_max_pitch()); overflow2[w] = largest count above its pitch.
- *   nf_cconv_gf_layer  y = cconv(act(x)) + Linear(act(x)) + biases (+ residual) for Cin in {96, 64}, Cout <= 64 (:121-131),
+ *   nf_cconv_gf_layer  y = cconv(act(x)) + Linear(act(x)) + biases (+ residual) for Cin in {96, 64}, Cout <= 64 (:121-131)
+ *                      (relu = 0 when x already holds the activated values, as inside nf_trans_step),
  *                      optionally followed by pos_correction / update_pos_vel (:141-148).  packed = nf_cconv_gf_pack(kernel
  *                      (4,4,4,Cin,Cout), dense_w (Cout,Cin)); scratch = nf_cconv_gf_plan(...) floats; max_wg = CUs.
- *   nf_trans_step      prepare + front + three layers behind one call; optionally copies overflow2 to pinned host memory
- *                      right behind the front kernel and records `event` (hipEvent_t) there. */
+ *   nf_trans_step      prepare + front + three layers behind one call; the front kernel reports through the pinned words
+ *                      host_flag3 (overflow, completion) while the layers are still running. */
 int nf_trans_front_max_pitch(void);
 int nf_trans_front(const void* fluid_grid, const void* box_grid, const float* queries, const float* fluid_feats,
                    const float* box_feats, int n, float radius, float extent, int use_window, int pitch_fluid,
                    int pitch_box, int32_t* counts2, float* num_fluid_nbrs, int32_t* idx_f, float* d2_f, uint16_t* roff,
                    uint32_t* entries, const float* kernel_fluid, const float* bias_fluid, const float* kernel_obstacle,
                    const float* bias_obstacle, const float* dense_w, const float* dense_b, float* out96,
-                   int64_t* overflow2, nf_stream_t stream);
+                   int relu_out /* store max(a0, 0): what conv1 reads (models/transmodel.py:124) */, int64_t* overflow2,
+                   int32_t* host_flag3 /* or NULL: device address (nf_pinned_device_ptr) of three pinned host words: [0], [1] are
+                                         written with an overflowing count ONLY when a row overflows; [2] = step_id once the
+                                         LAST workgroup has finished (the host spins on it: a HIP event recorded in the middle
+                                         of a batch of launches completes with the batch, not behind this kernel) */,
+                   uint32_t* done_counter /* device word, zero between launches */, int step_id, nf_stream_t stream);
+void* nf_pinned_device_ptr(void* host_ptr /*[host] page-locked*/);
 size_t nf_cconv_gf_packed_floats(int cin, int cout);
 int nf_cconv_gf_pack(const float* kernel, const float* dense_w, int cin, int cout, float* packed, nf_stream_t stream);
 int nf_cconv_gf_plan(int n, int cout, int max_wg, int* tiles, int* nwg, int* maxseg, size_t* scratch_floats);
 int nf_cconv_gf_layer(const float* x, int n, int cin, int cout, int relu, const uint16_t* roff, const uint32_t* entries,
                       int pitch, const float* packed, const float* bias_conv, const float* bias_dense,
-                      const float* residual, float* out, float* scratch, int max_wg, const float* pos,
+                      const float* residual, float* out /*or NULL*/, float* out_relu /*max(y, 0), or NULL*/, float* scratch,
+                      int max_wg, const float* pos,
                       const float* pos_new, float scale, float dt, float* pos_c, float* vel_c, nf_stream_t stream);
+/* The 3-channel last layer (conv3 + dense3, :121-131 at i = 3, and the update of :141-148): transform (G3[j][node][co], 780 bytes
+ * per particle) then gather over the row entries.  x_act = relu(a2) (n x 64); workspace = nf_cconv3_workspace_floats(n). */
+size_t nf_cconv3_workspace_floats(int n);
+int nf_cconv3_layer(const float* x_act, int n, const uint16_t* roff, const uint32_t* entries, int pitch, const float* kernel,
+                    const float* dense_w, const float* bias_conv, const float* bias_dense, float* workspace, float* y3,
+                    const float* pos /*or NULL: no update*/, const float* pos_new, float scale, float dt, float* pos_c,
+                    float* vel_c, nf_stream_t stream);
 typedef struct {
     /* model (device pointers; wpK = nf_cconv_gf_pack of convK / denseK) */
     const float *k_fluid, *b_fluid, *k_obst, *b_obst, *dense0_w, *dense0_b;
-    const float *wp1, *bc1, *bd1, *wp2, *bc2, *bd2, *wp3, *bc3, *bd3;
+    const float *wp1, *bc1, *bd1, *wp2, *bc2, *bd2, *k3 /*conv3.kernel*/, *w3 /*dense3.weight*/, *bc3, *bd3;
     /* scene */
     const void* box_grid; const float* box_feats;
     /* workspace of one particle count */
     void* grid_ws; size_t grid_ws_bytes;
     float *pos_new, *vel_new, *feats; int32_t* counts2; int32_t* idx_f; float* d2_f; uint16_t* roff; uint32_t* ent;
-    float *a0, *a1, *a2, *y3, *scratch; int64_t* overflow2;
+    float *a0 /*relu(layer 0)*/, *a1, *a1r /*relu(a1)*/, *a2 /*relu(layer 2)*/, *y3, *scratch; int64_t* overflow2;
+    uint32_t* done_counter;
     int n, pitch_f, pitch_b, use_window, max_wg;
     float radius, extent, dt, scale;
     float gravity[3]; float bbox[6];
 } nf_trans_step_t;
 int nf_trans_step(const nf_trans_step_t* s /*[host]*/, const float* pos, const float* vel, float* num_fluid_nbrs, float* pos_c,
-                  float* vel_c, int64_t* host_overflow2 /*[pinned host] or NULL*/, void* event /*hipEvent_t or NULL*/,
-                  nf_stream_t stream);
+                  float* vel_c, int32_t* host_flag3 /* see nf_trans_front */, int step_id, nf_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -22,14 +22,17 @@
 //     leaves one partial accumulator slab per (workgroup, K-quarter); a small epilogue launch adds them up in a fixed order
 //     (deterministic) with the biases, the residual and — for the last layer — the position / velocity update.
 #include "nf_common.h"
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define GF_TILE 32
 #define GF_UNITS 17            // 16 rows of 4 filter nodes + the Linear branch
 #define GF_COST 65             // filter nodes per tile, Linear branch included
 #define GF_THREADS 512
 #define GF_ROFF_PITCH 20       // uint16 per particle (17 used)
+#define GF_SLOTS 4             // entry slots per producer thread: 8 threads x 4 = 32 entries of a (point, row) list prefetched
 
 struct GfArgs {
     const float* x;            // (n x CIN) features of the previous layer (ReLU applied on load when relu)
@@ -56,7 +59,7 @@ __device__ __host__ __forceinline__ int gf_owner(long long cost, int nwg, int ct
 template <int K>
 __device__ __forceinline__ int gf_bcast8(int v) { return __builtin_amdgcn_ds_swizzle(v, 0x18 | (K << 5)); }
 
-template <int CIN, int NB>
+template <int CIN, int NB, bool RELU>
 __global__ void __launch_bounds__(GF_THREADS) k_cconv_gf(GfArgs A)
 {
     constexpr int PITCH = CIN + 4;             // floats per Z row: (CIN + 4) / 4 odd -> ds_read_b128 of 16 rows conflict-free
@@ -67,10 +70,19 @@ __global__ void __launch_bounds__(GF_THREADS) k_cconv_gf(GfArgs A)
     constexpr int COUTP = 32 * NB;
     extern __shared__ float Z[];               // 2 * ZB floats
 
+    // the arguments as plain locals (a by-value struct whose address reaches a lambda is kept — and re-read — in scratch memory)
+    const float* const a_x = A.x;
+    const int a_n = A.n, a_pitch = A.pitch, a_nwg = A.nwg, a_maxseg = A.maxseg, a_ctot = A.ctot;
+    const uint16_t* const a_roff = A.roff;
+    const uint32_t* const a_ent = A.ent;
+    const float* const a_wp = A.wp;
+    float* const a_scratch = A.scratch;
     const int w = blockIdx.x;
-    const int g0 = gf_begin(w, A.nwg, A.ctot), g1 = gf_begin(w + 1, A.nwg, A.ctot);
+    const int g0 = gf_begin(w, a_nwg, a_ctot), g1 = gf_begin(w + 1, a_nwg, a_ctot);
     const int nun = g1 - g0;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // the role is a SCALAR (wave-uniform) value: the two halves below are separate scalar branches, each wave meets exactly
+    // the s_barriers of its own half
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
 
     if (wave < 4) {
         // ------------------------------------------------------------------ consumers
@@ -80,40 +92,74 @@ __global__ void __launch_bounds__(GF_THREADS) k_cconv_gf(GfArgs A)
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
-        const float4* wp4 = (const float4*)A.wp;
+        const float4* wp4 = (const float4*)a_wp;
+        // B operands (filter, from L2) run one filter node AHEAD of the MFMAs along the workgroup's whole unit sequence —
+        // also across the s_barrier of a unit boundary (the filter does not depend on it; only the A operands from LDS do).
+        // Two operand buffers in STATIC ping-pong (the parity is a template argument): copying a prefetched register into
+        // the "current" one would wait for the load it was meant to hide.
+        float4 Bf[2][QW][NB], Af[2][QW];
+        auto load_b = [&](int node, float4 (&b)[QW][NB]) {
+#pragma unroll
+            for (int gq = 0; gq < QW; ++gq)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                    b[gq][nb] = wp4[((size_t)(node * (CIN / 8) + kq * QW + gq) * NB + nb) * 64 + lane];
+        };
+        auto load_a = [&](const float* Zc, float4 (&a)[QW]) {
+#pragma unroll
+            for (int gq = 0; gq < QW; ++gq) a[gq] = *(const float4*)(Zc + 8 * (kq * QW + gq));
+        };
+        auto mma = [&](const float4 (&a)[QW], const float4 (&b)[QW][NB]) {
+#pragma unroll
+            for (int gq = 0; gq < QW; ++gq) {
+                const float av[4] = {a[gq].x, a[gq].y, a[gq].z, a[gq].w};
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const float bv = s == 0 ? b[gq][nb].x : (s == 1 ? b[gq][nb].y : (s == 2 ? b[gq][nb].z : b[gq][nb].w));
+                        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv, acc[nb], 0, 0, 0);
+                    }
+            }
+        };
+        auto first_node = [&](int g) __attribute__((always_inline)) { const int u = g % GF_UNITS; return u < 16 ? 4 * u : 64; };
+        // a unit of NC nodes whose first B operand sits in buffer P0; next_node = first node of the following unit (-1: none)
+        auto run_unit = [&](auto par, auto ncells, const float* Zb, int cell0, int next_node) __attribute__((always_inline)) {
+            constexpr int P0 = decltype(par)::value, NC = decltype(ncells)::value;
+            load_a(Zb, Af[P0]);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                constexpr int dummy = 0; (void)dummy;
+                const int cur = (P0 + c) & 1, nx = cur ^ 1;
+                const int nxt = c + 1 < NC ? cell0 + c + 1 : next_node;
+                if (c + 1 < NC) load_a(Zb + (c + 1) * ZC, Af[nx]);
+                if (nxt >= 0) load_b(nxt, Bf[nx]);
+#ifndef GF_AB_NO_MFMA
+                mma(Af[cur], Bf[cur]);
+#endif
+            }
+        };
+        int parity = 0;
+        if (nun > 0) load_b(first_node(g0), Bf[0]);
         for (int p = 0; p <= nun; ++p) {
             if (p >= 1) {
                 const int g = g0 + p - 1, tile = g / GF_UNITS, u = g - tile * GF_UNITS;
-                const int ncell = u < 16 ? 4 : 1, cell0 = u < 16 ? 4 * u : 64;
                 const float* Zb = Z + ((p - 1) & 1) * ZB + m * PITCH + 4 * h;
-                for (int c = 0; c < ncell; ++c) {
-                    float4 a[QW], b[QW][NB];
-#pragma unroll
-                    for (int gq = 0; gq < QW; ++gq) {
-                        const int q = kq * QW + gq;
-                        a[gq] = *(const float4*)(Zb + c * ZC + 8 * q);
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb)
-                            b[gq][nb] = wp4[((size_t)((cell0 + c) * (CIN / 8) + q) * NB + nb) * 64 + lane];
-                    }
-#pragma unroll
-                    for (int gq = 0; gq < QW; ++gq) {
-                        const float av[4] = {a[gq].x, a[gq].y, a[gq].z, a[gq].w};
-#pragma unroll
-                        for (int s = 0; s < 4; ++s)
-#pragma unroll
-                            for (int nb = 0; nb < NB; ++nb) {
-                                const float bv = s == 0 ? b[gq][nb].x : (s == 1 ? b[gq][nb].y : (s == 2 ? b[gq][nb].z : b[gq][nb].w));
-                                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv, acc[nb], 0, 0, 0);
-                            }
-                    }
+                const int next_node = p < nun ? first_node(g + 1) : -1;
+                if (u < 16) {
+                    if (parity == 0) run_unit(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{}, Zb, 4 * u, next_node);
+                    else run_unit(std::integral_constant<int, 1>{}, std::integral_constant<int, 4>{}, Zb, 4 * u, next_node);
+                } else {
+                    if (parity == 0) run_unit(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, Zb, 64, next_node);
+                    else run_unit(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, Zb, 64, next_node);
+                    parity ^= 1;
                 }
                 const bool last_of_tile = (p == nun) || ((g + 1) / GF_UNITS != tile);
                 if (last_of_tile) {
                     // partial slab of (tile, this workgroup's segment, K-quarter): [col][row]; a lane's 4 consecutive
                     // accumulator registers are 4 consecutive rows of one column -> 16-byte stores
-                    const int seg = w - gf_owner((long long)tile * GF_COST, A.nwg, A.ctot);
-                    float* slab = A.scratch + ((size_t)(tile * A.maxseg + seg) * 4 + kq) * (COUTP * GF_TILE);
+                    const int seg = w - gf_owner((long long)tile * GF_COST, a_nwg, a_ctot);
+                    float* slab = a_scratch + ((size_t)(tile * a_maxseg + seg) * 4 + kq) * (COUTP * GF_TILE);
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -133,38 +179,45 @@ __global__ void __launch_bounds__(GF_THREADS) k_cconv_gf(GfArgs A)
     }
 
     // ---------------------------------------------------------------------- producers
-    const int pt = threadIdx.x - 256, pp = pt >> 3, t = pt & 7;
-    struct Ent { int jc[3]; float w0[3], w1[3]; int e0, cnt; };
-    auto load_roff = [&](int g, int& e0, int& e1) {
+    const int pt = threadIdx.x - 256, pp = pt >> 3, t = pt & 7;          // (lane = threadIdx.x & 63 as for the consumers)
+    auto load_roff = [&](int g, int& e0, int& e1) __attribute__((always_inline)) {
         const int tile = g / GF_UNITS, u = g - tile * GF_UNITS, i = tile * GF_TILE + pp;
         e0 = e1 = 0;
-        if (u < 16 && i < A.n) {
-            const uint16_t* r = A.roff + (size_t)i * GF_ROFF_PITCH + u;
+        if (u < 16 && i < a_n) {
+            const uint16_t* r = a_roff + (size_t)i * GF_ROFF_PITCH + u;
             e0 = r[0]; e1 = r[1];
         }
     };
-    auto load_entries = [&](int g, int e0, int e1, Ent& E) {
-        const int tile = g / GF_UNITS, i = min(tile * GF_TILE + pp, A.n - 1);
-        const uint32_t* eb = A.ent + (size_t)i * (size_t)(4 * A.pitch) * 3;
-        E.e0 = e0; E.cnt = e1 - e0;
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            const int e = 8 * s + t;
-            E.jc[s] = 0; E.w0[s] = 0.f; E.w1[s] = 0.f;
-            if (e < E.cnt) {
-                const uint32_t* src = eb + 3 * (size_t)(e0 + e);
-                E.jc[s] = (int)src[0]; E.w0[s] = __uint_as_float(src[1]); E.w1[s] = __uint_as_float(src[2]);
-            }
+    // (plain scalars, not a struct: a struct that is copied and captured by reference stays in scratch memory)
+    // (nine separate scalars per unit, not arrays: the slot of an entry is picked at run time, and an array that is indexed —
+    // or selected from, which the optimiser turns back into indexing — at run time lives in scratch memory)
+    auto load_one = [&](const uint32_t* eb, int e0, int cnt_, int e, int& jc, float& w0, float& w1) __attribute__((always_inline)) {
+        jc = 0; w0 = 0.f; w1 = 0.f;
+        if (e < cnt_) {
+            const uint32_t* src = eb + 3 * (size_t)(e0 + e);
+            jc = (int)src[0]; w0 = __uint_as_float(src[1]); w1 = __uint_as_float(src[2]);
         }
     };
+#define GF_LOAD_ENTRIES(G, E0, E1, P)                                                                           \
+    do {                                                                                                        \
+        const int tl_ = (G) / GF_UNITS, ii_ = min(tl_ * GF_TILE + pp, a_n - 1);                                 \
+        const uint32_t* eb_ = a_ent + (size_t)ii_ * (size_t)(4 * a_pitch) * 3;                                  \
+        P##e0 = (E0); P##cnt = (E1) - (E0);                                                                     \
+        load_one(eb_, P##e0, P##cnt, t, P##j0, P##a0, P##b0);                                                   \
+        load_one(eb_, P##e0, P##cnt, 8 + t, P##j1, P##a1, P##b1);                                               \
+        load_one(eb_, P##e0, P##cnt, 16 + t, P##j2, P##a2, P##b2);                                              \
+        load_one(eb_, P##e0, P##cnt, 24 + t, P##j3, P##a3, P##b3);                                              \
+    } while (0)
 
-    Ent Ecur, Enext;
+    int cj0 = 0, cj1 = 0, cj2 = 0, cj3 = 0, nj0 = 0, nj1 = 0, nj2 = 0, nj3 = 0;
+    float ca0 = 0.f, ca1 = 0.f, ca2 = 0.f, ca3 = 0.f, cb0 = 0.f, cb1 = 0.f, cb2 = 0.f, cb3 = 0.f;       // a = w(cx), b = w(cx + 1)
+    float na0 = 0.f, na1 = 0.f, na2 = 0.f, na3 = 0.f, nb0 = 0.f, nb1 = 0.f, nb2 = 0.f, nb3 = 0.f;
+    int ccnt = 0, ce0 = 0, ncnt = 0, ne0 = 0;
     int r1a = 0, r1b = 0, r2a = 0, r2b = 0;
-    Ecur.cnt = Ecur.e0 = 0;
     if (nun > 0) {
         int a, b;
         load_roff(g0, a, b);
-        load_entries(g0, a, b, Ecur);
+        GF_LOAD_ENTRIES(g0, a, b, c);
         if (nun > 1) load_roff(g0 + 1, r1a, r1b);
     }
     for (int p = 0; p <= nun; ++p) {
@@ -173,92 +226,121 @@ __global__ void __launch_bounds__(GF_THREADS) k_cconv_gf(GfArgs A)
             const int i = tile * GF_TILE + pp;
             // requests for the units ahead go out first: they land while this unit is built
             if (p + 2 < nun) load_roff(g + 2, r2a, r2b);
-            if (p + 1 < nun) load_entries(g + 1, r1a, r1b, Enext); else Enext.cnt = Enext.e0 = 0;
+            if (p + 1 < nun) GF_LOAD_ENTRIES(g + 1, r1a, r1b, n); else ncnt = ne0 = 0;
             float* Zb = Z + (p & 1) * ZB + pp * PITCH;
             if (u == 16) {
                 // Linear branch: Z = relu(x_i)
 #pragma unroll
                 for (int k = 0; k < NQ; ++k) {
                     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (i < A.n) v = *(const float4*)(A.x + (size_t)i * CIN + 4 * (t + 8 * k));
-                    if (A.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    if (i < a_n) v = *(const float4*)(a_x + (size_t)i * CIN + 4 * (t + 8 * k));
+                    if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                     *(float4*)(Zb + 4 * (t + 8 * k)) = v;
                 }
             } else {
-                float4 acc[4][NQ];
+                struct Acc4 { f32x2 lo, hi; };
+                Acc4 acc[4][NQ];
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
 #pragma unroll
-                    for (int k = 0; k < NQ; ++k) acc[c][k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                const int cnt = Ecur.cnt;
-                const int isafe = min(i, A.n - 1);
+                    for (int k = 0; k < NQ; ++k) { acc[c][k].lo = f32x2{0.f, 0.f}; acc[c][k].hi = f32x2{0.f, 0.f}; }
+                const int cnt = ccnt;
+                const int isafe = min(i, a_n - 1);
                 // one entry: gather relu(x[j]) and add it into the two touched nodes (weights of the other two are zero)
-                auto add_entry = [&](int jc, float w0, float w1, const float4 (&xv)[NQ]) {
+                auto add_entry = [&](int jc, float w0, float w1, const float4 (&xv)[NQ]) __attribute__((always_inline)) {
                     const int cx = (int)((unsigned)jc >> 30);
                     const float wc0 = cx == 0 ? w0 : 0.f;
                     const float wc1 = cx == 0 ? w1 : (cx == 1 ? w0 : 0.f);
                     const float wc2 = cx == 1 ? w1 : (cx == 2 ? w0 : 0.f);
                     const float wc3 = cx == 2 ? w1 : 0.f;
+                    const f32x2 p0 = {wc0, wc0}, p1 = {wc1, wc1}, p2 = {wc2, wc2}, p3 = {wc3, wc3};
 #pragma unroll
                     for (int k = 0; k < NQ; ++k) {
                         float4 v = xv[k];
-                        if (A.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                        acc[0][k].x += wc0 * v.x; acc[0][k].y += wc0 * v.y; acc[0][k].z += wc0 * v.z; acc[0][k].w += wc0 * v.w;
-                        acc[1][k].x += wc1 * v.x; acc[1][k].y += wc1 * v.y; acc[1][k].z += wc1 * v.z; acc[1][k].w += wc1 * v.w;
-                        acc[2][k].x += wc2 * v.x; acc[2][k].y += wc2 * v.y; acc[2][k].z += wc2 * v.z; acc[2][k].w += wc2 * v.w;
-                        acc[3][k].x += wc3 * v.x; acc[3][k].y += wc3 * v.y; acc[3][k].z += wc3 * v.z; acc[3][k].w += wc3 * v.w;
+                        if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                        // explicit (packed) FMAs: the library is built with -ffp-contract=off, which turns `acc += w * v` into a
+                        // multiply AND an add — twice the issue slots of the wave that bounds this kernel
+                        const f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
+                        acc[0][k].lo = __builtin_elementwise_fma(p0, lo, acc[0][k].lo); acc[0][k].hi = __builtin_elementwise_fma(p0, hi, acc[0][k].hi);
+                        acc[1][k].lo = __builtin_elementwise_fma(p1, lo, acc[1][k].lo); acc[1][k].hi = __builtin_elementwise_fma(p1, hi, acc[1][k].hi);
+                        acc[2][k].lo = __builtin_elementwise_fma(p2, lo, acc[2][k].lo); acc[2][k].hi = __builtin_elementwise_fma(p2, hi, acc[2][k].hi);
+                        acc[3][k].lo = __builtin_elementwise_fma(p3, lo, acc[3][k].lo); acc[3][k].hi = __builtin_elementwise_fma(p3, hi, acc[3][k].hi);
                     }
                 };
-                // the 8 threads of a point hold entries e0 + 8 s + t; four at a time are broadcast, their x rows requested
-                // together, then accumulated in list order
-#define GF_HALF(S, K0)                                                                                                   \
-                if (__any(8 * (S) + (K0) < cnt)) {                                                                       \
-                    int jc4[4]; float w04[4], w14[4]; float4 xv4[4][NQ];                                                 \
-                    jc4[0] = gf_bcast8<(K0)>(Ecur.jc[S]);     jc4[1] = gf_bcast8<(K0) + 1>(Ecur.jc[S]);                  \
-                    jc4[2] = gf_bcast8<(K0) + 2>(Ecur.jc[S]); jc4[3] = gf_bcast8<(K0) + 3>(Ecur.jc[S]);                  \
-                    w04[0] = __int_as_float(gf_bcast8<(K0)>(__float_as_int(Ecur.w0[S])));                                \
-                    w04[1] = __int_as_float(gf_bcast8<(K0) + 1>(__float_as_int(Ecur.w0[S])));                            \
-                    w04[2] = __int_as_float(gf_bcast8<(K0) + 2>(__float_as_int(Ecur.w0[S])));                            \
-                    w04[3] = __int_as_float(gf_bcast8<(K0) + 3>(__float_as_int(Ecur.w0[S])));                            \
-                    w14[0] = __int_as_float(gf_bcast8<(K0)>(__float_as_int(Ecur.w1[S])));                                \
-                    w14[1] = __int_as_float(gf_bcast8<(K0) + 1>(__float_as_int(Ecur.w1[S])));                            \
-                    w14[2] = __int_as_float(gf_bcast8<(K0) + 2>(__float_as_int(Ecur.w1[S])));                            \
-                    w14[3] = __int_as_float(gf_bcast8<(K0) + 3>(__float_as_int(Ecur.w1[S])));                            \
-                    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                      \
-                        const bool ok = 8 * (S) + (K0) + e < cnt;                                                        \
-                        const int j = ok ? (jc4[e] & 0x3fffffff) : isafe;                                                \
-                        if (!ok) { w04[e] = 0.f; w14[e] = 0.f; jc4[e] = 0; }                                             \
-                        _Pragma("unroll") for (int k = 0; k < NQ; ++k)                                                   \
-                            xv4[e][k] = *(const float4*)(A.x + (size_t)j * CIN + 4 * (t + 8 * k));                       \
-                    }                                                                                                    \
-                    _Pragma("unroll") for (int e = 0; e < 4; ++e) add_entry(jc4[e], w04[e], w14[e], xv4[e]);             \
+                struct XS { int jc; float w0, w1; float4 xv[NQ]; };
+                // entry E (a compile-time index: the loop below is fully unrolled, so slot and source lane are constants —
+                // a run-time slot choice among the 12 entry registers is turned into a table in scratch memory by the compiler)
+                auto issue = [&](auto ec, XS& S) __attribute__((always_inline)) {
+                    constexpr int E = decltype(ec)::value, SL = E >> 3;
+                    const int src = (lane & ~7) | (E & 7);
+                    const int jcS = SL == 0 ? cj0 : (SL == 1 ? cj1 : (SL == 2 ? cj2 : cj3));
+                    const float w0S = SL == 0 ? ca0 : (SL == 1 ? ca1 : (SL == 2 ? ca2 : ca3));
+                    const float w1S = SL == 0 ? cb0 : (SL == 1 ? cb1 : (SL == 2 ? cb2 : cb3));
+                    int jc = __shfl(jcS, src, 64);
+                    float w0 = __shfl(w0S, src, 64), w1 = __shfl(w1S, src, 64);
+                    const bool ok = E < cnt;
+                    const int j = ok ? (jc & 0x3fffffff) : isafe;
+                    S.jc = ok ? jc : 0; S.w0 = ok ? w0 : 0.f; S.w1 = ok ? w1 : 0.f;
+#pragma unroll
+                    for (int k = 0; k < NQ; ++k) S.xv[k] = *(const float4*)(a_x + (size_t)j * CIN + 4 * (t + 8 * k));
+                };
+                int wmax = cnt;                                   // the longest list among the wave's 8 points
+#pragma unroll
+                for (int o = 8; o <= 32; o <<= 1) wmax = max(wmax, __shfl_xor(wmax, o, 64));
+                // FOUR entries in flight: a slot is refilled (broadcast + x-row request of the entry four ahead) right after its
+                // entry has been accumulated.  Straight-line code with early exits (every group of 4 is unconditional inside:
+                // an entry past a point's own list is a masked request to a valid row with zero weights) — with conditional
+                // requests the compiler can no longer count the loads in flight and waits for ALL of them before every use.
+#ifdef GF_AB_NO_GATHER
+                const int ne4 = 0;
+#else
+                const int ne4 = (min(wmax, GF_SLOTS * 8) + 3) & ~3;
+#endif
+                XS S0, S1, S2, S3;
+                if (ne4 > 0) {
+                    issue(std::integral_constant<int, 0>{}, S0); issue(std::integral_constant<int, 1>{}, S1);
+                    issue(std::integral_constant<int, 2>{}, S2); issue(std::integral_constant<int, 3>{}, S3);
                 }
-                GF_HALF(0, 0) GF_HALF(0, 4) GF_HALF(1, 0) GF_HALF(1, 4) GF_HALF(2, 0) GF_HALF(2, 4)
-#undef GF_HALF
-                if (__any(cnt > 24)) {
-                    // rows with more than 24 entries (rare): the tail straight from the list, one entry at a time
-                    const uint32_t* eb = A.ent + (size_t)isafe * (size_t)(4 * A.pitch) * 3;
+#define GF_GROUP(E)                                                                                                      \
+                if (ne4 > (E)) {                                                                                         \
+                    add_entry(S0.jc, S0.w0, S0.w1, S0.xv);                                                               \
+                    if ((E) + 4 < GF_SLOTS * 8) issue(std::integral_constant<int, ((E) + 4) % (GF_SLOTS * 8)>{}, S0);     \
+                    add_entry(S1.jc, S1.w0, S1.w1, S1.xv);                                                               \
+                    if ((E) + 5 < GF_SLOTS * 8) issue(std::integral_constant<int, ((E) + 5) % (GF_SLOTS * 8)>{}, S1);     \
+                    add_entry(S2.jc, S2.w0, S2.w1, S2.xv);                                                               \
+                    if ((E) + 6 < GF_SLOTS * 8) issue(std::integral_constant<int, ((E) + 6) % (GF_SLOTS * 8)>{}, S2);     \
+                    add_entry(S3.jc, S3.w0, S3.w1, S3.xv);                                                               \
+                    if ((E) + 7 < GF_SLOTS * 8) issue(std::integral_constant<int, ((E) + 7) % (GF_SLOTS * 8)>{}, S3);
+                GF_GROUP(0) GF_GROUP(4) GF_GROUP(8) GF_GROUP(12) GF_GROUP(16) GF_GROUP(20) GF_GROUP(24) GF_GROUP(28)
+                }}}}}}}}
+#undef GF_GROUP
+                if (__any(cnt > GF_SLOTS * 8)) {
+                    // rows with more than 32 entries (rare): the tail straight from the list, one entry at a time
+                    const uint32_t* eb = a_ent + (size_t)isafe * (size_t)(4 * a_pitch) * 3;
                     int emax = cnt;
 #pragma unroll
                     for (int o = 8; o <= 32; o <<= 1) emax = max(emax, __shfl_xor(emax, o, 64));
-                    for (int e = 24; e < emax; ++e) {
+                    for (int e = GF_SLOTS * 8; e < emax; ++e) {
                         const bool ok = e < cnt;
-                        const uint32_t* src = eb + 3 * (size_t)(Ecur.e0 + (ok ? e : 0));
+                        const uint32_t* src = eb + 3 * (size_t)(ce0 + (ok ? e : 0));
                         int jc = ok ? (int)src[0] : 0;
                         const float w0 = ok ? __uint_as_float(src[1]) : 0.f, w1 = ok ? __uint_as_float(src[2]) : 0.f;
                         const int j = ok ? (jc & 0x3fffffff) : isafe;
                         float4 xv[NQ];
 #pragma unroll
-                        for (int k = 0; k < NQ; ++k) xv[k] = *(const float4*)(A.x + (size_t)j * CIN + 4 * (t + 8 * k));
+                        for (int k = 0; k < NQ; ++k) xv[k] = *(const float4*)(a_x + (size_t)j * CIN + 4 * (t + 8 * k));
                         add_entry(jc, w0, w1, xv);
                     }
                 }
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
 #pragma unroll
-                    for (int k = 0; k < NQ; ++k) *(float4*)(Zb + c * ZC + 4 * (t + 8 * k)) = acc[c][k];
+                    for (int k = 0; k < NQ; ++k)
+                        *(float4*)(Zb + c * ZC + 4 * (t + 8 * k)) = make_float4(acc[c][k].lo.x, acc[c][k].lo.y, acc[c][k].hi.x, acc[c][k].hi.y);
             }
-            Ecur = Enext;
+            cj0 = nj0; cj1 = nj1; cj2 = nj2; cj3 = nj3; ca0 = na0; ca1 = na1; ca2 = na2; ca3 = na3;
+            cb0 = nb0; cb1 = nb1; cb2 = nb2; cb3 = nb3;
+            ccnt = ncnt; ce0 = ne0;
             r1a = r2a; r1b = r2b;
         }
         __syncthreads();
@@ -272,30 +354,37 @@ __global__ void __launch_bounds__(GF_THREADS) k_cconv_gf(GfArgs A)
 struct GfEpi {
     const float* scratch; int tiles, nwg, maxseg, ctot, coutp, cout, n;
     const float* bias_c; const float* bias_d; const float* residual; float* out;
+    float* out_relu;          // optional: max(y, 0), what the next layer gathers (so that it need not apply the ReLU per gathered row)
     const float* pos; const float* pos_new; float* pos_c; float* vel_c; float scale, dt;       // pos == null: no update
 };
 
 __global__ void __launch_bounds__(256) k_cconv_gf_epi(GfEpi E)
 {
+    // one output per thread: block = (tile, group of 8 columns); thread = (column, row): the slab reads of a wave are two
+    // runs of 128 contiguous bytes, all of a thread's nseg * 4 loads are independent (one round trip)
     const int tile = blockIdx.x;
+    const int col = blockIdx.y * 8 + (threadIdx.x >> 5), row = threadIdx.x & 31, i = tile * GF_TILE + row;
+    if (col >= E.cout || i >= E.n) return;
     const int wfirst = gf_owner((long long)tile * GF_COST, E.nwg, E.ctot), wlast = gf_owner((long long)tile * GF_COST + 64, E.nwg, E.ctot);
-    const int nseg = wlast - wfirst + 1;
+    const int nq = (wlast - wfirst + 1) * 4;
     const int slab = E.coutp * GF_TILE;
-    for (int o = threadIdx.x; o < slab; o += 256) {
-        const int col = o >> 5, row = o & 31, i = tile * GF_TILE + row;      // consecutive threads: consecutive rows of a column
-        if (col >= E.cout || i >= E.n) continue;
-        const float* s = E.scratch + (size_t)tile * E.maxseg * 4 * slab + o;
-        float v = 0.f;
-        for (int q = 0; q < nseg * 4; ++q) v += s[(size_t)q * slab];
-        v += E.bias_c[col] + E.bias_d[col];
-        if (E.residual) v += E.residual[(size_t)i * E.cout + col];
-        E.out[(size_t)i * E.cout + col] = v;
-        if (E.pos) {                                                          // cout == 3: col = coordinate (k_trans_update's expressions)
-            const size_t e = (size_t)i * 3 + col;
-            const float pc = E.pos_new[e] + E.scale * v;
-            E.pos_c[e] = pc;
-            E.vel_c[e] = (pc - E.pos[e]) / E.dt;
-        }
+    const float* s = E.scratch + (size_t)tile * E.maxseg * 4 * slab + col * GF_TILE + row;
+    float v = 0.f;
+    int q = 0;
+    for (; q + 4 <= nq; q += 4) {
+        const float p0 = s[(size_t)q * slab], p1 = s[(size_t)(q + 1) * slab], p2 = s[(size_t)(q + 2) * slab], p3 = s[(size_t)(q + 3) * slab];
+        v += p0; v += p1; v += p2; v += p3;                  // segment-major, K-quarter-minor: a fixed order
+    }
+    for (; q < nq; ++q) v += s[(size_t)q * slab];
+    v += E.bias_c[col] + E.bias_d[col];
+    if (E.residual) v += E.residual[(size_t)i * E.cout + col];
+    if (E.out) E.out[(size_t)i * E.cout + col] = v;
+    if (E.out_relu) E.out_relu[(size_t)i * E.cout + col] = fmaxf(v, 0.f);
+    if (E.pos) {                                              // cout == 3: col = coordinate (k_trans_update's expressions)
+        const size_t e = (size_t)i * 3 + col;
+        const float pc = E.pos_new[e] + E.scale * v;
+        E.pos_c[e] = pc;
+        E.vel_c[e] = (pc - E.pos[e]) / E.dt;
     }
 }
 
@@ -357,7 +446,7 @@ extern "C" int nf_cconv_gf_plan(int n, int cout, int max_wg, int* tiles, int* nw
     return NF_OK;
 }
 
-template <int CIN, int NB>
+template <int CIN, int NB, bool RELU>
 static int gf_launch(const GfArgs& a, hipStream_t st)
 {
     const size_t lds = (size_t)2 * 4 * GF_TILE * (CIN + 4) * sizeof(float);
@@ -365,20 +454,20 @@ static int gf_launch(const GfArgs& a, hipStream_t st)
     int dev = 0;
     hipGetDevice(&dev);
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        hipFuncSetAttribute((const void*)k_cconv_gf<CIN, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)k_cconv_gf<CIN, NB, RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((k_cconv_gf<CIN, NB>), dim3(a.nwg), dim3(GF_THREADS), lds, st, a);
+    hipLaunchKernelGGL((k_cconv_gf<CIN, NB, RELU>), dim3(a.nwg), dim3(GF_THREADS), lds, st, a);
     return 0;
 }
 
 // One G-free layer: y = cconv(act(x)) + Linear(act(x)) + biases (+ residual) [+ position / velocity update when pos != NULL]
 extern "C" int nf_cconv_gf_layer(const float* x, int n, int cin, int cout, int relu, const uint16_t* roff, const uint32_t* ent,
                                  int pitch, const float* packed, const float* bias_conv, const float* bias_dense,
-                                 const float* residual, float* out, float* scratch, int max_wg, const float* pos,
+                                 const float* residual, float* out, float* out_relu, float* scratch, int max_wg, const float* pos,
                                  const float* pos_new, float scale, float dt, float* pos_c, float* vel_c, nf_stream_t stream)
 {
-    NF_CHECK_ARG(x && roff && ent && packed && bias_conv && bias_dense && out && scratch, "null pointer");
+    NF_CHECK_ARG(x && roff && ent && packed && bias_conv && bias_dense && (out || out_relu) && scratch, "null pointer");
     NF_CHECK_ARG((cin == 96 || cin == 64) && cout >= 1 && cout <= 64, "cin must be 96 or 64 (the transition model's layers), cout <= 64");
     NF_CHECK_ARG(!pos || (cout == 3 && pos_new && pos_c && vel_c), "the update epilogue belongs to the 3-channel layer");
     if (n <= 0) return NF_OK;
@@ -389,16 +478,132 @@ extern "C" int nf_cconv_gf_layer(const float* x, int n, int cin, int cout, int r
     a.ctot = a.tiles * GF_COST;
     hipStream_t st = (hipStream_t)stream;
     const int nb = cout > 32 ? 2 : 1;
-    if (cin == 96 && nb == 2) gf_launch<96, 2>(a, st);
-    else if (cin == 96) gf_launch<96, 1>(a, st);
-    else if (nb == 2) gf_launch<64, 2>(a, st);
-    else gf_launch<64, 1>(a, st);
+    // (the ReLU-on-load variants serve callers that hand over pre-activation features; nf_trans_step stores activated arrays)
+    if (relu) {
+        if (cin == 96 && nb == 2) gf_launch<96, 2, true>(a, st);
+        else if (cin == 96) gf_launch<96, 1, true>(a, st);
+        else if (nb == 2) gf_launch<64, 2, true>(a, st);
+        else gf_launch<64, 1, true>(a, st);
+    } else {
+        if (cin == 96 && nb == 2) gf_launch<96, 2, false>(a, st);
+        else if (cin == 96) gf_launch<96, 1, false>(a, st);
+        else if (nb == 2) gf_launch<64, 2, false>(a, st);
+        else gf_launch<64, 1, false>(a, st);
+    }
     NF_CHECK_LAUNCH();
     GfEpi e;
     e.scratch = scratch; e.tiles = a.tiles; e.nwg = a.nwg; e.maxseg = a.maxseg; e.ctot = a.ctot; e.coutp = 32 * nb; e.cout = cout; e.n = n;
-    e.bias_c = bias_conv; e.bias_d = bias_dense; e.residual = residual; e.out = out;
+    e.bias_c = bias_conv; e.bias_d = bias_dense; e.residual = residual; e.out = out; e.out_relu = out_relu;
     e.pos = pos; e.pos_new = pos_new; e.pos_c = pos_c; e.vel_c = vel_c; e.scale = scale; e.dt = dt;
-    hipLaunchKernelGGL(k_cconv_gf_epi, dim3(a.tiles), dim3(256), 0, st, e);
+    hipLaunchKernelGGL(k_cconv_gf_epi, dim3(a.tiles, (cout + 7) / 8), dim3(256), 0, st, e);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The last layer (conv3 + dense3: 64 -> 3 channels, models/transmodel.py:121-131 at i = 3, then :141-148).  Its contraction is
+// 2 % of the step's FLOPs; on the tile machinery above it would pad 3 output channels to a 32-wide MFMA block and pay the full
+// gather.  Here "transform, then gather" IS the right order, because the transformed array is tiny:
+//   G3[j][node][co] = sum_ci relu(a2)[j][ci] * K3[node][ci][co]       (65 x 3 floats = 780 bytes per particle, 3.8 MB in all;
+//                                                                      node 64 = the Linear branch)
+//   y3[i][co] = sum over the row entries of i of  w(cx) G3[j][4 rho + cx][co] + w(cx + 1) G3[j][4 rho + cx + 1][co]
+//               + G3[i][64][co] + biases;      pos_correction = y3 / 128, update_pos_vel.
+// ------------------------------------------------------------------------------------------------
+#define G3_PITCH 196            // floats per particle (65 x 3 = 195, padded)
+#define G3_TILE 8               // particles per workgroup of the transform (614 workgroups at 4 913 particles)
+
+__global__ void __launch_bounds__(256) k_cconv3_transform(const float* __restrict__ xr /* n x 64, activated */, int n,
+                                                          const float* __restrict__ kernel /* (64, 64, 3) */,
+                                                          const float* __restrict__ dense_w /* (3, 64) */, float* __restrict__ G3)
+{
+    __shared__ float xs[G3_TILE][64];
+    const int i0 = blockIdx.x * G3_TILE;
+    for (int t = threadIdx.x; t < G3_TILE * 16; t += 256) {
+        const int r = t >> 4, q = t & 15;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i0 + r < n) v = *(const float4*)(xr + (size_t)(i0 + r) * 64 + 4 * q);
+        *(float4*)&xs[r][4 * q] = v;
+    }
+    __syncthreads();
+    const int o = threadIdx.x;                   // output column: node * 3 + co
+    if (o >= 195) return;
+    const int node = o / 3, co = o - 3 * node;
+    float w[64];
+#pragma unroll
+    for (int ci = 0; ci < 64; ++ci) w[ci] = node < 64 ? kernel[((size_t)node * 64 + ci) * 3 + co] : dense_w[co * 64 + ci];
+    for (int r = 0; r < G3_TILE && i0 + r < n; ++r) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float4 v = *(const float4*)&xs[r][4 * q];          // (broadcast: every lane reads the same address)
+            a0 = fmaf(v.x, w[4 * q], a0); a1 = fmaf(v.y, w[4 * q + 1], a1); a2 = fmaf(v.z, w[4 * q + 2], a2); a3 = fmaf(v.w, w[4 * q + 3], a3);
+        }
+        G3[(size_t)(i0 + r) * G3_PITCH + o] = (a0 + a1) + (a2 + a3);
+    }
+}
+
+struct G3Epi { const float* pos; const float* pos_new; float* pos_c; float* vel_c; float scale, dt; };
+
+__global__ void __launch_bounds__(256) k_cconv3_gather(const float* __restrict__ G3, int n, const uint16_t* __restrict__ roff,
+                                                       const uint32_t* __restrict__ ent, int pitch, const float* __restrict__ bias_c,
+                                                       const float* __restrict__ bias_d, float* __restrict__ y3, G3Epi E)
+{
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    // the 17 row offsets of this particle: lane r holds roff[r]; an entry's row = number of offsets (1..15) it has reached
+    const int myoff = lane < 17 ? (int)roff[(size_t)i * GF_ROFF_PITCH + lane] : 0;
+    const int total = __builtin_amdgcn_readlane(myoff, 16);
+    int bound[15];
+#pragma unroll
+    for (int r = 0; r < 15; ++r) bound[r] = __builtin_amdgcn_readlane(myoff, r + 1);
+    const uint32_t* eb = ent + (size_t)i * (size_t)(4 * pitch) * 3;
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
+    for (int e = lane; e < total; e += 64) {
+        const uint32_t jc = eb[3 * (size_t)e];
+        const float w0 = __uint_as_float(eb[3 * (size_t)e + 1]), w1 = __uint_as_float(eb[3 * (size_t)e + 2]);
+        int rho = 0;
+#pragma unroll
+        for (int r = 0; r < 15; ++r) rho += e >= bound[r] ? 1 : 0;
+        const int j = (int)(jc & 0x3fffffffu), cx = (int)(jc >> 30);
+        const float* g = G3 + (size_t)j * G3_PITCH + (4 * rho + cx) * 3;      // nodes cx and cx + 1: six consecutive floats
+        acc0 = fmaf(w1, g[3], fmaf(w0, g[0], acc0));
+        acc1 = fmaf(w1, g[4], fmaf(w0, g[1], acc1));
+        acc2 = fmaf(w1, g[5], fmaf(w0, g[2], acc2));
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        acc0 += __shfl_xor(acc0, o, 64); acc1 += __shfl_xor(acc1, o, 64); acc2 += __shfl_xor(acc2, o, 64);
+    }
+    if (lane < 3) {
+        const float a = lane == 0 ? acc0 : (lane == 1 ? acc1 : acc2);
+        const float v = a + G3[(size_t)i * G3_PITCH + 192 + lane] + bias_c[lane] + bias_d[lane];
+        y3[(size_t)i * 3 + lane] = v;
+        if (E.pos) {                              // k_trans_update's expressions
+            const size_t q = (size_t)i * 3 + lane;
+            const float pc = E.pos_new[q] + E.scale * v;
+            E.pos_c[q] = pc;
+            E.vel_c[q] = (pc - E.pos[q]) / E.dt;
+        }
+    }
+}
+
+extern "C" size_t nf_cconv3_workspace_floats(int n) { return (size_t)(n > 0 ? n : 0) * G3_PITCH; }
+
+extern "C" int nf_cconv3_layer(const float* x_act, int n, const uint16_t* roff, const uint32_t* ent, int pitch, const float* kernel,
+                               const float* dense_w, const float* bias_conv, const float* bias_dense, float* workspace, float* y3,
+                               const float* pos, const float* pos_new, float scale, float dt, float* pos_c, float* vel_c,
+                               nf_stream_t stream)
+{
+    NF_CHECK_ARG(x_act && roff && ent && kernel && dense_w && bias_conv && bias_dense && workspace && y3, "null pointer");
+    NF_CHECK_ARG(!pos || (pos_new && pos_c && vel_c), "the update needs pos_new / pos_c / vel_c");
+    if (n <= 0) return NF_OK;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_cconv3_transform, dim3((n + G3_TILE - 1) / G3_TILE), dim3(256), 0, st, x_act, n, kernel, dense_w, workspace);
+    G3Epi E;
+    E.pos = pos; E.pos_new = pos_new; E.pos_c = pos_c; E.vel_c = vel_c; E.scale = scale; E.dt = dt;
+    hipLaunchKernelGGL(k_cconv3_gather, dim3((n + 3) / 4), dim3(256), 0, st, (const float*)workspace, n, roff, ent, pitch, bias_conv,
+                       bias_dense, y3, E);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }
@@ -409,7 +614,7 @@ extern "C" int nf_cconv_gf_layer(const float* x, int n, int cin, int cout, int r
 // overflow2 (largest neighbour count above its pitch, or 0) to decide whether the step has to be redone on the exact path.
 // ------------------------------------------------------------------------------------------------
 extern "C" int nf_trans_step(const nf_trans_step_t* s, const float* pos, const float* vel, float* num_nbrs, float* pos_c,
-                             float* vel_c, int64_t* host_overflow2, void* event, nf_stream_t stream)
+                             float* vel_c, int32_t* host_flag3, int step_id, nf_stream_t stream)
 {
     NF_CHECK_ARG(s && pos && vel && num_nbrs && pos_c && vel_c, "null pointer");
     int rc = nf_trans_prepare(pos, vel, s->gravity, s->dt, s->n, s->radius, s->bbox, s->grid_ws, s->grid_ws_bytes, s->pos_new,
@@ -417,23 +622,18 @@ extern "C" int nf_trans_step(const nf_trans_step_t* s, const float* pos, const f
     if (rc != NF_OK) return rc;
     rc = nf_trans_front(s->grid_ws, s->box_grid, s->pos_new, s->feats, s->box_feats, s->n, s->radius, s->extent, s->use_window,
                         s->pitch_f, s->pitch_b, s->counts2, num_nbrs, s->idx_f, s->d2_f, s->roff, s->ent, s->k_fluid, s->b_fluid,
-                        s->k_obst, s->b_obst, s->dense0_w, s->dense0_b, s->a0, s->overflow2, stream);
+                        s->k_obst, s->b_obst, s->dense0_w, s->dense0_b, s->a0, 1, s->overflow2, host_flag3, s->done_counter, step_id, stream);
     if (rc != NF_OK) return rc;
-    if (host_overflow2) {
-        // the overflow record is final behind the front kernel: it travels to the host (pinned memory) while the three
-        // convolutions run, so the caller's wait on `event` costs no GPU time
-        if (hipMemcpyAsync(host_overflow2, s->overflow2, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
-            (event && hipEventRecord((hipEvent_t)event, (hipStream_t)stream) != hipSuccess)) {
-            nf_set_error("nf_trans_step: overflow read-back failed");
-            return NF_ELAUNCH;
-        }
-    }
-    rc = nf_cconv_gf_layer(s->a0, s->n, 96, 64, 1, s->roff, s->ent, s->pitch_f, s->wp1, s->bc1, s->bd1, nullptr, s->a1, s->scratch,
+    // every layer reads relu(previous layer) (models/transmodel.py:124): the producers of a0 / a1 / a2 store the activated
+    // values (a0r, a1r, a2r), a1 itself is kept for conv2's residual
+    rc = nf_cconv_gf_layer(s->a0, s->n, 96, 64, 0, s->roff, s->ent, s->pitch_f, s->wp1, s->bc1, s->bd1, nullptr, s->a1, s->a1r, s->scratch,
                            s->max_wg, nullptr, nullptr, 0.f, 0.f, nullptr, nullptr, stream);
     if (rc != NF_OK) return rc;
-    rc = nf_cconv_gf_layer(s->a1, s->n, 64, 64, 1, s->roff, s->ent, s->pitch_f, s->wp2, s->bc2, s->bd2, s->a1, s->a2, s->scratch,
+    rc = nf_cconv_gf_layer(s->a1r, s->n, 64, 64, 0, s->roff, s->ent, s->pitch_f, s->wp2, s->bc2, s->bd2, s->a1, nullptr, s->a2, s->scratch,
                            s->max_wg, nullptr, nullptr, 0.f, 0.f, nullptr, nullptr, stream);
     if (rc != NF_OK) return rc;
-    return nf_cconv_gf_layer(s->a2, s->n, 64, 3, 1, s->roff, s->ent, s->pitch_f, s->wp3, s->bc3, s->bd3, nullptr, s->y3, s->scratch,
-                             s->max_wg, pos, s->pos_new, s->scale, s->dt, pos_c, vel_c, stream);
+    // the 3-channel layer: transform (3.8 MB) then gather, position / velocity update fused (the scratch of the layers above
+    // is free again: G3 lives there)
+    return nf_cconv3_layer(s->a2, s->n, s->roff, s->ent, s->pitch_f, s->k3, s->w3, s->bc3, s->bd3, s->scratch, s->y3, pos,
+                           s->pos_new, s->scale, s->dt, pos_c, vel_c, stream);
 }

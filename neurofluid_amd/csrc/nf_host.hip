@@ -74,3 +74,14 @@ extern "C" int nf_host_choice_mt19937(uint32_t* key, int* pos, int64_t n, int64_
     free(x);
     return NF_OK;
 }
+
+
+// Device-side address of a page-locked host allocation (hipHostMalloc / torch pinned memory), or NULL when the block is not
+// mapped into the device's address space: nf_trans_step's overflow words live there (written by a kernel only when a
+// neighbour row overflows, read by the host after the event behind that kernel).
+extern "C" void* nf_pinned_device_ptr(void* host_ptr)
+{
+    void* d = nullptr;
+    if (!host_ptr || hipHostGetDevicePointer(&d, host_ptr, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return d;
+}

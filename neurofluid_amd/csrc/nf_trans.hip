@@ -426,13 +426,20 @@ extern "C" int nf_trans_conv0(const float* box_feats, const float* fluid_feats, 
 // Rows keep a fixed pitch (capacity per particle); a count above it is reported through overflow2 and the host redoes the
 // step on the exact CSR path (ParticleNet._forward_impl) — nothing is poisoned, nothing surfaces later.
 // ================================================================================================
-#define TF_QPB 4
+#define TF_WAVES 8                       // particles in flight per workgroup (a wave each); the filter is staged once per workgroup
 #define TF_MAXP 128                      // staged pairs per wave = the largest pitch this kernel serves
 
-struct TfStage {
-    int j[TF_MAXP];
-    float fx[TF_MAXP], fy[TF_MAXP], fz[TF_MAXP], imp[TF_MAXP];
-    int cxyz[TF_MAXP];                   // cx | cy << 2 | cz << 4
+#define TF_CHUNK 32                      // pairs per round of the layer-0 patch build
+struct TfStage {                         // per wave
+    int j[TF_MAXP];                      // hits of the sweep, in hit order
+    float d2[TF_MAXP];
+    union {
+        struct { float px[TF_MAXP], py[TF_MAXP], pz[TF_MAXP]; } pos;     // ... their positions (dead once the pair data is in registers)
+        float feat[TF_CHUNK][4];         // then: the features of a round's neighbours
+    } u;
+    float iw[TF_CHUNK * 8];              // a round's (node, weight, pair) items, bucketed by node
+    unsigned char it[TF_CHUNK * 8];
+    int ccount[64], coff[64];
 };
 
 struct TfArgs {
@@ -442,7 +449,7 @@ struct TfArgs {
     const float* feats_b;                // container normals (nb x 3)
     int n;
     float r2, extent;
-    int use_window, pitch_f, pitch_b;
+    int use_window, pitch_f, pitch_b, relu_out;
     int32_t* counts2;                    // [2][n] true neighbour counts
     float* num_nbrs;                     // [n]
     int32_t* idx_f; float* d2_f;         // pitched rows (conv.nns)
@@ -452,6 +459,11 @@ struct TfArgs {
     const float* dense_w; const float* dense_b;
     float* a0;                           // n x 96
     unsigned long long* overflow2;       // [2] largest count seen above its pitch
+    volatile int* host_flag;             // [3] or null: host-mapped (pinned) words; [0], [1] are written ONLY on overflow, [2]
+                                         // receives step_id from the LAST workgroup to finish: the host spins on that word
+                                         // (a HIP event recorded in the middle of a batch of launches completes with the batch)
+    unsigned* done_ctr;                  // device counter of finished workgroups (zero between launches)
+    int step_id;
 };
 
 template <int CIN>
@@ -471,168 +483,295 @@ __device__ __forceinline__ float tf_patch_times_filter(const float* __restrict__
     return a + __shfl_xor(a, 32, 64);
 }
 
-__global__ void __launch_bounds__(64 * TF_QPB) k_trans_front(TfArgs A)
+// interpolation data of one pair, exactly k_pair_precompute (nf_cconv.hip): base node (bx, by, bz), fractions, window
+struct TfPair { int j, bx, by, bz; float fx, fy, fz, imp; };
+
+__device__ __forceinline__ TfPair tf_pair(const TfStage& st, int t, float qx, float qy, float qz, float scale, float inv_r2, int use_window)
+{
+    TfPair P;
+    P.j = st.j[t];
+    float x = (st.u.pos.px[t] - qx) * scale, y = (st.u.pos.py[t] - qy) * scale, z = (st.u.pos.pz[t] - qz) * scale;
+    tr_ball_to_cube(x, y, z);
+    P.imp = 1.f;
+    if (use_window) { const float tt = 1.f - st.d2[t] * inv_r2; P.imp = fminf(fmaxf(tt * tt * tt, 0.f), 1.f); }
+    const float c[3] = {(x + 1.f) * 1.5f, (y + 1.f) * 1.5f, (z + 1.f) * 1.5f};
+    int i0[3];
+    float f[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float cc = fminf(fmaxf(c[d], 0.f), 3.f);
+        const float fl = fminf(floorf(cc), 2.f);
+        i0[d] = (int)fl;
+        f[d] = cc - fl;
+    }
+    P.bx = i0[0]; P.by = i0[1]; P.bz = i0[2]; P.fx = f[0]; P.fy = f[1]; P.fz = f[2];
+    return P;
+}
+
+__global__ void __launch_bounds__(64 * TF_WAVES, 4) k_trans_front(TfArgs A)
 {
     __shared__ float Ks[64 * 4 * 32];
-    __shared__ TfStage stage[TF_QPB];
-    __shared__ float patch[TF_QPB][256];
-    __shared__ int rcnt[TF_QPB][16], rcur[TF_QPB][16], rbase[TF_QPB][17];
+    __shared__ TfStage stage[TF_WAVES];
+    __shared__ float patch[TF_WAVES][256];
+    __shared__ int rcnt[TF_WAVES][16], rcur[TF_WAVES][16], rbase[TF_WAVES][17];
     const int which = blockIdx.y;
     {
-        const float* ksrc = which ? A.k_obst : A.k_fluid;
-        const int kn = which ? 64 * 3 * 32 : 64 * 4 * 32;
-        for (int t = threadIdx.x; t < kn; t += 64 * TF_QPB) Ks[t] = ksrc[t];
+        const float4* ksrc = (const float4*)(which ? A.k_obst : A.k_fluid);
+        const int kn4 = (which ? 64 * 3 * 32 : 64 * 4 * 32) / 4;
+        for (int t = threadIdx.x; t < kn4; t += 64 * TF_WAVES) ((float4*)Ks)[t] = ksrc[t];
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int i = blockIdx.x * TF_QPB + wv;
-    if (i >= A.n) return;
     TfStage& st = stage[wv];
     const int pitch = which ? A.pitch_b : A.pitch_f;
     const int cap = min(pitch, TF_MAXP);
-    for (int t = lane; t < 256; t += 64) patch[wv][t] = 0.f;
-    if (lane < 16) { rcnt[wv][lane] = 0; rcur[wv][lane] = 0; }
-    const float qx = A.q[3 * i], qy = A.q[3 * i + 1], qz = A.q[3 * i + 2];
     const NfGridView g = nf_grid_view(A.grid[which]);
-    const int cx = nf_cell_coord(qx, g.ox, g.icx, g.dx);
-    const int cy = nf_cell_coord(qy, g.oy, g.icy, g.dy);
-    const int cz = nf_cell_coord(qz, g.oz, g.icz, g.dz);
     const unsigned long long lt = (1ull << lane) - 1ull;
     const float radius = 0.5f * A.extent, inv_r2 = 1.f / (radius * radius), scale = 2.f / A.extent;
-    const int64_t o = (int64_t)i * pitch;
-    // ---- pass 1: the sweep; hits staged in hit order (cell-major, as k_trans_search)
-    int cnt = 0;
-    for (int z = max(cz - 1, 0); z <= min(cz + 1, g.dz - 1); ++z)
-        for (int y = max(cy - 1, 0); y <= min(cy + 1, g.dy - 1); ++y) {
-            const int r0 = (z * g.dy + y) * g.dx;
-            const int s = g.cell_start[r0 + max(cx - 1, 0)], e = g.cell_start[r0 + min(cx + 1, g.dx - 1) + 1];
-            for (int t0 = s; t0 < e; t0 += 64) {
-                const int t = t0 + lane;
-                bool hit = false;
-                float d2 = 0.f;
-                float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (t < e) {
-                    p = g.sorted_pos[t];
-                    d2 = nf_dist2(qx, qy, qz, p.x, p.y, p.z);
-                    hit = d2 <= A.r2 && !(p.x == qx && p.y == qy && p.z == qz);      // radius_search_ignore_query_points=True
-                }
-                const unsigned long long m = __ballot(hit);
-                if (hit) {
-                    const int w = cnt + __popcll(m & lt);
-                    if (w < cap) {
-                        if (!which) { A.idx_f[o + w] = __float_as_int(p.w); A.d2_f[o + w] = d2; }
-                        // per-pair interpolation data, exactly k_pair_precompute (nf_cconv.hip)
-                        float x = (p.x - qx) * scale, yy = (p.y - qy) * scale, zz = (p.z - qz) * scale;
-                        tr_ball_to_cube(x, yy, zz);
-                        float imp = 1.f;
-                        if (A.use_window) { const float tt = 1.f - d2 * inv_r2; imp = fminf(fmaxf(tt * tt * tt, 0.f), 1.f); }
-                        const float c[3] = {(x + 1.f) * 1.5f, (yy + 1.f) * 1.5f, (zz + 1.f) * 1.5f};
-                        int i0[3];
-                        float f[3];
+    const int CI = which ? 3 : 4;
+    for (int i = blockIdx.x * TF_WAVES + wv; i < A.n; i += gridDim.x * TF_WAVES) {
+        if (lane < 16) { rcnt[wv][lane] = 0; rcur[wv][lane] = 0; }
+        const float qx = A.q[3 * i], qy = A.q[3 * i + 1], qz = A.q[3 * i + 2];
+        const int cx = nf_cell_coord(qx, g.ox, g.icx, g.dx);
+        const int cy = nf_cell_coord(qy, g.oy, g.icy, g.dy);
+        const int cz = nf_cell_coord(qz, g.oz, g.icz, g.dz);
+        // ---- pass 1: the sweep (cell-major, the order of k_trans_search / nf_radius_fill).  The ranges of the 9 (z, y) rows are
+        // fetched by 9 lanes at once and the first 64 candidates of EVERY row are requested before the first is looked at:
+        // two dependent round trips for the whole neighbourhood instead of two per row.
+        int rs = 0, re = 0;
+        if (lane < 9) {
+            const int z = cz - 1 + lane / 3, y = cy - 1 + lane % 3;
+            if (z >= 0 && z < g.dz && y >= 0 && y < g.dy) {
+                const int r0 = (z * g.dy + y) * g.dx;
+                rs = g.cell_start[r0 + max(cx - 1, 0)];
+                re = g.cell_start[r0 + min(cx + 1, g.dx - 1) + 1];
+            }
+        }
+        int cnt = 0;
+#ifdef TF_AB_SKIP_ALL
+        if (lane == 0) A.a0[(size_t)i * 96 + which] = (float)rs;
+        continue;
+#endif
+        // rows in two groups (5 + 4): the first batches of a group are in flight together
 #pragma unroll
-                        for (int d = 0; d < 3; ++d) {
-                            const float cc = fminf(fmaxf(c[d], 0.f), 3.f);
-                            const float fl = fminf(floorf(cc), 2.f);
-                            i0[d] = (int)fl;
-                            f[d] = cc - fl;
-                        }
-                        st.j[w] = __float_as_int(p.w);
-                        st.fx[w] = f[0]; st.fy[w] = f[1]; st.fz[w] = f[2]; st.imp[w] = imp;
-                        st.cxyz[w] = i0[0] | (i0[1] << 2) | (i0[2] << 4);
+        for (int grp = 0; grp < 2; ++grp) {
+            const int R0 = grp ? 5 : 0, RN = grp ? 4 : 5;
+            int rows_s[5], rows_e[5];
+            float4 first[5];
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+                rows_s[r] = rows_e[r] = 0;
+                first[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r < RN) {
+                    rows_s[r] = __builtin_amdgcn_readlane(rs, R0 + r);
+                    rows_e[r] = __builtin_amdgcn_readlane(re, R0 + r);
+                    if (rows_s[r] + lane < rows_e[r]) first[r] = g.sorted_pos[rows_s[r] + lane];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+                if (r >= RN) continue;
+                for (int t0 = rows_s[r]; t0 < rows_e[r]; t0 += 64) {
+                    const int t = t0 + lane;
+                    float4 p = first[r];
+                    if (t0 != rows_s[r]) { p = make_float4(0.f, 0.f, 0.f, 0.f); if (t < rows_e[r]) p = g.sorted_pos[t]; }
+                    bool hit = false;
+                    float d2 = 0.f;
+                    if (t < rows_e[r]) {
+                        d2 = nf_dist2(qx, qy, qz, p.x, p.y, p.z);
+                        hit = d2 <= A.r2 && !(p.x == qx && p.y == qy && p.z == qz);      // radius_search_ignore_query_points=True
                     }
+                    const unsigned long long m = __ballot(hit);
+                    if (hit) {
+                        const int w = cnt + __popcll(m & lt);
+                        if (w < cap) { st.j[w] = __float_as_int(p.w); st.d2[w] = d2; st.u.pos.px[w] = p.x; st.u.pos.py[w] = p.y; st.u.pos.pz[w] = p.z; }
+                    }
+                    cnt += __popcll(m);
                 }
-                cnt += __popcll(m);
             }
         }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-    if (lane == 0) {
-        A.counts2[(size_t)which * A.n + i] = cnt;
-        if (!which) A.num_nbrs[i] = (float)cnt;
-        if (cnt > pitch) atomicMax(A.overflow2 + which, (unsigned long long)cnt);
-    }
-    const int np = min(cnt, cap);
-    // ---- pass 2 (lane = pair): layer-0 patch, row counts
-    for (int base = 0; base < np; base += 64) {
-        const int t = base + lane;
-        if (t < np) {
-            const int j = st.j[t], cc = st.cxyz[t];
-            const int bx = cc & 3, by = (cc >> 2) & 3, bz = cc >> 4;
-            const float fx = st.fx[t], fy = st.fy[t], fz = st.fz[t], imp = st.imp[t];
-            float fj[4];
-            if (!which) { const float4 v = *(const float4*)(A.feats_f + 4 * (size_t)j); fj[0] = v.x; fj[1] = v.y; fj[2] = v.z; fj[3] = v.w; }
-            else { fj[0] = A.feats_b[3 * (size_t)j]; fj[1] = A.feats_b[3 * (size_t)j + 1]; fj[2] = A.feats_b[3 * (size_t)j + 2]; fj[3] = 0.f; }
-            const int CI = which ? 3 : 4;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
-                const float w = imp * ((dx ? fx : 1.f - fx) * (dy ? fy : 1.f - fy) * (dz ? fz : 1.f - fz));
-                const int cell = ((bz + dz) * 4 + (by + dy)) * 4 + (bx + dx);
-#pragma unroll
-                for (int ci = 0; ci < 4; ++ci)
-                    if (ci < CI) atomicAdd(&patch[wv][cell * CI + ci], w * fj[ci]);
-            }
-            if (!which) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) atomicAdd(&rcnt[wv][(bz + (r >> 1)) * 4 + by + (r & 1)], 1);
-            }
-        }
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-    if (!which) {
-        // ---- pass 3: exclusive scan of the 16 row counts -> roff
-        int c = lane < 16 ? rcnt[wv][lane] : 0;
-        int x = c;
-#pragma unroll
-        for (int o2 = 1; o2 < 16; o2 <<= 1) { const int y = __shfl_up(x, o2, 64); if (lane >= o2) x += y; }
-        if (lane < 16) rbase[wv][lane] = x - c;
-        if (lane == 15) rbase[wv][16] = x;
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
-        if (lane < 17) A.roff[(size_t)i * 20 + lane] = (uint16_t)rbase[wv][lane];
-        // ---- pass 4 (lane = pair): place the four row entries of every pair; LDS cursors advance in lane order, so a
-        // bucket keeps the pair order
-        uint32_t* ebase = A.ent + (size_t)i * (size_t)(4 * A.pitch_f) * 3;
-        for (int base = 0; base < np; base += 64) {
-            const int t = base + lane;
-            if (t < np) {
-                const int j = st.j[t], cc = st.cxyz[t];
-                const int bx = cc & 3, by = (cc >> 2) & 3, bz = cc >> 4;
-                const float fx = st.fx[t], fy = st.fy[t], fz = st.fz[t], imp = st.imp[t];
+        if (lane == 0) {
+            A.counts2[(size_t)which * A.n + i] = cnt;
+            if (!which) A.num_nbrs[i] = (float)cnt;
+            if (cnt > pitch) {
+                atomicMax(A.overflow2 + which, (unsigned long long)cnt);
+                if (A.host_flag) { A.host_flag[which] = cnt; __threadfence_system(); }      // (any overflowing count will do as the flag)
+            }
+        }
+        const int np = min(cnt, cap);
+        // ---- pass 2 (lane = pair, dense): interpolation data of up to two chunks of 64 pairs (kept in registers for the passes
+        // below), the pitched neighbour rows, row counts
+        TfPair P[2];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int dy = r & 1, dz = r >> 1;
-                    const int rho = (bz + dz) * 4 + by + dy;
-                    const int e = rbase[wv][rho] + atomicAdd(&rcur[wv][rho], 1);
-                    // the weights of k_pair_precompute, same expression and association
-                    const float w0 = imp * ((1.f - fx) * (dy ? fy : 1.f - fy) * (dz ? fz : 1.f - fz));
-                    const float w1 = imp * (fx * (dy ? fy : 1.f - fy) * (dz ? fz : 1.f - fz));
-                    uint32_t* dst = ebase + 3 * (size_t)e;
-                    dst[0] = (uint32_t)j | ((uint32_t)bx << 30);
-                    dst[1] = __float_as_uint(w0);
-                    dst[2] = __float_as_uint(w1);
+        for (int c = 0; c < 2; ++c) {
+            const int t = 64 * c + lane;
+            P[c].j = 0; P[c].bx = P[c].by = P[c].bz = 0; P[c].fx = P[c].fy = P[c].fz = P[c].imp = 0.f;
+            if (t < np) {
+                P[c] = tf_pair(st, t, qx, qy, qz, scale, inv_r2, A.use_window);
+                if (!which) {
+                    A.idx_f[(int64_t)i * pitch + t] = P[c].j; A.d2_f[(int64_t)i * pitch + t] = st.d2[t];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) atomicAdd(&rcnt[wv][(P[c].bz + (r >> 1)) * 4 + P[c].by + (r & 1)], 1);
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        // ---- layer-0 patch P[node][ci] = sum_pairs w(pair, node) * feat[pair][ci], in rounds of 32 pairs WITHOUT float atomics
+        // (ds_add_f32 with the same-address collisions of this scatter cost 44 of the kernel's 70 us): a pair's 8 (node, weight)
+        // items are bucketed by node with integer LDS atomics (the returned slot orders a bucket), then lane = NODE walks its
+        // bucket and accumulates in registers.
+        float pacc[4] = {0.f, 0.f, 0.f, 0.f};
+#ifndef TF_AB_SKIP_PATCH
+        for (int t0 = 0; t0 < np; t0 += TF_CHUNK) {
+            st.ccount[lane] = 0;
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            // this round's pairs sit in lanes (t0 & 63) .. +31 of register set t0 >> 6; lanes 0..31 take them over
+            const int srcl = (t0 & 63) + (lane & 31);
+            TfPair Q;
+            {
+                const TfPair& R = P[0];
+                const TfPair& R1 = P[1];
+                const bool hi = t0 >= 64;
+                Q.j = __shfl(hi ? R1.j : R.j, srcl, 64);
+                Q.bx = __shfl(hi ? R1.bx : R.bx, srcl, 64); Q.by = __shfl(hi ? R1.by : R.by, srcl, 64); Q.bz = __shfl(hi ? R1.bz : R.bz, srcl, 64);
+                Q.fx = __shfl(hi ? R1.fx : R.fx, srcl, 64); Q.fy = __shfl(hi ? R1.fy : R.fy, srcl, 64); Q.fz = __shfl(hi ? R1.fz : R.fz, srcl, 64);
+                Q.imp = __shfl(hi ? R1.imp : R.imp, srcl, 64);
+            }
+            const bool mine = lane < TF_CHUNK && t0 + lane < np;
+            int slot[8], cellk[8];
+            float wk[8];
+            if (mine) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
+                    wk[k] = Q.imp * ((dx ? Q.fx : 1.f - Q.fx) * (dy ? Q.fy : 1.f - Q.fy) * (dz ? Q.fz : 1.f - Q.fz));
+                    cellk[k] = ((Q.bz + dz) * 4 + (Q.by + dy)) * 4 + (Q.bx + dx);
+                    slot[k] = atomicAdd(&st.ccount[cellk[k]], 1);
+                }
+                float4 f4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!which) f4 = *(const float4*)(A.feats_f + 4 * (size_t)Q.j);
+                else { f4.x = A.feats_b[3 * (size_t)Q.j]; f4.y = A.feats_b[3 * (size_t)Q.j + 1]; f4.z = A.feats_b[3 * (size_t)Q.j + 2]; }
+                *(float4*)st.u.feat[lane] = f4;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            const int mycnt = st.ccount[lane];
+            int x = mycnt;
+#pragma unroll
+            for (int o2 = 1; o2 < 64; o2 <<= 1) { const int y = __shfl_up(x, o2, 64); if (lane >= o2) x += y; }
+            const int myoff = x - mycnt;
+            st.coff[lane] = myoff;
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            if (mine) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int pos = st.coff[cellk[k]] + slot[k];
+                    st.iw[pos] = wk[k];
+                    st.it[pos] = (unsigned char)lane;
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            int cmax = mycnt;
+#pragma unroll
+            for (int o2 = 1; o2 < 64; o2 <<= 1) cmax = max(cmax, __shfl_xor(cmax, o2, 64));
+            for (int e = 0; e < cmax; ++e) {
+                if (e < mycnt) {
+                    const float w = st.iw[myoff + e];
+                    const float4 f4 = *(const float4*)st.u.feat[st.it[myoff + e]];
+                    pacc[0] = fmaf(w, f4.x, pacc[0]); pacc[1] = fmaf(w, f4.y, pacc[1]);
+                    pacc[2] = fmaf(w, f4.z, pacc[2]); pacc[3] = fmaf(w, f4.w, pacc[3]);
                 }
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_wave_barrier();
         }
-    }
-    // ---- layer 0: patch x filter (+ the Linear branch on the particle's own features)
-    const int co = lane & 31, half = lane >> 5;
-    float* orow = A.a0 + (size_t)i * 96;
-    if (!which) {
-        const float af = tf_patch_times_filter<4>(patch[wv], Ks, co, half);
-        if (half == 0) orow[32 + co] = af + A.b_fluid[co];
-        else {
-            float s = A.dense_b[co];
+#endif
 #pragma unroll
-            for (int ci = 0; ci < 4; ++ci) s += A.feats_f[(size_t)i * 4 + ci] * A.dense_w[co * 4 + ci];
-            orow[64 + co] = s;
+        for (int ci = 0; ci < 4; ++ci)
+            if (ci < CI) patch[wv][lane * CI + ci] = pacc[ci];
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        if (!which) {
+            // ---- pass 3: exclusive scan of the 16 row counts -> roff
+            int c = lane < 16 ? rcnt[wv][lane] : 0;
+            int x = c;
+#pragma unroll
+            for (int o2 = 1; o2 < 16; o2 <<= 1) { const int y = __shfl_up(x, o2, 64); if (lane >= o2) x += y; }
+            if (lane < 16) rbase[wv][lane] = x - c;
+            if (lane == 15) rbase[wv][16] = x;
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 17) A.roff[(size_t)i * 20 + lane] = (uint16_t)rbase[wv][lane];
+            // ---- pass 4 (lane = pair): the four row entries of every pair; the LDS cursors advance in lane order, so a
+            // bucket keeps the pair order
+            uint32_t* ebase = A.ent + (size_t)i * (size_t)(4 * A.pitch_f) * 3;
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {
+#ifdef TF_AB_SKIP_ENT
+                break;
+#endif
+                if (64 * c2 < np) {
+                    if (64 * c2 + lane < np) {
+                        const TfPair& Q = P[c2];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int dy = r & 1, dz = r >> 1;
+                            const int rho = (Q.bz + dz) * 4 + Q.by + dy;
+                            const int e = rbase[wv][rho] + atomicAdd(&rcur[wv][rho], 1);
+                            // the weights of k_pair_precompute, same expression and association
+                            const float w0 = Q.imp * ((1.f - Q.fx) * (dy ? Q.fy : 1.f - Q.fy) * (dz ? Q.fz : 1.f - Q.fz));
+                            const float w1 = Q.imp * (Q.fx * (dy ? Q.fy : 1.f - Q.fy) * (dz ? Q.fz : 1.f - Q.fz));
+                            uint32_t* dst = ebase + 3 * (size_t)e;
+                            dst[0] = (uint32_t)Q.j | ((uint32_t)Q.bx << 30);
+                            dst[1] = __float_as_uint(w0);
+                            dst[2] = __float_as_uint(w1);
+                        }
+                    }
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
         }
-    } else {
-        const float ao = tf_patch_times_filter<3>(patch[wv], Ks, co, half);
-        if (half == 0) orow[co] = ao + A.b_obst[co];
+        // ---- layer 0: patch x filter (+ the Linear branch on the particle's own features)
+        const int co = lane & 31, half = lane >> 5;
+        float* orow = A.a0 + (size_t)i * 96;
+#ifdef TF_AB_SKIP_GEMV
+        if (lane == 0) orow[which] = patch[wv][5];
+        continue;
+#endif
+        if (!which) {
+            const float af = tf_patch_times_filter<4>(patch[wv], Ks, co, half);
+            if (half == 0) { const float v = af + A.b_fluid[co]; orow[32 + co] = A.relu_out ? fmaxf(v, 0.f) : v; }
+            else {
+                float s2 = A.dense_b[co];
+#pragma unroll
+                for (int ci = 0; ci < 4; ++ci) s2 += A.feats_f[(size_t)i * 4 + ci] * A.dense_w[co * 4 + ci];
+                orow[64 + co] = A.relu_out ? fmaxf(s2, 0.f) : s2;
+            }
+        } else {
+            const float ao = tf_patch_times_filter<3>(patch[wv], Ks, co, half);
+            if (half == 0) { const float v = ao + A.b_obst[co]; orow[co] = A.relu_out ? fmaxf(v, 0.f) : v; }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();          // the next particle of this wave reuses the stage / patch / counters
+    }
+    if (A.host_flag) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence_system();                // this workgroup's overflow words (if any) before its arrival
+            const unsigned old = atomicAdd(A.done_ctr, 1u);
+            if (old == gridDim.x * gridDim.y - 1) {
+                *A.done_ctr = 0u;
+                A.host_flag[2] = A.step_id;
+                __threadfence_system();
+            }
+        }
     }
 }
 
@@ -643,7 +782,8 @@ extern "C" int nf_trans_front(const void* fluid_grid, const void* box_grid, cons
                               int pitch_box, int32_t* counts2, float* num_fluid_nbrs, int32_t* idx_f, float* d2_f, uint16_t* roff,
                               uint32_t* entries, const float* kernel_fluid, const float* bias_fluid, const float* kernel_obstacle,
                               const float* bias_obstacle, const float* dense_w, const float* dense_b, float* out96,
-                              int64_t* overflow2, nf_stream_t stream)
+                              int relu_out, int64_t* overflow2, int32_t* host_flag3, uint32_t* done_counter, int step_id,
+                              nf_stream_t stream)
 {
     NF_CHECK_ARG(fluid_grid && box_grid && queries && fluid_feats && box_feats && counts2 && num_fluid_nbrs && idx_f && d2_f && roff &&
                  entries && kernel_fluid && bias_fluid && kernel_obstacle && bias_obstacle && dense_w && dense_b && out96 && overflow2,
@@ -653,10 +793,27 @@ extern "C" int nf_trans_front(const void* fluid_grid, const void* box_grid, cons
     TfArgs A;
     A.grid[0] = fluid_grid; A.grid[1] = box_grid; A.q = queries; A.feats_f = fluid_feats; A.feats_b = box_feats; A.n = n;
     A.r2 = radius * radius; A.extent = extent; A.use_window = use_window; A.pitch_f = pitch_fluid; A.pitch_b = pitch_box;
+    A.relu_out = relu_out;
     A.counts2 = counts2; A.num_nbrs = num_fluid_nbrs; A.idx_f = idx_f; A.d2_f = d2_f; A.roff = roff; A.ent = entries;
     A.k_fluid = kernel_fluid; A.b_fluid = bias_fluid; A.k_obst = kernel_obstacle; A.b_obst = bias_obstacle;
     A.dense_w = dense_w; A.dense_b = dense_b; A.a0 = out96; A.overflow2 = (unsigned long long*)overflow2;
-    hipLaunchKernelGGL(k_trans_front, dim3((n + TF_QPB - 1) / TF_QPB, 2), dim3(64 * TF_QPB), 0, (hipStream_t)stream, A);
+    NF_CHECK_ARG(!host_flag3 || done_counter, "the completion word needs the workgroup counter");
+    A.host_flag = (volatile int*)host_flag3; A.done_ctr = done_counter; A.step_id = step_id;
+    // two workgroups of 8 waves fit a CU (61 KB of LDS each: the filter is staged once per workgroup): size the grid so that
+    // every workgroup is resident at once and each wave walks the same number of particles
+    int ncu = 256;
+    {   // (cached per device: hipGetDeviceProperties costs tens of microseconds, this runs once per step)
+        static int cu_of[64] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+            if (!cu_of[dev]) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cu_of[dev] = v; }
+            if (cu_of[dev]) ncu = cu_of[dev];
+        }
+    }
+    const int per = TF_WAVES, iters = (n + ncu * per - 1) / (ncu * per);
+    int blocks = (n + per * iters - 1) / (per * iters);
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_trans_front, dim3(blocks, 2), dim3(64 * TF_WAVES), 0, (hipStream_t)stream, A);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }

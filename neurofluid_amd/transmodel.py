@@ -18,6 +18,10 @@ from . import _lib, ops
 from ._lib import check, ptr
 
 
+import os as _os
+_DIAG_NO_WAIT = _os.environ.get("NF_DIAG_TRANS_NO_WAIT") == "1"      # measurement only: skip the overflow wait
+
+
 class ContinuousConv(nn.Module):
     """Parameter container + standalone forward with the Open3D layer contract
     ``__call__(inp_features, inp_positions, out_positions, extents)``; exposes ``.nns`` afterwards."""
@@ -169,6 +173,7 @@ class ParticleNet(nn.Module):
         self.fused_inference = True
         self.fused_grow_pitch = True        # on overflow: redo the step exactly AND grow the pitch (False: only redo)
         self._fused, self._fused_skip = None, 0
+        self._lib_cached = None
 
     _window_poly6 = staticmethod(_window_poly6)
 
@@ -232,7 +237,9 @@ class ParticleNet(nn.Module):
     # the convolutions run), the host reads it before forward() returns, and on overflow THIS step is redone on the exact
     # CSR path (_forward_impl) and the pitch grows for the next ones — nothing is poisoned, nothing surfaces later.
     def _fused_ok(self, pos, box):
-        lib = _lib.load()
+        lib = self._lib_cached
+        if lib is None:
+            lib = self._lib_cached = _lib.load()
         if getattr(self, "_fused_limits", None) is None:
             mp, mc = ctypes.c_int(), ctypes.c_int()
             lib.nf_trans_prepare_limits(ctypes.byref(mp), ctypes.byref(mc))
@@ -267,26 +274,31 @@ class ParticleNet(nn.Module):
         max_wg = torch.cuda.get_device_properties(dev).multi_processor_count
         sf = ctypes.c_size_t()
         check(lib.nf_cconv_gf_plan(n, 64, max_wg, None, None, None, ctypes.byref(sf)), "nf_cconv_gf_plan")
+        sf.value = max(sf.value, lib.nf_cconv3_workspace_floats(n))      # the last layer's G3 reuses the scratch
         st = dict(key=key, pitch=(pitch_f, pitch_b), max_wg=max_wg,
                   grid_ws=E(lib.nf_grid_workspace_bytes(n, radius, bb), dtype=u8), pos_new=E(n, 3), vel_new=E(n, 3), feats=E(n, 4),
                   counts2=E(2 * n, dtype=i32), idx_f=E(n * pitch_f, dtype=i32), d2_f=E(n * pitch_f),
                   roff=torch.zeros(n * 20, dtype=i16, device=dev), ent=E(n * 4 * pitch_f * 3, dtype=i32),
-                  a0=E(n, 96), a1=E(n, 64), a2=E(n, 64), y3=E(n, 3), scratch=E(sf.value),
-                  # overflow records: rows of a pre-zeroed pool, one per step in turn; a row is written by the device only when
-                  # a count exceeds its pitch (and re-zeroed by the host after it has been read), so no per-step memset
-                  ovf=torch.zeros(8, 2, dtype=i64, device=dev), ovf_host=torch.zeros(8, 2, dtype=i64).pin_memory(),
-                  events=[torch.cuda.Event() for _ in range(8)], step=0, wsig=None, packed=None)
-        for ev in st["events"]:
-            ev.record()                     # materialises the hipEvent_t handle the library records on
+                  a0=E(n, 96), a1=E(n, 64), a1r=E(n, 64), a2=E(n, 64), y3=E(n, 3), scratch=E(sf.value),
+                  # overflow record: the device keeps the largest count above its pitch (atomicMax) and raises two pinned,
+                  # device-visible host words — both written ONLY when a row overflows, re-zeroed by the host after the redo
+                  ovf=torch.zeros(2, dtype=i64, device=dev), flag_host=torch.zeros(4, dtype=i32).pin_memory(),
+                  done=torch.zeros(1, dtype=i32, device=dev), step=0, wsig=None, packed=None, skey=None)
+        st["flag_np"] = st["flag_host"].numpy()
+        st["flag_dev"] = lib.nf_pinned_device_ptr(st["flag_host"].data_ptr())
+        if not st["flag_dev"]:
+            raise RuntimeError("pinned host memory is not mapped into the device address space (nf_pinned_device_ptr)")
         S = _lib.TransStep()
         S.grid_ws, S.grid_ws_bytes = st["grid_ws"].data_ptr(), st["grid_ws"].numel()
-        for k in ("pos_new", "vel_new", "feats", "counts2", "idx_f", "d2_f", "roff", "ent", "a0", "a1", "a2", "y3", "scratch"):
+        for k in ("pos_new", "vel_new", "feats", "counts2", "idx_f", "d2_f", "roff", "ent", "a0", "a1", "a1r", "a2", "y3", "scratch"):
             setattr(S, k, st[k].data_ptr())
+        S.overflow2, S.done_counter = st["ovf"].data_ptr(), st["done"].data_ptr()
         S.n, S.pitch_f, S.pitch_b, S.use_window, S.max_wg = n, pitch_f, pitch_b, int(self.use_window), max_wg
         S.radius, S.extent, S.dt, S.scale = radius, float(self.filter_extent), float(self.time_step), 1.0 / 128
         for d in range(6):
             S.bbox[d] = float(bbox[d])
-        st["S"] = S
+        st["S"], st["Sref"] = S, ctypes.byref(S)
+        st["nns"] = _PitchedNeighbors(st["idx_f"], st["d2_f"], st["counts2"][:n], pitch_f)
         self._fused = st
         return st
 
@@ -298,7 +310,7 @@ class ParticleNet(nn.Module):
         tensors = [c0f.kernel, c0f.bias, c0o.kernel, c0o.bias, d0.weight, d0.bias]
         for conv, dense in zip(self.convs, self.denses):
             tensors += [conv.kernel, conv.bias, dense.weight, dense.bias]
-        sig = tuple((t.data_ptr(), t._version) for t in tensors) + (str(dev),)
+        sig = tuple([t._version for t in tensors] + [t.data_ptr() for t in tensors])
         if st["wsig"] == sig:
             return
         S = st["S"]
@@ -308,12 +320,15 @@ class ParticleNet(nn.Module):
         for li, (conv, dense) in enumerate(zip(self.convs, self.denses)):
             k, bc, w, bd = keep[6 + 4 * li:10 + 4 * li]
             cin, cout = k.shape[-2], k.shape[-1]
+            setattr(S, f"bc{li + 1}", bc.data_ptr())
+            setattr(S, f"bd{li + 1}", bd.data_ptr())
+            if li == 2:                 # the 3-channel layer takes its filter as it is (nf_cconv3_layer)
+                S.k3, S.w3 = k.data_ptr(), w.data_ptr()
+                continue
             wp = torch.empty(lib.nf_cconv_gf_packed_floats(cin, cout), dtype=torch.float32, device=dev)
             check(lib.nf_cconv_gf_pack(ptr(k), ptr(w), cin, cout, ptr(wp), _lib.stream()), "nf_cconv_gf_pack")
             packed.append(wp)
             setattr(S, f"wp{li + 1}", wp.data_ptr())
-            setattr(S, f"bc{li + 1}", bc.data_ptr())
-            setattr(S, f"bd{li + 1}", bd.data_ptr())
         st["wsig"], st["packed"], st["keep"] = sig, packed, keep
 
     def check_capacity(self, wait=False):
@@ -322,43 +337,64 @@ class ParticleNet(nn.Module):
         return None
 
     def _forward_fused(self, pos, vel, box, box_feats):
-        lib = _lib.load()
-        pos = pos.detach().contiguous().float()
-        vel = vel.detach().contiguous().float()
-        box = box.detach().contiguous().float()
-        box_feats = box_feats.detach().contiguous().float()
+        # The host side of a step is on the critical path of a rollout (it must fit behind the ~100 us of GPU work that follow
+        # the front kernel): nothing here allocates or converts unless an input really needs it.
+        lib = self._lib_cached
+        f32 = torch.float32
+        if pos.dtype is not f32 or not pos.is_contiguous():
+            pos = pos.detach().contiguous().float()
+        if vel.dtype is not f32 or not vel.is_contiguous():
+            vel = vel.detach().contiguous().float()
+        if box.dtype is not f32 or not box.is_contiguous():
+            box = box.detach().contiguous().float()
+        if box_feats.dtype is not f32 or not box_feats.is_contiguous():
+            box_feats = box_feats.detach().contiguous().float()
         n, dev = pos.shape[0], pos.device
         st = self._fused_buffers(n, dev, self._scene_bbox(box))
         self._fused_weights(st, dev)
         S = st["S"]
-        bgrid = self._box_grid(box)
-        S.box_grid, S.box_feats = bgrid.ws.data_ptr(), box_feats.data_ptr()
-        g = self._gravity_host()
-        for d in range(3):
-            S.gravity[d] = float(g[d])
-        k = st["step"] % 8
-        st["step"] += 1
-        S.overflow2 = st["ovf"][k].data_ptr()
-        nn = torch.empty(n, dtype=torch.float32, device=dev)
+        skey = (box.data_ptr(), box_feats.data_ptr(), self.gravity._version)
+        if st["skey"] != skey:                 # scene pointers / gravity in the step struct
+            bgrid = self._box_grid(box)
+            S.box_grid, S.box_feats = bgrid.ws.data_ptr(), box_feats.data_ptr()
+            g = self._gravity_host()
+            for d in range(3):
+                S.gravity[d] = float(g[d])
+            st["skey"], st["scene_refs"] = skey, (bgrid, box, box_feats)
+        sid = st["step"] = (st["step"] + 1) & 0x3fffffff or 1
+        nn = torch.empty(n, dtype=f32, device=dev)
         pos_c, vel_c = torch.empty_like(pos), torch.empty_like(pos)
-        ev = st["events"][k]
-        check(lib.nf_trans_step(ctypes.byref(S), ptr(pos), ptr(vel), ptr(nn), ptr(pos_c), ptr(vel_c), st["ovf_host"][k].data_ptr(),
-                                ev.cuda_event, _lib.stream()), "nf_trans_step")
-        ev.synchronize()                    # the record left the device behind the front kernel: the convolutions are still running
-        of, ob = st["ovf_host"][k].tolist()
-        if of or ob:
-            return self._fused_overflow(st, k, of, ob, pos, vel, box, box_feats)
-        cnt_f = st["counts2"][:n]
+        rc = lib.nf_trans_step(st["Sref"], pos.data_ptr(), vel.data_ptr(), nn.data_ptr(), pos_c.data_ptr(), vel_c.data_ptr(),
+                               st["flag_dev"], sid, torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            check(rc, "nf_trans_step")
+        # The front kernel's last workgroup writes `sid` into a pinned word; the host spins on that word (plain memory reads,
+        # no runtime call): the overflow words are final then, and the three convolutions are still to run — the wait costs
+        # no GPU time.  (A HIP event recorded between the launches of one batch completes with the batch.)
+        flag = st["flag_np"]
+        spins = 0
+        while flag[2] != sid and not _DIAG_NO_WAIT:
+            spins += 1
+            if spins > 2000000:                # ~1 s without the word: surface whatever went wrong on the device
+                torch.cuda.synchronize()
+                if flag[2] != sid:
+                    raise RuntimeError("nf_trans_step: the front kernel never reported completion")
+        if flag[0] or flag[1]:
+            return self._fused_overflow(st, pos, vel, box, box_feats)
         self.num_fluid_neighbors = nn
         self._y3 = st["y3"]
-        self.conv0_fluid.nns = _PitchedNeighbors(st["idx_f"], st["d2_f"], cnt_f, st["pitch"][0])
+        nns = st["nns"]
+        nns._csr = None                        # lazily rebuilt view of THIS step's rows
+        self.conv0_fluid.nns = nns
         return pos_c, vel_c, nn
 
-    def _fused_overflow(self, st, k, of, ob, pos, vel, box, box_feats):
+    def _fused_overflow(self, st, pos, vel, box, box_feats):
         """A particle had more neighbours than its row pitch: redo THIS step on the exact CSR path (same results as the
         reference's uncapped search) and let the pitch grow for the following steps (up to what the front kernel stages;
         beyond that the exact path serves the next steps and the fused one is retried later)."""
-        st["ovf"][k].zero_()
+        of, ob = st["ovf"].tolist()            # (syncs: the exact maxima, for the pitch growth)
+        st["ovf"].zero_()
+        st["flag_np"][:2] = 0
         self.fused_overflows = getattr(self, "fused_overflows", 0) + 1
         cap = self._fused_limits[2]
         if self.fused_grow_pitch:

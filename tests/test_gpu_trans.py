@@ -363,7 +363,7 @@ def test_gfree_conv_layer_vs_oracle_and_transform_gather(dev):
         args0 = [dv(k0f), dv(b0f), dv(k0o), dv(b0o), dv(wd0), dv(bd0)]
         check(lib.nf_trans_front(ptr(fgrid.ws), ptr(bgrid.ws), ptr(Pd), ptr(feats4), ptr(bnd), n, radius, extent, 1, pitch_f, pitch_b,
                                  ptr(counts2), ptr(nn), ptr(idx_f), ptr(d2_f), ptr(roff), ptr(ent), *[ptr(t) for t in args0], ptr(a0),
-                                 ptr(ovf), _lib.stream()), "nf_trans_front")
+                                 0, ptr(ovf), None, None, 0, _lib.stream()), "nf_trans_front")
         assert ovf.tolist() == [0, 0]
         # ---- the search and layer 0 against the oracle
         f_idx, f_rs, f_d2 = to.radius_search(P, P, radius, True)
@@ -388,15 +388,25 @@ def test_gfree_conv_layer_vs_oracle_and_transform_gather(dev):
             sf = ctypes.c_size_t()
             check(lib.nf_cconv_gf_plan(n, cout, max_wg, None, None, None, ctypes.byref(sf)), "plan")
             scratch = torch.full((sf.value,), float("nan"), device=dev)          # every slab that is read must have been written
-            y = torch.empty(n, cout, device=dev)
+            y, yr = torch.empty(n, cout, device=dev), torch.empty(n, cout, device=dev)
             check(lib.nf_cconv_gf_layer(ptr(xd), n, cin, cout, 1, ptr(roff), ptr(ent), pitch_f, ptr(wp), ptr(bcd), ptr(bdd),
-                                        ptr(xd) if res else None, ptr(y), ptr(scratch), max_wg, None, None, 0.0, 0.0, None, None,
+                                        ptr(xd) if res else None, ptr(y), ptr(yr), ptr(scratch), max_wg, None, None, 0.0, 0.0, None, None,
                                         _lib.stream()), "nf_cconv_gf_layer")
+            assert torch.equal(yr, torch.relu(y))
             xr = torch.relu(x)
             ref = to.cconv(xr, P, P, extent, K, bc, f_idx, f_rs, f_d2) + torch.nn.functional.linear(xr, W, bd) + (x if res else 0)
             torch.testing.assert_close(y.cpu(), ref, rtol=1e-4, atol=2e-5)
             old = cconv_layer(xd, Kd, bcd, Wd, bdd, rsd, idxd, pw, pc, relu=True, residual=xd if res else None)
             torch.testing.assert_close(y, old, rtol=1e-4, atol=2e-5)
+            if cout == 3:           # the step's own last layer: transform (G3) + gather over the row entries + update
+                wsp = torch.empty(lib.nf_cconv3_workspace_floats(n), device=dev)
+                y3, pc3, vc3 = torch.empty(n, 3, device=dev), torch.empty(n, 3, device=dev), torch.empty(n, 3, device=dev)
+                pos0 = dv(P + 0.01)
+                check(lib.nf_cconv3_layer(ptr(dv(xr)), n, ptr(roff), ptr(ent), pitch_f, ptr(Kd), ptr(Wd), ptr(bcd), ptr(bdd), ptr(wsp),
+                                          ptr(y3), ptr(pos0), ptr(Pd), 1.0 / 128, 0.02, ptr(pc3), ptr(vc3), _lib.stream()), "nf_cconv3_layer")
+                torch.testing.assert_close(y3.cpu(), ref, rtol=1e-4, atol=2e-5)
+                torch.testing.assert_close(pc3, Pd + y3 / 128, rtol=0, atol=1e-7)
+                torch.testing.assert_close(vc3, (pc3 - pos0) / 0.02, rtol=0, atol=1e-5)
 
 
 def test_fused_inference_step_vs_multi_launch_path(dev):

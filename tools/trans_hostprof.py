@@ -18,6 +18,21 @@ with torch.no_grad():
     th = time.perf_counter() - t
     torch.cuda.synchronize(); tt = time.perf_counter() - t
     print(f"host enqueue {th/200*1e6:.1f} us/step, wall {tt/200*1e6:.1f} us/step")
+    # the C call alone (8 launches + event record), GPU idle before each call
+    import ctypes
+    from neurofluid_amd import _lib
+    st = pn._fused
+    lib = _lib.load()
+    nn = torch.empty(P0.shape[0], device=dev); pc, vc = torch.empty_like(pos), torch.empty_like(pos)
+    ts = []
+    for _ in range(50):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        lib.nf_trans_step(st["Sref"], pos.data_ptr(), vel.data_ptr(), nn.data_ptr(), pc.data_ptr(), vc.data_ptr(), st["flag_dev"],
+                          12345, torch.cuda.current_stream().cuda_stream)
+        ts.append(time.perf_counter() - t)
+    torch.cuda.synchronize()
+    print(f"nf_trans_step host time: median {sorted(ts)[25]*1e6:.1f} us")
     pr = cProfile.Profile(); pr.enable()
     for _ in range(200): pos, vel, _ = pn(pos, vel, box, bn)
     pr.disable(); torch.cuda.synchronize()

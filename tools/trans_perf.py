@@ -1,4 +1,5 @@
-"""Timing of ParticleNet.forward alone on the synthetic watercube (dev tool): particle-steps/s."""
+"""Timing of ParticleNet.forward alone on the synthetic watercube (dev tool): particle-steps/s.
+usage: tools/trans_perf.py [steps] [unfused]"""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -22,4 +23,4 @@ for it in range(3):
         for _ in range(steps):
             pos, vel, _ = pn(pos, vel, box, bn)
     torch.cuda.synchronize(); dt = time.time() - t
-    print(f"iter {it}: {dt/steps*1e6:.1f} us/step, {P0.shape[0]*steps/dt/1e6:.2f} M particle-steps/s")
+    print(f"iter {it}: {dt/steps*1e6:.1f} us/step, {P0.shape[0]*steps/dt/1e6:.2f} M particle-steps/s  overflows {getattr(pn, 'fused_overflows', 0)}")

@@ -390,23 +390,31 @@ int nf_trans_front(const void* fluid_grid, const void* box_grid, const float* qu
 void* nf_pinned_device_ptr(void* host_ptr /*[host] page-locked*/);
 size_t nf_cconv_gf_packed_floats(int cin, int cout);
 int nf_cconv_gf_pack(const float* kernel, const float* dense_w, int cin, int cout, float* packed, nf_stream_t stream);
+/* split-precision form of the same contraction (nf_cconv_gf_layer(split = 1)): every operand as hi + lo fp16, three fp16 MFMAs
+ * per product block, fp32 accumulate — fp32-LEVEL accuracy (products carry 22 bits) on the fp16 matrix pipe, which, unlike the
+ * fp32 MFMA on gfx950, does not share its ALUs with the gather arithmetic.  Not the reference's arithmetic: opt-in. */
+size_t nf_cconv_gf_packed_split_bytes(int cin, int cout);
+int nf_cconv_gf_pack_split(const float* kernel, const float* dense_w, int cin, int cout, void* packed, nf_stream_t stream);
 int nf_cconv_gf_plan(int n, int cout, int max_wg, int* tiles, int* nwg, int* maxseg, size_t* scratch_floats);
 int nf_cconv_gf_layer(const float* x, int n, int cin, int cout, int relu, const uint16_t* roff, const uint32_t* entries,
-                      int pitch, const float* packed, const float* bias_conv, const float* bias_dense,
+                      int pitch, const void* packed, int split /* 0: fp32 MFMA, packed = nf_cconv_gf_pack; 1: nf_cconv_gf_pack_split */,
+                      const float* bias_conv, const float* bias_dense,
                       const float* residual, float* out /*or NULL*/, float* out_relu /*max(y, 0), or NULL*/, float* scratch,
                       int max_wg, const float* pos,
                       const float* pos_new, float scale, float dt, float* pos_c, float* vel_c, nf_stream_t stream);
 /* The 3-channel last layer (conv3 + dense3, :121-131 at i = 3, and the update of :141-148): transform (G3[j][node][co], 780 bytes
  * per particle) then gather over the row entries.  x_act = relu(a2) (n x 64); workspace = nf_cconv3_workspace_floats(n). */
 size_t nf_cconv3_workspace_floats(int n);
-int nf_cconv3_layer(const float* x_act, int n, const uint16_t* roff, const uint32_t* entries, int pitch, const float* kernel,
-                    const float* dense_w, const float* bias_conv, const float* bias_dense, float* workspace, float* y3,
+size_t nf_cconv3_packed_floats(void);
+int nf_cconv3_pack(const float* kernel /*(4,4,4,64,3)*/, const float* dense_w /*(3,64)*/, float* packed, nf_stream_t stream);
+int nf_cconv3_layer(const float* x_act, int n, const uint16_t* roff, const uint32_t* entries, int pitch, const float* packed,
+                    const float* bias_conv, const float* bias_dense, float* workspace, float* y3,
                     const float* pos /*or NULL: no update*/, const float* pos_new, float scale, float dt, float* pos_c,
                     float* vel_c, nf_stream_t stream);
 typedef struct {
     /* model (device pointers; wpK = nf_cconv_gf_pack of convK / denseK) */
     const float *k_fluid, *b_fluid, *k_obst, *b_obst, *dense0_w, *dense0_b;
-    const float *wp1, *bc1, *bd1, *wp2, *bc2, *bd2, *k3 /*conv3.kernel*/, *w3 /*dense3.weight*/, *bc3, *bd3;
+    const void *wp1; const float *bc1, *bd1; const void *wp2; const float *bc2, *bd2, *wp3 /*nf_cconv3_pack*/, *bc3, *bd3;
     /* scene */
     const void* box_grid; const float* box_feats;
     /* workspace of one particle count */
@@ -417,6 +425,7 @@ typedef struct {
     int n, pitch_f, pitch_b, use_window, max_wg;
     float radius, extent, dt, scale;
     float gravity[3]; float bbox[6];
+    int split;          /* arithmetic of conv1 / conv2: 0 fp32 MFMA (wp1, wp2 from nf_cconv_gf_pack), 1 split fp16 (.._pack_split) */
 } nf_trans_step_t;
 int nf_trans_step(const nf_trans_step_t* s /*[host]*/, const float* pos, const float* vel, float* num_fluid_nbrs, float* pos_c,
                   float* vel_c, int32_t* host_flag3 /* see nf_trans_front */, int step_id, nf_stream_t stream);

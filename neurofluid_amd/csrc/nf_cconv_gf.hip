@@ -26,13 +26,18 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 #define GF_TILE 32
 #define GF_UNITS 17            // 16 rows of 4 filter nodes + the Linear branch
 #define GF_COST 65             // filter nodes per tile, Linear branch included
-#define GF_THREADS 512
+#define GF_PWAVES 4             // producer waves (8 were measured: no gain on the 64-channel layer, spills on the 96-channel one)
+#define GF_THREADS (256 + 64 * GF_PWAVES)
 #define GF_ROFF_PITCH 20       // uint16 per particle (17 used)
-#define GF_SLOTS 4             // entry slots per producer thread: 8 threads x 4 = 32 entries of a (point, row) list prefetched
+#define GF_TPP (2 * GF_PWAVES)   // producer threads per output point
+#define GF_SLOTS (32 / GF_TPP)  // entry slots per producer thread: 32 entries of a (point, row) list are prefetched
 
 struct GfArgs {
     const float* x;            // (n x CIN) features of the previous layer (ReLU applied on load when relu)
@@ -55,20 +60,28 @@ __device__ __host__ __forceinline__ int gf_begin(int w, int nwg, int ctot)
 }
 __device__ __host__ __forceinline__ int gf_owner(long long cost, int nwg, int ctot) { return (int)(cost * nwg / ctot); }
 
-// broadcast inside groups of 8 lanes: every lane reads lane (lane & ~7) | K
-template <int K>
-__device__ __forceinline__ int gf_bcast8(int v) { return __builtin_amdgcn_ds_swizzle(v, 0x18 | (K << 5)); }
 
-template <int CIN, int NB, bool RELU>
+// SPLIT = false: the contraction in fp32 (v_mfma_f32_32x32x2_f32: exact fp32 products and sums, the reference's arithmetic).
+// SPLIT = true:  every operand as hi + lo fp16 (z = zh + zl, 22 significant bits), three v_mfma_f32_32x32x16_f16 per product
+//                block (zh wh + zh wl + zl wh), fp32 accumulate — fp32-LEVEL accuracy (the dropped zl wl term is < 2^-22
+//                relative) on the fp16 matrix pipe.  On gfx950 the fp32 MFMA runs at the fp32 VECTOR rate, i.e. on the same
+//                ALUs as the producers' gather arithmetic (measured: producer-only 45 us + consumer-only 44 us = 81 us together,
+//                no overlap at all); the fp16 matrix pipe is a separate unit, 16x faster, and does overlap.
+template <int CIN, int NB, bool RELU, bool SPLIT>
 __global__ void __launch_bounds__(GF_THREADS) k_cconv_gf(GfArgs A)
 {
     constexpr int PITCH = CIN + 4;             // floats per Z row: (CIN + 4) / 4 odd -> ds_read_b128 of 16 rows conflict-free
     constexpr int ZC = GF_TILE * PITCH;        // one filter node
     constexpr int ZB = 4 * ZC;                 // one buffer (4 nodes)
-    constexpr int NQ = CIN / 32;               // 16-byte quads of an x row per producer thread (8 threads per point)
+    constexpr int NQ = (CIN / 4 + GF_TPP - 1) / GF_TPP;   // 16-byte quads of an x row per producer thread (16 threads per point; at
+                                               // CIN = 96 the second quad exists for the first 8 threads of a point only)
     constexpr int QW = CIN / 32;               // quad-groups (4 K-steps each) per consumer wave and node
     constexpr int COUTP = 32 * NB;
-    extern __shared__ float Z[];               // 2 * ZB floats
+    // split layout (halves): per buffer [hi: 4 nodes][lo: 4 nodes], a node = 32 rows of CIN + 8 halves (208 / 144 bytes:
+    // 16-byte aligned, and 13 / 9 x 16 bytes -> the ds_read_b128 of 16 rows fall on distinct banks)
+    constexpr int PH = CIN + 8, ZCH = GF_TILE * PH, ZLO = 4 * ZCH, ZBH = 2 * ZLO;
+    extern __shared__ float Z[];               // fp32: 2 * ZB floats; split: 2 * ZBH halves
+    _Float16* const Zh16 = (_Float16*)Z;
 
     // the arguments as plain locals (a by-value struct whose address reaches a lambda is kept — and re-read — in scratch memory)
     const float* const a_x = A.x;
@@ -86,6 +99,86 @@ __global__ void __launch_bounds__(GF_THREADS) k_cconv_gf(GfArgs A)
 
     if (wave < 4) {
         // ------------------------------------------------------------------ consumers
+      if constexpr (SPLIT) {
+        constexpr int KS = CIN / 16, KP = 4 / NB, SP = KS / KP;      // K-steps per node; K parts; K-steps of this wave per node
+        static_assert(KS % KP == 0, "the K-steps of a node must split evenly over the waves of an N-block");
+        const int nbw = wave % NB, kp = wave / NB, m = lane & 31, h = lane >> 5;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const h8* wp8 = (const h8*)a_wp;
+        h8 Bh[2][SP], Bl[2][SP], Ah[2][SP], Al[2][SP];
+        auto load_b = [&](int node, h8 (&bh)[SP], h8 (&bl)[SP]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int si = 0; si < SP; ++si) {
+                const size_t base = ((size_t)((node * KS + kp * SP + si) * NB + nbw) * 2) * 64 + lane;
+                bh[si] = wp8[base];
+                bl[si] = wp8[base + 64];
+            }
+        };
+        auto load_a = [&](const _Float16* Zc, h8 (&ah)[SP], h8 (&al)[SP]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int si = 0; si < SP; ++si) {
+                ah[si] = *(const h8*)(Zc + 16 * (kp * SP + si));
+                al[si] = *(const h8*)(Zc + ZLO + 16 * (kp * SP + si));
+            }
+        };
+        auto mma = [&](const h8 (&ah)[SP], const h8 (&al)[SP], const h8 (&bh)[SP], const h8 (&bl)[SP]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int si = 0; si < SP; ++si) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[si], bh[si], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[si], bl[si], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[si], bh[si], acc, 0, 0, 0);
+            }
+        };
+        auto first_node = [&](int g) __attribute__((always_inline)) { const int u = g % GF_UNITS; return u < 16 ? 4 * u : 64; };
+        auto run_unit = [&](auto par, auto ncells, const _Float16* Zb, int cell0, int next_node) __attribute__((always_inline)) {
+            constexpr int P0 = decltype(par)::value, NC = decltype(ncells)::value;
+            load_a(Zb, Ah[P0], Al[P0]);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int cur = (P0 + c) & 1, nx = cur ^ 1;
+                const int nxt = c + 1 < NC ? cell0 + c + 1 : next_node;
+                if (c + 1 < NC) load_a(Zb + (c + 1) * ZCH, Ah[nx], Al[nx]);
+                if (nxt >= 0) load_b(nxt, Bh[nx], Bl[nx]);
+#ifndef GF_AB_NO_MFMA
+                mma(Ah[cur], Al[cur], Bh[cur], Bl[cur]);
+#endif
+            }
+        };
+        int parity = 0;
+        if (nun > 0) load_b(first_node(g0), Bh[0], Bl[0]);
+        for (int p = 0; p <= nun; ++p) {
+            if (p >= 1) {
+                const int g = g0 + p - 1, tile = g / GF_UNITS, u = g - tile * GF_UNITS;
+                const _Float16* Zb = Zh16 + ((p - 1) & 1) * ZBH + m * PH + 8 * h;
+                const int next_node = p < nun ? first_node(g + 1) : -1;
+                if (u < 16) {
+                    if (parity == 0) run_unit(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{}, Zb, 4 * u, next_node);
+                    else run_unit(std::integral_constant<int, 1>{}, std::integral_constant<int, 4>{}, Zb, 4 * u, next_node);
+                } else {
+                    if (parity == 0) run_unit(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, Zb, 64, next_node);
+                    else run_unit(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, Zb, 64, next_node);
+                    parity ^= 1;
+                }
+                const bool last_of_tile = (p == nun) || ((g + 1) / GF_UNITS != tile);
+                if (last_of_tile) {
+                    // partial slab of (tile, segment, wave): the wave's N-block [32 cols][32 rows], its share of K
+                    const int seg = w - gf_owner((long long)tile * GF_COST, a_nwg, a_ctot);
+                    float* slab = a_scratch + ((size_t)(tile * a_maxseg + seg) * 4 + wave) * (32 * GF_TILE);
+#pragma unroll
+                    for (int gr = 0; gr < 4; ++gr) {
+                        const float4 v = make_float4(acc[4 * gr], acc[4 * gr + 1], acc[4 * gr + 2], acc[4 * gr + 3]);
+                        *(float4*)(slab + m * GF_TILE + 8 * gr + 4 * h) = v;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                }
+            }
+            __syncthreads();
+        }
+        return;
+      } else {
         const int kq = wave, m = lane & 31, h = lane >> 5;
         f32x16 acc[NB];
 #pragma unroll
@@ -176,10 +269,15 @@ __global__ void __launch_bounds__(GF_THREADS) k_cconv_gf(GfArgs A)
             __syncthreads();
         }
         return;
+      }
     }
 
     // ---------------------------------------------------------------------- producers
-    const int pt = threadIdx.x - 256, pp = pt >> 3, t = pt & 7;          // (lane = threadIdx.x & 63 as for the consumers)
+    // 8 producer waves = 2 per SIMD (next to a consumer wave): the gather is bound by the loads a wave keeps in flight times the L2
+    // latency, and by the wave's issue rate — twice the waves double both (4 waves, 8 threads per point: 45 us for conv1's gather
+    // alone, whatever was done to the instruction stream)
+    const int pt = threadIdx.x - 256, pp = pt / GF_TPP, t = pt % GF_TPP;      // (lane = threadIdx.x & 63 as for the consumers)
+    auto has_quad = [&](int k) __attribute__((always_inline)) { return t + GF_TPP * k < CIN / 4; };
     auto load_roff = [&](int g, int& e0, int& e1) __attribute__((always_inline)) {
         const int tile = g / GF_UNITS, u = g - tile * GF_UNITS, i = tile * GF_TILE + pp;
         e0 = e1 = 0;
@@ -203,15 +301,15 @@ __global__ void __launch_bounds__(GF_THREADS) k_cconv_gf(GfArgs A)
         const int tl_ = (G) / GF_UNITS, ii_ = min(tl_ * GF_TILE + pp, a_n - 1);                                 \
         const uint32_t* eb_ = a_ent + (size_t)ii_ * (size_t)(4 * a_pitch) * 3;                                  \
         P##e0 = (E0); P##cnt = (E1) - (E0);                                                                     \
-        load_one(eb_, P##e0, P##cnt, t, P##j0, P##a0, P##b0);                                                   \
-        load_one(eb_, P##e0, P##cnt, 8 + t, P##j1, P##a1, P##b1);                                               \
-        load_one(eb_, P##e0, P##cnt, 16 + t, P##j2, P##a2, P##b2);                                              \
-        load_one(eb_, P##e0, P##cnt, 24 + t, P##j3, P##a3, P##b3);                                              \
+        _Pragma("unroll") for (int sl_ = 0; sl_ < GF_SLOTS; ++sl_)                                              \
+            load_one(eb_, P##e0, P##cnt, GF_TPP * sl_ + t, P##j[sl_], P##a[sl_], P##b[sl_]);                     \
     } while (0)
 
-    int cj0 = 0, cj1 = 0, cj2 = 0, cj3 = 0, nj0 = 0, nj1 = 0, nj2 = 0, nj3 = 0;
-    float ca0 = 0.f, ca1 = 0.f, ca2 = 0.f, ca3 = 0.f, cb0 = 0.f, cb1 = 0.f, cb2 = 0.f, cb3 = 0.f;       // a = w(cx), b = w(cx + 1)
-    float na0 = 0.f, na1 = 0.f, na2 = 0.f, na3 = 0.f, nb0 = 0.f, nb1 = 0.f, nb2 = 0.f, nb3 = 0.f;
+    // (register arrays indexed by compile-time constants only)
+    int cj[GF_SLOTS], nj[GF_SLOTS];
+    float ca[GF_SLOTS], cb[GF_SLOTS], na[GF_SLOTS], nb[GF_SLOTS];       // a = w(cx), b = w(cx + 1)
+#pragma unroll
+    for (int q = 0; q < GF_SLOTS; ++q) { cj[q] = nj[q] = 0; ca[q] = cb[q] = na[q] = nb[q] = 0.f; }
     int ccnt = 0, ce0 = 0, ncnt = 0, ne0 = 0;
     int r1a = 0, r1b = 0, r2a = 0, r2b = 0;
     if (nun > 0) {
@@ -228,14 +326,28 @@ __global__ void __launch_bounds__(GF_THREADS) k_cconv_gf(GfArgs A)
             if (p + 2 < nun) load_roff(g + 2, r2a, r2b);
             if (p + 1 < nun) GF_LOAD_ENTRIES(g + 1, r1a, r1b, n); else ncnt = ne0 = 0;
             float* Zb = Z + (p & 1) * ZB + pp * PITCH;
+            _Float16* Zbh = Zh16 + (p & 1) * ZBH + pp * PH;
+            // a finished quad of Z: fp32 as it is, or split into hi = fp16(z) and lo = fp16(z - hi)
+            auto put_z = [&](int c, int k, float zx, float zy, float zz, float zw) __attribute__((always_inline)) {
+                if (!has_quad(k)) return;
+                if constexpr (SPLIT) {
+                    const f32x4v v = {zx, zy, zz, zw};
+                    const h4 hi = __builtin_convertvector(v, h4);
+                    const h4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4v), h4);
+                    *(h4*)(Zbh + c * ZCH + 4 * (t + GF_TPP * k)) = hi;
+                    *(h4*)(Zbh + ZLO + c * ZCH + 4 * (t + GF_TPP * k)) = lo;
+                } else {
+                    *(float4*)(Zb + c * ZC + 4 * (t + GF_TPP * k)) = make_float4(zx, zy, zz, zw);
+                }
+            };
             if (u == 16) {
                 // Linear branch: Z = relu(x_i)
 #pragma unroll
                 for (int k = 0; k < NQ; ++k) {
                     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (i < a_n) v = *(const float4*)(a_x + (size_t)i * CIN + 4 * (t + 8 * k));
+                    if (i < a_n && has_quad(k)) v = *(const float4*)(a_x + (size_t)i * CIN + 4 * (t + GF_TPP * k));
                     if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                    *(float4*)(Zb + 4 * (t + 8 * k)) = v;
+                    put_z(0, k, v.x, v.y, v.z, v.w);
                 }
             } else {
                 struct Acc4 { f32x2 lo, hi; };
@@ -268,59 +380,73 @@ __global__ void __launch_bounds__(GF_THREADS) k_cconv_gf(GfArgs A)
                     }
                 };
                 struct XS { int jc; float w0, w1; float4 xv[NQ]; };
-                // entry E (a compile-time index: the loop below is fully unrolled, so slot and source lane are constants —
-                // a run-time slot choice among the 12 entry registers is turned into a table in scratch memory by the compiler)
-                auto issue = [&](auto ec, XS& S) __attribute__((always_inline)) {
-                    constexpr int E = decltype(ec)::value, SL = E >> 3;
-                    const int src = (lane & ~7) | (E & 7);
-                    const int jcS = SL == 0 ? cj0 : (SL == 1 ? cj1 : (SL == 2 ? cj2 : cj3));
-                    const float w0S = SL == 0 ? ca0 : (SL == 1 ? ca1 : (SL == 2 ? ca2 : ca3));
-                    const float w1S = SL == 0 ? cb0 : (SL == 1 ? cb1 : (SL == 2 ? cb2 : cb3));
-                    int jc = __shfl(jcS, src, 64);
-                    float w0 = __shfl(w0S, src, 64), w1 = __shfl(w1S, src, 64);
+                struct TB { int jc; float w0, w1; };
+                // Entry E (a compile-time index: the loop below is fully unrolled, so slot and source lane are constants — a
+                // run-time slot choice among the 12 entry registers is turned into a table in scratch memory by the compiler).
+                // The 8 threads of a point hold entries e0 + 8 s + t; bcast() fetches entry E's record from its owner inside the
+                // point's 8 lanes (three ds_bpermute), ONE STEP before request() turns it into the x-row loads — the LDS round trip
+                // hides behind the accumulation in between instead of stalling every request.
+                auto bcast = [&](auto ec, TB& T) __attribute__((always_inline)) {
+                    constexpr int E = decltype(ec)::value, SL = E / GF_TPP;
+                    const int src = (lane & ~(GF_TPP - 1)) | (E & (GF_TPP - 1));
+                    const int jcS = cj[SL];
+                    const float w0S = ca[SL];
+                    const float w1S = cb[SL];
+                    const int jc = __shfl(jcS, src, 64);
+                    const float w0 = __shfl(w0S, src, 64), w1 = __shfl(w1S, src, 64);
                     const bool ok = E < cnt;
-                    const int j = ok ? (jc & 0x3fffffff) : isafe;
-                    S.jc = ok ? jc : 0; S.w0 = ok ? w0 : 0.f; S.w1 = ok ? w1 : 0.f;
+                    T.jc = ok ? jc : 0; T.w0 = ok ? w0 : 0.f; T.w1 = ok ? w1 : 0.f;      // masked: row 0, zero weights
+                };
+                auto request = [&](const TB& T, XS& S) __attribute__((always_inline)) {
+                    S.jc = T.jc; S.w0 = T.w0; S.w1 = T.w1;
+                    const int j = T.jc & 0x3fffffff;
 #pragma unroll
-                    for (int k = 0; k < NQ; ++k) S.xv[k] = *(const float4*)(a_x + (size_t)j * CIN + 4 * (t + 8 * k));
+                    for (int k = 0; k < NQ; ++k) {
+                        S.xv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (has_quad(k)) S.xv[k] = *(const float4*)(a_x + (size_t)j * CIN + 4 * (t + GF_TPP * k));
+                    }
                 };
                 int wmax = cnt;                                   // the longest list among the wave's 8 points
 #pragma unroll
-                for (int o = 8; o <= 32; o <<= 1) wmax = max(wmax, __shfl_xor(wmax, o, 64));
-                // FOUR entries in flight: a slot is refilled (broadcast + x-row request of the entry four ahead) right after its
-                // entry has been accumulated.  Straight-line code with early exits (every group of 4 is unconditional inside:
-                // an entry past a point's own list is a masked request to a valid row with zero weights) — with conditional
-                // requests the compiler can no longer count the loads in flight and waits for ALL of them before every use.
+                for (int o = GF_TPP; o <= 32; o <<= 1) wmax = max(wmax, __shfl_xor(wmax, o, 64));
+                // FOUR entries in flight: a slot is refilled (x-row request of the entry four ahead) right after its entry has
+                // been accumulated.  Straight-line groups of 4 with early exits on a SCALAR trip count; inside a group nothing is
+                // conditional (an entry past a point's own list is a masked request) — with conditional requests the compiler can
+                // no longer count the loads in flight and waits for ALL of them before every use.
 #ifdef GF_AB_NO_GATHER
                 const int ne4 = 0;
 #else
-                const int ne4 = (min(wmax, GF_SLOTS * 8) + 3) & ~3;
+                const int ne4 = __builtin_amdgcn_readfirstlane((min(wmax, GF_SLOTS * GF_TPP) + 3) & ~3);
 #endif
                 XS S0, S1, S2, S3;
+                TB T0, T1;
                 if (ne4 > 0) {
-                    issue(std::integral_constant<int, 0>{}, S0); issue(std::integral_constant<int, 1>{}, S1);
-                    issue(std::integral_constant<int, 2>{}, S2); issue(std::integral_constant<int, 3>{}, S3);
+                    bcast(std::integral_constant<int, 0>{}, T0); bcast(std::integral_constant<int, 1>{}, T1);
+                    request(T0, S0); request(T1, S1);
+                    bcast(std::integral_constant<int, 2>{}, T0); bcast(std::integral_constant<int, 3>{}, T1);
+                    request(T0, S2); request(T1, S3);
+                    bcast(std::integral_constant<int, 4>{}, T0);
                 }
-#define GF_GROUP(E)                                                                                                      \
-                if (ne4 > (E)) {                                                                                         \
-                    add_entry(S0.jc, S0.w0, S0.w1, S0.xv);                                                               \
-                    if ((E) + 4 < GF_SLOTS * 8) issue(std::integral_constant<int, ((E) + 4) % (GF_SLOTS * 8)>{}, S0);     \
-                    add_entry(S1.jc, S1.w0, S1.w1, S1.xv);                                                               \
-                    if ((E) + 5 < GF_SLOTS * 8) issue(std::integral_constant<int, ((E) + 5) % (GF_SLOTS * 8)>{}, S1);     \
-                    add_entry(S2.jc, S2.w0, S2.w1, S2.xv);                                                               \
-                    if ((E) + 6 < GF_SLOTS * 8) issue(std::integral_constant<int, ((E) + 6) % (GF_SLOTS * 8)>{}, S2);     \
-                    add_entry(S3.jc, S3.w0, S3.w1, S3.xv);                                                               \
-                    if ((E) + 7 < GF_SLOTS * 8) issue(std::integral_constant<int, ((E) + 7) % (GF_SLOTS * 8)>{}, S3);
+                // step E: accumulate entry E, re-use its slot for the request of entry E + 4 (record broadcast one step ago),
+                // broadcast the record of entry E + 5
+#define GF_STEP(E, S, TC, TN)                                                                                             \
+                    add_entry(S.jc, S.w0, S.w1, S.xv);                                                                    \
+                    if ((E) + 4 < GF_SLOTS * GF_TPP) request(TC, S);                                                           \
+                    if ((E) + 5 < GF_SLOTS * GF_TPP) bcast(std::integral_constant<int, ((E) + 5) % (GF_SLOTS * GF_TPP)>{}, TN);
+#define GF_GROUP(E)                                                                                                       \
+                if (ne4 > (E)) {                                                                                          \
+                    GF_STEP((E), S0, T0, T1) GF_STEP((E) + 1, S1, T1, T0) GF_STEP((E) + 2, S2, T0, T1) GF_STEP((E) + 3, S3, T1, T0)
                 GF_GROUP(0) GF_GROUP(4) GF_GROUP(8) GF_GROUP(12) GF_GROUP(16) GF_GROUP(20) GF_GROUP(24) GF_GROUP(28)
                 }}}}}}}}
 #undef GF_GROUP
-                if (__any(cnt > GF_SLOTS * 8)) {
+#undef GF_STEP
+                if (__any(cnt > GF_SLOTS * GF_TPP)) {
                     // rows with more than 32 entries (rare): the tail straight from the list, one entry at a time
                     const uint32_t* eb = a_ent + (size_t)isafe * (size_t)(4 * a_pitch) * 3;
                     int emax = cnt;
 #pragma unroll
-                    for (int o = 8; o <= 32; o <<= 1) emax = max(emax, __shfl_xor(emax, o, 64));
-                    for (int e = GF_SLOTS * 8; e < emax; ++e) {
+                    for (int o = GF_TPP; o <= 32; o <<= 1) emax = max(emax, __shfl_xor(emax, o, 64));
+                    for (int e = GF_SLOTS * GF_TPP; e < emax; ++e) {
                         const bool ok = e < cnt;
                         const uint32_t* src = eb + 3 * (size_t)(ce0 + (ok ? e : 0));
                         int jc = ok ? (int)src[0] : 0;
@@ -328,18 +454,20 @@ __global__ void __launch_bounds__(GF_THREADS) k_cconv_gf(GfArgs A)
                         const int j = ok ? (jc & 0x3fffffff) : isafe;
                         float4 xv[NQ];
 #pragma unroll
-                        for (int k = 0; k < NQ; ++k) xv[k] = *(const float4*)(a_x + (size_t)j * CIN + 4 * (t + 8 * k));
+                        for (int k = 0; k < NQ; ++k) {
+                            xv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                            if (has_quad(k)) xv[k] = *(const float4*)(a_x + (size_t)j * CIN + 4 * (t + GF_TPP * k));
+                        }
                         add_entry(jc, w0, w1, xv);
                     }
                 }
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
 #pragma unroll
-                    for (int k = 0; k < NQ; ++k)
-                        *(float4*)(Zb + c * ZC + 4 * (t + 8 * k)) = make_float4(acc[c][k].lo.x, acc[c][k].lo.y, acc[c][k].hi.x, acc[c][k].hi.y);
+                    for (int k = 0; k < NQ; ++k) put_z(c, k, acc[c][k].lo.x, acc[c][k].lo.y, acc[c][k].hi.x, acc[c][k].hi.y);
             }
-            cj0 = nj0; cj1 = nj1; cj2 = nj2; cj3 = nj3; ca0 = na0; ca1 = na1; ca2 = na2; ca3 = na3;
-            cb0 = nb0; cb1 = nb1; cb2 = nb2; cb3 = nb3;
+#pragma unroll
+            for (int q = 0; q < GF_SLOTS; ++q) { cj[q] = nj[q]; ca[q] = na[q]; cb[q] = nb[q]; }
             ccnt = ncnt; ce0 = ne0;
             r1a = r2a; r1b = r2b;
         }
@@ -352,7 +480,7 @@ __global__ void __launch_bounds__(GF_THREADS) k_cconv_gf(GfArgs A)
 // bias (+ residual); for the last layer (cout = 3) also pos_correction = y / 128 and update_pos_vel (models/transmodel.py:141-148)
 // ------------------------------------------------------------------------------------------------
 struct GfEpi {
-    const float* scratch; int tiles, nwg, maxseg, ctot, coutp, cout, n;
+    const float* scratch; int tiles, nwg, maxseg, ctot, coutp, cout, n, split;
     const float* bias_c; const float* bias_d; const float* residual; float* out;
     float* out_relu;          // optional: max(y, 0), what the next layer gathers (so that it need not apply the ReLU per gathered row)
     const float* pos; const float* pos_new; float* pos_c; float* vel_c; float scale, dt;       // pos == null: no update
@@ -366,16 +494,25 @@ __global__ void __launch_bounds__(256) k_cconv_gf_epi(GfEpi E)
     const int col = blockIdx.y * 8 + (threadIdx.x >> 5), row = threadIdx.x & 31, i = tile * GF_TILE + row;
     if (col >= E.cout || i >= E.n) return;
     const int wfirst = gf_owner((long long)tile * GF_COST, E.nwg, E.ctot), wlast = gf_owner((long long)tile * GF_COST + 64, E.nwg, E.ctot);
-    const int nq = (wlast - wfirst + 1) * 4;
-    const int slab = E.coutp * GF_TILE;
-    const float* s = E.scratch + (size_t)tile * E.maxseg * 4 * slab + col * GF_TILE + row;
+    const int nseg = wlast - wfirst + 1;
     float v = 0.f;
-    int q = 0;
-    for (; q + 4 <= nq; q += 4) {
-        const float p0 = s[(size_t)q * slab], p1 = s[(size_t)(q + 1) * slab], p2 = s[(size_t)(q + 2) * slab], p3 = s[(size_t)(q + 3) * slab];
-        v += p0; v += p1; v += p2; v += p3;                  // segment-major, K-quarter-minor: a fixed order
+    if (E.split) {
+        // slabs [tile][segment][wave][32 cols][32 rows]; wave = K-part * NB + N-block: the K-parts of this column's N-block
+        const int nb_ = E.coutp / 32, kparts = 4 / nb_, slab = 32 * GF_TILE;
+        const float* s = E.scratch + (size_t)tile * E.maxseg * 4 * slab + (col & 31) * GF_TILE + row;
+        for (int sg = 0; sg < nseg; ++sg)
+            for (int kp = 0; kp < kparts; ++kp) v += s[(size_t)(sg * 4 + kp * nb_ + (col >> 5)) * slab];
+    } else {
+        const int nq = nseg * 4;
+        const int slab = E.coutp * GF_TILE;
+        const float* s = E.scratch + (size_t)tile * E.maxseg * 4 * slab + col * GF_TILE + row;
+        int q = 0;
+        for (; q + 4 <= nq; q += 4) {
+            const float p0 = s[(size_t)q * slab], p1 = s[(size_t)(q + 1) * slab], p2 = s[(size_t)(q + 2) * slab], p3 = s[(size_t)(q + 3) * slab];
+            v += p0; v += p1; v += p2; v += p3;                  // segment-major, K-quarter-minor: a fixed order
+        }
+        for (; q < nq; ++q) v += s[(size_t)q * slab];
     }
-    for (; q < nq; ++q) v += s[(size_t)q * slab];
     v += E.bias_c[col] + E.bias_d[col];
     if (E.residual) v += E.residual[(size_t)i * E.cout + col];
     if (E.out) E.out[(size_t)i * E.cout + col] = v;
@@ -406,6 +543,44 @@ __global__ void __launch_bounds__(256) k_cconv_gf_pack(const float* __restrict__
     float v = 0.f;
     if (co < cout) v = c < 64 ? kernel[((size_t)c * cin + ci) * cout + co] : dense_w[(size_t)co * cin + ci];
     wp[id] = v;
+}
+
+// split packing: halves[((((c * KS + s) * NB + nb) * 2 + hl) * 64 + lane) * 8 + e] = hi / lo (hl = 0 / 1) of
+// W[c][ci = 16 s + 8 (lane >> 5) + e][co = 32 nb + (lane & 31)]
+__global__ void __launch_bounds__(256) k_cconv_gf_pack_split(const float* __restrict__ kernel, const float* __restrict__ dense_w, int cin,
+                                                             int cout, int nb_, _Float16* __restrict__ wp)
+{
+    const int ks = cin / 16;
+    const size_t total = (size_t)65 * ks * nb_ * 2 * 512;
+    const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= total) return;
+    const int e = (int)(id & 7), lane = (int)((id >> 3) & 63), hl = (int)((id >> 9) & 1);
+    size_t r = id >> 10;
+    const int nb = (int)(r % nb_); r /= nb_;
+    const int sidx = (int)(r % ks), c = (int)(r / ks);
+    const int ci = 16 * sidx + 8 * (lane >> 5) + e, co = 32 * nb + (lane & 31);
+    float v = 0.f;
+    if (co < cout) v = c < 64 ? kernel[((size_t)c * cin + ci) * cout + co] : dense_w[(size_t)co * cin + ci];
+    const _Float16 hi = (_Float16)v;
+    wp[id] = hl ? (_Float16)(v - (float)hi) : hi;
+}
+
+extern "C" size_t nf_cconv_gf_packed_split_bytes(int cin, int cout)
+{
+    if (cin <= 0 || cin % 32 || cout <= 0 || cout > 64) return 0;
+    const int nb = cout > 32 ? 2 : 1;
+    return (size_t)65 * (cin / 16) * nb * 2 * 512 * sizeof(_Float16);
+}
+
+extern "C" int nf_cconv_gf_pack_split(const float* kernel, const float* dense_w, int cin, int cout, void* packed, nf_stream_t stream)
+{
+    NF_CHECK_ARG(kernel && dense_w && packed, "null pointer");
+    const size_t total = nf_cconv_gf_packed_split_bytes(cin, cout) / sizeof(_Float16);
+    NF_CHECK_ARG(total > 0, "cin must be a multiple of 32, cout in [1, 64]");
+    hipLaunchKernelGGL(k_cconv_gf_pack_split, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, kernel, dense_w,
+                       cin, cout, cout > 32 ? 2 : 1, (_Float16*)packed);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
 }
 
 extern "C" size_t nf_cconv_gf_packed_floats(int cin, int cout)
@@ -446,52 +621,52 @@ extern "C" int nf_cconv_gf_plan(int n, int cout, int max_wg, int* tiles, int* nw
     return NF_OK;
 }
 
-template <int CIN, int NB, bool RELU>
+template <int CIN, int NB, bool RELU, bool SPLIT>
 static int gf_launch(const GfArgs& a, hipStream_t st)
 {
-    const size_t lds = (size_t)2 * 4 * GF_TILE * (CIN + 4) * sizeof(float);
+    const size_t lds = SPLIT ? (size_t)2 * 2 * 4 * GF_TILE * (CIN + 8) * sizeof(_Float16) : (size_t)2 * 4 * GF_TILE * (CIN + 4) * sizeof(float);
     static bool attr_set[64] = {};
     int dev = 0;
     hipGetDevice(&dev);
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        hipFuncSetAttribute((const void*)k_cconv_gf<CIN, NB, RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)k_cconv_gf<CIN, NB, RELU, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((k_cconv_gf<CIN, NB, RELU>), dim3(a.nwg), dim3(GF_THREADS), lds, st, a);
+    hipLaunchKernelGGL((k_cconv_gf<CIN, NB, RELU, SPLIT>), dim3(a.nwg), dim3(GF_THREADS), lds, st, a);
     return 0;
 }
 
 // One G-free layer: y = cconv(act(x)) + Linear(act(x)) + biases (+ residual) [+ position / velocity update when pos != NULL]
 extern "C" int nf_cconv_gf_layer(const float* x, int n, int cin, int cout, int relu, const uint16_t* roff, const uint32_t* ent,
-                                 int pitch, const float* packed, const float* bias_conv, const float* bias_dense,
+                                 int pitch, const void* packed, int split, const float* bias_conv, const float* bias_dense,
                                  const float* residual, float* out, float* out_relu, float* scratch, int max_wg, const float* pos,
                                  const float* pos_new, float scale, float dt, float* pos_c, float* vel_c, nf_stream_t stream)
 {
     NF_CHECK_ARG(x && roff && ent && packed && bias_conv && bias_dense && (out || out_relu) && scratch, "null pointer");
-    NF_CHECK_ARG((cin == 96 || cin == 64) && cout >= 1 && cout <= 64, "cin must be 96 or 64 (the transition model's layers), cout <= 64");
+    NF_CHECK_ARG(((cin == 96 && cout > 32) || cin == 64) && cout >= 1 && cout <= 64,
+                 "supported shapes: 96 -> 33..64, 64 -> 1..64 channels (the transition model's layers)");
     NF_CHECK_ARG(!pos || (cout == 3 && pos_new && pos_c && vel_c), "the update epilogue belongs to the 3-channel layer");
     if (n <= 0) return NF_OK;
     GfArgs a;
-    a.x = x; a.n = n; a.relu = relu; a.roff = roff; a.ent = ent; a.pitch = pitch; a.wp = packed; a.scratch = scratch;
+    a.x = x; a.n = n; a.relu = relu; a.roff = roff; a.ent = ent; a.pitch = pitch; a.wp = (const float*)packed; a.scratch = scratch;
     size_t sf;
     if (nf_cconv_gf_plan(n, cout, max_wg, &a.tiles, &a.nwg, &a.maxseg, &sf) != NF_OK) return NF_EINVAL;
     a.ctot = a.tiles * GF_COST;
     hipStream_t st = (hipStream_t)stream;
     const int nb = cout > 32 ? 2 : 1;
     // (the ReLU-on-load variants serve callers that hand over pre-activation features; nf_trans_step stores activated arrays)
-    if (relu) {
-        if (cin == 96 && nb == 2) gf_launch<96, 2, true>(a, st);
-        else if (cin == 96) gf_launch<96, 1, true>(a, st);
-        else if (nb == 2) gf_launch<64, 2, true>(a, st);
-        else gf_launch<64, 1, true>(a, st);
-    } else {
-        if (cin == 96 && nb == 2) gf_launch<96, 2, false>(a, st);
-        else if (cin == 96) gf_launch<96, 1, false>(a, st);
-        else if (nb == 2) gf_launch<64, 2, false>(a, st);
-        else gf_launch<64, 1, false>(a, st);
-    }
+#define GF_PICK(R, S)                                           \
+    do {                                                        \
+        if (cin == 96 && nb == 2) gf_launch<96, 2, R, S>(a, st); \
+        else if (cin == 64 && nb == 2) gf_launch<64, 2, R, S>(a, st); \
+        else gf_launch<64, 1, R, S>(a, st);                     \
+    } while (0)
+    if (split) { if (relu) GF_PICK(true, true); else GF_PICK(false, true); }
+    else { if (relu) GF_PICK(true, false); else GF_PICK(false, false); }
+#undef GF_PICK
     NF_CHECK_LAUNCH();
     GfEpi e;
+    e.split = split;
     e.scratch = scratch; e.tiles = a.tiles; e.nwg = a.nwg; e.maxseg = a.maxseg; e.ctot = a.ctot; e.coutp = 32 * nb; e.cout = cout; e.n = n;
     e.bias_c = bias_conv; e.bias_d = bias_dense; e.residual = residual; e.out = out; e.out_relu = out_relu;
     e.pos = pos; e.pos_new = pos_new; e.pos_c = pos_c; e.vel_c = vel_c; e.scale = scale; e.dt = dt;
@@ -512,9 +687,31 @@ extern "C" int nf_cconv_gf_layer(const float* x, int n, int cin, int cout, int r
 #define G3_PITCH 196            // floats per particle (65 x 3 = 195, padded)
 #define G3_TILE 8               // particles per workgroup of the transform (614 workgroups at 4 913 particles)
 
+// filter of the last layer as the transform reads it: kt[ci][o], o = node * 3 + co (195 columns, pitch G3_PITCH; node 64 = dense3) —
+// a thread's 64 weights are then 64 coalesced loads across the workgroup instead of 64 loads strided by 768 bytes
+__global__ void __launch_bounds__(256) k_cconv3_pack(const float* __restrict__ kernel /* (64, 64, 3) */, const float* __restrict__ dense_w /* (3, 64) */,
+                                                     float* __restrict__ kt)
+{
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    if (id >= 64 * G3_PITCH) return;
+    const int ci = id / G3_PITCH, o = id - ci * G3_PITCH;
+    float v = 0.f;
+    if (o < 195) { const int node = o / 3, co = o - 3 * node; v = node < 64 ? kernel[((size_t)node * 64 + ci) * 3 + co] : dense_w[co * 64 + ci]; }
+    kt[id] = v;
+}
+
+extern "C" size_t nf_cconv3_packed_floats(void) { return (size_t)64 * G3_PITCH; }
+
+extern "C" int nf_cconv3_pack(const float* kernel, const float* dense_w, float* packed, nf_stream_t stream)
+{
+    NF_CHECK_ARG(kernel && dense_w && packed, "null pointer");
+    hipLaunchKernelGGL(k_cconv3_pack, dim3((64 * G3_PITCH + 255) / 256), dim3(256), 0, (hipStream_t)stream, kernel, dense_w, packed);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
 __global__ void __launch_bounds__(256) k_cconv3_transform(const float* __restrict__ xr /* n x 64, activated */, int n,
-                                                          const float* __restrict__ kernel /* (64, 64, 3) */,
-                                                          const float* __restrict__ dense_w /* (3, 64) */, float* __restrict__ G3)
+                                                          const float* __restrict__ kt /* nf_cconv3_pack */, float* __restrict__ G3)
 {
     __shared__ float xs[G3_TILE][64];
     const int i0 = blockIdx.x * G3_TILE;
@@ -527,10 +724,9 @@ __global__ void __launch_bounds__(256) k_cconv3_transform(const float* __restric
     __syncthreads();
     const int o = threadIdx.x;                   // output column: node * 3 + co
     if (o >= 195) return;
-    const int node = o / 3, co = o - 3 * node;
     float w[64];
 #pragma unroll
-    for (int ci = 0; ci < 64; ++ci) w[ci] = node < 64 ? kernel[((size_t)node * 64 + ci) * 3 + co] : dense_w[co * 64 + ci];
+    for (int ci = 0; ci < 64; ++ci) w[ci] = kt[ci * G3_PITCH + o];
     for (int r = 0; r < G3_TILE && i0 + r < n; ++r) {
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
@@ -590,16 +786,16 @@ __global__ void __launch_bounds__(256) k_cconv3_gather(const float* __restrict__
 
 extern "C" size_t nf_cconv3_workspace_floats(int n) { return (size_t)(n > 0 ? n : 0) * G3_PITCH; }
 
-extern "C" int nf_cconv3_layer(const float* x_act, int n, const uint16_t* roff, const uint32_t* ent, int pitch, const float* kernel,
-                               const float* dense_w, const float* bias_conv, const float* bias_dense, float* workspace, float* y3,
+extern "C" int nf_cconv3_layer(const float* x_act, int n, const uint16_t* roff, const uint32_t* ent, int pitch, const float* packed,
+                               const float* bias_conv, const float* bias_dense, float* workspace, float* y3,
                                const float* pos, const float* pos_new, float scale, float dt, float* pos_c, float* vel_c,
                                nf_stream_t stream)
 {
-    NF_CHECK_ARG(x_act && roff && ent && kernel && dense_w && bias_conv && bias_dense && workspace && y3, "null pointer");
+    NF_CHECK_ARG(x_act && roff && ent && packed && bias_conv && bias_dense && workspace && y3, "null pointer");
     NF_CHECK_ARG(!pos || (pos_new && pos_c && vel_c), "the update needs pos_new / pos_c / vel_c");
     if (n <= 0) return NF_OK;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_cconv3_transform, dim3((n + G3_TILE - 1) / G3_TILE), dim3(256), 0, st, x_act, n, kernel, dense_w, workspace);
+    hipLaunchKernelGGL(k_cconv3_transform, dim3((n + G3_TILE - 1) / G3_TILE), dim3(256), 0, st, x_act, n, packed, workspace);
     G3Epi E;
     E.pos = pos; E.pos_new = pos_new; E.pos_c = pos_c; E.vel_c = vel_c; E.scale = scale; E.dt = dt;
     hipLaunchKernelGGL(k_cconv3_gather, dim3((n + 3) / 4), dim3(256), 0, st, (const float*)workspace, n, roff, ent, pitch, bias_conv,
@@ -626,14 +822,14 @@ extern "C" int nf_trans_step(const nf_trans_step_t* s, const float* pos, const f
     if (rc != NF_OK) return rc;
     // every layer reads relu(previous layer) (models/transmodel.py:124): the producers of a0 / a1 / a2 store the activated
     // values (a0r, a1r, a2r), a1 itself is kept for conv2's residual
-    rc = nf_cconv_gf_layer(s->a0, s->n, 96, 64, 0, s->roff, s->ent, s->pitch_f, s->wp1, s->bc1, s->bd1, nullptr, s->a1, s->a1r, s->scratch,
+    rc = nf_cconv_gf_layer(s->a0, s->n, 96, 64, 0, s->roff, s->ent, s->pitch_f, s->wp1, s->split, s->bc1, s->bd1, nullptr, s->a1, s->a1r, s->scratch,
                            s->max_wg, nullptr, nullptr, 0.f, 0.f, nullptr, nullptr, stream);
     if (rc != NF_OK) return rc;
-    rc = nf_cconv_gf_layer(s->a1r, s->n, 64, 64, 0, s->roff, s->ent, s->pitch_f, s->wp2, s->bc2, s->bd2, s->a1, nullptr, s->a2, s->scratch,
+    rc = nf_cconv_gf_layer(s->a1r, s->n, 64, 64, 0, s->roff, s->ent, s->pitch_f, s->wp2, s->split, s->bc2, s->bd2, s->a1, nullptr, s->a2, s->scratch,
                            s->max_wg, nullptr, nullptr, 0.f, 0.f, nullptr, nullptr, stream);
     if (rc != NF_OK) return rc;
     // the 3-channel layer: transform (3.8 MB) then gather, position / velocity update fused (the scratch of the layers above
     // is free again: G3 lives there)
-    return nf_cconv3_layer(s->a2, s->n, s->roff, s->ent, s->pitch_f, s->k3, s->w3, s->bc3, s->bd3, s->scratch, s->y3, pos,
+    return nf_cconv3_layer(s->a2, s->n, s->roff, s->ent, s->pitch_f, s->wp3, s->bc3, s->bd3, s->scratch, s->y3, pos,
                            s->pos_new, s->scale, s->dt, pos_c, vel_c, stream);
 }

@@ -172,6 +172,10 @@ class ParticleNet(nn.Module):
         self.max_fluid_neighbors, self.max_box_neighbors = 128, 64
         self.fused_inference = True
         self.fused_grow_pitch = True        # on overflow: redo the step exactly AND grow the pitch (False: only redo)
+        # build-only switch, arithmetic of the conv1 / conv2 contractions of the fused inference step: "fp32" (default: fp32
+        # MFMA, the reference's arithmetic) or "split" (hi + lo fp16 operands, three fp16 MFMAs per product block, fp32
+        # accumulate: fp32-LEVEL accuracy — 22-bit products — on the fp16 matrix pipe, which overlaps with the gather)
+        self.conv_arith = "fp32"
         self._fused, self._fused_skip = None, 0
         self._lib_cached = None
 
@@ -310,7 +314,10 @@ class ParticleNet(nn.Module):
         tensors = [c0f.kernel, c0f.bias, c0o.kernel, c0o.bias, d0.weight, d0.bias]
         for conv, dense in zip(self.convs, self.denses):
             tensors += [conv.kernel, conv.bias, dense.weight, dense.bias]
-        sig = tuple([t._version for t in tensors] + [t.data_ptr() for t in tensors])
+        if self.conv_arith not in ("fp32", "split"):
+            raise ValueError("ParticleNet.conv_arith must be 'fp32' or 'split'")
+        split = self.conv_arith == "split"
+        sig = tuple([t._version for t in tensors] + [t.data_ptr() for t in tensors] + [split])
         if st["wsig"] == sig:
             return
         S = st["S"]
@@ -322,13 +329,21 @@ class ParticleNet(nn.Module):
             cin, cout = k.shape[-2], k.shape[-1]
             setattr(S, f"bc{li + 1}", bc.data_ptr())
             setattr(S, f"bd{li + 1}", bd.data_ptr())
-            if li == 2:                 # the 3-channel layer takes its filter as it is (nf_cconv3_layer)
-                S.k3, S.w3 = k.data_ptr(), w.data_ptr()
+            if li == 2:                 # the 3-channel layer: transform + gather (nf_cconv3_layer), its own packing
+                wp = torch.empty(lib.nf_cconv3_packed_floats(), dtype=torch.float32, device=dev)
+                check(lib.nf_cconv3_pack(ptr(k), ptr(w), ptr(wp), _lib.stream()), "nf_cconv3_pack")
+                packed.append(wp)
+                S.wp3 = wp.data_ptr()
                 continue
-            wp = torch.empty(lib.nf_cconv_gf_packed_floats(cin, cout), dtype=torch.float32, device=dev)
-            check(lib.nf_cconv_gf_pack(ptr(k), ptr(w), cin, cout, ptr(wp), _lib.stream()), "nf_cconv_gf_pack")
+            if split:
+                wp = torch.empty(lib.nf_cconv_gf_packed_split_bytes(cin, cout), dtype=torch.uint8, device=dev)
+                check(lib.nf_cconv_gf_pack_split(ptr(k), ptr(w), cin, cout, ptr(wp), _lib.stream()), "nf_cconv_gf_pack_split")
+            else:
+                wp = torch.empty(lib.nf_cconv_gf_packed_floats(cin, cout), dtype=torch.float32, device=dev)
+                check(lib.nf_cconv_gf_pack(ptr(k), ptr(w), cin, cout, ptr(wp), _lib.stream()), "nf_cconv_gf_pack")
             packed.append(wp)
             setattr(S, f"wp{li + 1}", wp.data_ptr())
+        S.split = int(split)
         st["wsig"], st["packed"], st["keep"] = sig, packed, keep
 
     def check_capacity(self, wait=False):

@@ -383,26 +383,35 @@ def test_gfree_conv_layer_vs_oracle_and_transform_gather(dev):
             K = torch.randn(4, 4, 4, cin, cout, generator=g) * 0.1
             bc, W, bd = torch.randn(cout, generator=g), torch.randn(cout, cin, generator=g) * 0.1, torch.randn(cout, generator=g)
             xd, Kd, bcd, Wd, bdd = dv(x), dv(K), dv(bc), dv(W), dv(bd)
-            wp = torch.empty(lib.nf_cconv_gf_packed_floats(cin, cout), device=dev)
-            check(lib.nf_cconv_gf_pack(ptr(Kd), ptr(Wd), cin, cout, ptr(wp), _lib.stream()), "pack")
-            sf = ctypes.c_size_t()
-            check(lib.nf_cconv_gf_plan(n, cout, max_wg, None, None, None, ctypes.byref(sf)), "plan")
-            scratch = torch.full((sf.value,), float("nan"), device=dev)          # every slab that is read must have been written
-            y, yr = torch.empty(n, cout, device=dev), torch.empty(n, cout, device=dev)
-            check(lib.nf_cconv_gf_layer(ptr(xd), n, cin, cout, 1, ptr(roff), ptr(ent), pitch_f, ptr(wp), ptr(bcd), ptr(bdd),
-                                        ptr(xd) if res else None, ptr(y), ptr(yr), ptr(scratch), max_wg, None, None, 0.0, 0.0, None, None,
-                                        _lib.stream()), "nf_cconv_gf_layer")
-            assert torch.equal(yr, torch.relu(y))
             xr = torch.relu(x)
             ref = to.cconv(xr, P, P, extent, K, bc, f_idx, f_rs, f_d2) + torch.nn.functional.linear(xr, W, bd) + (x if res else 0)
-            torch.testing.assert_close(y.cpu(), ref, rtol=1e-4, atol=2e-5)
             old = cconv_layer(xd, Kd, bcd, Wd, bdd, rsd, idxd, pw, pc, relu=True, residual=xd if res else None)
-            torch.testing.assert_close(y, old, rtol=1e-4, atol=2e-5)
+            sf = ctypes.c_size_t()
+            check(lib.nf_cconv_gf_plan(n, cout, max_wg, None, None, None, ctypes.byref(sf)), "plan")
+            for split in (0, 1):        # fp32 MFMA, and hi + lo fp16 operands on the fp16 matrix pipe (fp32-level accuracy: same bars)
+                if split:
+                    wp = torch.empty(lib.nf_cconv_gf_packed_split_bytes(cin, cout), dtype=torch.uint8, device=dev)
+                    check(lib.nf_cconv_gf_pack_split(ptr(Kd), ptr(Wd), cin, cout, ptr(wp), _lib.stream()), "pack_split")
+                else:
+                    wp = torch.empty(lib.nf_cconv_gf_packed_floats(cin, cout), device=dev)
+                    check(lib.nf_cconv_gf_pack(ptr(Kd), ptr(Wd), cin, cout, ptr(wp), _lib.stream()), "pack")
+                scratch = torch.full((sf.value,), float("nan"), device=dev)          # every slab that is read must have been written
+                y, yr = torch.empty(n, cout, device=dev), torch.empty(n, cout, device=dev)
+                check(lib.nf_cconv_gf_layer(ptr(xd), n, cin, cout, 1, ptr(roff), ptr(ent), pitch_f, ptr(wp), split, ptr(bcd), ptr(bdd),
+                                            ptr(xd) if res else None, ptr(y), ptr(yr), ptr(scratch), max_wg, None, None, 0.0, 0.0, None,
+                                            None, _lib.stream()), "nf_cconv_gf_layer")
+                assert torch.equal(yr, torch.relu(y))
+                torch.testing.assert_close(y.cpu(), ref, rtol=1e-4, atol=2e-5)
+                torch.testing.assert_close(y, old, rtol=1e-4, atol=2e-5)
+                err = float((y - old).abs().max() / old.abs().max())
+                assert err < (5e-6 if split else 2e-6), (split, err)              # observed ~1e-6 split, ~3e-7 fp32
             if cout == 3:           # the step's own last layer: transform (G3) + gather over the row entries + update
                 wsp = torch.empty(lib.nf_cconv3_workspace_floats(n), device=dev)
                 y3, pc3, vc3 = torch.empty(n, 3, device=dev), torch.empty(n, 3, device=dev), torch.empty(n, 3, device=dev)
                 pos0 = dv(P + 0.01)
-                check(lib.nf_cconv3_layer(ptr(dv(xr)), n, ptr(roff), ptr(ent), pitch_f, ptr(Kd), ptr(Wd), ptr(bcd), ptr(bdd), ptr(wsp),
+                wp3 = torch.empty(lib.nf_cconv3_packed_floats(), device=dev)
+                check(lib.nf_cconv3_pack(ptr(Kd), ptr(Wd), ptr(wp3), _lib.stream()), "nf_cconv3_pack")
+                check(lib.nf_cconv3_layer(ptr(dv(xr)), n, ptr(roff), ptr(ent), pitch_f, ptr(wp3), ptr(bcd), ptr(bdd), ptr(wsp),
                                           ptr(y3), ptr(pos0), ptr(Pd), 1.0 / 128, 0.02, ptr(pc3), ptr(vc3), _lib.stream()), "nf_cconv3_layer")
                 torch.testing.assert_close(y3.cpu(), ref, rtol=1e-4, atol=2e-5)
                 torch.testing.assert_close(pc3, Pd + y3 / 128, rtol=0, atol=1e-7)
@@ -417,9 +426,11 @@ def test_fused_inference_step_vs_multi_launch_path(dev):
     from neurofluid_amd import synthetic
     from oracle import trans_oracle as to
     box, bn = [t.to(dev) for t in to.watercube_box()]
-    for P in (synthetic.watercube_particles(), synthetic.shaped_particles("bunny", order="random"),
-              torch.tensor([[0.0, 0.0, 0.5], [0.5, 0.5, 0.5], [0.52, 0.5, 0.5], [5.0, 5.0, 5.0], [-0.99, -0.99, -0.99]])):
+    for arith, P in [("fp32", synthetic.watercube_particles()), ("fp32", synthetic.shaped_particles("bunny", order="random")),
+                     ("fp32", torch.tensor([[0.0, 0.0, 0.5], [0.5, 0.5, 0.5], [0.52, 0.5, 0.5], [5.0, 5.0, 5.0], [-0.99, -0.99, -0.99]])),
+                     ("split", synthetic.watercube_particles()), ("split", synthetic.shaped_particles("honeycone", order="random"))]:
         pa, _ = make_pn(dev)
+        pa.conv_arith = arith
         pb, _ = make_pn(dev)
         pb.fused_inference = False
         p1 = P.to(dev)

@@ -1,5 +1,6 @@
 """Timing of ParticleNet.forward alone on the synthetic watercube (dev tool): particle-steps/s.
-usage: tools/trans_perf.py [steps] [unfused]"""
+usage: tools/trans_perf.py [steps] [unfused|split]     (steps from the initial cloud, as bench.py measures: the rate depends
+on the state of the rollout — a cloud that has fallen and piled up has more neighbours per particle)"""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,9 +14,12 @@ pn.load_state_dict(scene["trans_state"], strict=True)
 pn = pn.to(dev)
 P0 = scene["P"].to(dev)
 box, bn = scene["box"].to(dev), scene["bn"].to(dev)
-steps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
-if len(sys.argv) > 2 and sys.argv[2] == "unfused":
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+mode = sys.argv[2] if len(sys.argv) > 2 else "fp32"
+if mode == "unfused":
     pn.fused_inference = False
+elif mode == "split":
+    pn.conv_arith = "split"
 for it in range(3):
     pos, vel = P0.clone(), torch.zeros_like(P0)
     torch.cuda.synchronize(); t = time.time()
@@ -23,4 +27,4 @@ for it in range(3):
         for _ in range(steps):
             pos, vel, _ = pn(pos, vel, box, bn)
     torch.cuda.synchronize(); dt = time.time() - t
-    print(f"iter {it}: {dt/steps*1e6:.1f} us/step, {P0.shape[0]*steps/dt/1e6:.2f} M particle-steps/s  overflows {getattr(pn, 'fused_overflows', 0)}")
+    print(f"iter {it} [{mode}]: {dt/steps*1e6:.1f} us/step, {P0.shape[0]*steps/dt/1e6:.2f} M particle-steps/s  overflows {getattr(pn, 'fused_overflows', 0)}")

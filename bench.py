@@ -367,7 +367,9 @@ def main():
         # same 157.3 TFLOP/s peak), time measured here; HBM-side bytes from the committed PMC passes
         ct = committed_transition()
         tflops = PARTICLE_STEP_FLOP * P0.shape[0] / pstep_dt / 1e12
-        trans_roofline = {"bound": "mfma (conv1 / conv2 contractions) after the gather is taken off HBM", "flop_per_particle_step": PARTICLE_STEP_FLOP,
+        trans_roofline = {"bound": "fp32 ALUs (on gfx950 the fp32 MFMA runs at the fp32 vector rate, on the same units as the gather "
+                                   "arithmetic: 157.3 TFLOP/s for both together)", "arithmetic": "fp32 (default)",
+                          "flop_per_particle_step": PARTICLE_STEP_FLOP,
                           "particles": int(P0.shape[0]), "us_per_step": pstep_dt * 1e6, "achieved": tflops,
                           "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / F32_MATRIX_PEAK_TFLOPS,
                           "traffic": ct["hbm_bytes_per_step"] if ct else None, "traffic_unit": "HBM-side bytes per step (PMC)",
@@ -375,6 +377,26 @@ def main():
                           "hbm_frac": (ct["hbm_bytes_per_step"] / pstep_dt / 1e9 / HBM_PEAK_GBS) if ct else None,
                           "kernel_us_per_step": ct["kernel_us_per_step"] if ct else None,
                           "traffic_source": ct["source"] if ct else None}
+        # the same step with the conv1 / conv2 contractions on the fp16 matrix pipe (hi + lo fp16 operands, 3 MFMAs per product
+        # block, fp32 accumulate: fp32-level accuracy, NOT the reference's arithmetic -> an extra key, never the default)
+        pn_s = ParticleNet(gravity=(0, 0, -9.81))
+        pn_s.load_state_dict(scene["trans_state"], strict=True)
+        pn_s = pn_s.to(dev)
+        pn_s.conv_arith = "split"
+        sp, sv = P0.clone(), torch.zeros_like(P0)
+        with torch.no_grad():
+            for _ in range(3):
+                sp, sv, _ = pn_s(sp, sv, box, bn)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(nts):
+                sp, sv, _ = pn_s(sp, sv, box, bn)
+            torch.cuda.synchronize()
+        sdt = (time.perf_counter() - t1) / nts
+        trans_roofline["split_precision_variant"] = {
+            "particle_steps_per_sec": P0.shape[0] / sdt, "us_per_step": sdt * 1e6,
+            "max_abs_pos_diff_vs_fp32_after_%d_steps" % (nts + 3): float((sp - tp).abs().max()),
+            "note": "ParticleNet.conv_arith = 'split': conv1 / conv2 contractions as zh wh + zh wl + zl wh on v_mfma_f32_32x32x16_f16"}
 
     # ---- extras (NOT the headline, which stays fp32 = the reference's arithmetic): the same render step with
     #   fp16:  the fp16-MFMA MLP, fp32 accumulate (BASELINE config 5)

@@ -290,44 +290,22 @@ int nf_cconv_small(const float* feats, int cin, const int64_t* row_splits, const
 int nf_cconv_transform(const float* A, int M, int cin, int cout, int relu, const float* kernel /*(4,4,4,Cin,Cout)*/,
                        const float* dense_w /*[Cout][Cin]*/, float* G, nf_stream_t stream);
 /* step 2: y[i] = sum_pairs sum_corners pair_w * G[j][cell] + G[i][dense] + bias_conv + bias_dense (+ residual[i])
- * (models/transmodel.py:125-130).  Neighbour rows: CSR (row_splits, row_count = NULL) or rows of a fixed pitch with a
- * count per row (row_count != NULL: row i = entries [i * row_pitch, i * row_pitch + min(row_count[i], row_pitch)),
- * row_splits ignored) as nf_trans_search writes them. */
-int nf_cconv_gather(const float* G, int cout, const int64_t* row_splits, int row_pitch, const int32_t* row_count,
-                    const int32_t* nbr, const float* pair_w, const uint8_t* pair_cell, const float* bias_conv,
-                    const float* bias_dense, const float* residual /*n_out*Cout or NULL*/, int n_out, float* out,
-                    nf_stream_t stream);
-/* the last layer's gather (Cout = 3, fixed-pitch rows) with the update epilogue fused: y3 as above, then
- * pos_c = pos_new + scale * y3, vel_c = (pos_c - pos) / dt (models/transmodel.py:141-148).  overflow2 (device, int64[2],
- * zero-initialised by the caller once) may be NULL; otherwise a particle whose fluid / box neighbour count exceeds its
- * pitch gets NaN in pos_c / vel_c and the count is recorded (atomic max) in overflow2[0] / [1]. */
-int nf_cconv_gather_update(const float* G, int pitch_fluid, const int32_t* count_fluid, const int32_t* nbr, const float* pair_w,
-                           const uint8_t* pair_cell, const float* bias_conv, const float* bias_dense, int n_out, float* y3,
-                           const float* pos, const float* pos_new, float scale, float dt, int pitch_box,
-                           const int32_t* count_box, int64_t* overflow2, float* pos_c, float* vel_c, nf_stream_t stream);
+ * (models/transmodel.py:125-130) over CSR neighbour rows.  (Training path and oversize clouds; the inference step uses the
+ * G-free layers below.) */
+int nf_cconv_gather(const float* G, int cout, const int64_t* row_splits, const int32_t* nbr, const float* pair_w,
+                    const uint8_t* pair_cell, const float* bias_conv, const float* bias_dense,
+                    const float* residual /*n_out*Cout or NULL*/, int n_out, float* out, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
- * Fused front half of the inference transition step (nf_trans.hip): 3 launches, no host round trip.
- * Neighbour rows have a fixed pitch (capacity per particle): row i of the fluid (box) search occupies entries
- * [i * pitch, (i + 1) * pitch) of idx / d2 / pw (x8) / pc (x8); counts2 = [fluid (n) | box (n)] int32 TRUE counts.
+ * First launch of the inference transition step (nf_trans.hip): B1 + the fluid cell grid of the integrated positions in ONE
+ * workgroup (same grid workspace layout as nf_grid_build with with_firstk_lists = 0; bbox as there).  NF_EINVAL when the
+ * cloud / grid exceeds nf_trans_prepare_limits.  The rest of the step: nf_trans_front / nf_cconv_gf_layer / nf_cconv3_layer /
+ * nf_trans_step at the end of this header.
  * ------------------------------------------------------------------------------------------ */
 int nf_trans_prepare_limits(int* max_points, int* max_cells);
-/* B1 + fluid cell grid of the integrated positions in ONE workgroup (same grid workspace layout as nf_grid_build with
- * with_firstk_lists = 0; bbox as there).  NF_EINVAL when the cloud / grid exceeds nf_trans_prepare_limits. */
 int nf_trans_prepare(const float* pos, const float* vel, const float gravity[3], float dt, int n, float cell,
                      const float bbox[6], void* grid_ws, size_t ws_bytes, float* pos_new, float* vel_new, float* feats4,
                      nf_stream_t stream);
-/* B2 + B3 + B6 in one sweep: Open3D FixedRadiusSearch semantics (d2 <= r2, identical positions skipped) of the integrated
- * positions against the fluid grid and the box grid (models/transmodel.py:106,116-118), the per-pair interpolation data of
- * nf_cconv_pairs, and num_fluid_nbrs[i] = fluid count as float (:135-138). */
-int nf_trans_search(const void* fluid_grid, const void* box_grid, const float* queries, int n, float radius, float extent,
-                    int use_window, int pitch_fluid, int pitch_box, int32_t* counts2, float* num_fluid_nbrs, int32_t* idx_f,
-                    float* d2_f, float* pw_f, uint8_t* pc_f, int32_t* idx_b, float* d2_b, float* pw_b, uint8_t* pc_b,
-                    nf_stream_t stream);
-int nf_trans_conv0(const float* box_feats, const float* fluid_feats, const int32_t* counts2, int pitch_fluid, int pitch_box,
-                   int n, const int32_t* idx_f, const float* pw_f, const uint8_t* pc_f, const int32_t* idx_b, const float* pw_b,
-                   const uint8_t* pc_b, const float* kernel_obstacle, const float* bias_obstacle, const float* kernel_fluid,
-                   const float* bias_fluid, const float* dense_w, const float* dense_b, float* out96, nf_stream_t stream);
 
 /* B8: backward of the continuous convolutions.  Open3D differentiates continuous_conv w.r.t. filter and input
  * features only (not positions); the reference trains through it at trainer/trainer_e2e.py:277.

@@ -95,15 +95,11 @@ PROTOTYPES = {
                               c_void_p]),
     "nf_host_choice_mt19937": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "nf_cconv_transform": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "nf_cconv_gather": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                c_int, c_void_p, c_void_p]),
-    "nf_cconv_gather_update": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
-                                       c_void_p, c_void_p, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nf_cconv_gather": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                c_void_p]),
     "nf_trans_prepare_limits": (c_int, [ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "nf_trans_prepare": (c_int, [c_void_p, c_void_p, ctypes.POINTER(c_float), c_float, c_int, c_float, ctypes.POINTER(c_float), c_void_p,
                                 c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "nf_trans_search": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_int, c_int, c_int] + [c_void_p] * 11),
-    "nf_trans_conv0": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 14),
     "nf_trans_front_max_pitch": (c_int, []),
     "nf_trans_front": (c_int, [c_void_p] * 5 + [c_int, c_float, c_float, c_int, c_int, c_int] + [c_void_p] * 13 + [c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "nf_pinned_device_ptr": (c_void_p, [c_void_p]),

@@ -381,26 +381,12 @@ extern "C" int nf_cconv_transform(const float* A, int M, int cin, int cout, int 
 // one wave per output point; the row's (j, 8 cells, 8 weights) are staged through LDS 64 entries
 // at a time, then every lane walks them for its output channel(s).
 // ------------------------------------------------------------------------------------------------
-// optional epilogue of the LAST layer (Cout = 3): pos_correction = y / 128, update_pos_vel (models/transmodel.py:141-148),
-// and the capacity check of the fused step (nf_trans.hip): a pair total above its capacity poisons the outputs with NaN
-struct NfUpdateEpi {
-    const float* pos;        // null: no epilogue
-    const float* pos_new;
-    float* pos_c;
-    float* vel_c;
-    float scale, dt;
-    const int32_t* cnt_b;    // [n] true box-neighbour counts or null (the fluid counts are the row counts)
-    int pitch_b;
-    unsigned long long* overflow;   // [2] largest (fluid, box) count seen above its pitch; never reset by the device
-};
-
 __global__ void __launch_bounds__(256) k_cconv_gather(const float* __restrict__ G, int cout,
                                                       const int64_t* __restrict__ row_splits,
                                                       const int32_t* __restrict__ nbr, const float* __restrict__ pw,
                                                       const uint8_t* __restrict__ pc, const float* __restrict__ bias_c,
                                                       const float* __restrict__ bias_d, const float* __restrict__ residual,
-                                                      int n_out, float* __restrict__ out, NfUpdateEpi epi,
-                                                      int row_pitch, const int32_t* __restrict__ row_count)
+                                                      int n_out, float* __restrict__ out)
 {
     __shared__ int s_j[4][64];
     __shared__ float s_w[4][64 * 8];
@@ -416,10 +402,7 @@ __global__ void __launch_bounds__(256) k_cconv_gather(const float* __restrict__ 
     const int vblk = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
     for (int row = vblk * 4 + wv; row < n_out; row += gridDim.x * 4) {
         float acc = 0.f;
-        // CSR rows (row_splits) or fixed-pitch rows with a count per row (the fused inference step, nf_trans.hip)
-        int64_t s, e;
-        if (row_count) { s = (int64_t)row * row_pitch; e = s + min(row_count[row], row_pitch); }
-        else { s = row_splits[row]; e = row_splits[row + 1]; }
+        const int64_t s = row_splits[row], e = row_splits[row + 1];
         for (int64_t base = s; base < e; base += 64) {
             int cnt = (int)((e - base) < 64 ? (e - base) : 64);
             if (lane < cnt) {
@@ -455,61 +438,22 @@ __global__ void __launch_bounds__(256) k_cconv_gather(const float* __restrict__ 
             float v = acc + G[(size_t)row * ntot + 64 * cout + lane] + bias_c[lane] + bias_d[lane];
             if (residual) v += residual[(size_t)row * cout + lane];
             out[(size_t)row * cout + lane] = v;
-            if (epi.pos) {      // cout == 3: lane = coordinate (same expressions as k_trans_update)
-                const size_t e = (size_t)row * 3 + lane;
-                float pcv = epi.pos_new[e] + epi.scale * v;
-                float vcv = (pcv - epi.pos[e]) / epi.dt;
-                if (epi.overflow) {     // a neighbour row that did not fit its pitch: NaN for this particle, count recorded
-                    const int cf = row_count[row], cb = epi.cnt_b[row];
-                    if (cf > row_pitch || cb > epi.pitch_b) {
-                        pcv = vcv = __int_as_float(0x7fc00000);
-                        if (lane == 0) {
-                            if (cf > row_pitch) atomicMax(epi.overflow, (unsigned long long)cf);
-                            if (cb > epi.pitch_b) atomicMax(epi.overflow + 1, (unsigned long long)cb);
-                        }
-                    }
-                }
-                epi.pos_c[e] = pcv;
-                epi.vel_c[e] = vcv;
-            }
         }
     }
 }
 
-extern "C" int nf_cconv_gather(const float* G, int cout, const int64_t* row_splits, int row_pitch, const int32_t* row_count,
-                               const int32_t* nbr, const float* pair_w, const uint8_t* pair_cell, const float* bias_conv,
-                               const float* bias_dense, const float* residual, int n_out, float* out, nf_stream_t stream)
+extern "C" int nf_cconv_gather(const float* G, int cout, const int64_t* row_splits, const int32_t* nbr, const float* pair_w,
+                               const uint8_t* pair_cell, const float* bias_conv, const float* bias_dense, const float* residual,
+                               int n_out, float* out, nf_stream_t stream)
 {
-    NF_CHECK_ARG(G && (row_splits || (row_count && row_pitch >= 1)) && bias_conv && bias_dense && out, "null pointer");
+    NF_CHECK_ARG(G && row_splits && bias_conv && bias_dense && out, "null pointer");
     NF_CHECK_ARG(cout >= 1 && cout <= 64, "cout must be in [1,64]");
     if (n_out <= 0) return NF_OK;
     int blocks = (n_out + 3) / 4;
     if (blocks > 4096) blocks = 4096;
     blocks = (blocks + 7) & ~7;      // the kernel's XCD-aware row order needs a multiple of 8
-    NfUpdateEpi epi = {};
     hipLaunchKernelGGL(k_cconv_gather, dim3(blocks), dim3(256), 0, (hipStream_t)stream, G, cout, row_splits, nbr, pair_w,
-                       pair_cell, bias_conv, bias_dense, residual, n_out, out, epi, row_pitch, row_count);
-    NF_CHECK_LAUNCH();
-    return NF_OK;
-}
-
-extern "C" int nf_cconv_gather_update(const float* G, int pitch_fluid, const int32_t* count_fluid, const int32_t* nbr,
-                                      const float* pair_w, const uint8_t* pair_cell, const float* bias_conv, const float* bias_dense,
-                                      int n_out, float* y3, const float* pos, const float* pos_new, float scale, float dt,
-                                      int pitch_box, const int32_t* count_box, int64_t* overflow2, float* pos_c, float* vel_c,
-                                      nf_stream_t stream)
-{
-    NF_CHECK_ARG(G && count_fluid && pitch_fluid >= 1 && bias_conv && bias_dense && y3 && pos && pos_new && pos_c && vel_c, "null pointer");
-    NF_CHECK_ARG(!overflow2 || (count_box && pitch_box >= 1), "the overflow check needs the box counts");
-    if (n_out <= 0) return NF_OK;
-    int blocks = (n_out + 3) / 4;
-    if (blocks > 4096) blocks = 4096;
-    blocks = (blocks + 7) & ~7;
-    NfUpdateEpi epi;
-    epi.pos = pos; epi.pos_new = pos_new; epi.pos_c = pos_c; epi.vel_c = vel_c; epi.scale = scale; epi.dt = dt;
-    epi.cnt_b = count_box; epi.pitch_b = pitch_box; epi.overflow = (unsigned long long*)overflow2;
-    hipLaunchKernelGGL(k_cconv_gather, dim3(blocks), dim3(256), 0, (hipStream_t)stream, G, 3, (const int64_t*)nullptr, nbr, pair_w,
-                       pair_cell, bias_conv, bias_dense, (const float*)nullptr, n_out, y3, epi, pitch_fluid, count_fluid);
+                       pair_cell, bias_conv, bias_dense, residual, n_out, out);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }

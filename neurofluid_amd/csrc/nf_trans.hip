@@ -1,20 +1,13 @@
-// nf_trans.hip — fused front half of the transition step (ParticleNet.forward, models/transmodel.py:151-163) for the
-// inference path: 3 launches where round 1 used ~20.
+// nf_trans.hip — front half of the transition step (ParticleNet.forward, models/transmodel.py:151-163) for the inference path:
 //
 //   nf_trans_prepare   ONE workgroup: gravity integration (B1, :100-104) + the fluid cell grid of the integrated
 //                      positions (counting sort in LDS, stable in original index) — replaces k_trans_integrate and the
 //                      six k_grid_* / scan launches of nf_grid_build(with_firstk_lists = 0)
-//   nf_trans_search    fluid->fluid and box->fluid fixed-radius search in ONE sweep per (particle, grid) (blockIdx.y picks
-//                      the grid): neighbour index, squared distance and the per-pair interpolation data (ball->cube map,
-//                      trilinear cells / weights, poly6 window; B3) are written where the hit is found, into rows of a
-//                      fixed pitch; the per-particle counts (B6) fall out of the same sweep — replaces 2 counts + 2
-//                      scans + 2 fills + 2 k_pair_precompute + the ATen diff
-//   nf_trans_conv0     conv0_obstacle + conv0_fluid + dense0_fluid in one launch (both 64-cell filters in LDS) —
-//                      replaces 2 k_cconv_small
-// Neighbour rows have a fixed PITCH (capacity per particle): no offsets to compute, no host round trip anywhere in the
-// step.  The true counts stay on the device; the last kernel of the step (nf_cconv_gather_update) turns the outputs of a
-// particle whose count exceeds its pitch into NaN and records the count, and the host checks that record of step t
-// while later steps are in flight.
+//   nf_trans_front     fixed-radius search of both clouds, the row-entry lists of the fluid pairs (what the G-free
+//                      convolutions of nf_cconv_gf.hip consume) and layer 0 (conv0_obstacle, conv0_fluid, dense0_fluid)
+// Neighbour rows have a fixed PITCH (capacity per particle): no offsets to compute, no host round trip inside the step.
+// The true counts stay on the device; a count above its pitch is reported through pinned host words, and the host redoes
+// THAT step on the exact CSR path before ParticleNet.forward returns (neurofluid_amd/transmodel.py).
 #include "nf_common.h"
 #include <math.h>
 
@@ -145,10 +138,7 @@ extern "C" int nf_trans_prepare(const float* pos, const float* vel, const float 
     return NF_OK;
 }
 
-// ------------------------------------------------------------------------------------------------
-// neighbour search of both clouds (Open3D FixedRadiusSearch contract, as k_radius in nf_grid.hip: one wave per query,
-// the 3 x-adjacent cells of each (z, y) row swept 64 candidates at a time, ballot/popcount placement)
-// ------------------------------------------------------------------------------------------------
+// ball -> cube map of the pair offsets (identical to nf_cconv.hip:ball_to_cube)
 __device__ __forceinline__ void tr_ball_to_cube(float& x, float& y, float& z)
 {
     // sphere -> cylinder -> cube, volume preserving (identical to nf_cconv.hip:ball_to_cube)
@@ -177,235 +167,6 @@ __device__ __forceinline__ void tr_ball_to_cube(float& x, float& y, float& z)
         y = t;
     }
 }
-
-struct TrSearch {
-    const void* grid[2];        // 0: fluid, 1: box
-    const float* q;             // queries = integrated positions
-    int n;
-    float r2;
-};
-
-#define TR_QPB 4
-__device__ __forceinline__ int tr_sweep(const NfGridView& g, float qx, float qy, float qz, float r2, int lane, int64_t o,
-                                        int64_t cap, float extent, int use_window, int32_t* __restrict__ idx,
-                                        float* __restrict__ dist2, float* __restrict__ pw, uint8_t* __restrict__ pc)
-{
-    const int cx = nf_cell_coord(qx, g.ox, g.icx, g.dx);
-    const int cy = nf_cell_coord(qy, g.oy, g.icy, g.dy);
-    const int cz = nf_cell_coord(qz, g.oz, g.icz, g.dz);
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    const float radius = 0.5f * extent, inv_r2 = 1.f / (radius * radius), scale = 2.f / extent;
-    int cnt = 0;
-    for (int z = max(cz - 1, 0); z <= min(cz + 1, g.dz - 1); ++z)
-        for (int y = max(cy - 1, 0); y <= min(cy + 1, g.dy - 1); ++y) {
-            const int r0 = (z * g.dy + y) * g.dx;
-            const int s = g.cell_start[r0 + max(cx - 1, 0)], e = g.cell_start[r0 + min(cx + 1, g.dx - 1) + 1];
-            for (int t0 = s; t0 < e; t0 += 64) {
-                const int t = t0 + lane;
-                bool hit = false;
-                float d2 = 0.f;
-                float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (t < e) {
-                    p = g.sorted_pos[t];
-                    d2 = nf_dist2(qx, qy, qz, p.x, p.y, p.z);
-                    hit = d2 <= r2 && !(p.x == qx && p.y == qy && p.z == qz);      // radius_search_ignore_query_points=True
-                }
-                const unsigned long long m = __ballot(hit);
-                if (hit) {
-                    const int64_t w = o + cnt + __popcll(m & lt);
-                    if (w < cap) {
-                        idx[w] = __float_as_int(p.w);
-                        dist2[w] = d2;
-                        // per-pair interpolation data, exactly k_pair_precompute (nf_cconv.hip)
-                        float x = (p.x - qx) * scale, yy = (p.y - qy) * scale, zz = (p.z - qz) * scale;
-                        tr_ball_to_cube(x, yy, zz);
-                        float imp = 1.f;
-                        if (use_window) { const float tt = 1.f - d2 * inv_r2; imp = fminf(fmaxf(tt * tt * tt, 0.f), 1.f); }
-                        const float c[3] = {(x + 1.f) * 1.5f, (yy + 1.f) * 1.5f, (zz + 1.f) * 1.5f};
-                        int i0[3];
-                        float f[3];
-#pragma unroll
-                        for (int d = 0; d < 3; ++d) {
-                            const float cc = fminf(fmaxf(c[d], 0.f), 3.f);
-                            const float fl = fminf(floorf(cc), 2.f);
-                            i0[d] = (int)fl;
-                            f[d] = cc - fl;
-                        }
-                        float wv[8];
-                        unsigned cl[2] = {0u, 0u};
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) {
-                            const int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
-                            wv[k] = imp * ((dx ? f[0] : 1.f - f[0]) * (dy ? f[1] : 1.f - f[1]) * (dz ? f[2] : 1.f - f[2]));
-                            cl[k >> 2] |= (unsigned)(((i0[2] + dz) * 4 + (i0[1] + dy)) * 4 + (i0[0] + dx)) << (8 * (k & 3));
-                        }
-                        *(float4*)(pw + w * 8) = make_float4(wv[0], wv[1], wv[2], wv[3]);
-                        *(float4*)(pw + w * 8 + 4) = make_float4(wv[4], wv[5], wv[6], wv[7]);
-                        *(uint2*)(pc + w * 8) = make_uint2(cl[0], cl[1]);
-                    }
-                }
-                cnt += __popcll(m);
-            }
-        }
-    return cnt;
-}
-
-// ONE sweep per (query, grid): the neighbours are found, counted and written with their interpolation data in the same pass.
-// Rows live at a fixed PITCH (row i of grid w starts at i * pitch_w: `max_fluid_neighbors` / `max_box_neighbors` per
-// particle), so no offsets have to be known before the fill — the count kernel, its scan by the last workgroup and the
-// second sweep of the former count + fill pair are gone (31 + 21 us -> one launch).  counts2[w][i] is the TRUE
-// neighbour count (consumers clamp it to the pitch; a count above the pitch is an overflow that the last kernel of the step
-// turns into NaN outputs for that particle and reports through overflow2), num_nbrs[i] the fluid count as float
-// (reduce_subarrays_sum of ones, models/transmodel.py:135-138).
-__global__ void __launch_bounds__(64 * TR_QPB) k_trans_search(TrSearch S, int pitch_f, int pitch_b, float extent, int use_window,
-                                                              int32_t* __restrict__ counts2, float* __restrict__ num_nbrs,
-                                                              int32_t* __restrict__ idx_f, float* __restrict__ d2_f,
-                                                              float* __restrict__ pw_f, uint8_t* __restrict__ pc_f,
-                                                              int32_t* __restrict__ idx_b, float* __restrict__ d2_b,
-                                                              float* __restrict__ pw_b, uint8_t* __restrict__ pc_b)
-{
-    const int lane = threadIdx.x & 63, which = blockIdx.y;
-    const int i = blockIdx.x * TR_QPB + (threadIdx.x >> 6);
-    if (i >= S.n) return;
-    const int pitch = which ? pitch_b : pitch_f;
-    const int64_t o = (int64_t)i * pitch;
-    NfGridView g = nf_grid_view(S.grid[which]);
-    const int cnt = tr_sweep(g, S.q[3 * i], S.q[3 * i + 1], S.q[3 * i + 2], S.r2, lane, o, o + pitch, extent, use_window,
-                             which ? idx_b : idx_f, which ? d2_b : d2_f, which ? pw_b : pw_f, which ? pc_b : pc_f);
-    if (lane == 0) {
-        counts2[(size_t)which * S.n + i] = cnt;
-        if (!which) num_nbrs[i] = (float)cnt;
-    }
-}
-
-extern "C" int nf_trans_search(const void* fluid_grid, const void* box_grid, const float* queries, int n, float radius, float extent,
-                               int use_window, int pitch_fluid, int pitch_box, int32_t* counts2, float* num_fluid_nbrs,
-                               int32_t* idx_f, float* d2_f, float* pw_f, uint8_t* pc_f, int32_t* idx_b, float* d2_b, float* pw_b,
-                               uint8_t* pc_b, nf_stream_t stream)
-{
-    NF_CHECK_ARG(fluid_grid && box_grid && queries && counts2 && num_fluid_nbrs && idx_f && d2_f && pw_f && pc_f && idx_b && d2_b &&
-                 pw_b && pc_b, "null pointer");
-    NF_CHECK_ARG(n > 0 && radius > 0.f && extent > 0.f && pitch_fluid >= 1 && pitch_box >= 1, "bad n/radius/extent/pitch");
-    TrSearch S;
-    S.grid[0] = fluid_grid; S.grid[1] = box_grid; S.q = queries; S.n = n; S.r2 = radius * radius;
-    hipLaunchKernelGGL(k_trans_search, dim3((n + TR_QPB - 1) / TR_QPB, 2), dim3(64 * TR_QPB), 0, (hipStream_t)stream, S, pitch_fluid,
-                       pitch_box, extent, use_window, counts2, num_fluid_nbrs, idx_f, d2_f, pw_f, pc_f, idx_b, d2_b, pw_b, pc_b);
-    NF_CHECK_LAUNCH();
-    return NF_OK;
-}
-
-// ------------------------------------------------------------------------------------------------
-// layer 0: [conv0_obstacle(box normals) | conv0_fluid([1, v]) | dense0_fluid([1, v])] -> a0 (n x 96)
-// (models/transmodel.py:116-120).  One wave per point; both 64-cell filters (3 x 32 and 4 x 32 per cell) in LDS; a
-// half-wave per pair, lane = output channel; the pair's 8 weights / 8 cells arrive as two 16-B and one 8-B load.
-// ------------------------------------------------------------------------------------------------
-// One row: the pair records (neighbour, 8 weights, 8 cells) and the neighbours' input features are staged through the wave's
-// LDS slice 64 pairs at a time (two dependent global round trips per 64 pairs instead of two per pair), then a half-wave
-// per pair, lane = output channel.  Measured alternatives that did NOT help (the kernel is bound by the 8 x Cin LDS reads +
-// FMAs per pair and lane, not by latency or staging): 16-B filter reads from a [cell][co][4] copy (34.5 us), 16-wave
-// workgroups staging both filters once per CU (42 us), fewer / more workgroups (33-60 us).
-struct TrStage {
-    float f[64][4];
-    float w[64][8];
-    uint2 c[64];
-};
-
-template <int CIN>
-__device__ __forceinline__ float tr_conv_row(const float* __restrict__ Ks, const float* __restrict__ feats, int64_t begin, int count,
-                                             const int32_t* __restrict__ nbr, const float* __restrict__ pw,
-                                             const uint8_t* __restrict__ pc, int co, int half, int lane, TrStage& st)
-{
-    float acc = 0.f;
-    for (int base = 0; base < count; base += 64) {
-        const int m = min(64, count - base);
-        if (lane < m) {
-            const int64_t p = begin + base + lane;
-            const int j = nbr[p];
-            const float4 w0 = *(const float4*)(pw + p * 8), w1 = *(const float4*)(pw + p * 8 + 4);
-            st.c[lane] = *(const uint2*)(pc + p * 8);
-            *(float4*)&st.w[lane][0] = w0;
-            *(float4*)&st.w[lane][4] = w1;
-#pragma unroll
-            for (int ci = 0; ci < CIN; ++ci) st.f[lane][ci] = feats[(size_t)j * CIN + ci];
-        }
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the staged records are visible wave-wide
-        for (int t = half; t < m; t += 2) {
-            float fj[CIN];
-#pragma unroll
-            for (int ci = 0; ci < CIN; ++ci) fj[ci] = st.f[t][ci];
-            const uint2 cc = st.c[t];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int cell = (int)(((k < 4 ? cc.x : cc.y) >> (8 * (k & 3))) & 0xffu);
-                const float* kc = Ks + cell * CIN * 32 + co;
-                float s = 0.f;
-#pragma unroll
-                for (int ci = 0; ci < CIN; ++ci) s += fj[ci] * kc[ci * 32];
-                acc += st.w[t][k] * s;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-    return acc + __shfl_xor(acc, 32, 64);
-}
-
-__global__ void __launch_bounds__(256) k_trans_conv0(const float* __restrict__ box_feats, const float* __restrict__ fluid_feats,
-                                                     const int32_t* __restrict__ counts2, int pitch_f, int pitch_b, int n,
-                                                     const int32_t* __restrict__ idx_f,
-                                                     const float* __restrict__ pw_f, const uint8_t* __restrict__ pc_f,
-                                                     const int32_t* __restrict__ idx_b, const float* __restrict__ pw_b,
-                                                     const uint8_t* __restrict__ pc_b, const float* __restrict__ k_obst,
-                                                     const float* __restrict__ b_obst, const float* __restrict__ k_fluid,
-                                                     const float* __restrict__ b_fluid, const float* __restrict__ dense_w,
-                                                     const float* __restrict__ dense_b, float* __restrict__ out /*n x 96*/)
-{
-    // blockIdx.y = 0: conv0_obstacle -> columns 0..31; 1: conv0_fluid -> 32..63 and dense0_fluid -> 64..95.  A workgroup
-    // stages only its own filter (24 / 32 KB), so both halves keep the occupancy of the separate launches.
-    __shared__ float Ks[64 * 4 * 32];
-    __shared__ TrStage stage[4];
-    const bool fluid = blockIdx.y == 1;
-    const float* ksrc = fluid ? k_fluid : k_obst;
-    const int kn = fluid ? 64 * 4 * 32 : 64 * 3 * 32;
-    for (int t = threadIdx.x; t < kn; t += 256) Ks[t] = ksrc[t];
-    __syncthreads();
-    const int lane = threadIdx.x & 63, co = lane & 31, half = lane >> 5;
-    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < n; row += gridDim.x * 4) {
-        float* o = out + (size_t)row * 96;
-        if (!fluid) {
-            const float ao = tr_conv_row<3>(Ks, box_feats, (int64_t)row * pitch_b, min(counts2[n + row], pitch_b), idx_b, pw_b, pc_b, co, half, lane, stage[threadIdx.x >> 6]);
-            if (half == 0) o[co] = ao + b_obst[co];
-        } else {
-            const float af = tr_conv_row<4>(Ks, fluid_feats, (int64_t)row * pitch_f, min(counts2[row], pitch_f), idx_f, pw_f, pc_f, co, half, lane, stage[threadIdx.x >> 6]);
-            if (half == 0) o[32 + co] = af + b_fluid[co];
-            else {
-                float s = dense_b[co];
-#pragma unroll
-                for (int ci = 0; ci < 4; ++ci) s += fluid_feats[(size_t)row * 4 + ci] * dense_w[co * 4 + ci];
-                o[64 + co] = s;
-            }
-        }
-    }
-}
-
-extern "C" int nf_trans_conv0(const float* box_feats, const float* fluid_feats, const int32_t* counts2, int pitch_fluid,
-                              int pitch_box, int n, const int32_t* idx_f, const float* pw_f, const uint8_t* pc_f, const int32_t* idx_b,
-                              const float* pw_b, const uint8_t* pc_b, const float* kernel_obstacle, const float* bias_obstacle,
-                              const float* kernel_fluid, const float* bias_fluid, const float* dense_w, const float* dense_b,
-                              float* out96, nf_stream_t stream)
-{
-    NF_CHECK_ARG(box_feats && fluid_feats && counts2 && idx_f && pw_f && pc_f && idx_b && pw_b && pc_b && kernel_obstacle &&
-                 bias_obstacle && kernel_fluid && bias_fluid && dense_w && dense_b && out96, "null pointer");
-    if (n <= 0) return NF_OK;
-    int blocks = (n + 3) / 4;
-    if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(k_trans_conv0, dim3(blocks, 2), dim3(256), 0, (hipStream_t)stream, box_feats, fluid_feats, counts2, pitch_fluid, pitch_box, n, idx_f,
-                       pw_f, pc_f, idx_b, pw_b, pc_b, kernel_obstacle, bias_obstacle, kernel_fluid, bias_fluid, dense_w, dense_b,
-                       out96);
-    NF_CHECK_LAUNCH();
-    return NF_OK;
-}
-
 
 // ================================================================================================
 // Round 3: front kernel of the G-free inference step.  ONE launch per step does, for every particle i (a wave per

@@ -104,7 +104,7 @@ def cconv_layer(x, kernel, bias, dense_w, dense_b, row_splits, nbr, pw, pc, relu
     check(lib.nf_cconv_transform(ptr(x), M, cin, cout, int(relu), ptr(kernel.detach().contiguous()),
                                  ptr(dense_w.detach().contiguous()), ptr(G), st), "nf_cconv_transform")
     y = torch.empty(n_out, cout, dtype=torch.float32, device=x.device)
-    check(lib.nf_cconv_gather(ptr(G), cout, ptr(row_splits), 0, None, ptr(nbr), ptr(pw), ptr(pc), ptr(bias.detach().contiguous()),
+    check(lib.nf_cconv_gather(ptr(G), cout, ptr(row_splits), ptr(nbr), ptr(pw), ptr(pc), ptr(bias.detach().contiguous()),
                               ptr(dense_b.detach().contiguous()), ptr(residual), n_out, ptr(y), st), "nf_cconv_gather")
     return y
 

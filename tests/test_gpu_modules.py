@@ -123,7 +123,8 @@ def test_nerf_forward_autograd_vs_oracle(dev):
         r = stc["nerf_fine." + name].grad
         rel = float((p.grad.cpu() - r).norm() / (r.norm() + 1e-30))
         worst = max(worst, rel)
-        assert rel < 1e-2, (name, rel)          # the same kink rows enter the weight sums
+        assert rel < 5e-2, (name, rel)          # the same kink rows enter the weight sums (observed 1.6e-2 on one layer; the
+                                                # kernels are exact for their operands: test_backward_kernels_exact_for_their_operands)
     # sigma_only: gradient reaches x[:, :cx] and the eight trunk layers + sigma head only
     for p in net.parameters():
         p.grad = None
@@ -138,8 +139,68 @@ def test_nerf_forward_autograd_vs_oracle(dev):
     rows_agree(xs.grad.cpu(), xc2.grad, "dx (sigma_only)")
     gw = dict(net.named_parameters())["xyz_encoding_3.0.weight"].grad.cpu()
     rw = stc2["nerf_fine.xyz_encoding_3.0.weight"].grad
-    assert float((gw - rw).norm() / rw.norm()) < 1e-2
+    assert float((gw - rw).norm() / rw.norm()) < 5e-2
     assert float(dict(net.named_parameters())["rgb.0.weight"].grad.abs().sum()) == 0.0
+
+
+def test_backward_kernels_exact_for_their_operands(dev):
+    """The comparison with the oracle's autograd above cannot be tight: two different forwards put a hidden unit whose
+    pre-activation is ~1e-7 on different sides of the ReLU kink.  This test removes that freedom: nf_nerf_wgrad (15 weight
+    GEMMs + bias sums) and the dX GEMMs (nf_gemm_f32) against the float64 product of THEIR OWN operands (the dpre and the
+    activations the HIP forward / backward produced), for row counts from a fraction of a slice to many slices: <= 2e-6."""
+    import ctypes
+    from neurofluid_amd import _lib, ops
+    from neurofluid_amd._lib import check, ptr
+    from neurofluid_amd.nerf import _nerf_param_struct
+    from neurofluid_amd.autograd_bwd import _pack_bwd, DPRE
+    lib = _lib.load()
+    net, _ = _nerf(dev, "nerf_fine")
+    layers = net.linear_layers()
+    cx, cd = 198, 54
+    for n in (7, 300, 4096, 20000):
+        g = torch.Generator().manual_seed(n)
+        x = (torch.rand(n, 252, generator=g) * 2 - 1).to(dev)
+        gout = torch.randn(n, 4, generator=g).to(dev)
+        P, keep = _nerf_param_struct(layers)
+        packed = torch.empty(lib.nf_nerf_packed_floats(cx, cd), device=dev)
+        check(lib.nf_nerf_pack(ctypes.byref(P), cx, cd, ptr(packed), _lib.stream()))
+        X = ops.rows_to_tiles(x, cx, cd)
+        n_rows = torch.tensor([n], dtype=torch.int32, device=dev)
+        row_sample = torch.arange(n, dtype=torch.int32, device=dev)
+        out = torch.zeros(n, 4, device=dev)
+        acts = torch.empty(n * 2432, device=dev)
+        check(lib.nf_nerf_mlp_fwd(ptr(packed), cx, cd, ptr(X), ptr(n_rows), n, ptr(row_sample), ptr(out), ptr(acts), _lib.stream()))
+        packed_t = _pack_bwd(net, cx, cd, dev)
+        dpre = torch.empty(n, DPRE, device=dev)
+        check(lib.nf_nerf_mlp_bwd(ptr(packed), ptr(packed_t), cx, cd, ptr(acts), ptr(n_rows), n, ptr(row_sample), ptr(out), ptr(gout),
+                                  ptr(dpre), _lib.stream()))
+        blob = torch.empty(lib.nf_nerf_wgrad_floats(cx, cd), device=dev)
+        wsp = torch.empty(lib.nf_nerf_wgrad_workspace_floats(cx, cd, 16), device=dev)
+        colsum = torch.empty(DPRE, device=dev)
+        check(lib.nf_nerf_wgrad(ptr(dpre), ptr(acts), ptr(X), cx, cd, n, 16, ptr(wsp), ptr(blob), ptr(colsum), _lib.stream()))
+        A, D, xd = acts.view(n, 2432).double(), dpre.double(), x.double()
+        o = 0
+        for li, l in enumerate(layers):
+            k = l.weight.numel()
+            got = blob[o:o + k].view_as(l.weight).double()
+            o += k
+            if li == 0: ref = D[:, 0:256].t() @ xd[:, :cx]
+            elif li == 4: ref = D[:, 1024:1280].t() @ torch.cat([xd[:, :cx], A[:, 768:1024]], 1)
+            elif li < 8: ref = D[:, 256 * li:256 * (li + 1)].t() @ A[:, 256 * (li - 1):256 * li]
+            elif li == 8: ref = D[:, 2048:2304].t() @ A[:, 1792:2048]
+            elif li == 9: ref = D[:, 2304:2432].t() @ torch.cat([A[:, 2048:2304], xd[:, cx:]], 1)
+            elif li == 10: ref = D[:, 2435:2436].t() @ A[:, 1792:2048]
+            else: ref = D[:, 2432:2435].t() @ A[:, 2304:2432]
+            assert float((got - ref).norm() / (ref.norm() + 1e-300)) <= 2e-6, (n, li)
+        bias_ref = D.sum(0)
+        assert float((colsum.double() - bias_ref).norm() / bias_ref.norm()) <= 2e-6
+        W1, W5, Wd = layers[0].weight.detach(), layers[4].weight.detach(), layers[9].weight.detach()
+        dx = torch.empty(n, cx + cd, device=dev)
+        ops.gemm(dpre[:, 0:256], W1, out=dx[:, :cx])
+        ops.gemm(dpre[:, 1024:1280], W5[:, :cx], out=dx[:, :cx], accumulate=True)
+        ops.gemm(dpre[:, 2304:2432], Wd[:, 256:], out=dx[:, cx:])
+        ref = torch.cat([D[:, 0:256] @ W1.double() + D[:, 1024:1280] @ W5[:, :cx].double(), D[:, 2304:2432] @ Wd[:, 256:].double()], 1)
+        assert float((dx.double() - ref).norm() / ref.norm()) <= 2e-6, n
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 1, 1), (37, 5, 3), (128, 128, 32), (129, 131, 33), (300, 198, 256), (96, 4160, 4913),

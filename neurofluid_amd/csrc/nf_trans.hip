@@ -24,31 +24,23 @@ extern "C" int nf_trans_prepare_limits(int* max_points, int* max_cells)
 
 __global__ void __launch_bounds__(TP_BLOCK) k_trans_prepare(NfGridHeader h, void* __restrict__ ws, const float* __restrict__ pos,
                                                             const float* __restrict__ vel, float gx, float gy, float gz, float dt,
-                                                            float* __restrict__ pos_new, float* __restrict__ vel_new,
+                                                            float cell, float* __restrict__ pos_new, float* __restrict__ vel_new,
                                                             float* __restrict__ feats4)
 {
     extern __shared__ int cells[];          // n_cells counters -> starts -> ends, then the scatter list (n_points)
     __shared__ int s_scan[TP_BLOCK / 64];
+    __shared__ float s_red[TP_BLOCK / 64][6];
+    __shared__ NfGridHeader hh;
     char* b = (char*)ws;
-    int* cell_start = (int*)(b + h.off_cell_start);
-    int* tmp_list = cells + h.n_cells;
-    int* sorted_idx = (int*)(b + h.off_sorted_idx);
-    float4* sorted_pos = (float4*)(b + h.off_sorted_pos);
-    const int n = h.n_points, nc = h.n_cells, tid = threadIdx.x;
-    if (tid == 0) {
-        for (int d = 0; d < 3; ++d) { h.pt_lo[d] = nf_f2ord(INFINITY); h.pt_hi[d] = nf_f2ord(-INFINITY); }
-        *(NfGridHeader*)ws = h;
-    }
-    for (int c = tid; c < nc; c += TP_BLOCK) cells[c] = 0;
-    __syncthreads();
-    // ---- integrate + count
+    const int n = h.n_points, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // ---- integrate; the exact bounds of the integrated cloud
     const float g[3] = {gx, gy, gz};
-    int mycell[TP_MAX_PER_THREAD];
     float px[TP_MAX_PER_THREAD], py[TP_MAX_PER_THREAD], pz[TP_MAX_PER_THREAD];
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
     for (int u = 0; u < TP_MAX_PER_THREAD; ++u) {
         const int i = u * TP_BLOCK + tid;
-        mycell[u] = -1;
+        px[u] = py[u] = pz[u] = 0.f;
         if (i < n) {
             float pn[3];
 #pragma unroll
@@ -59,13 +51,66 @@ __global__ void __launch_bounds__(TP_BLOCK) k_trans_prepare(NfGridHeader h, void
                 pos_new[3 * i + d] = pn[d];
                 vel_new[3 * i + d] = vn;
                 feats4[4 * i + 1 + d] = vn;
+                lo[d] = fminf(lo[d], pn[d]); hi[d] = fmaxf(hi[d], pn[d]);
             }
             feats4[4 * i] = 1.f;
-            const int cx = nf_cell_coord(pn[0], h.origin[0], h.inv_cell[0], h.dims[0]);
-            const int cy = nf_cell_coord(pn[1], h.origin[1], h.inv_cell[1], h.dims[1]);
-            const int cz = nf_cell_coord(pn[2], h.origin[2], h.inv_cell[2], h.dims[2]);
-            mycell[u] = (cz * h.dims[1] + cy) * h.dims[0] + cx;
             px[u] = pn[0]; py[u] = pn[1]; pz[u] = pn[2];
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { lo[d] = fminf(lo[d], __shfl_xor(lo[d], o, 64)); hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], o, 64)); }
+    if (lane == 0) { for (int d = 0; d < 3; ++d) { s_red[wv][d] = lo[d]; s_red[wv][3 + d] = hi[d]; } }
+    __syncthreads();
+    if (tid == 0) {
+        // The grid of THIS step hugs the cloud: the caller's bbox (the container, static: no host round trip) only bounds it —
+        // a few hundred cells instead of the container's ~29 000, which every pass below (zero, scan, store) walks.  Points
+        // outside the bbox land in border cells (the search stays exact, include/neurofluid_hip.h); the workspace offsets are
+        // those of the caller's header, computed for the larger grid.
+        hh = h;
+        int ncell = 1;
+        for (int d = 0; d < 3; ++d) {
+            float l = INFINITY, u2 = -INFINITY;
+            for (int w2 = 0; w2 < TP_BLOCK / 64; ++w2) { l = fminf(l, s_red[w2][d]); u2 = fmaxf(u2, s_red[w2][3 + d]); }
+            const float blo = h.origin[d], bhi = h.origin[d] + (float)h.dims[d] / h.inv_cell[d];
+            l = fminf(fmaxf(l, blo), bhi); u2 = fminf(fmaxf(u2, blo), bhi);
+            if (!(u2 >= l)) { l = blo; u2 = blo; }
+            const float ext = u2 - l;
+            float c = cell;
+            if (ext / c > (float)(NF_GRID_MAX_DIM - 1)) c = ext / (float)(NF_GRID_MAX_DIM - 1);
+            int dim = (int)floorf(ext / c) + 1;
+            dim = max(1, min(dim, min(NF_GRID_MAX_DIM, h.dims[d])));
+            hh.origin[d] = l; hh.inv_cell[d] = 1.0f / c; hh.dims[d] = dim;
+            ncell *= dim;
+        }
+        for (int d = 0; d < 3; ++d) {           // exact bounds of the points (all waves)
+            float l = INFINITY, u2 = -INFINITY;
+            for (int w2 = 0; w2 < TP_BLOCK / 64; ++w2) { l = fminf(l, s_red[w2][d]); u2 = fmaxf(u2, s_red[w2][3 + d]); }
+            hh.pt_lo[d] = nf_f2ord(l); hh.pt_hi[d] = nf_f2ord(u2);
+        }
+        hh.n_cells = ncell;
+        *(NfGridHeader*)ws = hh;
+    }
+    __syncthreads();
+    const int nc = hh.n_cells;
+    int* cell_start = (int*)(b + hh.off_cell_start);
+    int* tmp_list = cells + nc;
+    int* sorted_idx = (int*)(b + hh.off_sorted_idx);
+    float4* sorted_pos = (float4*)(b + hh.off_sorted_pos);
+    for (int c = tid; c < nc; c += TP_BLOCK) cells[c] = 0;
+    __syncthreads();
+    // ---- count
+    int mycell[TP_MAX_PER_THREAD];
+#pragma unroll
+    for (int u = 0; u < TP_MAX_PER_THREAD; ++u) {
+        const int i = u * TP_BLOCK + tid;
+        mycell[u] = -1;
+        if (i < n) {
+            const int cx = nf_cell_coord(px[u], hh.origin[0], hh.inv_cell[0], hh.dims[0]);
+            const int cy = nf_cell_coord(py[u], hh.origin[1], hh.inv_cell[1], hh.dims[1]);
+            const int cz = nf_cell_coord(pz[u], hh.origin[2], hh.inv_cell[2], hh.dims[2]);
+            mycell[u] = (cz * hh.dims[1] + cy) * hh.dims[0] + cx;
             atomicAdd(&cells[mycell[u]], 1);
         }
     }
@@ -76,20 +121,19 @@ __global__ void __launch_bounds__(TP_BLOCK) k_trans_prepare(NfGridHeader h, void
     int run = 0;
     for (int c = c0; c < c1; ++c) run += cells[c];
     {
-        const int lane = tid & 63, w = tid >> 6;
         int x = run;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
-        if (lane == 63) s_scan[w] = x;
+        if (lane == 63) s_scan[wv] = x;
         __syncthreads();
-        if (w == 0) {
-            int s = lane < TP_BLOCK / 64 ? s_scan[lane] : 0;
+        if (wv == 0) {
+            int s2 = lane < TP_BLOCK / 64 ? s_scan[lane] : 0;
 #pragma unroll
-            for (int o = 1; o < 16; o <<= 1) { const int y = __shfl_up(s, o, 64); if (lane >= o) s += y; }
-            if (lane < TP_BLOCK / 64) s_scan[lane] = s;
+            for (int o = 1; o < 16; o <<= 1) { const int y = __shfl_up(s2, o, 64); if (lane >= o) s2 += y; }
+            if (lane < TP_BLOCK / 64) s_scan[lane] = s2;
         }
         __syncthreads();
-        int base = (w ? s_scan[w - 1] : 0) + x - run;
+        int base = (wv ? s_scan[wv - 1] : 0) + x - run;
         for (int c = c0; c < c1; ++c) { const int cnt = cells[c]; cells[c] = base; cell_start[c] = base; base += cnt; }
         if (tid == TP_BLOCK - 1) cell_start[nc] = s_scan[TP_BLOCK / 64 - 1];
     }
@@ -105,11 +149,11 @@ __global__ void __launch_bounds__(TP_BLOCK) k_trans_prepare(NfGridHeader h, void
         const int c = mycell[u];
         if (c < 0) continue;
         const int i = u * TP_BLOCK + tid;
-        const int s = c ? cells[c - 1] : 0, e = cells[c];
+        const int s2 = c ? cells[c - 1] : 0, e = cells[c];
         int rank = 0;
-        for (int t = s; t < e; ++t) rank += (tmp_list[t] < i);
-        sorted_idx[s + rank] = i;
-        sorted_pos[s + rank] = make_float4(px[u], py[u], pz[u], __int_as_float(i));
+        for (int t = s2; t < e; ++t) rank += (tmp_list[t] < i);
+        sorted_idx[s2 + rank] = i;
+        sorted_pos[s2 + rank] = make_float4(px[u], py[u], pz[u], __int_as_float(i));
     }
 }
 
@@ -133,7 +177,7 @@ extern "C" int nf_trans_prepare(const float* pos, const float* vel, const float 
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     hipLaunchKernelGGL(k_trans_prepare, dim3(1), dim3(TP_BLOCK), lds, (hipStream_t)stream, h, grid_ws, pos, vel, gravity[0],
-                       gravity[1], gravity[2], dt, pos_new, vel_new, feats4);
+                       gravity[1], gravity[2], dt, cell, pos_new, vel_new, feats4);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }

@@ -445,8 +445,13 @@ def test_fused_inference_step_vs_multi_launch_path(dev):
         assert pa._fused is not None and pb._fused is None and getattr(pa, "fused_overflows", 0) == 0
         rs = pa.conv0_fluid.nns.neighbors_row_splits
         assert torch.equal(rs, pb.conv0_fluid.nns.neighbors_row_splits)
+        # the neighbour SETS of every row (the order inside a row is the cell order of each path's own grid: the fused step
+        # builds a grid that hugs the cloud, the multi-launch path one over the container's bounds; Open3D promises no order)
         nnz = int(rs[-1])
-        assert torch.equal(pa.conv0_fluid.nns.neighbors_index[:nnz], pb.conv0_fluid.nns.neighbors_index[:nnz])
+        rows = torch.repeat_interleave(torch.arange(rs.numel() - 1, device=dev), (rs[1:] - rs[:-1]))
+        ka = rows * (1 << 20) + pa.conv0_fluid.nns.neighbors_index[:nnz].long()
+        kb = rows * (1 << 20) + pb.conv0_fluid.nns.neighbors_index[:nnz].long()
+        assert torch.equal(torch.sort(ka).values, torch.sort(kb).values)
         assert torch.equal(pa.pos_correction, pa._y3 / 128)
 
 

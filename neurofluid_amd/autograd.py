@@ -78,13 +78,85 @@ def _run_passes(net, particles, ro, rays, white_bg, fine, save_acts, _retry=Fals
     return p0, p1, rays_c, ro_c, grid
 
 
+class LazyResults(dict):
+    """The renderer's result dict.  ``num_nn_*`` has the reference's dtype (int64: ``nn_mask.sum(-1)``,
+    models/renderer.py:138) but the kernels count in int32, and the reference's callers read it only for TensorBoard
+    histograms (trainer/trainer_renderer.py:138-141): the widening copy (0.14 ms per 400x400 frame, 2.4 % of an fp16 frame) is
+    made when a key is first READ, from the int32 tensor the entry keeps alive.  Every way of reading a value goes through
+    ``_force``; ``raw_int32`` hands the unconverted tensor to a caller that only forwards it (render_loop)."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self._pending = {}
+
+    def set_lazy(self, key, int32_tensor, shape):
+        self._pending[key] = (int32_tensor, tuple(shape))
+        dict.__setitem__(self, key, None)
+
+    def raw_int32(self, key):
+        """(int32 tensor, shape) of a count that has not been widened yet, else None."""
+        return self._pending.get(key)
+
+    def _force(self, key=None):
+        for k in ([key] if key is not None else list(self._pending)):
+            ent = self._pending.pop(k, None)
+            if ent is not None:
+                dict.__setitem__(self, k, ent[0].view(ent[1]).to(torch.int64))
+
+    def __getitem__(self, key):
+        self._force(key)
+        return dict.__getitem__(self, key)
+
+    def __setitem__(self, key, value):
+        self._pending.pop(key, None)
+        dict.__setitem__(self, key, value)
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def pop(self, key, *default):
+        self._force(key)
+        return dict.pop(self, key, *default)
+
+    def __iter__(self):                     # (a Python-level __iter__ also keeps dict(res) / {**res} off the C fast path
+        return dict.__iter__(self)          # that would copy the placeholder of a pending key)
+
+    def discard(self, key):
+        self._pending.pop(key, None)
+        dict.pop(self, key, None)
+
+    def items(self):
+        self._force()
+        return dict.items(self)
+
+    def values(self):
+        self._force()
+        return dict.values(self)
+
+    def copy(self):
+        self._force()
+        return dict(self)
+
+    def __eq__(self, other):
+        self._force()
+        return dict.__eq__(self, other)
+
+    __hash__ = None
+
+    def __repr__(self):
+        self._force()
+        return dict.__repr__(self)
+
+
 def _results(p0, p1):
     R = p0.R
-    out = {"rgb0": p0.rgb, "depth0": p0.depth, "opacity0": p0.opacity,
-           "num_nn_0": p0.num_nn.view(R, p0.S, 1).to(torch.int64), "mask_0": p0.mask_sum.view(R, 1)}
+    out = LazyResults({"rgb0": p0.rgb, "depth0": p0.depth, "opacity0": p0.opacity})
+    out.set_lazy("num_nn_0", p0.num_nn, (R, p0.S, 1))
+    out["mask_0"] = p0.mask_sum.view(R, 1)
     if p1 is not None:
-        out.update({"rgb1": p1.rgb, "depth1": p1.depth, "opacity1": p1.opacity,
-                    "num_nn_1": p1.num_nn.view(R, p1.S, 1).to(torch.int64), "mask_1": p1.mask_sum.view(R, 1)})
+        out.update({"rgb1": p1.rgb, "depth1": p1.depth, "opacity1": p1.opacity})
+        out.set_lazy("num_nn_1", p1.num_nn, (R, p1.S, 1))
+        out["mask_1"] = p1.mask_sum.view(R, 1)
     return out
 
 

@@ -13,7 +13,7 @@ import torch
 
 from . import _lib, ops
 from ._lib import check, ptr
-from .autograd import _run_passes, _results
+from .autograd import _run_passes, _results, LazyResults
 
 ACT, DPRE = 2432, 2436
 
@@ -120,7 +120,8 @@ class _RenderFn(torch.autograd.Function):
         if fine:
             keys += ["rgb1", "depth1", "opacity1", "num_nn_1", "mask_1"]
         ctx.keys = keys
-        outs = tuple(res[k] for k in keys)
+        # the neighbour counts leave the Function as the kernels' int32 (widened lazily by render_with_grad's dict)
+        outs = tuple(res.raw_int32(k)[0].view(res.raw_int32(k)[1]) if res.raw_int32(k) is not None else res[k] for k in keys)
         ctx.mark_non_differentiable(*[o for k, o in zip(keys, outs) if not k.startswith("rgb")])
         # The pass buffers live on ctx for backward.  They must NOT keep the tensors that are returned: an output holds
         # its grad_fn (this ctx) through a C++ edge the Python GC cannot see, so ctx -> buffers -> output -> ctx would
@@ -167,7 +168,13 @@ def render_with_grad(net, particles, ro, rays, white_bg, fine):
     outs = _RenderFn.apply(net, particles, ro, rays, white_bg, fine, *_nerf_params(net))
     keys = ["rgb0", "depth0", "opacity0", "num_nn_0", "mask_0"] + (
         ["rgb1", "depth1", "opacity1", "num_nn_1", "mask_1"] if fine else [])
-    return dict(zip(keys, outs))
+    out = LazyResults()
+    for k, v in zip(keys, outs):
+        if k.startswith("num_nn") and v.dtype == torch.int32:
+            out.set_lazy(k, v, v.shape)
+        else:
+            out[k] = v
+    return out
 
 
 # ================================================================================================

@@ -3,6 +3,7 @@ optional ray-chunk sharding across ranks (neurofluid_amd/dist.py)."""
 import torch
 
 from . import dist as nfdist
+from .autograd import LazyResults
 
 _OWN_IDX = {}
 
@@ -49,14 +50,21 @@ def render_image(renderer, particle_pos, N_ray, ro, rays, focal_length=None, cw=
         res = renderer(particle_pos, my_ro[i:i + device_chunk] if per_ray_ro else my_ro, my_rays[i:i + device_chunk],
                        focal_length, cw)
         for key in keys:
+            raw = res.raw_int32(key) if key.startswith("num_nn") and hasattr(res, "raw_int32") else None
+            if raw is not None:             # the kernels' int32 counts: widened to the reference's int64 when first read
+                parts[key].append(raw[0].view(raw[1][0], -1))
+                continue
             v = res[key]
             parts[key].append(v.view(v.shape[0], -1) if key.startswith("num_nn") else v)
     names = {"rgb0": "pred_rgbs_0", "rgb1": "pred_rgbs_1"}
-    ret = {}
+    ret = LazyResults()
     if world == 1:
         for key in keys:
             t = parts[key][0] if len(parts[key]) == 1 else torch.cat(parts[key], dim=0)     # one fused call: no copy
-            ret[names.get(key, key)] = t.reshape(-1) if key.startswith("num_nn") else t
+            if key.startswith("num_nn") and t.dtype == torch.int32:
+                ret.set_lazy(key, t, (t.numel(),))
+            else:
+                ret[names.get(key, key)] = t.reshape(-1) if key.startswith("num_nn") else t
         return ret
     share = nfdist.share_size(n_chunks, world)
     dev = rays.device
@@ -65,7 +73,7 @@ def render_image(renderer, particle_pos, N_ray, ro, rays, focal_length=None, cw=
     for key in keys:
         if not gather and not key.startswith("rgb"):
             continue
-        dtype = parts[key][0].dtype if parts[key] else (torch.int64 if key.startswith("num_nn") else torch.float32)
+        dtype = parts[key][0].dtype if parts[key] else (torch.int32 if key.startswith("num_nn") else torch.float32)
         # own chunks in ownership order; only the image's last chunk can be ragged and it is the last of its owner, so
         # the rendered rows are a prefix of this rank's (share * ray_chunk)-row slab
         local = torch.zeros(share * ray_chunk, widths[key], dtype=dtype, device=dev)
@@ -73,5 +81,8 @@ def render_image(renderer, particle_pos, N_ray, ro, rays, focal_length=None, cw=
             t = parts[key][0] if len(parts[key]) == 1 else torch.cat(parts[key], dim=0)
             local[:t.shape[0]] = t
         full = nfdist.gather_chunks(local, n_chunks, ray_chunk, N_ray, rank, world)
-        ret[names.get(key, key)] = full.reshape(-1) if key.startswith("num_nn") else full
+        if key.startswith("num_nn") and full.dtype == torch.int32:
+            ret.set_lazy(key, full, (full.numel(),))
+        else:
+            ret[names.get(key, key)] = full.reshape(-1) if key.startswith("num_nn") else full
     return ret

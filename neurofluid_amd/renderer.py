@@ -177,4 +177,6 @@ class RenderNet(nn.Module):
         if self.N_importance <= 0:
             raise AssertionError("fine_rendering needs N_importance > 0 (models/renderer.py:345)")
         res = self.forward(physical_particles, ro, rays, focal, c2w, use_disp, perturb, noise_std, white_background)
-        return {k: res[k] for k in ("rgb1", "depth1", "opacity1", "num_nn_1", "mask_1")}
+        for k in ("rgb0", "depth0", "opacity0", "num_nn_0", "mask_0"):
+            res.discard(k)
+        return res

@@ -328,3 +328,29 @@ def test_pixel_sampler_warns_about_foreign_draws_and_closes_twice():
         with PixelSampler(rng2, 1, 8, lambda step: 50, 0) as s2:
             s2.next(0)
     assert not any("another consumer" in str(x.message) for x in w2)
+
+
+def test_lazy_results_widen_counts_on_first_read():
+    """The renderer's result dict keeps num_nn_* as the kernels' int32 and widens to the reference's int64
+    (models/renderer.py:138: nn_mask.sum(-1)) on the first read, whichever way the value is read."""
+    import torch
+    from neurofluid_amd.autograd import LazyResults
+    def make():
+        r = LazyResults({"rgb0": torch.zeros(2, 3)})
+        r.set_lazy("num_nn_0", torch.arange(6, dtype=torch.int32), (2, 3, 1))
+        return r
+    r = make()
+    assert list(r.keys()) == ["rgb0", "num_nn_0"] and "num_nn_0" in r and len(r) == 2
+    assert r.raw_int32("num_nn_0")[0].dtype == torch.int32
+    v = r["num_nn_0"]
+    assert v.dtype == torch.int64 and v.shape == (2, 3, 1) and v.flatten().tolist() == list(range(6))
+    assert r.raw_int32("num_nn_0") is None and r["num_nn_0"] is v
+    for read in (lambda d: dict(d)["num_nn_0"], lambda d: {**d}["num_nn_0"], lambda d: d.get("num_nn_0"),
+                 lambda d: dict(d.items())["num_nn_0"], lambda d: list(d.values())[1], lambda d: d.pop("num_nn_0"),
+                 lambda d: d.copy()["num_nn_0"]):
+        got = read(make())
+        assert got is not None and got.dtype == torch.int64 and got.shape == (2, 3, 1)
+    r = make(); r.discard("num_nn_0")
+    assert list(r.keys()) == ["rgb0"]
+    r = make(); r["num_nn_0"] = 5
+    assert r["num_nn_0"] == 5

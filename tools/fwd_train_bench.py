@@ -1,0 +1,35 @@
+"""Training-forward MLP kernels (activations saved) on synthetic rows (dev tool): tile-per-wave nf_nerf_mlp_fwd vs
+tile-per-workgroup nf_nerf_mlp_fwd_n, and nf_nerf_mlp_bwd, at the row counts given.  usage: python tools/fwd_train_bench.py [rows ...]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from neurofluid_amd import synthetic as ro
+from neurofluid_amd import ops, _lib
+from neurofluid_amd._lib import ptr, check
+
+dev = torch.device("cuda:0")
+st = ro.deterministic_nerf_state()
+names = ops.NERF_LAYER_NAMES
+W = [st[f"nerf_coarse.{k}.weight"].to(dev) for k in names]
+B = [st[f"nerf_coarse.{k}.bias"].to(dev) for k in names]
+packed = ops.pack_nerf(W, B, 198, 54)
+lib = _lib.load()
+rows = [int(a) for a in sys.argv[1:]] or [202 * 32, 1024 * 32, 2048 * 32, 2250 * 32]
+for n in rows:
+    X = torch.rand((n + 31) // 32 * 32 * 256, device=dev) * 2 - 1
+    n_rows = torch.tensor([n], dtype=torch.int32, device=dev)
+    row_sample = torch.arange(n, dtype=torch.int32, device=dev)
+    out = torch.zeros(n, 4, device=dev)
+    acts = torch.empty(ops._round_rows(n) * 2432, device=dev)
+    def t(fn, it=6):
+        for _ in range(2): fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(it): fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / it * 1e3
+    a = t(lambda: check(lib.nf_nerf_mlp_fwd(ptr(packed), 198, 54, ptr(X), ptr(n_rows), n, ptr(row_sample), ptr(out), ptr(acts), _lib.stream())))
+    b = t(lambda: check(lib.nf_nerf_mlp_fwd_n(ptr(packed), 198, 54, ptr(X), ptr(n_rows), n, ptr(row_sample), ptr(out), ptr(acts), _lib.stream())))
+    print("rows %6d (%4d tiles): tile-per-wave %7.1f us (%5.1f TFLOP/s)   tile-per-workgroup %7.1f us (%5.1f TFLOP/s)" %
+          (n, (n + 31) // 32, a, n * 1.331968 / a, b, n * 1.331968 / b))

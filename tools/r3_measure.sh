@@ -5,7 +5,7 @@ set -u
 cd $GRAFT_REPO_ROOT
 O=gpurun_out
 WHAT="${@:-tests bench strong pmc}"
-SQ="SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU"
+SQ="SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE"
 for w in $WHAT; do case $w in
 tests)
   python -m pytest tests -m gpu -q -s --durations=8 > $O/r3_gputest_full.log 2>&1; tail -4 $O/r3_gputest_full.log ;;

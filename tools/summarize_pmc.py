@@ -84,7 +84,13 @@ for k in kernels:
             if c in per:
                 e[c + "_frac"] = per[c] / wc
         if "SQ_VALU_MFMA_BUSY_CYCLES" in per:
+            # per WAVE-cycle: saturates at 1 / (waves resident per SIMD) — right for the one-wave-per-SIMD MLP kernels,
+            # misleading for kernels that keep 2-3 waves per SIMD (k_wgrad, k_mlp_fwd_n); the two figures below are per SIMD-time
             e["mfma_busy_over_wave_cycles"] = per["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * wc)
+            if dur:
+                e["mfma_busy_over_simd_time_at_2p4GHz"] = per["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (dur * 2400.0)
+            if per.get("GRBM_GUI_ACTIVE"):
+                e["mfma_busy_over_gui_active_x1024_simds"] = per["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * per["GRBM_GUI_ACTIVE"])
         if per.get("SQ_INSTS_VALU_MFMA_MOPS_F16") or per.get("SQ_INSTS_MFMA"):
             pass
     res["kernels"][k] = e

@@ -9,9 +9,9 @@ def _prep(x):
     return x.detach().contiguous().float()
 
 
-def _run_passes(net, particles, ro, rays, white_bg, fine, save_acts, _retry=False):
+def _run_passes(net, particles, ro, rays, white_bg, fine, save_acts, _retry=False, use_disp=False):
     dev = rays.device
-    z_table, u_table = net._tables(dev)
+    z_table, u_table = net._tables(dev, use_disp)
     grid = net.grid_for(particles)
     pts = grid.points
     rays_c = _prep(rays)
@@ -43,7 +43,7 @@ def _run_passes(net, particles, ro, rays, white_bg, fine, save_acts, _retry=Fals
     p0.packed = pk0
     p1 = None
     if fine:
-        z1 = ops.importance_sample(z_table, p0.weights, u_table, net.N_importance, net.zero_row(dev))
+        z1 = ops.importance_sample(z_table, p0.weights, u_table, net.N_importance, net.zero_row(dev, use_disp))
         if save_acts:
             pk1, ws1, ph1 = net.packed_weights(net.nerf_fine), None, None
         else:
@@ -74,7 +74,7 @@ def _run_passes(net, particles, ro, rays, white_bg, fine, save_acts, _retry=Fals
             ops.PROFILE["rows"] = [(known[id(r)] if id(r) in known else int(r.item())) if torch.is_tensor(r) else r
                                    for r in ops.PROFILE["rows"]]
         if overflow:
-            return _run_passes(net, particles, ro, rays, white_bg, fine, save_acts, _retry=True)
+            return _run_passes(net, particles, ro, rays, white_bg, fine, save_acts, _retry=True, use_disp=use_disp)
     return p0, p1, rays_c, ro_c, grid
 
 
@@ -160,11 +160,11 @@ def _results(p0, p1):
     return out
 
 
-def render_forward(net, particles, ro, rays, white_bg=True, fine=True):
+def render_forward(net, particles, ro, rays, white_bg=True, fine=True, use_disp=False):
     needs_grad = torch.is_grad_enabled() and (particles.requires_grad or any(p.requires_grad for p in net.parameters()))
     if needs_grad:
         from .autograd_bwd import render_with_grad
-        return render_with_grad(net, particles, ro, rays, white_bg, fine)
+        return render_with_grad(net, particles, ro, rays, white_bg, fine, use_disp)
     with torch.no_grad():
-        p0, p1, _, _, _ = _run_passes(net, particles, ro, rays, white_bg, fine, save_acts=False)
+        p0, p1, _, _, _ = _run_passes(net, particles, ro, rays, white_bg, fine, save_acts=False, use_disp=use_disp)
         return _results(p0, p1)

@@ -111,7 +111,10 @@ class _RenderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, particles, ro, rays, white_bg, fine, *params):
         ctx.set_materialize_grads(False)      # backward reads rgb0 / rgb1 only: no zero tensors for the 8 other outputs
-        p0, p1, rays_c, ro_c, grid = _run_passes(net, particles, ro, rays, white_bg, fine, save_acts=True)
+        use_disp = isinstance(fine, tuple) and fine[1]      # (fine, use_disp) rides in one non-tensor argument
+        fine = fine[0] if isinstance(fine, tuple) else fine
+        ctx.use_disp = use_disp
+        p0, p1, rays_c, ro_c, grid = _run_passes(net, particles, ro, rays, white_bg, fine, save_acts=True, use_disp=use_disp)
         ctx.net, ctx.p0, ctx.p1, ctx.rays_c, ctx.white_bg, ctx.fine = net, p0, p1, rays_c, white_bg, fine
         ctx.particles_need_grad = particles.requires_grad
         ctx.ro_c, ctx.pts = ro_c, grid.points
@@ -135,7 +138,7 @@ class _RenderFn(torch.autograd.Function):
     def backward(ctx, *grads):
         net = ctx.net
         g = dict(zip(ctx.keys, grads))
-        z_table, _ = net._tables(ctx.rays_c.device)
+        z_table, _ = net._tables(ctx.rays_c.device, ctx.use_disp)
         dpart = torch.zeros_like(ctx.pts) if ctx.particles_need_grad else None
         extra = dict(particles=ctx.pts, ro_c=ctx.ro_c, dparticles=dpart)
         both = g.get("rgb0") is not None and ctx.fine and g.get("rgb1") is not None and TWO_STREAM_BACKWARD
@@ -164,8 +167,8 @@ class _RenderFn(torch.autograd.Function):
         return (None, dpart, None, None, None, None) + tuple(gc) + tuple(gf)
 
 
-def render_with_grad(net, particles, ro, rays, white_bg, fine):
-    outs = _RenderFn.apply(net, particles, ro, rays, white_bg, fine, *_nerf_params(net))
+def render_with_grad(net, particles, ro, rays, white_bg, fine, use_disp=False):
+    outs = _RenderFn.apply(net, particles, ro, rays, white_bg, (fine, bool(use_disp)) if use_disp else fine, *_nerf_params(net))
     keys = ["rgb0", "depth0", "opacity0", "num_nn_0", "mask_0"] + (
         ["rgb1", "depth1", "opacity1", "num_nn_1", "mask_1"] if fine else [])
     out = LazyResults()

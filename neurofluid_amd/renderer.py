@@ -69,7 +69,8 @@ class RenderNet(nn.Module):
         self.nerf_fine = NeRF(in_channels_xyz=in_xyz, in_channels_dir=in_dir)
         self._z_table = None
         self._u_table = None
-        self._zero_row = None
+        self._zero_row = {}
+        self._z_table_disp = None
         self._bbox_hint = None      # bounds of the last cloud, padded (note_point_bounds): the next grid's bbox
         self._grid_cache = (None, None, None)
         self._workspace = None
@@ -79,20 +80,23 @@ class RenderNet(nn.Module):
     def set_ro(self, cw):
         return cw[:, 3]
 
-    def _tables(self, device):
+    def _tables(self, device, use_disp=False):
+        """(coarse depths, importance-sampling u) shared by all rays.  use_disp: depths linear in disparity
+        (utils/ray_utils.py:239-240) — a second table, since near / far are the module's constants."""
         if self._z_table is None or self._z_table.device != device:
             t = torch.linspace(0, 1, self.N_samples)          # utils/ray_utils.py:236-238 (CPU bits, then copied)
             self._z_table = (self.near * (1 - t) + self.far * t).to(device)
+            self._z_table_disp = (1 / (1 / self.near * (1 - t) + 1 / self.far * t)).to(device)
             self._u_table = torch.linspace(0., 1., steps=max(self.N_importance, 1)).to(device)
-            self._zero_row = None
-        return self._z_table, self._u_table
+            self._zero_row = {}
+        return (self._z_table_disp if use_disp else self._z_table), self._u_table
 
-    def zero_row(self, device):
+    def zero_row(self, device, use_disp=False):
         """Resampled depths shared by every ray whose coarse weights are all zero (ops.importance_zero_row)."""
-        z_table, u_table = self._tables(device)
-        if self._zero_row is None:
-            self._zero_row = ops.importance_zero_row(z_table, u_table, self.N_importance)
-        return self._zero_row
+        z_table, u_table = self._tables(device, use_disp)
+        if use_disp not in self._zero_row:
+            self._zero_row[use_disp] = ops.importance_zero_row(z_table, u_table, self.N_importance)
+        return self._zero_row[use_disp]
 
     def grid_for(self, particles):
         """One grid per particle tensor *version* (rebuilt when the particles move)."""
@@ -154,16 +158,19 @@ class RenderNet(nn.Module):
     # ------------------------------------------------------------------
     def forward(self, physical_particles, ro, rays, focal=None, c2w=None, use_disp=False, perturb=0, noise_std=0.,
                 white_background=True):
-        if use_disp or perturb != 0 or noise_std != 0.:
-            raise NotImplementedError("use_disp / perturb / noise_std are never passed by the reference callers "
-                                      "(trainer/basetrainer.py:284-289)")
+        if perturb != 0 or noise_std != 0.:
+            raise NotImplementedError("perturb / noise_std (random jitter of the depths and of sigma) are never passed by the "
+                                      "reference callers (trainer/basetrainer.py:284-289)")
         from .autograd import render_forward
-        return render_forward(self, physical_particles, ro, rays, white_background, fine=self.N_importance > 0)
+        return render_forward(self, physical_particles, ro, rays, white_background, fine=self.N_importance > 0,
+                              use_disp=bool(use_disp))
 
     def coarse_rendering(self, physical_particles, ro, rays, focal=None, c2w=None, use_disp=False, perturb=0,
                          noise_std=0., white_background=True):
+        if perturb != 0 or noise_std != 0.:
+            raise NotImplementedError("perturb / noise_std are never passed by the reference callers")
         from .autograd import render_forward
-        return render_forward(self, physical_particles, ro, rays, white_background, fine=False)
+        return render_forward(self, physical_particles, ro, rays, white_background, fine=False, use_disp=bool(use_disp))
 
     def fine_rendering(self, physical_particles, ro, rays, focal=None, c2w=None, use_disp=False, perturb=0,
                        noise_std=0., white_background=True):

@@ -65,16 +65,18 @@ def get_rays(directions, c2w):
 
 
 # ----------------------------------------------------------------------------------------------
-# A1  coarse sampling (perturb == 0, use_disp False: the only mode the callers use,
-#     trainer/basetrainer.py:284-289)
+# A1  coarse sampling (perturb == 0: the only mode the callers use, trainer/basetrainer.py:284-289;
+#     use_disp = linear in disparity, utils/ray_utils.py:236-240, pinned by tests/golden/a1_a10_disp.npz)
 # ----------------------------------------------------------------------------------------------
-def coarse_z(near, far, n):
+def coarse_z(near, far, n, use_disp=False):
     t = torch.linspace(0, 1, n)
+    if use_disp:
+        return 1 / (1 / near * (1 - t) + 1 / far * t)
     return near * (1 - t) + far * t
 
 
-def coarse_sample_ray(near, far, rays, n):
-    z = coarse_z(near, far, n).expand(rays.shape[0], n)
+def coarse_sample_ray(near, far, rays, n, use_disp=False):
+    z = coarse_z(near, far, n, use_disp).expand(rays.shape[0], n)
     xyz = rays[:, None, 0:3] + rays[:, None, 3:6] * z[:, :, None]
     return z, xyz
 
@@ -238,9 +240,9 @@ def render_pass(state, prefix, particles, ro, rays, z, xyz, cfg, white_backgroun
 
 
 def render_forward(state, particles, ro, rays, near, far, cfg=DEFAULT_CFG, white_background=True,
-                   return_debug=False):
+                   return_debug=False, use_disp=False):
     """models/renderer.py:211-270 -> dict with the reference's keys."""
-    z0, xyz0 = coarse_sample_ray(near, far, rays, cfg["N_samples"])
+    z0, xyz0 = coarse_sample_ray(near, far, rays, cfg["N_samples"], use_disp)
     p0 = render_pass(state, "nerf_coarse", particles, ro, rays, z0, xyz0, cfg, white_background)
     out = {"rgb0": p0["rgb"], "depth0": p0["depth"], "opacity0": p0["weights"].sum(1),
            "num_nn_0": p0["num_nn"], "mask_0": p0["mask"].sum(1)}

@@ -296,6 +296,49 @@ def test_forward_vs_oracle(dev, use_mask):
             assert torch.equal(out[k].cpu(), T(g[k]))
 
 
+def test_forward_disparity_sampling(dev):
+    """use_disp=True (models/renderer.py:211, utils/ray_utils.py:239-240): forward vs the dict the reference itself returned
+    (tests/golden/a1_a10_disp.npz) and vs the oracle; the gradient path runs on the same depth table (loss decreases along
+    -grad); coarse_rendering / fine_rendering accept the flag; perturb / noise_std still raise."""
+    from oracle import render_oracle as ro
+    g = load_golden("a1_a10_disp")
+    net = make_net(dev)
+    P, rays, roc = T(g["particles"], dev), T(g["rays"], dev), T(g["ro"], dev)
+    with torch.no_grad():
+        out = net(P, roc, rays, None, None, use_disp=True)
+        lin = net(P, roc, rays, None, None)
+        fine = net.fine_rendering(P, roc, rays, use_disp=True)
+        coarse = net.coarse_rendering(P, roc, rays, use_disp=True)
+    for k in ("num_nn_0", "num_nn_1", "mask_0", "mask_1"):
+        assert torch.equal(out[k].cpu(), T(g[k])), k
+    for k in ("rgb0", "rgb1"):
+        torch.testing.assert_close(out[k].cpu(), T(g[k]), rtol=0, atol=RGB_ATOL, msg="golden " + k)
+    for k in ("depth0", "depth1", "opacity0", "opacity1"):
+        torch.testing.assert_close(out[k].cpu(), T(g[k]), rtol=1e-4, atol=2e-4, msg=k)
+    ref = ro.render_forward(ro.deterministic_nerf_state(), P.cpu(), roc.cpu(), rays.cpu(), 9.0, 13.0, use_disp=True)
+    assert torch.equal(out["mask_1"].cpu(), ref["mask_1"]) and ro.psnr(out["rgb1"].cpu(), ref["rgb1"]) >= RGB_PSNR_MIN
+    assert not torch.equal(out["mask_0"], lin["mask_0"])                      # a different depth table, not the cached linear one
+    assert torch.equal(fine["rgb1"], out["rgb1"]) and torch.equal(coarse["rgb0"], out["rgb0"])
+    with pytest.raises(NotImplementedError):
+        net(P, roc, rays, None, None, perturb=1.0)
+    with pytest.raises(NotImplementedError):
+        net(P, roc, rays, None, None, noise_std=1.0)
+    # gradients through the disparity table: one SGD step on the loss lowers it
+    tgt = torch.full((rays.shape[0], 3), 0.25, device=dev)
+    def loss_of():
+        o = net(P, roc, rays, None, None, use_disp=True)
+        return torch.nn.functional.mse_loss(o["rgb0"], tgt) + torch.nn.functional.mse_loss(o["rgb1"], tgt)
+    l0 = loss_of()
+    l0.backward()
+    with torch.no_grad():
+        gn = sum(float(p.grad.norm()) ** 2 for p in net.parameters() if p.grad is not None) ** 0.5
+        assert gn > 0
+        for p in net.parameters():
+            if p.grad is not None:
+                p -= 1e-3 * p.grad / gn
+        assert float(loss_of()) < float(l0.detach())
+
+
 def test_forward_empty_and_ragged(dev):
     """Edge cases the chunk loop produces: rays that miss everything, a 1-ray chunk, a chunk that is
     not a multiple of the wave / tile size."""

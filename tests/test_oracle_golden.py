@@ -87,6 +87,23 @@ def test_a10_forward(golden):
     assert float(out["mask_1"].max()) > 50 and float((1 - out["opacity1"]).max()) > 0.5
 
 
+def test_a1_a10_disparity_sampling(golden):
+    """use_disp=True (coarse depths linear in disparity, utils/ray_utils.py:239-240): the depths bit for bit, the whole forward
+    at the bars of test_a10_forward (tests/golden/gen_golden_disp.py recorded the reference's own outputs)."""
+    g = golden("a1_a10_disp")
+    z, xyz = ro.coarse_sample_ray(float(g["near"]), float(g["far"]), T(g["rays5"]), 64, use_disp=True)
+    assert torch.equal(z, T(g["z"])) and torch.equal(xyz, T(g["xyz"]))
+    st = ro.deterministic_nerf_state()
+    out = ro.render_forward(st, T(g["particles"]), T(g["ro"]), T(g["rays"]), float(g["near"]), float(g["far"]), use_disp=True)
+    for k in ["num_nn_0", "num_nn_1", "mask_0", "mask_1"]:
+        assert torch.equal(out[k], T(g[k])), k
+    for k in ["rgb0", "rgb1", "depth0", "depth1", "opacity0", "opacity1"]:
+        torch.testing.assert_close(out[k], T(g[k]), rtol=0, atol=2e-6, msg=k)
+    assert float(out["mask_1"].max()) > 50 and float((1 - out["opacity1"]).max()) > 0.5
+    lin = ro.render_forward(st, T(g["particles"]), T(g["ro"]), T(g["rays"]), float(g["near"]), float(g["far"]))
+    assert not torch.equal(lin["mask_0"], out["mask_0"])          # the mode changes which samples fall into the fluid
+
+
 def test_b1_integrate(golden):
     g = golden("b1_integrate")
     p2, v2 = to.integrate_pos_vel(T(g["pos"]), T(g["vel"]), T(g["gravity"]), float(g["dt"]))

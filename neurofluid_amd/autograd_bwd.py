@@ -67,7 +67,7 @@ def _pass_backward(net, nerf, pb, rays_c, z, z_table, g_rgb, white_bg, particles
     check(lib.nf_nerf_mlp_bwd(ptr(pb.packed), ptr(packed_t), cx, cd, ptr(pb.acts), ptr(pb.n_rows), n, ptr(pb.row_sample),
                               ptr(pb.rgbsigma), ptr(d_rs), ptr(dpre_full), st), "nf_nerf_mlp_bwd")
     # weight gradients: one batched fp32-MFMA launch for all 15 GEMMs of the net (nf_nerf_wgrad)
-    nsl = 16          # 46 tiles x 16 row slices = 736 workgroups (3 per CU); 11...44 slices measure the same
+    nsl = 22          # 46 tiles x 22 row slices = 1 012 waves, one per SIMD (a 128 x 128 tile per wave needs the whole register file)
     blob = torch.empty(lib.nf_nerf_wgrad_floats(cx, cd), dtype=torch.float32, device=dev)
     wsp = torch.empty(lib.nf_nerf_wgrad_workspace_floats(cx, cd, nsl), dtype=torch.float32, device=dev)
     colsum = torch.empty(DPRE, dtype=torch.float32, device=dev)

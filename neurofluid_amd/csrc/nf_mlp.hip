@@ -22,6 +22,8 @@
 //    per sample scatters (r,g,b,sigma) to the dense per-sample array.
 #include "nf_common.h"
 #include <math.h>
+#include <type_traits>
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -691,11 +693,11 @@ extern "C" int nf_nerf_mlp_bwd(const float* packed, const float* packed_t, int c
 
 // ================================================================================================
 // weight gradients: all 15 GEMMs  dW[m][n] = sum_rows dpre[row][a_col+m] * B[row][b_col+n]  of one NeRF in ONE
-// batched launch on fp32 MFMA.  grid.x = tile (over all GEMMs), grid.y = K-slice (split over rows).  128x128 output
-// tile per 4-wave workgroup, 32-row slabs of both operands staged through LDS (k-major, conflict-free fragment
-// reads), per-slice partial tiles written to P[slice][...] and summed by k_wgrad_reduce (deterministic, no atomics).
-// (Measured and set aside: double-buffered slabs with one barrier per slab — 68 KB of LDS, two workgroups per CU instead of
-// three, slices cut to one round of 506 workgroups: 744 vs 686 us per launch inside the training step.)
+// batched launch on fp32 MFMA: a 128 x 128 output tile per WAVE (k_wgrad2 below), the rows split into slices, per-slice
+// partial tiles written to P[slice][...] and summed by k_wgrad_reduce (deterministic, no atomics).
+// Rounds 1-2 staged 32-row slabs of both operands through LDS for a 128 x 128 tile per 4-wave workgroup (two barriers per
+// slab, three workgroups per CU): 0.55-0.58 of the matrix peak on 72 000 rows; double-buffered slabs with one barrier were
+// slower (two workgroups per CU).  Neither HBM nor L2 bound it (the same time with every operand row aliased into 2.5 MB).
 // ================================================================================================
 #define WG_MAX_GEMMS 16
 struct NfWgradGemm { int a_col, b_src, b_col, M, N, c_off, ldc, c_col, tile0, tiles_n, colsum; };
@@ -732,130 +734,183 @@ static NfWgradPlan wgrad_plan(int cx, int cd)
 
 extern "C" size_t nf_nerf_wgrad_floats(int cx, int cd) { return (size_t)wgrad_plan(cx, cd).total; }
 
-#define WG_KS 32
-// one quad (4 consecutive columns) of a row-slab operand: a 16-B load when the quad is whole and aligned
-__device__ __forceinline__ float4 wg_load4(const float* __restrict__ rowp, int col, int ncols, bool vec_ok)
+// ---- round 3: a 128 x 128 tile per WAVE, operands straight from global memory into MFMA fragments (no LDS, no barrier).
+// Both operands are row-major in the reduction index (row = sample), so one 16-B load per lane covers, for lanes 0..31, 128
+// consecutive columns of row k and, for lanes 32..63, of row k + 1 — exactly the K pair of one v_mfma_f32_32x32x2_f32 step.
+// Lane i holds columns 4i .. 4i+3: component c of the A quad is a valid A fragment whose output ROW i stands for column 4i + c,
+// component c' of the B quad a B fragment whose output COLUMN j stands for column 4j + c' (which column an MFMA row / column
+// means is free, it is only a matter of where the result is stored).  Two loads therefore feed 16 MFMAs (1 024 cycles of
+// the matrix pipe): 256 accumulator registers, one wave per SIMD, a 4-step register ring hides the load latency.  The four
+// waves of a workgroup take four consecutive tiles of the plan — the 2 x 2 tiles of a 256 x 256 layer for the same row
+// slice — so every operand block is wanted by two waves of ONE CU at about the same time.  The LDS-staged kernel above issued
+// 2.6 vector instructions and one LDS access per MFMA and met two barriers per 32 rows: 0.58 of the matrix peak on 72 000
+// rows against the bare loop's 0.95.
+#define WG2_D 5
+__global__ void __launch_bounds__(256) k_wgrad2(NfWgradPlan P, const float* __restrict__ dpre, const float* __restrict__ acts,
+                                                const float* __restrict__ xtiles, int Q, int n_rows, int rows_per_slice,
+                                                int nslices, float* __restrict__ partial)
 {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (col + 3 < ncols && vec_ok) return *(const float4*)(rowp + col);
-    if (col < ncols) v.x = rowp[col];
-    if (col + 1 < ncols) v.y = rowp[col + 1];
-    if (col + 2 < ncols) v.z = rowp[col + 2];
-    if (col + 3 < ncols) v.w = rowp[col + 3];
-    return v;
-}
-
-// B operands come from the saved activations (row-major, NF_ACT_STRIDE) or, for the three X-fed GEMMs (b_src = 1), straight
-// from the MLP's operand X in its tile layout [tile][q][h][j][4] (row = 32 tile + j, feature = 8 q + 4 h + c): a quad of 4
-// consecutive features of a row is one aligned 16-B load there, and the 32 rows of a slab are 512 contiguous bytes — the
-// row-major copy of X that round 1 made for this kernel (permute + cat: 0.6 ms of a 5.2 ms training step) is gone.
-__global__ void __launch_bounds__(256) k_wgrad(NfWgradPlan P, const float* __restrict__ dpre, const float* __restrict__ acts,
-                                               const float* __restrict__ xtiles, int Q, int n_rows, int rows_per_slice,
-                                               float* __restrict__ partial)
-{
-    __shared__ float As[WG_KS][128 + 4];
-    __shared__ float Bs[WG_KS][128 + 4];
-    // locate the GEMM of this tile
+    __shared__ float4 wg2_ring[4][WG2_D + 1][2][64];          // per wave: WG2_D + 1 slots x (A quad, B quad) x 64 lanes = 12 KB
+    const int lane = threadIdx.x & 63;
+    const int v = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (v >= P.ntiles * nslices) return;
+    const int by = v / P.ntiles, bx = v - by * P.ntiles;
     int gi = 0;
 #pragma unroll 1
-    for (int i = 1; i < P.ngemm; ++i) if ((int)blockIdx.x >= P.g[i].tile0) gi = i;
+    for (int i = 1; i < P.ngemm; ++i) if (bx >= P.g[i].tile0) gi = i;
     const NfWgradGemm G = P.g[gi];
-    const int t = blockIdx.x - G.tile0;
+    const int t = bx - G.tile0;
     const int m0 = (t / G.tiles_n) * 128, n0 = (t % G.tiles_n) * 128;
-    const int ldb = NF_ACT_STRIDE;
-    const int r0 = blockIdx.y * rows_per_slice, r1 = min(n_rows, r0 + rows_per_slice);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-    // 16-B loads need the first column of the tile and the row pitch to be multiples of 4 floats (all big GEMMs are;
-    // the sigma / rgb rows and the dir-feature block of xrow start at odd columns and take the scalar path)
-    const bool va = ((G.a_col + m0) & 3) == 0, vb = ((G.b_col + n0) & 3) == 0;
-    const int ma = G.M - m0, nb = G.N - n0;       // live columns of this tile
-    f32x16 acc[2][2];
+    const int i32 = lane & 31, h = lane >> 5;
+    const int r0 = by * rows_per_slice, r1 = min(n_rows, r0 + rows_per_slice);      // r0 is a multiple of 32
+    const int nsteps = (r1 - r0 + 1) >> 1;
+    // A: the quad of columns a_al + m0 + 4 i; the sigma row starts 3 columns into its quad (a_shift), rows of dW that do not
+    // exist are never stored; lanes beyond the live span read the tile's first quad instead of running off the row
+    const int a_shift = G.a_col & 3, a_al = G.a_col - a_shift;
+    const int a_span = min(128, G.M - m0 + a_shift);
+    const int f0 = G.b_col + n0 + 4 * i32;                     // first of this lane's four B columns
+    const bool b_ok = G.b_src ? f0 < 8 * Q : 4 * i32 < G.N - n0;
+    const int fb = b_ok ? f0 : G.b_col + n0;
+    // addresses = a wave-uniform base (the slice's first row) + a 32-bit lane offset: row rel of the slice (clamped to its last
+    // row, so that the ring's read-ahead and an odd last row stay inside the arrays) times the row pitch + the lane's column
+    const char* const sA = (const char*)(dpre + (size_t)r0 * NF_DPRE_STRIDE);
+    const char* const sB = G.b_src ? (const char*)(xtiles + (size_t)(r0 >> 5) * Q * 256) : (const char*)(acts + (size_t)r0 * NF_ACT_STRIDE);
+    const unsigned cA = 4u * (unsigned)(a_al + m0 + (4 * i32 < a_span ? 4 * i32 : 0));
+    const unsigned cB = G.b_src ? 4u * (unsigned)(((fb >> 3) * 2 + ((fb >> 2) & 1)) * 128) : 4u * (unsigned)fb;
+    // A step reads the row pair (2 s, 2 s + 1) of the slice: the pair's start goes into the SCALAR base of the load (clamped to
+    // the last pair that holds a live row, for the ring's read-ahead), the lane offset — row parity x pitch + the lane's column —
+    // is a constant.  If the arrays end on an odd row, the upper half of the last pair reads the lower row instead (its
+    // values are masked out anyway): nothing is read beyond row n_rows - 1.
+    const int lim_even = (n_rows - 1 - r0) & ~1;
+    const bool odd_end = ((n_rows - r0) & 1) != 0;
+    const unsigned pitchB = G.b_src ? 16u : (unsigned)(NF_ACT_STRIDE * 4);
+    const unsigned voA = cA + (unsigned)h * (unsigned)(NF_DPRE_STRIDE * 4), voB = cB + (unsigned)h * pitchB;
+    const unsigned voA_last = odd_end ? cA : voA, voB_last = odd_end ? cB : voB;
+    const unsigned xq4 = (unsigned)Q * 1024u;
+    // live A components: all four for whole tiles; the sigma / rgb rows use 1 / 3 of them and skip the other MFMAs
+    int cmask = 0;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int c = 0; c < 4; ++c) if (c >= a_shift && c - a_shift < G.M - m0) cmask |= 1 << c;
+    if (G.M - m0 + a_shift > 4) cmask = 15;
+    f32x16 acc[4][4];
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-    float4 ra[4], rb[4];
-    // bias gradients = column sums of dpre: the n0 == 0 tiles of a block's first GEMM add up the A quads they stage anyway
     const bool do_colsum = G.colsum && n0 == 0;
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto load_slab = [&](int k0) {          // 32 rows x 32 quads per operand, 4 quads per thread, coalesced along the columns
+    auto k_loop = [&](auto full_tag, auto xb_tag, auto cs_tag) __attribute__((always_inline)) {
+        constexpr bool CS = decltype(cs_tag)::value;              // this tile also sums its dpre columns (bias gradients)
+        constexpr bool FULL = decltype(full_tag)::value;          // whole tiles: 16 MFMAs per step, no test inside the loop
+        constexpr bool XB = decltype(xb_tag)::value;              // B from the X tiles
+        // Read-ahead through a wave-private LDS ring filled by LDS-DMA (global_load_lds_dwordx4: each lane's 16 bytes land at
+        // slot + 16 lane, the order ds_read_b128 reads them back).  Step s + WG2_D is requested while step s runs; the ring has
+        // WG2_D + 1 slots and the loop is unrolled by as many steps, so every slot address is a constant.  Nothing of the ring
+        // lives in registers across iterations except the operands of the NEXT step (read from LDS behind this step's MFMAs):
+        // a register ring of loop-carried loads came back from the compiler as copies behind vmcnt(0), i.e. without read-ahead.
+        // The compiler does not track LDS-DMA: the counted s_waitcnt are explicit.
+        typedef __attribute__((address_space(1))) const void* gptr_t;
+        typedef __attribute__((address_space(3))) void* lptr_t;
+        float4* const myring = &wg2_ring[threadIdx.x >> 6][0][0][0];
+        auto dma_a = [&](int s, int slot) __attribute__((always_inline)) {
+            const int r2 = min(2 * s, lim_even);                                      // scalar
+            const char* pa = sA + (size_t)r2 * (size_t)(NF_DPRE_STRIDE * 4) + (r2 == lim_even ? voA_last : voA);
+            __builtin_amdgcn_global_load_lds((gptr_t)pa, (lptr_t)(myring + (slot * 2 + 0) * 64), 16, 0, 0);
+        };
+        auto dma_b = [&](int s, int slot) __attribute__((always_inline)) {
+            const int r2 = min(2 * s, lim_even);
+            const char* pb = XB ? sB + ((size_t)(r2 >> 5) * xq4 + (size_t)(r2 & 31) * 16u)
+                                : sB + (size_t)r2 * (size_t)(NF_ACT_STRIDE * 4);
+            pb += r2 == lim_even ? voB_last : voB;
+            __builtin_amdgcn_global_load_lds((gptr_t)pb, (lptr_t)(myring + (slot * 2 + 1) * 64), 16, 0, 0);
+        };
+        auto dma = [&](int s, int slot) __attribute__((always_inline)) { dma_a(s, slot); dma_b(s, slot); };
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int e = tid + 256 * u, k = e >> 5, cq = (e & 31) * 4;
-            const int row = k0 + k;
-            ra[u] = rb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < r1) {
-                ra[u] = wg_load4(dpre + (size_t)row * NF_DPRE_STRIDE + G.a_col + m0, cq, ma, va);
-                if (G.b_src) {      // X tiles: columns beyond N hold other features / padding and are never stored
-                    const int f0 = G.b_col + n0 + cq;
-                    if (f0 < 8 * Q)
-                        rb[u] = *(const float4*)(xtiles + ((((size_t)(row >> 5) * Q + (f0 >> 3)) * 2 + ((f0 >> 2) & 1)) * 32 + (row & 31)) * 4);
-                } else
-                    rb[u] = wg_load4(acts + (size_t)row * ldb + G.b_col + n0, cq, nb, vb);
+        for (int d = 0; d < WG2_D; ++d) dma(d, d);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (WG2_D - 1)) : "memory");
+        // (the ring is read with inline-asm ds_read_b128: a read the compiler can see makes it wait vmcnt(0) for the DMA writes
+        // it believes may alias — all of them, the read-ahead included)
+        const unsigned ring_lane = (unsigned)(size_t)(lptr_t)myring + 16u * (unsigned)lane;
+        f32x4 a, b;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(a) : "v"(ring_lane));
+        asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(b) : "v"(ring_lane));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)::"memory");
+        auto group = [&](int s0, auto mask_tag) __attribute__((always_inline)) {
+            constexpr bool MASK = decltype(mask_tag)::value;      // the slice's last group: rows past its end contribute nothing
+#pragma unroll
+            for (int d = 0; d < WG2_D + 1; ++d) {
+                const int s = s0 + d;
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (WG2_D - 2)) : "memory");       // step s + 1 has landed
+                f32x4 an, bn;
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(an) : "v"(ring_lane), "n"((((d + 1) % (WG2_D + 1)) * 2 + 0) * 1024));
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bn) : "v"(ring_lane), "n"((((d + 1) % (WG2_D + 1)) * 2 + 1) * 1024));
+                if (MASK && r0 + 2 * s + h >= r1) a = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (CS) { cs.x += a[0]; cs.y += a[1]; cs.z += a[2]; cs.w += a[3]; }
+                const float av[4] = {a[0], a[1], a[2], a[3]}, bv[4] = {b[0], b[1], b[2], b[3]};
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (FULL || (cmask >> c & 1)) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[c][e] = MFMA32(av[c], bv[e], acc[c][e]);
+                    }
+                    if (c == 0 || c == 2) {       // the step's two read-ahead requests, each behind four MFMAs of its own: a VMEM issue
+                                                  // holds the wave's issue slot about as long as one MFMA runs (slot of step s - 1: read out)
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (c == 0) dma_a(s + WG2_D, (d + WG2_D) % (WG2_D + 1));
+                        else dma_b(s + WG2_D, (d + WG2_D) % (WG2_D + 1));
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(an), "+v"(bn)::"memory");
+                a = an; b = bn;
+                __builtin_amdgcn_sched_barrier(0);
             }
-        }
+        };
+        const int nfull = (r1 - r0) / (2 * (WG2_D + 1)) * (WG2_D + 1);       // steps in whole, unmasked groups
+#pragma unroll 1
+        for (int s0 = 0; s0 < nfull; s0 += WG2_D + 1) group(s0, std::false_type{});
+        if (nfull < nsteps) group(nfull, std::true_type{});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
-    load_slab(r0);
-    for (int k0 = r0; k0 < r1; k0 += WG_KS) {
+    if (cmask == 15) {
+        if (G.b_src) { if (do_colsum) k_loop(std::true_type{}, std::true_type{}, std::true_type{}); else k_loop(std::true_type{}, std::true_type{}, std::false_type{}); }
+        else { if (do_colsum) k_loop(std::true_type{}, std::false_type{}, std::true_type{}); else k_loop(std::true_type{}, std::false_type{}, std::false_type{}); }
+    } else k_loop(std::false_type{}, std::false_type{}, std::true_type{});
+    float* const slice = partial + (size_t)by * (P.total + NF_DPRE_STRIDE);
+    if (do_colsum) {        // bias gradients: the two row parities of a column quad sit in lanes i and i + 32
+        cs.x += __shfl_xor(cs.x, 32, 64); cs.y += __shfl_xor(cs.y, 32, 64);
+        cs.z += __shfl_xor(cs.z, 32, 64); cs.w += __shfl_xor(cs.w, 32, 64);
+        if (h == 0) {
+            const float cv[4] = {cs.x, cs.y, cs.z, cs.w};
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int e = tid + 256 * u, k = e >> 5, cq = (e & 31) * 4;
-            *(float4*)&As[k][cq] = ra[u];
-            *(float4*)&Bs[k][cq] = rb[u];
-            if (do_colsum) { cs.x += ra[u].x; cs.y += ra[u].y; cs.z += ra[u].z; cs.w += ra[u].w; }
-        }
-        __syncthreads();
-        if (k0 + WG_KS < r1) load_slab(k0 + WG_KS);      // next slab in flight behind the MFMAs
-        {   // fragments of K-step kk + 2 are read from LDS BEFORE the four MFMAs of step kk are issued (the compiler's own
-            // order was read, wait lgkmcnt(0), 4 MFMAs: every step exposed the LDS latency behind one MFMA)
-            const int c = lane & 31, h = lane >> 5;
-            float a0 = As[h][wm + c], a1 = As[h][wm + 32 + c], b0 = Bs[h][wn + c], b1 = Bs[h][wn + 32 + c];
-#pragma unroll
-            for (int kk = 0; kk < WG_KS; kk += 2) {
-                float a0n = a0, a1n = a1, b0n = b0, b1n = b1;
-                if (kk + 2 < WG_KS) {
-                    const int kr = kk + 2 + h;
-                    a0n = As[kr][wm + c]; a1n = As[kr][wm + 32 + c]; b0n = Bs[kr][wn + c]; b1n = Bs[kr][wn + 32 + c];
-                }
-                acc[0][0] = MFMA32(a0, b0, acc[0][0]);
-                acc[0][1] = MFMA32(a0, b1, acc[0][1]);
-                acc[1][0] = MFMA32(a1, b0, acc[1][0]);
-                acc[1][1] = MFMA32(a1, b1, acc[1][1]);
-                if (kk + 2 < WG_KS) {
-                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);      // DS reads of the next step first
-                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);      // then this step's MFMAs
-                }
-                a0 = a0n; a1 = a1n; b0 = b0n; b1 = b1n;
+            for (int c = 0; c < 4; ++c) {
+                const int m = m0 + 4 * i32 + c - a_shift;
+                if (m >= m0 && m < G.M && 4 * i32 < a_span) slice[P.total + G.a_col + m] = cv[c];
             }
         }
-        __syncthreads();
     }
-    float* const slice = partial + (size_t)blockIdx.y * (P.total + NF_DPRE_STRIDE);
-    if (do_colsum) {        // 8 row groups (tid >> 5) hold partial sums of the same column quad: fold them through LDS
-        *(float4*)&As[tid >> 5][(tid & 31) * 4] = cs;
-        __syncthreads();
-        if (tid < 128 && tid < ma) {
-            float v = 0.f;
+    // D of MFMA (c, e): register r of lane (j = lane & 31, h) is output row i = (r & 3) + 8 (r >> 2) + 4 h, column j, i.e.
+    // dW[m0 + 4 i + c - a_shift][n0 + 4 j + e]: the four e of a (c, r) are 16 consecutive bytes of one dW row
+    float* const out = slice + G.c_off + G.c_col;
+    const bool vec = (G.ldc & 3) == 0 && ((G.c_off + G.c_col + n0) & 3) == 0 && G.N - n0 >= 128;
 #pragma unroll
-            for (int g8 = 0; g8 < 8; ++g8) v += As[g8][tid];
-            slice[P.total + G.a_col + m0 + tid] = v;
+    for (int c = 0; c < 4; ++c) {
+        if (!(cmask >> c & 1)) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + 4 * ((r & 3) + 8 * (r >> 2) + 4 * h) + c - a_shift;
+            if (m < m0 || m >= G.M) continue;
+            float* o = out + (size_t)m * G.ldc + n0 + 4 * i32;
+            if (vec) *(float4*)o = make_float4(acc[c][0][r], acc[c][1][r], acc[c][2][r], acc[c][3][r]);
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (n0 + 4 * i32 + e < G.N) o[e] = acc[c][e][r];
+            }
         }
     }
-    float* out = slice + G.c_off;
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int m = m0 + wm + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                int n = n0 + wn + 32 * b + (lane & 31);
-                if (m < G.M && n < G.N) out[(size_t)m * G.ldc + G.c_col + n] = acc[a][b][r];
-            }
 }
 
 // partial[slice][total + NF_DPRE_STRIDE] -> dweights[total] | dbias[NF_DPRE_STRIDE]; one float4 per thread, the slices in
@@ -903,9 +958,10 @@ extern "C" int nf_nerf_wgrad(const float* dpre, const float* acts, const float* 
         return NF_OK;
     }
     int rows_per = (n_rows + nslices - 1) / nslices;
-    rows_per = (rows_per + WG_KS - 1) / WG_KS * WG_KS;
+    rows_per = (rows_per + 31) / 32 * 32;          // slices start on a 32-row boundary (the X tiles' granule)
     int ns = (n_rows + rows_per - 1) / rows_per;
-    hipLaunchKernelGGL(k_wgrad, dim3(P.ntiles, ns), dim3(256), 0, st, P, dpre, acts, X, (cx + 7) / 8 + (cd + 7) / 8, n_rows, rows_per, workspace);
+    hipLaunchKernelGGL(k_wgrad2, dim3((P.ntiles * ns + 3) / 4), dim3(256), 0, st, P, dpre, acts, X, (cx + 7) / 8 + (cd + 7) / 8, n_rows,
+                       rows_per, ns, workspace);
     hipLaunchKernelGGL(k_wgrad_reduce, dim3(((P.total + NF_DPRE_STRIDE) / 4 + 255) / 256), dim3(256), 0, st,
                        (const float*)workspace, P.total, ns, dweights, dbias);
     NF_CHECK_LAUNCH();

@@ -175,9 +175,9 @@ def test_backward_kernels_exact_for_their_operands(dev):
         check(lib.nf_nerf_mlp_bwd(ptr(packed), ptr(packed_t), cx, cd, ptr(acts), ptr(n_rows), n, ptr(row_sample), ptr(out), ptr(gout),
                                   ptr(dpre), _lib.stream()))
         blob = torch.empty(lib.nf_nerf_wgrad_floats(cx, cd), device=dev)
-        wsp = torch.empty(lib.nf_nerf_wgrad_workspace_floats(cx, cd, 16), device=dev)
+        wsp = torch.empty(lib.nf_nerf_wgrad_workspace_floats(cx, cd, 22), device=dev)
         colsum = torch.empty(DPRE, device=dev)
-        check(lib.nf_nerf_wgrad(ptr(dpre), ptr(acts), ptr(X), cx, cd, n, 16, ptr(wsp), ptr(blob), ptr(colsum), _lib.stream()))
+        check(lib.nf_nerf_wgrad(ptr(dpre), ptr(acts), ptr(X), cx, cd, n, 22, ptr(wsp), ptr(blob), ptr(colsum), _lib.stream()))
         A, D, xd = acts.view(n, 2432).double(), dpre.double(), x.double()
         o = 0
         for li, l in enumerate(layers):

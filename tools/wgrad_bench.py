@@ -11,7 +11,7 @@ cx, cd = 198, 54          # the configs' encodings: 63 + 9 + 63 + 63 position-li
 ptr = lambda t: ctypes.c_void_p(t.data_ptr())
 ACT, DPRE = 2432, 2436
 rows_list = [int(a) for a in sys.argv[1:]] or [8000, 72000]
-nsl = int(os.environ.get("NSL", 16))
+nsl = int(os.environ.get("NSL", 22))
 for n in rows_list:
     g = torch.Generator(device=dev); g.manual_seed(1)
     dpre = torch.randn(n, DPRE, device=dev, generator=g)
@@ -40,6 +40,17 @@ for n in rows_list:
     off = 256 * cx + 256 * 256
     w2 = blob[off:off + 65536].view(256, 256).double()
     r2 = dpre[:, 512:768].double().t() @ acts[:, 256:512].double()
-    err = max(((w0 - r0).abs().max() / r0.abs().max()).item(), ((w2 - r2).abs().max() / r2.abs().max()).item(),
+    tot = blob.numel()
+    w_rgb = blob[tot - 3 * 128:].view(3, 128).double()
+    r_rgb = dpre[:, 2432:2435].double().t() @ acts[:, 2304:2432].double()
+    w_sig = blob[tot - 3 * 128 - 256:tot - 3 * 128].view(1, 256).double()
+    r_sig = dpre[:, 2435:2436].double().t() @ acts[:, 1792:2048].double()
+    o_dir = tot - 3 * 128 - 256 - 128 * (256 + cd)
+    w_dir = blob[o_dir:o_dir + 128 * (256 + cd)].view(128, 256 + cd).double()
+    r_dir = dpre[:, 2304:2432].double().t() @ torch.cat([acts[:, 2048:2304], x[:, cx:]], 1).double()
+    err_heads = max(((w_rgb - r_rgb).abs().max() / r_rgb.abs().max()).item(), ((w_sig - r_sig).abs().max() / r_sig.abs().max()).item(),
+                    ((w_dir - r_dir).abs().max() / r_dir.abs().max()).item(),
+                    ((colsum[2432:2436].double() - dpre[:, 2432:2436].double().sum(0)).abs().max() / n ** 0.5).item())
+    err = max(err_heads, ((w0 - r0).abs().max() / r0.abs().max()).item(), ((w2 - r2).abs().max() / r2.abs().max()).item(),
               ((colsum[:2432].double() - dpre[:, :2432].double().sum(0)).abs().max() / n ** 0.5).item())
     print("rows %6d: %7.1f us per launch (wgrad + reduce), %6.1f TFLOP/s, rel err %.2e" % (n, us, flop / us / 1e6, err))

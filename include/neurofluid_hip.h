@@ -217,6 +217,11 @@ int nf_nerf_pack_bwd(const nf_nerf_params_t* params /*[host]*/, int cx, int cd, 
 int nf_nerf_mlp_bwd(const float* packed, const float* packed_t, int cx, int cd, const float* acts,
                     const int32_t* n_rows, int max_rows, const int32_t* row_sample, const float* rgbsigma,
                     const float* d_rgbsigma, float* dpre, nf_stream_t stream);
+/* The same data gradient, bit for bit, with a 32-row tile per WORKGROUP instead of per wave (the training steps' launches of a
+ * few hundred to a few thousand tiles: a quarter of the per-tile latency, no whole round lost to a partly filled last one). */
+int nf_nerf_mlp_bwd_n(const float* packed, const float* packed_t, int cx, int cd, const float* acts,
+                      const int32_t* n_rows, int max_rows, const int32_t* row_sample, const float* rgbsigma,
+                      const float* d_rgbsigma, float* dpre, nf_stream_t stream);
 
 /* A12 (weight gradients of the nn.Linear layers of models/nerf.py:55-81): all 15 GEMMs dW_l = dpre_l^T * input_l of one NeRF in one batched fp32-MFMA launch +
  * one deterministic slice reduction.  X = the MLP operand of nf_render_features (tile layout) that the forward consumed.

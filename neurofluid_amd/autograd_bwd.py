@@ -64,8 +64,8 @@ def _pass_backward(net, nerf, pb, rays_c, z, z_table, g_rgb, white_bg, particles
     cap = ops._round_rows(n)
     dpre_full = torch.empty(cap, DPRE, dtype=torch.float32, device=dev)
     dpre = dpre_full[:n]
-    check(lib.nf_nerf_mlp_bwd(ptr(pb.packed), ptr(packed_t), cx, cd, ptr(pb.acts), ptr(pb.n_rows), n, ptr(pb.row_sample),
-                              ptr(pb.rgbsigma), ptr(d_rs), ptr(dpre_full), st), "nf_nerf_mlp_bwd")
+    check(lib.nf_nerf_mlp_bwd_n(ptr(pb.packed), ptr(packed_t), cx, cd, ptr(pb.acts), ptr(pb.n_rows), n, ptr(pb.row_sample),
+                              ptr(pb.rgbsigma), ptr(d_rs), ptr(dpre_full), st), "nf_nerf_mlp_bwd_n")
     # weight gradients: one batched fp32-MFMA launch for all 15 GEMMs of the net (nf_nerf_wgrad)
     nsl = 22          # 46 tiles x 22 row slices = 1 012 waves, one per SIMD (a 128 x 128 tile per wave needs the whole register file)
     blob = torch.empty(lib.nf_nerf_wgrad_floats(cx, cd), dtype=torch.float32, device=dev)

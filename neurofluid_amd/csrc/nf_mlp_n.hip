@@ -79,6 +79,7 @@ __device__ __forceinline__ void n_xpart2(const NCtx& c, const f32x4* __restrict_
 }
 
 // hidden part: acc += W * act, act read from the LDS image (already activated); 128 K-steps = 8 source blocks x 16
+template <int NS = 128>
 __device__ __forceinline__ void n_hpart2(const NCtx& c, const f32x4* __restrict__ p, const float* __restrict__ act, f32x16 (&acc)[2])
 {
     constexpr int D = 8;
@@ -92,8 +93,8 @@ __device__ __forceinline__ void n_hpart2(const NCtx& c, const f32x4* __restrict_
         bv[s] = ap[(32 * (s >> 4) + (s & 3) + 8 * ((s & 15) >> 2)) * 32];
     }
 #pragma unroll
-    for (int s = 0; s < 128; ++s) {
-        if (s + D < 128) {
+    for (int s = 0; s < NS; ++s) {
+        if (s + D < NS) {
             const int t = s + D;
             ring[t % (D + 1)] = wp[t * 256];
             bv[t % (D + 1)] = ap[(32 * (t >> 4) + (t & 3) + 8 * ((t & 15) >> 2)) * 32];
@@ -102,7 +103,7 @@ __device__ __forceinline__ void n_hpart2(const NCtx& c, const f32x4* __restrict_
         const float b = bv[s % (D + 1)];
         acc[0] = MFMA32(wv[0], b, acc[0]);
         acc[1] = MFMA32(wv[1], b, acc[1]);
-        if (s + D < 128) {      // one VMEM and one LDS read per K-step, each in an MFMA shadow
+        if (s + D < NS) {      // one VMEM and one LDS read per K-step, each in an MFMA shadow
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -253,6 +254,155 @@ __global__ void __launch_bounds__(256) k_mlp_fwd_n(NfMlpLayout L, const float* _
         }
         __syncthreads();        // the images are rewritten by the next tile
     }
+}
+
+// ================================================================================================
+// backward (data gradient) for small launches: k_mlp_bwd (nf_mlp.hip) cut the same way — a tile per workgroup, every wave
+// two of the eight 32-feature blocks of each layer's input gradient, the pre-activation gradients exchanged through the two
+// LDS images.  Per layer g = 8 .. 1:   slot g = T_g(raw gradient)  -> dpre row (global) + LDS image;  barrier;
+//                                       raw gradient of the layer below = W_g^T . image   (128 K-steps x 2 MFMAs per wave)
+// with T_8 = identity (xyz_encoding_final has no activation), T_7 = [h8 > 0] (. + dsigma w_sigma), T_g = [h_(g+1) > 0] otherwise;
+// slot 9 (the view branch's hidden units, from the rgb head) and slot 0 come before and after the loop.  Same transposed
+// blob (nf_nerf_pack_bwd), same K order from a zero accumulator: the results equal k_mlp_bwd's bit for bit.
+// Why: one wave per tile for ~0.45 ms makes a launch cost ceil(tiles / 1024) rounds whatever the fill of the last one — the
+// fine pass of a 4 x 1024-ray training step (2 250 tiles) paid three rounds for 2.2, its coarse pass (220 tiles) a whole round.
+// ================================================================================================
+template <int MODE>
+__device__ __forceinline__ void n_bwd_slot(const NCtx& c, const f32x16 (&raw)[2], const float* __restrict__ hrow, const float* __restrict__ wsig,
+                                           float dsig, float* __restrict__ img, float* __restrict__ save_row, bool row_ok)
+{
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int b = 2 * c.w + i;
+        float v[16];
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            f32x4 hv = {1.f, 1.f, 1.f, 1.f};
+            if (MODE != 0) hv = *(const f32x4*)(hrow + 32 * b + 8 * rq + 4 * c.h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * rq + e;
+                float x = raw[i][r];
+                if (MODE == 2) x += dsig * (c.h ? wsig[(b * 16 + r) * 2 + 1] : wsig[(b * 16 + r) * 2]);
+                if (MODE != 0) x = hv[e] > 0.f ? x : 0.f;
+                v[r] = x;
+                if (img) img[(32 * b + (r & 3) + 8 * (r >> 2) + 4 * c.h) * 32 + c.j] = x;
+            }
+        }
+        if (row_ok) {
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                f32x4 o = {v[4 * rq], v[4 * rq + 1], v[4 * rq + 2], v[4 * rq + 3]};
+                *(f32x4*)(save_row + 32 * b + 8 * rq + 4 * c.h) = o;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void n_zero2(f32x16 (&acc)[2])
+{
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+}
+
+__global__ void __launch_bounds__(256) k_mlp_bwd_n(NfMlpLayout L, NfMlpLayoutT T, const float* __restrict__ packed,
+                                                   const float* __restrict__ packed_t, const float* __restrict__ acts,
+                                                   const int* __restrict__ n_rows, int max_rows, const int* __restrict__ row_sample,
+                                                   const float4* __restrict__ rgbsigma, const float4* __restrict__ d_rgbsigma,
+                                                   float* __restrict__ dpre)
+{
+    extern __shared__ float nlds[];
+    float* cur = nlds;
+    float* nxt = nlds + NN_ACT;
+    NCtx c;
+    c.lane = threadIdx.x & 63; c.h = c.lane >> 5; c.j = c.lane & 31; c.w = threadIdx.x >> 6; c.g = c.w >> 1; c.c0 = 2 * (c.w & 1);
+    const int nrows = min(*n_rows, max_rows);
+    const int ntiles = (nrows + 31) >> 5;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int z0 = opaque_zero();
+        const float* __restrict__ pk = packed + z0;
+        const f32x4* PT4 = (const f32x4*)(packed_t + z0);
+        const int row = tile * 32 + c.j;
+        const bool valid = row < nrows;
+        const float* arow = acts + (size_t)(valid ? row : 0) * NF_ACT_STRIDE;
+        float* drow = dpre + (size_t)(valid ? row : 0) * NF_DPRE_STRIDE;
+        float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f), g4 = o4;
+        if (valid) {
+            const int sample = row_sample[row];
+            o4 = rgbsigma[sample];
+            g4 = d_rgbsigma[sample];
+        }
+        // rgb = sigmoid(z): dz = g * y (1 - y)
+        const float dz0 = g4.x * o4.x * (1.f - o4.x), dz1 = g4.y * o4.y * (1.f - o4.y), dz2 = g4.z * o4.z * (1.f - o4.z);
+        const float dsig = g4.w;
+        if (valid && c.h == 0 && c.w == 0) *(float4*)(drow + 2432) = make_float4(dz0, dz1, dz2, dsig);
+        // slot 9: d(view-branch hidden) = [hd > 0] W_rgb^T dz, block w by wave w
+        {
+            const float* wr = pk + L.off_wrgb;
+            const int b = c.w;
+            float v[16];
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const f32x4 hv = *(const f32x4*)(arow + 9 * 256 + 32 * b + 8 * rq + 4 * c.h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * rq + e, k = (b * 16 + r) * 2;
+                    const float x = dz0 * (c.h ? wr[k + 1] : wr[k]) + dz1 * (c.h ? wr[128 + k + 1] : wr[128 + k]) +
+                                    dz2 * (c.h ? wr[256 + k + 1] : wr[256 + k]);
+                    v[r] = hv[e] > 0.f ? x : 0.f;
+                    cur[(32 * b + (r & 3) + 8 * (r >> 2) + 4 * c.h) * 32 + c.j] = v[r];
+                }
+            }
+            if (valid) {
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    f32x4 o = {v[4 * rq], v[4 * rq + 1], v[4 * rq + 2], v[4 * rq + 3]};
+                    *(f32x4*)(drow + 9 * 256 + 32 * b + 8 * rq + 4 * c.h) = o;
+                }
+            }
+        }
+        __syncthreads();
+        // raw d(final) = W_dir[:, :256]^T slot 9: 64 K-steps over the 128 hidden units
+        f32x16 acc[2];
+        n_zero2(acc);
+        n_hpart2<64>(c, PT4 + (T.off_dir >> 2), cur, acc);
+        const float* ws_ = pk + L.off_wsig;
+#pragma unroll 1
+        for (int g = 8; g >= 1; --g) {
+            if (g == 8) n_bwd_slot<0>(c, acc, nullptr, ws_, dsig, nxt, drow + 8 * 256, valid);
+            else if (g == 7) n_bwd_slot<2>(c, acc, arow + 7 * 256, ws_, dsig, nxt, drow + 7 * 256, valid);
+            else n_bwd_slot<1>(c, acc, arow + g * 256, ws_, dsig, nxt, drow + g * 256, valid);
+            __syncthreads();
+            float* t = cur; cur = nxt; nxt = t;
+            n_zero2(acc);
+            n_hpart2<128>(c, PT4 + (T.off_h[g] >> 2), cur, acc);
+        }
+        // slot 0 = [h1 > 0] d_h1
+        n_bwd_slot<1>(c, acc, arow, ws_, dsig, nullptr, drow, valid);
+        __syncthreads();        // the images are rewritten by the next tile
+    }
+}
+
+extern "C" int nf_nerf_mlp_bwd_n(const float* packed, const float* packed_t, int cx, int cd, const float* acts,
+                                 const int32_t* n_rows, int max_rows, const int32_t* row_sample, const float* rgbsigma,
+                                 const float* d_rgbsigma, float* dpre, nf_stream_t stream)
+{
+    NF_CHECK_ARG(packed && packed_t && acts && n_rows && row_sample && rgbsigma && d_rgbsigma && dpre, "null pointer");
+    NF_CHECK_ARG(cx >= 1 && cx <= 256 && cd >= 1 && cd <= 256, "bad channel counts");
+    if (max_rows <= 0) return NF_OK;
+    NfMlpLayout L = mlp_layout(cx, cd);
+    NfMlpLayoutT T = mlp_layout_t();
+    const int tiles = (max_rows + 31) / 32;
+    const size_t lds = (size_t)(2 * NN_ACT) * sizeof(float);       // 64 KB: two workgroups per CU
+    static bool attr_set[64] = {};
+    if (nf_first_use_on_device(attr_set))
+        hipFuncSetAttribute((const void*)k_mlp_bwd_n, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(k_mlp_bwd_n, dim3(tiles), dim3(256), lds, (hipStream_t)stream, L, T, packed, packed_t, acts, n_rows, max_rows,
+                       row_sample, (const float4*)rgbsigma, (const float4*)d_rgbsigma, dpre);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
 }
 
 extern "C" int nf_nerf_mlp_fwd_n(const float* packed, int cx, int cd, const float* X, const int32_t* n_rows, int max_rows,

@@ -122,8 +122,8 @@ class _NerfFn(torch.autograd.Function):
             d_rs.copy_(g.detach().float())
         packed_t = _pack_bwd(net, cx, cd, dev)
         dpre = torch.empty(n, DPRE, dtype=torch.float32, device=dev)
-        check(lib.nf_nerf_mlp_bwd(ptr(packed), ptr(packed_t), cx, cd, ptr(acts), ptr(n_rows), n, ptr(row_sample), ptr(out),
-                                  ptr(d_rs), ptr(dpre), st), "nf_nerf_mlp_bwd")
+        check(lib.nf_nerf_mlp_bwd_n(ptr(packed), ptr(packed_t), cx, cd, ptr(acts), ptr(n_rows), n, ptr(row_sample), ptr(out),
+                                  ptr(d_rs), ptr(dpre), st), "nf_nerf_mlp_bwd_n")
         nsl = 22          # 46 tiles x 22 row slices = 1 012 waves: one 128 x 128 tile per wave, one wave per SIMD
         blob = torch.empty(lib.nf_nerf_wgrad_floats(cx, cd), dtype=torch.float32, device=dev)
         wsp = torch.empty(lib.nf_nerf_wgrad_workspace_floats(cx, cd, nsl), dtype=torch.float32, device=dev)

@@ -174,6 +174,11 @@ def test_backward_kernels_exact_for_their_operands(dev):
         dpre = torch.empty(n, DPRE, device=dev)
         check(lib.nf_nerf_mlp_bwd(ptr(packed), ptr(packed_t), cx, cd, ptr(acts), ptr(n_rows), n, ptr(row_sample), ptr(out), ptr(gout),
                                   ptr(dpre), _lib.stream()))
+        # the tile-per-workgroup kernel of the training steps: the same sums in the same order, bit for bit (also on a ragged tile)
+        dpre_n = torch.full((n, DPRE), float("nan"), device=dev)
+        check(lib.nf_nerf_mlp_bwd_n(ptr(packed), ptr(packed_t), cx, cd, ptr(acts), ptr(n_rows), n, ptr(row_sample), ptr(out), ptr(gout),
+                                    ptr(dpre_n), _lib.stream()))
+        assert torch.equal(dpre_n, dpre)
         blob = torch.empty(lib.nf_nerf_wgrad_floats(cx, cd), device=dev)
         wsp = torch.empty(lib.nf_nerf_wgrad_workspace_floats(cx, cd, 22), device=dev)
         colsum = torch.empty(DPRE, device=dev)

@@ -1,6 +1,6 @@
 """Training-forward MLP kernels (activations saved) on synthetic rows (dev tool): tile-per-wave nf_nerf_mlp_fwd vs
 tile-per-workgroup nf_nerf_mlp_fwd_n, and nf_nerf_mlp_bwd, at the row counts given.  usage: python tools/fwd_train_bench.py [rows ...]"""
-import sys, os
+import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from neurofluid_amd import synthetic as ro
@@ -31,5 +31,17 @@ for n in rows:
         return e0.elapsed_time(e1) / it * 1e3
     a = t(lambda: check(lib.nf_nerf_mlp_fwd(ptr(packed), 198, 54, ptr(X), ptr(n_rows), n, ptr(row_sample), ptr(out), ptr(acts), _lib.stream())))
     b = t(lambda: check(lib.nf_nerf_mlp_fwd_n(ptr(packed), 198, 54, ptr(X), ptr(n_rows), n, ptr(row_sample), ptr(out), ptr(acts), _lib.stream())))
-    print("rows %6d (%4d tiles): tile-per-wave %7.1f us (%5.1f TFLOP/s)   tile-per-workgroup %7.1f us (%5.1f TFLOP/s)" %
+    print("rows %6d (%4d tiles): fwd tile-per-wave %7.1f us (%5.1f TFLOP/s)   tile-per-workgroup %7.1f us (%5.1f TFLOP/s)" %
           (n, (n + 31) // 32, a, n * 1.331968 / a, b, n * 1.331968 / b))
+    packed_t = torch.empty(lib.nf_nerf_packed_bwd_floats(), device=dev)
+    P = _lib.NerfParams()
+    for i in range(12):
+        P.w[i], P.b[i] = W[i].data_ptr(), B[i].data_ptr()
+    check(lib.nf_nerf_pack_bwd(ctypes.byref(P), 198, 54, ptr(packed_t), _lib.stream()))
+    g = torch.randn(n, 4, device=dev)
+    d1 = torch.zeros(ops._round_rows(n), 2436, device=dev); d2 = torch.zeros_like(d1)
+    args = lambda d: (ptr(packed), ptr(packed_t), 198, 54, ptr(acts), ptr(n_rows), n, ptr(row_sample), ptr(out), ptr(g), ptr(d), _lib.stream())
+    a = t(lambda: check(lib.nf_nerf_mlp_bwd(*args(d1))))
+    b = t(lambda: check(lib.nf_nerf_mlp_bwd_n(*args(d2))))
+    print("             bwd tile-per-wave %7.1f us (%5.1f TFLOP/s)   tile-per-workgroup %7.1f us (%5.1f TFLOP/s)   bit-equal: %s" %
+          (a, n * 1.331968 / a, b, n * 1.331968 / b, bool(torch.equal(d1[:n], d2[:n]))))

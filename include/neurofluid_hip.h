@@ -394,6 +394,16 @@ int nf_cconv3_layer(const float* x_act, int n, const uint16_t* roff, const uint3
                     const float* bias_conv, const float* bias_dense, float* workspace, float* y3,
                     const float* pos /*or NULL: no update*/, const float* pos_new, float scale, float dt, float* pos_c,
                     float* vel_c, nf_stream_t stream);
+/* The two halves of nf_cconv3_layer as the fused step runs them: nf_cconv_gf_layer for a 64-channel layer whose epilogue ALSO
+ * transforms relu(y) with the packed 3-channel filter (g3 = nf_cconv3_workspace_floats(n) floats; out / out_relu optional — the
+ * step passes neither: conv2's output is read by conv3 only), and the gather + update over g3. */
+int nf_cconv_gf_layer_g3(const float* x, int n, int cin, int relu, const uint16_t* roff, const uint32_t* entries, int pitch,
+                         const void* packed, int split, const float* bias_conv, const float* bias_dense, const float* residual,
+                         float* out /*or NULL*/, float* out_relu /*or NULL*/, float* scratch, int max_wg,
+                         const float* packed3 /*nf_cconv3_pack*/, float* g3, nf_stream_t stream);
+int nf_cconv3_gather(const float* g3, int n, const uint16_t* roff, const uint32_t* entries, int pitch, const float* bias_conv,
+                     const float* bias_dense, float* y3, const float* pos /*or NULL: no update*/, const float* pos_new,
+                     float scale, float dt, float* pos_c, float* vel_c, nf_stream_t stream);
 typedef struct {
     /* model (device pointers; wpK = nf_cconv_gf_pack of convK / denseK) */
     const float *k_fluid, *b_fluid, *k_obst, *b_obst, *dense0_w, *dense0_b;
@@ -403,7 +413,7 @@ typedef struct {
     /* workspace of one particle count */
     void* grid_ws; size_t grid_ws_bytes;
     float *pos_new, *vel_new, *feats; int32_t* counts2; int32_t* idx_f; float* d2_f; uint16_t* roff; uint32_t* ent;
-    float *a0 /*relu(layer 0)*/, *a1, *a1r /*relu(a1)*/, *a2 /*relu(layer 2)*/, *y3, *scratch; int64_t* overflow2;
+    float *a0 /*relu(layer 0)*/, *a1, *a1r /*relu(a1)*/, *g3 /*nf_cconv3_workspace_floats(n): conv3's transformed array*/, *y3, *scratch; int64_t* overflow2;
     uint32_t* done_counter;
     int n, pitch_f, pitch_b, use_window, max_wg;
     float radius, extent, dt, scale;

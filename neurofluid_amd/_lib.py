@@ -20,7 +20,7 @@ class TransStep(ctypes.Structure):
     _fields_ = [(k, c_void_p) for k in ("k_fluid", "b_fluid", "k_obst", "b_obst", "dense0_w", "dense0_b", "wp1", "bc1", "bd1", "wp2",
                                         "bc2", "bd2", "wp3", "bc3", "bd3", "box_grid", "box_feats", "grid_ws")] + \
                [("grid_ws_bytes", c_size_t)] + \
-               [(k, c_void_p) for k in ("pos_new", "vel_new", "feats", "counts2", "idx_f", "d2_f", "roff", "ent", "a0", "a1", "a1r", "a2", "y3",
+               [(k, c_void_p) for k in ("pos_new", "vel_new", "feats", "counts2", "idx_f", "d2_f", "roff", "ent", "a0", "a1", "a1r", "g3", "y3",
                                         "scratch", "overflow2", "done_counter")] + \
                [(k, c_int) for k in ("n", "pitch_f", "pitch_b", "use_window", "max_wg")] + \
                [(k, c_float) for k in ("radius", "extent", "dt", "scale")] + [("gravity", c_float * 3), ("bbox", c_float * 6), ("split", c_int)]
@@ -117,6 +117,10 @@ PROTOTYPES = {
     "nf_cconv3_workspace_floats": (c_size_t, [c_int]),
     "nf_cconv3_packed_floats": (c_size_t, []),
     "nf_cconv3_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nf_cconv_gf_layer_g3": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "nf_cconv3_gather": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                 c_float, c_void_p, c_void_p, c_void_p]),
     "nf_cconv3_layer": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "nf_trans_step": (c_int, [ctypes.POINTER(TransStep), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,

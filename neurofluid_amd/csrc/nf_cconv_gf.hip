@@ -486,15 +486,9 @@ struct GfEpi {
     const float* pos; const float* pos_new; float* pos_c; float* vel_c; float scale, dt;       // pos == null: no update
 };
 
-__global__ void __launch_bounds__(256) k_cconv_gf_epi(GfEpi E)
+// sum of a tile's partial slabs for output (row, col) + biases (+ residual): a fixed order (segment-major, K-quarter-minor)
+__device__ __forceinline__ float gf_epi_value(const GfEpi& E, int tile, int nseg, int row, int col, int i)
 {
-    // one output per thread: block = (tile, group of 8 columns); thread = (column, row): the slab reads of a wave are two
-    // runs of 128 contiguous bytes, all of a thread's nseg * 4 loads are independent (one round trip)
-    const int tile = blockIdx.x;
-    const int col = blockIdx.y * 8 + (threadIdx.x >> 5), row = threadIdx.x & 31, i = tile * GF_TILE + row;
-    if (col >= E.cout || i >= E.n) return;
-    const int wfirst = gf_owner((long long)tile * GF_COST, E.nwg, E.ctot), wlast = gf_owner((long long)tile * GF_COST + 64, E.nwg, E.ctot);
-    const int nseg = wlast - wfirst + 1;
     float v = 0.f;
     if (E.split) {
         // slabs [tile][segment][wave][32 cols][32 rows]; wave = K-part * NB + N-block: the K-parts of this column's N-block
@@ -509,12 +503,25 @@ __global__ void __launch_bounds__(256) k_cconv_gf_epi(GfEpi E)
         int q = 0;
         for (; q + 4 <= nq; q += 4) {
             const float p0 = s[(size_t)q * slab], p1 = s[(size_t)(q + 1) * slab], p2 = s[(size_t)(q + 2) * slab], p3 = s[(size_t)(q + 3) * slab];
-            v += p0; v += p1; v += p2; v += p3;                  // segment-major, K-quarter-minor: a fixed order
+            v += p0; v += p1; v += p2; v += p3;
         }
         for (; q < nq; ++q) v += s[(size_t)q * slab];
     }
     v += E.bias_c[col] + E.bias_d[col];
     if (E.residual) v += E.residual[(size_t)i * E.cout + col];
+    return v;
+}
+
+__global__ void __launch_bounds__(256) k_cconv_gf_epi(GfEpi E)
+{
+    // one output per thread: block = (tile, group of 8 columns); thread = (column, row): the slab reads of a wave are two
+    // runs of 128 contiguous bytes, all of a thread's nseg * 4 loads are independent (one round trip)
+    const int tile = blockIdx.x;
+    const int col = blockIdx.y * 8 + (threadIdx.x >> 5), row = threadIdx.x & 31, i = tile * GF_TILE + row;
+    if (col >= E.cout || i >= E.n) return;
+    const int wfirst = gf_owner((long long)tile * GF_COST, E.nwg, E.ctot), wlast = gf_owner((long long)tile * GF_COST + 64, E.nwg, E.ctot);
+    const int nseg = wlast - wfirst + 1;
+    const float v = gf_epi_value(E, tile, nseg, row, col, i);
     if (E.out) E.out[(size_t)i * E.cout + col] = v;
     if (E.out_relu) E.out_relu[(size_t)i * E.cout + col] = fmaxf(v, 0.f);
     if (E.pos) {                                              // cout == 3: col = coordinate (k_trans_update's expressions)
@@ -637,22 +644,15 @@ static int gf_launch(const GfArgs& a, hipStream_t st)
 }
 
 // One G-free layer: y = cconv(act(x)) + Linear(act(x)) + biases (+ residual) [+ position / velocity update when pos != NULL]
-extern "C" int nf_cconv_gf_layer(const float* x, int n, int cin, int cout, int relu, const uint16_t* roff, const uint32_t* ent,
-                                 int pitch, const void* packed, int split, const float* bias_conv, const float* bias_dense,
-                                 const float* residual, float* out, float* out_relu, float* scratch, int max_wg, const float* pos,
-                                 const float* pos_new, float scale, float dt, float* pos_c, float* vel_c, nf_stream_t stream)
+// the contraction kernel of one layer into the partial slabs; fills the epilogue's description of them
+static int gf_run_conv(const float* x, int n, int cin, int cout, int relu, const uint16_t* roff, const uint32_t* ent, int pitch,
+                       const void* packed, int split, float* scratch, int max_wg, hipStream_t st, GfEpi* e)
 {
-    NF_CHECK_ARG(x && roff && ent && packed && bias_conv && bias_dense && (out || out_relu) && scratch, "null pointer");
-    NF_CHECK_ARG(((cin == 96 && cout > 32) || cin == 64) && cout >= 1 && cout <= 64,
-                 "supported shapes: 96 -> 33..64, 64 -> 1..64 channels (the transition model's layers)");
-    NF_CHECK_ARG(!pos || (cout == 3 && pos_new && pos_c && vel_c), "the update epilogue belongs to the 3-channel layer");
-    if (n <= 0) return NF_OK;
     GfArgs a;
     a.x = x; a.n = n; a.relu = relu; a.roff = roff; a.ent = ent; a.pitch = pitch; a.wp = (const float*)packed; a.scratch = scratch;
     size_t sf;
     if (nf_cconv_gf_plan(n, cout, max_wg, &a.tiles, &a.nwg, &a.maxseg, &sf) != NF_OK) return NF_EINVAL;
     a.ctot = a.tiles * GF_COST;
-    hipStream_t st = (hipStream_t)stream;
     const int nb = cout > 32 ? 2 : 1;
     // (the ReLU-on-load variants serve callers that hand over pre-activation features; nf_trans_step stores activated arrays)
 #define GF_PICK(R, S)                                           \
@@ -665,12 +665,28 @@ extern "C" int nf_cconv_gf_layer(const float* x, int n, int cin, int cout, int r
     else { if (relu) GF_PICK(true, false); else GF_PICK(false, false); }
 #undef GF_PICK
     NF_CHECK_LAUNCH();
+    e->split = split;
+    e->scratch = scratch; e->tiles = a.tiles; e->nwg = a.nwg; e->maxseg = a.maxseg; e->ctot = a.ctot; e->coutp = 32 * nb; e->cout = cout; e->n = n;
+    return NF_OK;
+}
+
+extern "C" int nf_cconv_gf_layer(const float* x, int n, int cin, int cout, int relu, const uint16_t* roff, const uint32_t* ent,
+                                 int pitch, const void* packed, int split, const float* bias_conv, const float* bias_dense,
+                                 const float* residual, float* out, float* out_relu, float* scratch, int max_wg, const float* pos,
+                                 const float* pos_new, float scale, float dt, float* pos_c, float* vel_c, nf_stream_t stream)
+{
+    NF_CHECK_ARG(x && roff && ent && packed && bias_conv && bias_dense && (out || out_relu) && scratch, "null pointer");
+    NF_CHECK_ARG(((cin == 96 && cout > 32) || cin == 64) && cout >= 1 && cout <= 64,
+                 "supported shapes: 96 -> 33..64, 64 -> 1..64 channels (the transition model's layers)");
+    NF_CHECK_ARG(!pos || (cout == 3 && pos_new && pos_c && vel_c), "the update epilogue belongs to the 3-channel layer");
+    if (n <= 0) return NF_OK;
+    hipStream_t st = (hipStream_t)stream;
     GfEpi e;
-    e.split = split;
-    e.scratch = scratch; e.tiles = a.tiles; e.nwg = a.nwg; e.maxseg = a.maxseg; e.ctot = a.ctot; e.coutp = 32 * nb; e.cout = cout; e.n = n;
+    const int rc = gf_run_conv(x, n, cin, cout, relu, roff, ent, pitch, packed, split, scratch, max_wg, st, &e);
+    if (rc != NF_OK) return rc;
     e.bias_c = bias_conv; e.bias_d = bias_dense; e.residual = residual; e.out = out; e.out_relu = out_relu;
     e.pos = pos; e.pos_new = pos_new; e.pos_c = pos_c; e.vel_c = vel_c; e.scale = scale; e.dt = dt;
-    hipLaunchKernelGGL(k_cconv_gf_epi, dim3(a.tiles, (cout + 7) / 8), dim3(256), 0, st, e);
+    hipLaunchKernelGGL(k_cconv_gf_epi, dim3(e.tiles, (cout + 7) / 8), dim3(256), 0, st, e);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }
@@ -732,6 +748,49 @@ __global__ void __launch_bounds__(256) k_cconv3_transform(const float* __restric
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const float4 v = *(const float4*)&xs[r][4 * q];          // (broadcast: every lane reads the same address)
+            a0 = fmaf(v.x, w[4 * q], a0); a1 = fmaf(v.y, w[4 * q + 1], a1); a2 = fmaf(v.z, w[4 * q + 2], a2); a3 = fmaf(v.w, w[4 * q + 3], a3);
+        }
+        G3[(size_t)(i0 + r) * G3_PITCH + o] = (a0 + a1) + (a2 + a3);
+    }
+}
+
+// conv2's epilogue and conv3's transform in one kernel (a tile of 32 particles per workgroup): the transform of a particle needs
+// only that particle's own 64 activated channels, which the epilogue has just summed — they go through LDS instead of through
+// a2 in global memory and a launch of their own.  Same expressions as k_cconv_gf_epi and k_cconv3_transform: identical G3.
+__global__ void __launch_bounds__(1024) k_cconv_gf_epi_g3(GfEpi E, const float* __restrict__ kt /* nf_cconv3_pack */, float* __restrict__ G3)
+{
+    // 1 024 threads per 32-particle tile: the epilogue reads the slabs in whole 128-byte rows (thread = row, column group), the
+    // transform runs as four 256-thread groups of 8 particles each, like k_cconv3_transform's workgroups.  (256 threads per tile:
+    // 26 us, 154 workgroups walking 32 rows each; 8-row workgroups: 16 us, the slab reads fall apart into 32-byte pieces.)
+    __shared__ float xs[GF_TILE][64];
+    const int tile = blockIdx.x, i0 = tile * GF_TILE;
+    const int wfirst = gf_owner((long long)tile * GF_COST, E.nwg, E.ctot), wlast = gf_owner((long long)tile * GF_COST + 64, E.nwg, E.ctot);
+    const int nseg = wlast - wfirst + 1;
+    {
+        const int row = threadIdx.x & 31, i = i0 + row;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int col = 32 * k + (threadIdx.x >> 5);
+            float v = 0.f;
+            if (i < E.n) {
+                v = gf_epi_value(E, tile, nseg, row, col, i);
+                if (E.out) E.out[(size_t)i * 64 + col] = v;
+                if (E.out_relu) E.out_relu[(size_t)i * 64 + col] = fmaxf(v, 0.f);
+            }
+            xs[row][col] = fmaxf(v, 0.f);
+        }
+    }
+    __syncthreads();
+    const int o = threadIdx.x & 255, r0 = (threadIdx.x >> 8) * G3_TILE;      // output column: node * 3 + co; this group's 8 rows
+    if (o >= 195) return;
+    float w[64];
+#pragma unroll
+    for (int ci = 0; ci < 64; ++ci) w[ci] = kt[ci * G3_PITCH + o];
+    for (int r = r0; r < r0 + G3_TILE && i0 + r < E.n; ++r) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float4 v = *(const float4*)&xs[r][4 * q];
             a0 = fmaf(v.x, w[4 * q], a0); a1 = fmaf(v.y, w[4 * q + 1], a1); a2 = fmaf(v.z, w[4 * q + 2], a2); a3 = fmaf(v.w, w[4 * q + 3], a3);
         }
         G3[(size_t)(i0 + r) * G3_PITCH + o] = (a0 + a1) + (a2 + a3);
@@ -804,9 +863,44 @@ extern "C" int nf_cconv3_layer(const float* x_act, int n, const uint16_t* roff, 
     return NF_OK;
 }
 
+extern "C" int nf_cconv_gf_layer_g3(const float* x, int n, int cin, int relu, const uint16_t* roff, const uint32_t* ent, int pitch,
+                                    const void* packed, int split, const float* bias_conv, const float* bias_dense,
+                                    const float* residual, float* out, float* out_relu, float* scratch, int max_wg,
+                                    const float* packed3, float* g3, nf_stream_t stream)
+{
+    NF_CHECK_ARG(x && roff && ent && packed && bias_conv && bias_dense && scratch && packed3 && g3, "null pointer");
+    NF_CHECK_ARG(cin == 96 || cin == 64, "supported shapes: 96 -> 64, 64 -> 64 channels");
+    if (n <= 0) return NF_OK;
+    hipStream_t st = (hipStream_t)stream;
+    GfEpi e;
+    const int rc = gf_run_conv(x, n, cin, 64, relu, roff, ent, pitch, packed, split, scratch, max_wg, st, &e);
+    if (rc != NF_OK) return rc;
+    e.bias_c = bias_conv; e.bias_d = bias_dense; e.residual = residual; e.out = out; e.out_relu = out_relu;
+    e.pos = nullptr; e.pos_new = nullptr; e.pos_c = nullptr; e.vel_c = nullptr; e.scale = 0.f; e.dt = 0.f;
+    hipLaunchKernelGGL(k_cconv_gf_epi_g3, dim3(e.tiles), dim3(1024), 0, st, e, packed3, g3);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+extern "C" int nf_cconv3_gather(const float* g3, int n, const uint16_t* roff, const uint32_t* ent, int pitch, const float* bias_conv,
+                                const float* bias_dense, float* y3, const float* pos, const float* pos_new, float scale, float dt,
+                                float* pos_c, float* vel_c, nf_stream_t stream)
+{
+    NF_CHECK_ARG(g3 && roff && ent && bias_conv && bias_dense && y3, "null pointer");
+    NF_CHECK_ARG(!pos || (pos_new && pos_c && vel_c), "the update needs pos_new / pos_c / vel_c");
+    if (n <= 0) return NF_OK;
+    G3Epi E;
+    E.pos = pos; E.pos_new = pos_new; E.pos_c = pos_c; E.vel_c = vel_c; E.scale = scale; E.dt = dt;
+    hipLaunchKernelGGL(k_cconv3_gather, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, g3, n, roff, ent, pitch, bias_conv, bias_dense,
+                       y3, E);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // The whole inference step behind ONE call (models/transmodel.py:151-163): prepare (integrate + fluid grid) -> front (search,
-// row-entry lists, layer 0) -> conv1 -> conv2 -> conv3 + update.  8 launches, no host round trip inside; the host reads
+// row-entry lists, layer 0) -> conv1 (+ epilogue) -> conv2 (+ epilogue fused with conv3's transform) -> conv3's gather + update.
+// 7 launches, no host round trip inside; the host reads
 // overflow2 (largest neighbour count above its pitch, or 0) to decide whether the step has to be redone on the exact path.
 // ------------------------------------------------------------------------------------------------
 extern "C" int nf_trans_step(const nf_trans_step_t* s, const float* pos, const float* vel, float* num_nbrs, float* pos_c,
@@ -825,11 +919,10 @@ extern "C" int nf_trans_step(const nf_trans_step_t* s, const float* pos, const f
     rc = nf_cconv_gf_layer(s->a0, s->n, 96, 64, 0, s->roff, s->ent, s->pitch_f, s->wp1, s->split, s->bc1, s->bd1, nullptr, s->a1, s->a1r, s->scratch,
                            s->max_wg, nullptr, nullptr, 0.f, 0.f, nullptr, nullptr, stream);
     if (rc != NF_OK) return rc;
-    rc = nf_cconv_gf_layer(s->a1r, s->n, 64, 64, 0, s->roff, s->ent, s->pitch_f, s->wp2, s->split, s->bc2, s->bd2, s->a1, nullptr, s->a2, s->scratch,
-                           s->max_wg, nullptr, nullptr, 0.f, 0.f, nullptr, nullptr, stream);
+    // conv2's output is read by conv3 only (a 64 -> 3 layer has no residual): it never goes to global memory
+    rc = nf_cconv_gf_layer_g3(s->a1r, s->n, 64, 0, s->roff, s->ent, s->pitch_f, s->wp2, s->split, s->bc2, s->bd2, s->a1, nullptr, nullptr,
+                              s->scratch, s->max_wg, s->wp3, s->g3, stream);
     if (rc != NF_OK) return rc;
-    // the 3-channel layer: transform (3.8 MB) then gather, position / velocity update fused (the scratch of the layers above
-    // is free again: G3 lives there)
-    return nf_cconv3_layer(s->a2, s->n, s->roff, s->ent, s->pitch_f, s->wp3, s->bc3, s->bd3, s->scratch, s->y3, pos,
-                           s->pos_new, s->scale, s->dt, pos_c, vel_c, stream);
+    return nf_cconv3_gather(s->g3, s->n, s->roff, s->ent, s->pitch_f, s->bc3, s->bd3, s->y3, pos, s->pos_new, s->scale, s->dt, pos_c, vel_c,
+                            stream);
 }

@@ -278,12 +278,11 @@ class ParticleNet(nn.Module):
         max_wg = torch.cuda.get_device_properties(dev).multi_processor_count
         sf = ctypes.c_size_t()
         check(lib.nf_cconv_gf_plan(n, 64, max_wg, None, None, None, ctypes.byref(sf)), "nf_cconv_gf_plan")
-        sf.value = max(sf.value, lib.nf_cconv3_workspace_floats(n))      # the last layer's G3 reuses the scratch
         st = dict(key=key, pitch=(pitch_f, pitch_b), max_wg=max_wg,
                   grid_ws=E(lib.nf_grid_workspace_bytes(n, radius, bb), dtype=u8), pos_new=E(n, 3), vel_new=E(n, 3), feats=E(n, 4),
                   counts2=E(2 * n, dtype=i32), idx_f=E(n * pitch_f, dtype=i32), d2_f=E(n * pitch_f),
                   roff=torch.zeros(n * 20, dtype=i16, device=dev), ent=E(n * 4 * pitch_f * 3, dtype=i32),
-                  a0=E(n, 96), a1=E(n, 64), a1r=E(n, 64), a2=E(n, 64), y3=E(n, 3), scratch=E(sf.value),
+                  a0=E(n, 96), a1=E(n, 64), a1r=E(n, 64), g3=E(lib.nf_cconv3_workspace_floats(n)), y3=E(n, 3), scratch=E(sf.value),
                   # overflow record: the device keeps the largest count above its pitch (atomicMax) and raises two pinned,
                   # device-visible host words — both written ONLY when a row overflows, re-zeroed by the host after the redo
                   ovf=torch.zeros(2, dtype=i64, device=dev), flag_host=torch.zeros(4, dtype=i32).pin_memory(),
@@ -294,7 +293,7 @@ class ParticleNet(nn.Module):
             raise RuntimeError("pinned host memory is not mapped into the device address space (nf_pinned_device_ptr)")
         S = _lib.TransStep()
         S.grid_ws, S.grid_ws_bytes = st["grid_ws"].data_ptr(), st["grid_ws"].numel()
-        for k in ("pos_new", "vel_new", "feats", "counts2", "idx_f", "d2_f", "roff", "ent", "a0", "a1", "a1r", "a2", "y3", "scratch"):
+        for k in ("pos_new", "vel_new", "feats", "counts2", "idx_f", "d2_f", "roff", "ent", "a0", "a1", "a1r", "g3", "y3", "scratch"):
             setattr(S, k, st[k].data_ptr())
         S.overflow2, S.done_counter = st["ovf"].data_ptr(), st["done"].data_ptr()
         S.n, S.pitch_f, S.pitch_b, S.use_window, S.max_wg = n, pitch_f, pitch_b, int(self.use_window), max_wg

@@ -405,6 +405,31 @@ def test_gfree_conv_layer_vs_oracle_and_transform_gather(dev):
                 torch.testing.assert_close(y, old, rtol=1e-4, atol=2e-5)
                 err = float((y - old).abs().max() / old.abs().max())
                 assert err < (5e-6 if split else 2e-6), (split, err)              # observed ~1e-6 split, ~3e-7 fp32
+                if cout == 64:      # the step's form of a 64-channel layer: epilogue fused with the last layer's transform ->
+                    # the same y / relu(y), and G3 = what nf_cconv3_layer's own transform makes of relu(y), bit for bit
+                    K3 = torch.randn(4, 4, 4, 64, 3, generator=g).to(dev) * 0.1
+                    W3 = torch.randn(3, 64, generator=g).to(dev) * 0.1
+                    b3 = torch.randn(3, generator=g).to(dev) * 0.1
+                    wp3 = torch.empty(lib.nf_cconv3_packed_floats(), device=dev)
+                    check(lib.nf_cconv3_pack(ptr(K3), ptr(W3), ptr(wp3), _lib.stream()), "nf_cconv3_pack")
+                    scratch.fill_(float("nan"))
+                    y2, yr2 = torch.empty_like(y), torch.empty_like(y)
+                    g3 = torch.full((lib.nf_cconv3_workspace_floats(n),), float("nan"), device=dev)
+                    check(lib.nf_cconv_gf_layer_g3(ptr(xd), n, cin, 1, ptr(roff), ptr(ent), pitch_f, ptr(wp), split, ptr(bcd), ptr(bdd),
+                                                   ptr(xd) if res else None, ptr(y2), ptr(yr2), ptr(scratch), max_wg, ptr(wp3), ptr(g3),
+                                                   _lib.stream()), "nf_cconv_gf_layer_g3")
+                    assert torch.equal(y2, y) and torch.equal(yr2, yr)
+                    ya, pa, va = torch.empty(n, 3, device=dev), torch.empty(n, 3, device=dev), torch.empty(n, 3, device=dev)
+                    yb, pb, vb = torch.empty(n, 3, device=dev), torch.empty(n, 3, device=dev), torch.empty(n, 3, device=dev)
+                    pos0 = dv(P + 0.01)
+                    wsp = torch.empty(lib.nf_cconv3_workspace_floats(n), device=dev)
+                    check(lib.nf_cconv3_layer(ptr(yr), n, ptr(roff), ptr(ent), pitch_f, ptr(wp3), ptr(b3), ptr(b3), ptr(wsp), ptr(ya),
+                                              ptr(pos0), ptr(Pd), 1.0 / 128, 0.02, ptr(pa), ptr(va), _lib.stream()), "nf_cconv3_layer")
+                    check(lib.nf_cconv3_gather(ptr(g3), n, ptr(roff), ptr(ent), pitch_f, ptr(b3), ptr(b3), ptr(yb), ptr(pos0), ptr(Pd),
+                                               1.0 / 128, 0.02, ptr(pb), ptr(vb), _lib.stream()), "nf_cconv3_gather")
+                    m = n * 196
+                    g3v, wv = g3[:m].view(n, 196)[:, :195], wsp[:m].view(n, 196)[:, :195]
+                    assert torch.equal(g3v, wv) and torch.equal(ya, yb) and torch.equal(pa, pb) and torch.equal(va, vb)
             if cout == 3:           # the step's own last layer: transform (G3) + gather over the row entries + update
                 wsp = torch.empty(lib.nf_cconv3_workspace_floats(n), device=dev)
                 y3, pc3, vc3 = torch.empty(n, 3, device=dev), torch.empty(n, 3, device=dev), torch.empty(n, 3, device=dev)

@@ -22,14 +22,14 @@ python tools/summarize_pmc.py $P/round3_kernels_pmc.json r3_stats_render r3_pmc_
 for mode in fp32 split; do
   short_stats r3_stats_trans_$mode $P/round3_transition_${mode}_kernel_stats.csv
   python tools/summarize_pmc.py $P/round3_transition_${mode}_pmc.json r3_stats_trans_$mode r3_pmc_fetch_trans_$mode r3_pmc_write_trans_$mode r3_pmc_sq_trans_$mode -- \
-      "k_cconv_gf<" k_cconv_gf_epi k_trans_prepare k_trans_front k_cconv3_transform k_cconv3_gather > /dev/null
+      "k_cconv_gf<" "k_cconv_gf_epi(" k_cconv_gf_epi_g3 k_trans_prepare k_trans_front k_cconv3_gather > /dev/null
 done
 cp $P/round3_transition_fp32_pmc.json $P/round3_transition_pmc.json
 cp $P/round3_transition_fp32_kernel_stats.csv $P/round3_transition_kernel_stats.csv
 if [ -d $O/r3_stats_train ]; then
   short_stats r3_stats_train $P/round3_train_kernel_stats.csv
   python tools/summarize_pmc.py $P/round3_train_pmc.json r3_stats_train r3_pmc_fetch_train r3_pmc_write_train r3_pmc_sq_train -- \
-      k_mlp_fwd_n k_mlp_bwd "k_wgrad(" k_search k_composite_bwd_w k_gemm_f32 > /dev/null
+      k_mlp_fwd_n k_mlp_bwd_n k_wgrad2 k_wgrad_reduce k_search k_composite_bwd_w k_gemm_f32 > /dev/null
 fi
 python - <<'PY'
 import json

@@ -90,7 +90,9 @@ for k in kernels:
             if dur:
                 e["mfma_busy_over_simd_time_at_2p4GHz"] = per["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (dur * 2400.0)
             if per.get("GRBM_GUI_ACTIVE"):
-                e["mfma_busy_over_gui_active_x1024_simds"] = per["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * per["GRBM_GUI_ACTIVE"])
+                # GRBM_GUI_ACTIVE comes back summed over the 8 XCDs (k_mlp_fwd_l, one wave per SIMD for the whole launch, calibrates it:
+                # 0.86 this way against 0.88 per wave-cycle); while a second stream runs other kernels it counts their cycles too
+                e["mfma_busy_over_kernel_cycles"] = per["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * per["GRBM_GUI_ACTIVE"] / 8.0)
         if per.get("SQ_INSTS_VALU_MFMA_MOPS_F16") or per.get("SQ_INSTS_MFMA"):
             pass
     res["kernels"][k] = e

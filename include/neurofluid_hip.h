@@ -251,6 +251,16 @@ int nf_composite_bwd(const float* rgbsigma, const float* z, const float* z_table
                      float* scratch /*R*S*/, float* d_rgbsigma /*R*S*4*/, const int32_t* num_nn /*or NULL*/, int k_full,
                      nf_stream_t stream);
 
+/* noise_std > 0 (models/renderer.py:193-196): `noise` (R*S, = noise_std * randn, drawn by the caller in the reference's order: coarse
+ * pass, then fine pass) is added to sigma before the ReLU — at EVERY sample: a masked sample's sigma is 0 * mask + noise, so
+ * nothing is skipped; rgbsigma is still read only where the mask allows. */
+int nf_composite_fwd_noise(const float* rgbsigma, const float* z, const float* z_table, const float* rays, const uint8_t* mask,
+                           int gate_by_mask, int R, int S, int white_bg, const float* noise, float* rgb, float* depth,
+                           float* opacity, float* weights, float* mask_sum, const int32_t* num_nn, int k_full, nf_stream_t stream);
+int nf_composite_bwd_noise(const float* rgbsigma, const float* z, const float* z_table, const float* rays, const float* d_rgb,
+                           const uint8_t* mask, int gate_by_mask, int R, int S, int white_bg, const float* noise, float* scratch,
+                           float* d_rgbsigma, const int32_t* num_nn, int k_full, nf_stream_t stream);
+
 /* A9: ImportanceSampling(det=True) (utils/ray_utils.py:178-229): z1 = sort(cat(z0, inverse-CDF samples)).
  * u_table = torch.linspace(0,1,N_imp) supplied by the caller (bit-identical to the reference).
  * zero_row (optional, S0+N_imp floats): this function's own output for a ray with all-zero weights

@@ -9,7 +9,7 @@ def _prep(x):
     return x.detach().contiguous().float()
 
 
-def _run_passes(net, particles, ro, rays, white_bg, fine, save_acts, _retry=False, use_disp=False):
+def _run_passes(net, particles, ro, rays, white_bg, fine, save_acts, _retry=False, use_disp=False, noise_std=0.0, _noise=None):
     dev = rays.device
     z_table, u_table = net._tables(dev, use_disp)
     grid = net.grid_for(particles)
@@ -37,9 +37,17 @@ def _run_passes(net, particles, ro, rays, white_bg, fine, save_acts, _retry=Fals
         pk0, ws0, ph0 = net.packed_weights(net.nerf_coarse), None, None
     else:
         pk0, ws0, ph0 = net.packed_for_inference(net.nerf_coarse, use_h)
+    # noise_std > 0 (models/renderer.py:193-196): one (R, S) normal draw per pass, coarse first — the reference's order; a redo of
+    # the call (row capacities) reuses the draws of the first attempt
+    R_ = rays_c.shape[0]
+    if noise_std and _noise is None:
+        _noise = [net.draw_noise((R_, net.N_samples), dev) * noise_std,
+                  net.draw_noise((R_, net.N_samples + net.N_importance), dev) * noise_std if fine else None]
+    nz0, nz1 = (_noise if _noise is not None else (None, None))
     p0 = ops.render_pass(grid, pts, rays_c, None, z_table, net.N_samples, net.raduis, net.num_neighbor, net.enc_flags,
                          net.use_mask, ro_c, pk0, net.in_channels_xyz, net.in_channels_dir, white_bg, save_acts,
-                         packed_h=ph0, ws=ws, need_weights=fine, optimistic=opt, caps=caps, wstream=ws0, after_search=after)
+                         packed_h=ph0, ws=ws, need_weights=fine, optimistic=opt, caps=caps, wstream=ws0, after_search=after,
+                         noise=nz0)
     p0.packed = pk0
     p1 = None
     if fine:
@@ -51,7 +59,7 @@ def _run_passes(net, particles, ro, rays, white_bg, fine, save_acts, _retry=Fals
         p1 = ops.render_pass(grid, pts, rays_c, z1, None, net.N_samples + net.N_importance, net.raduis, net.num_neighbor,
                              net.enc_flags, net.use_mask, ro_c, pk1, net.in_channels_xyz, net.in_channels_dir, white_bg,
                              save_acts, packed_h=ph1, ws=ws, need_weights=False, optimistic=opt, caps=caps, wstream=ws1,
-                             after_search=after)
+                             after_search=after, noise=nz1)
         p1.z = z1
         p1.packed = pk1
     # Inference passes ran against learnt row capacities without a host round trip: verify ONCE, here, with the whole
@@ -74,7 +82,8 @@ def _run_passes(net, particles, ro, rays, white_bg, fine, save_acts, _retry=Fals
             ops.PROFILE["rows"] = [(known[id(r)] if id(r) in known else int(r.item())) if torch.is_tensor(r) else r
                                    for r in ops.PROFILE["rows"]]
         if overflow:
-            return _run_passes(net, particles, ro, rays, white_bg, fine, save_acts, _retry=True, use_disp=use_disp)
+            return _run_passes(net, particles, ro, rays, white_bg, fine, save_acts, _retry=True, use_disp=use_disp, noise_std=noise_std,
+                               _noise=_noise)
     return p0, p1, rays_c, ro_c, grid
 
 
@@ -160,11 +169,12 @@ def _results(p0, p1):
     return out
 
 
-def render_forward(net, particles, ro, rays, white_bg=True, fine=True, use_disp=False):
+def render_forward(net, particles, ro, rays, white_bg=True, fine=True, use_disp=False, noise_std=0.0):
     needs_grad = torch.is_grad_enabled() and (particles.requires_grad or any(p.requires_grad for p in net.parameters()))
     if needs_grad:
         from .autograd_bwd import render_with_grad
-        return render_with_grad(net, particles, ro, rays, white_bg, fine, use_disp)
+        return render_with_grad(net, particles, ro, rays, white_bg, fine, use_disp, noise_std)
     with torch.no_grad():
-        p0, p1, _, _, _ = _run_passes(net, particles, ro, rays, white_bg, fine, save_acts=False, use_disp=use_disp)
+        p0, p1, _, _, _ = _run_passes(net, particles, ro, rays, white_bg, fine, save_acts=False, use_disp=use_disp,
+                                      noise_std=noise_std)
         return _results(p0, p1)

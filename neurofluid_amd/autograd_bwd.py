@@ -55,8 +55,13 @@ def _pass_backward(net, nerf, pb, rays_c, z, z_table, g_rgb, white_bg, particles
     scratch = torch.empty(R * S, dtype=torch.float32, device=dev)
     d_rs = torch.empty(R * S, 4, dtype=torch.float32, device=dev)
     g = g_rgb.detach().contiguous().float()
-    check(lib.nf_composite_bwd(ptr(pb.rgbsigma), ptr(z), ptr(z_table), ptr(rays_c), ptr(g), None, pb.gate, R, S,
-                               int(white_bg), ptr(scratch), ptr(d_rs), ptr(pb.num_nn), pb.K, st), "nf_composite_bwd")
+    if getattr(pb, "noise", None) is not None:
+        check(lib.nf_composite_bwd_noise(ptr(pb.rgbsigma), ptr(z), ptr(z_table), ptr(rays_c), ptr(g), None, pb.gate, R, S,
+                                         int(white_bg), ptr(pb.noise), ptr(scratch), ptr(d_rs), ptr(pb.num_nn), pb.K, st),
+              "nf_composite_bwd_noise")
+    else:
+        check(lib.nf_composite_bwd(ptr(pb.rgbsigma), ptr(z), ptr(z_table), ptr(rays_c), ptr(g), None, pb.gate, R, S,
+                                   int(white_bg), ptr(scratch), ptr(d_rs), ptr(pb.num_nn), pb.K, st), "nf_composite_bwd")
     packed_t = _pack_bwd(nerf, cx, cd, dev)
     # every row-sized temporary is allocated at the pass's bucketed capacity (ops._round_rows): the active-row count
     # changes from step to step, and exact sizes make the caching allocator grow by a fresh block per step (and give
@@ -111,10 +116,11 @@ class _RenderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, particles, ro, rays, white_bg, fine, *params):
         ctx.set_materialize_grads(False)      # backward reads rgb0 / rgb1 only: no zero tensors for the 8 other outputs
-        use_disp = isinstance(fine, tuple) and fine[1]      # (fine, use_disp) rides in one non-tensor argument
-        fine = fine[0] if isinstance(fine, tuple) else fine
+        opts = fine if isinstance(fine, tuple) else (fine, False, 0.0)      # (fine, use_disp, noise_std) ride in one non-tensor argument
+        fine, use_disp, noise_std = opts
         ctx.use_disp = use_disp
-        p0, p1, rays_c, ro_c, grid = _run_passes(net, particles, ro, rays, white_bg, fine, save_acts=True, use_disp=use_disp)
+        p0, p1, rays_c, ro_c, grid = _run_passes(net, particles, ro, rays, white_bg, fine, save_acts=True, use_disp=use_disp,
+                                                 noise_std=noise_std)
         ctx.net, ctx.p0, ctx.p1, ctx.rays_c, ctx.white_bg, ctx.fine = net, p0, p1, rays_c, white_bg, fine
         ctx.particles_need_grad = particles.requires_grad
         ctx.ro_c, ctx.pts = ro_c, grid.points
@@ -167,8 +173,9 @@ class _RenderFn(torch.autograd.Function):
         return (None, dpart, None, None, None, None) + tuple(gc) + tuple(gf)
 
 
-def render_with_grad(net, particles, ro, rays, white_bg, fine, use_disp=False):
-    outs = _RenderFn.apply(net, particles, ro, rays, white_bg, (fine, bool(use_disp)) if use_disp else fine, *_nerf_params(net))
+def render_with_grad(net, particles, ro, rays, white_bg, fine, use_disp=False, noise_std=0.0):
+    opts = (fine, bool(use_disp), float(noise_std)) if (use_disp or noise_std) else fine
+    outs = _RenderFn.apply(net, particles, ro, rays, white_bg, opts, *_nerf_params(net))
     keys = ["rgb0", "depth0", "opacity0", "num_nn_0", "mask_0"] + (
         ["rgb1", "depth1", "opacity1", "num_nn_1", "mask_1"] if fine else [])
     out = LazyResults()

@@ -565,8 +565,12 @@ __global__ void __launch_bounds__(64) k_composite(const float4* __restrict__ rgb
                                                   const uint8_t* __restrict__ mask, int gate, int R, int S, int white_bg,
                                                   float* __restrict__ rgb, float* __restrict__ depth,
                                                   float* __restrict__ opacity, float* __restrict__ weights,
-                                                  float* __restrict__ mask_sum, const int* __restrict__ num_nn, int k_full)
+                                                  float* __restrict__ mask_sum, const int* __restrict__ num_nn, int k_full,
+                                                  const float* __restrict__ noise)
 {
+    // noise (optional, R x S): added to sigma before the ReLU (models/renderer.py:193-196, noise_std > 0).  The reference adds it to
+    // EVERY sample, masked ones included (their sigma is 0 * mask + noise), so no tile is skipped then; rgbsigma is still
+    // read only where the mask allows.
     __shared__ float4 s_rs[64 * CP_PITCH];
     __shared__ float s_z[64 * (CP_TS + 1) + 64];
     __shared__ float s_w[64 * CP_PITCH];
@@ -613,7 +617,7 @@ __global__ void __launch_bounds__(64) k_composite(const float4* __restrict__ rgb
             ms += __popc(mbits);
         }
         const unsigned abits = gate ? mbits : (live ? 0xffffu : 0u);     // samples whose rgbsigma is read
-        if (__ballot(abits != 0u) == 0ull) {
+        if (!noise && __ballot(abits != 0u) == 0ull) {
             // nothing to composite in this tile for any of the 64 rays
             if (weights) {
 #pragma unroll 4
@@ -654,7 +658,8 @@ __global__ void __launch_bounds__(64) k_composite(const float4* __restrict__ rgb
                 float zc = s_z[t * (CP_TS + 1) + k], zn = s_z[t * (CP_TS + 1) + k + 1];
                 float delta = ((s + 1 < S) ? (zn - zc) : 1e10f) * nrm;
                 float4 v = s_rs[t * CP_PITCH + k];
-                float alpha = 1.f - expf(-delta * fmaxf(v.w, 0.f));
+                const float sg = noise ? v.w + noise[(size_t)r * S + s] : v.w;
+                float alpha = 1.f - expf(-delta * fmaxf(sg, 0.f));
                 float w = alpha * T;
                 T = T * ((1.f - alpha) + 1e-10f);
                 cr += w * v.x; cg += w * v.y; cb += w * v.z; cd += w * zc; ws += w;
@@ -895,7 +900,22 @@ extern "C" int nf_composite_fwd(const float* rgbsigma, const float* z, const flo
         return NF_OK;
     }
     hipLaunchKernelGGL(k_composite, dim3((R + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const float4*)rgbsigma, z,
-                       z_table, rays, mask, gate_by_mask, R, S, white_bg, rgb, depth, opacity, weights, mask_sum, num_nn, k_full);
+                       z_table, rays, mask, gate_by_mask, R, S, white_bg, rgb, depth, opacity, weights, mask_sum, num_nn, k_full,
+                       (const float*)nullptr);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+extern "C" int nf_composite_fwd_noise(const float* rgbsigma, const float* z, const float* z_table, const float* rays,
+                                      const uint8_t* mask, int gate_by_mask, int R, int S, int white_bg, const float* noise,
+                                      float* rgb, float* depth, float* opacity, float* weights, float* mask_sum,
+                                      const int32_t* num_nn, int k_full, nf_stream_t stream)
+{
+    NF_CHECK_ARG(rgbsigma && (z || z_table) && rays && rgb && depth && opacity && noise, "null pointer");
+    NF_CHECK_ARG(!gate_by_mask || mask || num_nn, "gate_by_mask needs the mask (or num_nn + k_full)");
+    if (R == 0) return NF_OK;
+    hipLaunchKernelGGL(k_composite, dim3((R + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const float4*)rgbsigma, z,
+                       z_table, rays, mask, gate_by_mask, R, S, white_bg, rgb, depth, opacity, weights, mask_sum, num_nn, k_full, noise);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }
@@ -1138,7 +1158,8 @@ __global__ void __launch_bounds__(64) k_composite_bwd(const float4* __restrict__
                                                       const float* __restrict__ z_table, const float* __restrict__ rays,
                                                       const float* __restrict__ d_rgb, const uint8_t* __restrict__ mask,
                                                       int gate, int R, int S, int white_bg, float* __restrict__ scratch,
-                                                      float4* __restrict__ d_rgbsigma, const int* __restrict__ num_nn, int k_full)
+                                                      float4* __restrict__ d_rgbsigma, const int* __restrict__ num_nn, int k_full,
+                                                      const float* __restrict__ noise)
 {
     int r = blockIdx.x * 64 + threadIdx.x;
     if (r >= R) return;
@@ -1152,7 +1173,8 @@ __global__ void __launch_bounds__(64) k_composite_bwd(const float4* __restrict__
     for (int s = 0; s < S; ++s) {
         float delta = ((s + 1 < S) ? (zr[s + 1] - zr[s]) : 1e10f) * nrm;
         const bool on = !gate || (mask ? mask[(size_t)r * S + s] != 0 : num_nn[(size_t)r * S + s] == k_full);      // rgbsigma is defined (written by the MLP) only there
-        float alpha = on ? 1.f - expf(-delta * fmaxf(rgbsigma[(size_t)r * S + s].w, 0.f)) : 0.f;
+        float alpha = on ? 1.f - expf(-delta * fmaxf(rgbsigma[(size_t)r * S + s].w + (noise ? noise[(size_t)r * S + s] : 0.f), 0.f)) : 0.f;
+        if (noise && !on) alpha = 1.f - expf(-delta * fmaxf(noise[(size_t)r * S + s], 0.f));      // a masked sample: sigma = 0 + noise
         Tr[s] = T;
         T = T * ((1.f - alpha) + 1e-10f);
     }
@@ -1161,14 +1183,15 @@ __global__ void __launch_bounds__(64) k_composite_bwd(const float4* __restrict__
         const bool on = !gate || (mask ? mask[(size_t)r * S + s] != 0 : num_nn[(size_t)r * S + s] == k_full);
         float4 v = on ? rgbsigma[(size_t)r * S + s] : make_float4(0.f, 0.f, 0.f, 0.f);
         float delta = ((s + 1 < S) ? (zr[s + 1] - zr[s]) : 1e10f) * nrm;
-        float e = expf(-delta * fmaxf(v.w, 0.f));
+        const float sg = noise ? v.w + noise[(size_t)r * S + s] : v.w;
+        float e = expf(-delta * fmaxf(sg, 0.f));
         float alpha = 1.f - e;
         float Ti = Tr[s];
         float w = alpha * Ti;
         float dw = g0 * v.x + g1 * v.y + g2 * v.z - gsum;
         float dalpha = Ti * dw - suffix / ((1.f - alpha) + 1e-10f);
         suffix += dw * w;
-        float dsigma = v.w > 0.f ? dalpha * delta * e : 0.f;
+        float dsigma = sg > 0.f ? dalpha * delta * e : 0.f;
         d_rgbsigma[(size_t)r * S + s] = make_float4(w * g0, w * g1, w * g2, dsigma);
     }
 }
@@ -1258,7 +1281,22 @@ extern "C" int nf_composite_bwd(const float* rgbsigma, const float* z, const flo
         return NF_OK;
     }
     hipLaunchKernelGGL(k_composite_bwd, dim3((R + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const float4*)rgbsigma, z,
-                       z_table, rays, d_rgb, mask, gate_by_mask, R, S, white_bg, scratch, (float4*)d_rgbsigma, num_nn, k_full);
+                       z_table, rays, d_rgb, mask, gate_by_mask, R, S, white_bg, scratch, (float4*)d_rgbsigma, num_nn, k_full,
+                       (const float*)nullptr);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+extern "C" int nf_composite_bwd_noise(const float* rgbsigma, const float* z, const float* z_table, const float* rays,
+                                      const float* d_rgb, const uint8_t* mask, int gate_by_mask, int R, int S, int white_bg,
+                                      const float* noise, float* scratch, float* d_rgbsigma, const int32_t* num_nn, int k_full,
+                                      nf_stream_t stream)
+{
+    NF_CHECK_ARG(rgbsigma && (z || z_table) && rays && d_rgb && scratch && d_rgbsigma && noise, "null pointer");
+    NF_CHECK_ARG(!gate_by_mask || mask || num_nn, "gate_by_mask needs the mask (or num_nn + k_full)");
+    if (R == 0) return NF_OK;
+    hipLaunchKernelGGL(k_composite_bwd, dim3((R + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const float4*)rgbsigma, z,
+                       z_table, rays, d_rgb, mask, gate_by_mask, R, S, white_bg, scratch, (float4*)d_rgbsigma, num_nn, k_full, noise);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }

@@ -387,7 +387,7 @@ class HostFetch:
 
 def render_pass(grid, particles, rays, z, z_table, S, radius, K, enc_flags, use_mask, ro, packed, cx, cd,
                 white_bg=True, save_acts=False, max_rows=None, packed_h=None, ws=None, need_weights=True, wstream=None,
-                optimistic=False, caps=None, after_search=None):
+                optimistic=False, caps=None, after_search=None, noise=None):
     """Runs classify -> search -> features -> MLP -> composite for R rays x S samples.
     z: (R,S) per-ray depths or None (then z_table (S,) is shared by all rays).
     Returns a PassBuffers with rgb, depth, opacity, weights, num_nn, mask_sum and the row lists.
@@ -553,6 +553,12 @@ def render_pass(grid, particles, rays, z, z_table, S, radius, K, enc_flags, use_
     b.weights = torch.empty(R, S, dtype=torch.float32, device=dev) if need_weights else None
     b.mask_sum = torch.empty(R, dtype=torch.float32, device=dev)
     b.gate = int(bool(use_mask))       # rgbsigma is defined where mask = 1 only (nobody writes the rest)
+    b.noise = noise
+    if noise is not None:       # noise_std > 0 (models/renderer.py:193-196): (R, S) = noise_std * randn, added to sigma before the ReLU
+        check(lib.nf_composite_fwd_noise(ptr(b.rgbsigma), ptr(z), ptr(z_table), ptr(rays), None, b.gate, R, S, int(white_bg), ptr(noise),
+                                         ptr(b.rgb), ptr(b.depth), ptr(b.opacity), ptr(b.weights), ptr(b.mask_sum), ptr(b.num_nn), K, st),
+              "nf_composite_fwd_noise")
+        return b
     check(lib.nf_composite_fwd(ptr(b.rgbsigma), ptr(z), ptr(z_table), ptr(rays), None, b.gate, R, S, int(white_bg),
                                ptr(b.rgb), ptr(b.depth), ptr(b.opacity), ptr(b.weights), ptr(b.mask_sum), ptr(b.num_nn), K, st),
           "nf_composite_fwd")

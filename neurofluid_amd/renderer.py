@@ -158,19 +158,31 @@ class RenderNet(nn.Module):
     # ------------------------------------------------------------------
     def forward(self, physical_particles, ro, rays, focal=None, c2w=None, use_disp=False, perturb=0, noise_std=0.,
                 white_background=True):
-        if perturb != 0 or noise_std != 0.:
-            raise NotImplementedError("perturb / noise_std (random jitter of the depths and of sigma) are never passed by the "
-                                      "reference callers (trainer/basetrainer.py:284-289)")
+        self._check_perturb(perturb)
         from .autograd import render_forward
         return render_forward(self, physical_particles, ro, rays, white_background, fine=self.N_importance > 0,
-                              use_disp=bool(use_disp))
+                              use_disp=bool(use_disp), noise_std=float(noise_std))
+
+    @staticmethod
+    def _check_perturb(perturb):
+        if perturb != 0:
+            raise NotImplementedError(
+                "perturb > 0 cannot run in the reference on a GPU either: its sample_pdf draws u = torch.rand(...) on the CPU and "
+                "searches a CUDA cdf with it (utils/ray_utils.py:190, :204 — a device-mismatch error), and no caller passes it "
+                "(trainer/basetrainer.py:284-289)")
+
+    @staticmethod
+    def draw_noise(shape, device):
+        """The sigma noise of noise_std > 0 (models/renderer.py:194): torch.randn on the rays' device, one draw per pass in the
+        reference's order (coarse, then fine).  A method so that a test can feed the same numbers to the oracle."""
+        return torch.randn(shape, device=device)
 
     def coarse_rendering(self, physical_particles, ro, rays, focal=None, c2w=None, use_disp=False, perturb=0,
                          noise_std=0., white_background=True):
-        if perturb != 0 or noise_std != 0.:
-            raise NotImplementedError("perturb / noise_std are never passed by the reference callers")
+        self._check_perturb(perturb)
         from .autograd import render_forward
-        return render_forward(self, physical_particles, ro, rays, white_background, fine=False, use_disp=bool(use_disp))
+        return render_forward(self, physical_particles, ro, rays, white_background, fine=False, use_disp=bool(use_disp),
+                              noise_std=float(noise_std))
 
     def fine_rendering(self, physical_particles, ro, rays, focal=None, c2w=None, use_disp=False, perturb=0,
                        noise_std=0., white_background=True):

@@ -174,9 +174,11 @@ def embedding_local_geometry(dists, neighbors_xyz, radius, ray_particles, rays, 
 # ----------------------------------------------------------------------------------------------
 # A8  alpha compositing
 # ----------------------------------------------------------------------------------------------
-def render_image(rgbsigma, zvals, rays, white_background=True):
-    """models/renderer.py:182-208 with noise_std = 0."""
+def render_image(rgbsigma, zvals, rays, white_background=True, noise=None):
+    """models/renderer.py:182-208; noise = noise_std * randn(sigmas.shape) (:193-195) or None."""
     rgbs, sigmas = rgbsigma[..., :3], rgbsigma[..., 3]
+    if noise is not None:
+        sigmas = sigmas + noise
     deltas = zvals[:, 1:] - zvals[:, :-1]
     deltas = torch.cat([deltas, 1e10 * torch.ones_like(deltas[:, :1])], -1)
     deltas = deltas * torch.norm(rays[:, 3:].unsqueeze(1), dim=-1)
@@ -224,7 +226,7 @@ def importance_sampling(zvals, weights, n_importance, rays_o, rays_d):
 # ----------------------------------------------------------------------------------------------
 # A10  the whole chunk
 # ----------------------------------------------------------------------------------------------
-def render_pass(state, prefix, particles, ro, rays, z, xyz, cfg, white_background=True):
+def render_pass(state, prefix, particles, ro, rays, z, xyz, cfg, white_background=True, noise=None):
     radius = cfg["search_raduis_scale"] * cfg["particle_radius"]
     cx, cd = nerf_channels(cfg)
     S = z.shape[1]
@@ -234,22 +236,30 @@ def render_pass(state, prefix, particles, ro, rays, z, xyz, cfg, white_backgroun
     mask = torch.all(dists != 0, dim=-1, keepdim=True).float()
     if cfg["use_mask"]:
         rgbsigma = rgbsigma * mask
-    rgb, depth, weights = render_image(rgbsigma, z, rays, white_background)
+    rgb, depth, weights = render_image(rgbsigma, z, rays, white_background, noise)
     return dict(rgb=rgb, depth=depth, weights=weights, num_nn=num_nn, mask=mask, rgbsigma=rgbsigma,
                 idx=idx, dists=dists, feats=feats)
 
 
 def render_forward(state, particles, ro, rays, near, far, cfg=DEFAULT_CFG, white_background=True,
-                   return_debug=False, use_disp=False):
-    """models/renderer.py:211-270 -> dict with the reference's keys."""
+                   return_debug=False, use_disp=False, noise_std=0.0, noise=None):
+    """models/renderer.py:211-270 -> dict with the reference's keys.  noise_std > 0: sigma noise, one torch.randn draw per pass
+    in the reference's order (coarse, fine) from the global CPU generator, or the two tensors `noise` = (n0, n1) (already scaled)."""
     z0, xyz0 = coarse_sample_ray(near, far, rays, cfg["N_samples"], use_disp)
-    p0 = render_pass(state, "nerf_coarse", particles, ro, rays, z0, xyz0, cfg, white_background)
+    n0 = n1 = None
+    if noise is not None:
+        n0, n1 = noise
+    elif noise_std:
+        n0 = torch.randn(rays.shape[0], cfg["N_samples"]) * noise_std
+    p0 = render_pass(state, "nerf_coarse", particles, ro, rays, z0, xyz0, cfg, white_background, n0)
     out = {"rgb0": p0["rgb"], "depth0": p0["depth"], "opacity0": p0["weights"].sum(1),
            "num_nn_0": p0["num_nn"], "mask_0": p0["mask"].sum(1)}
     dbg = {"z0": z0, "weights0": p0["weights"], "rgbsigma0": p0["rgbsigma"]}
     if cfg["N_importance"] > 0:
         xyz1, z1 = importance_sampling(z0, p0["weights"], cfg["N_importance"], rays[..., :3], rays[..., 3:])
-        p1 = render_pass(state, "nerf_fine", particles, ro, rays, z1, xyz1, cfg, white_background)
+        if noise is None and noise_std:
+            n1 = torch.randn(rays.shape[0], cfg["N_samples"] + cfg["N_importance"]) * noise_std
+        p1 = render_pass(state, "nerf_fine", particles, ro, rays, z1, xyz1, cfg, white_background, n1)
         out.update({"rgb1": p1["rgb"], "depth1": p1["depth"], "opacity1": p1["weights"].sum(1),
                     "num_nn_1": p1["num_nn"], "mask_1": p1["mask"].sum(1)})
         dbg.update({"z1": z1, "weights1": p1["weights"], "rgbsigma1": p1["rgbsigma"]})

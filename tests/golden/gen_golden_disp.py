@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Golden vectors of the renderer's `use_disp=True` mode (coarse depths linear in disparity, utils/ray_utils.py:236-240),
+"""Golden vectors of the renderer's optional modes: `noise_std > 0` (a10_noise.npz) and `use_disp=True` mode (coarse depths linear in disparity, utils/ray_utils.py:236-240),
 recorded from the reference's own Python exactly like gen_golden.py (same stand-ins, same scene), in a file of its own so
 that gen_golden.py keeps regenerating its fixtures bit for bit.  Runs only where /root/reference exists.
 Usage:  python tests/golden/gen_golden_disp.py"""
@@ -35,6 +35,13 @@ def main():
     ro_cam = rn.set_ro(c2w)
     with torch.no_grad():
         out = rn(P, ro_cam, sel, focal, c2w, use_disp=True)
+    # noise_std > 0 (models/renderer.py:193-195): the reference draws torch.randn(sigmas.shape) once per pass from the global
+    # generator — seeded here, so that the oracle can repeat the draws
+    torch.manual_seed(4321)
+    with torch.no_grad():
+        outn = rn(P, ro_cam, sel, focal, c2w, noise_std=0.5)
+    gg.save("a10_noise", particles=P, rays=sel, ro=ro_cam, seed=4321, noise_std=0.5, standin_ball_query=1,
+            **{k: v for k, v in outn.items()})
     gg.save("a1_a10_disp", rays5=sel[:5], near=9.0, far=13.0, z=z.contiguous(), xyz=xyz, particles=P, rays=sel, ro=ro_cam,
             standin_ball_query=1, **{k: v for k, v in out.items()})
 

@@ -321,8 +321,6 @@ def test_forward_disparity_sampling(dev):
     assert torch.equal(fine["rgb1"], out["rgb1"]) and torch.equal(coarse["rgb0"], out["rgb0"])
     with pytest.raises(NotImplementedError):
         net(P, roc, rays, None, None, perturb=1.0)
-    with pytest.raises(NotImplementedError):
-        net(P, roc, rays, None, None, noise_std=1.0)
     # gradients through the disparity table: one SGD step on the loss lowers it
     tgt = torch.full((rays.shape[0], 3), 0.25, device=dev)
     def loss_of():
@@ -337,6 +335,60 @@ def test_forward_disparity_sampling(dev):
             if p.grad is not None:
                 p -= 1e-3 * p.grad / gn
         assert float(loss_of()) < float(l0.detach())
+
+
+def test_forward_sigma_noise(dev):
+    """noise_std > 0 (models/renderer.py:193-195): sigma + noise_std * randn before the ReLU, at every sample (masked ones included).
+    The same two draws are fed to the HIP path (RenderNet.draw_noise) and to the oracle; they are also the reference's own
+    draws for this seed, so the result must match the dict the reference returned (tests/golden/a10_noise.npz).  Gradients
+    vs torch autograd through the oracle with the same noise; perturb > 0 raises (the reference fails there itself)."""
+    from oracle import render_oracle as ro
+    g = load_golden("a10_noise")
+    net = make_net(dev)
+    P, rays, roc = T(g["particles"], dev), T(g["rays"], dev), T(g["ro"], dev)
+    R, std = rays.shape[0], float(g["noise_std"])
+    torch.manual_seed(int(g["seed"]))
+    draws = [torch.randn(R, 64), torch.randn(R, 192)]
+
+    def feed():
+        it = iter(draws)
+        net.draw_noise = lambda shape, device: next(it).to(device)
+
+    feed()
+    with torch.no_grad():
+        out = net(P, roc, rays, None, None, noise_std=std)
+    ref = ro.render_forward(ro.deterministic_nerf_state(), P.cpu(), roc.cpu(), rays.cpu(), 9.0, 13.0,
+                            noise=(draws[0] * std, draws[1] * std))
+    for k in ("num_nn_0", "num_nn_1", "mask_0", "mask_1"):
+        assert torch.equal(out[k].cpu(), T(g[k])), k
+    for k in ("rgb0", "rgb1"):
+        torch.testing.assert_close(out[k].cpu(), ref[k], rtol=0, atol=RGB_ATOL, msg=k)
+        torch.testing.assert_close(out[k].cpu(), T(g[k]), rtol=0, atol=RGB_ATOL, msg="golden " + k)
+    for k in ("depth0", "depth1", "opacity0", "opacity1"):
+        torch.testing.assert_close(out[k].cpu(), T(g[k]), rtol=1e-4, atol=2e-4, msg=k)
+    with pytest.raises(NotImplementedError):
+        net(P, roc, rays, None, None, perturb=1.0)
+    # gradients: coarse net (same samples on both sides) against autograd through the oracle
+    r8 = rays[:8].contiguous()
+    d8 = [draws[0][:8].contiguous(), draws[1][:8].contiguous()]
+    tgt = torch.full((8, 3), 0.3)
+    it = iter(d8)
+    net.draw_noise = lambda shape, device: next(it).to(device)
+    net.zero_grad()
+    o = net(P, roc, r8, None, None, noise_std=std)
+    loss = torch.nn.functional.mse_loss(o["rgb0"], tgt.to(dev)) + torch.nn.functional.mse_loss(o["rgb1"], tgt.to(dev))
+    loss.backward()
+    st = {k: v.clone().requires_grad_(True) for k, v in ro.deterministic_nerf_state().items()}
+    oref = ro.render_forward(st, P.cpu(), roc.cpu(), r8.cpu(), 9.0, 13.0, noise=(d8[0] * std, d8[1] * std))
+    lref = torch.nn.functional.mse_loss(oref["rgb0"], tgt) + torch.nn.functional.mse_loss(oref["rgb1"], tgt)
+    lref.backward()
+    assert abs(float(loss.detach()) - float(lref.detach())) < 1e-5
+    for name, p in net.named_parameters():
+        if not name.startswith("nerf_coarse") or st[name].grad is None:
+            continue
+        rel = float((p.grad.cpu() - st[name].grad).norm() / (st[name].grad.norm() + 1e-30))
+        assert rel < 1e-3, (name, rel)
+    del net.draw_noise
 
 
 def test_forward_empty_and_ragged(dev):

@@ -104,6 +104,21 @@ def test_a1_a10_disparity_sampling(golden):
     assert not torch.equal(lin["mask_0"], out["mask_0"])          # the mode changes which samples fall into the fluid
 
 
+def test_a10_sigma_noise(golden):
+    """noise_std > 0 (models/renderer.py:193-195): the oracle repeats the reference's two torch.randn draws (same seed, same shapes,
+    same order) and must land on the dict the reference returned (tests/golden/gen_golden_disp.py)."""
+    g = golden("a10_noise")
+    st = ro.deterministic_nerf_state()
+    torch.manual_seed(int(g["seed"]))
+    out = ro.render_forward(st, T(g["particles"]), T(g["ro"]), T(g["rays"]), 9.0, 13.0, noise_std=float(g["noise_std"]))
+    for k in ["num_nn_0", "num_nn_1", "mask_0", "mask_1"]:
+        assert torch.equal(out[k], T(g[k])), k
+    for k in ["rgb0", "rgb1", "depth0", "depth1", "opacity0", "opacity1"]:
+        torch.testing.assert_close(out[k], T(g[k]), rtol=0, atol=2e-6, msg=k)
+    clean = ro.render_forward(st, T(g["particles"]), T(g["ro"]), T(g["rays"]), 9.0, 13.0)
+    assert float((clean["rgb1"] - out["rgb1"]).abs().max()) > 1e-2          # the noise matters (empty space turns slightly opaque)
+
+
 def test_b1_integrate(golden):
     g = golden("b1_integrate")
     p2, v2 = to.integrate_pos_vel(T(g["pos"]), T(g["vel"]), T(g["gravity"]), float(g["dt"]))

@@ -207,12 +207,12 @@ def _virtual_b(kernel, dense_w):
 
 class _ParticleNetFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pn, pos, vel, box, box_feats, *params):
+    def forward(ctx, pn, pos, vel, box, box_feats, feats, *params):
         ctx.set_materialize_grads(False)      # g_pos / g_vel arrive as None when unused (backward handles both)
-        pos_c, vel_c, nn, aux = pn._forward_impl(pos, vel, box, box_feats, keep=True)
+        pos_c, vel_c, nn, aux = pn._forward_impl(pos, vel, box, box_feats, keep=True, other=feats)
         ctx.pn, ctx.aux = pn, aux
         ctx.box, ctx.box_feats = box.detach().contiguous().float(), box_feats.detach().contiguous().float()
-        ctx.in_grad = (pos.requires_grad, vel.requires_grad)
+        ctx.in_grad = (pos.requires_grad, vel.requires_grad, feats is not None and feats.requires_grad)
         ctx.mark_non_differentiable(nn)
         return pos_c, vel_c, nn
 
@@ -263,8 +263,18 @@ class _ParticleNetFn(torch.autograd.Function):
         wsf = torch.empty(lib.nf_cconv_small_bwd_filter_workspace_floats(4, n), dtype=torch.float32, device=dev)
         check(lib.nf_cconv_small_bwd_filter(ptr(ctx.box_feats), 3, ptr(b_rs), ptr(b_idx), ptr(b_pw), ptr(b_pc), ptr(dy), 96, 0,
                                             n, ptr(wsf), ptr(dKo), st), "conv0_obstacle filter grad")
-        check(lib.nf_cconv_small_bwd_filter(ptr(ff), 4, ptr(f_rs), ptr(f_idx), ptr(f_pw), ptr(f_pc), ptr(dy), 96, 32, n,
-                                            ptr(wsf), ptr(dKf), st), "conv0_fluid filter grad")
+        cin0 = ff.shape[1]
+        dG0 = None
+        if cin0 == 4:
+            check(lib.nf_cconv_small_bwd_filter(ptr(ff), 4, ptr(f_rs), ptr(f_idx), ptr(f_pw), ptr(f_pc), ptr(dy), 96, 32, n,
+                                                ptr(wsf), ptr(dKf), st), "conv0_fluid filter grad")
+        else:       # other_feats_channels > 0: the general layer's backward (transposed gather + GEMM), no activation on the input
+            dyf = dy[:, 32:64].contiguous()
+            dG0 = torch.empty(n, 65 * 32, dtype=torch.float32, device=dev)
+            check(lib.nf_cconv_gather_bwd(ptr(dyf), 32, ptr(f_rs), ptr(f_idx), ptr(t_pw), ptr(t_pc), n, ptr(dG0), st),
+                  "nf_cconv_gather_bwd")
+            dB0 = ops.gemm(ff.t(), dG0[:, :64 * 32])
+            dKf = dB0.reshape(cin0, 64, 32).permute(1, 0, 2).reshape(c0f.kernel.shape).contiguous()
         grads[c0o.kernel], grads[c0f.kernel] = dKo, dKf
         grads[c0o.bias], grads[c0f.bias] = dy[:, :32].sum(0), dy[:, 32:64].sum(0)
         grads[d0.weight], grads[d0.bias] = ops.gemm(dy[:, 64:].t(), ff), dy[:, 64:].sum(0)
@@ -272,14 +282,22 @@ class _ParticleNetFn(torch.autograd.Function):
         g_in_pos = g_in_vel = None
         if ctx.in_grad[0]:
             g_in_pos = d_pos_c - (g_vel.detach().float() / dt if g_vel is not None else 0.)
-        if ctx.in_grad[1]:
-            dfeat = torch.empty(n, 4, dtype=torch.float32, device=dev)
-            check(lib.nf_cconv_small_bwd_feat(ptr(c0f.kernel.detach().contiguous()), 4, ptr(f_rs), ptr(f_idx), ptr(t_pw),
-                                              ptr(t_pc), ptr(dy), 96, 32, n, ptr(dfeat), st), "conv0_fluid feature grad")
+        g_in_feats = None
+        if ctx.in_grad[1] or ctx.in_grad[2]:
+            if cin0 == 4:
+                dfeat = torch.empty(n, 4, dtype=torch.float32, device=dev)
+                check(lib.nf_cconv_small_bwd_feat(ptr(c0f.kernel.detach().contiguous()), 4, ptr(f_rs), ptr(f_idx), ptr(t_pw),
+                                                  ptr(t_pc), ptr(dy), 96, 32, n, ptr(dfeat), st), "conv0_fluid feature grad")
+            else:
+                zw = torch.zeros(32, cin0, dtype=torch.float32, device=dev)
+                dfeat = ops.gemm(dG0, _virtual_b(c0f.kernel, zw).t())          # (n, 4 + F)
             ops.gemm(dy[:, 64:], d0.weight.detach(), out=dfeat, accumulate=True)
-            g_in_vel = d_pos_c * dt + dfeat[:, 1:4]                 # pos_new = pos + vel dt + g dt^2/2 ; feats = [1, vel + g dt]
-        return (None, g_in_pos, g_in_vel, None, None) + tuple(grads[p] for p in _pn_params(pn))
+            if ctx.in_grad[1]:
+                g_in_vel = d_pos_c * dt + dfeat[:, 1:4]             # pos_new = pos + vel dt + g dt^2/2 ; feats = [1, vel + g dt]
+            if ctx.in_grad[2]:
+                g_in_feats = dfeat[:, 4:].contiguous()
+        return (None, g_in_pos, g_in_vel, None, None, g_in_feats) + tuple(grads[p] for p in _pn_params(pn))
 
 
-def particle_net_with_grad(pn, pos, vel, box, box_feats):
-    return _ParticleNetFn.apply(pn, pos, vel, box, box_feats, *_pn_params(pn))
+def particle_net_with_grad(pn, pos, vel, box, box_feats, feats=None):
+    return _ParticleNetFn.apply(pn, pos, vel, box, box_feats, feats, *_pn_params(pn))

@@ -137,8 +137,10 @@ class ParticleNet(nn.Module):
                  interpolation='linear', use_window=True, particle_radius=0.025, timestep=1 / 50,
                  gravity=(0, -9.81, 0), other_feats_channels=0):
         super().__init__()
-        if other_feats_channels != 0:
-            raise NotImplementedError("other_feats_channels > 0 is never used by the reference callers")
+        # other_feats_channels > 0 (models/transmodel.py:24,43,50,111-114): extra per-particle input features next to [1, v].  No
+        # reference caller uses them; they are served on the exact multi-launch path (the fused step's front kernel is built
+        # for the 4-channel input).
+        self.other_feats_channels = int(other_feats_channels)
         self.layer_channels = [32, 64, 64, 3]
         self.coordinate_mapping, self.interpolation, self.use_window = coordinate_mapping, interpolation, use_window
         self.kernel_size, self.radius_scale, self.particle_radius = kernel_size, radius_scale, particle_radius
@@ -152,9 +154,9 @@ class ParticleNet(nn.Module):
                                   interpolation=interpolation, coordinate_mapping=coordinate_mapping, normalize=False,
                                   window_function=window, radius_search_ignore_query_points=True)
 
-        self.conv0_fluid = conv(4, 32)
+        self.conv0_fluid = conv(4 + self.other_feats_channels, 32)
         self.conv0_obstacle = conv(3, 32)
-        self.dense0_fluid = nn.Linear(4, 32)
+        self.dense0_fluid = nn.Linear(4 + self.other_feats_channels, 32)
         torch.nn.init.xavier_uniform_(self.dense0_fluid.weight)
         torch.nn.init.zeros_(self.dense0_fluid.bias)
         self.convs, self.denses = [], []
@@ -220,16 +222,17 @@ class ParticleNet(nn.Module):
 
     # ------------------------------------------------------------------
     def forward(self, pos, vel, box, box_feats, feats=None, fixed_radius_search_hash_table=None):
-        if feats is not None:
-            raise NotImplementedError("other feats are never passed by the reference callers")
-        if torch.is_grad_enabled() and (pos.requires_grad or vel.requires_grad or
+        nf = 0 if feats is None else int(feats.shape[-1])
+        if nf != self.other_feats_channels:
+            raise ValueError(f"feats has {nf} channels, the model was built with other_feats_channels={self.other_feats_channels}")
+        if torch.is_grad_enabled() and (pos.requires_grad or vel.requires_grad or (feats is not None and feats.requires_grad) or
                                         any(p.requires_grad for p in self.parameters())):
             from .autograd_bwd import particle_net_with_grad
-            return particle_net_with_grad(self, pos, vel, box, box_feats)
+            return particle_net_with_grad(self, pos, vel, box, box_feats, feats)
         with torch.no_grad():
-            if self.fused_inference and self._fused_ok(pos, box):
+            if feats is None and self.fused_inference and self._fused_ok(pos, box):
                 return self._forward_fused(pos, vel, box, box_feats)
-            return self._forward_impl(pos, vel, box, box_feats)[:3]
+            return self._forward_impl(pos, vel, box, box_feats, other=feats)[:3]
 
     # ------------------------------------------------------------------
     # Fused inference step, round 3: ONE C call = prepare (integrate + fluid grid, one workgroup) ->
@@ -420,7 +423,7 @@ class ParticleNet(nn.Module):
             self._fused_skip = 16           # a clump denser than the front kernel stages: exact path for a while
         return self._forward_impl(pos, vel, box, box_feats)[:3]
 
-    def _forward_impl(self, pos, vel, box, box_feats, keep=False):
+    def _forward_impl(self, pos, vel, box, box_feats, keep=False, other=None):
         """The exact multi-launch path (CSR neighbour lists sized by one host round trip): training (keep=True saves what the
         backward needs), clouds beyond the fused step's limits, and the redo of a fused step whose row pitch overflowed."""
         lib = _lib.load()
@@ -451,9 +454,16 @@ class ParticleNet(nn.Module):
         c0o, c0f, d0 = self.conv0_obstacle, self.conv0_fluid, self.dense0_fluid
         check(lib.nf_cconv_small(ptr(box_feats), 3, ptr(b_rs), ptr(b_idx), ptr(b_pw), ptr(b_pc), ptr(c0o.kernel.detach()),
                                  ptr(c0o.bias.detach()), n, ptr(a0), 96, 0, None, None, None, 0, st), "conv0_obstacle")
-        check(lib.nf_cconv_small(ptr(fluid_feats), 4, ptr(f_rs), ptr(f_idx), ptr(f_pw), ptr(f_pc), ptr(c0f.kernel.detach()),
-                                 ptr(c0f.bias.detach()), n, ptr(a0), 96, 32, ptr(fluid_feats), ptr(d0.weight.detach()),
-                                 ptr(d0.bias.detach()), 64, st), "conv0_fluid")
+        if other is None:
+            check(lib.nf_cconv_small(ptr(fluid_feats), 4, ptr(f_rs), ptr(f_idx), ptr(f_pw), ptr(f_pc), ptr(c0f.kernel.detach()),
+                                     ptr(c0f.bias.detach()), n, ptr(a0), 96, 32, ptr(fluid_feats), ptr(d0.weight.detach()),
+                                     ptr(d0.bias.detach()), 64, st), "conv0_fluid")
+        else:       # 4 + F input channels: the general layer kernels (transform GEMM + gather) and a plain GEMM for dense0
+            fluid_feats = torch.cat([fluid_feats, other.detach().float().to(fluid_feats.device)], 1).contiguous()
+            zw = torch.zeros(32, fluid_feats.shape[1], dtype=torch.float32, device=pos.device)
+            zb = torch.zeros(32, dtype=torch.float32, device=pos.device)
+            a0[:, 32:64] = cconv_layer(fluid_feats, c0f.kernel, c0f.bias, zw, zb, f_rs, f_idx, f_pw, f_pc, relu=False)
+            a0[:, 64:96] = ops.gemm(fluid_feats, d0.weight.detach().t()) + d0.bias.detach()
         ans = [a0]
         for conv, dense in zip(self.convs, self.denses):
             prev = ans[-1]

@@ -142,14 +142,15 @@ def cconv(feats, inp_pos, out_pos, extent, kernel, bias, nbr_idx, row_splits, d2
 
 
 def particle_net_forward(state, pos, vel, box, box_feats, gravity=None, dt=1 / 50, extent=FILTER_EXTENT,
-                         return_debug=False):
-    """ParticleNet.forward (transmodel.py:151-163) -> (pos'', vel'', num_fluid_neighbors)."""
+                         return_debug=False, feats=None):
+    """ParticleNet.forward (transmodel.py:151-163) -> (pos'', vel'', num_fluid_neighbors).  feats: the optional per-particle
+    features of other_feats_channels > 0, appended to [1, v] (:111-114)."""
     g = state["gravity"] if gravity is None else gravity
     pos_new, vel_new = integrate_pos_vel(pos, vel, g, dt)
     radius = 0.5 * extent
     f_idx, f_rs, f_d2 = radius_search(pos_new, pos_new, radius, True)
     b_idx, b_rs, b_d2 = radius_search(box, pos_new, radius, True)
-    fluid_feats = torch.cat([torch.ones_like(pos_new[:, 0:1]), vel_new], -1)
+    fluid_feats = torch.cat([torch.ones_like(pos_new[:, 0:1]), vel_new] + ([feats] if feats is not None else []), -1)
 
     def conv(name, feats, inp_pos, idx, rs, d2):
         return cconv(feats, inp_pos, pos_new, extent, state[f"{name}.kernel"], state[f"{name}.bias"], idx, rs, d2)
@@ -187,8 +188,8 @@ def conv_shapes(other_feats_channels=0):
     return shapes, dense
 
 
-def deterministic_transition_state(gravity=(0.0, 0.0, -9.81)):
-    convs, denses = conv_shapes()
+def deterministic_transition_state(gravity=(0.0, 0.0, -9.81), other_feats_channels=0):
+    convs, denses = conv_shapes(other_feats_channels)
     st = {"gravity": torch.tensor(gravity, dtype=torch.float32)}
     for l, (name, (ci, co)) in enumerate(convs.items()):
         n = KSIZE ** 3 * ci * co

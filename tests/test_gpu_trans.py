@@ -136,6 +136,56 @@ def test_particle_net_backward_vs_oracle_autograd(dev):
     print("worst relative parameter-gradient error", worst)
 
 
+def test_other_feats_channels(dev):
+    """ParticleNet(other_feats_channels=F).forward(..., feats=...) (models/transmodel.py:24,43,50,111-114: extra per-particle input
+    features next to [1, v]; no reference caller passes them): forward vs the oracle, parameter / velocity / feature gradients vs
+    torch autograd through the oracle; the channel count is checked; the 4-channel model keeps taking the fused step."""
+    from neurofluid_amd.transmodel import ParticleNet
+    from oracle import render_oracle as ro, trans_oracle as to
+    F = 3
+    st = to.deterministic_transition_state(other_feats_channels=F)
+    pn = ParticleNet(gravity=(0, 0, -9.81), other_feats_channels=F)
+    pn.load_state_dict(st, strict=True)
+    pn = pn.to(dev)
+    P = ro.watercube_particles()[::2].contiguous()
+    g = torch.Generator().manual_seed(5)
+    V = torch.randn(P.shape, generator=g) * 0.2
+    X = torch.randn(P.shape[0], F, generator=g)
+    box, bn = to.watercube_box()
+    with torch.no_grad():
+        p, v, n = pn(P.to(dev), V.to(dev), box.to(dev), bn.to(dev), feats=X.to(dev))
+    rp, rv, rn = to.particle_net_forward(st, P, V, box, bn, feats=X)
+    assert torch.equal(n.cpu(), rn)
+    assert float((p.cpu() - rp).norm(dim=1).mean()) < 1e-7 and float((v.cpu() - rv).abs().max()) < 2e-5
+    p0, _, _ = to.particle_net_forward(st, P, V, box, bn, feats=torch.zeros_like(X))
+    assert float((rp - p0).abs().max()) > 1e-6                       # the features matter
+    with pytest.raises(ValueError):
+        pn(P.to(dev), V.to(dev), box.to(dev), bn.to(dev))
+    with pytest.raises(ValueError):
+        make_pn(dev)[0](P.to(dev), V.to(dev), box.to(dev), bn.to(dev), feats=X.to(dev))
+    # gradients
+    tgt = P + 0.01 * torch.randn(P.shape, generator=g)
+    Vd, Xd = V.to(dev).requires_grad_(True), X.to(dev).requires_grad_(True)
+    p, v, _ = pn(P.to(dev), Vd, box.to(dev), bn.to(dev), feats=Xd)
+    loss = ((p - tgt.to(dev)) ** 2).sum() + 0.01 * (v ** 2).sum()
+    loss.backward()
+    sg = {k: (t.clone().requires_grad_(True) if (k.endswith("kernel") or k.endswith("bias") or k.endswith("weight")) else t)
+          for k, t in st.items()}
+    Vo, Xo = V.clone().requires_grad_(True), X.clone().requires_grad_(True)
+    rp, rv, _ = to.particle_net_forward(sg, P, Vo, box, bn, feats=Xo)
+    lo = ((rp - tgt) ** 2).sum() + 0.01 * (rv ** 2).sum()
+    lo.backward()
+    assert abs(float(loss.detach()) - float(lo.detach())) <= 1e-4 * abs(float(lo.detach()))
+    for name, prm in pn.named_parameters():
+        ref = sg[name].grad
+        assert ref is not None and float(ref.norm()) > 0, name
+        rel = float((prm.grad.cpu() - ref).norm() / ref.norm())
+        assert rel < 2e-3, (name, rel)
+    for got, ref, nm in ((Vd.grad, Vo.grad, "vel"), (Xd.grad, Xo.grad, "feats")):
+        rel = float((got.cpu() - ref).norm() / ref.norm())
+        assert rel < 2e-3, (nm, rel)
+
+
 def test_fluid_errors_vs_kdtree(dev):
     """FluidErrors on the device (nf_nearest + device reductions) against the reference's host recipe
     (utils/point_eval.py:10-58: numpy statistics + scipy cKDTree), restated here as the checker."""

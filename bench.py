@@ -486,6 +486,49 @@ def main():
                          "ms_per_step_median": dtc * 1e3, "rays_per_sec": n_rays / dtc,
                          "ms_per_step_by_frame_of_cycle": [round(sum(per_step[k::8]) / len(per_step[k::8]) * 1e3, 3) for k in range(8)]}
 
+    # ---- extra: BASELINE configs[2] (train_e2e.py step: transition forward -> render of the predicted particles from the config's
+    # views -> rgb loss -> backward through both models -> two Adams) through the E2ETrainer itself on a synthetic on-disk dataset
+    # in the reference's format (tools/e2e_perf.py is the dev version with a phase breakdown).  Single rank only.
+    e2e_extra = None
+    if args.workload == "render" and not args.no_extras and image == 400 and world == 1:
+        import shutil, tempfile
+        import configs as nf_configs
+        from neurofluid_amd.datasets import write_synthetic_dataset
+        from neurofluid_amd.trainers import E2ETrainer
+        root = tempfile.mkdtemp(prefix="nf_bench_e2e_")
+        try:
+            n_frames = 12
+            write_synthetic_dataset(os.path.join(root, "data", "watercube"), n_frames=n_frames + 6, img=400, n_side=17)
+            cfg = nf_configs.end2end_training_config(["--expdir", os.path.join(root, "exps"), "--expname", "bench", "--dataset", "watercube"])
+            dsc = nf_configs.dataset_config()["watercube"]
+            for split in ("train", "test"):
+                dsc[split].path = os.path.join(root, "data", "watercube")
+                dsc[split].start_index, dsc[split].end_index = 0, n_frames + 6
+            cfg.update(dsc)
+            for node in (cfg.TRAIN, cfg.TEST):
+                node.imgW = node.imgH = 400
+            cfg.TRAIN.save_interval = 10 ** 9
+            cfg.TRAIN.epochs = 10
+            tr = E2ETrainer(cfg)
+            tr.train(max_steps=len(tr.dataset))          # one pass over every frame (decoded frames are cached), kernels warm
+            torch.cuda.synchronize()
+            blocks = []
+            for _ in range(3):
+                tr.start_step = 0
+                t5 = time.perf_counter()
+                tr.train(max_steps=n_frames)
+                torch.cuda.synchronize()
+                blocks.append((time.perf_counter() - t5) / n_frames)
+            dte = sorted(blocks)[1]
+            nv, rc = len(tr.train_view_names), int(cfg.RENDERER.ray.ray_chunk)
+            e2e_extra = {"workload": "train_e2e.py step (E2ETrainer): transition forward + render of %d view(s) x %d rays of the predicted "
+                                     "particles + backward through both models + optimiser steps, 4 913 particles" % (nv, rc),
+                         "ms_per_step": dte * 1e3, "rays_per_sec": nv * rc / dte, "blocks_ms": [round(b * 1e3, 3) for b in blocks],
+                         "note": "host-bound: ~170 small launches per step (tools/e2e_perf.py, tools/e2e_cprof.py)"}
+            del tr
+        finally:
+            shutil.rmtree(root, ignore_errors=True)
+
     # ---- extra: BASELINE configs[1] (train_renderer.py step: 4 views x 1024 rays, fwd + bwd + Adam) on this rank
     if args.workload == "render" and not args.no_extras and image == 400:
         from neurofluid_amd.train_step import make_train_step
@@ -537,7 +580,7 @@ def main():
                "roofline": roofline, "roofline_transition": trans_roofline, "load_balance": balance,
                "max_over_mean": balance["max_over_mean"] if balance else None,
                "fp16_mfma_path": fp16_extra, "split_precision_path": split_extra,
-               "train_step": train_extra, "coupled_moving_cloud": coupled_extra}
+               "train_step": train_extra, "train_e2e_step": e2e_extra, "coupled_moving_cloud": coupled_extra}
         if single_dev and world > 1:
             res["single_device_emulation"] = ("NF_BENCH_SINGLE_DEVICE=1: %d ranks time-share ONE GPU over gloo; control flow and "
                                               "load-balance accounting are real, `value` is not a scaling measurement" % world)

@@ -164,9 +164,9 @@ int nf_nerf_mlp_fwd_l(const float* packed, const float* wstream, int cx, int cd,
 
 /* A6 for small launches (models/nerf.py:83-124, the forward of a training step; nf_mlp_n.hip): one 32-row tile per WORKGROUP, a layer's 8 output blocks split over its 4 waves,
  * activations exchanged through an LDS image — a quarter of nf_nerf_mlp_fwd's per-tile latency (it keeps a tile in one
- * wave for 0.35 ms: a launch costs ceil(tiles / 1024) such rounds however empty the last one is).  Same packed blob, same
- * operand X, same outputs (rgbsigma, and acts when not NULL) BIT FOR BIT. */
-int nf_nerf_mlp_fwd_n(const float* packed, int cx, int cd, const float* X, const int32_t* n_rows, int max_rows,
+ * wave for 0.35 ms: a launch costs ceil(tiles / 1024) such rounds however empty the last one is).  packed_n = nf_nerf_pack_n
+ * of the standard blob; same operand X, same outputs (rgbsigma, and acts when not NULL) BIT FOR BIT. */
+int nf_nerf_mlp_fwd_n(const float* packed_n, int cx, int cd, const float* X, const int32_t* n_rows, int max_rows,
                       const int32_t* row_sample, float* rgbsigma, float* acts /*or NULL*/, nf_stream_t stream);
 
 /* fp16-MFMA forward of A6 (models/nerf.py:83-124), version 3 (nf_mlp_h2.hip): two 32-row tiles per wave, out-block-major, packed fp16 activations
@@ -217,7 +217,13 @@ int nf_nerf_pack_bwd(const nf_nerf_params_t* params /*[host]*/, int cx, int cd, 
 int nf_nerf_mlp_bwd(const float* packed, const float* packed_t, int cx, int cd, const float* acts,
                     const int32_t* n_rows, int max_rows, const int32_t* row_sample, const float* rgbsigma,
                     const float* d_rgbsigma, float* dpre, nf_stream_t stream);
-/* The same data gradient, bit for bit, with a 32-row tile per WORKGROUP instead of per wave (the training steps' launches of a
+/* Weight blobs of the tile-per-workgroup kernels (nf_nerf_mlp_fwd_n / nf_nerf_mlp_bwd_n): the standard blobs of nf_nerf_pack /
+ * nf_nerf_pack_bwd re-arranged (same size, out of place) so that one 16-byte load per lane holds a wave's operands of two
+ * K-steps.  Re-run after every nf_nerf_pack / nf_nerf_pack_bwd. */
+int nf_nerf_pack_n(const float* packed, int cx, int cd, float* packed_n, nf_stream_t stream);
+int nf_nerf_pack_bwd_n(const float* packed_t, float* packed_tn, nf_stream_t stream);
+/* The same data gradient, bit for bit, with a 32-row tile per WORKGROUP instead of per wave; packed = nf_nerf_pack (the heads),
+ * packed_t = nf_nerf_pack_bwd_n (the training steps' launches of a
  * few hundred to a few thousand tiles: a quarter of the per-tile latency, no whole round lost to a partly filled last one). */
 int nf_nerf_mlp_bwd_n(const float* packed, const float* packed_t, int cx, int cd, const float* acts,
                       const int32_t* n_rows, int max_rows, const int32_t* row_sample, const float* rgbsigma,

@@ -79,6 +79,8 @@ PROTOTYPES = {
     "nf_nerf_pack_bwd": (c_int, [ctypes.POINTER(NerfParams), c_int, c_int, c_void_p, c_void_p]),
     "nf_nerf_mlp_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                 c_void_p, c_void_p]),
+    "nf_nerf_pack_n": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "nf_nerf_pack_bwd_n": (c_int, [c_void_p, c_void_p, c_void_p]),
     "nf_nerf_mlp_bwd_n": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_void_p]),
     "nf_embed_fwd": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),

@@ -26,7 +26,7 @@ def _nerf_params(net):
     return ps
 
 
-def _pack_bwd(nerf, cx, cd, dev):
+def _pack_bwd(nerf, cx, cd, dev, n_layout=True):
     lib = _lib.load()
     layers = nerf.linear_layers()
     P = _lib.NerfParams()
@@ -37,7 +37,11 @@ def _pack_bwd(nerf, cx, cd, dev):
         P.w[i], P.b[i] = w.data_ptr(), b.data_ptr()
     out = torch.empty(lib.nf_nerf_packed_bwd_floats(), dtype=torch.float32, device=dev)
     check(lib.nf_nerf_pack_bwd(ctypes.byref(P), cx, cd, ptr(out), _lib.stream()), "nf_nerf_pack_bwd")
-    return out
+    if not n_layout:
+        return out
+    out_n = torch.empty_like(out)           # nf_nerf_mlp_bwd_n's arrangement: two K-steps of a wave's blocks per 16-B load
+    check(lib.nf_nerf_pack_bwd_n(ptr(out), ptr(out_n), _lib.stream()), "nf_nerf_pack_bwd_n")
+    return out_n
 
 
 def _pass_backward(net, nerf, pb, rays_c, z, z_table, g_rgb, white_bg, particles=None, ro_c=None, dparticles=None):

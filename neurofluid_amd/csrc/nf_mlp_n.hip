@@ -10,8 +10,13 @@
 // operands back, one ds_read_b32 per K-step (lane-linear, conflict-free both ways).
 //
 // Same arithmetic as k_mlp_fwd, bit for bit: same MFMA, same K order (bias step first, X part, hidden part), the sigma / rgb
-// heads summed by one wave in the same order from the LDS image.  Same packed blob (nf_nerf_pack): a wave reads the 16-B
-// operand of its half of the blocks and uses two of the four lanes' values.
+// heads summed by one wave in the same order from the LDS image.
+//
+// Weight blob (round 3): nf_nerf_pack_n / nf_nerf_pack_bwd_n re-arrange the standard blobs (same size, same part offsets) so that
+// ONE 16-B load per lane holds a wave's operands of TWO K-steps (its two blocks x two steps; the one-block view branch: four
+// steps): [pair][wave][lane][step-in-pair * 2 + block-in-wave].  With the standard layout a wave used 8 of the 16 bytes of a
+// K-step's quad, i.e. one vector-memory instruction (and its 64-bit address arithmetic) per TWO MFMAs — the single wave of a
+// SIMD spends about as long issuing that as one MFMA runs: a workgroup alone on its CU kept the matrix pipe 53 % busy.
 #include "nf_mlp_layout.h"
 #include <math.h>
 
@@ -39,78 +44,87 @@ __device__ __forceinline__ void n_bias2(const NCtx& c, const f32x4* __restrict__
 // skip layer ~30 us later: 32 KB per tile that the L2 still holds; no LDS stash, so two workgroups fit a CU and each SIMD
 // has a second tile's wave to issue from while the first one waits at a layer barrier).
 template <int nq>
-__device__ __forceinline__ void n_xpart2(const NCtx& c, const f32x4* __restrict__ p /* part base */, const f32x4* __restrict__ xt /* + lane */,
+__device__ __forceinline__ void n_xpart2(const NCtx& c, const f32x4* __restrict__ p /* part base, N layout */, const f32x4* __restrict__ xt /* + lane */,
                                          f32x16 (&acc)[2])
 {
-    // the wave's two blocks are components c0, c0 + 1 of the 16-B operand: an 8-B load at that offset, no select
-    const f32x2* wp = (const f32x2*)((const float*)(p + c.g * 64 + c.lane) + c.c0);       // K-step stride: 128 f32x4 = 256 f32x2
+    const f32x4* wp = p + c.w * 64 + c.lane;          // pair stride: 256 f32x4; a group of 4 K-steps = 2 pairs
     // a group is only 4 K-steps x 2 MFMAs = 512 cycles here: X (HBM the first time, L2 the second) is requested XD groups
     // ahead, the weights (L2) two groups ahead
     constexpr int XD = 6;
     f32x4 xr[XD];
-    f32x2 wr[2][4];
+    f32x4 wr[2][2];
 #pragma unroll
     for (int q = 0; q < XD; ++q) xr[q] = q < nq ? xt[q * 64] : xt[0];
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) wr[q][i] = wp[(q * 4 + i) * 256];
+        for (int i = 0; i < 2; ++i) wr[q][i] = wp[(q * 2 + i) * 256];
 #pragma unroll
     for (int q = 0; q < nq; ++q) {
         const f32x4 xv = xr[0];
-        f32x2 w[4];
+        f32x4 w[2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) w[i] = wr[0][i];
+        for (int i = 0; i < 2; ++i) w[i] = wr[0][i];
 #pragma unroll
         for (int k = 0; k + 1 < XD; ++k) xr[k] = xr[k + 1];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) wr[0][i] = wr[1][i];
+        for (int i = 0; i < 2; ++i) wr[0][i] = wr[1][i];
         if (q + XD < nq) xr[XD - 1] = xt[(q + XD) * 64];
         if (q + 2 < nq) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) wr[1][i] = wp[((q + 2) * 4 + i) * 256];
+            for (int i = 0; i < 2; ++i) wr[1][i] = wp[((q + 2) * 2 + i) * 256];
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            acc[0] = MFMA32(w[i][0], xv[i], acc[0]);
-            acc[1] = MFMA32(w[i][1], xv[i], acc[1]);
+        for (int i = 0; i < 2; ++i) {
+            acc[0] = MFMA32(w[i][0], xv[2 * i], acc[0]);
+            acc[1] = MFMA32(w[i][1], xv[2 * i], acc[1]);
+            acc[0] = MFMA32(w[i][2], xv[2 * i + 1], acc[0]);
+            acc[1] = MFMA32(w[i][3], xv[2 * i + 1], acc[1]);
         }
     }
 }
 
 // hidden part: acc += W * act, act read from the LDS image (already activated); 128 K-steps = 8 source blocks x 16
 template <int NS = 128>
-__device__ __forceinline__ void n_hpart2(const NCtx& c, const f32x4* __restrict__ p, const float* __restrict__ act, f32x16 (&acc)[2])
+__device__ __forceinline__ void n_hpart2(const NCtx& c, const f32x4* __restrict__ p /* part base, N layout */, const float* __restrict__ act,
+                                         f32x16 (&acc)[2])
 {
-    constexpr int D = 8;
-    const f32x2* wp = (const f32x2*)((const float*)(p + c.g * 64 + c.lane) + c.c0);
+    constexpr int NP = NS / 2, D = 4;                 // K-step pairs; read-ahead in pairs
+    const f32x4* wp = p + c.w * 64 + c.lane;
     const float* ap = act + (4 * c.h) * 32 + c.j;           // feature frag_feature(b, r, h) = 32 b + (r & 3) + 8 (r >> 2) + 4 h
-    f32x2 ring[D + 1];
-    float bv[D + 1];
+    f32x4 ring[D + 1];
+    float b0[D + 1], b1[D + 1];
+#define NH_F(S) ((32 * ((S) >> 4) + ((S) & 3) + 8 * (((S) & 15) >> 2)) * 32)
 #pragma unroll
     for (int s = 0; s < D; ++s) {
         ring[s] = wp[s * 256];
-        bv[s] = ap[(32 * (s >> 4) + (s & 3) + 8 * ((s & 15) >> 2)) * 32];
+        b0[s] = ap[NH_F(2 * s)];
+        b1[s] = ap[NH_F(2 * s + 1)];
     }
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        if (s + D < NS) {
+    for (int s = 0; s < NP; ++s) {
+        if (s + D < NP) {
             const int t = s + D;
             ring[t % (D + 1)] = wp[t * 256];
-            bv[t % (D + 1)] = ap[(32 * (t >> 4) + (t & 3) + 8 * ((t & 15) >> 2)) * 32];
+            b0[t % (D + 1)] = ap[NH_F(2 * t)];
+            b1[t % (D + 1)] = ap[NH_F(2 * t + 1)];
         }
-        const f32x2 wv = ring[s % (D + 1)];
-        const float b = bv[s % (D + 1)];
-        acc[0] = MFMA32(wv[0], b, acc[0]);
-        acc[1] = MFMA32(wv[1], b, acc[1]);
-        if (s + D < NS) {      // one VMEM and one LDS read per K-step, each in an MFMA shadow
+        const f32x4 wv = ring[s % (D + 1)];
+        const float x0 = b0[s % (D + 1)], x1 = b1[s % (D + 1)];
+        acc[0] = MFMA32(wv[0], x0, acc[0]);
+        acc[1] = MFMA32(wv[1], x0, acc[1]);
+        acc[0] = MFMA32(wv[2], x1, acc[0]);
+        acc[1] = MFMA32(wv[3], x1, acc[1]);
+        if (s + D < NP) {      // one VMEM and the LDS reads of a pair, each in an MFMA shadow
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+#undef NH_F
 }
 
 // the wave's two blocks -> LDS image (RELU or raw) and, when training, the saved-activation row (row-major, as k_mlp_fwd)
@@ -203,17 +217,24 @@ __global__ void __launch_bounds__(256) k_mlp_fwd_n(NfMlpLayout L, const float* _
             const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             const f32x4* pb = P4 + (L.off_bstep_dir >> 2) + c.lane;
             hd = MFMA32(((const float*)pb)[c.w], 1.f, z);
-            const f32x4* px = P4 + (L.off_dir_x >> 2) + c.lane;         // [s][64][4]
+            const f32x4* px = P4 + (L.off_dir_x >> 2) + c.w * 64 + c.lane;         // N layout: [group of 4 steps][wave][64] x 16 B
 #pragma unroll
             for (int q = 0; q < QD; ++q) {
+                const f32x4 wv = px[q * 256];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) hd = MFMA32(((const float*)(px + (q * 4 + i) * 64))[c.w], xdir[q][i], hd);
+                for (int i = 0; i < 4; ++i) hd = MFMA32(wv[i], xdir[q][i], hd);
             }
-            const f32x4* ph = P4 + (L.off_dir_h >> 2) + c.lane;         // [128][64][4]
+            const f32x4* ph = P4 + (L.off_dir_h >> 2) + c.w * 64 + c.lane;
             const float* ap = cur + (4 * c.h) * 32 + c.j;
-#pragma unroll 8
-            for (int s = 0; s < 128; ++s)
-                hd = MFMA32(((const float*)(ph + s * 64))[c.w], ap[(32 * (s >> 4) + (s & 3) + 8 * ((s & 15) >> 2)) * 32], hd);
+#pragma unroll 4
+            for (int q = 0; q < 32; ++q) {
+                const f32x4 wv = ph[q * 256];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int s = 4 * q + i;
+                    hd = MFMA32(wv[i], ap[(32 * (s >> 4) + (s & 3) + 8 * ((s & 15) >> 2)) * 32], hd);
+                }
+            }
         }
         {
             float v[16];
@@ -254,6 +275,48 @@ __global__ void __launch_bounds__(256) k_mlp_fwd_n(NfMlpLayout L, const float* _
         }
         __syncthreads();        // the images are rewritten by the next tile
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// N layout of a weight blob (see the header): regions of 8-block K-steps ([step][2][64][4], 512 floats) become
+// [pair][wave][lane][2 sp + i] (block = 2 wave + i, step = 2 pair + sp); regions of 4-block K-steps ([step][64][4], 256 floats)
+// become [group of 4][wave = block][lane][step in group]; everything else is copied.  Parts hold an even (resp. multiple-of-4)
+// number of steps and follow each other without gaps, so one formula per region covers them all and part offsets stay valid.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_mlp_pack_n(const float* __restrict__ in, float* __restrict__ out, int total, int end8, int end4)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    int o = idx;
+    if (idx < end8) {
+        const int S = idx >> 9, wi = idx & 511, g = wi >> 8, lane = (wi >> 2) & 63, e = wi & 3;
+        const int blk = 4 * g + e, w = blk >> 1, i = blk & 1;
+        o = (((S >> 1) * 4 + w) * 64 + lane) * 4 + 2 * (S & 1) + i;
+    } else if (idx < end4) {
+        const int r = idx - end8, T = r >> 8, wi = r & 255, lane = wi >> 2, w = wi & 3;
+        o = end8 + (((T >> 2) * 4 + w) * 64 + lane) * 4 + (T & 3);
+    }
+    out[o] = in[idx];
+}
+
+extern "C" int nf_nerf_pack_n(const float* packed, int cx, int cd, float* packed_n, nf_stream_t stream)
+{
+    NF_CHECK_ARG(packed && packed_n && packed != packed_n, "null pointer / in-place");
+    NfMlpLayout L = mlp_layout(cx, cd);
+    NF_CHECK_ARG((L.qx * 4) % 2 == 0 && (L.qd * 4) % 4 == 0, "odd part length");
+    hipLaunchKernelGGL(k_mlp_pack_n, dim3((L.total + 255) / 256), dim3(256), 0, (hipStream_t)stream, packed, packed_n, L.total, L.off_dir_h,
+                       L.off_wsig);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+extern "C" int nf_nerf_pack_bwd_n(const float* packed_t, float* packed_tn, nf_stream_t stream)
+{
+    NF_CHECK_ARG(packed_t && packed_tn && packed_t != packed_tn, "null pointer / in-place");
+    NfMlpLayoutT T = mlp_layout_t();
+    hipLaunchKernelGGL(k_mlp_pack_n, dim3((T.total + 255) / 256), dim3(256), 0, (hipStream_t)stream, packed_t, packed_tn, T.total, T.total, T.total);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
 }
 
 // ================================================================================================

@@ -254,6 +254,14 @@ def pack_nerf(weights, biases, cx, cd, out=None):
     return out
 
 
+def pack_nerf_n(packed, cx, cd):
+    """The tile-per-workgroup kernels' arrangement of a packed blob (nf_nerf_pack_n): nf_nerf_mlp_fwd_n's `packed_n`."""
+    lib = _lib.load()
+    out = torch.empty_like(packed)
+    check(lib.nf_nerf_pack_n(ptr(packed), cx, cd, ptr(out), _lib.stream()), "nf_nerf_pack_n")
+    return out
+
+
 def pack_nerf_stream(packed, cx, cd):
     """Weight stream of the LDS-ring fp32 kernel (nf_nerf_mlp_fwd_l) from the packed blob, or None when the feature
     row is not the default 198 + 54 one (the direct-from-L2 kernel nf_nerf_mlp_fwd then serves the pass)."""
@@ -488,7 +496,10 @@ def render_pass(grid, particles, rays, z, z_table, S, radius, K, enc_flags, use_
             # (nf_mlp_n.hip) — a third of the per-tile latency of the tile-per-wave kernel, bit-identical outputs.  (The
             # inference passes stay on the ring kernel at every size: its sums differ in the place of the bias, and results
             # must not depend on how a frame is cut into calls.)
-            check(lib.nf_nerf_mlp_fwd_n(ptr(packed), cx, cd, X_, ptr(nrows_t), mx, rs_, ptr(b.rgbsigma), ptr(b.acts), stream_),
+            if getattr(b, "packed_n", None) is None:        # the tile-per-workgroup kernels' own arrangement of the blob
+                b.packed_n = torch.empty_like(packed)
+                check(lib.nf_nerf_pack_n(ptr(packed), cx, cd, ptr(b.packed_n), stream_), "nf_nerf_pack_n")
+            check(lib.nf_nerf_mlp_fwd_n(ptr(b.packed_n), cx, cd, X_, ptr(nrows_t), mx, rs_, ptr(b.rgbsigma), ptr(b.acts), stream_),
                   "nf_nerf_mlp_fwd_n")
         else:
             check(lib.nf_nerf_mlp_fwd(ptr(packed), cx, cd, X_, ptr(nrows_t), mx, rs_, ptr(b.rgbsigma), ptr(b.acts), stream_),

@@ -170,13 +170,13 @@ def test_backward_kernels_exact_for_their_operands(dev):
         out = torch.zeros(n, 4, device=dev)
         acts = torch.empty(n * 2432, device=dev)
         check(lib.nf_nerf_mlp_fwd(ptr(packed), cx, cd, ptr(X), ptr(n_rows), n, ptr(row_sample), ptr(out), ptr(acts), _lib.stream()))
-        packed_t = _pack_bwd(net, cx, cd, dev)
+        packed_t, packed_tn = _pack_bwd(net, cx, cd, dev, n_layout=False), _pack_bwd(net, cx, cd, dev)
         dpre = torch.empty(n, DPRE, device=dev)
         check(lib.nf_nerf_mlp_bwd(ptr(packed), ptr(packed_t), cx, cd, ptr(acts), ptr(n_rows), n, ptr(row_sample), ptr(out), ptr(gout),
                                   ptr(dpre), _lib.stream()))
         # the tile-per-workgroup kernel of the training steps: the same sums in the same order, bit for bit (also on a ragged tile)
         dpre_n = torch.full((n, DPRE), float("nan"), device=dev)
-        check(lib.nf_nerf_mlp_bwd_n(ptr(packed), ptr(packed_t), cx, cd, ptr(acts), ptr(n_rows), n, ptr(row_sample), ptr(out), ptr(gout),
+        check(lib.nf_nerf_mlp_bwd_n(ptr(packed), ptr(packed_tn), cx, cd, ptr(acts), ptr(n_rows), n, ptr(row_sample), ptr(out), ptr(gout),
                                     ptr(dpre_n), _lib.stream()))
         assert torch.equal(dpre_n, dpre)
         blob = torch.empty(lib.nf_nerf_wgrad_floats(cx, cd), device=dev)

@@ -1208,6 +1208,7 @@ def test_mlp_tile_per_workgroup_bit_equal(dev):
     W = [st[f"nerf_fine.{k}.weight"].to(dev) for k in ops.NERF_LAYER_NAMES]
     B = [st[f"nerf_fine.{k}.bias"].to(dev) for k in ops.NERF_LAYER_NAMES]
     packed = ops.pack_nerf(W, B, 198, 54)
+    packed_n = ops.pack_nerf_n(packed, 198, 54)          # the workgroup kernel's own arrangement of the same blob
     g = torch.Generator().manual_seed(21)
     for n, live in [(1, 1), (31, 31), (33, 33), (4096, 4096), (5000, 4321), (130, 97)]:
         x = (torch.rand(n, 252, generator=g) * 2 - 1).to(dev)
@@ -1215,11 +1216,11 @@ def test_mlp_tile_per_workgroup_bit_equal(dev):
         n_rows = torch.tensor([live], dtype=torch.int32, device=dev)
         row_sample = torch.randperm(n, generator=g).to(torch.int32).to(dev)
         outs = []
-        for fn in (lib.nf_nerf_mlp_fwd, lib.nf_nerf_mlp_fwd_n):
+        for fn, blob in ((lib.nf_nerf_mlp_fwd, packed), (lib.nf_nerf_mlp_fwd_n, packed_n)):
             for save in (False, True):
                 out = torch.full((n, 4), -7.0, device=dev)
                 acts = torch.full(((n + 31) // 32 * 32 * 2432,), -7.0, device=dev) if save else None
-                _lib.check(fn(packed.data_ptr(), 198, 54, X.data_ptr(), n_rows.data_ptr(), n, row_sample.data_ptr(), out.data_ptr(),
+                _lib.check(fn(blob.data_ptr(), 198, 54, X.data_ptr(), n_rows.data_ptr(), n, row_sample.data_ptr(), out.data_ptr(),
                               acts.data_ptr() if save else None, _lib.stream()))
                 outs.append((out, acts[:live * 2432] if save else None))
         assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[1][0], outs[3][0]) and torch.equal(outs[0][0], outs[1][0])

@@ -13,6 +13,7 @@ names = ops.NERF_LAYER_NAMES
 W = [st[f"nerf_coarse.{k}.weight"].to(dev) for k in names]
 B = [st[f"nerf_coarse.{k}.bias"].to(dev) for k in names]
 packed = ops.pack_nerf(W, B, 198, 54)
+packed_n = ops.pack_nerf_n(packed, 198, 54)
 lib = _lib.load()
 rows = [int(a) for a in sys.argv[1:]] or [202 * 32, 1024 * 32, 2048 * 32, 2250 * 32]
 for n in rows:
@@ -30,7 +31,7 @@ for n in rows:
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) / it * 1e3
     a = t(lambda: check(lib.nf_nerf_mlp_fwd(ptr(packed), 198, 54, ptr(X), ptr(n_rows), n, ptr(row_sample), ptr(out), ptr(acts), _lib.stream())))
-    b = t(lambda: check(lib.nf_nerf_mlp_fwd_n(ptr(packed), 198, 54, ptr(X), ptr(n_rows), n, ptr(row_sample), ptr(out), ptr(acts), _lib.stream())))
+    b = t(lambda: check(lib.nf_nerf_mlp_fwd_n(ptr(packed_n), 198, 54, ptr(X), ptr(n_rows), n, ptr(row_sample), ptr(out), ptr(acts), _lib.stream())))
     print("rows %6d (%4d tiles): fwd tile-per-wave %7.1f us (%5.1f TFLOP/s)   tile-per-workgroup %7.1f us (%5.1f TFLOP/s)" %
           (n, (n + 31) // 32, a, n * 1.331968 / a, b, n * 1.331968 / b))
     packed_t = torch.empty(lib.nf_nerf_packed_bwd_floats(), device=dev)
@@ -38,10 +39,12 @@ for n in rows:
     for i in range(12):
         P.w[i], P.b[i] = W[i].data_ptr(), B[i].data_ptr()
     check(lib.nf_nerf_pack_bwd(ctypes.byref(P), 198, 54, ptr(packed_t), _lib.stream()))
+    packed_tn = torch.empty_like(packed_t)
+    check(lib.nf_nerf_pack_bwd_n(ptr(packed_t), ptr(packed_tn), _lib.stream()))
     g = torch.randn(n, 4, device=dev)
     d1 = torch.zeros(ops._round_rows(n), 2436, device=dev); d2 = torch.zeros_like(d1)
-    args = lambda d: (ptr(packed), ptr(packed_t), 198, 54, ptr(acts), ptr(n_rows), n, ptr(row_sample), ptr(out), ptr(g), ptr(d), _lib.stream())
+    args = lambda d, pt=None: (ptr(packed), ptr(pt if pt is not None else packed_t), 198, 54, ptr(acts), ptr(n_rows), n, ptr(row_sample), ptr(out), ptr(g), ptr(d), _lib.stream())
     a = t(lambda: check(lib.nf_nerf_mlp_bwd(*args(d1))))
-    b = t(lambda: check(lib.nf_nerf_mlp_bwd_n(*args(d2))))
+    b = t(lambda: check(lib.nf_nerf_mlp_bwd_n(*args(d2, packed_tn))))
     print("             bwd tile-per-wave %7.1f us (%5.1f TFLOP/s)   tile-per-workgroup %7.1f us (%5.1f TFLOP/s)   bit-equal: %s" %
           (a, n * 1.331968 / a, b, n * 1.331968 / b, bool(torch.equal(d1[:n], d2[:n]))))

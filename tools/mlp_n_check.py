@@ -13,6 +13,7 @@ names = ops.NERF_LAYER_NAMES
 W = [st[f"nerf_fine.{k}.weight"].to(dev) for k in names]
 B = [st[f"nerf_fine.{k}.bias"].to(dev) for k in names]
 packed = ops.pack_nerf(W, B, 198, 54)
+packed_n = ops.pack_nerf_n(packed, 198, 54)
 lib = _lib.load()
 for n in [int(a) for a in sys.argv[1:]] or [5000, 15000, 20000, 67000, 200000]:
     g = torch.Generator().manual_seed(n)
@@ -21,7 +22,7 @@ for n in [int(a) for a in sys.argv[1:]] or [5000, 15000, 20000, 67000, 200000]:
     n_rows = torch.tensor([n], dtype=torch.int32, device=dev)
     row_sample = torch.randperm(n, generator=g).to(torch.int32).to(dev)
     res = {}
-    for name, fn in (("wave", lib.nf_nerf_mlp_fwd), ("wg", lib.nf_nerf_mlp_fwd_n)):
+    for name, fn, blob in (("wave", lib.nf_nerf_mlp_fwd, packed), ("wg", lib.nf_nerf_mlp_fwd_n, packed_n)):
         for save in (False, True):
             out = torch.full((n, 4), float("nan"), device=dev)
             acts = torch.full(((n + 31) // 32 * 32 * 2432,), float("nan"), device=dev) if save else None
@@ -29,7 +30,7 @@ for n in [int(a) for a in sys.argv[1:]] or [5000, 15000, 20000, 67000, 200000]:
             for it in range(3):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                check(fn(ptr(packed), 198, 54, ptr(X), ptr(n_rows), n, ptr(row_sample), ptr(out), ptr(acts), _lib.stream()))
+                check(fn(ptr(blob), 198, 54, ptr(X), ptr(n_rows), n, ptr(row_sample), ptr(out), ptr(acts), _lib.stream()))
                 e1.record(); torch.cuda.synchronize()
                 ms.append(e0.elapsed_time(e1))
             res[(name, save)] = (out, acts[:n * 2432] if save else None, min(ms))

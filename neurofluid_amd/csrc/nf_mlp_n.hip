@@ -26,6 +26,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 #define NN_ACT (256 * 32)          // floats of one activation image
+#ifndef NH_DEPTH
+#define NH_DEPTH 4               // read-ahead of the hidden parts' K loops, in K-step pairs
+#endif
 
 struct NCtx {
     int lane, h, j, w, g, c0;      // wave w owns blocks 2w, 2w + 1 = half g = w >> 1, components c0, c0 + 1 of its 16-B operands
@@ -89,7 +92,7 @@ template <int NS = 128>
 __device__ __forceinline__ void n_hpart2(const NCtx& c, const f32x4* __restrict__ p /* part base, N layout */, const float* __restrict__ act,
                                          f32x16 (&acc)[2])
 {
-    constexpr int NP = NS / 2, D = 4;                 // K-step pairs; read-ahead in pairs
+    constexpr int NP = NS / 2, D = NH_DEPTH;          // K-step pairs; read-ahead in pairs
     const f32x4* wp = p + c.w * 64 + c.lane;
     const float* ap = act + (4 * c.h) * 32 + c.j;           // feature frag_feature(b, r, h) = 32 b + (r & 3) + 8 (r >> 2) + 4 h
     f32x4 ring[D + 1];

@@ -186,6 +186,43 @@ def test_other_feats_channels(dev):
         assert rel < 2e-3, (nm, rel)
 
 
+def test_step_properties_full_size(dev):
+    """Size-independent properties of the transition step on the whole 4 913-particle cloud (no oracle involved): the fused step is
+    deterministic (two models, 20 steps each: bit-equal); a permutation of the particle order permutes the outputs (neighbour
+    counts exactly, positions to the summation order); a translation of particles AND container translates the result (the cell
+    grid, the search and the ball-to-cube map see relative positions only), neighbour counts unchanged except for pairs within
+    rounding of the radius."""
+    from oracle import render_oracle as ro, trans_oracle as to
+    P0 = ro.watercube_particles().to(dev)
+    box, bn = [t.to(dev) for t in to.watercube_box()]
+    V0 = 0.1 * torch.randn(P0.shape, generator=torch.Generator().manual_seed(11)).to(dev)
+
+    def roll(pn, P, V, bx, steps):
+        outs = []
+        with torch.no_grad():
+            for _ in range(steps):
+                P, V, n = pn(P, V, bx, bn)
+                outs.append((P, V, n))
+        return outs
+
+    a, b = roll(make_pn(dev)[0], P0, V0, box, 20), roll(make_pn(dev)[0], P0, V0, box, 20)
+    for (p1, v1, n1), (p2, v2, n2) in zip(a, b):
+        assert torch.equal(p1, p2) and torch.equal(v1, v2) and torch.equal(n1, n2)
+    assert float(a[-1][2].max()) > 20                                   # a dense fluid, not an empty search
+    # permutation of the particles
+    perm = torch.randperm(P0.shape[0], generator=torch.Generator().manual_seed(12)).to(dev)
+    pp = roll(make_pn(dev)[0], P0[perm].contiguous(), V0[perm].contiguous(), box, 3)
+    for (p1, v1, n1), (p2, v2, n2) in zip(a[:3], pp):
+        assert torch.equal(n1[perm], n2)
+        assert float((p1[perm] - p2).abs().max()) < 2e-6 and float((v1[perm] - v2).abs().max()) < 1e-4
+    # translation of the scene
+    t = torch.tensor([0.375, -0.25, 0.125], device=dev)
+    tt = roll(make_pn(dev)[0], P0 + t, V0, box + t, 3)
+    for k, ((p1, v1, n1), (p2, v2, n2)) in enumerate(zip(a[:3], tt)):
+        assert float((n1 != n2).float().mean()) < 2e-3, k             # only pairs within rounding of the search radius may flip
+        assert float(((p2 - t) - p1).abs().max()) < 2e-5 * (k + 1), (k, float(((p2 - t) - p1).abs().max()))
+
+
 def test_fluid_errors_vs_kdtree(dev):
     """FluidErrors on the device (nf_nearest + device reductions) against the reference's host recipe
     (utils/point_eval.py:10-58: numpy statistics + scipy cKDTree), restated here as the checker."""

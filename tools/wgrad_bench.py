@@ -7,7 +7,7 @@ from neurofluid_amd import _lib, ops
 
 lib = _lib.load()
 dev = torch.device("cuda:0")
-cx, cd = 198, 54          # the configs' encodings: 63 + 9 + 63 + 63 position-like, 27 + 27 direction-like features
+cx, cd = int(os.environ.get("CX", 198)), int(os.environ.get("CD", 54))      # default: the configs' encodings (63 + 9 + 63 + 63, 27 + 27)
 ptr = lambda t: ctypes.c_void_p(t.data_ptr())
 ACT, DPRE = 2432, 2436
 rows_list = [int(a) for a in sys.argv[1:]] or [8000, 72000]
@@ -51,6 +51,10 @@ for n in rows_list:
     err_heads = max(((w_rgb - r_rgb).abs().max() / r_rgb.abs().max()).item(), ((w_sig - r_sig).abs().max() / r_sig.abs().max()).item(),
                     ((w_dir - r_dir).abs().max() / r_dir.abs().max()).item(),
                     ((colsum[2432:2436].double() - dpre[:, 2432:2436].double().sum(0)).abs().max() / n ** 0.5).item())
+    o4 = 256 * cx + 3 * 65536
+    w4 = blob[o4:o4 + 256 * (cx + 256)].view(256, cx + 256).double()
+    r4 = dpre[:, 1024:1280].double().t() @ torch.cat([x[:, :cx], acts[:, 768:1024]], 1).double()
+    err_heads = max(err_heads, ((w4 - r4).abs().max() / r4.abs().max()).item())
     err = max(err_heads, ((w0 - r0).abs().max() / r0.abs().max()).item(), ((w2 - r2).abs().max() / r2.abs().max()).item(),
               ((colsum[:2432].double() - dpre[:, :2432].double().sum(0)).abs().max() / n ** 0.5).item())
     print("rows %6d: %7.1f us per launch (wgrad + reduce), %6.1f TFLOP/s, rel err %.2e" % (n, us, flop / us / 1e6, err))

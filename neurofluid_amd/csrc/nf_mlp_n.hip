@@ -26,6 +26,14 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 #define NN_ACT (256 * 32)          // floats of one activation image
+// Weight operands are fetched with buffer loads: resource = the blob (scalar registers), scalar offset = part + K-step pair,
+// vector offset = the lane's constant 16-B slot.  A global load from a per-lane 64-bit pointer paid two vector adds per load
+// (the pair stride of 4 KB does not fit the instruction's immediate) — on the ALUs the fp32 MFMA runs on.
+typedef unsigned n_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 n_wload(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff)
+{
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0));
+}
 #ifndef NH_DEPTH
 #define NH_DEPTH 4               // read-ahead of the hidden parts' K loops, in K-step pairs
 #endif
@@ -47,10 +55,10 @@ __device__ __forceinline__ void n_bias2(const NCtx& c, const f32x4* __restrict__
 // skip layer ~30 us later: 32 KB per tile that the L2 still holds; no LDS stash, so two workgroups fit a CU and each SIMD
 // has a second tile's wave to issue from while the first one waits at a layer barrier).
 template <int nq>
-__device__ __forceinline__ void n_xpart2(const NCtx& c, const f32x4* __restrict__ p /* part base, N layout */, const f32x4* __restrict__ xt /* + lane */,
-                                         f32x16 (&acc)[2])
+__device__ __forceinline__ void n_xpart2(const NCtx& c, __amdgpu_buffer_rsrc_t wr_, int poff /* part offset in bytes, N layout */,
+                                         const f32x4* __restrict__ xt /* + lane */, f32x16 (&acc)[2])
 {
-    const f32x4* wp = p + c.w * 64 + c.lane;          // pair stride: 256 f32x4; a group of 4 K-steps = 2 pairs
+    const unsigned voff = (unsigned)(c.w * 64 + c.lane) * 16u;          // pair stride: 4 KB; a group of 4 K-steps = 2 pairs
     // a group is only 4 K-steps x 2 MFMAs = 512 cycles here: X (HBM the first time, L2 the second) is requested XD groups
     // ahead, the weights (L2) two groups ahead
     constexpr int XD = 6;
@@ -61,7 +69,7 @@ __device__ __forceinline__ void n_xpart2(const NCtx& c, const f32x4* __restrict_
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) wr[q][i] = wp[(q * 2 + i) * 256];
+        for (int i = 0; i < 2; ++i) wr[q][i] = n_wload(wr_, voff, poff + (q * 2 + i) * 4096);
 #pragma unroll
     for (int q = 0; q < nq; ++q) {
         const f32x4 xv = xr[0];
@@ -75,7 +83,7 @@ __device__ __forceinline__ void n_xpart2(const NCtx& c, const f32x4* __restrict_
         if (q + XD < nq) xr[XD - 1] = xt[(q + XD) * 64];
         if (q + 2 < nq) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) wr[1][i] = wp[((q + 2) * 2 + i) * 256];
+            for (int i = 0; i < 2; ++i) wr[1][i] = n_wload(wr_, voff, poff + ((q + 2) * 2 + i) * 4096);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -89,18 +97,18 @@ __device__ __forceinline__ void n_xpart2(const NCtx& c, const f32x4* __restrict_
 
 // hidden part: acc += W * act, act read from the LDS image (already activated); 128 K-steps = 8 source blocks x 16
 template <int NS = 128>
-__device__ __forceinline__ void n_hpart2(const NCtx& c, const f32x4* __restrict__ p /* part base, N layout */, const float* __restrict__ act,
-                                         f32x16 (&acc)[2])
+__device__ __forceinline__ void n_hpart2(const NCtx& c, __amdgpu_buffer_rsrc_t wr_, int poff /* part offset in bytes, N layout */,
+                                         const float* __restrict__ act, f32x16 (&acc)[2])
 {
     constexpr int NP = NS / 2, D = NH_DEPTH;          // K-step pairs; read-ahead in pairs
-    const f32x4* wp = p + c.w * 64 + c.lane;
+    const unsigned voff = (unsigned)(c.w * 64 + c.lane) * 16u;
     const float* ap = act + (4 * c.h) * 32 + c.j;           // feature frag_feature(b, r, h) = 32 b + (r & 3) + 8 (r >> 2) + 4 h
     f32x4 ring[D + 1];
     float b0[D + 1], b1[D + 1];
 #define NH_F(S) ((32 * ((S) >> 4) + ((S) & 3) + 8 * (((S) & 15) >> 2)) * 32)
 #pragma unroll
     for (int s = 0; s < D; ++s) {
-        ring[s] = wp[s * 256];
+        ring[s] = n_wload(wr_, voff, poff + s * 4096);
         b0[s] = ap[NH_F(2 * s)];
         b1[s] = ap[NH_F(2 * s + 1)];
     }
@@ -108,7 +116,7 @@ __device__ __forceinline__ void n_hpart2(const NCtx& c, const f32x4* __restrict_
     for (int s = 0; s < NP; ++s) {
         if (s + D < NP) {
             const int t = s + D;
-            ring[t % (D + 1)] = wp[t * 256];
+            ring[t % (D + 1)] = n_wload(wr_, voff, poff + t * 4096);
             b0[t % (D + 1)] = ap[NH_F(2 * t)];
             b1[t % (D + 1)] = ap[NH_F(2 * t + 1)];
         }
@@ -169,8 +177,10 @@ __global__ void __launch_bounds__(256) k_mlp_fwd_n(NfMlpLayout L, const float* _
     const int ntiles = (nrows + 31) >> 5;
     constexpr int Q = QX + QD;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const float* __restrict__ pk = packed + opaque_zero();
+        const int z0 = opaque_zero();
+        const float* __restrict__ pk = packed + z0;
         const f32x4* P4 = (const f32x4*)pk;
+        const __amdgpu_buffer_rsrc_t wr_ = __builtin_amdgcn_make_buffer_rsrc((void*)packed, 0, L.total * 4, 0x27000);
         const f32x4* xt = (const f32x4*)X + (size_t)tile * Q * 64 + c.lane;
         const int row = tile * 32 + c.j;
         const bool row_ok = row < nrows;
@@ -182,7 +192,7 @@ __global__ void __launch_bounds__(256) k_mlp_fwd_n(NfMlpLayout L, const float* _
 
         // layer 0 = xyz_encoding_1 -> h1 in A
         n_bias2(c, P4 + (L.off_bstep[0] >> 2), acc);
-        n_xpart2<QX>(c, P4 + (L.off_x[0] >> 2), xt, acc);
+        n_xpart2<QX>(c, wr_, L.off_x[0] * 4 + z0, xt, acc);
         n_store2<true, SAVE>(c, acc, actA, arow, row_ok);
         __syncthreads();
         float* cur = actA;
@@ -191,8 +201,8 @@ __global__ void __launch_bounds__(256) k_mlp_fwd_n(NfMlpLayout L, const float* _
 #pragma unroll 1
         for (int l = 1; l < 9; ++l) {
             n_bias2(c, P4 + (L.off_bstep[l] >> 2), acc);
-            if (L.off_x[l] >= 0) n_xpart2<QX>(c, P4 + (L.off_x[l] >> 2), xt, acc);
-            n_hpart2(c, P4 + (L.off_h[l] >> 2), cur, acc);
+            if (L.off_x[l] >= 0) n_xpart2<QX>(c, wr_, L.off_x[l] * 4 + z0, xt, acc);
+            n_hpart2(c, wr_, L.off_h[l] * 4 + z0, cur, acc);
             if (l == 8) {
                 // `cur` holds h8: the sigma head, by wave 0, in k_mlp_fwd's order (its lanes sum their own 128 features)
                 if (c.w == 0) {
@@ -220,18 +230,17 @@ __global__ void __launch_bounds__(256) k_mlp_fwd_n(NfMlpLayout L, const float* _
             const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             const f32x4* pb = P4 + (L.off_bstep_dir >> 2) + c.lane;
             hd = MFMA32(((const float*)pb)[c.w], 1.f, z);
-            const f32x4* px = P4 + (L.off_dir_x >> 2) + c.w * 64 + c.lane;         // N layout: [group of 4 steps][wave][64] x 16 B
+            const unsigned voff = (unsigned)(c.w * 64 + c.lane) * 16u;               // N layout: [group of 4 steps][wave][64] x 16 B
 #pragma unroll
             for (int q = 0; q < QD; ++q) {
-                const f32x4 wv = px[q * 256];
+                const f32x4 wv = n_wload(wr_, voff, L.off_dir_x * 4 + z0 + q * 4096);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) hd = MFMA32(wv[i], xdir[q][i], hd);
             }
-            const f32x4* ph = P4 + (L.off_dir_h >> 2) + c.w * 64 + c.lane;
             const float* ap = cur + (4 * c.h) * 32 + c.j;
 #pragma unroll 4
             for (int q = 0; q < 32; ++q) {
-                const f32x4 wv = ph[q * 256];
+                const f32x4 wv = n_wload(wr_, voff, L.off_dir_h * 4 + z0 + q * 4096);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int s = 4 * q + i;
@@ -389,7 +398,7 @@ __global__ void __launch_bounds__(256) k_mlp_bwd_n(NfMlpLayout L, NfMlpLayoutT T
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int z0 = opaque_zero();
         const float* __restrict__ pk = packed + z0;
-        const f32x4* PT4 = (const f32x4*)(packed_t + z0);
+        const __amdgpu_buffer_rsrc_t wt_ = __builtin_amdgcn_make_buffer_rsrc((void*)packed_t, 0, T.total * 4, 0x27000);
         const int row = tile * 32 + c.j;
         const bool valid = row < nrows;
         const float* arow = acts + (size_t)(valid ? row : 0) * NF_ACT_STRIDE;
@@ -433,7 +442,7 @@ __global__ void __launch_bounds__(256) k_mlp_bwd_n(NfMlpLayout L, NfMlpLayoutT T
         // raw d(final) = W_dir[:, :256]^T slot 9: 64 K-steps over the 128 hidden units
         f32x16 acc[2];
         n_zero2(acc);
-        n_hpart2<64>(c, PT4 + (T.off_dir >> 2), cur, acc);
+        n_hpart2<64>(c, wt_, T.off_dir * 4 + z0, cur, acc);
         const float* ws_ = pk + L.off_wsig;
 #pragma unroll 1
         for (int g = 8; g >= 1; --g) {
@@ -443,7 +452,7 @@ __global__ void __launch_bounds__(256) k_mlp_bwd_n(NfMlpLayout L, NfMlpLayoutT T
             __syncthreads();
             float* t = cur; cur = nxt; nxt = t;
             n_zero2(acc);
-            n_hpart2<128>(c, PT4 + (T.off_h[g] >> 2), cur, acc);
+            n_hpart2<128>(c, wt_, T.off_h[g] * 4 + z0, cur, acc);
         }
         // slot 0 = [h1 > 0] d_h1
         n_bwd_slot<1>(c, acc, arow, ws_, dsig, nullptr, drow, valid);

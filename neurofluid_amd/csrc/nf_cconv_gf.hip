@@ -375,8 +375,10 @@ __global__ void __launch_bounds__(GF_THREADS) k_cconv_gf(GfArgs A)
                         const f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
                         acc[0][k].lo = __builtin_elementwise_fma(p0, lo, acc[0][k].lo); acc[0][k].hi = __builtin_elementwise_fma(p0, hi, acc[0][k].hi);
                         acc[1][k].lo = __builtin_elementwise_fma(p1, lo, acc[1][k].lo); acc[1][k].hi = __builtin_elementwise_fma(p1, hi, acc[1][k].hi);
+#ifndef GF_AB_HALF_FMA
                         acc[2][k].lo = __builtin_elementwise_fma(p2, lo, acc[2][k].lo); acc[2][k].hi = __builtin_elementwise_fma(p2, hi, acc[2][k].hi);
                         acc[3][k].lo = __builtin_elementwise_fma(p3, lo, acc[3][k].lo); acc[3][k].hi = __builtin_elementwise_fma(p3, hi, acc[3][k].hi);
+#endif
                     }
                 };
                 struct XS { int jc; float w0, w1; float4 xv[NQ]; };

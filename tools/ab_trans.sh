@@ -1,7 +1,7 @@
 #!/bin/bash
 # dev tool: A/B builds of the transition-step kernels on the GPU box (NF_EXTRA_DEFS switches), per-kernel times via rocprofv3
 cd $GRAFT_REPO_ROOT
-VARIANTS=("" "-DGF_AB_NO_MFMA" "-DGF_AB_NO_GATHER" "-DTF_AB_SKIP_PATCH" "-DTF_AB_SKIP_ENT" "-DTF_AB_SKIP_GEMV")
+VARIANTS=("" "-DGF_AB_NO_MFMA" "-DGF_AB_NO_MFMA -DGF_AB_HALF_FMA" "-DGF_AB_NO_GATHER" "-DTF_AB_SKIP_PATCH" "-DTF_AB_SKIP_ENT" "-DTF_AB_SKIP_GEMV")
 for defs in "${VARIANTS[@]}"; do
   NF_EXTRA_DEFS="$defs" python -m neurofluid_amd.build > /dev/null 2>&1 || { echo "build failed: $defs"; continue; }
   tag=$(echo "base$defs" | tr -d ' ' | tr -c 'A-Za-z0-9_\n' '_')

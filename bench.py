@@ -2,7 +2,9 @@
 """bench.py — NeuroFluid hot path on MI355X: rays/sec (+ particle-steps/sec), synthetic watercube 400^2.
 
   python bench.py --gpus N --steps K --warmup W [--scaling weak|strong] [--image 400|800] [--workload render|train]
-  (N>1: launched by torch.distributed.run, one rank per GPU over RCCL)
+  (N>1: one rank per GPU over RCCL.  Under torch.distributed.run the ranks read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*;
+   typed without a launcher, `python bench.py --gpus N` starts its own N ranks through torch.distributed.run on a free
+   local port — `self_launch` — and rank 0 prints the one JSON line)
 
 One "step" = the coupled per-frame body of the reference's e2e loop (eval_e2e.py:58-134): one ParticleNet transition
 step on the 4 913-particle cloud (replicated on every rank: the step does not shard), a rebuild of the renderer's
@@ -202,6 +204,32 @@ def imbalance(per_chunk_rows, world, interleaved=True):
     return (max(loads) / mean) if mean > 0 else 1.0
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` typed without a launcher: start the N ranks here (one process per GPU through
+    torch.distributed.run on a free local port, the command the task statement's driver uses) and hand their exit code
+    back.  Rank 0 of the child job prints the one JSON line; this parent prints nothing of its own."""
+    import socket
+    single_dev = os.environ.get("NF_BENCH_SINGLE_DEVICE") == "1"
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < 1:
+        sys.stderr.write("bench.py: --gpus %d needs MI355X devices, none is visible\n" % n)
+        return 2
+    if have < n and not single_dev:
+        sys.stderr.write("bench.py: --gpus %d but only %d device(s) visible; run on a node with %d GPUs (or set "
+                         "NF_BENCH_SINGLE_DEVICE=1 to exercise the %d-rank control flow on one device over gloo: not a "
+                         "scaling measurement)\n" % (n, have, n, n))
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -216,6 +244,13 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the fp16 / train-step / particle-step extras")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher set WORLD_SIZE=%s (start one rank per GPU: torch.distributed.run "
+                 "--nproc-per-node %d, or plain `python bench.py --gpus %d`, which spawns its own ranks)"
+                 % (args.gpus, os.environ["WORLD_SIZE"], args.gpus, args.gpus))
+
     from neurofluid_amd import dist as nfdist, ops
     from neurofluid_amd.renderer import RenderNet
     from neurofluid_amd.transmodel import ParticleNet
@@ -229,8 +264,8 @@ def main():
     rank, world, local = nfdist.init_from_env("gloo" if single_dev else None)
     if single_dev:
         local = 0
-    assert world == args.gpus or (args.gpus == 1 and world == 1), f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     strong = args.scaling == "strong"

@@ -5,8 +5,11 @@
  * Python-level operator boundaries.  This header is the drop-in boundary underneath
  * them; each entry point cites the reference interface it replaces.  All pointers are DEVICE
  * pointers unless marked [host]; the caller owns every buffer (torch caching allocator); the
- * library allocates nothing, keeps no global state except a thread-local error string, enqueues
- * all work on the hipStream_t argument and never synchronises.  Return 0 on success, <0 on error
+ * library allocates nothing, enqueues all work on the hipStream_t argument and never synchronises.
+ * State it keeps: a thread-local error string, and per launch site a per-device "launch attribute
+ * set" flag (the dynamic-LDS limit of a kernel is set once per device; the flags are accessed
+ * atomically and setting the attribute twice is harmless, so the entry points are re-entrant).
+ * Nothing a result depends on lives in the library.  Return 0 on success, <0 on error
  * (nf_last_error() gives the message).  No torch types cross this boundary.
  */
 #ifndef NEUROFLUID_HIP_H
@@ -275,6 +278,17 @@ int nf_composite_bwd_noise(const float* rgbsigma, const float* z, const float* z
 int nf_importance_sample(const float* z_table0 /*S0*/, const float* weights0 /*R*S0*/, const float* u_table /*N_imp*/,
                          int R, int S0, int N_imp, const float* zero_row, float* z1 /*R*(S0+N_imp)*/,
                          nf_stream_t stream);
+
+/* perturb > 0 (models/renderer.py:225, :250).  The uniform draws are the CALLER's (torch.rand in the reference:
+ * utils/ray_utils.py:252 for the coarse jitter, :190 for the inverse-CDF u), so that results are reproducible against a seed.
+ * nf_coarse_perturb: coarse_sample_ray's perturb branch (utils/ray_utils.py:247-253):
+ *   z[r][k] = lower[k] + (upper[k] - lower[k]) * (perturb * rnd[r][k]),  lower / upper from the mid-points of z_table.
+ * nf_importance_sample_rays: ImportanceSampling(det=False) (utils/ray_utils.py:178-229) with PER-RAY coarse depths z0 (R*S0)
+ *   and per-ray draws u (R*N_imp, any order): z1 = sort(cat(z0, inverse-CDF(u))). */
+int nf_coarse_perturb(const float* z_table /*S*/, const float* rnd /*R*S*/, float perturb, int R, int S, float* z /*R*S*/,
+                      nf_stream_t stream);
+int nf_importance_sample_rays(const float* z0 /*R*S0*/, const float* weights0 /*R*S0*/, const float* u /*R*N_imp*/, int R,
+                              int S0, int N_imp, float* z1 /*R*(S0+N_imp)*/, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Transition model (ParticleNet.forward, models/transmodel.py:151-163).

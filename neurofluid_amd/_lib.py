@@ -61,6 +61,8 @@ PROTOTYPES = {
     "nf_composite_bwd_noise": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                        c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "nf_importance_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "nf_coarse_perturb": (c_int, [c_void_p, c_void_p, c_float, c_int, c_int, c_void_p, c_void_p]),
+    "nf_importance_sample_rays": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "nf_nerf_stream_floats": (c_size_t, [c_int, c_int]),
     "nf_nerf_pack_stream": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "nf_nerf_mlp_fwd_l": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),

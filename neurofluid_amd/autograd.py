@@ -9,7 +9,8 @@ def _prep(x):
     return x.detach().contiguous().float()
 
 
-def _run_passes(net, particles, ro, rays, white_bg, fine, save_acts, _retry=False, use_disp=False, noise_std=0.0, _noise=None):
+def _run_passes(net, particles, ro, rays, white_bg, fine, save_acts, _retry=False, use_disp=False, noise_std=0.0, _noise=None,
+                perturb=0.0):
     dev = rays.device
     z_table, u_table = net._tables(dev, use_disp)
     grid = net.grid_for(particles)
@@ -37,21 +38,30 @@ def _run_passes(net, particles, ro, rays, white_bg, fine, save_acts, _retry=Fals
         pk0, ws0, ph0 = net.packed_weights(net.nerf_coarse), None, None
     else:
         pk0, ws0, ph0 = net.packed_for_inference(net.nerf_coarse, use_h)
-    # noise_std > 0 (models/renderer.py:193-196): one (R, S) normal draw per pass, coarse first — the reference's order; a redo of
-    # the call (row capacities) reuses the draws of the first attempt
+    # Random draws, all up front and in the reference's order, so that a seeded generator gives the reference's numbers: the
+    # coarse jitter (perturb > 0: torch.rand(R, S0), utils/ray_utils.py:252), the coarse pass's sigma noise (noise_std > 0:
+    # torch.randn(R, S0), models/renderer.py:193-196), the inverse-CDF draws (perturb > 0: torch.rand(R, N_imp),
+    # utils/ray_utils.py:190), the fine pass's sigma noise.  A redo of the call (row capacities) reuses the first attempt's.
     R_ = rays_c.shape[0]
-    if noise_std and _noise is None:
-        _noise = [net.draw_noise((R_, net.N_samples), dev) * noise_std,
-                  net.draw_noise((R_, net.N_samples + net.N_importance), dev) * noise_std if fine else None]
-    nz0, nz1 = (_noise if _noise is not None else (None, None))
-    p0 = ops.render_pass(grid, pts, rays_c, None, z_table, net.N_samples, net.raduis, net.num_neighbor, net.enc_flags,
+    if (noise_std or perturb > 0) and _noise is None:
+        _noise = [net.draw_perturb((R_, net.N_samples), dev) if perturb > 0 else None,
+                  net.draw_noise((R_, net.N_samples), dev) * noise_std if noise_std else None,
+                  net.draw_perturb((R_, net.N_importance), dev) if (perturb > 0 and fine) else None,
+                  net.draw_noise((R_, net.N_samples + net.N_importance), dev) * noise_std if (noise_std and fine) else None]
+    pr0, nz0, pu1, nz1 = (_noise if _noise is not None else (None, None, None, None))
+    z0 = ops.coarse_perturb(z_table, pr0, perturb) if pr0 is not None else None       # per-ray coarse depths
+    p0 = ops.render_pass(grid, pts, rays_c, z0, None if z0 is not None else z_table, net.N_samples, net.raduis, net.num_neighbor, net.enc_flags,
                          net.use_mask, ro_c, pk0, net.in_channels_xyz, net.in_channels_dir, white_bg, save_acts,
                          packed_h=ph0, ws=ws, need_weights=fine, optimistic=opt, caps=caps, wstream=ws0, after_search=after,
                          noise=nz0)
     p0.packed = pk0
+    p0.z = z0
     p1 = None
     if fine:
-        z1 = ops.importance_sample(z_table, p0.weights, u_table, net.N_importance, net.zero_row(dev, use_disp))
+        if pu1 is not None:
+            z1 = ops.importance_sample_rays(z0, p0.weights, pu1, net.N_importance)
+        else:
+            z1 = ops.importance_sample(z_table, p0.weights, u_table, net.N_importance, net.zero_row(dev, use_disp))
         if save_acts:
             pk1, ws1, ph1 = net.packed_weights(net.nerf_fine), None, None
         else:
@@ -83,7 +93,7 @@ def _run_passes(net, particles, ro, rays, white_bg, fine, save_acts, _retry=Fals
                                    for r in ops.PROFILE["rows"]]
         if overflow:
             return _run_passes(net, particles, ro, rays, white_bg, fine, save_acts, _retry=True, use_disp=use_disp, noise_std=noise_std,
-                               _noise=_noise)
+                               _noise=_noise, perturb=perturb)
     return p0, p1, rays_c, ro_c, grid
 
 
@@ -169,12 +179,12 @@ def _results(p0, p1):
     return out
 
 
-def render_forward(net, particles, ro, rays, white_bg=True, fine=True, use_disp=False, noise_std=0.0):
+def render_forward(net, particles, ro, rays, white_bg=True, fine=True, use_disp=False, noise_std=0.0, perturb=0.0):
     needs_grad = torch.is_grad_enabled() and (particles.requires_grad or any(p.requires_grad for p in net.parameters()))
     if needs_grad:
         from .autograd_bwd import render_with_grad
-        return render_with_grad(net, particles, ro, rays, white_bg, fine, use_disp, noise_std)
+        return render_with_grad(net, particles, ro, rays, white_bg, fine, use_disp, noise_std, perturb)
     with torch.no_grad():
         p0, p1, _, _, _ = _run_passes(net, particles, ro, rays, white_bg, fine, save_acts=False, use_disp=use_disp,
-                                      noise_std=noise_std)
+                                      noise_std=noise_std, perturb=perturb)
         return _results(p0, p1)

@@ -120,11 +120,11 @@ class _RenderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, particles, ro, rays, white_bg, fine, *params):
         ctx.set_materialize_grads(False)      # backward reads rgb0 / rgb1 only: no zero tensors for the 8 other outputs
-        opts = fine if isinstance(fine, tuple) else (fine, False, 0.0)      # (fine, use_disp, noise_std) ride in one non-tensor argument
-        fine, use_disp, noise_std = opts
+        opts = fine if isinstance(fine, tuple) else (fine, False, 0.0, 0.0)      # (fine, use_disp, noise_std, perturb) ride in one non-tensor argument
+        fine, use_disp, noise_std, perturb = opts
         ctx.use_disp = use_disp
         p0, p1, rays_c, ro_c, grid = _run_passes(net, particles, ro, rays, white_bg, fine, save_acts=True, use_disp=use_disp,
-                                                 noise_std=noise_std)
+                                                 noise_std=noise_std, perturb=perturb)
         ctx.net, ctx.p0, ctx.p1, ctx.rays_c, ctx.white_bg, ctx.fine = net, p0, p1, rays_c, white_bg, fine
         ctx.particles_need_grad = particles.requires_grad
         ctx.ro_c, ctx.pts = ro_c, grid.points
@@ -149,6 +149,8 @@ class _RenderFn(torch.autograd.Function):
         net = ctx.net
         g = dict(zip(ctx.keys, grads))
         z_table, _ = net._tables(ctx.rays_c.device, ctx.use_disp)
+        z0 = getattr(ctx.p0, "z", None)                  # perturb > 0: the coarse pass ran on per-ray depths
+        zt0 = None if z0 is not None else z_table
         dpart = torch.zeros_like(ctx.pts) if ctx.particles_need_grad else None
         extra = dict(particles=ctx.pts, ro_c=ctx.ro_c, dparticles=dpart)
         both = g.get("rgb0") is not None and ctx.fine and g.get("rgb1") is not None and TWO_STREAM_BACKWARD
@@ -161,14 +163,14 @@ class _RenderFn(torch.autograd.Function):
             side = _side_stream(ctx.rays_c.device)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
-                gc = _pass_backward(net, net.nerf_coarse, ctx.p0, ctx.rays_c, None, z_table, g["rgb0"], ctx.white_bg, **extra)
+                gc = _pass_backward(net, net.nerf_coarse, ctx.p0, ctx.rays_c, z0, zt0, g["rgb0"], ctx.white_bg, **extra)
                 for t in gc:
                     if t is not None:
                         t.record_stream(cur)        # allocated on the side stream, consumed on the current one
             gf = _pass_backward(net, net.nerf_fine, ctx.p1, ctx.rays_c, ctx.p1.z, None, g["rgb1"], ctx.white_bg, **extra)
             cur.wait_stream(side)
             return (None, dpart, None, None, None, None) + tuple(gc) + tuple(gf)
-        gc = _pass_backward(net, net.nerf_coarse, ctx.p0, ctx.rays_c, None, z_table, g["rgb0"], ctx.white_bg, **extra) \
+        gc = _pass_backward(net, net.nerf_coarse, ctx.p0, ctx.rays_c, z0, zt0, g["rgb0"], ctx.white_bg, **extra) \
             if g.get("rgb0") is not None else [None] * 24
         if ctx.fine and g.get("rgb1") is not None:
             gf = _pass_backward(net, net.nerf_fine, ctx.p1, ctx.rays_c, ctx.p1.z, None, g["rgb1"], ctx.white_bg, **extra)
@@ -177,8 +179,8 @@ class _RenderFn(torch.autograd.Function):
         return (None, dpart, None, None, None, None) + tuple(gc) + tuple(gf)
 
 
-def render_with_grad(net, particles, ro, rays, white_bg, fine, use_disp=False, noise_std=0.0):
-    opts = (fine, bool(use_disp), float(noise_std)) if (use_disp or noise_std) else fine
+def render_with_grad(net, particles, ro, rays, white_bg, fine, use_disp=False, noise_std=0.0, perturb=0.0):
+    opts = (fine, bool(use_disp), float(noise_std), float(perturb)) if (use_disp or noise_std or perturb) else fine
     outs = _RenderFn.apply(net, particles, ro, rays, white_bg, opts, *_nerf_params(net))
     keys = ["rgb0", "depth0", "opacity0", "num_nn_0", "mask_0"] + (
         ["rgb1", "depth1", "opacity1", "num_nn_1", "mask_1"] if fine else [])

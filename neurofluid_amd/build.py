@@ -48,6 +48,12 @@ def build(force=False, verbose=False):
             if verbose:
                 print(" ".join(cmd))
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    # leftovers of removed sources / of `llvm-objdump --offloading` runs in this directory must not ship with the package
+    keep = set(objs) | {o + ".cmd" for o in objs} | {LIB}
+    for f in os.listdir(LIBDIR):
+        fp = os.path.join(LIBDIR, f)
+        if fp not in keep and (f.endswith(".o") or f.endswith(".o.cmd") or ".o." in f):
+            os.remove(fp)
     failed = False
     for src, p in procs:
         out, _ = p.communicate()

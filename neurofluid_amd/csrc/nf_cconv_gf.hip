@@ -635,12 +635,8 @@ static int gf_launch(const GfArgs& a, hipStream_t st)
 {
     const size_t lds = SPLIT ? (size_t)2 * 2 * 4 * GF_TILE * (CIN + 8) * sizeof(_Float16) : (size_t)2 * 4 * GF_TILE * (CIN + 4) * sizeof(float);
     static bool attr_set[64] = {};
-    int dev = 0;
-    hipGetDevice(&dev);
-    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+    if (nf_first_use_on_device(attr_set))
         hipFuncSetAttribute((const void*)k_cconv_gf<CIN, NB, RELU, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set[dev] = true;
-    }
     hipLaunchKernelGGL((k_cconv_gf<CIN, NB, RELU, SPLIT>), dim3(a.nwg), dim3(GF_THREADS), lds, st, a);
     return 0;
 }

@@ -17,13 +17,14 @@ void nf_set_error(const char* fmt, ...);
 
 // true the first time a call site runs on the CURRENT device (hipFuncSetAttribute belongs to a device's copy of the function:
 // a process-wide "done" flag would leave every device but the first at the 64 KB default).  `flags` = the call site's own
-// static bool[64].
+// static bool[64].  The flags are the library's only process-wide state besides the thread-local error string: they are read and
+// written atomically, and a lost race only repeats an idempotent hipFuncSetAttribute, so concurrent callers are safe.
 static inline bool nf_first_use_on_device(bool* flags)
 {
     int d = 0;
     if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return true;
-    if (flags[d]) return false;
-    flags[d] = true;
+    if (__atomic_load_n(&flags[d], __ATOMIC_ACQUIRE)) return false;
+    __atomic_store_n(&flags[d], true, __ATOMIC_RELEASE);
     return true;
 }
 

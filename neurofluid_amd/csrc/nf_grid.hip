@@ -500,13 +500,9 @@ extern "C" int nf_grid_build(const float* pts, int n, float cell, const float bb
     int* cstart = (int*)((char*)ws + h.off_cell_start);
     if (n > 0 && n <= GB_BLOCK * GB_MAX_PER_THREAD && (long)h.n_cells + n <= GB_MAX_LDS_INTS) {
         static bool attr_set[64] = {};          // per DEVICE: the attribute belongs to the device's copy of the function
-        int dev = 0;
-        hipGetDevice(&dev);
-        if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        if (nf_first_use_on_device(attr_set))
             hipFuncSetAttribute((const void*)k_grid_cells_1wg, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 GB_MAX_LDS_INTS * (int)sizeof(int));
-            if (dev >= 0 && dev < 64) attr_set[dev] = true;
-        }
         hipLaunchKernelGGL(k_grid_cells_1wg, dim3(1), dim3(GB_BLOCK), sizeof(int) * ((size_t)h.n_cells + n), st, h, ws, pts);
     } else {
         hipLaunchKernelGGL(k_grid_init, dim3(gc), dim3(B), 0, st, h, ws);

@@ -1148,6 +1148,133 @@ extern "C" int nf_importance_sample(const float* z_table0, const float* weights0
 }
 
 // ------------------------------------------------------------------------------------------------
+// perturb > 0 (utils/ray_utils.py:186-190, :247-252; models/renderer.py:225, :250): per-ray coarse depths jittered inside
+// their intervals, and the inverse CDF evaluated at per-ray uniform draws instead of the shared linspace.  The draws come
+// from the caller (RenderNet.draw_perturb = torch.rand on the rays' device, in the reference's order), so a test can hand
+// the same numbers to the oracle.  Not on any reference caller's path (trainer/basetrainer.py:284-289 never passes it):
+// written for exactness, not tuned.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_coarse_perturb(const float* __restrict__ zt, const float* __restrict__ rnd, float perturb,
+                                                        int R, int S, float* __restrict__ z)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)R * S) return;
+    const int k = (int)(i % S);
+    // mid-points of the shared depth table; lower = [z0, mid...], upper = [mid..., z_last]   (:248-251)
+    const float zk = zt[k];
+    const float lower = k == 0 ? zk : 0.5f * (zt[k - 1] + zk);
+    const float upper = k == S - 1 ? zk : 0.5f * (zk + zt[k + 1]);
+    const float pr = perturb * rnd[i];
+    z[i] = lower + (upper - lower) * pr;          // (-ffp-contract=off: mul, then add, as torch evaluates it)
+}
+
+extern "C" int nf_coarse_perturb(const float* z_table, const float* rnd, float perturb, int R, int S, float* z, nf_stream_t stream)
+{
+    NF_CHECK_ARG(z_table && rnd && z, "null pointer");
+    NF_CHECK_ARG(S >= 2 && R >= 0, "bad R/S");
+    if (R == 0) return NF_OK;
+    const long n = (long)R * S;
+    hipLaunchKernelGGL(k_coarse_perturb, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, z_table, rnd, perturb, R, S, z);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+// A wave per ray, per-ray depths z0[r][S0] and draws u[r][NI] (any order: the samples are sorted with the coarse depths
+// afterwards, utils/ray_utils.py:225, so only the multiset matters).  Elementwise parts on the 64 lanes, the order-dependent
+// sums (total, running CDF) and the merge walked by one lane in k_importance's order; the NI samples are ordered by a rank
+// sort (every lane counts the elements in front of its own: stable, deterministic) instead of a serial insertion sort,
+// which is quadratic on unsorted input.
+__global__ void __launch_bounds__(256) k_importance_r(const float* __restrict__ z0g, const float* __restrict__ w0,
+                                                      const float* __restrict__ ug, int R, int S0, int NI, float* __restrict__ z1)
+{
+    extern __shared__ float smr[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + wv;
+    if (r >= R) return;                                  // wave-uniform; no workgroup barrier below
+    const int NB = S0 - 1, NW = S0 - 2, ST = S0 + NI;
+    float* pw = smr + (size_t)wv * (3 * S0 + 2 * NI + ST);   // pdf terms
+    float* cdf = pw + S0;                                      // [NB]
+    float* zc = cdf + S0;                                      // [S0] this ray's coarse depths
+    float* zn = zc + S0;                                       // [NI] samples as drawn
+    float* zs = zn + NI;                                       // [NI] samples sorted
+    float* mg = zs + NI;                                       // [ST] merged row
+    const float* w = w0 + (size_t)r * S0;
+    const float* z0 = z0g + (size_t)r * S0;
+    const float* u_row = ug + (size_t)r * NI;
+    float* out = z1 + (size_t)r * ST;
+    for (int k = lane; k < NW; k += 64) pw[k] = w[k + 1] + 1e-5f;
+    for (int k = lane; k < S0; k += 64) zc[k] = z0[k];
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    float tot = 0.f;
+    if (lane == 0) {
+        for (int k = 0; k < NW; ++k) tot += pw[k];
+    }
+    tot = __shfl(tot, 0, 64);
+    for (int k = lane; k < NW; k += 64) pw[k] = pw[k] / tot;
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        float c = 0.f;
+        cdf[0] = 0.f;
+        for (int k = 0; k < NW; ++k) { c += pw[k]; cdf[k + 1] = c; }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    for (int k = lane; k < NI; k += 64) {
+        const float u = u_row[k];
+        int ind = 0;                                      // searchsorted(cdf, u, right=True): entries <= u
+        while (ind < NB && cdf[ind] <= u) ++ind;
+        const int below = ind - 1 < 0 ? 0 : ind - 1;
+        const int above = ind > NB - 1 ? NB - 1 : ind;
+        const float c0 = cdf[below], c1 = cdf[above];
+        const float b0 = 0.5f * (zc[below + 1] + zc[below]);
+        const float b1 = 0.5f * (zc[above + 1] + zc[above]);
+        float denom = c1 - c0;
+        if (denom < 1e-5f) denom = 1.f;
+        const float t = (u - c0) / denom;
+        zn[k] = b0 + t * (b1 - b0);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    for (int k = lane; k < NI; k += 64) {
+        const float v = zn[k];
+        int rank = 0;
+        for (int j = 0; j < NI; ++j) {
+            const float o = zn[j];
+            rank += (o < v || (o == v && j < k)) ? 1 : 0;
+        }
+        zs[rank] = v;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        int a = 0, b = 0;
+        for (int k = 0; k < ST; ++k) {
+            const float va = a < S0 ? zc[a] : INFINITY;
+            const float vb = b < NI ? zs[b] : INFINITY;
+            if (b >= NI || (a < S0 && va <= vb)) { mg[k] = va; ++a; } else { mg[k] = vb; ++b; }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    for (int k = lane; k < ST; k += 64) out[k] = mg[k];
+}
+
+extern "C" int nf_importance_sample_rays(const float* z0, const float* weights0, const float* u, int R, int S0, int N_imp, float* z1,
+                                         nf_stream_t stream)
+{
+    NF_CHECK_ARG(z0 && weights0 && u && z1, "null pointer");
+    NF_CHECK_ARG(S0 >= 3 && N_imp >= 1, "bad S0/N_imp");
+    const size_t lds = (size_t)4 * (3 * S0 + 2 * N_imp + S0 + N_imp) * sizeof(float);
+    NF_CHECK_ARG(lds <= 64 * 1024, "S0 + N_imp too large for LDS staging");
+    if (R == 0) return NF_OK;
+    hipLaunchKernelGGL(k_importance_r, dim3((R + 3) / 4), dim3(256), lds, (hipStream_t)stream, z0, weights0, u, R, S0, N_imp, z1);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // composite backward (A12, compositing part): dL/d(rgbsigma) from dL/d(rgb).
 //   w_i = a_i T_i,  T_i = prod_{j<i} (1 - a_j + 1e-10),  a_i = 1 - exp(-delta_i relu(sigma_i))
 //   rgb = sum w_i c_i (+ 1 - sum w_i)

@@ -170,12 +170,8 @@ extern "C" int nf_trans_prepare(const float* pos, const float* vel, const float 
                  "cloud or grid too large for the single-workgroup build (use nf_trans_integrate + nf_grid_build)");
     const size_t lds = (size_t)(h.n_cells + n) * sizeof(int);
     static bool attr_set[64] = {};              // per DEVICE
-    int dev = 0;
-    hipGetDevice(&dev);
-    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+    if (nf_first_use_on_device(attr_set))
         hipFuncSetAttribute((const void*)k_trans_prepare, hipFuncAttributeMaxDynamicSharedMemorySize, TP_MAX_LDS_INTS * (int)sizeof(int));
-        if (dev >= 0 && dev < 64) attr_set[dev] = true;
-    }
     hipLaunchKernelGGL(k_trans_prepare, dim3(1), dim3(TP_BLOCK), lds, (hipStream_t)stream, h, grid_ws, pos, vel, gravity[0],
                        gravity[1], gravity[2], dt, cell, pos_new, vel_new, feats4);
     NF_CHECK_LAUNCH();

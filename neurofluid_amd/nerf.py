@@ -99,28 +99,36 @@ class _NerfFn(torch.autograd.Function):
         ctx.net, ctx.sigma_only, ctx.n = net, sigma_only, n
         ctx.x_needs_grad = bool(ctx.needs_input_grad[1])
         if need:
-            ctx.save_for_backward(packed, X, n_rows, row_sample, out, acts)
+            # the transposed blob of the backward is packed NOW, from the weights this forward used: an optimiser step between
+            # forward and backward must not pair forward-time activations with newer weights
+            from .autograd_bwd import _pack_bwd
+            packed_t = _pack_bwd(net, cx, cd, dev)
+            ctx.save_for_backward(packed, packed_t, X, n_rows, row_sample, out, acts,
+                                  layers[0].weight.detach().clone(), layers[4].weight.detach().clone(), layers[9].weight.detach().clone())
         return out[:, 3:4].clone() if sigma_only else out
 
     @staticmethod
     def backward(ctx, g):
-        from .autograd_bwd import _pack_bwd, DPRE
+        from .autograd_bwd import DPRE
         lib = _lib.load()
         st = _lib.stream()
         net, n = ctx.net, ctx.n
         cx, cd = net.in_channels_xyz, net.in_channels_dir
         layers = net.linear_layers()
-        packed, X, n_rows, row_sample, out, acts = ctx.saved_tensors
+        packed, packed_t, X, n_rows, row_sample, out, acts, W1, W5, Wd = ctx.saved_tensors
         dev = out.device
+        # sigma_only (models/nerf.py:100-113) never touches xyz_encoding_final / dir_encoding / rgb: the reference leaves their
+        # .grad at None (an optimiser with weight decay or moment decay must not step them), so do we
+        unused = (8, 9, 11) if ctx.sigma_only else ()
         if n == 0:
-            zeros = [torch.zeros_like(l.weight) for l in layers] + [torch.zeros_like(l.bias) for l in layers]
+            zeros = [None if i in unused else torch.zeros_like(l.weight) for i, l in enumerate(layers)] + \
+                    [None if i in unused else torch.zeros_like(l.bias) for i, l in enumerate(layers)]
             return (None, torch.zeros(0, cx if ctx.sigma_only else cx + cd, device=dev) if ctx.x_needs_grad else None, None) + tuple(zeros)
         d_rs = torch.zeros(n, 4, dtype=torch.float32, device=dev)
         if ctx.sigma_only:
             d_rs[:, 3:4] = g.detach().float()
         else:
             d_rs.copy_(g.detach().float())
-        packed_t = _pack_bwd(net, cx, cd, dev)
         dpre = torch.empty(n, DPRE, dtype=torch.float32, device=dev)
         check(lib.nf_nerf_mlp_bwd_n(ptr(packed), ptr(packed_t), cx, cd, ptr(acts), ptr(n_rows), n, ptr(row_sample), ptr(out),
                                   ptr(d_rs), ptr(dpre), st), "nf_nerf_mlp_bwd_n")
@@ -137,8 +145,9 @@ class _NerfFn(torch.autograd.Function):
         gb = [colsum[k * 256:(k + 1) * 256] for k in range(8)]
         gb += [colsum[8 * 256:9 * 256], colsum[9 * 256:9 * 256 + 128], colsum[2435:2436], colsum[2432:2435]]
         dx = None
+        for i in unused:
+            gw[i] = gb[i] = None
         if ctx.x_needs_grad:
-            W1, W5, Wd = layers[0].weight.detach(), layers[4].weight.detach(), layers[9].weight.detach()
             dx = torch.empty(n, cx + cd, dtype=torch.float32, device=dev)
             ops.gemm(dpre[:, 0:256], W1, out=dx[:, :cx])
             ops.gemm(dpre[:, 4 * 256:5 * 256], W5[:, :cx], out=dx[:, :cx], accumulate=True)

@@ -586,6 +586,29 @@ def importance_sample(z_table0, weights0, u_table, n_importance, zero_row=None):
     return z1
 
 
+def coarse_perturb(z_table, rnd, perturb):
+    """coarse_sample_ray's perturb branch (utils/ray_utils.py:247-253): per-ray depths from the shared table and the caller's
+    uniform draws rnd (R, S)."""
+    lib = _lib.load()
+    R, S = rnd.shape
+    rnd = rnd.detach().contiguous().float()
+    z = torch.empty(R, S, dtype=torch.float32, device=rnd.device)
+    check(lib.nf_coarse_perturb(ptr(z_table), ptr(rnd), float(perturb), R, S, ptr(z), _lib.stream()), "nf_coarse_perturb")
+    return z
+
+
+def importance_sample_rays(z0, weights0, u, n_importance):
+    """ImportanceSampling(det=False): per-ray coarse depths z0 (R, S0) and per-ray uniform draws u (R, N_imp)."""
+    lib = _lib.load()
+    R, S0 = weights0.shape
+    u = u.detach().contiguous().float()
+    assert tuple(z0.shape) == (R, S0) and tuple(u.shape) == (R, n_importance)
+    z1 = torch.empty(R, S0 + n_importance, dtype=torch.float32, device=weights0.device)
+    check(lib.nf_importance_sample_rays(ptr(z0), ptr(weights0), ptr(u), R, S0, n_importance, ptr(z1), _lib.stream()),
+          "nf_importance_sample_rays")
+    return z1
+
+
 def importance_zero_row(z_table0, u_table, n_importance):
     """The resampled depths of a ray with all-zero weights, computed by the general path of the same kernel."""
     w = torch.zeros(1, z_table0.shape[0], dtype=torch.float32, device=z_table0.device)

@@ -158,18 +158,24 @@ class RenderNet(nn.Module):
     # ------------------------------------------------------------------
     def forward(self, physical_particles, ro, rays, focal=None, c2w=None, use_disp=False, perturb=0, noise_std=0.,
                 white_background=True):
-        self._check_perturb(perturb)
         from .autograd import render_forward
         return render_forward(self, physical_particles, ro, rays, white_background, fine=self.N_importance > 0,
-                              use_disp=bool(use_disp), noise_std=float(noise_std))
+                              use_disp=bool(use_disp), noise_std=float(noise_std), perturb=self._perturb(perturb))
 
     @staticmethod
-    def _check_perturb(perturb):
-        if perturb != 0:
-            raise NotImplementedError(
-                "perturb > 0 cannot run in the reference on a GPU either: its sample_pdf draws u = torch.rand(...) on the CPU and "
-                "searches a CUDA cdf with it (utils/ray_utils.py:190, :204 — a device-mismatch error), and no caller passes it "
-                "(trainer/basetrainer.py:284-289)")
+    def _perturb(perturb):
+        """perturb > 0 (models/renderer.py:225, :250): the coarse depths are jittered inside their intervals by
+        perturb * U[0,1) (utils/ray_utils.py:247-253) and the inverse CDF is evaluated at uniform draws instead of the
+        linspace (det = (perturb == 0), utils/ray_utils.py:186-190).  <= 0 leaves both deterministic, as in the reference."""
+        perturb = float(perturb)
+        return perturb if perturb > 0 else 0.0
+
+    @staticmethod
+    def draw_perturb(shape, device):
+        """The uniform draws of perturb > 0: torch.rand, first (R, N_samples) for the coarse jitter (utils/ray_utils.py:252),
+        then (R, N_importance) for the inverse CDF (utils/ray_utils.py:190; under the reference launchers' default tensor type
+        that draw lands on the GPU too).  A method so that a test can feed the same numbers to the oracle."""
+        return torch.rand(shape, device=device)
 
     @staticmethod
     def draw_noise(shape, device):
@@ -179,10 +185,9 @@ class RenderNet(nn.Module):
 
     def coarse_rendering(self, physical_particles, ro, rays, focal=None, c2w=None, use_disp=False, perturb=0,
                          noise_std=0., white_background=True):
-        self._check_perturb(perturb)
         from .autograd import render_forward
         return render_forward(self, physical_particles, ro, rays, white_background, fine=False, use_disp=bool(use_disp),
-                              noise_std=float(noise_std))
+                              noise_std=float(noise_std), perturb=self._perturb(perturb))
 
     def fine_rendering(self, physical_particles, ro, rays, focal=None, c2w=None, use_disp=False, perturb=0,
                        noise_std=0., white_background=True):

@@ -19,7 +19,7 @@ from ._lib import check, ptr
 
 
 import os as _os
-_DIAG_NO_WAIT = _os.environ.get("NF_DIAG_TRANS_NO_WAIT") == "1"      # measurement only: skip the overflow wait
+import time as _time
 
 
 class ContinuousConv(nn.Module):
@@ -370,7 +370,9 @@ class ParticleNet(nn.Module):
         st = self._fused_buffers(n, dev, self._scene_bbox(box))
         self._fused_weights(st, dev)
         S = st["S"]
-        skey = (box.data_ptr(), box_feats.data_ptr(), self.gravity._version)
+        # (a box updated IN PLACE — a moving obstacle — keeps its pointer: the versions and the row count are part of the key,
+        # as they are of _box_grid's own)
+        skey = (box.data_ptr(), box._version, box.shape[0], box_feats.data_ptr(), box_feats._version, self.gravity._version)
         if st["skey"] != skey:                 # scene pointers / gravity in the step struct
             bgrid = self._box_grid(box)
             S.box_grid, S.box_feats = bgrid.ws.data_ptr(), box_feats.data_ptr()
@@ -389,13 +391,17 @@ class ParticleNet(nn.Module):
         # no runtime call): the overflow words are final then, and the three convolutions are still to run — the wait costs
         # no GPU time.  (A HIP event recorded between the launches of one batch completes with the batch.)
         flag = st["flag_np"]
-        spins = 0
-        while flag[2] != sid and not _DIAG_NO_WAIT:
+        spins, deadline = 0, None
+        while flag[2] != sid:
             spins += 1
-            if spins > 2000000:                # ~1 s without the word: surface whatever went wrong on the device
-                torch.cuda.synchronize()
-                if flag[2] != sid:
-                    raise RuntimeError("nf_trans_step: the front kernel never reported completion")
+            if spins & 0x3ff == 0:             # the clock is read every 1024 polls: the common case (tens of us) never reads it
+                now = _time.perf_counter()
+                if deadline is None:
+                    deadline = now + 2.0
+                elif now > deadline:           # 2 s without the word: surface whatever went wrong on the device
+                    torch.cuda.synchronize()
+                    if flag[2] != sid:
+                        raise RuntimeError("nf_trans_step: the front kernel never reported completion")
         if flag[0] or flag[1]:
             return self._fused_overflow(st, pos, vel, box, box_feats)
         self.num_fluid_neighbors = nn
@@ -408,7 +414,10 @@ class ParticleNet(nn.Module):
     def _fused_overflow(self, st, pos, vel, box, box_feats):
         """A particle had more neighbours than its row pitch: redo THIS step on the exact CSR path (same results as the
         reference's uncapped search) and let the pitch grow for the following steps (up to what the front kernel stages;
-        beyond that the exact path serves the next steps and the fused one is retried later)."""
+        beyond that the exact path serves the next steps and the fused one is retried later).  The exact path sums in another
+        order than the fused step (both within 2e-7 of the oracle per step; neighbour sets and counts bit-equal), so the low
+        bits of a rollout depend on which steps were redone, i.e. on the pitch history and on `fused_grow_pitch`: for
+        bit-reproducible rollouts across runs start from the same `max_*_neighbors` (or set `fused_inference = False`)."""
         of, ob = st["ovf"].tolist()            # (syncs: the exact maxima, for the pitch growth)
         st["ovf"].zero_()
         st["flag_np"][:2] = 0

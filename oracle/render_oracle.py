@@ -75,8 +75,18 @@ def coarse_z(near, far, n, use_disp=False):
     return near * (1 - t) + far * t
 
 
-def coarse_sample_ray(near, far, rays, n, use_disp=False):
+def coarse_sample_ray(near, far, rays, n, use_disp=False, perturb=0, perturb_rand=None):
+    """utils/ray_utils.py:232-256.  perturb > 0 (:247-253): every depth is redrawn inside its interval [lower, upper]
+    (mid-points of the table) at perturb * U[0,1); perturb_rand = the (R, n) uniform draws, or None = torch.rand from the
+    global generator, as the reference draws them."""
     z = coarse_z(near, far, n, use_disp).expand(rays.shape[0], n)
+    if perturb > 0:
+        mid = 0.5 * (z[:, :-1] + z[:, 1:])
+        upper = torch.cat([mid, z[:, -1:]], -1)
+        lower = torch.cat([z[:, :1], mid], -1)
+        if perturb_rand is None:
+            perturb_rand = torch.rand(z.shape)
+        z = lower + (upper - lower) * (perturb * perturb_rand)
     xyz = rays[:, None, 0:3] + rays[:, None, 3:6] * z[:, :, None]
     return z, xyz
 
@@ -194,15 +204,17 @@ def render_image(rgbsigma, zvals, rays, white_background=True, noise=None):
 
 
 # ----------------------------------------------------------------------------------------------
-# A9  importance sampling (det=True: perturb == 0, models/renderer.py:250)
+# A9  importance sampling (det = (perturb == 0), models/renderer.py:250)
 # ----------------------------------------------------------------------------------------------
-def sample_pdf(bins, weights, n):
-    """utils/ray_utils.py:178-220, det branch."""
+def sample_pdf(bins, weights, n, u=None):
+    """utils/ray_utils.py:178-220.  u = None: the det branch (linspace); else the (R, n) uniform draws of :190."""
     weights = weights + 1e-5
     pdf = weights / torch.sum(weights, -1, keepdim=True)
     cdf = torch.cumsum(pdf, -1)
     cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], -1)
-    u = torch.linspace(0., 1., steps=n).expand(list(cdf.shape[:-1]) + [n]).contiguous()
+    if u is None:
+        u = torch.linspace(0., 1., steps=n).expand(list(cdf.shape[:-1]) + [n])
+    u = u.contiguous()
     inds = torch.searchsorted(cdf.detach(), u, right=True)
     below = torch.clamp(inds - 1, min=0)
     above = torch.clamp(inds, max=cdf.shape[-1] - 1)
@@ -214,10 +226,10 @@ def sample_pdf(bins, weights, n):
     return bin_lo + t * (bin_hi - bin_lo)
 
 
-def importance_sampling(zvals, weights, n_importance, rays_o, rays_d):
+def importance_sampling(zvals, weights, n_importance, rays_o, rays_d, u=None):
     """utils/ray_utils.py:222-229."""
     mid = 0.5 * (zvals[..., 1:] + zvals[..., :-1])
-    z_new = sample_pdf(mid, weights[:, 1:-1], n_importance).detach()
+    z_new = sample_pdf(mid, weights[:, 1:-1], n_importance, u).detach()
     z_all, _ = torch.sort(torch.cat([zvals, z_new], -1), -1)
     xyz = rays_o[..., None, :] + rays_d[..., None, :] * z_all[..., :, None]
     return xyz, z_all
@@ -242,10 +254,14 @@ def render_pass(state, prefix, particles, ro, rays, z, xyz, cfg, white_backgroun
 
 
 def render_forward(state, particles, ro, rays, near, far, cfg=DEFAULT_CFG, white_background=True,
-                   return_debug=False, use_disp=False, noise_std=0.0, noise=None):
+                   return_debug=False, use_disp=False, noise_std=0.0, noise=None, perturb=0, perturb_draws=None):
     """models/renderer.py:211-270 -> dict with the reference's keys.  noise_std > 0: sigma noise, one torch.randn draw per pass
-    in the reference's order (coarse, fine) from the global CPU generator, or the two tensors `noise` = (n0, n1) (already scaled)."""
-    z0, xyz0 = coarse_sample_ray(near, far, rays, cfg["N_samples"], use_disp)
+    in the reference's order (coarse, fine) from the global CPU generator, or the two tensors `noise` = (n0, n1) (already scaled).
+    perturb > 0: jittered coarse depths and random inverse-CDF draws; perturb_draws = (rand (R, N_samples), rand (R, N_importance))
+    or None = torch.rand from the global generator at the reference's two call sites (so that, seeded alike, the draws of this
+    function and of the reference coincide: coarse jitter, [coarse noise], u, [fine noise])."""
+    pr0, pu1 = perturb_draws if perturb_draws is not None else (None, None)
+    z0, xyz0 = coarse_sample_ray(near, far, rays, cfg["N_samples"], use_disp, perturb, pr0)
     n0 = n1 = None
     if noise is not None:
         n0, n1 = noise
@@ -256,7 +272,10 @@ def render_forward(state, particles, ro, rays, near, far, cfg=DEFAULT_CFG, white
            "num_nn_0": p0["num_nn"], "mask_0": p0["mask"].sum(1)}
     dbg = {"z0": z0, "weights0": p0["weights"], "rgbsigma0": p0["rgbsigma"]}
     if cfg["N_importance"] > 0:
-        xyz1, z1 = importance_sampling(z0, p0["weights"], cfg["N_importance"], rays[..., :3], rays[..., 3:])
+        if perturb > 0 and pu1 is None:
+            pu1 = torch.rand(rays.shape[0], cfg["N_importance"])
+        xyz1, z1 = importance_sampling(z0, p0["weights"], cfg["N_importance"], rays[..., :3], rays[..., 3:],
+                                       pu1 if perturb > 0 else None)
         if noise is None and noise_std:
             n1 = torch.randn(rays.shape[0], cfg["N_samples"] + cfg["N_importance"]) * noise_std
         p1 = render_pass(state, "nerf_fine", particles, ro, rays, z1, xyz1, cfg, white_background, n1)

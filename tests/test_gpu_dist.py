@@ -42,3 +42,35 @@ def test_rccl_single_rank_collectives():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0 and "rccl ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def _bench(args, env_extra, timeout=900):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
+                          timeout=timeout, env=env, cwd=ROOT)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` as a driver types it (no torchrun): bench.py starts the ranks itself and rank 0 prints the
+    one JSON line (strong ray-tile scaling, chunk k -> rank k mod 2).  The box has ONE device, so the two ranks share it over
+    gloo (NF_BENCH_SINGLE_DEVICE=1): launch path, sharding, collectives and accounting are what is checked, not the rate."""
+    import json
+    r = _bench(["--gpus", "2", "--steps", "1", "--warmup", "1", "--no-extras", "--no-cpu-baseline"], {"NF_BENCH_SINGLE_DEVICE": "1"})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["scaling"] == "strong" and res["steps"] == 1
+    assert res["max_over_mean"] is not None and 1.0 <= res["max_over_mean"] < 1.1
+    assert len(res["load_balance"]["executed_rows_per_rank_per_step"]) == 2
+    assert res["value"] > 0 and "single_device_emulation" in res
+
+
+def test_bench_more_ranks_than_devices_is_refused_with_a_message():
+    import torch
+    n = torch.cuda.device_count() + 1
+    r = _bench(["--gpus", str(n), "--steps", "1", "--warmup", "1", "--no-extras", "--no-cpu-baseline"], {"NF_BENCH_SINGLE_DEVICE": "0"}, timeout=300)
+    assert r.returncode == 2
+    assert "device(s) visible" in r.stderr and "AssertionError" not in r.stderr and "Traceback" not in r.stderr

@@ -140,7 +140,11 @@ def test_nerf_forward_autograd_vs_oracle(dev):
     gw = dict(net.named_parameters())["xyz_encoding_3.0.weight"].grad.cpu()
     rw = stc2["nerf_fine.xyz_encoding_3.0.weight"].grad
     assert float((gw - rw).norm() / rw.norm()) < 5e-2
-    assert float(dict(net.named_parameters())["rgb.0.weight"].grad.abs().sum()) == 0.0
+    # the view branch is not evaluated in this form (models/nerf.py:100-113): like the reference, no gradient at all — not zeros
+    for name, p in net.named_parameters():
+        unused = name.startswith(("xyz_encoding_final", "dir_encoding", "rgb"))
+        assert (p.grad is None) == unused, name
+        assert (stc2["nerf_fine." + name].grad is None) == unused, name
 
 
 def test_backward_kernels_exact_for_their_operands(dev):

@@ -341,7 +341,7 @@ def test_forward_sigma_noise(dev):
     """noise_std > 0 (models/renderer.py:193-195): sigma + noise_std * randn before the ReLU, at every sample (masked ones included).
     The same two draws are fed to the HIP path (RenderNet.draw_noise) and to the oracle; they are also the reference's own
     draws for this seed, so the result must match the dict the reference returned (tests/golden/a10_noise.npz).  Gradients
-    vs torch autograd through the oracle with the same noise; perturb > 0 raises (the reference fails there itself)."""
+    vs torch autograd through the oracle with the same noise."""
     from oracle import render_oracle as ro
     g = load_golden("a10_noise")
     net = make_net(dev)
@@ -366,8 +366,6 @@ def test_forward_sigma_noise(dev):
         torch.testing.assert_close(out[k].cpu(), T(g[k]), rtol=0, atol=RGB_ATOL, msg="golden " + k)
     for k in ("depth0", "depth1", "opacity0", "opacity1"):
         torch.testing.assert_close(out[k].cpu(), T(g[k]), rtol=1e-4, atol=2e-4, msg=k)
-    with pytest.raises(NotImplementedError):
-        net(P, roc, rays, None, None, perturb=1.0)
     # gradients: coarse net (same samples on both sides) against autograd through the oracle
     r8 = rays[:8].contiguous()
     d8 = [draws[0][:8].contiguous(), draws[1][:8].contiguous()]
@@ -389,6 +387,88 @@ def test_forward_sigma_noise(dev):
         rel = float((p.grad.cpu() - st[name].grad).norm() / (st[name].grad.norm() + 1e-30))
         assert rel < 1e-3, (name, rel)
     del net.draw_noise
+
+
+def test_forward_perturb(dev):
+    """perturb > 0 (models/renderer.py:225, :250; utils/ray_utils.py:186-190, :247-253): coarse depths jittered per ray, inverse CDF at
+    random u.  The HIP path gets the reference's own draws for the recorded seed (RenderNet.draw_perturb / draw_noise, consumed in
+    the reference's order: jitter, coarse noise, u, fine noise) and must land on the dicts the reference returned
+    (tests/golden/a10_perturb.npz, a10_perturb_noise.npz) and on the oracle fed the same draws; the per-ray depths themselves
+    bit for bit; coarse_rendering alone; gradients of the coarse net vs autograd through the oracle."""
+    from oracle import render_oracle as ro
+    from neurofluid_amd import ops
+    net = make_net(dev)
+    st0 = ro.deterministic_nerf_state()
+    g = load_golden("a10_perturb")
+    # A1 with jitter: the kernel's depths = the reference's, bit for bit
+    torch.manual_seed(int(g["seed_coarse"]))
+    rnd = torch.rand(5, 64)
+    zt, _ = net._tables(dev)
+    z = ops.coarse_perturb(zt, rnd.to(dev), float(g["perturb_coarse"]))
+    assert torch.equal(z.cpu(), T(g["z_coarse"]))
+    for name in ("a10_perturb", "a10_perturb_noise"):
+        g = load_golden(name)
+        P, rays, roc = T(g["particles"], dev), T(g["rays"], dev), T(g["ro"], dev)
+        R, pert = rays.shape[0], float(g["perturb"])
+        std = float(g["noise_std"]) if "noise_std" in g else 0.0
+        torch.manual_seed(int(g["seed"]))
+        pr0 = torch.rand(R, 64)
+        n0 = torch.randn(R, 64) if std else None
+        pu1 = torch.rand(R, 128)
+        n1 = torch.randn(R, 192) if std else None
+
+        def feed(sl=slice(None)):
+            itp, itn = iter([pr0[sl], pu1[sl]]), iter([n0[sl], n1[sl]] if std else [])
+            net.draw_perturb = lambda shape, device: next(itp).contiguous().to(device)
+            net.draw_noise = lambda shape, device: next(itn).contiguous().to(device)
+
+        feed()
+        with torch.no_grad():
+            out = net(P, roc, rays, None, None, perturb=pert, noise_std=std)
+        ref = ro.render_forward(st0, P.cpu(), roc.cpu(), rays.cpu(), 9.0, 13.0, perturb=pert, perturb_draws=(pr0, pu1),
+                                noise=(n0 * std, n1 * std) if std else None)
+        for k in ("num_nn_0", "num_nn_1", "mask_0", "mask_1"):
+            assert torch.equal(out[k].cpu(), T(g[k])), (name, k)
+            assert torch.equal(out[k].cpu(), ref[k]), (name, k)
+        for k in ("rgb0", "rgb1"):
+            torch.testing.assert_close(out[k].cpu(), ref[k], rtol=0, atol=RGB_ATOL, msg=f"{name} {k}")
+            torch.testing.assert_close(out[k].cpu(), T(g[k]), rtol=0, atol=RGB_ATOL, msg=f"{name} golden {k}")
+        for k in ("depth0", "depth1", "opacity0", "opacity1"):
+            torch.testing.assert_close(out[k].cpu(), T(g[k]), rtol=1e-4, atol=2e-4, msg=f"{name} {k}")
+        # the coarse pass on its own (models/renderer.py:273-307) draws only the jitter (+ its noise)
+        feed()
+        with torch.no_grad():
+            outc = net.coarse_rendering(P, roc, rays, None, None, perturb=pert, noise_std=std)
+        assert torch.equal(outc["rgb0"], out["rgb0"]) and "rgb1" not in outc
+        # gradients on 8 rays: loss, and the coarse net's parameters (same samples on both sides)
+        sl = slice(0, 8)
+        r8 = rays[sl].contiguous()
+        tgt = torch.full((8, 3), 0.3)
+        feed(sl)
+        net.zero_grad()
+        o = net(P, roc, r8, None, None, perturb=pert, noise_std=std)
+        loss = torch.nn.functional.mse_loss(o["rgb0"], tgt.to(dev)) + torch.nn.functional.mse_loss(o["rgb1"], tgt.to(dev))
+        loss.backward()
+        st = {k: v.clone().requires_grad_(True) for k, v in st0.items()}
+        oref = ro.render_forward(st, P.cpu(), roc.cpu(), r8.cpu(), 9.0, 13.0, perturb=pert, perturb_draws=(pr0[sl], pu1[sl]),
+                                 noise=(n0[sl] * std, n1[sl] * std) if std else None)
+        lref = torch.nn.functional.mse_loss(oref["rgb0"], tgt) + torch.nn.functional.mse_loss(oref["rgb1"], tgt)
+        lref.backward()
+        assert abs(float(loss.detach()) - float(lref.detach())) < 1e-5
+        for pname, p in net.named_parameters():
+            if not pname.startswith("nerf_coarse") or st[pname].grad is None:
+                continue
+            rel = float((p.grad.cpu() - st[pname].grad).norm() / (st[pname].grad.norm() + 1e-30))
+            assert rel < 1e-3, (name, pname, rel)
+    del net.draw_perturb, net.draw_noise
+    # without hooks the module draws from torch's generator on the device: two seeded calls agree, unseeded ones differ
+    torch.manual_seed(5)
+    with torch.no_grad():
+        a = net(P, roc, rays, None, None, perturb=1.0)["rgb1"].clone()
+        torch.manual_seed(5)
+        b = net(P, roc, rays, None, None, perturb=1.0)["rgb1"].clone()
+        c = net(P, roc, rays, None, None, perturb=1.0)["rgb1"].clone()
+    assert torch.equal(a, b) and not torch.equal(a, c)
 
 
 def test_forward_empty_and_ragged(dev):

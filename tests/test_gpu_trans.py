@@ -597,6 +597,37 @@ def test_fused_step_overflow_is_redone_exactly(dev):
             assert pc.fused_overflows == 4 and pc.max_fluid_neighbors == 8
 
 
+def test_fused_step_sees_a_box_updated_in_place(dev):
+    """A moving obstacle: `box` / `box_feats` updated IN PLACE keep their pointers and (when the extreme points stay) their
+    bounds.  The fused step must search the NEW contents (its scene key carries the tensors' versions): it stays bit-equal in
+    counts and within the fused/exact bar of the multi-launch path, which rebuilds the box grid from the tensor every step."""
+    from neurofluid_amd import synthetic
+    from oracle import trans_oracle as to
+    box, bn = [t.to(dev).clone() for t in to.watercube_box()]
+    P = synthetic.watercube_particles().to(dev)
+    fused, _ = make_pn(dev)
+    exact, _ = make_pn(dev)
+    exact.fused_inference = False
+    # the floor's interior points near the fluid column (the cube sits at z >= -0.975 over the floor z = -1)
+    lo, hi = box.min(0).values, box.max(0).values
+    moving = (box[:, 2] < -0.99) & (box[:, 0].abs() < 0.5) & (box[:, 1].abs() < 0.5)
+    assert int(moving.sum()) > 100
+    v = torch.zeros_like(P)
+    with torch.no_grad():
+        pf, vf, nf = fused(P, v, box, bn)
+        pe, ve, ne = exact(P, v, box, bn)
+        assert torch.equal(nf, ne) and float((pf - pe).abs().max()) <= 2e-7
+        before = pf.clone()
+        box[moving, 2] += 0.06                     # the floor patch under the fluid rises INTO the search radius of more particles
+        bn[moving] *= 0.5                          # and its features change too
+        assert torch.equal(box.min(0).values, lo) and torch.equal(box.max(0).values, hi)      # same bounds, same pointer
+        pf, vf, nf = fused(P, v, box, bn)
+        pe, ve, ne = exact(P, v, box, bn)
+        assert torch.equal(nf, ne) and float((pf - pe).abs().max()) <= 2e-7 and float((vf - ve).abs().max()) <= 2e-5
+        assert float((pf - before).abs().max()) > 1e-6          # the update mattered
+    assert fused._fused is not None and getattr(fused, "fused_overflows", 0) == 0
+
+
 # ------------------------------------------------------------------------------------------------
 # round 3: convention known-answer tests (tests/kat_conventions.py) against the HIP path.  The expected values come from
 # the operators' published contracts, not from the oracle: a convention error that the oracle and the kernels share

@@ -1,5 +1,9 @@
 """Host-side logic that needs no GPU: operand layout transforms, pixel sampling, LR schedule, chunk sharding."""
+import os
+import sys
+
 import numpy as np
+import pytest
 import torch
 
 from neurofluid_amd import dist as nfdist, ops
@@ -354,3 +358,17 @@ def test_lazy_results_widen_counts_on_first_read():
     assert list(r.keys()) == ["rgb0"]
     r = make(); r["num_nn_0"] = 5
     assert r["num_nn_0"] == 5
+
+
+def test_bench_without_a_gpu_fails_with_a_message_not_an_assert():
+    """bench.py --gpus N typed without a launcher spawns its own ranks; where no device is visible it must say so."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    for n in ("1", "8"):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", n, "--steps", "1", "--warmup", "0"],
+                           capture_output=True, text=True, timeout=300, env=env, cwd=root)
+        assert r.returncode != 0
+        assert "MI355X" in r.stderr and "Traceback" not in r.stderr, r.stderr[-2000:]

@@ -119,6 +119,28 @@ def test_a10_sigma_noise(golden):
     assert float((clean["rgb1"] - out["rgb1"]).abs().max()) > 1e-2          # the noise matters (empty space turns slightly opaque)
 
 
+def test_a10_perturb(golden):
+    """perturb > 0 (models/renderer.py:225, :250): the oracle repeats the reference's torch.rand draws (same seed, shapes, order:
+    coarse jitter (R, 64), [coarse noise], u (R, 128), [fine noise]) and must land on the dict the reference returned
+    (tests/golden/gen_golden_perturb.py) — alone and together with noise_std."""
+    g = golden("a10_perturb")
+    torch.manual_seed(int(g["seed_coarse"]))
+    z, _ = ro.coarse_sample_ray(9.0, 13.0, T(g["rays"])[:5], 64, False, float(g["perturb_coarse"]))
+    assert torch.equal(z, T(g["z_coarse"]))
+    st = ro.deterministic_nerf_state()
+    clean = ro.render_forward(st, T(g["particles"]), T(g["ro"]), T(g["rays"]), 9.0, 13.0)
+    for name in ("a10_perturb", "a10_perturb_noise"):
+        g = golden(name)
+        torch.manual_seed(int(g["seed"]))
+        out = ro.render_forward(st, T(g["particles"]), T(g["ro"]), T(g["rays"]), 9.0, 13.0, perturb=float(g["perturb"]),
+                                noise_std=float(g["noise_std"]) if "noise_std" in g else 0.0)
+        for k in ["num_nn_0", "num_nn_1", "mask_0", "mask_1"]:
+            assert torch.equal(out[k], T(g[k])), (name, k)
+        for k in ["rgb0", "rgb1", "depth0", "depth1", "opacity0", "opacity1"]:
+            torch.testing.assert_close(out[k], T(g[k]), rtol=0, atol=2e-6, msg=f"{name} {k}")
+        assert not torch.equal(clean["num_nn_0"], out["num_nn_0"])          # the jitter moves samples in and out of the fluid
+
+
 def test_b1_integrate(golden):
     g = golden("b1_integrate")
     p2, v2 = to.integrate_pos_vel(T(g["pos"]), T(g["vel"]), T(g["gravity"]), float(g["dt"]))

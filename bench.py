@@ -564,6 +564,103 @@ def main():
         finally:
             shutil.rmtree(root, ignore_errors=True)
 
+    # ---- extras: BASELINE configs[3] / [4] at one GPU (eval_e2e.py:58-134 is the loop).  (a) one 800 x 800 frame of the bunny-shaped
+    # cloud in RANDOM index order (no spatial coherence of the index: the hardest regime of the first-K search), fp32;
+    # (b) the honeycone body: transition step -> grid rebuild -> 800 x 800 render of the PREDICTED cloud on the fp16-MFMA path,
+    # 24 frames from the initial state.  Each with the executed MLP rows and the MLP's fraction of ITS matrix peak.
+    cfg45_extra = None
+    if args.workload == "render" and not args.no_extras and image == 400 and world == 1:
+        from neurofluid_amd import ray_utils, synthetic
+        rays8 = ray_utils.get_rays_cpu(800, 800, synthetic.camera_focal(800), scene["c2w"]).view(-1, 6).to(dev)
+        n8 = rays8.shape[0]
+
+        def timed_frames(fn, n_warm, n_timed):
+            for _ in range(n_warm):
+                fn()
+            sync()
+            ops.PROFILE = {"mlp": [], "rows": []}
+            ts = []
+            for _ in range(n_timed):
+                t6 = time.perf_counter()
+                fn()
+                sync()
+                ts.append(time.perf_counter() - t6)
+            pr = ops.PROFILE
+            ops.PROFILE = None
+            ms = sum(a.elapsed_time(b) for a, b in pr["mlp"])
+            rws = sum(int(r.item()) if torch.is_tensor(r) else int(r) for r in pr["rows"])
+            return ts, ms, rws
+
+        # (a) config 4's body, fp32
+        Pb = synthetic.shaped_particles("bunny", order="random").to(dev)
+        net_b = RenderNet(renderer_cfg(), 9.0, 13.0)
+        net_b.load_state_dict(scene["nerf_state"], strict=True)
+        net_b = net_b.to(dev)
+
+        def frame_b():
+            with torch.no_grad():
+                net_b.invalidate_grid()
+                return render_image(net_b, Pb, n8, roc, rays8, None, None, iseval=True, ray_chunk=1024, gather=False, device_chunk=device_chunk)
+        ts, ms, rws = timed_frames(frame_b, 3, 3)
+        dtb = sorted(ts)[1]
+        tfb = rws * MLP_FLOP_PER_ROW / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        bunny = {"workload": "one 800x800 frame (640 000 rays) of the bunny-shaped cloud, %d particles in random index order, grid rebuilt "
+                             "every frame, fp32 path" % Pb.shape[0],
+                 "ms_per_frame": dtb * 1e3, "rays_per_sec": n8 / dtb, "executed_mlp_rows_per_frame": rws / 3,
+                 "roofline": {"bound": "mfma", "kernel": "k_mlp_fwd_l", "achieved": tfb, "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": tfb / F32_MATRIX_PEAK_TFLOPS, "mlp_ms_per_frame": ms / 3, "flop_per_row": MLP_FLOP_PER_ROW}}
+        del net_b
+        # (b) config 5's body: rollout + fp16 render of the predicted cloud
+        Ph = synthetic.shaped_particles("honeycone", order="random").to(dev)
+        cfg16 = renderer_cfg(); cfg16["mlp_dtype"] = "fp16"
+        net_h = RenderNet(cfg16, 9.0, 13.0)
+        net_h.load_state_dict(scene["nerf_state"], strict=True)
+        net_h = net_h.to(dev)
+        pn_h = ParticleNet(gravity=(0, 0, -9.81))
+        pn_h.load_state_dict(scene["trans_state"], strict=True)
+        pn_h = pn_h.to(dev)
+        n_roll = 24
+        hst = {}
+
+        def rollout():
+            pos, vel = Ph.clone(), torch.zeros_like(Ph)
+            per = []
+            with torch.no_grad():
+                for _ in range(n_roll):
+                    t7 = time.perf_counter()
+                    pos, vel, _ = pn_h(pos, vel, box, bn)
+                    out_h = render_image(net_h, pos, n8, roc, rays8, None, None, iseval=True, ray_chunk=1024, gather=False,
+                                         device_chunk=device_chunk)
+                    sync()
+                    per.append(time.perf_counter() - t7)
+            hst["per"], hst["final"], hst["hit"] = per, pos, float((out_h["mask_1"] > 0).float().mean())
+        rollout()                               # learns row capacities / pitches along the trajectory
+        redo0, ovf0 = getattr(net_h, "capacity_redos", 0), getattr(pn_h, "fused_overflows", 0)
+        sync()
+        ops.PROFILE = {"mlp": [], "rows": []}
+        rollout()
+        prh = ops.PROFILE
+        ops.PROFILE = None
+        msh = sum(a.elapsed_time(b) for a, b in prh["mlp"])
+        rwh = sum(int(r.item()) if torch.is_tensor(r) else int(r) for r in prh["rows"])
+        tfh = rwh * MLP_FLOP_PER_ROW / (msh * 1e-3) / 1e12 if msh > 0 else 0.0
+        per = hst["per"]
+        honey = {"workload": "honeycone body (%d particles, random index order): %d frames of ParticleNet step -> grid rebuild -> 800x800 "
+                             "render (640 000 rays) of the PREDICTED cloud, fp16-MFMA MLP (fp32 accumulate); second pass over the "
+                             "trajectory (the first learnt the row capacities)" % (Ph.shape[0], n_roll),
+                 "ms_per_frame_median": sorted(per)[len(per) // 2] * 1e3, "ms_per_frame_mean": sum(per) / len(per) * 1e3,
+                 "ms_per_frame_first_last": [round(per[0] * 1e3, 3), round(per[-1] * 1e3, 3)],
+                 "rays_per_sec": n8 * len(per) / sum(per), "executed_mlp_rows_per_frame": rwh / n_roll,
+                 "fraction_of_rays_hitting_the_body_last_frame": hst["hit"],
+                 "transition_steps_redone_on_the_exact_path": int(getattr(pn_h, "fused_overflows", 0) - ovf0),
+                 "renderer_calls_redone_for_row_capacity": int(getattr(net_h, "capacity_redos", 0) - redo0),
+                 "first_pass": {"transition_steps_redone": int(ovf0), "renderer_calls_redone": int(redo0)},
+                 "roofline": {"bound": "mfma", "kernel": "k_mlp_fwd_h2 (v_mfma_f32_32x32x16_f16)", "achieved": tfh, "peak": F16_MATRIX_PEAK_TFLOPS,
+                              "unit": "TFLOP/s", "frac": tfh / F16_MATRIX_PEAK_TFLOPS, "mlp_ms_per_frame": msh / n_roll,
+                              "flop_per_row": MLP_FLOP_PER_ROW}}
+        cfg45_extra = {"bunny_800_fp32": bunny, "honeycone_800_fp16_rollout": honey}
+        del net_h, pn_h, rays8
+
     # ---- extra: BASELINE configs[1] (train_renderer.py step: 4 views x 1024 rays, fwd + bwd + Adam) on this rank
     if args.workload == "render" and not args.no_extras and image == 400:
         from neurofluid_amd.train_step import make_train_step
@@ -616,6 +713,8 @@ def main():
                "max_over_mean": balance["max_over_mean"] if balance else None,
                "fp16_mfma_path": fp16_extra, "split_precision_path": split_extra,
                "train_step": train_extra, "train_e2e_step": e2e_extra, "coupled_moving_cloud": coupled_extra}
+        if cfg45_extra:
+            res.update(cfg45_extra)
         if single_dev and world > 1:
             res["single_device_emulation"] = ("NF_BENCH_SINGLE_DEVICE=1: %d ranks time-share ONE GPU over gloo; control flow and "
                                               "load-balance accounting are real, `value` is not a scaling measurement" % world)

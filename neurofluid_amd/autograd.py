@@ -92,6 +92,7 @@ def _run_passes(net, particles, ro, rays, white_bg, fine, save_acts, _retry=Fals
             ops.PROFILE["rows"] = [(known[id(r)] if id(r) in known else int(r.item())) if torch.is_tensor(r) else r
                                    for r in ops.PROFILE["rows"]]
         if overflow:
+            net.capacity_redos = getattr(net, "capacity_redos", 0) + 1        # (diagnostic: bench.py reports it for rollouts)
             return _run_passes(net, particles, ro, rays, white_bg, fine, save_acts, _retry=True, use_disp=use_disp, noise_std=noise_std,
                                _noise=_noise, perturb=perturb)
     return p0, p1, rays_c, ro_c, grid

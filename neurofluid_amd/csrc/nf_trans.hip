@@ -614,7 +614,11 @@ extern "C" int nf_trans_front(const void* fluid_grid, const void* box_grid, cons
     const int per = TF_WAVES, iters = (n + ncu * per - 1) / (ncu * per);
     int blocks = (n + per * iters - 1) / (per * iters);
     if (blocks < 1) blocks = 1;
+#ifdef TF_AB_NO_BOX
+    hipLaunchKernelGGL(k_trans_front, dim3(blocks, 1), dim3(64 * TF_WAVES), 0, (hipStream_t)stream, A);
+#else
     hipLaunchKernelGGL(k_trans_front, dim3(blocks, 2), dim3(64 * TF_WAVES), 0, (hipStream_t)stream, A);
+#endif
     NF_CHECK_LAUNCH();
     return NF_OK;
 }

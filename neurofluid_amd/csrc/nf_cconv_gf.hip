@@ -191,7 +191,20 @@ __global__ void __launch_bounds__(GF_THREADS) k_cconv_gf(GfArgs A)
         // Two operand buffers in STATIC ping-pong (the parity is a template argument): copying a prefetched register into
         // the "current" one would wait for the load it was meant to hide.
         float4 Bf[2][QW][NB], Af[2][QW];
+#if defined(GF_AB_NO_BLOAD) || defined(GF_AB_NO_ALOAD)
+#pragma unroll
+        for (int z1 = 0; z1 < 2; ++z1)
+#pragma unroll
+            for (int z2 = 0; z2 < QW; ++z2) {
+                Af[z1][z2] = make_float4(1.f + lane, 2.f, 3.f, 4.f);
+#pragma unroll
+                for (int z3 = 0; z3 < NB; ++z3) Bf[z1][z2][z3] = make_float4(0.5f, 0.25f + lane, 0.125f, 1.f);
+            }
+#endif
         auto load_b = [&](int node, float4 (&b)[QW][NB]) {
+#ifdef GF_AB_NO_BLOAD
+            return;
+#endif
 #pragma unroll
             for (int gq = 0; gq < QW; ++gq)
 #pragma unroll
@@ -199,6 +212,9 @@ __global__ void __launch_bounds__(GF_THREADS) k_cconv_gf(GfArgs A)
                     b[gq][nb] = wp4[((size_t)(node * (CIN / 8) + kq * QW + gq) * NB + nb) * 64 + lane];
         };
         auto load_a = [&](const float* Zc, float4 (&a)[QW]) {
+#ifdef GF_AB_NO_ALOAD
+            return;
+#endif
 #pragma unroll
             for (int gq = 0; gq < QW; ++gq) a[gq] = *(const float4*)(Zc + 8 * (kq * QW + gq));
         };
@@ -905,12 +921,8 @@ extern "C" int nf_trans_step(const nf_trans_step_t* s, const float* pos, const f
                              float* vel_c, int32_t* host_flag3, int step_id, nf_stream_t stream)
 {
     NF_CHECK_ARG(s && pos && vel && num_nbrs && pos_c && vel_c, "null pointer");
-    int rc = nf_trans_prepare(pos, vel, s->gravity, s->dt, s->n, s->radius, s->bbox, s->grid_ws, s->grid_ws_bytes, s->pos_new,
-                              s->vel_new, s->feats, stream);
-    if (rc != NF_OK) return rc;
-    rc = nf_trans_front(s->grid_ws, s->box_grid, s->pos_new, s->feats, s->box_feats, s->n, s->radius, s->extent, s->use_window,
-                        s->pitch_f, s->pitch_b, s->counts2, num_nbrs, s->idx_f, s->d2_f, s->roff, s->ent, s->k_fluid, s->b_fluid,
-                        s->k_obst, s->b_obst, s->dense0_w, s->dense0_b, s->a0, 1, s->overflow2, host_flag3, s->done_counter, step_id, stream);
+    // stage 1 (grid build beside the container half) + the fluid half of the front (nf_trans.hip)
+    int rc = nf_trans_stage12(s, pos, vel, num_nbrs, host_flag3, step_id, stream);
     if (rc != NF_OK) return rc;
     // every layer reads relu(previous layer) (models/transmodel.py:124): the producers of a0 / a1 / a2 store the activated
     // values (a0r, a1r, a2r), a1 itself is kept for conv2's residual

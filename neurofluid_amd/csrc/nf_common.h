@@ -58,6 +58,11 @@ struct NfGridHeader {
     int off_dil_pos;     // float4[sum cell_dil] (<= 27 n): xyz + index bits, ascending ORIGINAL index inside each list
     int off_dil_box;     // 2 x float4 per 16 consecutive dil_pos entries: {lo.xyz, -} {hi.xyz, -} (chunk AABB)
     unsigned pt_lo[3], pt_hi[3];   // exact AABB of the points (order-preserving uint encoding; device-written at build)
+    // The cell lists cover the SUB-BOX [sub0, sub0 + subd) of the grid's cells (cell coordinates are always computed on the full
+    // grid: origin / inv_cell / dims): cell_start is indexed ((z - sub0z) * subd_y + (y - sub0y)) * subd_x + (x - sub0x) and holds
+    // subd_x * subd_y * subd_z + 1 entries.  Ordinary builds: sub0 = 0, subd = dims.  The transition step's build
+    // (nf_trans.hip:k_trans_stage1) bins on the static container grid and lists only the cells the cloud occupies.
+    int sub0[3], subd[3];
 };
 
 // order-preserving float <-> uint (atomicMin / atomicMax on floats of either sign)
@@ -68,6 +73,7 @@ struct NfGridView {
     float ox, oy, oz;
     float icx, icy, icz;
     int dx, dy, dz;
+    int s0x, s0y, s0z, sdx, sdy, sdz;      // sub-box of listed cells (NfGridHeader::sub0 / subd)
     int n_points;
     const int* cell_start;
     const int* cell_dil;
@@ -89,6 +95,8 @@ __device__ __forceinline__ NfGridView nf_grid_view(const void* ws)
     v.ox = h->origin[0]; v.oy = h->origin[1]; v.oz = h->origin[2];
     v.icx = h->inv_cell[0]; v.icy = h->inv_cell[1]; v.icz = h->inv_cell[2];
     v.dx = h->dims[0]; v.dy = h->dims[1]; v.dz = h->dims[2];
+    v.s0x = h->sub0[0]; v.s0y = h->sub0[1]; v.s0z = h->sub0[2];
+    v.sdx = h->subd[0]; v.sdy = h->subd[1]; v.sdz = h->subd[2];
     v.n_points = h->n_points;
     v.cell_start = (const int*)(b + h->off_cell_start);
     v.cell_dil = (const int*)(b + h->off_cell_dil);
@@ -217,3 +225,6 @@ __device__ __forceinline__ int firstk_search(const NfGridView& g, float qx, floa
 
 // host-side helper shared by the grid functions
 int nf_grid_make_header(int n_points, float cell, const float bbox[6], NfGridHeader* h, size_t* total_bytes);
+// the first two launches of nf_trans_step (nf_trans.hip): grid build beside the container half, then the fluid half of the front
+int nf_trans_stage12(const nf_trans_step_t* s, const float* pos, const float* vel, float* num_nbrs, int32_t* host_flag3, int step_id,
+                     nf_stream_t stream);

@@ -173,6 +173,8 @@ int nf_grid_make_header(int n, float cell, const float bbox[6], NfGridHeader* h,
         h->origin[d] = lo;
         h->inv_cell[d] = 1.0f / c;
         h->dims[d] = dim;
+        h->sub0[d] = 0;
+        h->subd[d] = dim;
         cells *= dim;
     }
     h->n_points = n;

@@ -10,15 +10,17 @@
 // THAT step on the exact CSR path before ParticleNet.forward returns (neurofluid_amd/transmodel.py).
 #include "nf_common.h"
 #include <math.h>
+#include <string.h>
 
 #define TP_BLOCK 1024
 #define TP_MAX_PER_THREAD 16            // n <= 16 384 particles
 #define TP_MAX_LDS_INTS 39936           // cell counters + the scatter list, 156 KB of LDS: n_cells + n_points <= this
+#define TS_MAX_LDS_INTS 38912           // the same for k_trans_stage1 (152 KB dynamic next to 5.3 KB of static LDS)
 
 extern "C" int nf_trans_prepare_limits(int* max_points, int* max_cells)
 {
     if (max_points) *max_points = TP_BLOCK * TP_MAX_PER_THREAD;
-    if (max_cells) *max_cells = TP_MAX_LDS_INTS;     /* n_cells + n_points must not exceed this */
+    if (max_cells) *max_cells = TS_MAX_LDS_INTS;     /* n_cells + n_points must not exceed this */
     return NF_OK;
 }
 
@@ -81,7 +83,7 @@ __global__ void __launch_bounds__(TP_BLOCK) k_trans_prepare(NfGridHeader h, void
             if (ext / c > (float)(NF_GRID_MAX_DIM - 1)) c = ext / (float)(NF_GRID_MAX_DIM - 1);
             int dim = (int)floorf(ext / c) + 1;
             dim = max(1, min(dim, min(NF_GRID_MAX_DIM, h.dims[d])));
-            hh.origin[d] = l; hh.inv_cell[d] = 1.0f / c; hh.dims[d] = dim;
+            hh.origin[d] = l; hh.inv_cell[d] = 1.0f / c; hh.dims[d] = dim; hh.sub0[d] = 0; hh.subd[d] = dim;
             ncell *= dim;
         }
         for (int d = 0; d < 3; ++d) {           // exact bounds of the points (all waves)
@@ -246,6 +248,8 @@ struct TfStage {                         // per wave
 struct TfArgs {
     const void* grid[2];                 // 0: fluid (integrated positions), 1: container
     const float* q;                      // integrated positions (n x 3)
+    const float* pos; const float* vel;  // FROM_STATE bodies integrate the positions themselves
+    float gx, gy, gz, dt;
     const float* feats_f;                // fluid features [1, v] (n x 4)
     const float* feats_b;                // container normals (nb x 3)
     int n;
@@ -309,51 +313,136 @@ __device__ __forceinline__ TfPair tf_pair(const TfStage& st, int t, float qx, fl
     return P;
 }
 
-__global__ void __launch_bounds__(64 * TF_WAVES, 4) k_trans_front(TfArgs A)
+// LDS regions of the front body (static __shared__ in k_trans_front, carved from the dynamic block in k_trans_stage1)
+struct TfLds {
+    float* Ks;                          // 64 * CI * 32 floats: the layer-0 filter of this cloud
+    TfStage* stage;                     // [TF_WAVES]
+    float* patch;                       // [TF_WAVES][256]
+    int* rcnt; int* rcur; int* rbase;   // [TF_WAVES][16], [TF_WAVES][16], [TF_WAVES][17]
+};
+#define TF_LDS_BYTES(CI, NW) ((size_t)64 * (CI) * 32 * 4 + sizeof(TfStage) * (NW) + (size_t)(NW) * 256 * 4 + (size_t)(NW) * (16 + 16 + 17) * 4)
+
+template <int NW>
+__device__ __forceinline__ TfLds tf_carve(char* base, int ci)
 {
-    __shared__ float Ks[64 * 4 * 32];
-    __shared__ TfStage stage[TF_WAVES];
-    __shared__ float patch[TF_WAVES][256];
-    __shared__ int rcnt[TF_WAVES][16], rcur[TF_WAVES][16], rbase[TF_WAVES][17];
-    const int which = blockIdx.y;
-    {
-        const float4* ksrc = (const float4*)(which ? A.k_obst : A.k_fluid);
-        const int kn4 = (which ? 64 * 3 * 32 : 64 * 4 * 32) / 4;
-        for (int t = threadIdx.x; t < kn4; t += 64 * TF_WAVES) ((float4*)Ks)[t] = ksrc[t];
-    }
-    __syncthreads();
+    TfLds L;
+    L.Ks = (float*)base; base += (size_t)64 * ci * 32 * 4;
+    L.stage = (TfStage*)base; base += sizeof(TfStage) * NW;
+    L.patch = (float*)base; base += (size_t)NW * 256 * 4;
+    L.rcnt = (int*)base; base += NW * 16 * 4;
+    L.rcur = (int*)base; base += NW * 16 * 4;
+    L.rbase = (int*)base;
+    return L;
+}
+
+// The front body of one cloud (WHICH = 0 the fluid, 1 the container) for the particles blk * TF_WAVES + wave, + nblk * TF_WAVES, ...
+// FROM_STATE: the query positions are integrated here from (pos, vel) — the same expressions as the grid build, bit for bit — so
+// that the container half can run BESIDE the fluid grid build instead of behind it (k_trans_stage1).
+// Latency: a particle's chain is position -> cell -> row ranges -> candidates -> (pair data) -> neighbour features, four dependent
+// global round trips; with ~3 particles per wave that chain, not the arithmetic, was a third of the kernel.  The position of the
+// particle after next and the row ranges of the next one are requested while the current one is processed, and the filter is
+// staged behind the first requests instead of in front of them.
+template <int WHICH, bool FROM_STATE, int NW>
+__device__ __forceinline__ void tf_body(const TfArgs& A, const TfLds& L, int blk, int nblk)
+{
+    constexpr int CI = WHICH ? 3 : 4;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    TfStage& st = stage[wv];
-    const int pitch = which ? A.pitch_b : A.pitch_f;
+    TfStage& st = L.stage[wv];
+    float* const patch = L.patch + wv * 256;
+    int* const rcnt = L.rcnt + wv * 16;
+    int* const rcur = L.rcur + wv * 16;
+    int* const rbase = L.rbase + wv * 17;
+    const float* const Ks = L.Ks;
+    const int pitch = WHICH ? A.pitch_b : A.pitch_f;
     const int cap = min(pitch, TF_MAXP);
-    const NfGridView g = nf_grid_view(A.grid[which]);
+    const NfGridView g = nf_grid_view(A.grid[WHICH]);
     const unsigned long long lt = (1ull << lane) - 1ull;
     const float radius = 0.5f * A.extent, inv_r2 = 1.f / (radius * radius), scale = 2.f / A.extent;
-    const int CI = which ? 3 : 4;
-    for (int i = blockIdx.x * TF_WAVES + wv; i < A.n; i += gridDim.x * TF_WAVES) {
-        if (lane < 16) { rcnt[wv][lane] = 0; rcur[wv][lane] = 0; }
-        const float qx = A.q[3 * i], qy = A.q[3 * i + 1], qz = A.q[3 * i + 2];
-        const int cx = nf_cell_coord(qx, g.ox, g.icx, g.dx);
-        const int cy = nf_cell_coord(qy, g.oy, g.icy, g.dy);
-        const int cz = nf_cell_coord(qz, g.oz, g.icz, g.dz);
-        // ---- pass 1: the sweep (cell-major, the order of k_trans_search / nf_radius_fill).  The ranges of the 9 (z, y) rows are
-        // fetched by 9 lanes at once and the first 64 candidates of EVERY row are requested before the first is looked at:
-        // two dependent round trips for the whole neighbourhood instead of two per row.
-        int rs = 0, re = 0;
-        if (lane < 9) {
-            const int z = cz - 1 + lane / 3, y = cy - 1 + lane % 3;
-            if (z >= 0 && z < g.dz && y >= 0 && y < g.dy) {
-                const int r0 = (z * g.dy + y) * g.dx;
-                rs = g.cell_start[r0 + max(cx - 1, 0)];
-                re = g.cell_start[r0 + min(cx + 1, g.dx - 1) + 1];
+    const int stride = nblk * NW;
+    int i = blk * NW + wv;
+
+    auto load_q = [&](int ii, float& x, float& y, float& z) __attribute__((always_inline)) {
+        x = y = z = 0.f;
+        if (ii < A.n) {
+            if constexpr (FROM_STATE) {
+                const float g3[3] = {A.gx, A.gy, A.gz};
+                float o[3];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const float v = A.vel[3 * (size_t)ii + d];
+                    const float vn = v + g3[d] * A.dt;                    // k_trans_stage1's / k_trans_integrate's expressions
+                    o[d] = A.pos[3 * (size_t)ii + d] + (v + vn) / 2 * A.dt;
+                }
+                x = o[0]; y = o[1]; z = o[2];
+            } else {
+                x = A.q[3 * (size_t)ii]; y = A.q[3 * (size_t)ii + 1]; z = A.q[3 * (size_t)ii + 2];
             }
         }
+    };
+    // row ranges of the 9 (z, y) rows around the query's cell (lanes 0..8); cells are listed for the grid's sub-box only
+    auto load_ranges = [&](float x, float y, float z, int& rs, int& re) __attribute__((always_inline)) {
+        const int cx = min(max(nf_cell_coord(x, g.ox, g.icx, g.dx) - g.s0x, 0), g.sdx - 1);
+        const int cy = min(max(nf_cell_coord(y, g.oy, g.icy, g.dy) - g.s0y, 0), g.sdy - 1);
+        const int cz = min(max(nf_cell_coord(z, g.oz, g.icz, g.dz) - g.s0z, 0), g.sdz - 1);
+        rs = re = 0;
+        if (lane < 9) {
+            const int zz = cz - 1 + lane / 3, yy = cy - 1 + lane % 3;
+            if (zz >= 0 && zz < g.sdz && yy >= 0 && yy < g.sdy) {
+                const int r0 = (zz * g.sdy + yy) * g.sdx;
+                rs = g.cell_start[r0 + max(cx - 1, 0)];
+                re = g.cell_start[r0 + min(cx + 1, g.sdx - 1) + 1];
+            }
+        }
+    };
+    float qx, qy, qz, q1x, q1y, q1z, q2x, q2y, q2z;
+    int rs = 0, re = 0;
+    bool first_particle = true;
+    load_q(i, qx, qy, qz);
+#ifdef TF_AB_READAHEAD
+    load_q(i + stride, q1x, q1y, q1z);
+#else
+    q1x = q1y = q1z = 0.f;
+#endif
+    {   // the layer-0 filter of this cloud: requested now, parked in LDS behind the first ranges request
+        const float4* ksrc = (const float4*)(WHICH ? A.k_obst : A.k_fluid);
+        constexpr int KN4 = 64 * CI * 32 / 4, PER = (KN4 + 64 * NW - 1) / (64 * NW);
+        float4 kv[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int t = threadIdx.x + u * 64 * NW;
+            kv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t < KN4) kv[u] = ksrc[t];
+        }
+        if (g.sdx > 0 && i < A.n) load_ranges(qx, qy, qz, rs, re);
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int t = threadIdx.x + u * 64 * NW;
+            if (t < KN4) ((float4*)L.Ks)[t] = kv[u];
+        }
+        __syncthreads();
+    }
+    for (; i < A.n; i += stride) {
+        // requests for the particles ahead: the position two ahead, the row ranges one ahead
+        int rs1 = 0, re1 = 0;
+#ifndef TF_AB_READAHEAD
+        // (default since the A/B of round 4: the read-ahead made the kernel SLOWER, 50.1 vs 45.9 us — the requests of the next
+        // particles queue in front of the current one's candidates, and their registers cost the sweep its allocation)
+        if (!first_particle) { load_q(i, qx, qy, qz); if (g.sdx > 0) load_ranges(qx, qy, qz, rs, re); }
+        first_particle = false;
+        q2x = q2y = q2z = 0.f;
+#else
+        load_q(i + 2 * stride, q2x, q2y, q2z);
+        if (g.sdx > 0 && i + stride < A.n) load_ranges(q1x, q1y, q1z, rs1, re1);
+#endif
+        if (lane < 16) { rcnt[lane] = 0; rcur[lane] = 0; }
         int cnt = 0;
 #ifdef TF_AB_SKIP_ALL
-        if (lane == 0) A.a0[(size_t)i * 96 + which] = (float)rs;
+        if (lane == 0) A.a0[(size_t)i * 96 + WHICH] = (float)rs;
+        qx = q1x; qy = q1y; qz = q1z; q1x = q2x; q1y = q2y; q1z = q2z; rs = rs1; re = re1;
         continue;
 #endif
-        // rows in two groups (5 + 4): the first batches of a group are in flight together
+        // ---- pass 1: the sweep (cell-major, the order of nf_radius_fill).  The first 64 candidates of EVERY row of a group are
+        // requested before the first is looked at
 #pragma unroll
         for (int grp = 0; grp < 2; ++grp) {
             const int R0 = grp ? 5 : 0, RN = grp ? 4 : 5;
@@ -394,14 +483,22 @@ __global__ void __launch_bounds__(64 * TF_WAVES, 4) k_trans_front(TfArgs A)
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) {
-            A.counts2[(size_t)which * A.n + i] = cnt;
-            if (!which) A.num_nbrs[i] = (float)cnt;
+            A.counts2[(size_t)WHICH * A.n + i] = cnt;
+            if (!WHICH) A.num_nbrs[i] = (float)cnt;
             if (cnt > pitch) {
-                atomicMax(A.overflow2 + which, (unsigned long long)cnt);
-                if (A.host_flag) { A.host_flag[which] = cnt; __threadfence_system(); }      // (any overflowing count will do as the flag)
+                atomicMax(A.overflow2 + WHICH, (unsigned long long)cnt);
+                if (A.host_flag) { A.host_flag[WHICH] = cnt; __threadfence_system(); }      // (any overflowing count will do as the flag)
             }
         }
         const int np = min(cnt, cap);
+        const float cqx = qx, cqy = qy, cqz = qz;
+        qx = q1x; qy = q1y; qz = q1z; q1x = q2x; q1y = q2y; q1z = q2z; rs = rs1; re = re1;      // rotate the read-ahead
+        float* orow = A.a0 + (size_t)i * 96;
+        if (WHICH && np == 0) {
+            // no container point in reach (the large majority of a fluid body): conv0_obstacle = its bias
+            if (lane < 32) { const float v = A.b_obst[lane]; orow[lane] = A.relu_out ? fmaxf(v, 0.f) : v; }
+            continue;
+        }
         // ---- pass 2 (lane = pair, dense): interpolation data of up to two chunks of 64 pairs (kept in registers for the passes
         // below), the pitched neighbour rows, row counts
         TfPair P[2];
@@ -410,11 +507,11 @@ __global__ void __launch_bounds__(64 * TF_WAVES, 4) k_trans_front(TfArgs A)
             const int t = 64 * c + lane;
             P[c].j = 0; P[c].bx = P[c].by = P[c].bz = 0; P[c].fx = P[c].fy = P[c].fz = P[c].imp = 0.f;
             if (t < np) {
-                P[c] = tf_pair(st, t, qx, qy, qz, scale, inv_r2, A.use_window);
-                if (!which) {
+                P[c] = tf_pair(st, t, cqx, cqy, cqz, scale, inv_r2, A.use_window);
+                if (!WHICH) {
                     A.idx_f[(int64_t)i * pitch + t] = P[c].j; A.d2_f[(int64_t)i * pitch + t] = st.d2[t];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) atomicAdd(&rcnt[wv][(P[c].bz + (r >> 1)) * 4 + P[c].by + (r & 1)], 1);
+                    for (int r = 0; r < 4; ++r) atomicAdd(&rcnt[(P[c].bz + (r >> 1)) * 4 + P[c].by + (r & 1)], 1);
                 }
             }
         }
@@ -454,7 +551,7 @@ __global__ void __launch_bounds__(64 * TF_WAVES, 4) k_trans_front(TfArgs A)
                     slot[k] = atomicAdd(&st.ccount[cellk[k]], 1);
                 }
                 float4 f4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (!which) f4 = *(const float4*)(A.feats_f + 4 * (size_t)Q.j);
+                if (!WHICH) f4 = *(const float4*)(A.feats_f + 4 * (size_t)Q.j);
                 else { f4.x = A.feats_b[3 * (size_t)Q.j]; f4.y = A.feats_b[3 * (size_t)Q.j + 1]; f4.z = A.feats_b[3 * (size_t)Q.j + 2]; }
                 *(float4*)st.u.feat[lane] = f4;
             }
@@ -495,20 +592,20 @@ __global__ void __launch_bounds__(64 * TF_WAVES, 4) k_trans_front(TfArgs A)
 #endif
 #pragma unroll
         for (int ci = 0; ci < 4; ++ci)
-            if (ci < CI) patch[wv][lane * CI + ci] = pacc[ci];
+            if (ci < CI) patch[lane * CI + ci] = pacc[ci];
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
-        if (!which) {
+        if (!WHICH) {
             // ---- pass 3: exclusive scan of the 16 row counts -> roff
-            int c = lane < 16 ? rcnt[wv][lane] : 0;
+            int c = lane < 16 ? rcnt[lane] : 0;
             int x = c;
 #pragma unroll
             for (int o2 = 1; o2 < 16; o2 <<= 1) { const int y = __shfl_up(x, o2, 64); if (lane >= o2) x += y; }
-            if (lane < 16) rbase[wv][lane] = x - c;
-            if (lane == 15) rbase[wv][16] = x;
+            if (lane < 16) rbase[lane] = x - c;
+            if (lane == 15) rbase[16] = x;
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_wave_barrier();
-            if (lane < 17) A.roff[(size_t)i * 20 + lane] = (uint16_t)rbase[wv][lane];
+            if (lane < 17) A.roff[(size_t)i * 20 + lane] = (uint16_t)rbase[lane];
             // ---- pass 4 (lane = pair): the four row entries of every pair; the LDS cursors advance in lane order, so a
             // bucket keeps the pair order
             uint32_t* ebase = A.ent + (size_t)i * (size_t)(4 * A.pitch_f) * 3;
@@ -524,7 +621,7 @@ __global__ void __launch_bounds__(64 * TF_WAVES, 4) k_trans_front(TfArgs A)
                         for (int r = 0; r < 4; ++r) {
                             const int dy = r & 1, dz = r >> 1;
                             const int rho = (Q.bz + dz) * 4 + Q.by + dy;
-                            const int e = rbase[wv][rho] + atomicAdd(&rcur[wv][rho], 1);
+                            const int e = rbase[rho] + atomicAdd(&rcur[rho], 1);
                             // the weights of k_pair_precompute, same expression and association
                             const float w0 = Q.imp * ((1.f - Q.fx) * (dy ? Q.fy : 1.f - Q.fy) * (dz ? Q.fz : 1.f - Q.fz));
                             const float w1 = Q.imp * (Q.fx * (dy ? Q.fy : 1.f - Q.fy) * (dz ? Q.fz : 1.f - Q.fz));
@@ -541,13 +638,12 @@ __global__ void __launch_bounds__(64 * TF_WAVES, 4) k_trans_front(TfArgs A)
         }
         // ---- layer 0: patch x filter (+ the Linear branch on the particle's own features)
         const int co = lane & 31, half = lane >> 5;
-        float* orow = A.a0 + (size_t)i * 96;
 #ifdef TF_AB_SKIP_GEMV
-        if (lane == 0) orow[which] = patch[wv][5];
+        if (lane == 0) orow[WHICH] = patch[5];
         continue;
 #endif
-        if (!which) {
-            const float af = tf_patch_times_filter<4>(patch[wv], Ks, co, half);
+        if (!WHICH) {
+            const float af = tf_patch_times_filter<4>(patch, Ks, co, half);
             if (half == 0) { const float v = af + A.b_fluid[co]; orow[32 + co] = A.relu_out ? fmaxf(v, 0.f) : v; }
             else {
                 float s2 = A.dense_b[co];
@@ -556,27 +652,62 @@ __global__ void __launch_bounds__(64 * TF_WAVES, 4) k_trans_front(TfArgs A)
                 orow[64 + co] = A.relu_out ? fmaxf(s2, 0.f) : s2;
             }
         } else {
-            const float ao = tf_patch_times_filter<3>(patch[wv], Ks, co, half);
+            const float ao = tf_patch_times_filter<3>(patch, Ks, co, half);
             if (half == 0) { const float v = ao + A.b_obst[co]; orow[co] = A.relu_out ? fmaxf(v, 0.f) : v; }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();          // the next particle of this wave reuses the stage / patch / counters
     }
-    if (A.host_flag) {
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            __threadfence_system();                // this workgroup's overflow words (if any) before its arrival
-            const unsigned old = atomicAdd(A.done_ctr, 1u);
-            if (old == gridDim.x * gridDim.y - 1) {
-                *A.done_ctr = 0u;
-                A.host_flag[2] = A.step_id;
-                __threadfence_system();
-            }
+}
+
+// the completion word: the LAST workgroup of the launch to arrive writes step_id into the pinned host word
+__device__ __forceinline__ void tf_arrive(const TfArgs& A, unsigned total)
+{
+    if (!A.host_flag) return;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence_system();                // this workgroup's overflow words (if any) before its arrival
+        const unsigned old = atomicAdd(A.done_ctr, 1u);
+        if (old == total - 1) {
+            *A.done_ctr = 0u;
+            A.host_flag[2] = A.step_id;
+            __threadfence_system();
         }
     }
 }
 
+// blockIdx.y = cloud when clouds == 3 (the stand-alone entry point: both halves in one launch), else the cloud clouds - 1
+__global__ void __launch_bounds__(64 * TF_WAVES, 4) k_trans_front(TfArgs A, int clouds)
+{
+    __shared__ __attribute__((aligned(16))) char lds[TF_LDS_BYTES(4, TF_WAVES)];
+    const int which = clouds == 3 ? (int)blockIdx.y : clouds - 1;
+    if (which == 0) tf_body<0, false, TF_WAVES>(A, tf_carve<TF_WAVES>(lds, 4), blockIdx.x, gridDim.x);
+    else tf_body<1, false, TF_WAVES>(A, tf_carve<TF_WAVES>(lds, 3), blockIdx.x, gridDim.x);
+    tf_arrive(A, gridDim.x * gridDim.y);
+}
+
 extern "C" int nf_trans_front_max_pitch(void) { return TF_MAXP; }
+
+static int tf_ncu()
+{   // (cached per device: hipGetDeviceProperties costs tens of microseconds, this runs once per step)
+    static int cu_of[64] = {};
+    int dev = 0, ncu = 256;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+        int v = __atomic_load_n(&cu_of[dev], __ATOMIC_RELAXED);
+        if (!v && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) __atomic_store_n(&cu_of[dev], v, __ATOMIC_RELAXED);
+        if (v > 0) ncu = v;
+    }
+    return ncu;
+}
+
+// two workgroups of 8 waves fit a CU (61 KB of LDS each: the filter is staged once per workgroup): size the grid so that
+// every workgroup is resident at once and each wave walks the same number of particles
+static int tf_blocks(int n)
+{
+    const int ncu = tf_ncu(), per = TF_WAVES, iters = (n + ncu * per - 1) / (ncu * per);
+    const int blocks = (n + per * iters - 1) / (per * iters);
+    return blocks < 1 ? 1 : blocks;
+}
 
 extern "C" int nf_trans_front(const void* fluid_grid, const void* box_grid, const float* queries, const float* fluid_feats,
                               const float* box_feats, int n, float radius, float extent, int use_window, int pitch_fluid,
@@ -591,34 +722,282 @@ extern "C" int nf_trans_front(const void* fluid_grid, const void* box_grid, cons
                  "null pointer");
     NF_CHECK_ARG(n > 0 && radius > 0.f && extent > 0.f, "bad n/radius/extent");
     NF_CHECK_ARG(pitch_fluid >= 1 && pitch_fluid <= TF_MAXP && pitch_box >= 1 && pitch_box <= TF_MAXP, "pitch must be in [1, nf_trans_front_max_pitch()]");
+    NF_CHECK_ARG(!host_flag3 || done_counter, "the completion word needs the workgroup counter");
     TfArgs A;
+    memset(&A, 0, sizeof(A));
     A.grid[0] = fluid_grid; A.grid[1] = box_grid; A.q = queries; A.feats_f = fluid_feats; A.feats_b = box_feats; A.n = n;
     A.r2 = radius * radius; A.extent = extent; A.use_window = use_window; A.pitch_f = pitch_fluid; A.pitch_b = pitch_box;
     A.relu_out = relu_out;
     A.counts2 = counts2; A.num_nbrs = num_fluid_nbrs; A.idx_f = idx_f; A.d2_f = d2_f; A.roff = roff; A.ent = entries;
     A.k_fluid = kernel_fluid; A.b_fluid = bias_fluid; A.k_obst = kernel_obstacle; A.b_obst = bias_obstacle;
     A.dense_w = dense_w; A.dense_b = dense_b; A.a0 = out96; A.overflow2 = (unsigned long long*)overflow2;
-    NF_CHECK_ARG(!host_flag3 || done_counter, "the completion word needs the workgroup counter");
     A.host_flag = (volatile int*)host_flag3; A.done_ctr = done_counter; A.step_id = step_id;
-    // two workgroups of 8 waves fit a CU (61 KB of LDS each: the filter is staged once per workgroup): size the grid so that
-    // every workgroup is resident at once and each wave walks the same number of particles
-    int ncu = 256;
-    {   // (cached per device: hipGetDeviceProperties costs tens of microseconds, this runs once per step)
-        static int cu_of[64] = {};
-        int dev = 0;
-        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
-            if (!cu_of[dev]) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cu_of[dev] = v; }
-            if (cu_of[dev]) ncu = cu_of[dev];
+#ifdef TF_AB_NO_BOX
+    hipLaunchKernelGGL(k_trans_front, dim3(tf_blocks(n), 1), dim3(64 * TF_WAVES), 0, (hipStream_t)stream, A, 1);
+#else
+    hipLaunchKernelGGL(k_trans_front, dim3(tf_blocks(n), 2), dim3(64 * TF_WAVES), 0, (hipStream_t)stream, A, 3);
+#endif
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+// ================================================================================================
+// Round 4: stage 1 of the step = ONE launch that does, side by side,
+//   * workgroup 0: gravity integration (B1) + the fluid cell grid of the integrated positions (ts_build: k_trans_prepare's
+//     single-workgroup counting sort in LDS, with the per-thread particle count a TEMPLATE argument: every load of the
+//     integration is issued up front — the guarded 16-way unrolled loop of k_trans_prepare walked its 5 live iterations one
+//     global round trip after the other);
+//   * workgroups 1...: the CONTAINER half of the front kernel (box sweep + conv0_obstacle).  It needs the integrated positions
+//     only — which it computes itself from (pos, vel), bit-identical — and the static box grid, so it runs beside the grid build
+//     instead of behind it; most particles of a body have no container point in reach and leave after the sweep.
+// The fluid half (k_trans_front with clouds = 1) follows as its own launch: it needs the complete grid.
+// Measured and set aside (round 4): the grid build spread over ceil(n / 512) workgroups — binning on the static container grid
+// with returning global atomics, the occupied cell range reduced with integer atomics, the LAST workgroup to arrive (device-scope
+// ticket behind an agent-scope release / acquire) scanning the occupied sub-box and ordering each cell by original index: 31.9 us
+// against 22 us for the single workgroup.  Every hand-over is a global round trip behind a fence (release ~2-6 us, ticket, acquire,
+// the counters' exchange, the per-particle (cell, slot) reads), and the finishing workgroup still walks all n particles alone; a
+// cloud of 5 000 particles is too small for its build to be anything but a chain of latencies, and the chain is shortest when it
+// stays in one workgroup's LDS.  (The sub-box fields of the grid header — cell lists for a sub-range of the grid's cells — were
+// built for it and are kept: ordinary builds set them to the whole grid.)
+// ================================================================================================
+#define TS_BLOCK 1024
+#define TS_WAVES (TS_BLOCK / 64)
+
+struct TsArgs {
+    NfGridHeader h;                        // the container grid (host-made): bounds + workspace offsets
+    void* ws;
+    const float* pos; const float* vel;
+    float gx, gy, gz, dt, cell;
+    float* pos_new; float* vel_new; float* feats4;
+    int per;                               // particles per thread of workgroup 0: ceil(n / TS_BLOCK)
+};
+
+template <int PER>
+__device__ __forceinline__ void ts_build(const TsArgs& S, char* lds)
+{
+    int* cells = (int*)lds;                // n_cells counters -> starts -> ends, then the scatter list (n_points)
+    __shared__ int s_scan[TS_WAVES];
+    __shared__ float s_red[TS_WAVES][6];
+    __shared__ NfGridHeader hh;
+    const NfGridHeader& h = S.h;
+    char* b = (char*)S.ws;
+    const int n = h.n_points, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // ---- integrate (all loads in flight at once: clamped indices, no guards); the exact bounds of the integrated cloud
+    const float g[3] = {S.gx, S.gy, S.gz};
+    float pv[PER][3], vv[PER][3];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int ic = min(u * TS_BLOCK + tid, n - 1);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { pv[u][d] = S.pos[3 * (size_t)ic + d]; vv[u][d] = S.vel[3 * (size_t)ic + d]; }
+    }
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int i = u * TS_BLOCK + tid;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float v = vv[u][d];
+            const float vn = v + g[d] * S.dt;                       // same expressions as k_trans_integrate
+            pv[u][d] = pv[u][d] + (v + vn) / 2 * S.dt;
+            vv[u][d] = vn;
+        }
+        if (i < n) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                S.pos_new[3 * (size_t)i + d] = pv[u][d];
+                S.vel_new[3 * (size_t)i + d] = vv[u][d];
+                lo[d] = fminf(lo[d], pv[u][d]); hi[d] = fmaxf(hi[d], pv[u][d]);
+            }
+            *(float4*)(S.feats4 + 4 * (size_t)i) = make_float4(1.f, vv[u][0], vv[u][1], vv[u][2]);
         }
     }
-    const int per = TF_WAVES, iters = (n + ncu * per - 1) / (ncu * per);
-    int blocks = (n + per * iters - 1) / (per * iters);
-    if (blocks < 1) blocks = 1;
-#ifdef TF_AB_NO_BOX
-    hipLaunchKernelGGL(k_trans_front, dim3(blocks, 1), dim3(64 * TF_WAVES), 0, (hipStream_t)stream, A);
-#else
-    hipLaunchKernelGGL(k_trans_front, dim3(blocks, 2), dim3(64 * TF_WAVES), 0, (hipStream_t)stream, A);
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { lo[d] = fminf(lo[d], __shfl_xor(lo[d], o, 64)); hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], o, 64)); }
+    if (lane == 0) { for (int d = 0; d < 3; ++d) { s_red[wv][d] = lo[d]; s_red[wv][3 + d] = hi[d]; } }
+#if defined(TS_AB_STOP) && TS_AB_STOP == 1
+    return;
 #endif
+    __syncthreads();
+    if (tid == 0) {
+        // The grid of THIS step hugs the cloud: the caller's bbox (the container, static: no host round trip) only bounds it —
+        // a few hundred cells instead of the container's ~29 000, which every pass below (zero, scan, store) walks.  Points
+        // outside the bbox land in border cells (the search stays exact, include/neurofluid_hip.h); the workspace offsets are
+        // those of the caller's header, computed for the larger grid.
+        NfGridHeader t = h;
+        int ncell = 1;
+        for (int d = 0; d < 3; ++d) {
+            float l = INFINITY, u2 = -INFINITY;
+            for (int w2 = 0; w2 < TS_WAVES; ++w2) { l = fminf(l, s_red[w2][d]); u2 = fmaxf(u2, s_red[w2][3 + d]); }
+            t.pt_lo[d] = nf_f2ord(l); t.pt_hi[d] = nf_f2ord(u2);          // exact bounds of the points
+            const float blo = h.origin[d], bhi = h.origin[d] + (float)h.dims[d] / h.inv_cell[d];
+            l = fminf(fmaxf(l, blo), bhi); u2 = fminf(fmaxf(u2, blo), bhi);
+            if (!(u2 >= l)) { l = blo; u2 = blo; }
+            const float ext = u2 - l;
+            float c = S.cell;
+            if (ext / c > (float)(NF_GRID_MAX_DIM - 1)) c = ext / (float)(NF_GRID_MAX_DIM - 1);
+            int dim = (int)floorf(ext / c) + 1;
+            dim = max(1, min(dim, min(NF_GRID_MAX_DIM, h.dims[d])));
+            t.origin[d] = l; t.inv_cell[d] = 1.0f / c; t.dims[d] = dim; t.sub0[d] = 0; t.subd[d] = dim;
+            ncell *= dim;
+        }
+        t.n_cells = ncell;
+        hh = t;
+        *(NfGridHeader*)S.ws = t;
+    }
+    __syncthreads();
+    const int nc = hh.n_cells;
+    int* cell_start = (int*)(b + hh.off_cell_start);
+    int* tmp_list = cells + nc;
+    int* sorted_idx = (int*)(b + hh.off_sorted_idx);
+    float4* sorted_pos = (float4*)(b + hh.off_sorted_pos);
+    for (int c = tid; c < nc; c += TS_BLOCK) cells[c] = 0;
+#if defined(TS_AB_STOP) && TS_AB_STOP == 2
+    return;
+#endif
+    __syncthreads();
+    // ---- count
+    int mycell[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int i = u * TS_BLOCK + tid;
+        mycell[u] = -1;
+        if (i < n) {
+            const int cx = nf_cell_coord(pv[u][0], hh.origin[0], hh.inv_cell[0], hh.dims[0]);
+            const int cy = nf_cell_coord(pv[u][1], hh.origin[1], hh.inv_cell[1], hh.dims[1]);
+            const int cz = nf_cell_coord(pv[u][2], hh.origin[2], hh.inv_cell[2], hh.dims[2]);
+            mycell[u] = (cz * hh.dims[1] + cy) * hh.dims[0] + cx;
+            atomicAdd(&cells[mycell[u]], 1);
+        }
+    }
+#if defined(TS_AB_STOP) && TS_AB_STOP == 3
+    return;
+#endif
+    __syncthreads();
+    // ---- exclusive scan of the cell counts (each thread a contiguous run, block scan of the run sums)
+    const int per = (nc + TS_BLOCK - 1) / TS_BLOCK;
+    const int c0 = tid * per, c1 = min(c0 + per, nc);
+    int run = 0;
+    for (int c = c0; c < c1; ++c) run += cells[c];
+    {
+        int x = run;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+        if (lane == 63) s_scan[wv] = x;
+        __syncthreads();
+        if (wv == 0) {
+            int s2 = lane < TS_WAVES ? s_scan[lane] : 0;
+#pragma unroll
+            for (int o = 1; o < TS_WAVES; o <<= 1) { const int y = __shfl_up(s2, o, 64); if (lane >= o) s2 += y; }
+            if (lane < TS_WAVES) s_scan[lane] = s2;
+        }
+        __syncthreads();
+        int base = (wv ? s_scan[wv - 1] : 0) + x - run;
+        for (int c = c0; c < c1; ++c) { const int cnt = cells[c]; cells[c] = base; cell_start[c] = base; base += cnt; }
+        if (tid == TS_BLOCK - 1) cell_start[nc] = s_scan[TS_WAVES - 1];
+    }
+#if defined(TS_AB_STOP) && TS_AB_STOP == 4
+    return;
+#endif
+    __syncthreads();
+    // ---- scatter (arrival order), cells[] ends up holding the END of every cell
+#pragma unroll
+    for (int u = 0; u < PER; ++u)
+        if (mycell[u] >= 0) tmp_list[atomicAdd(&cells[mycell[u]], 1)] = u * TS_BLOCK + tid;
+#if defined(TS_AB_STOP) && TS_AB_STOP == 5
+    return;
+#endif
+    __syncthreads();
+    // ---- stable order inside each cell: rank = number of same-cell points with a smaller original index
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int c = mycell[u];
+        if (c < 0) continue;
+        const int i = u * TS_BLOCK + tid;
+        const int s2 = c ? cells[c - 1] : 0, e = cells[c];
+        int rank = 0;
+        for (int t = s2; t < e; ++t) rank += (tmp_list[t] < i);
+        sorted_idx[s2 + rank] = i;
+        sorted_pos[s2 + rank] = make_float4(pv[u][0], pv[u][1], pv[u][2], __int_as_float(i));
+    }
+}
+
+__global__ void __launch_bounds__(TS_BLOCK) k_trans_stage1(TsArgs S, TfArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) char ts_lds[];
+    if (blockIdx.x == 0) {
+        switch (S.per) {
+            case 1: ts_build<1>(S, ts_lds); break;
+            case 2: ts_build<2>(S, ts_lds); break;
+            case 3: ts_build<3>(S, ts_lds); break;
+            case 4: ts_build<4>(S, ts_lds); break;
+            case 5: ts_build<5>(S, ts_lds); break;
+            case 6: ts_build<6>(S, ts_lds); break;
+            case 7: case 8: ts_build<8>(S, ts_lds); break;
+            case 9: case 10: case 11: case 12: ts_build<12>(S, ts_lds); break;
+            default: ts_build<16>(S, ts_lds); break;
+        }
+        return;
+    }
+    tf_body<1, true, TS_WAVES>(A, tf_carve<TS_WAVES>(ts_lds, 3), (int)blockIdx.x - 1, (int)gridDim.x - 1);
+}
+
+// nf_trans_step's first two launches (see the comment above); the caller's TfArgs carries both halves' arguments
+static int ts_launch(const TsArgs& S0, const TfArgs& A, hipStream_t st)
+{
+    TsArgs S = S0;
+    const int n = S.h.n_points;
+    S.per = (n + TS_BLOCK - 1) / TS_BLOCK;
+    const size_t lds_build = (size_t)(S.h.n_cells + n) * sizeof(int), lds_box = TF_LDS_BYTES(3, TS_WAVES);
+    const size_t lds = lds_build > lds_box ? lds_build : lds_box;
+    static bool attr_set[64] = {};
+    if (nf_first_use_on_device(attr_set))
+        hipFuncSetAttribute((const void*)k_trans_stage1, hipFuncAttributeMaxDynamicSharedMemorySize, TS_MAX_LDS_INTS * (int)sizeof(int));
+    // the container half: one workgroup of 16 waves per CU (the LDS of the grid build's workgroup sizes the launch), a particle
+    // per wave and round (most waves leave after the sweep).  (The container half raises its overflow word from here; the
+    // completion word is the fluid half's: the last launch of the front.)
+    const int ncu = tf_ncu(), per = TS_WAVES;
+    int iters = (n + ncu * per - 1) / (ncu * per);
+    if (iters < 1) iters = 1;
+#ifdef TS_AB_NO_BOX
+    const int box_wg = 0;
+#else
+    const int box_wg = (n + per * iters - 1) / (per * iters);
+#endif
+    hipLaunchKernelGGL(k_trans_stage1, dim3(1 + box_wg), dim3(TS_BLOCK), lds, st, S, A);
+    return 0;
+}
+
+int nf_trans_stage12(const nf_trans_step_t* s, const float* pos, const float* vel, float* num_nbrs, int32_t* host_flag3,
+                     int step_id, nf_stream_t stream)
+{
+    NF_CHECK_ARG(s && pos && vel && num_nbrs, "null pointer");
+    NF_CHECK_ARG(s->pitch_f >= 1 && s->pitch_f <= TF_MAXP && s->pitch_b >= 1 && s->pitch_b <= TF_MAXP, "pitch must be in [1, nf_trans_front_max_pitch()]");
+    NF_CHECK_ARG(!host_flag3 || s->done_counter, "the completion word needs the workgroup counter");
+    TsArgs S;
+    size_t tot = 0;
+    NF_CHECK_ARG(nf_grid_make_header(s->n, s->radius, s->bbox, &S.h, &tot) == NF_OK, "bad grid parameters");
+    NF_CHECK_ARG(s->grid_ws_bytes >= tot, "workspace too small");
+    NF_CHECK_ARG(s->n > 0 && s->n <= TP_BLOCK * TP_MAX_PER_THREAD && S.h.n_cells + s->n <= TS_MAX_LDS_INTS,
+                 "cloud or grid too large for the fused step (use the multi-launch path)");
+    S.ws = s->grid_ws; S.pos = pos; S.vel = vel; S.gx = s->gravity[0]; S.gy = s->gravity[1]; S.gz = s->gravity[2]; S.dt = s->dt;
+    S.pos_new = s->pos_new; S.vel_new = s->vel_new; S.feats4 = s->feats; S.per = 0; S.cell = s->radius;
+    TfArgs A;
+    memset(&A, 0, sizeof(A));
+    A.grid[0] = s->grid_ws; A.grid[1] = s->box_grid; A.q = s->pos_new; A.pos = pos; A.vel = vel;
+    A.gx = S.gx; A.gy = S.gy; A.gz = S.gz; A.dt = S.dt;
+    A.feats_f = s->feats; A.feats_b = s->box_feats; A.n = s->n;
+    A.r2 = s->radius * s->radius; A.extent = s->extent; A.use_window = s->use_window; A.pitch_f = s->pitch_f; A.pitch_b = s->pitch_b;
+    A.relu_out = 1;
+    A.counts2 = s->counts2; A.num_nbrs = num_nbrs; A.idx_f = s->idx_f; A.d2_f = s->d2_f; A.roff = s->roff; A.ent = s->ent;
+    A.k_fluid = s->k_fluid; A.b_fluid = s->b_fluid; A.k_obst = s->k_obst; A.b_obst = s->b_obst;
+    A.dense_w = s->dense0_w; A.dense_b = s->dense0_b; A.a0 = s->a0; A.overflow2 = (unsigned long long*)s->overflow2;
+    A.host_flag = (volatile int*)host_flag3; A.done_ctr = s->done_counter; A.step_id = step_id;
+    ts_launch(S, A, (hipStream_t)stream);
+    NF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_trans_front, dim3(tf_blocks(s->n), 1), dim3(64 * TF_WAVES), 0, (hipStream_t)stream, A, 1);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }

@@ -282,7 +282,8 @@ class ParticleNet(nn.Module):
         sf = ctypes.c_size_t()
         check(lib.nf_cconv_gf_plan(n, 64, max_wg, None, None, None, ctypes.byref(sf)), "nf_cconv_gf_plan")
         st = dict(key=key, pitch=(pitch_f, pitch_b), max_wg=max_wg,
-                  grid_ws=E(lib.nf_grid_workspace_bytes(n, radius, bb), dtype=u8), pos_new=E(n, 3), vel_new=E(n, 3), feats=E(n, 4),
+                  # (zeroed: the step's grid build keeps its cell counters and ticket in here and expects them at rest)
+                  grid_ws=torch.zeros(lib.nf_grid_workspace_bytes(n, radius, bb), dtype=u8, device=dev), pos_new=E(n, 3), vel_new=E(n, 3), feats=E(n, 4),
                   counts2=E(2 * n, dtype=i32), idx_f=E(n * pitch_f, dtype=i32), d2_f=E(n * pitch_f),
                   roff=torch.zeros(n * 20, dtype=i16, device=dev), ent=E(n * 4 * pitch_f * 3, dtype=i32),
                   a0=E(n, 96), a1=E(n, 64), a1r=E(n, 64), g3=E(lib.nf_cconv3_workspace_floats(n)), y3=E(n, 3), scratch=E(sf.value),

@@ -79,6 +79,11 @@ size_t nf_radius_scan_workspace_bytes(int nq);
 int nf_radius_fill(const void* grid_ws, const float* queries, int nq, float radius, int ignore_same_pos,
                    const int64_t* row_splits, int32_t* idx, float* dist2, int64_t nnz_capacity,
                    nf_stream_t stream);
+/* The clamp named above, for callers that run against a learnt capacity without a host round trip: total_out[0] (optional) =
+ * row_splits[n_rows] as counted (saturated to int32), then row_splits[i] = min(row_splits[i], capacity) in place.  The caller
+ * compares total_out with the capacity once its work is enqueued and redoes the call when it was exceeded. */
+int nf_csr_clamp(int64_t* row_splits /*n_rows+1*/, int n_rows, int64_t capacity, int32_t* total_out /*or NULL*/,
+                 nf_stream_t stream);
 
 /* Exact nearest neighbour of every query among pts (FluidErrors' gt -> prediction metric,
  * utils/point_eval.py:36-58, where the reference calls scipy.spatial.cKDTree(pred).query(gt) on the

@@ -38,6 +38,7 @@ PROTOTYPES = {
     "nf_radius_scan_workspace_bytes": (c_size_t, [c_int]),
     "nf_radius_count": (c_int, [c_void_p, c_void_p, c_int, c_float, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "nf_radius_fill": (c_int, [c_void_p, c_void_p, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "nf_csr_clamp": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_void_p]),
     "nf_nearest": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "nf_get_rays": (c_int, [c_int, c_int, c_float, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "nf_render_classify": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p, c_void_p,

@@ -654,6 +654,26 @@ extern "C" int nf_radius_count(const void* ws, const float* queries, int nq, flo
     return NF_OK;
 }
 
+// row_splits of a search whose arrays were sized by a BOUND (a capacity learnt from earlier calls) instead of row_splits[nq]:
+// report the true total, then clamp every split to the capacity, so that every consumer of the CSR stays inside the arrays
+// (rows beyond the capacity are truncated; the caller compares total with the capacity and redoes the call when it was exceeded).
+__global__ void __launch_bounds__(256) k_csr_clamp(int64_t* __restrict__ rs, int n_rows, int64_t cap, int32_t* __restrict__ total)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i > n_rows) return;
+    const int64_t v = rs[i];
+    if (i == n_rows && total) total[0] = v > 0x7fffffff ? 0x7fffffff : (int32_t)v;
+    if (v > cap) rs[i] = cap;
+}
+
+extern "C" int nf_csr_clamp(int64_t* row_splits, int n_rows, int64_t capacity, int32_t* total_out, nf_stream_t stream)
+{
+    NF_CHECK_ARG(row_splits && n_rows >= 0 && capacity >= 0, "bad arguments");
+    hipLaunchKernelGGL(k_csr_clamp, dim3((n_rows + 1 + 255) / 256), dim3(256), 0, (hipStream_t)stream, row_splits, n_rows, capacity, total_out);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
 extern "C" int nf_radius_fill(const void* ws, const float* queries, int nq, float radius, int ignore_same_pos,
                               const int64_t* row_splits, int32_t* idx, float* dist2, int64_t nnz_capacity,
                               nf_stream_t stream)

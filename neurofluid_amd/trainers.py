@@ -442,7 +442,8 @@ class E2ETrainer(BaseTrainer):
                     if max_steps is not None and done >= max_steps:
                         return loss
         finally:
-            self.release_frame_cache()          # the pinned frames are only useful inside the epoch loop
+            if not getattr(self, 'keep_frame_cache', False):      # (a caller that calls train() block by block — bench.py — keeps it)
+                self.release_frame_cache()      # the cached frames are only useful inside the epoch loop
         return loss
 
     def trainsition_step_for_training(self, data, data_idx):

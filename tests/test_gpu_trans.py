@@ -597,6 +597,39 @@ def test_fused_step_overflow_is_redone_exactly(dev):
             assert pc.fused_overflows == 4 and pc.max_fluid_neighbors == 8
 
 
+def test_exact_path_pair_capacity_overflow_is_redone_exactly(dev):
+    """The multi-launch (training / exact) path sizes its pair arrays by capacities learnt from earlier calls of the same cloud
+    size and verifies them after the step is enqueued (no mid-step host round trip).  A later, DENSER cloud of the same size
+    overflows them: the step must be redone with exact sizes before forward() returns — bit-equal to a model that sizes exactly
+    every time — and the CSR it publishes (conv.nns) must be the complete one."""
+    from neurofluid_amd import synthetic
+    from oracle import trans_oracle as to
+    box, bn = [t.to(dev) for t in to.watercube_box()]
+    P = synthetic.watercube_particles().to(dev)
+    dense = (P * 0.8 + torch.tensor([0.0, 0.0, -0.19], device=dev)).contiguous()      # same count, 1.95x the density
+    opt, _ = make_pn(dev)
+    opt.fused_inference = False
+    ref, _ = make_pn(dev)
+    ref.fused_inference, ref.optimistic_pair_capacity = False, False
+    v = torch.zeros_like(P)
+    with torch.no_grad():
+        for cloud, redo in ((P, 0), (P, 0), (dense, 1), (dense, 1), (P, 1)):
+            a, b = opt(cloud, v, box, bn), ref(cloud, v, box, bn)
+            assert all(torch.equal(x, y) for x, y in zip(a, b))
+            assert getattr(opt, "pair_capacity_redos", 0) == redo
+            na, nb = opt.conv0_fluid.nns, ref.conv0_fluid.nns
+            assert torch.equal(na.neighbors_row_splits, nb.neighbors_row_splits) and torch.equal(na.neighbors_index, nb.neighbors_index)
+    # and with gradients (the training path): same loss gradients either way
+    for m in (opt, ref):
+        m.zero_grad()
+        p2, v2, _ = m(dense.clone().requires_grad_(False), v, box, bn)
+        (p2.sum() + v2.square().sum()).backward()
+    for (na_, pa), (_, pb) in zip(opt.named_parameters(), ref.named_parameters()):
+        assert (pa.grad is None) == (pb.grad is None), na_
+        if pa.grad is not None:
+            assert torch.equal(pa.grad, pb.grad), na_
+
+
 def test_fused_step_sees_a_box_updated_in_place(dev):
     """A moving obstacle: `box` / `box_feats` updated IN PLACE keep their pointers and (when the extreme points stay) their
     bounds.  The fused step must search the NEW contents (its scene key carries the tensors' versions): it stays bit-equal in

@@ -22,6 +22,7 @@ for node in (cfg.TRAIN, cfg.TEST):
 cfg.TRAIN.save_interval = 10 ** 9
 cfg.TRAIN.epochs = 10
 tr = E2ETrainer(cfg)
+tr.keep_frame_cache = True      # steady state of a multi-epoch run: frames stay on the device between train() calls
 tr.train(max_steps=len(tr.dataset))
 torch.cuda.synchronize()
 tr.start_step = 0

@@ -21,6 +21,7 @@ for node in (cfg.TRAIN, cfg.TEST):
 cfg.TRAIN.save_interval = 10 ** 9
 cfg.TRAIN.epochs = 10
 tr = E2ETrainer(cfg)
+tr.keep_frame_cache = True      # steady state of a multi-epoch run: frames stay on the device between train() calls
 print("views", tr.train_view_names, "ray_chunk", cfg.RENDERER.ray.ray_chunk, "frames", len(tr.dataset))
 tr.train(max_steps=len(tr.dataset))        # warm-up: one pass over every frame (the dataset caches decoded frames)
 torch.cuda.synchronize()

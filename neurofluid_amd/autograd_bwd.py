@@ -224,8 +224,14 @@ class _ParticleNetFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_pos, g_vel, _g_nn):
+        g_in_pos, g_in_vel, g_in_feats, grads = _trans_backward(ctx.pn, ctx.aux, ctx.box_feats, ctx.in_grad, g_pos, g_vel)
+        return (None, g_in_pos, g_in_vel, None, None, g_in_feats) + grads
+
+
+def _trans_backward(pn, aux, box_feats_c, in_grad, g_pos, g_vel):
+    """Backward of one ParticleNet step (B8): (g_in_pos, g_in_vel, g_in_feats, parameter gradients in _pn_params order)."""
+    if True:
         from .transmodel import cconv_pairs
-        pn, aux = ctx.pn, ctx.aux
         lib = _lib.load()
         st = _lib.stream()
         dt = float(pn.time_step)
@@ -267,7 +273,7 @@ class _ParticleNetFn(torch.autograd.Function):
         dKo = torch.zeros_like(c0o.kernel)
         dKf = torch.zeros_like(c0f.kernel)
         wsf = torch.empty(lib.nf_cconv_small_bwd_filter_workspace_floats(4, n), dtype=torch.float32, device=dev)
-        check(lib.nf_cconv_small_bwd_filter(ptr(ctx.box_feats), 3, ptr(b_rs), ptr(b_idx), ptr(b_pw), ptr(b_pc), ptr(dy), 96, 0,
+        check(lib.nf_cconv_small_bwd_filter(ptr(box_feats_c), 3, ptr(b_rs), ptr(b_idx), ptr(b_pw), ptr(b_pc), ptr(dy), 96, 0,
                                             n, ptr(wsf), ptr(dKo), st), "conv0_obstacle filter grad")
         cin0 = ff.shape[1]
         dG0 = None
@@ -286,10 +292,10 @@ class _ParticleNetFn(torch.autograd.Function):
         grads[d0.weight], grads[d0.bias] = ops.gemm(dy[:, 64:].t(), ff), dy[:, 64:].sum(0)
         # input gradients (2-step unrolls, trainer_transmodel.py): through integrate/update and the velocity features
         g_in_pos = g_in_vel = None
-        if ctx.in_grad[0]:
+        if in_grad[0]:
             g_in_pos = d_pos_c - (g_vel.detach().float() / dt if g_vel is not None else 0.)
         g_in_feats = None
-        if ctx.in_grad[1] or ctx.in_grad[2]:
+        if in_grad[1] or in_grad[2]:
             if cin0 == 4:
                 dfeat = torch.empty(n, 4, dtype=torch.float32, device=dev)
                 check(lib.nf_cconv_small_bwd_feat(ptr(c0f.kernel.detach().contiguous()), 4, ptr(f_rs), ptr(f_idx), ptr(t_pw),
@@ -298,12 +304,129 @@ class _ParticleNetFn(torch.autograd.Function):
                 zw = torch.zeros(32, cin0, dtype=torch.float32, device=dev)
                 dfeat = ops.gemm(dG0, _virtual_b(c0f.kernel, zw).t())          # (n, 4 + F)
             ops.gemm(dy[:, 64:], d0.weight.detach(), out=dfeat, accumulate=True)
-            if ctx.in_grad[1]:
+            if in_grad[1]:
                 g_in_vel = d_pos_c * dt + dfeat[:, 1:4]             # pos_new = pos + vel dt + g dt^2/2 ; feats = [1, vel + g dt]
-            if ctx.in_grad[2]:
+            if in_grad[2]:
                 g_in_feats = dfeat[:, 4:].contiguous()
-        return (None, g_in_pos, g_in_vel, None, None, g_in_feats) + tuple(grads[p] for p in _pn_params(pn))
+        return g_in_pos, g_in_vel, g_in_feats, tuple(grads[p] for p in _pn_params(pn))
+
 
 
 def particle_net_with_grad(pn, pos, vel, box, box_feats, feats=None):
     return _ParticleNetFn.apply(pn, pos, vel, box, box_feats, feats, *_pn_params(pn))
+
+
+# ================================================================================================
+# Graph-replayed training step of the transition model (ParticleNet.training_graph; E2ETrainer sets it)
+# ================================================================================================
+class _TransGraphs:
+    """The captured forward / backward launch sequences of one ParticleNet for one (cloud size, pair capacities, scene,
+    parameter storage) key, with their static input / output buffers."""
+
+    def __init__(self):
+        self.key = None
+        self.serial = 0
+
+
+def _tg_key(pn, n, box, box_feats):
+    caps = pn.__dict__.get("_pair_caps", {}).get(n)
+    return (n, caps, box.data_ptr(), box._version, box.shape[0], box_feats.data_ptr(), box_feats._version, bool(pn.use_window),
+            tuple(p.data_ptr() for p in _pn_params(pn)), pn.gravity._version)
+
+
+def particle_net_graphed(pn, pos, vel, box, box_feats):
+    """ParticleNet.forward under autograd through HIP-graph replay, or None when this call cannot take that route yet (the pair
+    capacities of this cloud size are not learnt: the eager path learns them and warms every kernel up)."""
+    n = pos.shape[0]
+    if pn.__dict__.get("_pair_caps", {}).get(n) is None or n == 0:
+        return None
+    if not (box.is_contiguous() and box_feats.is_contiguous() and box.dtype == torch.float32 and box_feats.dtype == torch.float32):
+        return None
+    return _GraphedParticleNetFn.apply(pn, pos, vel, box, box_feats, *_pn_params(pn))
+
+
+class _GraphedParticleNetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pn, pos, vel, box, box_feats, *params):
+        ctx.set_materialize_grads(False)
+        tg = pn.__dict__.setdefault("_tgraphs", _TransGraphs())
+        n, dev = pos.shape[0], pos.device
+        pn._scene_bbox(box); pn._box_grid(box)                       # caches filled OUTSIDE any capture (they may sync)
+        key = _tg_key(pn, n, box, box_feats)
+        if tg.key != key:
+            tg.key, tg.bwd = key, {}
+            tg.caps = key[1]
+            tg.pos_s, tg.vel_s = torch.empty(n, 3, device=dev), torch.empty(n, 3, device=dev)
+            tg.tot_pinned = torch.zeros(2, dtype=torch.int32).pin_memory()
+            tg.ev = torch.cuda.Event()
+            tg.box, tg.box_feats = box, box_feats                    # pins the storages the graphs read
+            cap_state = {"tot_pinned": tg.tot_pinned, "total_fluid": lambda: tg.total_fluid()}
+            tg.pos_s.copy_(pos.detach()); tg.vel_s.copy_(vel.detach())
+            torch.cuda.synchronize()
+            tg.fwd = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(tg.fwd):
+                tg.outs = pn._forward_impl(tg.pos_s, tg.vel_s, box, box_feats, keep=True, _capture=cap_state)
+            tg.total_fluid = lambda: _tg_totals(tg)[0]
+        else:
+            tg.pos_s.copy_(pos.detach()); tg.vel_s.copy_(vel.detach())
+        tg.fwd.replay()
+        tg.ev.record()
+        tg.serial += 1
+        tg.checked = False
+        ctx.pn, ctx.tg, ctx.serial = pn, tg, tg.serial
+        pos_c, vel_c, nn, _aux = tg.outs
+        pn.num_fluid_neighbors, pn._y3 = nn, _aux["ans"][-1]
+        out = (pos_c.clone(), vel_c.clone(), nn.clone())
+        ctx.mark_non_differentiable(out[2])
+        return out
+
+    @staticmethod
+    def backward(ctx, g_pos, g_vel, _g_nn):
+        pn, tg = ctx.pn, ctx.tg
+        if ctx.serial != tg.serial:
+            raise RuntimeError("ParticleNet.training_graph: a second forward ran before this step's backward (the graphs hold ONE "
+                               "step's activations: truncated BPTT of length 1); use training_graph = False for unrolled steps")
+        _tg_check(pn, tg)
+        dev = tg.pos_s.device
+        n = tg.pos_s.shape[0]
+        has_vel = g_vel is not None
+        b = tg.bwd.get(has_vel)
+        gp = torch.zeros(n, 3, device=dev) if g_pos is None else g_pos.detach().float()
+        if b is None:
+            b = {"g_pos": torch.empty(n, 3, device=dev), "g_vel": torch.empty(n, 3, device=dev) if has_vel else None}
+            b["g_pos"].copy_(gp)
+            if has_vel:
+                b["g_vel"].copy_(g_vel.detach().float())
+            aux = tg.outs[3]
+            torch.cuda.synchronize()
+            b["graph"] = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(b["graph"]):
+                b["out"] = _trans_backward(pn, aux, tg.box_feats, (False, False, False), b["g_pos"], b["g_vel"])
+            tg.bwd[has_vel] = b
+        else:
+            b["g_pos"].copy_(gp)
+            if has_vel:
+                b["g_vel"].copy_(g_vel.detach().float())
+        b["graph"].replay()
+        return (None, None, None, None, None) + b["out"][3]
+
+
+def _tg_totals(tg):
+    tg.ev.synchronize()
+    return int(tg.tot_pinned[0]), int(tg.tot_pinned[1])
+
+
+def _tg_check(pn, tg):
+    """Compare the step's true pair totals (they travelled to pinned memory inside the forward graph) with the capacities the
+    graphs were captured with; on overflow raise the capacities (the next forward recaptures) and hand the step back."""
+    if tg.checked:
+        return
+    from .transmodel import PairCapacityExceeded
+    got_f, got_b = _tg_totals(tg)
+    cap_f, cap_b = tg.caps
+    if got_f > cap_f or got_b > cap_b:
+        n = tg.pos_s.shape[0]
+        pn._pair_caps[n] = (max(cap_f, ops.round_pairs(got_f + got_f // 8 + 4096)), max(cap_b, ops.round_pairs(got_b + got_b // 4 + 4096)))
+        pn.pair_capacity_redos = getattr(pn, "pair_capacity_redos", 0) + 1
+        raise PairCapacityExceeded("%d / %d neighbour pairs exceed the captured capacities %d / %d" % (got_f, got_b, cap_f, cap_b))
+    tg.checked = True

@@ -28,11 +28,11 @@ struct GemmArgs {
 
 // A tile (128 x 32) -> registers.  KC = true: the operand is contiguous along k (thread: row t >> 3, quad t & 7);
 // false: contiguous along m (thread: k = t >> 5, quad of rows t & 31).
-template <bool KC, bool VEC>
+template <int MB, bool KC, bool VEC>
 __device__ __forceinline__ void gg_load_a(const GemmArgs& g, int m0, int k0, int k_end, int tid, float4 (&r)[4])
 {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < MB; ++u) {
         const int t = tid + 256 * u;
         float e[4] = {0.f, 0.f, 0.f, 0.f};
         if (KC) {
@@ -46,7 +46,7 @@ __device__ __forceinline__ void gg_load_a(const GemmArgs& g, int m0, int k0, int
                 }
             }
         } else {
-            const int k = k0 + (t >> 5), m = m0 + 4 * (t & 31);
+            const int k = k0 + t / (8 * MB), m = m0 + 4 * (t % (8 * MB));
             if (k < k_end) {
                 const float* src = g.A + (long long)k * g.sa_k + m;
                 if (VEC && m + 3 < g.M) { const float4 v = *(const float4*)src; e[0] = v.x; e[1] = v.y; e[2] = v.z; e[3] = v.w; }
@@ -98,72 +98,72 @@ __device__ __forceinline__ void gg_load_b(const GemmArgs& g, int n0, int k0, int
     }
 }
 
-template <bool A_KC, bool B_NC, bool VA, bool VB>
+// MB = 32-row blocks of the output tile (tile = 32 MB x 128): every wave owns 32 columns and all MB row blocks, so an output
+// with few rows (the filter gradients of the continuous convolutions: M = Cin = 96 / 64) fits its tile exactly instead of
+// padding a 128-row tile, and a tall product with few tiles (dX of the renderer: 6 000 x 198, K = 256) gets twice the
+// workgroups from 64-row tiles.  The sums of an output element do not depend on MB (same K order, same split).
+template <int MB, bool A_KC, bool B_NC, bool VA, bool VB>
 __global__ void __launch_bounds__(256) k_gemm_f32(GemmArgs g)
 {
-    // A: m-major [128][33] (A_KC) or k-major [32][132]; B: k-major [32][132] (B_NC) or n-major [128][33]
+    // A: m-major [32 MB][33] (A_KC) or k-major [32][132]; B: k-major [32][132] (B_NC) or n-major [128][33]
     __shared__ float As[GG_M * GG_PM > GG_K * GG_PK ? GG_M * GG_PM : GG_K * GG_PK];
     __shared__ float Bs[GG_M * GG_PM > GG_K * GG_PK ? GG_M * GG_PM : GG_K * GG_PK];
-    const int m0 = blockIdx.y * GG_M, n0 = blockIdx.x * GG_N;
+    const int m0 = blockIdx.y * (32 * MB), n0 = blockIdx.x * GG_N;
     const int kb = blockIdx.z * g.k_per_split, k_end = min(g.K, kb + g.k_per_split);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-    f32x16 acc[2][2];
+    const int wn = wave * 32;
+    f32x16 acc[MB];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < MB; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
     float4 ra[4], rb[4];
-    gg_load_a<A_KC, VA>(g, m0, kb, k_end, tid, ra);
+    gg_load_a<MB, A_KC, VA>(g, m0, kb, k_end, tid, ra);
     gg_load_b<B_NC, VB>(g, n0, kb, k_end, tid, rb);
     for (int k0 = kb; k0 < k_end; k0 += GG_K) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int t = tid + 256 * u;
-            if (A_KC) { float* d = As + (t >> 3) * GG_PM + 4 * (t & 7); d[0] = ra[u].x; d[1] = ra[u].y; d[2] = ra[u].z; d[3] = ra[u].w; }
-            else *(float4*)(As + (t >> 5) * GG_PK + 4 * (t & 31)) = ra[u];
+            if (u < MB) {
+                if (A_KC) { float* d = As + (t >> 3) * GG_PM + 4 * (t & 7); d[0] = ra[u].x; d[1] = ra[u].y; d[2] = ra[u].z; d[3] = ra[u].w; }
+                else *(float4*)(As + (t / (8 * MB)) * GG_PK + 4 * (t % (8 * MB))) = ra[u];
+            }
             if (B_NC) *(float4*)(Bs + (t >> 5) * GG_PK + 4 * (t & 31)) = rb[u];
             else { float* d = Bs + (t >> 3) * GG_PM + 4 * (t & 7); d[0] = rb[u].x; d[1] = rb[u].y; d[2] = rb[u].z; d[3] = rb[u].w; }
         }
         __syncthreads();
         if (k0 + GG_K < k_end) {      // next slab in flight while this one is multiplied
-            gg_load_a<A_KC, VA>(g, m0, k0 + GG_K, k_end, tid, ra);
+            gg_load_a<MB, A_KC, VA>(g, m0, k0 + GG_K, k_end, tid, ra);
             gg_load_b<B_NC, VB>(g, n0, k0 + GG_K, k_end, tid, rb);
         }
 #pragma unroll
         for (int kk = 0; kk < GG_K; kk += 2) {
             const int kr = kk + (lane >> 5), c = lane & 31;
-            const float a0 = A_KC ? As[(wm + c) * GG_PM + kr] : As[kr * GG_PK + wm + c];
-            const float a1 = A_KC ? As[(wm + 32 + c) * GG_PM + kr] : As[kr * GG_PK + wm + 32 + c];
             const float b0 = B_NC ? Bs[kr * GG_PK + wn + c] : Bs[(wn + c) * GG_PM + kr];
-            const float b1 = B_NC ? Bs[kr * GG_PK + wn + 32 + c] : Bs[(wn + 32 + c) * GG_PM + kr];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+#pragma unroll
+            for (int a = 0; a < MB; ++a) {
+                const float av = A_KC ? As[(32 * a + c) * GG_PM + kr] : As[kr * GG_PK + 32 * a + c];
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[a], 0, 0, 0);
+            }
         }
         __syncthreads();
     }
     // D layout: lane -> column j = lane & 31, rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     const bool split = gridDim.z > 1;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < MB; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int n = n0 + wn + 32 * b + (lane & 31);
-                if (m < g.M && n < g.N) {
-                    if (split) g.ws[((size_t)blockIdx.z * g.M + m) * g.N + n] = acc[a][b][r];
-                    else {
-                        float* dst = g.C + (long long)m * g.ldc + n;
-                        *dst = g.accumulate ? *dst + acc[a][b][r] : acc[a][b][r];
-                    }
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int n = n0 + wn + (lane & 31);
+            if (m < g.M && n < g.N) {
+                if (split) g.ws[((size_t)blockIdx.z * g.M + m) * g.N + n] = acc[a][r];
+                else {
+                    float* dst = g.C + (long long)m * g.ldc + n;
+                    *dst = g.accumulate ? *dst + acc[a][r] : acc[a][r];
                 }
             }
+        }
 }
 
 // slices folded in a fixed order (deterministic), four independent loads per step
@@ -213,8 +213,19 @@ extern "C" int nf_gemm_f32(int M, int N, int K, const float* A, int64_t sa_m, in
     // 16-B vector loads need an aligned base and a stride of whole quads along the non-contiguous axis
     const bool va = ((uintptr_t)A % 16 == 0) && ((a_kc ? sa_m : sa_k) % 4 == 0);
     const bool vb = ((uintptr_t)B % 16 == 0) && ((b_nc ? sb_k : sb_n) % 4 == 0);
-    dim3 grid((N + GG_N - 1) / GG_N, (M + GG_M - 1) / GG_M, splits);
-#define GG_LAUNCH(AK, BN, VA_, VB_) hipLaunchKernelGGL((k_gemm_f32<AK, BN, VA_, VB_>), grid, dim3(256), 0, st, g)
+    // rows per tile: an output of at most 128 rows gets a tile that fits it; a taller one 128-row tiles, or 64-row tiles when
+    // 128-row tiles would leave most of the chip without a workgroup
+    int mb = 4;
+    if (M <= 128) mb = (M + 31) / 32;
+    else if ((long long)((N + GG_N - 1) / GG_N) * ((M + 127) / 128) * splits < 192) mb = 2;
+    dim3 grid((N + GG_N - 1) / GG_N, (M + 32 * mb - 1) / (32 * mb), splits);
+#define GG_LAUNCH(AK, BN, VA_, VB_)                                                                                   \
+    do {                                                                                                              \
+        if (mb == 4) hipLaunchKernelGGL((k_gemm_f32<4, AK, BN, VA_, VB_>), grid, dim3(256), 0, st, g);                 \
+        else if (mb == 3) hipLaunchKernelGGL((k_gemm_f32<3, AK, BN, VA_, VB_>), grid, dim3(256), 0, st, g);            \
+        else if (mb == 2) hipLaunchKernelGGL((k_gemm_f32<2, AK, BN, VA_, VB_>), grid, dim3(256), 0, st, g);            \
+        else hipLaunchKernelGGL((k_gemm_f32<1, AK, BN, VA_, VB_>), grid, dim3(256), 0, st, g);                         \
+    } while (0)
 #define GG_PICK_V(AK, BN)                                       \
     do {                                                        \
         if (va && vb) GG_LAUNCH(AK, BN, true, true);            \

@@ -214,7 +214,7 @@ def gemm(a, b, out=None, accumulate=False, relu_a=False, splits=None):
     sa_m, sa_k = strides(a)
     sb_k, sb_n = strides(b)
     if splits is None:
-        tiles = ((M + 127) // 128) * ((N + 127) // 128)
+        tiles = ((M + 127) // 128) * ((N + 127) // 128)      # (an output of <= 128 rows gets ONE tile row that fits it: nf_gemm.hip)
         splits = max(1, min(512 // max(tiles, 1), K // 256, 64)) if tiles < 128 else 1
     wsp = torch.empty(lib.nf_gemm_f32_workspace_floats(M, N, splits), dtype=torch.float32, device=a.device) if splits > 1 else None
     ldc = out.stride(0) if M > 1 else max(N, out.stride(0))

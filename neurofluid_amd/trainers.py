@@ -22,7 +22,7 @@ from .render_loop import render_image as _render_image
 from .renderer import RenderNet
 from .train_step import (ExponentialLR, PixelSampler, random_sample_coords, _upload, choice_without_replacement, gather_view_pixels,
                          make_adam, summed_view_mse, portable_optimizer_state, load_optimizer_state)
-from .transmodel import ParticleNet
+from .transmodel import ParticleNet, PairCapacityExceeded
 
 to8b = lambda x: (255 * np.clip(x, 0, 1)).astype(np.uint8)   # noqa: E731  trainer/basetrainer.py:16
 img2mse = lambda x, y: torch.mean((x - y) ** 2)              # noqa: E731
@@ -383,6 +383,9 @@ class E2ETrainer(BaseTrainer):
         self.dataset = self._dataset('train', self.train_view_names, 'train', o.TRAIN)
         self.test_dataset = self._dataset('test', self.test_viewnames, 'test', o.TEST)
         self.transition_model = ParticleNet(gravity=o.gravity).to(self.device)
+        # truncated BPTT of length 1 (trainer_e2e.py:196-198): one forward per backward, so the transition step's launch
+        # sequences can be replayed as HIP graphs (the step is bound by the host's launch rate)
+        self.transition_model.training_graph = bool(getattr(o.TRAIN, 'transition_graph', True))
         self.renderer = RenderNet(o.RENDERER, near=o.near, far=o.far).to(self.device)
         if o.TRAIN.pretrained_transition_model != '':
             self.load_pretained_transition_model(o.TRAIN.pretrained_transition_model)
@@ -433,8 +436,17 @@ class E2ETrainer(BaseTrainer):
                 self.tmp_fluid_error = FluidErrors()
                 for data_idx in range(len(self.dataset)):
                     data = self._frame_on_device(self.dataset, data_idx)
-                    loss = self.train_step(data, data_idx, len(self.train_view_names), H, W, global_step)
-                    self.update_step(loss, global_step)
+                    saved = (getattr(self, 'pos_for_next_step', None), getattr(self, 'vel_for_next_step', None), np.random.get_state())
+                    try:
+                        loss = self.train_step(data, data_idx, len(self.train_view_names), H, W, global_step)
+                        self.update_step(loss, global_step)
+                    except PairCapacityExceeded:
+                        # the graph-replayed transition step met more neighbour pairs than its graphs were captured for (the
+                        # capacities have been raised): redo THIS step from the state and the random stream it started with
+                        self.pos_for_next_step, self.vel_for_next_step = saved[0], saved[1]
+                        np.random.set_state(saved[2])
+                        loss = self.train_step(data, data_idx, len(self.train_view_names), H, W, global_step)
+                        self.update_step(loss, global_step)
                     global_step += 1; done += 1
                     if (global_step + 1) % o.TRAIN.save_interval == 0:
                         self.eval(global_step)

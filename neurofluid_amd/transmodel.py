@@ -109,6 +109,22 @@ def cconv_layer(x, kernel, bias, dense_w, dense_b, row_splits, nbr, pw, pc, relu
     return y
 
 
+class PairCapacityExceeded(RuntimeError):
+    """Raised by the graph-replayed training step (ParticleNet.training_graph) when a step's neighbour pairs did not fit the
+    capacities its graphs were captured with: the capacities have been raised, the caller redoes the step (E2ETrainer does)."""
+
+
+class _LazyCSR:
+    """`conv.nns` of a step that ran against pair capacities whose true totals are still on their way to the host: the arrays are
+    cut to the true count on first access (which waits for the step's event)."""
+
+    def __init__(self, idx, rs, d2, total_fn):
+        self._idx, self.neighbors_row_splits, self._d2, self._total = idx, rs, d2, total_fn
+
+    neighbors_index = property(lambda self: self._idx[:self._total()])
+    neighbors_distance = property(lambda self: self._d2[:self._total()])
+
+
 class _PitchedNeighbors:
     """`conv.nns` of the fused inference step: the neighbour rows live at a fixed pitch on the device; the CSR view the
     Open3D attribute names promise (neighbors_index / neighbors_row_splits / neighbors_distance) is built on first access."""
@@ -175,6 +191,11 @@ class ParticleNet(nn.Module):
         self.fused_inference = True
         self.fused_grow_pitch = True        # on overflow: redo the step exactly AND grow the pitch (False: only redo)
         self.optimistic_pair_capacity = True    # exact path: pair arrays sized by learnt capacities, no mid-step host round trip
+        # Opt-in (E2ETrainer sets it): the training step's forward and backward launch sequences (~30 and ~60 small kernels) are
+        # captured into HIP graphs per (cloud size, pair capacities, scene) and REPLAYED — the end-to-end step is bound by the
+        # host's launch rate, not by the GPU.  One forward may be outstanding per backward (truncated BPTT of length 1); a
+        # step whose pairs exceed the captured capacities raises PairCapacityExceeded from backward() (autograd_bwd.py).
+        self.training_graph = False
         # build-only switch, arithmetic of the conv1 / conv2 contractions of the fused inference step: "fp32" (default: fp32
         # MFMA, the reference's arithmetic) or "split" (hi + lo fp16 operands, three fp16 MFMAs per product block, fp32
         # accumulate: fp32-LEVEL accuracy — 22-bit products — on the fp16 matrix pipe, which overlaps with the gather)
@@ -228,7 +249,11 @@ class ParticleNet(nn.Module):
             raise ValueError(f"feats has {nf} channels, the model was built with other_feats_channels={self.other_feats_channels}")
         if torch.is_grad_enabled() and (pos.requires_grad or vel.requires_grad or (feats is not None and feats.requires_grad) or
                                         any(p.requires_grad for p in self.parameters())):
-            from .autograd_bwd import particle_net_with_grad
+            from .autograd_bwd import particle_net_with_grad, particle_net_graphed
+            if self.training_graph and feats is None and not pos.requires_grad and not vel.requires_grad and self.optimistic_pair_capacity:
+                out = particle_net_graphed(self, pos, vel, box, box_feats)
+                if out is not None:
+                    return out
             return particle_net_with_grad(self, pos, vel, box, box_feats, feats)
         with torch.no_grad():
             if feats is None and self.fused_inference and self._fused_ok(pos, box):
@@ -434,7 +459,7 @@ class ParticleNet(nn.Module):
             self._fused_skip = 16           # a clump denser than the front kernel stages: exact path for a while
         return self._forward_impl(pos, vel, box, box_feats)[:3]
 
-    def _forward_impl(self, pos, vel, box, box_feats, keep=False, other=None, _exact=False):
+    def _forward_impl(self, pos, vel, box, box_feats, keep=False, other=None, _exact=False, _capture=None):
         """The exact multi-launch path (CSR neighbour lists sized by one host round trip): training (keep=True saves what the
         backward needs), clouds beyond the fused step's limits, and the redo of a fused step whose row pitch overflowed."""
         lib = _lib.load()
@@ -464,13 +489,16 @@ class ParticleNet(nn.Module):
         fetch = None
         if cap is not None:
             nnz_f, nnz_b = cap
-            fetch = ops.HostFetch(pos.device)
             tot = torch.empty(2, dtype=torch.int32, device=pos.device)
             f_idx, f_d2 = ops.radius_fill(fgrid, pos_new, radius, f_rs, nnz_f, True)
             b_idx, b_d2 = ops.radius_fill(bgrid, pos_new, radius, b_rs, nnz_b, True)
             check(lib.nf_csr_clamp(ptr(f_rs), n, nnz_f, tot.data_ptr(), st), "nf_csr_clamp")
             check(lib.nf_csr_clamp(ptr(b_rs), n, nnz_b, tot.data_ptr() + 4, st), "nf_csr_clamp")
-            fetch.add(tot)
+            if _capture is not None:        # under graph capture: the totals go to the caller's pinned words (a copy node), the
+                _capture["tot_pinned"].copy_(tot, non_blocking=True)      # caller compares them after the replay's event
+            else:
+                fetch = ops.HostFetch(pos.device)
+                fetch.add(tot)
         else:
             nnz_f, nnz_b = torch.stack([f_rs[-1], b_rs[-1]]).tolist()
             caps[n] = (ops.round_pairs(nnz_f + nnz_f // 8 + 4096), ops.round_pairs(nnz_b + nnz_b // 4 + 4096))
@@ -509,8 +537,11 @@ class ParticleNet(nn.Module):
                 self.pair_capacity_redos = getattr(self, "pair_capacity_redos", 0) + 1
                 return self._forward_impl(pos, vel, box, box_feats, keep=keep, other=other, _exact=True)
             nnz_f, nnz_b = got_f, got_b
-        self.conv0_fluid.nns = SimpleNamespace(neighbors_index=f_idx[:nnz_f], neighbors_row_splits=f_rs,
-                                               neighbors_distance=f_d2[:nnz_f])
+        if _capture is not None:
+            self.conv0_fluid.nns = _LazyCSR(f_idx, f_rs, f_d2, _capture["total_fluid"])
+        else:
+            self.conv0_fluid.nns = SimpleNamespace(neighbors_index=f_idx[:nnz_f], neighbors_row_splits=f_rs,
+                                                   neighbors_distance=f_d2[:nnz_f])
         aux = dict(ans=ans, f=(f_rs, f_idx, f_pw, f_pc), f_d2=f_d2, b=(b_rs, b_idx, b_pw, b_pc), pos_new=pos_new,
                    vel_new=vel_new, fluid_feats=fluid_feats) if keep else None
         return pos_c, vel_c, self.num_fluid_neighbors, aux

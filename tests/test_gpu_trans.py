@@ -630,6 +630,60 @@ def test_exact_path_pair_capacity_overflow_is_redone_exactly(dev):
             assert torch.equal(pa.grad, pb.grad), na_
 
 
+def test_graph_replayed_training_step_equals_eager(dev):
+    """ParticleNet.training_graph (E2ETrainer's mode): the forward / backward launch sequences of the training step replayed as
+    HIP graphs.  Same kernels in the same order on the same operands: outputs and ALL parameter gradients bit-equal to the eager
+    path over a short rollout with a changing state; a second forward before backward is refused; a denser cloud than the graphs
+    were captured for raises PairCapacityExceeded from backward (never wrong gradients), after which the step runs again."""
+    from neurofluid_amd import synthetic
+    from neurofluid_amd.transmodel import PairCapacityExceeded
+    from oracle import trans_oracle as to
+    box, bn = [t.to(dev) for t in to.watercube_box()]
+    P = synthetic.watercube_particles().to(dev)
+    ga, _ = make_pn(dev)
+    ea, _ = make_pn(dev)
+    for m in (ga, ea):
+        m.fused_inference = False
+    ga.training_graph = True
+    tgt = torch.rand(P.shape[0], 3, generator=torch.Generator().manual_seed(1)).to(dev)
+
+    def step(m, p, v):
+        m.zero_grad()
+        p2, v2, nn = m(p, v, box, bn)
+        ((p2 - tgt).square().mean() + 0.1 * p2.abs().mean()).backward()
+        return p2.detach().clone(), v2.detach().clone(), nn
+
+    p, v = P, torch.zeros_like(P)
+    for it in range(5):
+        (pg, vg, ng), (pe, ve, ne) = step(ga, p, v), step(ea, p, v)
+        assert torch.equal(pg, pe) and torch.equal(vg, ve) and torch.equal(ng, ne), it
+        for (name, a), (_, b) in zip(ga.named_parameters(), ea.named_parameters()):
+            assert (a.grad is None) == (b.grad is None), name
+            if a.grad is not None:
+                assert torch.equal(a.grad, b.grad), (it, name)
+        assert torch.equal(ga.conv0_fluid.nns.neighbors_index, ea.conv0_fluid.nns.neighbors_index)
+        p, v = pe, ve
+    assert getattr(ga, "_tgraphs", None) is not None and ga._tgraphs.serial >= 3          # the graphs did run (step 0 learnt the capacities)
+    # one outstanding forward per backward
+    a1 = ga(p, v, box, bn)[0]
+    a2 = ga(p, v, box, bn)[0]
+    with pytest.raises(RuntimeError, match="second forward"):
+        a1.sum().backward()
+    a2.sum().backward()
+    # more pairs than the captured capacities: backward refuses, the capacities grow, the redo matches the eager path
+    dense = (P * 0.8 + torch.tensor([0.0, 0.0, -0.19], device=dev)).contiguous()
+    ga.zero_grad()
+    pd = ga(dense, v, box, bn)[0]
+    with pytest.raises(PairCapacityExceeded):
+        pd.square().mean().backward()
+    (pg, vg, ng), (pe, ve, ne) = step(ga, dense, v), step(ea, dense, v)
+    (pg, vg, ng), (pe, ve, ne) = step(ga, dense, v), step(ea, dense, v)          # (first redo ran eagerly: capacities relearnt; second: new graphs)
+    assert torch.equal(pg, pe) and torch.equal(ng, ne)
+    for (name, a), (_, b) in zip(ga.named_parameters(), ea.named_parameters()):
+        if a.grad is not None:
+            assert torch.equal(a.grad, b.grad), name
+
+
 def test_fused_step_sees_a_box_updated_in_place(dev):
     """A moving obstacle: `box` / `box_feats` updated IN PLACE keep their pointers and (when the extreme points stay) their
     bounds.  The fused step must search the NEW contents (its scene key carries the tensors' versions): it stays bit-equal in

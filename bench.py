@@ -42,9 +42,9 @@ F32_MATRIX_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f3
 F16_MATRIX_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense fp16 MFMA
 F32_VECTOR_PEAK_TFLOPS = 157.3
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s
-PMC_FILES = ("round3_mlp_pmc.json", "round2_mlp_pmc.json", "round1_mlp_pmc.json")      # newest first
-TRANS_PMC_FILES = ("round3_transition_pmc.json", "round2_transition_pmc.json")
-TRANS_STATS_FILES = ("round3_transition_kernel_stats.csv", "round2_transition_kernel_stats.csv")
+PMC_FILES = ("round4_mlp_pmc.json", "round3_mlp_pmc.json", "round2_mlp_pmc.json", "round1_mlp_pmc.json")      # newest first
+TRANS_PMC_FILES = ("round4_transition_pmc.json", "round3_transition_pmc.json", "round2_transition_pmc.json")
+TRANS_STATS_FILES = ("round4_transition_kernel_stats.csv", "round3_transition_kernel_stats.csv", "round2_transition_kernel_stats.csv")
 
 
 def renderer_cfg():
@@ -172,15 +172,15 @@ def committed_traffic():
 
 def committed_transition():
     """Per-step HBM-side bytes and per-kernel microseconds of the transition step from the COMMITTED rocprofv3 passes of
-    `tools/trans_perf.py` (separate --pmc passes; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE).  One k_trans_prepare
-    launch = one step."""
+    `tools/trans_perf.py` (separate --pmc passes; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE).  One k_trans_stage1 (round 3:
+    k_trans_prepare) launch = one step."""
     for name in TRANS_PMC_FILES:
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
         d = json.load(open(path))
         ks = d.get("kernels", {})
-        steps = (ks.get("k_trans_prepare") or {}).get("calls")
+        steps = (ks.get("k_trans_stage1") or ks.get("k_trans_prepare") or {}).get("calls")      # one launch per step
         if not steps:
             continue
         hbm, us = 0.0, {}

@@ -390,18 +390,20 @@ def main():
         pn_t = ParticleNet(gravity=(0, 0, -9.81))      # its own instance: row pitches / fallback state start fresh
         pn_t.load_state_dict(scene["trans_state"], strict=True)
         pn_t = pn_t.to(dev)
-        tp, tv = P0.clone(), torch.zeros_like(P0)
-        for _ in range(3):
-            with torch.no_grad():
-                tp, tv, _ = pn_t(tp, tv, box, bn)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
         nts = 20
-        for _ in range(nts):
-            with torch.no_grad():
-                tp, tv, _ = pn_t(tp, tv, box, bn)
-        torch.cuda.synchronize()
-        pstep_dt = (time.perf_counter() - t1) / nts
+        pblocks = []
+        with torch.no_grad():
+            for _ in range(4):              # blocks of 3 untimed + 20 timed steps from the initial state; the first block warms up
+                tp, tv = P0.clone(), torch.zeros_like(P0)
+                for _ in range(3):
+                    tp, tv, _ = pn_t(tp, tv, box, bn)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(nts):
+                    tp, tv, _ = pn_t(tp, tv, box, bn)
+                torch.cuda.synchronize()
+                pblocks.append((time.perf_counter() - t1) / nts)
+        pstep_dt = sorted(pblocks[1:])[1]       # median of the three timed blocks (a 20-step block is ~5 ms: one host hiccup is 5 %)
         pstep = P0.shape[0] / pstep_dt
         # roofline of the transition step (north_star: "achieved HBM GB/s on the gather" next to the MFMA figure): executed
         # FLOP = BASELINE.md section 2's per-particle-step count x particles (all of it runs on fp32 MFMA or the fp32 VALU,
@@ -411,7 +413,8 @@ def main():
         trans_roofline = {"bound": "fp32 ALUs (on gfx950 the fp32 MFMA runs at the fp32 vector rate, on the same units as the gather "
                                    "arithmetic: 157.3 TFLOP/s for both together)", "arithmetic": "fp32 (default)",
                           "flop_per_particle_step": PARTICLE_STEP_FLOP,
-                          "particles": int(P0.shape[0]), "us_per_step": pstep_dt * 1e6, "achieved": tflops,
+                          "particles": int(P0.shape[0]), "us_per_step": pstep_dt * 1e6,
+                          "us_per_step_blocks": [round(b * 1e6, 1) for b in pblocks[1:]], "achieved": tflops,
                           "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / F32_MATRIX_PEAK_TFLOPS,
                           "traffic": ct["hbm_bytes_per_step"] if ct else None, "traffic_unit": "HBM-side bytes per step (PMC)",
                           "hbm_GBps": (ct["hbm_bytes_per_step"] / pstep_dt / 1e9) if ct else None,

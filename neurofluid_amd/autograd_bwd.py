@@ -335,40 +335,57 @@ def _tg_key(pn, n, box, box_feats):
 
 
 def particle_net_graphed(pn, pos, vel, box, box_feats):
-    """ParticleNet.forward under autograd through HIP-graph replay, or None when this call cannot take that route yet (the pair
-    capacities of this cloud size are not learnt: the eager path learns them and warms every kernel up)."""
+    """ParticleNet.forward under autograd through HIP-graph replay, or None when this call cannot take that route (the pair
+    capacities of this cloud size are not learnt yet: the eager path learns them and warms every kernel up; or a capture failed:
+    the module then stays on the eager path)."""
     n = pos.shape[0]
     if pn.__dict__.get("_pair_caps", {}).get(n) is None or n == 0:
         return None
     if not (box.is_contiguous() and box_feats.is_contiguous() and box.dtype == torch.float32 and box_feats.dtype == torch.float32):
         return None
-    return _GraphedParticleNetFn.apply(pn, pos, vel, box, box_feats, *_pn_params(pn))
+    tg = _tg_prepare(pn, pos, vel, box, box_feats)
+    if tg is None:
+        return None
+    return _GraphedParticleNetFn.apply(pn, tg, pos, vel, *_pn_params(pn))
+
+
+def _tg_prepare(pn, pos, vel, box, box_feats):
+    """The graphs of this (cloud size, capacities, scene, parameter storage), captured on first use."""
+    tg = pn.__dict__.setdefault("_tgraphs", _TransGraphs())
+    n, dev = pos.shape[0], pos.device
+    pn._scene_bbox(box); pn._box_grid(box)                       # caches filled OUTSIDE any capture (they may sync)
+    key = _tg_key(pn, n, box, box_feats)
+    if tg.key == key:
+        return tg
+    tg.key, tg.bwd = None, {}
+    tg.caps = key[1]
+    tg.pos_s, tg.vel_s = torch.empty(n, 3, device=dev), torch.empty(n, 3, device=dev)
+    tg.tot_pinned = torch.zeros(2, dtype=torch.int32).pin_memory()
+    tg.ev = torch.cuda.Event()
+    tg.box, tg.box_feats = box, box_feats                        # pins the storages the graphs read
+    tg.total_fluid = lambda: _tg_totals(tg)[0]
+    cap_state = {"tot_pinned": tg.tot_pinned, "total_fluid": lambda: tg.total_fluid()}
+    tg.pos_s.copy_(pos.detach()); tg.vel_s.copy_(vel.detach())
+    torch.cuda.synchronize()
+    try:
+        tg.fwd = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(tg.fwd):
+            tg.outs = pn._forward_impl(tg.pos_s, tg.vel_s, box, box_feats, keep=True, _capture=cap_state)
+    except Exception as ex:          # noqa: BLE001  a stack that cannot capture this sequence: stay eager, say so once
+        import warnings
+        warnings.warn("ParticleNet.training_graph: graph capture of the training step failed (%r); using the eager path" % (ex,))
+        pn.training_graph = False
+        torch.cuda.synchronize()
+        return None
+    tg.key = key
+    return tg
 
 
 class _GraphedParticleNetFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pn, pos, vel, box, box_feats, *params):
+    def forward(ctx, pn, tg, pos, vel, *params):
         ctx.set_materialize_grads(False)
-        tg = pn.__dict__.setdefault("_tgraphs", _TransGraphs())
-        n, dev = pos.shape[0], pos.device
-        pn._scene_bbox(box); pn._box_grid(box)                       # caches filled OUTSIDE any capture (they may sync)
-        key = _tg_key(pn, n, box, box_feats)
-        if tg.key != key:
-            tg.key, tg.bwd = key, {}
-            tg.caps = key[1]
-            tg.pos_s, tg.vel_s = torch.empty(n, 3, device=dev), torch.empty(n, 3, device=dev)
-            tg.tot_pinned = torch.zeros(2, dtype=torch.int32).pin_memory()
-            tg.ev = torch.cuda.Event()
-            tg.box, tg.box_feats = box, box_feats                    # pins the storages the graphs read
-            cap_state = {"tot_pinned": tg.tot_pinned, "total_fluid": lambda: tg.total_fluid()}
-            tg.pos_s.copy_(pos.detach()); tg.vel_s.copy_(vel.detach())
-            torch.cuda.synchronize()
-            tg.fwd = torch.cuda.CUDAGraph()
-            with torch.no_grad(), torch.cuda.graph(tg.fwd):
-                tg.outs = pn._forward_impl(tg.pos_s, tg.vel_s, box, box_feats, keep=True, _capture=cap_state)
-            tg.total_fluid = lambda: _tg_totals(tg)[0]
-        else:
-            tg.pos_s.copy_(pos.detach()); tg.vel_s.copy_(vel.detach())
+        tg.pos_s.copy_(pos.detach()); tg.vel_s.copy_(vel.detach())
         tg.fwd.replay()
         tg.ev.record()
         tg.serial += 1
@@ -392,23 +409,33 @@ class _GraphedParticleNetFn(torch.autograd.Function):
         has_vel = g_vel is not None
         b = tg.bwd.get(has_vel)
         gp = torch.zeros(n, 3, device=dev) if g_pos is None else g_pos.detach().float()
+        gv = g_vel.detach().float() if has_vel else None
+        aux = tg.outs[3]
         if b is None:
-            b = {"g_pos": torch.empty(n, 3, device=dev), "g_vel": torch.empty(n, 3, device=dev) if has_vel else None}
+            b = {"g_pos": torch.empty(n, 3, device=dev), "g_vel": torch.empty(n, 3, device=dev) if has_vel else None, "graph": None}
             b["g_pos"].copy_(gp)
             if has_vel:
-                b["g_vel"].copy_(g_vel.detach().float())
-            aux = tg.outs[3]
+                b["g_vel"].copy_(gv)
             torch.cuda.synchronize()
-            b["graph"] = torch.cuda.CUDAGraph()
-            with torch.no_grad(), torch.cuda.graph(b["graph"]):
-                b["out"] = _trans_backward(pn, aux, tg.box_feats, (False, False, False), b["g_pos"], b["g_vel"])
+            try:
+                graph = torch.cuda.CUDAGraph()
+                with torch.no_grad(), torch.cuda.graph(graph):
+                    b["out"] = _trans_backward(pn, aux, tg.box_feats, (False, False, False), b["g_pos"], b["g_vel"])
+                b["graph"] = graph
+            except Exception as ex:          # noqa: BLE001  (the forward graph's activations are ordinary tensors: the eager backward reads them)
+                import warnings
+                warnings.warn("ParticleNet.training_graph: graph capture of the backward failed (%r); it runs eagerly" % (ex,))
+                torch.cuda.synchronize()
             tg.bwd[has_vel] = b
         else:
             b["g_pos"].copy_(gp)
             if has_vel:
-                b["g_vel"].copy_(g_vel.detach().float())
+                b["g_vel"].copy_(gv)
+        if b["graph"] is None:
+            with torch.no_grad():
+                return (None, None, None, None) + _trans_backward(pn, aux, tg.box_feats, (False, False, False), gp, gv)[3]
         b["graph"].replay()
-        return (None, None, None, None, None) + b["out"][3]
+        return (None, None, None, None) + b["out"][3]
 
 
 def _tg_totals(tg):

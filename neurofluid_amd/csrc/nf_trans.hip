@@ -358,8 +358,18 @@ __device__ __forceinline__ void tf_body(const TfArgs& A, const TfLds& L, int blk
     const NfGridView g = nf_grid_view(A.grid[WHICH]);
     const unsigned long long lt = (1ull << lane) - 1ull;
     const float radius = 0.5f * A.extent, inv_r2 = 1.f / (radius * radius), scale = 2.f / A.extent;
+#ifndef TF_AB_STRIDED
+    // a wave's particles are CONSECUTIVE indices (index order is spatially coherent: their cell rows and candidates overlap in
+    // the L1 / L2: 46.0 -> 44.2 us against particles strided by the launch width, round 4)
+    const int per_wave = (A.n + nblk * NW - 1) / (nblk * NW);
+    const int stride = 1;
+    int i = (blk * NW + wv) * per_wave;
+    const int i_end = min(A.n, i + per_wave);
+#else
     const int stride = nblk * NW;
     int i = blk * NW + wv;
+    const int i_end = A.n;
+#endif
 
     auto load_q = [&](int ii, float& x, float& y, float& z) __attribute__((always_inline)) {
         x = y = z = 0.f;
@@ -397,7 +407,7 @@ __device__ __forceinline__ void tf_body(const TfArgs& A, const TfLds& L, int blk
     float qx, qy, qz, q1x, q1y, q1z, q2x, q2y, q2z;
     int rs = 0, re = 0;
     bool first_particle = true;
-    load_q(i, qx, qy, qz);
+    if (i < i_end) load_q(i, qx, qy, qz); else qx = qy = qz = 0.f;
 #ifdef TF_AB_READAHEAD
     load_q(i + stride, q1x, q1y, q1z);
 #else
@@ -413,7 +423,7 @@ __device__ __forceinline__ void tf_body(const TfArgs& A, const TfLds& L, int blk
             kv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (t < KN4) kv[u] = ksrc[t];
         }
-        if (g.sdx > 0 && i < A.n) load_ranges(qx, qy, qz, rs, re);
+        if (g.sdx > 0 && i < i_end) load_ranges(qx, qy, qz, rs, re);
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
             const int t = threadIdx.x + u * 64 * NW;
@@ -421,7 +431,7 @@ __device__ __forceinline__ void tf_body(const TfArgs& A, const TfLds& L, int blk
         }
         __syncthreads();
     }
-    for (; i < A.n; i += stride) {
+    for (; i < i_end; i += stride) {
         // requests for the particles ahead: the position two ahead, the row ranges one ahead
         int rs1 = 0, re1 = 0;
 #ifndef TF_AB_READAHEAD

@@ -232,7 +232,9 @@ __device__ __forceinline__ void tr_ball_to_cube(float& x, float& y, float& z)
 #define TF_WAVES 8                       // particles in flight per workgroup (a wave each); the filter is staged once per workgroup
 #define TF_MAXP 128                      // staged pairs per wave = the largest pitch this kernel serves
 
-#define TF_CHUNK 32                      // pairs per round of the layer-0 patch build
+#ifndef TF_CHUNK
+#define TF_CHUNK 64                      // pairs per round of the layer-0 patch build (round 4: 64 — a particle's ~40 pairs are ONE round of
+#endif                                   // shuffles / scans / wave barriers instead of a full one and a nearly empty one)
 struct TfStage {                         // per wave
     int j[TF_MAXP];                      // hits of the sweep, in hit order
     float d2[TF_MAXP];
@@ -317,10 +319,9 @@ __device__ __forceinline__ TfPair tf_pair(const TfStage& st, int t, float qx, fl
 struct TfLds {
     float* Ks;                          // 64 * CI * 32 floats: the layer-0 filter of this cloud
     TfStage* stage;                     // [TF_WAVES]
-    float* patch;                       // [TF_WAVES][256]
     int* rcnt; int* rcur; int* rbase;   // [TF_WAVES][16], [TF_WAVES][16], [TF_WAVES][17]
 };
-#define TF_LDS_BYTES(CI, NW) ((size_t)64 * (CI) * 32 * 4 + sizeof(TfStage) * (NW) + (size_t)(NW) * 256 * 4 + (size_t)(NW) * (16 + 16 + 17) * 4)
+#define TF_LDS_BYTES(CI, NW) ((size_t)64 * (CI) * 32 * 4 + sizeof(TfStage) * (NW) + (size_t)(NW) * (16 + 16 + 17) * 4)
 
 template <int NW>
 __device__ __forceinline__ TfLds tf_carve(char* base, int ci)
@@ -328,7 +329,6 @@ __device__ __forceinline__ TfLds tf_carve(char* base, int ci)
     TfLds L;
     L.Ks = (float*)base; base += (size_t)64 * ci * 32 * 4;
     L.stage = (TfStage*)base; base += sizeof(TfStage) * NW;
-    L.patch = (float*)base; base += (size_t)NW * 256 * 4;
     L.rcnt = (int*)base; base += NW * 16 * 4;
     L.rcur = (int*)base; base += NW * 16 * 4;
     L.rbase = (int*)base;
@@ -348,7 +348,7 @@ __device__ __forceinline__ void tf_body(const TfArgs& A, const TfLds& L, int blk
     constexpr int CI = WHICH ? 3 : 4;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     TfStage& st = L.stage[wv];
-    float* const patch = L.patch + wv * 256;
+    float* const patch = st.iw;          // (the patch of a particle is written when the rounds' items are dead: 256 of iw's floats)
     int* const rcnt = L.rcnt + wv * 16;
     int* const rcur = L.rcur + wv * 16;
     int* const rbase = L.rbase + wv * 17;
@@ -538,7 +538,7 @@ __device__ __forceinline__ void tf_body(const TfArgs& A, const TfLds& L, int blk
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_wave_barrier();
             // this round's pairs sit in lanes (t0 & 63) .. +31 of register set t0 >> 6; lanes 0..31 take them over
-            const int srcl = (t0 & 63) + (lane & 31);
+            const int srcl = (t0 & 63) + (lane & (TF_CHUNK - 1));
             TfPair Q;
             {
                 const TfPair& R = P[0];

@@ -1,0 +1,12 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+VARIANTS=("" "-DTF_CHUNK=32" "${@}")
+for defs in "${VARIANTS[@]}"; do
+  NF_EXTRA_DEFS="$defs" python -m neurofluid_amd.build > /dev/null 2>&1 || { echo "build failed: $defs"; continue; }
+  tag=$(echo "base$defs" | tr -d ' ' | tr -c 'A-Za-z0-9_\n' '_')
+  bash tools/prof.sh ab_$tag python $GRAFT_REPO_ROOT/tools/trans_perf.py 30 > /dev/null 2>&1
+  echo "== $defs"; grep iter gpurun_out/ab_$tag/run.log | tail -1
+  grep "k_trans_" gpurun_out/ab_$tag/p_kernel_stats.csv | cut -d, -f1,4 | cut -c1-60
+done
+NF_EXTRA_DEFS="" python -m neurofluid_amd.build > /dev/null 2>&1
+rm -rf gpurun_out/ab_*

@@ -15,7 +15,7 @@
 #define TP_BLOCK 1024
 #define TP_MAX_PER_THREAD 16            // n <= 16 384 particles
 #define TP_MAX_LDS_INTS 39936           // cell counters + the scatter list, 156 KB of LDS: n_cells + n_points <= this
-#define TS_MAX_LDS_INTS 38912           // the same for k_trans_stage1 (152 KB dynamic next to 5.3 KB of static LDS)
+#define TS_MAX_LDS_INTS 38911           // the same for k_trans_stage1 (152 KB dynamic next to 5.3 KB of static LDS)
 
 extern "C" int nf_trans_prepare_limits(int* max_points, int* max_cells)
 {
@@ -831,36 +831,46 @@ __device__ __forceinline__ void ts_build(const TsArgs& S, char* lds)
     return;
 #endif
     __syncthreads();
-    if (tid == 0) {
-        // The grid of THIS step hugs the cloud: the caller's bbox (the container, static: no host round trip) only bounds it —
-        // a few hundred cells instead of the container's ~29 000, which every pass below (zero, scan, store) walks.  Points
-        // outside the bbox land in border cells (the search stays exact, include/neurofluid_hip.h); the workspace offsets are
-        // those of the caller's header, computed for the larger grid.
-        NfGridHeader t = h;
-        int ncell = 1;
-        for (int d = 0; d < 3; ++d) {
-            float l = INFINITY, u2 = -INFINITY;
-            for (int w2 = 0; w2 < TS_WAVES; ++w2) { l = fminf(l, s_red[w2][d]); u2 = fmaxf(u2, s_red[w2][3 + d]); }
-            t.pt_lo[d] = nf_f2ord(l); t.pt_hi[d] = nf_f2ord(u2);          // exact bounds of the points
-            const float blo = h.origin[d], bhi = h.origin[d] + (float)h.dims[d] / h.inv_cell[d];
-            l = fminf(fmaxf(l, blo), bhi); u2 = fminf(fmaxf(u2, blo), bhi);
-            if (!(u2 >= l)) { l = blo; u2 = blo; }
-            const float ext = u2 - l;
-            float c = S.cell;
-            if (ext / c > (float)(NF_GRID_MAX_DIM - 1)) c = ext / (float)(NF_GRID_MAX_DIM - 1);
-            int dim = (int)floorf(ext / c) + 1;
-            dim = max(1, min(dim, min(NF_GRID_MAX_DIM, h.dims[d])));
-            t.origin[d] = l; t.inv_cell[d] = 1.0f / c; t.dims[d] = dim; t.sub0[d] = 0; t.subd[d] = dim;
-            ncell *= dim;
+    if (wv == 0) {
+        // the six bound columns, one per lane (min for 0..2, max for 3..5) over the waves' partial results
+        float red = 0.f;
+        if (lane < 6) {
+            red = s_red[0][lane];
+            for (int w2 = 1; w2 < TS_WAVES; ++w2) red = lane < 3 ? fminf(red, s_red[w2][lane]) : fmaxf(red, s_red[w2][lane]);
         }
-        t.n_cells = ncell;
-        hh = t;
-        *(NfGridHeader*)S.ws = t;
+        float bl[3], bu[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { bl[d] = __shfl(red, d, 64); bu[d] = __shfl(red, 3 + d, 64); }
+        if (lane == 0) {
+            // The grid of THIS step hugs the cloud: the caller's bbox (the container, static: no host round trip) only bounds it —
+            // a few hundred cells instead of the container's ~29 000, which every pass below (zero, scan, store) walks.  Points
+            // outside the bbox land in border cells (the search stays exact, include/neurofluid_hip.h); the workspace offsets are
+            // those of the caller's header, computed for the larger grid.
+            NfGridHeader t = h;
+            int ncell = 1;
+            for (int d = 0; d < 3; ++d) {
+                float l = bl[d], u2 = bu[d];
+                t.pt_lo[d] = nf_f2ord(l); t.pt_hi[d] = nf_f2ord(u2);          // exact bounds of the points
+                const float blo = h.origin[d], bhi = h.origin[d] + (float)h.dims[d] / h.inv_cell[d];
+                l = fminf(fmaxf(l, blo), bhi); u2 = fminf(fmaxf(u2, blo), bhi);
+                if (!(u2 >= l)) { l = blo; u2 = blo; }
+                const float ext = u2 - l;
+                float c = S.cell;
+                if (ext / c > (float)(NF_GRID_MAX_DIM - 1)) c = ext / (float)(NF_GRID_MAX_DIM - 1);
+                int dim = (int)floorf(ext / c) + 1;
+                dim = max(1, min(dim, min(NF_GRID_MAX_DIM, h.dims[d])));
+                t.origin[d] = l; t.inv_cell[d] = 1.0f / c; t.dims[d] = dim; t.sub0[d] = 0; t.subd[d] = dim;
+                ncell *= dim;
+            }
+            t.n_cells = ncell;
+            hh = t;
+            *(NfGridHeader*)S.ws = t;
+        }
     }
     __syncthreads();
     const int nc = hh.n_cells;
     int* cell_start = (int*)(b + hh.off_cell_start);
-    int* tmp_list = cells + nc;
+    int* tmp_list = cells + nc + 1;
     int* sorted_idx = (int*)(b + hh.off_sorted_idx);
     float4* sorted_pos = (float4*)(b + hh.off_sorted_pos);
     for (int c = tid; c < nc; c += TS_BLOCK) cells[c] = 0;
@@ -869,17 +879,17 @@ __device__ __forceinline__ void ts_build(const TsArgs& S, char* lds)
 #endif
     __syncthreads();
     // ---- count
-    int mycell[PER];
+    int mycell[PER], myslot[PER];
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
         const int i = u * TS_BLOCK + tid;
-        mycell[u] = -1;
+        mycell[u] = -1; myslot[u] = 0;
         if (i < n) {
             const int cx = nf_cell_coord(pv[u][0], hh.origin[0], hh.inv_cell[0], hh.dims[0]);
             const int cy = nf_cell_coord(pv[u][1], hh.origin[1], hh.inv_cell[1], hh.dims[1]);
             const int cz = nf_cell_coord(pv[u][2], hh.origin[2], hh.inv_cell[2], hh.dims[2]);
             mycell[u] = (cz * hh.dims[1] + cy) * hh.dims[0] + cx;
-            atomicAdd(&cells[mycell[u]], 1);
+            myslot[u] = atomicAdd(&cells[mycell[u]], 1);          // arrival slot inside the cell (the scatter below needs no second atomic)
         }
     }
 #if defined(TS_AB_STOP) && TS_AB_STOP == 3
@@ -906,16 +916,16 @@ __device__ __forceinline__ void ts_build(const TsArgs& S, char* lds)
         __syncthreads();
         int base = (wv ? s_scan[wv - 1] : 0) + x - run;
         for (int c = c0; c < c1; ++c) { const int cnt = cells[c]; cells[c] = base; cell_start[c] = base; base += cnt; }
-        if (tid == TS_BLOCK - 1) cell_start[nc] = s_scan[TS_WAVES - 1];
+        if (tid == TS_BLOCK - 1) { cell_start[nc] = s_scan[TS_WAVES - 1]; cells[nc] = s_scan[TS_WAVES - 1]; }
     }
 #if defined(TS_AB_STOP) && TS_AB_STOP == 4
     return;
 #endif
     __syncthreads();
-    // ---- scatter (arrival order), cells[] ends up holding the END of every cell
+    // ---- scatter (arrival order): cells[] holds the START of every cell (+ the total behind the last)
 #pragma unroll
     for (int u = 0; u < PER; ++u)
-        if (mycell[u] >= 0) tmp_list[atomicAdd(&cells[mycell[u]], 1)] = u * TS_BLOCK + tid;
+        if (mycell[u] >= 0) tmp_list[cells[mycell[u]] + myslot[u]] = u * TS_BLOCK + tid;
 #if defined(TS_AB_STOP) && TS_AB_STOP == 5
     return;
 #endif
@@ -926,7 +936,7 @@ __device__ __forceinline__ void ts_build(const TsArgs& S, char* lds)
         const int c = mycell[u];
         if (c < 0) continue;
         const int i = u * TS_BLOCK + tid;
-        const int s2 = c ? cells[c - 1] : 0, e = cells[c];
+        const int s2 = cells[c], e = cells[c + 1];
         int rank = 0;
         for (int t = s2; t < e; ++t) rank += (tmp_list[t] < i);
         sorted_idx[s2 + rank] = i;
@@ -960,11 +970,11 @@ static int ts_launch(const TsArgs& S0, const TfArgs& A, hipStream_t st)
     TsArgs S = S0;
     const int n = S.h.n_points;
     S.per = (n + TS_BLOCK - 1) / TS_BLOCK;
-    const size_t lds_build = (size_t)(S.h.n_cells + n) * sizeof(int), lds_box = TF_LDS_BYTES(3, TS_WAVES);
+    const size_t lds_build = (size_t)(S.h.n_cells + 1 + n) * sizeof(int), lds_box = TF_LDS_BYTES(3, TS_WAVES);
     const size_t lds = lds_build > lds_box ? lds_build : lds_box;
     static bool attr_set[64] = {};
     if (nf_first_use_on_device(attr_set))
-        hipFuncSetAttribute((const void*)k_trans_stage1, hipFuncAttributeMaxDynamicSharedMemorySize, TS_MAX_LDS_INTS * (int)sizeof(int));
+        hipFuncSetAttribute((const void*)k_trans_stage1, hipFuncAttributeMaxDynamicSharedMemorySize, (TS_MAX_LDS_INTS + 1) * (int)sizeof(int));
     // the container half: one workgroup of 16 waves per CU (the LDS of the grid build's workgroup sizes the launch), a particle
     // per wave and round (most waves leave after the sweep).  (The container half raises its overflow word from here; the
     // completion word is the fluid half's: the last launch of the front.)

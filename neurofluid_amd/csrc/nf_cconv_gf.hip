@@ -715,7 +715,7 @@ extern "C" int nf_cconv_gf_layer(const float* x, int n, int cin, int cout, int r
 //               + G3[i][64][co] + biases;      pos_correction = y3 / 128, update_pos_vel.
 // ------------------------------------------------------------------------------------------------
 #define G3_PITCH 196            // floats per particle (65 x 3 = 195, padded)
-#define G3_TILE 8               // particles per workgroup of the transform (614 workgroups at 4 913 particles)
+#define G3_TILE 8               // (rounds 2-3: particles per workgroup of the VALU transform; round 4: 32-particle tiles on the matrix pipe)
 
 // filter of the last layer as the transform reads it: kt[ci][o], o = node * 3 + co (195 columns, pitch G3_PITCH; node 64 = dense3) —
 // a thread's 64 weights are then 64 coalesced loads across the workgroup instead of 64 loads strided by 768 bytes
@@ -740,32 +740,49 @@ extern "C" int nf_cconv3_pack(const float* kernel, const float* dense_w, float* 
     return NF_OK;
 }
 
-__global__ void __launch_bounds__(256) k_cconv3_transform(const float* __restrict__ xr /* n x 64, activated */, int n,
+// G3[32 x 195] = xs[32 x 64] . kt[64 x 195] of one tile on the matrix pipe (round 4): 7 column blocks of 32, one per wave, 32 K-steps of
+// v_mfma_f32_32x32x2_f32 each — 224 MFMAs per tile instead of ~700 vector instructions per thread.  An element's sum runs over
+// k = 0..63 in ONE chain (exact fp32: fmaf per product).  xs: LDS tile with an odd pitch (the A fragment reads 32 rows at one k).
+#define G3_XS_PITCH 65
+__device__ __forceinline__ void g3_transform_tile(const float* __restrict__ xs, const float* __restrict__ kt, float* __restrict__ G3,
+                                                  int i0, int n, int wave, int lane)
+{
+    if (wave >= 7) return;
+    const int c = lane & 31, kh = lane >> 5;
+    const int ncol = 32 * wave + c;
+    const bool col_ok = ncol < 195;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float bw[32];
+#pragma unroll
+    for (int st = 0; st < 32; ++st) bw[st] = col_ok ? kt[(2 * st + kh) * G3_PITCH + ncol] : 0.f;
+#pragma unroll
+    for (int st = 0; st < 32; ++st) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[c * G3_XS_PITCH + 2 * st + kh], bw[st], acc, 0, 0, 0);
+    if (col_ok) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (i0 + row < n) G3[(size_t)(i0 + row) * G3_PITCH + ncol] = acc[r];
+        }
+    }
+}
+
+// stand-alone transform (nf_cconv3_layer): a 32-particle tile per workgroup of 8 waves (7 column blocks)
+__global__ void __launch_bounds__(512) k_cconv3_transform(const float* __restrict__ xr /* n x 64, activated */, int n,
                                                           const float* __restrict__ kt /* nf_cconv3_pack */, float* __restrict__ G3)
 {
-    __shared__ float xs[G3_TILE][64];
-    const int i0 = blockIdx.x * G3_TILE;
-    for (int t = threadIdx.x; t < G3_TILE * 16; t += 256) {
+    __shared__ float xs[GF_TILE * G3_XS_PITCH];
+    const int i0 = blockIdx.x * GF_TILE;
+    for (int t = threadIdx.x; t < GF_TILE * 16; t += 512) {
         const int r = t >> 4, q = t & 15;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i0 + r < n) v = *(const float4*)(xr + (size_t)(i0 + r) * 64 + 4 * q);
-        *(float4*)&xs[r][4 * q] = v;
+        float* d = xs + r * G3_XS_PITCH + 4 * q;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
     __syncthreads();
-    const int o = threadIdx.x;                   // output column: node * 3 + co
-    if (o >= 195) return;
-    float w[64];
-#pragma unroll
-    for (int ci = 0; ci < 64; ++ci) w[ci] = kt[ci * G3_PITCH + o];
-    for (int r = 0; r < G3_TILE && i0 + r < n; ++r) {
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const float4 v = *(const float4*)&xs[r][4 * q];          // (broadcast: every lane reads the same address)
-            a0 = fmaf(v.x, w[4 * q], a0); a1 = fmaf(v.y, w[4 * q + 1], a1); a2 = fmaf(v.z, w[4 * q + 2], a2); a3 = fmaf(v.w, w[4 * q + 3], a3);
-        }
-        G3[(size_t)(i0 + r) * G3_PITCH + o] = (a0 + a1) + (a2 + a3);
-    }
+    g3_transform_tile(xs, kt, G3, i0, n, threadIdx.x >> 6, threadIdx.x & 63);
 }
 
 // conv2's epilogue and conv3's transform in one kernel (a tile of 32 particles per workgroup): the transform of a particle needs
@@ -773,10 +790,11 @@ __global__ void __launch_bounds__(256) k_cconv3_transform(const float* __restric
 // a2 in global memory and a launch of their own.  Same expressions as k_cconv_gf_epi and k_cconv3_transform: identical G3.
 __global__ void __launch_bounds__(1024) k_cconv_gf_epi_g3(GfEpi E, const float* __restrict__ kt /* nf_cconv3_pack */, float* __restrict__ G3)
 {
-    // 1 024 threads per 32-particle tile: the epilogue reads the slabs in whole 128-byte rows (thread = row, column group), the
-    // transform runs as four 256-thread groups of 8 particles each, like k_cconv3_transform's workgroups.  (256 threads per tile:
-    // 26 us, 154 workgroups walking 32 rows each; 8-row workgroups: 16 us, the slab reads fall apart into 32-byte pieces.)
-    __shared__ float xs[GF_TILE][64];
+    // 1 024 threads per 32-particle tile: the epilogue reads the slabs in whole 128-byte rows (thread = row, column group); the
+    // transform then runs on the matrix pipe (g3_transform_tile: 12.6 -> 9.4 us for the kernel; rounds 2-3 ran it on the vector
+    // ALUs as four 256-thread groups of 8 particles).  (256 threads per tile: 26 us, 154 workgroups walking 32 rows each; 8-row
+    // workgroups: 16 us, the slab reads fall apart into 32-byte pieces.)
+    __shared__ float xs[GF_TILE * G3_XS_PITCH];
     const int tile = blockIdx.x, i0 = tile * GF_TILE;
     const int wfirst = gf_owner((long long)tile * GF_COST, E.nwg, E.ctot), wlast = gf_owner((long long)tile * GF_COST + 64, E.nwg, E.ctot);
     const int nseg = wlast - wfirst + 1;
@@ -791,24 +809,11 @@ __global__ void __launch_bounds__(1024) k_cconv_gf_epi_g3(GfEpi E, const float* 
                 if (E.out) E.out[(size_t)i * 64 + col] = v;
                 if (E.out_relu) E.out_relu[(size_t)i * 64 + col] = fmaxf(v, 0.f);
             }
-            xs[row][col] = fmaxf(v, 0.f);
+            xs[row * G3_XS_PITCH + col] = fmaxf(v, 0.f);
         }
     }
     __syncthreads();
-    const int o = threadIdx.x & 255, r0 = (threadIdx.x >> 8) * G3_TILE;      // output column: node * 3 + co; this group's 8 rows
-    if (o >= 195) return;
-    float w[64];
-#pragma unroll
-    for (int ci = 0; ci < 64; ++ci) w[ci] = kt[ci * G3_PITCH + o];
-    for (int r = r0; r < r0 + G3_TILE && i0 + r < E.n; ++r) {
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const float4 v = *(const float4*)&xs[r][4 * q];
-            a0 = fmaf(v.x, w[4 * q], a0); a1 = fmaf(v.y, w[4 * q + 1], a1); a2 = fmaf(v.z, w[4 * q + 2], a2); a3 = fmaf(v.w, w[4 * q + 3], a3);
-        }
-        G3[(size_t)(i0 + r) * G3_PITCH + o] = (a0 + a1) + (a2 + a3);
-    }
+    g3_transform_tile(xs, kt, G3, i0, E.n, threadIdx.x >> 6, threadIdx.x & 63);      // same function as k_cconv3_transform: identical G3
 }
 
 struct G3Epi { const float* pos; const float* pos_new; float* pos_c; float* vel_c; float scale, dt; };
@@ -868,7 +873,7 @@ extern "C" int nf_cconv3_layer(const float* x_act, int n, const uint16_t* roff, 
     NF_CHECK_ARG(!pos || (pos_new && pos_c && vel_c), "the update needs pos_new / pos_c / vel_c");
     if (n <= 0) return NF_OK;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_cconv3_transform, dim3((n + G3_TILE - 1) / G3_TILE), dim3(256), 0, st, x_act, n, packed, workspace);
+    hipLaunchKernelGGL(k_cconv3_transform, dim3((n + GF_TILE - 1) / GF_TILE), dim3(512), 0, st, x_act, n, packed, workspace);
     G3Epi E;
     E.pos = pos; E.pos_new = pos_new; E.pos_c = pos_c; E.vel_c = vel_c; E.scale = scale; E.dt = dt;
     hipLaunchKernelGGL(k_cconv3_gather, dim3((n + 3) / 4), dim3(256), 0, st, (const float*)workspace, n, roff, ent, pitch, bias_conv,

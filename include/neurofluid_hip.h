@@ -439,6 +439,16 @@ int nf_cconv_gf_layer_g3(const float* x, int n, int cin, int relu, const uint16_
 int nf_cconv3_gather(const float* g3, int n, const uint16_t* roff, const uint32_t* entries, int pitch, const float* bias_conv,
                      const float* bias_dense, float* y3, const float* pos /*or NULL: no update*/, const float* pos_new,
                      float scale, float dt, float* pos_c, float* vel_c, nf_stream_t stream);
+/* The optimiser step of the training callers (trainer/trainer_renderer.py:96-99, trainer/trainer_e2e.py:277-283: torch.optim.Adam.step):
+ * ONE launch over a whole parameter list.  [host] arrays of `count` device pointers / sizes; step_size[t] = lr / (1 - beta1^step_t),
+ * bc2_sqrt[t] = sqrt(1 - beta2^step_t) computed by the caller (torch keeps `step` per tensor).  torch.optim.Adam's default
+ * arithmetic, operation by operation: g' = g + wd p; m = lerp(m, g', 1 - beta1); v = v beta2 + (1 - beta2) g'^2;
+ * p = p - step_size m / (sqrt(v) / bc2_sqrt + eps). */
+int nf_adam_step(int count, float* const* params /*[host]*/, const float* const* grads /*[host]*/, float* const* exp_avg /*[host]*/,
+                 float* const* exp_avg_sq /*[host]*/, const int64_t* sizes /*[host]*/, const float* step_size /*[host]*/,
+                 const float* bc2_sqrt /*[host]*/, double beta1, double beta2 /* (1 - beta) is formed in double, as torch forms its scalars */,
+                 float eps, float weight_decay, nf_stream_t stream);
+
 typedef struct {
     /* model (device pointers; wpK = nf_cconv_gf_pack of convK / denseK) */
     const float *k_fluid, *b_fluid, *k_obst, *b_obst, *dense0_w, *dense0_b;

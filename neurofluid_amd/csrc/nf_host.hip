@@ -85,3 +85,72 @@ extern "C" void* nf_pinned_device_ptr(void* host_ptr)
     if (!host_ptr || hipHostGetDevicePointer(&d, host_ptr, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     return d;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Adam step of a whole parameter list in ONE launch (round 4).  torch's fused Adam walks the 48 + 22 tensors of the two models
+// through multi_tensor_apply: 2-3 launches of ~44 us for 2.0 M parameters (57 MB of traffic = ~10 us at HBM speed) on every
+// training step.  Here the tensor table (pointers, sizes, the per-tensor step size and bias correction) travels in the kernel
+// arguments and a block finds its (tensor, chunk) by a scan over the table's chunk prefix.  The arithmetic is torch.optim.Adam's
+// default (single-tensor) formulation, operation by operation:
+//     g' = g + wd p;  m = m + (g' - m)(1 - b1)  [lerp];  v = v b2 + (1 - b2) g' g';  p = p - step_size * m / (sqrt(v) / bc2_sqrt + eps)
+// ------------------------------------------------------------------------------------------------
+#define NA_MAX 64
+#define NA_CHUNK 4096
+struct NfAdamArgs {
+    float* p[NA_MAX]; const float* g[NA_MAX]; float* m[NA_MAX]; float* v[NA_MAX];
+    int n[NA_MAX]; int chunk0[NA_MAX + 1];
+    float step_size[NA_MAX], bc2_sqrt[NA_MAX];
+    int count;
+    float beta2, w1, w2, eps, weight_decay;      // w1 = 1 - beta1, w2 = 1 - beta2, rounded from the DOUBLE differences (as torch's scalars are)
+};
+
+__global__ void __launch_bounds__(256) k_adam(NfAdamArgs A)
+{
+    int t = 0;
+    const int b = blockIdx.x;
+    while (t + 1 < A.count && b >= A.chunk0[t + 1]) ++t;
+    const int base = (b - A.chunk0[t]) * NA_CHUNK, n = A.n[t];
+    float* __restrict__ p = A.p[t];
+    const float* __restrict__ g = A.g[t];
+    float* __restrict__ m = A.m[t];
+    float* __restrict__ v = A.v[t];
+    const float ss = A.step_size[t], bc = A.bc2_sqrt[t], w1 = A.w1, w2 = A.w2;
+#pragma unroll 4
+    for (int k = 0; k < NA_CHUNK / 256; ++k) {
+        const int i = base + k * 256 + threadIdx.x;
+        if (i >= n) break;
+        float gi = g[i];
+        const float pi = p[i];
+        if (A.weight_decay != 0.f) gi = gi + A.weight_decay * pi;
+        const float mi = m[i], vi = v[i];
+        const float mn = fmaf(w1, gi - mi, mi);                    // torch.lerp(m, g, 1 - b1) for a weight < 0.5: fma(w, g - m, m)
+        const float vn = vi * A.beta2 + w2 * (gi * gi);            // mul_(b2).addcmul_(g, g, value = 1 - b2)
+        const float denom = sqrtf(vn) / bc + A.eps;
+        m[i] = mn; v[i] = vn;
+        p[i] = pi + (-ss) * (mn / denom);                          // addcdiv_(m, denom, value = -step_size)
+    }
+}
+
+extern "C" int nf_adam_step(int count, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                            const int64_t* sizes, const float* step_size, const float* bc2_sqrt, double beta1, double beta2, float eps,
+                            float weight_decay, nf_stream_t stream)
+{
+    NF_CHECK_ARG(count >= 0 && (count == 0 || (params && grads && exp_avg && exp_avg_sq && sizes && step_size && bc2_sqrt)), "null pointer");
+    for (int t0 = 0; t0 < count; t0 += NA_MAX) {
+        NfAdamArgs A;
+        const int c = count - t0 < NA_MAX ? count - t0 : NA_MAX;
+        int chunks = 0;
+        for (int t = 0; t < c; ++t) {
+            NF_CHECK_ARG(sizes[t0 + t] >= 0 && sizes[t0 + t] < (1ll << 31), "tensor too large");
+            A.p[t] = params[t0 + t]; A.g[t] = grads[t0 + t]; A.m[t] = exp_avg[t0 + t]; A.v[t] = exp_avg_sq[t0 + t];
+            A.n[t] = (int)sizes[t0 + t]; A.chunk0[t] = chunks;
+            A.step_size[t] = step_size[t0 + t]; A.bc2_sqrt[t] = bc2_sqrt[t0 + t];
+            chunks += (A.n[t] + NA_CHUNK - 1) / NA_CHUNK;
+        }
+        A.chunk0[c] = chunks;
+        A.count = c; A.beta2 = (float)beta2; A.w1 = (float)(1.0 - beta1); A.w2 = (float)(1.0 - beta2); A.eps = eps; A.weight_decay = weight_decay;
+        if (chunks > 0) hipLaunchKernelGGL(k_adam, dim3(chunks), dim3(256), 0, (hipStream_t)stream, A);
+    }
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}

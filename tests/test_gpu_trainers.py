@@ -189,3 +189,55 @@ def test_tile_sharded_eval_two_ranks_one_gpu(workdir):
         assert p.exitcode == 0
     assert [r[:2] for r in res] == [(0, True), (1, True)]
     assert res[0][2] == res[1][2] and len(res[0][2]) > 0
+
+
+def test_hip_adam_matches_torch_adam():
+    """make_adam's optimiser (HipAdam: one nf_adam_step launch per step) against torch.optim.Adam's default implementation on the
+    same parameters and gradients: two groups with their own learning rates (trainer_e2e.py:83-139), tensors from 1 element to
+    several chunks, weight decay, 6 steps — parameters and both moments within 2 ulp-level bounds (the two run the same operations;
+    torch's division / sqrt and the kernel's may round the last bit differently), `step` counters equal; then the state dicts
+    interchange: HipAdam continues from a torch.optim.Adam checkpoint and vice versa, and portable_optimizer_state() of both agree."""
+    from neurofluid_amd.train_step import make_adam, HipAdam, portable_optimizer_state, load_optimizer_state
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(5)
+    shapes = [(1,), (3, 128), (256, 198), (256, 454), (4, 4, 4, 96, 64), (64,), (5000,)]
+
+    def params():
+        g = torch.Generator().manual_seed(11)
+        return [torch.nn.Parameter((torch.randn(*s, generator=g) * 0.1).to(dev)) for s in shapes]
+    pa, pb = params(), params()
+    groups = lambda ps: [{"params": ps[:4], "lr": 3e-4}, {"params": ps[4:], "lr": 1e-3, "weight_decay": 1e-2}]      # noqa: E731
+    oa = make_adam(groups(pa), betas=(0.9, 0.999), eps=1e-8)
+    ob = torch.optim.Adam(groups(pb), betas=(0.9, 0.999), eps=1e-8, foreach=False, fused=False)
+    assert isinstance(oa, HipAdam)
+
+    def run(steps, oa, ob, pa, pb):
+        for _ in range(steps):
+            for x, y in zip(pa, pb):
+                gr = (torch.randn(x.shape, generator=gen) * 0.05).to(dev)
+                x.grad, y.grad = gr.clone(), gr.clone()
+            oa.step(); ob.step()
+        for k, (x, y) in enumerate(zip(pa, pb)):
+            torch.testing.assert_close(x.detach(), y.detach(), rtol=2e-6, atol=2e-8, msg=f"param {k}")
+            sa, sb = oa.state[x], ob.state[y]
+            # (one rounding of a value of ~1e-2 is 2e-9: elements that nearly cancel differ by that much in absolute terms)
+            torch.testing.assert_close(sa["exp_avg"], sb["exp_avg"], rtol=2e-6, atol=1e-8)
+            torch.testing.assert_close(sa["exp_avg_sq"], sb["exp_avg_sq"], rtol=2e-6, atol=1e-11)
+            assert float(sa["step"]) == float(sb["step"])
+    run(6, oa, ob, pa, pb)
+    # interchange: each continues from the OTHER's checkpoint
+    sda, sdb = portable_optimizer_state(oa), portable_optimizer_state(ob)
+    assert sda["param_groups"] == sdb["param_groups"] or [{k: v for k, v in g.items() if k not in ("fused", "foreach")} for g in sda["param_groups"]] == \
+        [{k: v for k, v in g.items() if k not in ("fused", "foreach")} for g in sdb["param_groups"]]
+    oa2 = make_adam(groups(pa), betas=(0.9, 0.999), eps=1e-8)
+    ob2 = torch.optim.Adam(groups(pb), betas=(0.9, 0.999), eps=1e-8, foreach=False, fused=False)
+    load_optimizer_state(oa2, sdb)
+    load_optimizer_state(ob2, sda)
+    run(3, oa2, ob2, pa, pb)
+    assert float(oa2.state[pa[0]]["step"]) == 9.0
+    # a parameter without a gradient is skipped, like torch does
+    for x in pa:
+        x.grad = None
+    before = [x.detach().clone() for x in pa]
+    oa2.step()
+    assert all(torch.equal(a, b.detach()) for a, b in zip(before, pa))

@@ -95,9 +95,18 @@ __global__ void __launch_bounds__(GF_THREADS) k_cconv_gf(GfArgs A)
     const int nun = g1 - g0;
     // the role is a SCALAR (wave-uniform) value: the two halves below are separate scalar branches, each wave meets exactly
     // the s_barriers of its own half
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int hwave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+#ifdef GF_AB_SPLIT_SIMD
+    // roles by SIMD: a workgroup's waves go to the SIMDs in a cyclic order, so waves w and w + 4 share one.  Consumers = waves
+    // {0, 1, 4, 5} (two SIMDs run nothing but MFMAs), producers = waves {2, 3, 6, 7} (the other two run nothing but the gather)
+    const bool is_consumer = ((hwave >> 1) & 1) == 0;
+    const int wave = (hwave & 1) | ((hwave >> 2) << 1);          // index inside the role: 0..3
+#else
+    const bool is_consumer = hwave < 4;
+    const int wave = hwave & 3;
+#endif
 
-    if (wave < 4) {
+    if (is_consumer) {
         // ------------------------------------------------------------------ consumers
       if constexpr (SPLIT) {
         constexpr int KS = CIN / 16, KP = 4 / NB, SP = KS / KP;      // K-steps per node; K parts; K-steps of this wave per node
@@ -292,7 +301,7 @@ __global__ void __launch_bounds__(GF_THREADS) k_cconv_gf(GfArgs A)
     // 8 producer waves = 2 per SIMD (next to a consumer wave): the gather is bound by the loads a wave keeps in flight times the L2
     // latency, and by the wave's issue rate — twice the waves double both (4 waves, 8 threads per point: 45 us for conv1's gather
     // alone, whatever was done to the instruction stream)
-    const int pt = threadIdx.x - 256, pp = pt / GF_TPP, t = pt % GF_TPP;      // (lane = threadIdx.x & 63 as for the consumers)
+    const int pt = wave * 64 + lane, pp = pt / GF_TPP, t = pt % GF_TPP;      // (lane = threadIdx.x & 63 as for the consumers)
     auto has_quad = [&](int k) __attribute__((always_inline)) { return t + GF_TPP * k < CIN / 4; };
     auto load_roff = [&](int g, int& e0, int& e1) __attribute__((always_inline)) {
         const int tile = g / GF_UNITS, u = g - tile * GF_UNITS, i = tile * GF_TILE + pp;

@@ -392,8 +392,8 @@ class _GraphedParticleNetFn(torch.autograd.Function):
         tg.checked = False
         ctx.pn, ctx.tg, ctx.serial = pn, tg, tg.serial
         pos_c, vel_c, nn, _aux = tg.outs
-        pn.num_fluid_neighbors, pn._y3 = nn, _aux["ans"][-1]
-        out = (pos_c.clone(), vel_c.clone(), nn.clone())
+        out = (pos_c.clone(), vel_c.clone(), nn.clone())          # (the graph's own outputs are rewritten by the next replay)
+        pn.num_fluid_neighbors, pn._y3 = out[2], _aux["ans"][-1]
         ctx.mark_non_differentiable(out[2])
         return out
 

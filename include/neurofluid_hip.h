@@ -464,7 +464,11 @@ typedef struct {
     float radius, extent, dt, scale;
     float gravity[3]; float bbox[6];
     int split;          /* arithmetic of conv1 / conv2: 0 fp32 MFMA (wp1, wp2 from nf_cconv_gf_pack), 1 split fp16 (.._pack_split) */
+    int search;         /* fixed-radius search of the fluid cloud: 0 auto (all pairs up to nf_trans_all_pairs_max_points() particles,
+                           the cell grid beyond), 1 cell grid (grid_ws, bbox; limits: nf_trans_prepare_limits), 2 all pairs (no grid:
+                           grid_ws / bbox unused; rows in ascending neighbour index).  Same neighbour sets and counts either way */
 } nf_trans_step_t;
+int nf_trans_all_pairs_max_points(void);
 int nf_trans_step(const nf_trans_step_t* s /*[host]*/, const float* pos, const float* vel, float* num_fluid_nbrs, float* pos_c,
                   float* vel_c, int32_t* host_flag3 /* see nf_trans_front */, int step_id, nf_stream_t stream);
 

@@ -23,7 +23,7 @@ class TransStep(ctypes.Structure):
                [(k, c_void_p) for k in ("pos_new", "vel_new", "feats", "counts2", "idx_f", "d2_f", "roff", "ent", "a0", "a1", "a1r", "g3", "y3",
                                         "scratch", "overflow2", "done_counter")] + \
                [(k, c_int) for k in ("n", "pitch_f", "pitch_b", "use_window", "max_wg")] + \
-               [(k, c_float) for k in ("radius", "extent", "dt", "scale")] + [("gravity", c_float * 3), ("bbox", c_float * 6), ("split", c_int)]
+               [(k, c_float) for k in ("radius", "extent", "dt", "scale")] + [("gravity", c_float * 3), ("bbox", c_float * 6), ("split", c_int), ("search", c_int)]
 
 
 # name -> (restype, argtypes); mirrors include/neurofluid_hip.h one-to-one (tests check the list)
@@ -112,6 +112,7 @@ PROTOTYPES = {
     "nf_trans_prepare": (c_int, [c_void_p, c_void_p, ctypes.POINTER(c_float), c_float, c_int, c_float, ctypes.POINTER(c_float), c_void_p,
                                 c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nf_trans_front_max_pitch": (c_int, []),
+    "nf_trans_all_pairs_max_points": (c_int, []),
     "nf_trans_front": (c_int, [c_void_p] * 5 + [c_int, c_float, c_float, c_int, c_int, c_int] + [c_void_p] * 13 + [c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "nf_pinned_device_ptr": (c_void_p, [c_void_p]),
     "nf_cconv_gf_packed_floats": (c_size_t, [c_int, c_int]),

@@ -273,34 +273,57 @@ struct TfArgs {
     int step_id;
 };
 
-template <int CIN>
-__device__ __forceinline__ float tf_patch_times_filter(const float* __restrict__ patch, const float* __restrict__ Ks, int co, int half)
+// Layer 0 as patch x filter for the NP particles a wave has patches of:  out[p][co] = sum_m patch_p[m] * Ks[m][co],  m = node * CI + ci.
+// m = 8 k + s is split over the 8 lane groups s = lane >> 3 (8 CI values of k each); a lane holds 4 consecutive output channels
+// (cog = lane & 7), so a filter row segment is ONE ds_read_b128 — the 8 groups' rows fall on distinct banks — shared by the NP
+// particles, and the patches are stored transposed ([s][k]): four k of a group are one broadcast ds_read_b128.  (Before: 256
+// ds_read_b32 and 128 FMAs per lane for EVERY particle — the whole 32 KB filter through the LDS port once per particle; that product,
+// not the patch build, was the largest LDS consumer of the front kernel.)  The result is complete in the lanes of group 0.
+template <int CI, int NP>
+__device__ __forceinline__ void tf_gemv(const float* const (&pt)[NP], const float* __restrict__ Ks, float (&out)[NP][4])
 {
-    // out[co] = sum_m patch[m] * Ks[m][co], m = node * CIN + ci; the two half-waves take the two halves of m
-    const int M = 64 * CIN, m0 = half * (M / 2);
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll 4
-    for (int m = m0; m < m0 + M / 2; m += 4) {
-        a0 += patch[m] * Ks[m * 32 + co];
-        a1 += patch[m + 1] * Ks[(m + 1) * 32 + co];
-        a2 += patch[m + 2] * Ks[(m + 2) * 32 + co];
-        a3 += patch[m + 3] * Ks[(m + 3) * 32 + co];
+    constexpr int KS = 8 * CI;
+    const int lane = threadIdx.x & 63, s = lane >> 3, cog = lane & 7;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) out[p][0] = out[p][1] = out[p][2] = out[p][3] = 0.f;
+#pragma unroll
+    for (int k4 = 0; k4 < KS; k4 += 4) {
+        float pv[NP][4];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const float4 t = *(const float4*)(pt[p] + s * KS + k4);
+            pv[p][0] = t.x; pv[p][1] = t.y; pv[p][2] = t.z; pv[p][3] = t.w;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const float4 w = *(const float4*)(Ks + ((k4 + kk) * 8 + s) * 32 + cog * 4);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                out[p][0] = fmaf(pv[p][kk], w.x, out[p][0]); out[p][1] = fmaf(pv[p][kk], w.y, out[p][1]);
+                out[p][2] = fmaf(pv[p][kk], w.z, out[p][2]); out[p][3] = fmaf(pv[p][kk], w.w, out[p][3]);
+            }
+        }
     }
-    const float a = (a0 + a1) + (a2 + a3);
-    return a + __shfl_xor(a, 32, 64);
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) out[p][c] += __shfl_xor(out[p][c], o, 64);
 }
 
 // interpolation data of one pair, exactly k_pair_precompute (nf_cconv.hip): base node (bx, by, bz), fractions, window
 struct TfPair { int j, bx, by, bz; float fx, fy, fz, imp; };
 
-__device__ __forceinline__ TfPair tf_pair(const TfStage& st, int t, float qx, float qy, float qz, float scale, float inv_r2, int use_window)
+__device__ __forceinline__ TfPair tf_pair_v(int j, float px, float py, float pz, float d2, float qx, float qy, float qz, float scale,
+                                            float inv_r2, int use_window)
 {
     TfPair P;
-    P.j = st.j[t];
-    float x = (st.u.pos.px[t] - qx) * scale, y = (st.u.pos.py[t] - qy) * scale, z = (st.u.pos.pz[t] - qz) * scale;
+    P.j = j;
+    float x = (px - qx) * scale, y = (py - qy) * scale, z = (pz - qz) * scale;
     tr_ball_to_cube(x, y, z);
     P.imp = 1.f;
-    if (use_window) { const float tt = 1.f - st.d2[t] * inv_r2; P.imp = fminf(fmaxf(tt * tt * tt, 0.f), 1.f); }
+    if (use_window) { const float tt = 1.f - d2 * inv_r2; P.imp = fminf(fmaxf(tt * tt * tt, 0.f), 1.f); }
     const float c[3] = {(x + 1.f) * 1.5f, (y + 1.f) * 1.5f, (z + 1.f) * 1.5f};
     int i0[3];
     float f[3];
@@ -315,13 +338,21 @@ __device__ __forceinline__ TfPair tf_pair(const TfStage& st, int t, float qx, fl
     return P;
 }
 
+__device__ __forceinline__ TfPair tf_pair(const TfStage& st, int t, float qx, float qy, float qz, float scale, float inv_r2, int use_window)
+{
+    return tf_pair_v(st.j[t], st.u.pos.px[t], st.u.pos.py[t], st.u.pos.pz[t], st.d2[t], qx, qy, qz, scale, inv_r2, use_window);
+}
+
 // LDS regions of the front body (static __shared__ in k_trans_front, carved from the dynamic block in k_trans_stage1)
 struct TfLds {
     float* Ks;                          // 64 * CI * 32 floats: the layer-0 filter of this cloud
     TfStage* stage;                     // [TF_WAVES]
     int* rcnt; int* rcur; int* rbase;   // [TF_WAVES][16], [TF_WAVES][16], [TF_WAVES][17]
+    int* list; float* bias;             // container half: the queued particles ([TF_LISTMAX] + the count), conv0_obstacle's bias row
 };
-#define TF_LDS_BYTES(CI, NW) ((size_t)64 * (CI) * 32 * 4 + sizeof(TfStage) * (NW) + (size_t)(NW) * (16 + 16 + 17) * 4)
+#define TF_LISTMAX 512                  // particles one workgroup of the container half can be dealt
+#define TF_LDS_BYTES(CI, NW) ((size_t)64 * (CI) * 32 * 4 + sizeof(TfStage) * (NW) + (size_t)(NW) * (16 + 16 + 17) * 4 + \
+                              ((CI) == 3 ? (size_t)(TF_LISTMAX + 4 + 32) * 4 + 16 : 0))
 
 template <int NW>
 __device__ __forceinline__ TfLds tf_carve(char* base, int ci)
@@ -331,8 +362,187 @@ __device__ __forceinline__ TfLds tf_carve(char* base, int ci)
     L.stage = (TfStage*)base; base += sizeof(TfStage) * NW;
     L.rcnt = (int*)base; base += NW * 16 * 4;
     L.rcur = (int*)base; base += NW * 16 * 4;
-    L.rbase = (int*)base;
+    L.rbase = (int*)base; base += NW * 17 * 4;
+    base = (char*)(((uintptr_t)base + 15) & ~(uintptr_t)15);
+    L.list = (int*)base; base += (TF_LISTMAX + 4) * 4;
+    L.bias = (float*)base;
     return L;
+}
+
+// per-wave LDS pointers of the front body
+struct TfWave { TfStage* st; float* patch; int* rcnt; int* rcur; int* rbase; const float* Ks; };
+
+// The neighbour features of a pair (lane = pair), requested with the pair data instead of inside the patch rounds
+template <int WHICH>
+__device__ __forceinline__ float4 tf_feat(const TfArgs& A, int j)
+{
+    if (!WHICH) return *(const float4*)(A.feats_f + 4 * (size_t)j);
+    return make_float4(A.feats_b[3 * (size_t)j], A.feats_b[3 * (size_t)j + 1], A.feats_b[3 * (size_t)j + 2], 0.f);
+}
+
+// Everything behind the pair data of particle i (np staged pairs: P / F hold them with lane = pair, 64 per register set; the fluid
+// half's row counts are in rcnt) except the product with the filter: the layer-0 patch (left in W.patch, transposed), roff + the row
+// entries (fluid).
+template <int WHICH>
+__device__ __forceinline__ void tf_tail(const TfArgs& A, const TfWave& W, int i, int np, const TfPair (&P)[2], const float4 (&F)[2])
+{
+    static_assert(TF_CHUNK == 64, "a round of the patch build is one register set of pairs");
+    constexpr int CI = WHICH ? 3 : 4;
+    const int lane = threadIdx.x & 63;
+    TfStage& st = *W.st;
+    float* const patch = W.patch;
+    int* const rcnt = W.rcnt;
+    int* const rcur = W.rcur;
+    int* const rbase = W.rbase;
+    const float* const Ks = W.Ks;
+    // ---- layer-0 patch P[node][ci] = sum_pairs w(pair, node) * feat[pair][ci], in rounds of 64 pairs WITHOUT float atomics
+    // (ds_add_f32 with the same-address collisions of this scatter cost 44 of the kernel's 70 us): a pair's 8 (node, weight)
+    // items are bucketed by node with integer LDS atomics (the returned slot orders a bucket), then lane = NODE walks its
+    // bucket and accumulates in registers.
+    float pacc[4] = {0.f, 0.f, 0.f, 0.f};
+#ifndef TF_AB_SKIP_PATCH
+    for (int t0 = 0; t0 < np; t0 += TF_CHUNK) {
+        st.ccount[lane] = 0;
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        // a round = one register set of pair data (lane = pair), as pass 2 left it
+        const bool hi = t0 >= 64;
+        const TfPair Q = hi ? P[1] : P[0];
+        const float4 fq = hi ? F[1] : F[0];
+        const bool mine = lane < TF_CHUNK && t0 + lane < np;
+        int slot[8], cellk[8];
+        float wk[8];
+        if (mine) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
+                wk[k] = Q.imp * ((dx ? Q.fx : 1.f - Q.fx) * (dy ? Q.fy : 1.f - Q.fy) * (dz ? Q.fz : 1.f - Q.fz));
+                cellk[k] = ((Q.bz + dz) * 4 + (Q.by + dy)) * 4 + (Q.bx + dx);
+                slot[k] = atomicAdd(&st.ccount[cellk[k]], 1);
+            }
+            *(float4*)st.u.feat[lane] = fq;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        const int mycnt = st.ccount[lane];
+        int x = mycnt;
+#pragma unroll
+        for (int o2 = 1; o2 < 64; o2 <<= 1) { const int y = __shfl_up(x, o2, 64); if (lane >= o2) x += y; }
+        const int myoff = x - mycnt;
+        st.coff[lane] = myoff;
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        if (mine) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int pos = st.coff[cellk[k]] + slot[k];
+                st.iw[pos] = wk[k];
+                st.it[pos] = (unsigned char)lane;
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        int cmax = mycnt;
+#pragma unroll
+        for (int o2 = 1; o2 < 64; o2 <<= 1) cmax = max(cmax, __shfl_xor(cmax, o2, 64));
+        for (int e = 0; e < cmax; ++e) {
+            if (e < mycnt) {
+                const float w = st.iw[myoff + e];
+                const float4 f4 = *(const float4*)st.u.feat[st.it[myoff + e]];
+                pacc[0] = fmaf(w, f4.x, pacc[0]); pacc[1] = fmaf(w, f4.y, pacc[1]);
+                pacc[2] = fmaf(w, f4.z, pacc[2]); pacc[3] = fmaf(w, f4.w, pacc[3]);
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+    }
+#endif
+    // the patch, transposed for tf_gemv: element m = node * CI + ci goes to [m & 7][m >> 3]
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci)
+        if (ci < CI) { const int m = lane * CI + ci; patch[(m & 7) * (8 * CI) + (m >> 3)] = pacc[ci]; }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    if (!WHICH) {
+        // ---- pass 3: exclusive scan of the 16 row counts -> roff
+        int c = lane < 16 ? rcnt[lane] : 0;
+        int x = c;
+#pragma unroll
+        for (int o2 = 1; o2 < 16; o2 <<= 1) { const int y = __shfl_up(x, o2, 64); if (lane >= o2) x += y; }
+        if (lane < 16) rbase[lane] = x - c;
+        if (lane == 15) rbase[16] = x;
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 17) A.roff[(size_t)i * 20 + lane] = (uint16_t)rbase[lane];
+        // ---- pass 4 (lane = pair): the four row entries of every pair; the LDS cursors advance in lane order, so a
+        // bucket keeps the pair order
+        uint32_t* ebase = A.ent + (size_t)i * (size_t)(4 * A.pitch_f) * 3;
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+#ifdef TF_AB_SKIP_ENT
+            break;
+#endif
+            if (64 * c2 < np) {
+                if (64 * c2 + lane < np) {
+                    const TfPair& Q = P[c2];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int dy = r & 1, dz = r >> 1;
+                        const int rho = (Q.bz + dz) * 4 + Q.by + dy;
+                        const int e = rbase[rho] + atomicAdd(&rcur[rho], 1);
+                        // the weights of k_pair_precompute, same expression and association
+                        const float w0 = Q.imp * ((1.f - Q.fx) * (dy ? Q.fy : 1.f - Q.fy) * (dz ? Q.fz : 1.f - Q.fz));
+                        const float w1 = Q.imp * (Q.fx * (dy ? Q.fy : 1.f - Q.fy) * (dz ? Q.fz : 1.f - Q.fz));
+                        uint32_t* dst = ebase + 3 * (size_t)e;
+                        dst[0] = (uint32_t)Q.j | ((uint32_t)Q.bx << 30);
+                        dst[1] = __float_as_uint(w0);
+                        dst[2] = __float_as_uint(w1);
+                    }
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();          // the next particle of this wave reuses the stage / patch / counters
+}
+
+// Layer 0's product + output rows for the particles idx[0..NP) whose patches sit in pt[]: conv0 (+ bias, ReLU) from lane group 0, the
+// fluid's Linear branch on the particle's own features from the upper half-wave.
+template <int WHICH, int NP>
+__device__ __forceinline__ void tf_layer0_out(const TfArgs& A, const float* __restrict__ Ks, const float* const (&pt)[NP], const int (&idx)[NP])
+{
+    constexpr int CI = WHICH ? 3 : 4;
+    const int lane = threadIdx.x & 63;
+    float o[NP][4];
+#ifdef TF_AB_SKIP_GEMV
+    for (int p = 0; p < NP; ++p) o[p][0] = o[p][1] = o[p][2] = o[p][3] = pt[p][lane];
+#else
+    tf_gemv<CI, NP>(pt, Ks, o);
+#endif
+    if (lane < 8) {
+        const float4 b = *(const float4*)((WHICH ? A.b_obst : A.b_fluid) + lane * 4);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            float4 v = make_float4(o[p][0] + b.x, o[p][1] + b.y, o[p][2] + b.z, o[p][3] + b.w);
+            if (A.relu_out) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+            *(float4*)(A.a0 + (size_t)idx[p] * 96 + (WHICH ? 0 : 32) + lane * 4) = v;
+        }
+    } else if (!WHICH && lane >= 32) {
+        const int co = lane & 31;
+        const float4 dw = *(const float4*)(A.dense_w + co * 4);
+        const float db = A.dense_b[co];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const float4 f = *(const float4*)(A.feats_f + (size_t)idx[p] * 4);
+            float s2 = db;
+            s2 += f.x * dw.x; s2 += f.y * dw.y; s2 += f.z * dw.z; s2 += f.w * dw.w;
+            A.a0[(size_t)idx[p] * 96 + 64 + co] = A.relu_out ? fmaxf(s2, 0.f) : s2;
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();          // the next particles of this wave reuse the stage / patch / counters
 }
 
 // The front body of one cloud (WHICH = 0 the fluid, 1 the container) for the particles blk * TF_WAVES + wave, + nblk * TF_WAVES, ...
@@ -358,18 +568,11 @@ __device__ __forceinline__ void tf_body(const TfArgs& A, const TfLds& L, int blk
     const NfGridView g = nf_grid_view(A.grid[WHICH]);
     const unsigned long long lt = (1ull << lane) - 1ull;
     const float radius = 0.5f * A.extent, inv_r2 = 1.f / (radius * radius), scale = 2.f / A.extent;
-#ifndef TF_AB_STRIDED
-    // a wave's particles are CONSECUTIVE indices (index order is spatially coherent: their cell rows and candidates overlap in
-    // the L1 / L2: 46.0 -> 44.2 us against particles strided by the launch width, round 4)
+    // Work items.  Fluid: a wave walks CONSECUTIVE particle indices (index order is spatially coherent: their cell rows and candidates
+    // overlap in the L1 / L2: 46.0 -> 44.2 us against indices strided by the launch width, round 4).  Container: see the pre-pass.
     const int per_wave = (A.n + nblk * NW - 1) / (nblk * NW);
-    const int stride = 1;
-    int i = (blk * NW + wv) * per_wave;
-    const int i_end = min(A.n, i + per_wave);
-#else
-    const int stride = nblk * NW;
-    int i = blk * NW + wv;
-    const int i_end = A.n;
-#endif
+    const int i0 = (blk * NW + wv) * per_wave;
+    int k = 0, kstep = 1, kend = WHICH ? 0 : min(A.n, i0 + per_wave) - i0;
 
     auto load_q = [&](int ii, float& x, float& y, float& z) __attribute__((always_inline)) {
         x = y = z = 0.f;
@@ -404,16 +607,11 @@ __device__ __forceinline__ void tf_body(const TfArgs& A, const TfLds& L, int blk
             }
         }
     };
-    float qx, qy, qz, q1x, q1y, q1z, q2x, q2y, q2z;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
     int rs = 0, re = 0;
-    bool first_particle = true;
-    if (i < i_end) load_q(i, qx, qy, qz); else qx = qy = qz = 0.f;
-#ifdef TF_AB_READAHEAD
-    load_q(i + stride, q1x, q1y, q1z);
-#else
-    q1x = q1y = q1z = 0.f;
-#endif
-    {   // the layer-0 filter of this cloud: requested now, parked in LDS behind the first ranges request
+    bool first_particle = !WHICH;
+    if (!WHICH && kend > 0) load_q(i0, qx, qy, qz);
+    {   // the layer-0 filter of this cloud: requested now, parked in LDS behind the first requests of the particles
         const float4* ksrc = (const float4*)(WHICH ? A.k_obst : A.k_fluid);
         constexpr int KN4 = 64 * CI * 32 / 4, PER = (KN4 + 64 * NW - 1) / (64 * NW);
         float4 kv[PER];
@@ -423,7 +621,43 @@ __device__ __forceinline__ void tf_body(const TfArgs& A, const TfLds& L, int blk
             kv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (t < KN4) kv[u] = ksrc[t];
         }
-        if (g.sdx > 0 && i < i_end) load_ranges(qx, qy, qz, rs, re);
+        if constexpr (!WHICH) {
+            if (g.sdx > 0 && kend > 0) load_ranges(qx, qy, qz, rs, re);
+        } else {
+            // Container pre-pass, a THREAD per particle: most particles of a fluid body have no container point in the 27 cells
+            // around them (88 % of the watercube) — they get conv0_obstacle = its bias here, 64 at a time, and only the others are
+            // queued for the wave-per-particle sweep below.  Particles are dealt to the workgroups with a stride (the ones near
+            // the walls are consecutive indices: a contiguous deal gave some workgroups nothing but them).
+            if (threadIdx.x == 0) L.list[TF_LISTMAX] = 0;
+            if (threadIdx.x < 32) { const float v = A.b_obst[threadIdx.x]; L.bias[threadIdx.x] = A.relu_out ? fmaxf(v, 0.f) : v; }
+            __syncthreads();
+            for (int t = threadIdx.x; blk + nblk * t < A.n; t += 64 * NW) {
+                const int ii = blk + nblk * t;
+                float x, y, z;
+                load_q(ii, x, y, z);
+                int tot = 0;
+                if (g.sdx > 0) {
+                    const int cx = min(max(nf_cell_coord(x, g.ox, g.icx, g.dx) - g.s0x, 0), g.sdx - 1);
+                    const int cy = min(max(nf_cell_coord(y, g.oy, g.icy, g.dy) - g.s0y, 0), g.sdy - 1);
+                    const int cz = min(max(nf_cell_coord(z, g.oz, g.icz, g.dz) - g.s0z, 0), g.sdz - 1);
+#pragma unroll
+                    for (int r = 0; r < 9; ++r) {
+                        const int zz = cz - 1 + r / 3, yy = cy - 1 + r % 3;
+                        if (zz >= 0 && zz < g.sdz && yy >= 0 && yy < g.sdy) {
+                            const int r0 = (zz * g.sdy + yy) * g.sdx;
+                            tot += g.cell_start[r0 + min(cx + 1, g.sdx - 1) + 1] - g.cell_start[r0 + max(cx - 1, 0)];
+                        }
+                    }
+                }
+                if (tot > 0) L.list[atomicAdd(&L.list[TF_LISTMAX], 1)] = ii;
+                else {
+                    A.counts2[(size_t)A.n + ii] = 0;
+                    float4* orow4 = (float4*)(A.a0 + (size_t)ii * 96);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) orow4[c] = ((const float4*)L.bias)[c];
+                }
+            }
+        }
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
             const int t = threadIdx.x + u * 64 * NW;
@@ -431,26 +665,13 @@ __device__ __forceinline__ void tf_body(const TfArgs& A, const TfLds& L, int blk
         }
         __syncthreads();
     }
-    for (; i < i_end; i += stride) {
-        // requests for the particles ahead: the position two ahead, the row ranges one ahead
-        int rs1 = 0, re1 = 0;
-#ifndef TF_AB_READAHEAD
-        // (default since the A/B of round 4: the read-ahead made the kernel SLOWER, 50.1 vs 45.9 us — the requests of the next
-        // particles queue in front of the current one's candidates, and their registers cost the sweep its allocation)
+    if constexpr (WHICH) { k = wv; kstep = NW; kend = L.list[TF_LISTMAX]; }
+    for (; k < kend; k += kstep) {
+        const int i = WHICH ? L.list[k] : i0 + k;
         if (!first_particle) { load_q(i, qx, qy, qz); if (g.sdx > 0) load_ranges(qx, qy, qz, rs, re); }
         first_particle = false;
-        q2x = q2y = q2z = 0.f;
-#else
-        load_q(i + 2 * stride, q2x, q2y, q2z);
-        if (g.sdx > 0 && i + stride < A.n) load_ranges(q1x, q1y, q1z, rs1, re1);
-#endif
         if (lane < 16) { rcnt[lane] = 0; rcur[lane] = 0; }
         int cnt = 0;
-#ifdef TF_AB_SKIP_ALL
-        if (lane == 0) A.a0[(size_t)i * 96 + WHICH] = (float)rs;
-        qx = q1x; qy = q1y; qz = q1z; q1x = q2x; q1y = q2y; q1z = q2z; rs = rs1; re = re1;
-        continue;
-#endif
         // ---- pass 1: the sweep (cell-major, the order of nf_radius_fill).  The first 64 candidates of EVERY row of a group are
         // requested before the first is looked at
 #pragma unroll
@@ -502,7 +723,6 @@ __device__ __forceinline__ void tf_body(const TfArgs& A, const TfLds& L, int blk
         }
         const int np = min(cnt, cap);
         const float cqx = qx, cqy = qy, cqz = qz;
-        qx = q1x; qy = q1y; qz = q1z; q1x = q2x; q1y = q2y; q1z = q2z; rs = rs1; re = re1;      // rotate the read-ahead
         float* orow = A.a0 + (size_t)i * 96;
         if (WHICH && np == 0) {
             // no container point in reach (the large majority of a fluid body): conv0_obstacle = its bias
@@ -512,11 +732,14 @@ __device__ __forceinline__ void tf_body(const TfArgs& A, const TfLds& L, int blk
         // ---- pass 2 (lane = pair, dense): interpolation data of up to two chunks of 64 pairs (kept in registers for the passes
         // below), the pitched neighbour rows, row counts
         TfPair P[2];
+        float4 F[2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int t = 64 * c + lane;
             P[c].j = 0; P[c].bx = P[c].by = P[c].bz = 0; P[c].fx = P[c].fy = P[c].fz = P[c].imp = 0.f;
+            F[c] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (t < np) {
+                F[c] = tf_feat<WHICH>(A, st.j[t]);
                 P[c] = tf_pair(st, t, cqx, cqy, cqz, scale, inv_r2, A.use_window);
                 if (!WHICH) {
                     A.idx_f[(int64_t)i * pitch + t] = P[c].j; A.d2_f[(int64_t)i * pitch + t] = st.d2[t];
@@ -527,146 +750,134 @@ __device__ __forceinline__ void tf_body(const TfArgs& A, const TfLds& L, int blk
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
-        // ---- layer-0 patch P[node][ci] = sum_pairs w(pair, node) * feat[pair][ci], in rounds of 32 pairs WITHOUT float atomics
-        // (ds_add_f32 with the same-address collisions of this scatter cost 44 of the kernel's 70 us): a pair's 8 (node, weight)
-        // items are bucketed by node with integer LDS atomics (the returned slot orders a bucket), then lane = NODE walks its
-        // bucket and accumulates in registers.
-        float pacc[4] = {0.f, 0.f, 0.f, 0.f};
-#ifndef TF_AB_SKIP_PATCH
-        for (int t0 = 0; t0 < np; t0 += TF_CHUNK) {
-            st.ccount[lane] = 0;
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
-            // this round's pairs sit in lanes (t0 & 63) .. +31 of register set t0 >> 6; lanes 0..31 take them over
-            const int srcl = (t0 & 63) + (lane & (TF_CHUNK - 1));
-            TfPair Q;
-            {
-                const TfPair& R = P[0];
-                const TfPair& R1 = P[1];
-                const bool hi = t0 >= 64;
-                Q.j = __shfl(hi ? R1.j : R.j, srcl, 64);
-                Q.bx = __shfl(hi ? R1.bx : R.bx, srcl, 64); Q.by = __shfl(hi ? R1.by : R.by, srcl, 64); Q.bz = __shfl(hi ? R1.bz : R.bz, srcl, 64);
-                Q.fx = __shfl(hi ? R1.fx : R.fx, srcl, 64); Q.fy = __shfl(hi ? R1.fy : R.fy, srcl, 64); Q.fz = __shfl(hi ? R1.fz : R.fz, srcl, 64);
-                Q.imp = __shfl(hi ? R1.imp : R.imp, srcl, 64);
-            }
-            const bool mine = lane < TF_CHUNK && t0 + lane < np;
-            int slot[8], cellk[8];
-            float wk[8];
-            if (mine) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
-                    wk[k] = Q.imp * ((dx ? Q.fx : 1.f - Q.fx) * (dy ? Q.fy : 1.f - Q.fy) * (dz ? Q.fz : 1.f - Q.fz));
-                    cellk[k] = ((Q.bz + dz) * 4 + (Q.by + dy)) * 4 + (Q.bx + dx);
-                    slot[k] = atomicAdd(&st.ccount[cellk[k]], 1);
-                }
-                float4 f4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (!WHICH) f4 = *(const float4*)(A.feats_f + 4 * (size_t)Q.j);
-                else { f4.x = A.feats_b[3 * (size_t)Q.j]; f4.y = A.feats_b[3 * (size_t)Q.j + 1]; f4.z = A.feats_b[3 * (size_t)Q.j + 2]; }
-                *(float4*)st.u.feat[lane] = f4;
-            }
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
-            const int mycnt = st.ccount[lane];
-            int x = mycnt;
-#pragma unroll
-            for (int o2 = 1; o2 < 64; o2 <<= 1) { const int y = __shfl_up(x, o2, 64); if (lane >= o2) x += y; }
-            const int myoff = x - mycnt;
-            st.coff[lane] = myoff;
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
-            if (mine) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int pos = st.coff[cellk[k]] + slot[k];
-                    st.iw[pos] = wk[k];
-                    st.it[pos] = (unsigned char)lane;
-                }
-            }
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
-            int cmax = mycnt;
-#pragma unroll
-            for (int o2 = 1; o2 < 64; o2 <<= 1) cmax = max(cmax, __shfl_xor(cmax, o2, 64));
-            for (int e = 0; e < cmax; ++e) {
-                if (e < mycnt) {
-                    const float w = st.iw[myoff + e];
-                    const float4 f4 = *(const float4*)st.u.feat[st.it[myoff + e]];
-                    pacc[0] = fmaf(w, f4.x, pacc[0]); pacc[1] = fmaf(w, f4.y, pacc[1]);
-                    pacc[2] = fmaf(w, f4.z, pacc[2]); pacc[3] = fmaf(w, f4.w, pacc[3]);
-                }
-            }
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
+        tf_tail<WHICH>(A, TfWave{&st, patch, rcnt, rcur, rbase, Ks}, i, np, P, F);
+        {
+            const float* const pt[1] = {patch};
+            const int idx[1] = {i};
+            tf_layer0_out<WHICH, 1>(A, Ks, pt, idx);
         }
-#endif
+    }
+}
+
+// The fluid half behind an ALL-PAIRS search (k_trans_stage1b wrote the pitched rows idx_f / d2_f in ascending neighbour index and the
+// counts): a particle's chain is {its row, its count, its position} -> {the neighbours' positions and features} -> arithmetic, two
+// global round trips instead of the grid walk's four (position -> cell -> row ranges -> candidates -> features).  No sweep, no staging
+// of hits: the pair data is computed with lane = pair straight from the row.
+template <int NW>
+__device__ __forceinline__ void tf_body_rows(const TfArgs& A, const TfLds& L, int blk, int nblk)
+{
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    TfStage& st = L.stage[wv];
+    const TfWave W{&st, st.iw, L.rcnt + wv * 16, L.rcur + wv * 16, L.rbase + wv * 17, L.Ks};
+    const int pitch = A.pitch_f, cap = min(pitch, TF_MAXP);
+    const float radius = 0.5f * A.extent, inv_r2 = 1.f / (radius * radius), scale = 2.f / A.extent;
+    // workgroup blk owns the particles [n blk / nblk, n (blk + 1) / nblk), its waves equal shares of them (consecutive indices: index
+    // order is spatially coherent, so a wave's rows and gathers overlap in the L1 / L2)
+    const int w0 = (int)((unsigned)A.n * (unsigned)blk / (unsigned)nblk), wn = (int)((unsigned)A.n * (unsigned)(blk + 1) / (unsigned)nblk) - w0;   // (n <= 16 384)
+    int i = w0 + wn * wv / NW;
+    const int i_end = w0 + wn * (wv + 1) / NW;
+
+    struct Row { float qx, qy, qz; int cnt, j0, j1; float d0, d1; };
+    auto load_row = [&](int ii, Row& r) __attribute__((always_inline)) {
+        r.qx = r.qy = r.qz = r.d0 = r.d1 = 0.f; r.cnt = r.j0 = r.j1 = 0;
+        if (ii < i_end) {
+            r.qx = A.q[3 * (size_t)ii]; r.qy = A.q[3 * (size_t)ii + 1]; r.qz = A.q[3 * (size_t)ii + 2];
+            r.cnt = A.counts2[ii];
+            const int64_t base = (int64_t)ii * pitch;
+            // (slots behind the count hold whatever the buffer held: they are never used as indices — every use is guarded by np)
+            if (lane < cap) { r.j0 = A.idx_f[base + lane]; r.d0 = A.d2_f[base + lane]; }
+            if (64 + lane < cap) { r.j1 = A.idx_f[base + 64 + lane]; r.d1 = A.d2_f[base + 64 + lane]; }
+        }
+    };
+    Row cur;
+    load_row(i, cur);
+    {   // the layer-0 filter: requested behind the first row, parked in LDS
+        const float4* ksrc = (const float4*)A.k_fluid;
+        constexpr int KN4 = 64 * 4 * 32 / 4, PER = (KN4 + 64 * NW - 1) / (64 * NW);
+        float4 kv[PER];
 #pragma unroll
-        for (int ci = 0; ci < 4; ++ci)
-            if (ci < CI) patch[lane * CI + ci] = pacc[ci];
+        for (int u = 0; u < PER; ++u) {
+            const int t = threadIdx.x + u * 64 * NW;
+            kv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t < KN4) kv[u] = ksrc[t];
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int t = threadIdx.x + u * 64 * NW;
+            if (t < KN4) ((float4*)L.Ks)[t] = kv[u];
+        }
+        __syncthreads();
+    }
+    static_assert(sizeof(((TfStage*)0)->j) + sizeof(((TfStage*)0)->d2) >= 64 * 4 * sizeof(float), "room for a parked patch");
+#if defined(TF_AB_ROWS_STOP) && TF_AB_ROWS_STOP == 1
+    if (lane == 0 && i < i_end) A.a0[(size_t)i * 96] = (float)cur.cnt;
+    return;
+#endif
+    int gcount = 0, gidx[2] = {0, 0};
+    for (; i < i_end; ++i) {
+#ifdef TF_AB_ROWAHEAD
+        Row nxt;
+        load_row(i + 1, nxt);
+#endif
+        if (lane < 16) { W.rcnt[lane] = 0; W.rcur[lane] = 0; }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
-        if (!WHICH) {
-            // ---- pass 3: exclusive scan of the 16 row counts -> roff
-            int c = lane < 16 ? rcnt[lane] : 0;
-            int x = c;
+        const int np = min(cur.cnt, cap);
+        TfPair P[2];
+        float4 F[2];
+        float px[2], py[2], pz[2];
 #pragma unroll
-            for (int o2 = 1; o2 < 16; o2 <<= 1) { const int y = __shfl_up(x, o2, 64); if (lane >= o2) x += y; }
-            if (lane < 16) rbase[lane] = x - c;
-            if (lane == 15) rbase[16] = x;
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
-            if (lane < 17) A.roff[(size_t)i * 20 + lane] = (uint16_t)rbase[lane];
-            // ---- pass 4 (lane = pair): the four row entries of every pair; the LDS cursors advance in lane order, so a
-            // bucket keeps the pair order
-            uint32_t* ebase = A.ent + (size_t)i * (size_t)(4 * A.pitch_f) * 3;
-#pragma unroll
-            for (int c2 = 0; c2 < 2; ++c2) {
-#ifdef TF_AB_SKIP_ENT
-                break;
-#endif
-                if (64 * c2 < np) {
-                    if (64 * c2 + lane < np) {
-                        const TfPair& Q = P[c2];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int dy = r & 1, dz = r >> 1;
-                            const int rho = (Q.bz + dz) * 4 + Q.by + dy;
-                            const int e = rbase[rho] + atomicAdd(&rcur[rho], 1);
-                            // the weights of k_pair_precompute, same expression and association
-                            const float w0 = Q.imp * ((1.f - Q.fx) * (dy ? Q.fy : 1.f - Q.fy) * (dz ? Q.fz : 1.f - Q.fz));
-                            const float w1 = Q.imp * (Q.fx * (dy ? Q.fy : 1.f - Q.fy) * (dz ? Q.fz : 1.f - Q.fz));
-                            uint32_t* dst = ebase + 3 * (size_t)e;
-                            dst[0] = (uint32_t)Q.j | ((uint32_t)Q.bx << 30);
-                            dst[1] = __float_as_uint(w0);
-                            dst[2] = __float_as_uint(w1);
-                        }
-                    }
-                    __builtin_amdgcn_s_waitcnt(0xc07f);
-                    __builtin_amdgcn_wave_barrier();
-                }
+        for (int c = 0; c < 2; ++c) {               // all gathers of the particle in flight before the first is used
+            const int t = 64 * c + lane, j = c ? cur.j1 : cur.j0;
+            F[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            px[c] = py[c] = pz[c] = 0.f;
+            if (t < np) {
+                px[c] = A.q[3 * (size_t)j]; py[c] = A.q[3 * (size_t)j + 1]; pz[c] = A.q[3 * (size_t)j + 2];
+                F[c] = tf_feat<0>(A, j);
             }
         }
-        // ---- layer 0: patch x filter (+ the Linear branch on the particle's own features)
-        const int co = lane & 31, half = lane >> 5;
-#ifdef TF_AB_SKIP_GEMV
-        if (lane == 0) orow[WHICH] = patch[5];
-        continue;
-#endif
-        if (!WHICH) {
-            const float af = tf_patch_times_filter<4>(patch, Ks, co, half);
-            if (half == 0) { const float v = af + A.b_fluid[co]; orow[32 + co] = A.relu_out ? fmaxf(v, 0.f) : v; }
-            else {
-                float s2 = A.dense_b[co];
 #pragma unroll
-                for (int ci = 0; ci < 4; ++ci) s2 += A.feats_f[(size_t)i * 4 + ci] * A.dense_w[co * 4 + ci];
-                orow[64 + co] = A.relu_out ? fmaxf(s2, 0.f) : s2;
+        for (int c = 0; c < 2; ++c) {
+            const int t = 64 * c + lane;
+            P[c].j = 0; P[c].bx = P[c].by = P[c].bz = 0; P[c].fx = P[c].fy = P[c].fz = P[c].imp = 0.f;
+            if (t < np) {
+                P[c] = tf_pair_v(c ? cur.j1 : cur.j0, px[c], py[c], pz[c], c ? cur.d1 : cur.d0, cur.qx, cur.qy, cur.qz, scale, inv_r2, A.use_window);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) atomicAdd(&W.rcnt[(P[c].bz + (r >> 1)) * 4 + P[c].by + (r & 1)], 1);
             }
-        } else {
-            const float ao = tf_patch_times_filter<3>(patch, Ks, co, half);
-            if (half == 0) { const float v = ao + A.b_obst[co]; orow[co] = A.relu_out ? fmaxf(v, 0.f) : v; }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();          // the next particle of this wave reuses the stage / patch / counters
+        __builtin_amdgcn_wave_barrier();
+#if defined(TF_AB_ROWS_STOP) && TF_AB_ROWS_STOP == 2
+        if (lane < 16) A.a0[(size_t)i * 96 + lane] = (float)W.rcnt[lane] + P[0].fx + P[1].fy + F[0].x + F[1].y;
+        load_row(i + 1, cur);
+        continue;
+#endif
+        // the patch of the first particle of a group of two parks in the (here unused) sweep staging, the second one in the rounds'
+        // item buffer; one product with the filter serves both
+        const bool second = gcount == 1;
+        TfWave Wp = W;
+        Wp.patch = second ? st.iw : (float*)st.j;
+        tf_tail<0>(A, Wp, i, np, P, F);
+        gidx[gcount++] = i;
+        if (gcount == 2) {
+            const float* const pt[2] = {(const float*)st.j, st.iw};
+            const int idx[2] = {gidx[0], gidx[1]};
+            tf_layer0_out<0, 2>(A, W.Ks, pt, idx);
+            gcount = 0;
+        } else if (i + 1 == i_end) {
+            const float* const pt[1] = {(const float*)st.j};
+            const int idx[1] = {gidx[0]};
+            tf_layer0_out<0, 1>(A, W.Ks, pt, idx);
+            gcount = 0;
+        }
+#ifdef TF_AB_ROWAHEAD
+        cur = nxt;
+#else
+        // (requesting the next particle's row a particle ahead was measured: 32.5 vs 30.6 us — as in the grid walk, the early requests
+        // queue in front of the current particle's gathers)
+        load_row(i + 1, cur);
+#endif
     }
 }
 
@@ -676,7 +887,13 @@ __device__ __forceinline__ void tf_arrive(const TfArgs& A, unsigned total)
     if (!A.host_flag) return;
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence_system();                // this workgroup's overflow words (if any) before its arrival
+        // (this workgroup's overflow words, if it raised any, were followed by their own system-scope fence; the arrival itself is
+        // a device-scope matter — a system-scope fence here, in every workgroup, costs the launch microseconds)
+#ifdef TF_AB_SYSFENCE
+        __threadfence_system();
+#else
+        __threadfence();
+#endif
         const unsigned old = atomicAdd(A.done_ctr, 1u);
         if (old == total - 1) {
             *A.done_ctr = 0u;
@@ -696,6 +913,17 @@ __global__ void __launch_bounds__(64 * TF_WAVES, 4) k_trans_front(TfArgs A, int 
     tf_arrive(A, gridDim.x * gridDim.y);
 }
 
+// the fluid half behind k_trans_stage1b (rows + counts already written) in workgroups [0, nf); behind them (when the launch has any)
+// workgroups of the container half, on the CUs' second workgroup slots
+__global__ void __launch_bounds__(64 * TF_WAVES, 4) k_trans_front_rows(TfArgs A, int nf)
+{
+    __shared__ __attribute__((aligned(16))) char lds[TF_LDS_BYTES(4, TF_WAVES)];
+    static_assert(TF_LDS_BYTES(3, TF_WAVES) <= TF_LDS_BYTES(4, TF_WAVES), "the container half fits the fluid half's LDS");
+    if ((int)blockIdx.x < nf) tf_body_rows<TF_WAVES>(A, tf_carve<TF_WAVES>(lds, 4), blockIdx.x, nf);
+    else tf_body<1, false, TF_WAVES>(A, tf_carve<TF_WAVES>(lds, 3), (int)blockIdx.x - nf, (int)gridDim.x - nf);
+    tf_arrive(A, gridDim.x);
+}
+
 extern "C" int nf_trans_front_max_pitch(void) { return TF_MAXP; }
 
 static int tf_ncu()
@@ -712,9 +940,9 @@ static int tf_ncu()
 
 // two workgroups of 8 waves fit a CU (61 KB of LDS each: the filter is staged once per workgroup): size the grid so that
 // every workgroup is resident at once and each wave walks the same number of particles
-static int tf_blocks(int n)
+static int tf_blocks(int n, int wg_per_cu = 1)
 {
-    const int ncu = tf_ncu(), per = TF_WAVES, iters = (n + ncu * per - 1) / (ncu * per);
+    const int ncu = tf_ncu() * wg_per_cu, per = TF_WAVES, iters = (n + ncu * per - 1) / (ncu * per);
     const int blocks = (n + per * iters - 1) / (per * iters);
     return blocks < 1 ? 1 : blocks;
 }
@@ -964,6 +1192,215 @@ __global__ void __launch_bounds__(TS_BLOCK) k_trans_stage1(TsArgs S, TfArgs A)
     tf_body<1, true, TS_WAVES>(A, tf_carve<TS_WAVES>(ts_lds, 3), (int)blockIdx.x - 1, (int)gridDim.x - 1);
 }
 
+// ================================================================================================
+// Round 4 (late): stage 1 for SMALL clouds = an ALL-PAIRS search instead of a cell grid.  For the clouds this model steps (4 913
+// particles in the headline configuration) the grid was never about arithmetic: n^2 = 24 M distance tests are ~4 us of packed fp32
+// on 256 CUs, while the single-workgroup counting sort (19.6 us) and the position -> cell -> ranges -> candidates chain of the sweep
+// (14 + 12 us of the front kernel) are chains of dependent round trips.  Every workgroup integrates the WHOLE cloud into LDS
+// (3 x 4 B x n: 59 KB; it writes pos_new / vel_new / feats for its own queries only), then a wave per query walks all candidates
+// 128 at a time — two per lane, v_pk_* arithmetic in nf_dist2's operation order, so the test is bit-identical to the grid path's —
+// and appends the hits to the pitched rows idx_f / d2_f in ascending index (the oracle's own order).  The same workgroups then run
+// their share of the container half (it needs the static box grid only), re-using the LDS.  No fluid grid exists in this mode;
+// k_trans_front_rows consumes the rows.  Limit: TB_MAX_POINTS (LDS); larger clouds take the grid path above.
+// ================================================================================================
+#define TB_MAX_POINTS 8192
+typedef float tb_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int wv_of(int tid) { return __builtin_amdgcn_readfirstlane(tid >> 6); }
+#define TB_LDS_FLOATS(npad) (3 * (npad) + 6 * ((npad) >> 4) + 6 * ((npad) >> 7) + TF_MAXP * TS_WAVES / 2)
+
+// min / max over the 16 lanes of a DPP row: four row rotations (row_ror 1, 2, 4, 8), every lane ends up with the row's value — VALU
+// only (__shfl_xor goes through the LDS crossbar: the butterflies of this reduction cost 12 us that way)
+template <bool MAX>
+__device__ __forceinline__ float tb_row_minmax(float v)
+{
+#define TB_ROR(n) { const float t = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x120 | (n), 0xf, 0xf, false)); \
+                    v = MAX ? fmaxf(v, t) : fminf(v, t); }
+    TB_ROR(1) TB_ROR(2) TB_ROR(4) TB_ROR(8)
+#undef TB_ROR
+    return v;
+}
+
+__device__ __forceinline__ void tb_search(const TsArgs& S, const TfArgs& A, char* lds, int blk, int nblk)
+{
+    const int n = A.n, npad = (n + 127) & ~127, nrow = npad >> 4, nchunk = npad >> 7;
+    float* const sx = (float*)lds;
+    float* const sy = sx + npad;
+    float* const sz = sy + npad;
+    float* const rbox = sz + npad;                                      // [6][nrow]: bounds of every 16 consecutive particles
+    float* const cbox = rbox + 6 * nrow;                                // [6][nchunk]: bounds of every chunk of 128
+    uint16_t* const hits = (uint16_t*)(cbox + 6 * nchunk) + (size_t)TF_MAXP * wv_of(threadIdx.x);   // [waves][TF_MAXP] neighbour indices (< 8 192)
+    const int tid = threadIdx.x, lane = tid & 63, wv = wv_of(tid);
+    const int q0 = (int)((unsigned)n * (unsigned)blk / (unsigned)nblk), q1 = (int)((unsigned)n * (unsigned)(blk + 1) / (unsigned)nblk);   // (n <= 8 192, nblk <= #CUs)
+    // ---- integrate the whole cloud into LDS (all loads in flight at once: clamped indices); own queries also to memory
+    {
+        constexpr int PER = TB_MAX_POINTS / TS_BLOCK;
+        const float g[3] = {S.gx, S.gy, S.gz};
+        float pv[PER][3], vv[PER][3];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            if (u * TS_BLOCK >= npad) continue;                        // (uniform)
+            const int ic = min(u * TS_BLOCK + tid, n - 1);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { pv[u][d] = S.pos[3 * (size_t)ic + d]; vv[u][d] = S.vel[3 * (size_t)ic + d]; }
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            if (u * TS_BLOCK >= npad) continue;
+            const int i = u * TS_BLOCK + tid;
+            float o[3], w[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const float v = vv[u][d];
+                const float vn = v + g[d] * S.dt;                       // same expressions as k_trans_integrate
+                o[d] = pv[u][d] + (v + vn) / 2 * S.dt;
+                w[d] = vn;
+            }
+            if (i >= q0 && i < q1) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d) { S.pos_new[3 * (size_t)i + d] = o[d]; S.vel_new[3 * (size_t)i + d] = w[d]; }
+                *(float4*)(S.feats4 + 4 * (size_t)i) = make_float4(1.f, w[0], w[1], w[2]);
+            }
+            if (u * TS_BLOCK + 64 * wv < npad) {                        // (uniform per wave: a wave's 64 particles = one half chunk)
+                const bool live = i < n;                                // the padding never passes the radius test
+                sx[i] = live ? o[0] : INFINITY; sy[i] = live ? o[1] : INFINITY; sz[i] = live ? o[2] : INFINITY;
+                // bounds of every 16 consecutive particles (a DPP row), combined into the chunks' bounds below.  (All 16 waves of all
+                // workgroups do this for the whole cloud: its VALU instructions, four waves to a SIMD, are what the phase costs.)
+#ifdef TB_AB_NO_BOUNDS
+                if (0)
+#endif
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const float lo = tb_row_minmax<false>(live ? o[d] : INFINITY), hi = tb_row_minmax<true>(live ? o[d] : -INFINITY);
+                    if ((lane & 15) == 0) {
+                        const int r = i >> 4;
+                        rbox[d * nrow + r] = lo;
+                        rbox[(3 + d) * nrow + r] = hi;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int t = tid; t < 6 * nchunk; t += TS_BLOCK) {                  // chunk c, column k: 8 rows of 16
+        const int k = t / nchunk, c = t - k * nchunk;
+        const float* src = rbox + k * nrow + 8 * c;
+        float v = src[0];
+#pragma unroll
+        for (int e = 1; e < 8; ++e) v = k < 3 ? fminf(v, src[e]) : fmaxf(v, src[e]);
+        cbox[k * nchunk + c] = v;
+    }
+    __syncthreads();
+    // ---- a wave per query: lane c tests the bounds of chunk c (128 consecutive particles; index order is spatially coherent in
+    // the clouds this model steps, so most chunks are out of reach), then the wave walks the chunks in reach.  Hits are parked in the
+    // wave's LDS row and leave as whole rows
+    __syncthreads();
+    const int pitch = A.pitch_f, cap = min(pitch, TF_MAXP);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const float r2 = A.r2;
+#ifdef TB_AB_NO_SEARCH
+    return;
+#endif
+    float bb[6];
+    {
+        const int c = min(lane, nchunk - 1);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) bb[k] = cbox[k * nchunk + c];
+    }
+    const int qn = q1 - q0;
+    for (int i = q0 + qn * wv / TS_WAVES; i < q0 + qn * (wv + 1) / TS_WAVES; ++i) {
+        const float qx = sx[i], qy = sy[i], qz = sz[i];
+        int cnt = 0;
+#ifdef TB_AB_NO_CULL
+        unsigned long long todo = nchunk >= 64 ? ~0ull : (1ull << nchunk) - 1ull;
+#else
+        // nf_box_dist2's argument: fp32 sub / mul / add are monotone, so the distance to the bounds never exceeds nf_dist2 to a point inside
+        unsigned long long todo = __ballot(lane < nchunk && nf_box_dist2(bb, qx, qy, qz) <= r2);
+#endif
+        while (todo) {
+            const int c0 = (__ffsll((long long)todo) - 1) << 7;
+            todo &= todo - 1;
+            const tb_f2 X = {sx[c0 + lane], sx[c0 + 64 + lane]}, Y = {sy[c0 + lane], sy[c0 + 64 + lane]}, Z = {sz[c0 + lane], sz[c0 + 64 + lane]};
+            const tb_f2 dx = qx - X, dy = qy - Y, dz = qz - Z;          // nf_dist2: (q - p), mul + add chain in d = 0, 1, 2 order
+            tb_f2 s2 = dx * dx;
+            s2 = s2 + dy * dy;
+            s2 = s2 + dz * dz;
+            unsigned long long ma = __ballot(s2.x <= r2), mb = __ballot(s2.y <= r2);
+            if (ma | mb) {
+                // radius_search_ignore_query_points=True: a neighbour AT the query's position is not one (d2 == 0 happens once per
+                // query — itself — and for underflowing offsets: the rare path looks at the coordinates)
+                if (__ballot(s2.x == 0.f || s2.y == 0.f)) {
+                    ma = __ballot(s2.x <= r2 && !(X.x == qx && Y.x == qy && Z.x == qz));
+                    mb = __ballot(s2.y <= r2 && !(X.y == qx && Y.y == qy && Z.y == qz));
+                }
+                if ((ma >> lane) & 1) { const int w = cnt + __popcll(ma & lt); if (w < cap) hits[w] = (uint16_t)(c0 + lane); }
+                cnt += __popcll(ma);
+                if ((mb >> lane) & 1) { const int w = cnt + __popcll(mb & lt); if (w < cap) hits[w] = (uint16_t)(c0 + 64 + lane); }
+                cnt += __popcll(mb);
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        {
+            int32_t* const irow = A.idx_f + (int64_t)i * pitch;
+            float* const drow = A.d2_f + (int64_t)i * pitch;
+            const int np = min(cnt, cap);
+            // (the squared distance is evaluated again for the row: the same expression on the same operands, the same bits)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                if (64 * c + lane < np) {
+                    const int j = hits[64 * c + lane];
+                    irow[64 * c + lane] = j;
+                    drow[64 * c + lane] = nf_dist2(qx, qy, qz, sx[j], sy[j], sz[j]);
+                }
+        }
+        if (lane == 0) {
+            A.counts2[i] = cnt;
+            A.num_nbrs[i] = (float)cnt;
+            if (cnt > pitch) {
+                atomicMax(A.overflow2, (unsigned long long)cnt);
+                if (A.host_flag) { A.host_flag[0] = cnt; __threadfence_system(); }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// workgroups [0, nsearch): the all-pairs search; the workgroups behind them: the CONTAINER half (cell-grid sweep of the static box grid
+// from the state + conv0_obstacle) on 8 of their 16 waves — 70 KB of LDS, so that one of them shares a CU with a search workgroup: the
+// container half is a chain of round trips (one particle in eight has container points in reach), the search is arithmetic
+#define TB_BOX_WAVES 8
+__global__ void __launch_bounds__(TS_BLOCK) k_trans_stage1b(TsArgs S, TfArgs A, int nsearch)
+{
+    extern __shared__ __attribute__((aligned(16))) char ts_lds[];
+    if ((int)blockIdx.x < nsearch) { tb_search(S, A, ts_lds, blockIdx.x, nsearch); return; }
+    if (threadIdx.x >= 64 * TB_BOX_WAVES) return;
+    tf_body<1, true, TB_BOX_WAVES>(A, tf_carve<TB_BOX_WAVES>(ts_lds, 3), (int)blockIdx.x - nsearch, (int)gridDim.x - nsearch);
+}
+
+extern "C" int nf_trans_all_pairs_max_points(void) { return TB_MAX_POINTS; }
+
+static int tb_launch(const TsArgs& S, const TfArgs& A, hipStream_t st)
+{
+    const int n = A.n, npad = (n + 127) & ~127, ncu = tf_ncu();
+    int nsearch = (n + TS_WAVES - 1) / TS_WAVES;                         // a wave per query and round; one workgroup per CU
+    if (nsearch > ncu) nsearch = ncu;
+#ifdef TB_AB_BOX_IN_STAGE1
+    const int iters = (n + ncu * TB_BOX_WAVES - 1) / (ncu * TB_BOX_WAVES);
+    const int nbox = (n + TB_BOX_WAVES * iters - 1) / (TB_BOX_WAVES * iters);
+#else
+    const int nbox = 0;                                                  // (the container half rides in k_trans_front_rows' launch)
+#endif
+    const size_t lds_search = (size_t)TB_LDS_FLOATS(npad) * sizeof(float), lds_box = nbox ? TF_LDS_BYTES(3, TB_BOX_WAVES) : 0;
+    const size_t lds = lds_search > lds_box ? lds_search : lds_box;
+    static bool attr_set[64] = {};
+    if (nf_first_use_on_device(attr_set))
+        hipFuncSetAttribute((const void*)k_trans_stage1b, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(TF_LDS_BYTES(3, TB_BOX_WAVES) > (size_t)TB_LDS_FLOATS(TB_MAX_POINTS) * 4 ? TF_LDS_BYTES(3, TB_BOX_WAVES) : (size_t)TB_LDS_FLOATS(TB_MAX_POINTS) * 4));
+    hipLaunchKernelGGL(k_trans_stage1b, dim3(nsearch + nbox), dim3(TS_BLOCK), lds, st, S, A, nsearch);
+    return 0;
+}
+
 // nf_trans_step's first two launches (see the comment above); the caller's TfArgs carries both halves' arguments
 static int ts_launch(const TsArgs& S0, const TfArgs& A, hipStream_t st)
 {
@@ -996,12 +1433,19 @@ int nf_trans_stage12(const nf_trans_step_t* s, const float* pos, const float* ve
     NF_CHECK_ARG(s && pos && vel && num_nbrs, "null pointer");
     NF_CHECK_ARG(s->pitch_f >= 1 && s->pitch_f <= TF_MAXP && s->pitch_b >= 1 && s->pitch_b <= TF_MAXP, "pitch must be in [1, nf_trans_front_max_pitch()]");
     NF_CHECK_ARG(!host_flag3 || s->done_counter, "the completion word needs the workgroup counter");
+    NF_CHECK_ARG(s->search >= 0 && s->search <= 2, "search: 0 auto, 1 cell grid, 2 all pairs");
+    NF_CHECK_ARG(s->search != 2 || s->n <= TB_MAX_POINTS, "the all-pairs search serves clouds up to nf_trans_all_pairs_max_points()");
+    const bool all_pairs = s->search == 2 || (s->search == 0 && s->n <= TB_MAX_POINTS);
     TsArgs S;
-    size_t tot = 0;
-    NF_CHECK_ARG(nf_grid_make_header(s->n, s->radius, s->bbox, &S.h, &tot) == NF_OK, "bad grid parameters");
-    NF_CHECK_ARG(s->grid_ws_bytes >= tot, "workspace too small");
-    NF_CHECK_ARG(s->n > 0 && s->n <= TP_BLOCK * TP_MAX_PER_THREAD && S.h.n_cells + s->n <= TS_MAX_LDS_INTS,
-                 "cloud or grid too large for the fused step (use the multi-launch path)");
+    memset(&S, 0, sizeof(S));
+    if (!all_pairs) {
+        size_t tot = 0;
+        NF_CHECK_ARG(nf_grid_make_header(s->n, s->radius, s->bbox, &S.h, &tot) == NF_OK, "bad grid parameters");
+        NF_CHECK_ARG(s->grid_ws_bytes >= tot, "workspace too small");
+        NF_CHECK_ARG(s->n <= TP_BLOCK * TP_MAX_PER_THREAD && S.h.n_cells + s->n <= TS_MAX_LDS_INTS,
+                     "cloud or grid too large for the fused step (use the multi-launch path)");
+    }
+    NF_CHECK_ARG(s->n > 0, "empty cloud");
     S.ws = s->grid_ws; S.pos = pos; S.vel = vel; S.gx = s->gravity[0]; S.gy = s->gravity[1]; S.gz = s->gravity[2]; S.dt = s->dt;
     S.pos_new = s->pos_new; S.vel_new = s->vel_new; S.feats4 = s->feats; S.per = 0; S.cell = s->radius;
     TfArgs A;
@@ -1015,6 +1459,24 @@ int nf_trans_stage12(const nf_trans_step_t* s, const float* pos, const float* ve
     A.k_fluid = s->k_fluid; A.b_fluid = s->b_fluid; A.k_obst = s->k_obst; A.b_obst = s->b_obst;
     A.dense_w = s->dense0_w; A.dense_b = s->dense0_b; A.a0 = s->a0; A.overflow2 = (unsigned long long*)s->overflow2;
     A.host_flag = (volatile int*)host_flag3; A.done_ctr = s->done_counter; A.step_id = step_id;
+    if (all_pairs) {
+        tb_launch(S, A, (hipStream_t)stream);
+        NF_CHECK_LAUNCH();
+        // one fluid workgroup per CU, every one with its equal share of the particles
+#ifdef TF_AB_NF
+        const int nf = TF_AB_NF;
+#else
+        const int nf = (s->n + TF_WAVES - 1) / TF_WAVES < tf_ncu() ? (s->n + TF_WAVES - 1) / TF_WAVES : tf_ncu();
+#endif
+#if defined(TB_AB_BOX_IN_STAGE1) || defined(TS_AB_NO_BOX)
+        const int nb = 0;
+#else
+        const int nb = tf_blocks(s->n, 1);
+#endif
+        hipLaunchKernelGGL(k_trans_front_rows, dim3(nf + nb), dim3(64 * TF_WAVES), 0, (hipStream_t)stream, A, nf);
+        NF_CHECK_LAUNCH();
+        return NF_OK;
+    }
     ts_launch(S, A, (hipStream_t)stream);
     NF_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_trans_front, dim3(tf_blocks(s->n), 1), dim3(64 * TF_WAVES), 0, (hipStream_t)stream, A, 1);

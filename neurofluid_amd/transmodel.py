@@ -200,6 +200,10 @@ class ParticleNet(nn.Module):
         # MFMA, the reference's arithmetic) or "split" (hi + lo fp16 operands, three fp16 MFMAs per product block, fp32
         # accumulate: fp32-LEVEL accuracy — 22-bit products — on the fp16 matrix pipe, which overlaps with the gather)
         self.conv_arith = "fp32"
+        # fixed-radius search of the fused step: "auto" (all-pairs up to nf_trans_all_pairs_max_points() particles — for clouds of a
+        # few thousand particles n^2 distance tests are cheaper than any grid's chain of dependent round trips —, the cell grid
+        # beyond), "grid", "all_pairs".  Same neighbour sets and counts; the order inside a row differs (cell order / index order)
+        self.fused_search = "auto"
         self._fused, self._fused_skip = None, 0
         self._lib_cached = None
 
@@ -276,12 +280,18 @@ class ParticleNet(nn.Module):
         if getattr(self, "_fused_limits", None) is None:
             mp, mc = ctypes.c_int(), ctypes.c_int()
             lib.nf_trans_prepare_limits(ctypes.byref(mp), ctypes.byref(mc))
-            self._fused_limits = (mp.value, mc.value, lib.nf_trans_front_max_pitch())
+            self._fused_limits = (mp.value, mc.value, lib.nf_trans_front_max_pitch(), lib.nf_trans_all_pairs_max_points())
         n = pos.shape[0]
+        if self.fused_search not in ("auto", "grid", "all_pairs"):
+            raise ValueError("ParticleNet.fused_search must be 'auto', 'grid' or 'all_pairs'")
         if n < 1 or n > self._fused_limits[0] or self._fused_skip > 0:
             self._fused_skip = max(self._fused_skip - 1, 0)
             return False
         if max(int(self.max_fluid_neighbors), int(self.max_box_neighbors)) > self._fused_limits[2]:
+            return False
+        if self.fused_search != "grid" and n <= self._fused_limits[3]:
+            return True                         # all-pairs search: no grid, no bound on the scene
+        if self.fused_search == "all_pairs":
             return False
         # the single-workgroup grid build holds the cell counters and the scatter list in LDS; ask the library for the
         # cell count of THIS bbox (its header code: float32 floor + clamping) instead of re-deriving it here
@@ -295,7 +305,7 @@ class ParticleNet(nn.Module):
 
     def _fused_buffers(self, n, dev, bbox):
         st = self._fused
-        key = (n, str(dev), bbox, int(self.max_fluid_neighbors), int(self.max_box_neighbors))
+        key = (n, str(dev), bbox, int(self.max_fluid_neighbors), int(self.max_box_neighbors), self.conv_arith)
         if st is not None and st["key"] == key:
             return st
         lib = _lib.load()
@@ -408,6 +418,7 @@ class ParticleNet(nn.Module):
                 S.gravity[d] = float(g[d])
             st["skey"], st["scene_refs"] = skey, (bgrid, box, box_feats)
         sid = st["step"] = (st["step"] + 1) & 0x3fffffff or 1
+        st["S"].search = {"auto": 0, "grid": 1, "all_pairs": 2}[self.fused_search]
         nn = torch.empty(n, dtype=f32, device=dev)
         pos_c, vel_c = torch.empty_like(pos), torch.empty_like(pos)
         rc = lib.nf_trans_step(st["Sref"], pos.data_ptr(), vel.data_ptr(), nn.data_ptr(), pos_c.data_ptr(), vel_c.data_ptr(),

@@ -784,3 +784,64 @@ def test_kat_radius_inclusivity_hip(dev):
     d, i, nn = ops.ball_query(q[None], pts[None], kat.RADIUS, 5)
     assert i[0, 0].tolist() == kat.BALL_QUERY_EXPECTED + [-1, -1]
     assert d[0, 0].tolist()[:2] == [0.0, float(np.float32(0.05) ** 2)]
+
+
+def test_fused_step_all_pairs_search_equals_grid_search_and_oracle(dev):
+    """The fused step's two searches: the all-pairs search of small clouds (`fused_search="all_pairs"`,
+    what "auto" picks up to nf_trans_all_pairs_max_points() particles) and the cell grid.  Same counts, the same neighbour SETS per
+    row, rows of the all-pairs search in ascending index (the C oracle's order: compared element by element with its CSR, squared
+    distances bit-equal); positions / velocities within the summation-order bound of the other fused-step tests.  The known-answer
+    cloud of tests/kat_conventions.py (a point at exactly the radius, one an ulp beyond, one at the query's own position) goes
+    through the fused step's search too."""
+    import kat_conventions as kat
+    from neurofluid_amd import synthetic
+    from oracle import neighbors as onb
+    from oracle import trans_oracle as to
+    box, bn = [t.to(dev) for t in to.watercube_box()]
+    clouds = [synthetic.watercube_particles(), synthetic.shaped_particles("bunny", order="random"),
+              torch.tensor([[0.0, 0.0, 0.5], [0.5, 0.5, 0.5], [0.52, 0.5, 0.5], [5.0, 5.0, 5.0], [-0.99, -0.99, -0.99]])]
+    for P in clouds:
+        pa, _ = make_pn(dev)
+        pa.fused_search = "all_pairs"
+        pb, _ = make_pn(dev)
+        pb.fused_search = "grid"
+        p1 = P.to(dev)
+        v1 = torch.zeros_like(p1)
+        with torch.no_grad():
+            for it in range(3):
+                pg, vg, ng = pb(p1, v1, box, bn)                # both searches step from the SAME state
+                pn_, vn_, nn_ = pa(p1, v1, box, bn)
+                assert torch.equal(nn_, ng), it
+                assert float((pn_ - pg).abs().max()) <= 2e-7 and float((vn_ - vg).abs().max()) <= 2e-5, it
+                state = (p1, v1)
+                p1, v1 = pn_, vn_
+        assert pa._fused is not None and pb._fused is not None and getattr(pa, "fused_overflows", 0) == 0
+        na, nb_ = pa.conv0_fluid.nns, pb.conv0_fluid.nns
+        assert torch.equal(na.neighbors_row_splits, nb_.neighbors_row_splits)
+        rs = na.neighbors_row_splits
+        nnz = int(rs[-1])
+        rows = torch.repeat_interleave(torch.arange(rs.numel() - 1, device=dev), (rs[1:] - rs[:-1]))
+        ka = rows * (1 << 20) + na.neighbors_index[:nnz].long()
+        kb = rows * (1 << 20) + nb_.neighbors_index[:nnz].long()
+        assert torch.equal(ka, torch.sort(ka).values)           # ascending index inside every row
+        assert torch.equal(ka, torch.sort(kb).values)
+        # ... and against the C oracle on the integrated positions of the last step
+        vn = state[1] + pa.gravity.to(dev) * pa.time_step              # integrate_pos_vel's expressions
+        q = (state[0] + (state[1] + vn) / 2 * pa.time_step).cpu().numpy()
+        oi, ors, od2 = onb.fixed_radius_search(q, q, 0.5 * float(pa.filter_extent), True)
+        assert np.array_equal(ors, rs.cpu().numpy())
+        assert np.array_equal(oi, na.neighbors_index[:nnz].cpu().numpy())
+        assert np.array_equal(od2, na.neighbors_distance[:nnz].cpu().numpy())
+    # the radius known answers through the fused step's own search (extent = 2 * RADIUS, no gravity, zero velocities: the
+    # integrated positions are the points themselves)
+    pts = torch.from_numpy(kat.radius_points()).to(dev)
+    for mode in ("all_pairs", "grid"):
+        pk, _ = make_pn(dev)
+        pk.fused_search, pk.filter_extent = mode, 2.0 * kat.RADIUS
+        pk.gravity.zero_()
+        with torch.no_grad():
+            pk(pts, torch.zeros_like(pts), box, bn)
+        assert pk._fused is not None
+        nns = pk.conv0_fluid.nns
+        r0 = nns.neighbors_index[: int(nns.neighbors_row_splits[1])].tolist()
+        assert sorted(r0) == kat.FIXED_RADIUS_EXPECTED_IGNORE, mode

@@ -1,5 +1,5 @@
 """Timing of ParticleNet.forward alone on the synthetic watercube (dev tool): particle-steps/s.
-usage: tools/trans_perf.py [steps] [unfused|split]     (steps from the initial cloud, as bench.py measures: the rate depends
+usage: tools/trans_perf.py [steps] [unfused|split|grid|all_pairs]     (steps from the initial cloud, as bench.py measures: the rate depends
 on the state of the rollout — a cloud that has fallen and piled up has more neighbours per particle)"""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -20,6 +20,8 @@ if mode == "unfused":
     pn.fused_inference = False
 elif mode == "split":
     pn.conv_arith = "split"
+elif mode in ("grid", "all_pairs"):
+    pn.fused_search = mode
 for it in range(3):
     pos, vel = P0.clone(), torch.zeros_like(P0)
     torch.cuda.synchronize(); t = time.time()

@@ -172,7 +172,7 @@ def committed_traffic():
 
 def committed_transition():
     """Per-step HBM-side bytes and per-kernel microseconds of the transition step from the COMMITTED rocprofv3 passes of
-    `tools/trans_perf.py` (separate --pmc passes; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE).  One k_trans_stage1 (round 3:
+    `tools/trans_perf.py` (separate --pmc passes; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE).  One k_trans_stage1 / k_trans_stage1b (round 3:
     k_trans_prepare) launch = one step."""
     for name in TRANS_PMC_FILES:
         path = os.path.join(ROOT, "profiles", name)
@@ -421,6 +421,8 @@ def main():
                           "hbm_frac": (ct["hbm_bytes_per_step"] / pstep_dt / 1e9 / HBM_PEAK_GBS) if ct else None,
                           "kernel_us_per_step": ct["kernel_us_per_step"] if ct else None,
                           "traffic_source": ct["source"] if ct else None,
+                          "search": "all pairs (clouds up to nf_trans_all_pairs_max_points() particles; the cell grid beyond)"
+                                    if pn_t.fused_search != "grid" else "cell grid",
                           "steps_redone_on_the_exact_path": int(getattr(pn_t, "fused_overflows", 0)),
                           "steps_redone_in_the_render_loop": int(getattr(pn, "fused_overflows", 0))}
         # the same step with the conv1 / conv2 contractions on the fp16 matrix pipe (hi + lo fp16 operands, 3 MFMAs per product

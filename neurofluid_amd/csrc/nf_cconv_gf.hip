@@ -222,8 +222,9 @@ __global__ void __launch_bounds__(GF_THREADS) k_cconv_gf(GfArgs A)
 #pragma unroll
             for (int gq = 0; gq < QW; ++gq)
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
+                for (int nb = 0; nb < NB; ++nb) {
                     b[gq][nb] = wp4[((size_t)(node * (CIN / 8) + kq * QW + gq) * NB + nb) * 64 + lane];
+                }
         };
         auto load_a = [&](const float* Zc, float4 (&a)[QW]) {
 #ifdef GF_AB_NO_ALOAD
@@ -237,12 +238,13 @@ __global__ void __launch_bounds__(GF_THREADS) k_cconv_gf(GfArgs A)
             for (int gq = 0; gq < QW; ++gq) {
                 const float av[4] = {a[gq].x, a[gq].y, a[gq].z, a[gq].w};
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
+                for (int s = 0; s < 4; ++s) {
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) {
                         const float bv = s == 0 ? b[gq][nb].x : (s == 1 ? b[gq][nb].y : (s == 2 ? b[gq][nb].z : b[gq][nb].w));
                         acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv, acc[nb], 0, 0, 0);
                     }
+                }
             }
         };
         auto first_node = [&](int g) __attribute__((always_inline)) { const int u = g % GF_UNITS; return u < 16 ? 4 * u : 64; };

@@ -273,6 +273,27 @@ struct TfArgs {
     int step_id;
 };
 
+// Cross-lane steps on the DPP path (VALU; __shfl_* compile to ds_bpermute_b32, a round trip through the LDS crossbar per step —
+// a dependent chain of six of them is ~600 cycles).  Inclusive prefix sum over the wave: row_shr 1, 2, 4, 8 inside the 16-lane rows
+// (out-of-row sources read 0), then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3 (the GCN scan).
+__device__ __forceinline__ int tf_wave_scan_incl(int x)
+{
+#define TF_SHR(n) x += __builtin_amdgcn_update_dpp(0, x, 0x110 | (n), 0xf, 0xf, true);
+    TF_SHR(1) TF_SHR(2) TF_SHR(4) TF_SHR(8)
+#undef TF_SHR
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+    return x;
+}
+// max over the wave (non-negative ints), uniform result: row rotations, then the four rows through SGPRs
+__device__ __forceinline__ int tf_wave_max(int v)
+{
+#define TF_ROR(n) v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x120 | (n), 0xf, 0xf, false));
+    TF_ROR(1) TF_ROR(2) TF_ROR(4) TF_ROR(8)
+#undef TF_ROR
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
 // Layer 0 as patch x filter for the NP particles a wave has patches of:  out[p][co] = sum_m patch_p[m] * Ks[m][co],  m = node * CI + ci.
 // m = 8 k + s is split over the 8 lane groups s = lane >> 3 (8 CI values of k each); a lane holds 4 consecutive output channels
 // (cog = lane & 7), so a filter row segment is ONE ds_read_b128 — the 8 groups' rows fall on distinct banks — shared by the NP
@@ -425,10 +446,7 @@ __device__ __forceinline__ void tf_tail(const TfArgs& A, const TfWave& W, int i,
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
         const int mycnt = st.ccount[lane];
-        int x = mycnt;
-#pragma unroll
-        for (int o2 = 1; o2 < 64; o2 <<= 1) { const int y = __shfl_up(x, o2, 64); if (lane >= o2) x += y; }
-        const int myoff = x - mycnt;
+        const int myoff = tf_wave_scan_incl(mycnt) - mycnt;
         st.coff[lane] = myoff;
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
@@ -442,16 +460,15 @@ __device__ __forceinline__ void tf_tail(const TfArgs& A, const TfWave& W, int i,
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
-        int cmax = mycnt;
-#pragma unroll
-        for (int o2 = 1; o2 < 64; o2 <<= 1) cmax = max(cmax, __shfl_xor(cmax, o2, 64));
-        for (int e = 0; e < cmax; ++e) {
-            if (e < mycnt) {
-                const float w = st.iw[myoff + e];
-                const float4 f4 = *(const float4*)st.u.feat[st.it[myoff + e]];
-                pacc[0] = fmaf(w, f4.x, pacc[0]); pacc[1] = fmaf(w, f4.y, pacc[1]);
-                pacc[2] = fmaf(w, f4.z, pacc[2]); pacc[3] = fmaf(w, f4.w, pacc[3]);
-            }
+        const int cmax = tf_wave_max(mycnt);
+        // (two items per trip: their weight -> pair -> feature reads are independent chains; the sum keeps the bucket's order)
+        for (int e = 0; e < cmax; e += 2) {
+            const bool ok0 = e < mycnt, ok1 = e + 1 < mycnt;
+            const float w0 = ok0 ? st.iw[myoff + e] : 0.f, w1 = ok1 ? st.iw[myoff + e + 1] : 0.f;
+            const int t0_ = ok0 ? st.it[myoff + e] : 0, t1_ = ok1 ? st.it[myoff + e + 1] : 0;
+            const float4 f0 = *(const float4*)st.u.feat[t0_], f1 = *(const float4*)st.u.feat[t1_];
+            if (ok0) { pacc[0] = fmaf(w0, f0.x, pacc[0]); pacc[1] = fmaf(w0, f0.y, pacc[1]); pacc[2] = fmaf(w0, f0.z, pacc[2]); pacc[3] = fmaf(w0, f0.w, pacc[3]); }
+            if (ok1) { pacc[0] = fmaf(w1, f1.x, pacc[0]); pacc[1] = fmaf(w1, f1.y, pacc[1]); pacc[2] = fmaf(w1, f1.z, pacc[2]); pacc[3] = fmaf(w1, f1.w, pacc[3]); }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
@@ -466,9 +483,11 @@ __device__ __forceinline__ void tf_tail(const TfArgs& A, const TfWave& W, int i,
     if (!WHICH) {
         // ---- pass 3: exclusive scan of the 16 row counts -> roff
         int c = lane < 16 ? rcnt[lane] : 0;
-        int x = c;
-#pragma unroll
-        for (int o2 = 1; o2 < 16; o2 <<= 1) { const int y = __shfl_up(x, o2, 64); if (lane >= o2) x += y; }
+        int x = c;                                          // (16 counts: the scan stays inside the first DPP row)
+        x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);
+        x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);
+        x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);
+        x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);
         if (lane < 16) rbase[lane] = x - c;
         if (lane == 15) rbase[16] = x;
         __builtin_amdgcn_s_waitcnt(0xc07f);

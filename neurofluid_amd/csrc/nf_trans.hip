@@ -5,6 +5,10 @@
 //                      six k_grid_* / scan launches of nf_grid_build(with_firstk_lists = 0)
 //   nf_trans_front     fixed-radius search of both clouds, the row-entry lists of the fluid pairs (what the G-free
 //                      convolutions of nf_cconv_gf.hip consume) and layer 0 (conv0_obstacle, conv0_fluid, dense0_fluid)
+//   nf_trans_stage12   (C++ linkage: nf_trans_step's first two launches)  the same two stages as the fused step runs them.
+//                      Clouds up to nf_trans_all_pairs_max_points() particles: k_trans_stage1b (integration + an ALL-PAIRS
+//                      search, no grid) -> k_trans_front_rows (fluid half from the rows; the container half beside it);
+//                      larger clouds: k_trans_stage1 (grid build beside the container half) -> k_trans_front (grid walk).
 // Neighbour rows have a fixed PITCH (capacity per particle): no offsets to compute, no host round trip inside the step.
 // The true counts stay on the device; a count above its pitch is reported through pinned host words, and the host redoes
 // THAT step on the exact CSR path before ParticleNet.forward returns (neurofluid_amd/transmodel.py).

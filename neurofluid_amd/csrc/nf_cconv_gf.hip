@@ -215,15 +215,23 @@ __global__ void __launch_bounds__(GF_THREADS) k_cconv_gf(GfArgs A)
                 for (int z3 = 0; z3 < NB; ++z3) Bf[z1][z2][z3] = make_float4(0.5f, 0.25f + lane, 0.125f, 1.f);
             }
 #endif
+#ifdef GF_AB_B_L1
+#define GF_B_KQ 0
+#else
+#define GF_B_KQ kq
+#endif
         auto load_b = [&](int node, float4 (&b)[QW][NB]) {
 #ifdef GF_AB_NO_BLOAD
             return;
+#endif
+#ifdef GF_AB_B_L1
+            node = 0;                           // timing only: the same loads, but always the same 6 KB block (L1 hits): 81 / 64 us
 #endif
 #pragma unroll
             for (int gq = 0; gq < QW; ++gq)
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
-                    b[gq][nb] = wp4[((size_t)(node * (CIN / 8) + kq * QW + gq) * NB + nb) * 64 + lane];
+                    b[gq][nb] = wp4[((size_t)(node * (CIN / 8) + GF_B_KQ * QW + gq) * NB + nb) * 64 + lane];
                 }
         };
         auto load_a = [&](const float* Zc, float4 (&a)[QW]) {

@@ -108,6 +108,13 @@ __global__ void __launch_bounds__(GF_THREADS) k_cconv_gf(GfArgs A)
     const int wave = hwave & 3;
 #endif
 
+#ifdef GF_AB_B_LDS
+    // timing experiment: the consumers' B operands from LDS — one node's block staged once, the WRONG data for every other
+    // node — to see what a consumer without vector-memory loads costs
+    float* const Bl = Z + 2 * ZB;
+    for (int t = threadIdx.x; t < (CIN / 8) * NB * 64; t += GF_THREADS) ((float4*)Bl)[t] = ((const float4*)a_wp)[t];
+    __syncthreads();
+#endif
     if (is_consumer) {
         // ------------------------------------------------------------------ consumers
 #ifdef GF_AB_PRIO_C
@@ -212,26 +219,40 @@ __global__ void __launch_bounds__(GF_THREADS) k_cconv_gf(GfArgs A)
             for (int z2 = 0; z2 < QW; ++z2) {
                 Af[z1][z2] = make_float4(1.f + lane, 2.f, 3.f, 4.f);
 #pragma unroll
-                for (int z3 = 0; z3 < NB; ++z3) Bf[z1][z2][z3] = make_float4(0.5f, 0.25f + lane, 0.125f, 1.f);
+                for (int z3 = 0; z3 < NB; ++z3) {
+                    Bf[z1][z2][z3] = make_float4(0.5f, 0.25f + lane, 0.125f, 1.f);
+#ifdef GF_AB_RANDOM_CONST
+                    // (the same ablation with operands that LOOK like data: a hash of (lane, slot) scaled into [-1, 1))
+                    auto hv = [&](unsigned k) { unsigned x = (unsigned)lane * 2654435761u + k * 40503u + (unsigned)(z1 * 131 + z2 * 17 + z3) * 2246822519u; x ^= x >> 15; x *= 2654435761u; x ^= x >> 13; return (float)(int)x * 4.656612873e-10f; };
+                    Bf[z1][z2][z3] = make_float4(hv(1), hv(2), hv(3), hv(4));
+#endif
+                }
             }
 #endif
-#ifdef GF_AB_B_L1
-#define GF_B_KQ 0
-#else
-#define GF_B_KQ kq
-#endif
+        int b_once = 0; (void)b_once;
         auto load_b = [&](int node, float4 (&b)[QW][NB]) {
 #ifdef GF_AB_NO_BLOAD
             return;
 #endif
-#ifdef GF_AB_B_L1
-            node = 0;                           // timing only: the same loads, but always the same 6 KB block (L1 hits): 81 / 64 us
+#ifdef GF_AB_B_ONCE
+            if (b_once >= 2) return;            // timing only: real filter data in both operand buffers, loaded once, never again
+            ++b_once;
 #endif
 #pragma unroll
             for (int gq = 0; gq < QW; ++gq)
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
-                    b[gq][nb] = wp4[((size_t)(node * (CIN / 8) + GF_B_KQ * QW + gq) * NB + nb) * 64 + lane];
+#if defined(GF_AB_B_ONCE) && defined(GF_AB_RANDOM_CONST)
+                    {   // (the once-loaded variant's control flow with hash values in place of the filter data)
+                        const float4 t = wp4[((size_t)(node * (CIN / 8) + kq * QW + gq) * NB + nb) * 64 + lane];
+                        auto hv = [&](unsigned k) { unsigned x = (unsigned)lane * 2654435761u + k * 40503u + (unsigned)(gq * 17 + nb + b_once * 131) * 2246822519u; x ^= x >> 15; x *= 2654435761u; x ^= x >> 13; return (float)(int)x * 4.656612873e-10f; };
+                        b[gq][nb] = make_float4(hv(1) + 0.f * t.x, hv(2), hv(3), hv(4));
+                    }
+#elif defined(GF_AB_B_LDS)
+                    b[gq][nb] = ((const float4*)Bl)[((kq * QW + gq) * NB + nb) * 64 + lane];
+#else
+                    b[gq][nb] = wp4[((size_t)(node * (CIN / 8) + kq * QW + gq) * NB + nb) * 64 + lane];
+#endif
                 }
         };
         auto load_a = [&](const float* Zc, float4 (&a)[QW]) {
@@ -315,8 +336,9 @@ __global__ void __launch_bounds__(GF_THREADS) k_cconv_gf(GfArgs A)
     // ---------------------------------------------------------------------- producers
     // The producers run at a raised wave priority (round 4): on gfx950 the fp32 MFMA executes on the vector ALUs and holds them for its
     // 64 cycles, so next to a streaming consumer a producer gets ONE dependent vector instruction through per MFMA; with priority its
-    // ready instructions at least go first whenever the ALUs free up.  conv1 81.8 -> 73.6 us, conv2 57.2 -> 55.4 us (priority 1 vs 0;
-    // 3 vs 0 the same; consumers above producers: no change from equal priorities).
+    // ready instructions at least go first whenever the ALUs free up.  conv1 81.8 -> 73.6 us, conv2 57.2 -> 55.4 us over a 30-step rollout
+    // (the lists get longer as the body settles; 75.2 -> 73.8 / 56.9 -> 55.7 on the initial state), priority 1 vs 0; 3 vs 0 the same;
+    // consumers above producers: no change from equal priorities.
 #ifndef GF_AB_PRIO_P
 #define GF_AB_PRIO_P 1
 #endif
@@ -530,7 +552,7 @@ __global__ void __launch_bounds__(GF_THREADS) k_cconv_gf(GfArgs A)
 // On gfx950 v_mfma_f32_32x32x2_f32 executes on the fp32 vector ALUs and holds them for its 64 cycles.  A producer wave next to a
 // consumer wave therefore gets ONE dependent vector instruction through per MFMA: its address arithmetic and FMAs trickle at
 // ~1 / 68 cycles while the consumer streams, then the consumer waits at the unit's barrier while the producer runs alone — the
-// two sides took the SUM of their times (45 + 44 = 81 us on conv1), and raising the producers' priority (s_setprio) only moved it to 74.
+// two sides took nearly the SUM of their times (44.6 + 44.7 us apart, 73.8 together on conv1), the producers' raised priority included.
 // Here a wave does both, in BURSTS that the program order fixes: all vector work of a unit (4 - 5 cycles per instruction), then its
 // 96 MFMAs back to back — and nothing is exchanged between waves at all:
 //   * lane (m, h) of wave q owns point m of the tile and the channels {8 (q QW + g) + 4 h + s : g < QW, s < 4} — EXACTLY the K
@@ -896,7 +918,11 @@ extern "C" int nf_cconv_gf_plan(int n, int cout, int max_wg, int* tiles, int* nw
 template <int CIN, int NB, bool RELU, bool SPLIT>
 static int gf_launch(const GfArgs& a, hipStream_t st)
 {
+#ifdef GF_AB_B_LDS
+    const size_t lds = (SPLIT ? (size_t)2 * 2 * 4 * GF_TILE * (CIN + 8) * sizeof(_Float16) : (size_t)2 * 4 * GF_TILE * (CIN + 4) * sizeof(float)) + (size_t)(CIN / 8) * NB * 1024;
+#else
     const size_t lds = SPLIT ? (size_t)2 * 2 * 4 * GF_TILE * (CIN + 8) * sizeof(_Float16) : (size_t)2 * 4 * GF_TILE * (CIN + 4) * sizeof(float);
+#endif
     static bool attr_set[64] = {};
     if (nf_first_use_on_device(attr_set))
         hipFuncSetAttribute((const void*)k_cconv_gf<CIN, NB, RELU, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

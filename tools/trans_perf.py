@@ -16,6 +16,10 @@ P0 = scene["P"].to(dev)
 box, bn = scene["box"].to(dev), scene["bn"].to(dev)
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 mode = sys.argv[2] if len(sys.argv) > 2 else "fp32"
+# "frozen" as a third argument: every step starts from the SAME state (P0, zero velocities).  That is what A/B builds that corrupt
+# the step's OUTPUT (ablation switches) must be timed with: in a rollout their garbage positions change the neighbour lists — and with
+# them the work — of every following step
+frozen = len(sys.argv) > 3 and sys.argv[3] == "frozen"
 if mode == "unfused":
     pn.fused_inference = False
 elif mode == "split":
@@ -27,6 +31,9 @@ for it in range(3):
     torch.cuda.synchronize(); t = time.time()
     with torch.no_grad():
         for _ in range(steps):
-            pos, vel, _ = pn(pos, vel, box, bn)
+            if frozen:
+                pn(pos, vel, box, bn)
+            else:
+                pos, vel, _ = pn(pos, vel, box, bn)
     torch.cuda.synchronize(); dt = time.time() - t
-    print(f"iter {it} [{mode}]: {dt/steps*1e6:.1f} us/step, {P0.shape[0]*steps/dt/1e6:.2f} M particle-steps/s  overflows {getattr(pn, 'fused_overflows', 0)}")
+    print(f"iter {it} [{mode}{' frozen' if frozen else ''}]: {dt/steps*1e6:.1f} us/step, {P0.shape[0]*steps/dt/1e6:.2f} M particle-steps/s  overflows {getattr(pn, 'fused_overflows', 0)}")

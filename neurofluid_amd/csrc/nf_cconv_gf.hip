@@ -108,13 +108,6 @@ __global__ void __launch_bounds__(GF_THREADS) k_cconv_gf(GfArgs A)
     const int wave = hwave & 3;
 #endif
 
-#ifdef GF_AB_B_LDS
-    // timing experiment: the consumers' B operands from LDS — one node's block staged once, the WRONG data for every other
-    // node — to see what a consumer without vector-memory loads costs
-    float* const Bl = Z + 2 * ZB;
-    for (int t = threadIdx.x; t < (CIN / 8) * NB * 64; t += GF_THREADS) ((float4*)Bl)[t] = ((const float4*)a_wp)[t];
-    __syncthreads();
-#endif
     if (is_consumer) {
         // ------------------------------------------------------------------ consumers
 #ifdef GF_AB_PRIO_C
@@ -221,38 +214,18 @@ __global__ void __launch_bounds__(GF_THREADS) k_cconv_gf(GfArgs A)
 #pragma unroll
                 for (int z3 = 0; z3 < NB; ++z3) {
                     Bf[z1][z2][z3] = make_float4(0.5f, 0.25f + lane, 0.125f, 1.f);
-#ifdef GF_AB_RANDOM_CONST
-                    // (the same ablation with operands that LOOK like data: a hash of (lane, slot) scaled into [-1, 1))
-                    auto hv = [&](unsigned k) { unsigned x = (unsigned)lane * 2654435761u + k * 40503u + (unsigned)(z1 * 131 + z2 * 17 + z3) * 2246822519u; x ^= x >> 15; x *= 2654435761u; x ^= x >> 13; return (float)(int)x * 4.656612873e-10f; };
-                    Bf[z1][z2][z3] = make_float4(hv(1), hv(2), hv(3), hv(4));
-#endif
                 }
             }
 #endif
-        int b_once = 0; (void)b_once;
         auto load_b = [&](int node, float4 (&b)[QW][NB]) {
 #ifdef GF_AB_NO_BLOAD
             return;
-#endif
-#ifdef GF_AB_B_ONCE
-            if (b_once >= 2) return;            // timing only: real filter data in both operand buffers, loaded once, never again
-            ++b_once;
 #endif
 #pragma unroll
             for (int gq = 0; gq < QW; ++gq)
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
-#if defined(GF_AB_B_ONCE) && defined(GF_AB_RANDOM_CONST)
-                    {   // (the once-loaded variant's control flow with hash values in place of the filter data)
-                        const float4 t = wp4[((size_t)(node * (CIN / 8) + kq * QW + gq) * NB + nb) * 64 + lane];
-                        auto hv = [&](unsigned k) { unsigned x = (unsigned)lane * 2654435761u + k * 40503u + (unsigned)(gq * 17 + nb + b_once * 131) * 2246822519u; x ^= x >> 15; x *= 2654435761u; x ^= x >> 13; return (float)(int)x * 4.656612873e-10f; };
-                        b[gq][nb] = make_float4(hv(1) + 0.f * t.x, hv(2), hv(3), hv(4));
-                    }
-#elif defined(GF_AB_B_LDS)
-                    b[gq][nb] = ((const float4*)Bl)[((kq * QW + gq) * NB + nb) * 64 + lane];
-#else
                     b[gq][nb] = wp4[((size_t)(node * (CIN / 8) + kq * QW + gq) * NB + nb) * 64 + lane];
-#endif
                 }
         };
         auto load_a = [&](const float* Zc, float4 (&a)[QW]) {
@@ -548,221 +521,6 @@ __global__ void __launch_bounds__(GF_THREADS) k_cconv_gf(GfArgs A)
 }
 
 // ------------------------------------------------------------------------------------------------
-// Round 4 (late): the fp32 layer WITHOUT the producer / consumer split — k_cconv_gf2.
-// On gfx950 v_mfma_f32_32x32x2_f32 executes on the fp32 vector ALUs and holds them for its 64 cycles.  A producer wave next to a
-// consumer wave therefore gets ONE dependent vector instruction through per MFMA: its address arithmetic and FMAs trickle at
-// ~1 / 68 cycles while the consumer streams, then the consumer waits at the unit's barrier while the producer runs alone — the
-// two sides took nearly the SUM of their times (44.6 + 44.7 us apart, 73.8 together on conv1), the producers' raised priority included.
-// Here a wave does both, in BURSTS that the program order fixes: all vector work of a unit (4 - 5 cycles per instruction), then its
-// 96 MFMAs back to back — and nothing is exchanged between waves at all:
-//   * lane (m, h) of wave q owns point m of the tile and the channels {8 (q QW + g) + 4 h + s : g < QW, s < 4} — EXACTLY the K
-//     indices whose A operands that lane feeds to the MFMAs of the wave's K-quarter.  The patch row Z[node][m][those channels] is
-//     accumulated in registers and handed to the MFMA from the same registers: no LDS, no s_barrier, no Z anywhere.
-//   * a lane walks its point's row-entry list itself (entries straight from memory, four per batch, the x rows of the next batch
-//     and the entries of the one after in flight behind the FMAs of the current one; loads are unconditional on clamped addresses,
-//     so the compiler's wait counts stay exact);
-//   * the first batch of the NEXT unit is requested inside the MFMA burst (entries before it, their x rows behind its first node);
-//   * 256 threads and <= 256 registers: two workgroups share a CU, one wave computes while the other waits for memory.
-// Same stream-K units, slabs and epilogues as k_cconv_gf.
-// ------------------------------------------------------------------------------------------------
-#ifndef GF2_EB96
-#define GF2_EB96 2
-#endif
-#ifndef GF2_EB64
-#define GF2_EB64 4
-#endif
-#ifndef GF2_WPS
-#define GF2_WPS 2
-#endif
-typedef float gf2_f4 __attribute__((ext_vector_type(4)));
-typedef unsigned gf2_u3 __attribute__((ext_vector_type(3)));
-// acc += w.lo * x / acc += w.hi * x on both halves of the packed lanes (v_pk_fma_f32 with the weight's half picked by op_sel)
-__device__ __forceinline__ void gf2_fma_lo(f32x2& acc, f32x2 w, f32x2 x) { asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(w), "v"(x)); }
-__device__ __forceinline__ void gf2_fma_hi(f32x2& acc, f32x2 w, f32x2 x) { asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(w), "v"(x)); }
-template <int CIN, int NB, bool RELU>
-__global__ void __launch_bounds__(256, GF2_WPS) k_cconv_gf2(GfArgs A)
-{
-    constexpr int QW = CIN / 32;               // groups of 8 channels per wave and node; a lane holds 4 channels of each
-    constexpr int COUTP = 32 * NB;
-    constexpr int EB = CIN > 64 ? GF2_EB96 : GF2_EB64;      // entries per batch (registers: two batches of x rows + one of entries in flight)
-    const int a_n = A.n, a_nwg = A.nwg, a_maxseg = A.maxseg, a_ctot = A.ctot;
-    float* const a_scratch = A.scratch;
-    // Buffer resources: one address register per load, and a load past the range returns zeros — a slot past a point's list reads
-    // {j = 0, w = 0, 0}: row 0 with zero weights; no selects on the data, no branches (the wait counts stay exact)
-    const unsigned ent_stride = (unsigned)(4 * A.pitch) * 12u;
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)A.x, 0, (unsigned)a_n * CIN * 4u, 0x27000);
-    const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc((void*)A.ent, 0, (unsigned)a_n * ent_stride, 0x27000);
-    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)A.roff, 0, (unsigned)a_n * (GF_ROFF_PITCH * 2u), 0x27000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)A.wp, 0, 65u * (CIN / 8) * NB * 1024u, 0x27000);
-    const int w = blockIdx.x;
-    const int g0 = gf_begin(w, a_nwg, a_ctot), g1 = gf_begin(w + 1, a_nwg, a_ctot);
-    const int nun = g1 - g0;
-    const int kq = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
-    const unsigned xlane = (unsigned)(8 * kq * QW + 4 * h) * 4u;        // byte offset of this lane's first channel inside a row
-    f32x16 acc[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
-    gf2_f4 Bf[2][QW][NB];
-    auto load_b = [&](int node, gf2_f4 (&b)[QW][NB]) __attribute__((always_inline)) {
-        const int soff = ((node * (CIN / 8) + kq * QW) * NB) * 1024;
-#pragma unroll
-        for (int gq = 0; gq < QW; ++gq)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-                b[gq][nb] = __builtin_bit_cast(gf2_f4, __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16 + (gq * NB + nb) * 1024, soff, 0));
-    };
-    auto first_node = [&](int g) __attribute__((always_inline)) { const int u = g % GF_UNITS; return u < 16 ? 4 * u : 64; };
-
-    // ---- the row-entry walk of one lane
-    struct XS { unsigned jc; float w0, w1; gf2_f4 xv[QW]; };
-    // entries e .. e + EB - 1 of the list whose first entry sits at byte offset ebase (cnt of them)
-    auto load_ents = [&](unsigned ebase, int cnt, int e, gf2_u3 (&E)[EB]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int q = 0; q < EB; ++q) {
-            const unsigned off = (e + q < cnt) ? ebase + (unsigned)(e + q) * 12u : 0xfffffff0u;
-            E[q] = __builtin_bit_cast(gf2_u3, __builtin_amdgcn_raw_buffer_load_b96(re, (int)off, 0, 0));
-        }
-    };
-    auto request = [&](const gf2_u3 (&E)[EB], XS (&S)[EB]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int q = 0; q < EB; ++q) {
-            S[q].jc = E[q].x; S[q].w0 = __uint_as_float(E[q].y); S[q].w1 = __uint_as_float(E[q].z);
-            const unsigned rb = (E[q].x & 0x3fffffffu) * (unsigned)(CIN * 4) + xlane;
-#pragma unroll
-            for (int g = 0; g < QW; ++g) S[q].xv[g] = __builtin_bit_cast(gf2_f4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)rb + 32 * g, 0, 0));
-        }
-    };
-    struct Acc4 { f32x2 lo, hi; };
-    auto accumulate = [&](const XS (&S)[EB], Acc4 (&z)[4][QW]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int q = 0; q < EB; ++q) {
-            const unsigned cx = S[q].jc >> 30;
-            const float w0 = S[q].w0, w1 = S[q].w1;
-            // the four nodes' weights as TWO register pairs; the packed FMAs pick a half with op_sel (a {w, w} pair per node would
-            // cost two moves per node and entry)
-            const f32x2 p01 = {cx == 0 ? w0 : 0.f, cx == 0 ? w1 : (cx == 1 ? w0 : 0.f)};
-            const f32x2 p23 = {cx == 1 ? w1 : (cx == 2 ? w0 : 0.f), cx == 2 ? w1 : 0.f};
-#pragma unroll
-            for (int g = 0; g < QW; ++g) {
-                gf2_f4 v = S[q].xv[g];
-                if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                const f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
-                gf2_fma_lo(z[0][g].lo, p01, lo); gf2_fma_lo(z[0][g].hi, p01, hi);
-                gf2_fma_hi(z[1][g].lo, p01, lo); gf2_fma_hi(z[1][g].hi, p01, hi);
-                gf2_fma_lo(z[2][g].lo, p23, lo); gf2_fma_lo(z[2][g].hi, p23, hi);
-                gf2_fma_hi(z[3][g].lo, p23, lo); gf2_fma_hi(z[3][g].hi, p23, hi);
-            }
-        }
-    };
-    // the list of (unit g, this lane's point): byte offset of its first entry and its length.  Rows past n: the offsets load is
-    // out of range and returns zeros (an empty list); the Linear unit has none
-    auto unit_list = [&](int g, unsigned& ebase, int& cnt) __attribute__((always_inline)) {
-        const int tile = g / GF_UNITS, u = g - tile * GF_UNITS, i = tile * GF_TILE + m;
-        const unsigned ro = (unsigned)i * (GF_ROFF_PITCH * 2u) + 2u * (unsigned)min(u, 15);
-        const int a0 = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rr, (int)ro, 0, 0);
-        const int a1 = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rr, (int)ro + 2, 0, 0);
-        ebase = (unsigned)i * ent_stride + (unsigned)a0 * 12u;
-        cnt = u < 16 ? a1 - a0 : 0;
-    };
-
-    unsigned ebase = 0;
-    int cnt = 0;
-    gf2_u3 EN[EB];                              // the entries of the batch after the one(s) whose x rows are in flight
-    XS SA[EB], SB[EB];
-    if (nun > 0) {
-        unit_list(g0, ebase, cnt);
-        load_ents(ebase, cnt, 0, EN);
-        request(EN, SA);
-        load_ents(ebase, cnt, EB, EN);
-    }
-    for (int p = 0; p < nun; ++p) {
-        const int g = g0 + p, tile = g / GF_UNITS, u = g - tile * GF_UNITS;
-        const int nc = u < 16 ? 4 : 1, node0 = u < 16 ? 4 * u : 64;
-        // every unit starts in B buffer 0: its first node's filter block is requested here, in front of the unit's vector work
-        load_b(node0, Bf[0]);
-        // the NEXT unit's list (its offsets arrive behind this unit's vector work)
-        unsigned nebase = 0;
-        int ncnt = 0;
-        if (p + 1 < nun) unit_list(g + 1, nebase, ncnt);
-        Acc4 z[4][QW];
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int gq = 0; gq < QW; ++gq) { z[c][gq].lo = f32x2{0.f, 0.f}; z[c][gq].hi = f32x2{0.f, 0.f}; }
-        // ---- vector burst.  State: SA = x rows of batch 0 (requested), EN = entries of batch 1 (requested).  Batches go in pairs
-        // through two static buffers (no copies, one loop exit); a pair's second batch may lie past every list: it reads zeros
-        for (int e = 0; __any(e < cnt); e += 2 * EB) {
-            request(EN, SB);
-            load_ents(ebase, cnt, e + 2 * EB, EN);
-            __builtin_amdgcn_sched_barrier(0);
-            accumulate(SA, z);
-            __builtin_amdgcn_sched_barrier(0);
-            request(EN, SA);
-            load_ents(ebase, cnt, e + 3 * EB, EN);
-            __builtin_amdgcn_sched_barrier(0);
-            accumulate(SB, z);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (u == 16) {
-            // Linear branch: Z = act(x_i) (rows past n read zeros)
-            const unsigned rb = (unsigned)(tile * GF_TILE + m) * (unsigned)(CIN * 4) + xlane;
-#pragma unroll
-            for (int gq = 0; gq < QW; ++gq) {
-                gf2_f4 v = __builtin_bit_cast(gf2_f4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)rb + 32 * gq, 0, 0));
-                if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                z[0][gq].lo = f32x2{v.x, v.y}; z[0][gq].hi = f32x2{v.z, v.w};
-            }
-        }
-        // ---- MFMA burst; the next unit's first requests ride inside (entries in front of it, their x rows behind its first node)
-        __builtin_amdgcn_sched_barrier(0);
-        ebase = nebase; cnt = ncnt;
-        load_ents(ebase, cnt, 0, EN);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            if (c < nc) {
-                if (c + 1 < nc) load_b(node0 + c + 1, Bf[(c + 1) & 1]);
-                __builtin_amdgcn_sched_barrier(0);       // (the scheduler must not pull the next phase's loads above the burst)
-#pragma unroll
-                for (int gq = 0; gq < QW; ++gq) {
-                    const float av[4] = {z[c][gq].lo.x, z[c][gq].lo.y, z[c][gq].hi.x, z[c][gq].hi.y};
-#pragma unroll
-                    for (int s2 = 0; s2 < 4; ++s2)
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb)
-                            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2], Bf[c & 1][gq][nb][s2], acc[nb], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (c == 0) {
-                    request(EN, SA);
-                    load_ents(ebase, cnt, EB, EN);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
-        const bool last_of_tile = (p + 1 == nun) || ((g + 1) / GF_UNITS != tile);
-        if (last_of_tile) {
-            // partial slab of (tile, this workgroup's segment, K-quarter): [col][row]; a lane's 4 consecutive accumulator
-            // registers are 4 consecutive rows of one column -> 16-byte stores
-            const int seg = w - gf_owner((long long)tile * GF_COST, a_nwg, a_ctot);
-            float* slab = a_scratch + ((size_t)(tile * a_maxseg + seg) * 4 + kq) * (COUTP * GF_TILE);
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                for (int gr = 0; gr < 4; ++gr) {
-                    const float4 v = make_float4(acc[nb][4 * gr], acc[nb][4 * gr + 1], acc[nb][4 * gr + 2], acc[nb][4 * gr + 3]);
-                    *(float4*)(slab + (32 * nb + m) * GF_TILE + 8 * gr + 4 * h) = v;
-                }
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // epilogue: y[i][co] = sum over the tile's partial slabs (segment-major, K-quarter-minor: a fixed order) + conv bias + Linear
 // bias (+ residual); for the last layer (cout = 3) also pos_correction = y / 128 and update_pos_vel (models/transmodel.py:141-148)
 // ------------------------------------------------------------------------------------------------
@@ -918,11 +676,7 @@ extern "C" int nf_cconv_gf_plan(int n, int cout, int max_wg, int* tiles, int* nw
 template <int CIN, int NB, bool RELU, bool SPLIT>
 static int gf_launch(const GfArgs& a, hipStream_t st)
 {
-#ifdef GF_AB_B_LDS
-    const size_t lds = (SPLIT ? (size_t)2 * 2 * 4 * GF_TILE * (CIN + 8) * sizeof(_Float16) : (size_t)2 * 4 * GF_TILE * (CIN + 4) * sizeof(float)) + (size_t)(CIN / 8) * NB * 1024;
-#else
     const size_t lds = SPLIT ? (size_t)2 * 2 * 4 * GF_TILE * (CIN + 8) * sizeof(_Float16) : (size_t)2 * 4 * GF_TILE * (CIN + 4) * sizeof(float);
-#endif
     static bool attr_set[64] = {};
     if (nf_first_use_on_device(attr_set))
         hipFuncSetAttribute((const void*)k_cconv_gf<CIN, NB, RELU, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -948,19 +702,8 @@ static int gf_run_conv(const float* x, int n, int cin, int cout, int relu, const
         else if (cin == 64 && nb == 2) gf_launch<64, 2, R, S>(a, st); \
         else gf_launch<64, 1, R, S>(a, st);                     \
     } while (0)
-#define GF_PICK2(R)                                                                                                      \
-    do {                                                                                                                 \
-        if (cin == 96 && nb == 2) hipLaunchKernelGGL((k_cconv_gf2<96, 2, R>), dim3(a.nwg), dim3(256), 0, st, a);          \
-        else if (cin == 64 && nb == 2) hipLaunchKernelGGL((k_cconv_gf2<64, 2, R>), dim3(a.nwg), dim3(256), 0, st, a);     \
-        else hipLaunchKernelGGL((k_cconv_gf2<64, 1, R>), dim3(a.nwg), dim3(256), 0, st, a);                               \
-    } while (0)
     if (split) { if (relu) GF_PICK(true, true); else GF_PICK(false, true); }
-#ifdef GF_AB_FUSED_ROLES
-    else { if (relu) GF_PICK2(true); else GF_PICK2(false); }       // k_cconv_gf2 (measured slower, see its comment)
-#else
     else { if (relu) GF_PICK(true, false); else GF_PICK(false, false); }
-#endif
-#undef GF_PICK2
 #undef GF_PICK
     NF_CHECK_LAUNCH();
     e->split = split;

@@ -433,12 +433,26 @@ __global__ void __launch_bounds__(GF_THREADS) k_cconv_gf(GfArgs A)
                 // hides behind the accumulation in between instead of stalling every request.
                 auto bcast = [&](auto ec, TB& T) __attribute__((always_inline)) {
                     constexpr int E = decltype(ec)::value, SL = E / GF_TPP;
-                    const int src = (lane & ~(GF_TPP - 1)) | (E & (GF_TPP - 1));
                     const int jcS = cj[SL];
                     const float w0S = ca[SL];
                     const float w1S = cb[SL];
+#if GF_TPP == 8 && !defined(GF_AB_SHFL_BCAST)
+                    // lane (E & 7) of every 8-lane group to the whole group on the DPP path: a quad_perm broadcast inside the source's
+                    // quad, then a row shift by 4 into the group's other quad (bank mask) — two VALU moves per value instead of a
+                    // ds_bpermute round trip through the LDS crossbar (three per entry, ~100 per unit and wave before)
+                    auto oct = [&](int v) __attribute__((always_inline)) {
+                        constexpr int K = E & 7, QP = (K & 3) * 0x55;
+                        const int t = __builtin_amdgcn_update_dpp(v, v, QP, 0xf, 0xf, false);
+                        return K < 4 ? __builtin_amdgcn_update_dpp(t, t, 0x114, 0xf, 0xa, false)       // row_shr:4 into quads 1, 3
+                                     : __builtin_amdgcn_update_dpp(t, t, 0x104, 0xf, 0x5, false);      // row_shl:4 into quads 0, 2
+                    };
+                    const int jc = oct(jcS);
+                    const float w0 = __int_as_float(oct(__float_as_int(w0S))), w1 = __int_as_float(oct(__float_as_int(w1S)));
+#else
+                    const int src = (lane & ~(GF_TPP - 1)) | (E & (GF_TPP - 1));
                     const int jc = __shfl(jcS, src, 64);
                     const float w0 = __shfl(w0S, src, 64), w1 = __shfl(w1S, src, 64);
+#endif
                     const bool ok = E < cnt;
                     T.jc = ok ? jc : 0; T.w0 = ok ? w0 : 0.f; T.w1 = ok ? w1 : 0.f;      // masked: row 0, zero weights
                 };
@@ -872,10 +886,7 @@ __global__ void __launch_bounds__(256) k_cconv3_gather(const float* __restrict__
         acc1 = fmaf(w1, g[4], fmaf(w0, g[1], acc1));
         acc2 = fmaf(w1, g[5], fmaf(w0, g[2], acc2));
     }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        acc0 += __shfl_xor(acc0, o, 64); acc1 += __shfl_xor(acc1, o, 64); acc2 += __shfl_xor(acc2, o, 64);
-    }
+    acc0 = nf_wave_sum(acc0); acc1 = nf_wave_sum(acc1); acc2 = nf_wave_sum(acc2);
     if (lane < 3) {
         const float a = lane == 0 ? acc0 : (lane == 1 ? acc1 : acc2);
         const float v = a + G3[(size_t)i * G3_PITCH + 192 + lane] + bias_c[lane] + bias_d[lane];

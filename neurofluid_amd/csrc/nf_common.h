@@ -117,6 +117,18 @@ __device__ __forceinline__ int nf_cell_coord(float p, float o, float ic, int d)
     return c < 0 ? 0 : (c >= d ? d - 1 : c);
 }
 
+// Sum over a wave on the DPP path: four rotations inside the 16-lane rows, then the four rows through SGPRs — no LDS traffic (a
+// __shfl_xor butterfly is six ds_bpermute round trips through the LDS crossbar).  Uniform result.
+__device__ __forceinline__ float nf_wave_sum(float v)
+{
+#define NF_ROR_ADD(n) v += __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x120 | (n), 0xf, 0xf, false));
+    NF_ROR_ADD(1) NF_ROR_ADD(2) NF_ROR_ADD(4) NF_ROR_ADD(8)
+#undef NF_ROR_ADD
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
 // fp32 squared distance exactly as the oracle (oracle/csrc/nf_oracle.c:d2f): mul + add chain, d = 0,1,2,
 // no FMA contraction.
 __device__ __forceinline__ float nf_dist2(float qx, float qy, float qz, float px, float py, float pz)

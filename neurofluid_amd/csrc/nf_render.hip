@@ -1587,22 +1587,9 @@ __global__ void __launch_bounds__(128) k_features_bwd(const float* __restrict__ 
 // scalars (density, smoothed position, variance, smoothed direction) are differentiated by ten lanes at once — one sincos
 // chain deep instead of ten.  Same formulas as k_features_bwd; the neighbour sums associate differently (tree instead of
 // k = 0..K-1), a relative 1e-7 on the recomputed forward values.
-// (round 4: on the DPP path — four rotations inside the 16-lane rows, then the four rows through SGPRs.  The six-step __shfl_xor
-// butterfly is six ds_bpermute round trips through the LDS crossbar, and this kernel takes thirteen such sums per row)
-__device__ __forceinline__ float wave_sum(float v)
-{
-#ifdef NF_AB_SHFL_SUM
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-#endif
-#define NF_ROR_ADD(n) v += __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x120 | (n), 0xf, 0xf, false));
-    NF_ROR_ADD(1) NF_ROR_ADD(2) NF_ROR_ADD(4) NF_ROR_ADD(8)
-#undef NF_ROR_ADD
-    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
-    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
-    return (r0 + r1) + (r2 + r3);
-}
+// (round 4: the sums over neighbours on the DPP path — nf_wave_sum, nf_common.h; as __shfl_xor butterflies, thirteen per row, they were
+// a fifth of this kernel: 78.1 -> 61.7 us per launch)
+__device__ __forceinline__ float wave_sum(float v) { return nf_wave_sum(v); }
 
 template <int FLAGS>
 __global__ void __launch_bounds__(256) k_features_bwd_w(const float* __restrict__ particles, const float* __restrict__ rays,

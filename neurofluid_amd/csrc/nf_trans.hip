@@ -963,6 +963,13 @@ static int tf_ncu()
 
 // two workgroups of 8 waves fit a CU (61 KB of LDS each: the filter is staged once per workgroup): size the grid so that
 // every workgroup is resident at once and each wave walks the same number of particles
+// workgroups of the container half: at most TF_LISTMAX particles are dealt to one (its pre-pass queues them in LDS)
+static int tf_box_blocks(int blocks, int n)
+{
+    const int need = (n + TF_LISTMAX - 1) / TF_LISTMAX;
+    return blocks < need ? need : blocks;
+}
+
 static int tf_blocks(int n, int wg_per_cu = 1)
 {
     const int ncu = tf_ncu() * wg_per_cu, per = TF_WAVES, iters = (n + ncu * per - 1) / (ncu * per);
@@ -996,7 +1003,7 @@ extern "C" int nf_trans_front(const void* fluid_grid, const void* box_grid, cons
 #ifdef TF_AB_NO_BOX
     hipLaunchKernelGGL(k_trans_front, dim3(tf_blocks(n), 1), dim3(64 * TF_WAVES), 0, (hipStream_t)stream, A, 1);
 #else
-    hipLaunchKernelGGL(k_trans_front, dim3(tf_blocks(n), 2), dim3(64 * TF_WAVES), 0, (hipStream_t)stream, A, 3);
+    hipLaunchKernelGGL(k_trans_front, dim3(tf_box_blocks(tf_blocks(n), n), 2), dim3(64 * TF_WAVES), 0, (hipStream_t)stream, A, 3);
 #endif
     NF_CHECK_LAUNCH();
     return NF_OK;
@@ -1410,7 +1417,7 @@ static int tb_launch(const TsArgs& S, const TfArgs& A, hipStream_t st)
     if (nsearch > ncu) nsearch = ncu;
 #ifdef TB_AB_BOX_IN_STAGE1
     const int iters = (n + ncu * TB_BOX_WAVES - 1) / (ncu * TB_BOX_WAVES);
-    const int nbox = (n + TB_BOX_WAVES * iters - 1) / (TB_BOX_WAVES * iters);
+    const int nbox = tf_box_blocks((n + TB_BOX_WAVES * iters - 1) / (TB_BOX_WAVES * iters), n);
 #else
     const int nbox = 0;                                                  // (the container half rides in k_trans_front_rows' launch)
 #endif
@@ -1444,7 +1451,7 @@ static int ts_launch(const TsArgs& S0, const TfArgs& A, hipStream_t st)
 #ifdef TS_AB_NO_BOX
     const int box_wg = 0;
 #else
-    const int box_wg = (n + per * iters - 1) / (per * iters);
+    const int box_wg = tf_box_blocks((n + per * iters - 1) / (per * iters), n);
 #endif
     hipLaunchKernelGGL(k_trans_stage1, dim3(1 + box_wg), dim3(TS_BLOCK), lds, st, S, A);
     return 0;
@@ -1494,7 +1501,7 @@ int nf_trans_stage12(const nf_trans_step_t* s, const float* pos, const float* ve
 #if defined(TB_AB_BOX_IN_STAGE1) || defined(TS_AB_NO_BOX)
         const int nb = 0;
 #else
-        const int nb = tf_blocks(s->n, 1);
+        const int nb = tf_box_blocks(tf_blocks(s->n, 1), s->n);
 #endif
         hipLaunchKernelGGL(k_trans_front_rows, dim3(nf + nb), dim3(64 * TF_WAVES), 0, (hipStream_t)stream, A, nf);
         NF_CHECK_LAUNCH();

@@ -1,20 +1,14 @@
 #!/bin/bash
-# dev tool (round 4): where the front of the transition step spends its time — A/B builds of nf_trans.hip on the GPU box
+# A/B builds of the front kernels of the transition step (one box): tools/ab_front.sh "<defs>" ...   (AB_FROZEN=frozen: every step from the same state —
+# mandatory for switches that corrupt the output; AB_MODE: trans_perf.py's mode)
 cd $GRAFT_REPO_ROOT
-VARIANTS=("" "-DTF_AB_SKIP_PATCH" "-DTF_AB_SKIP_ENT" "-DTF_AB_SKIP_GEMV" "-DTF_AB_SKIP_PATCH -DTF_AB_SKIP_ENT -DTF_AB_SKIP_GEMV" "-DTF_AB_SKIP_ALL" "-DTF_AB_NO_BOX" "${@}")
+VARIANTS=("${@}")
 for defs in "${VARIANTS[@]}"; do
   NF_EXTRA_DEFS="$defs" python -m neurofluid_amd.build > /dev/null 2>&1 || { echo "build failed: $defs"; continue; }
   tag=$(echo "base$defs" | tr -d ' ' | tr -c 'A-Za-z0-9_\n' '_')
-  bash tools/prof.sh ab_$tag python $GRAFT_REPO_ROOT/tools/trans_perf.py 30 > /dev/null 2>&1
-  echo "== $defs"
-  python - "$tag" <<'PY'
-import csv, sys, glob
-f = glob.glob(f"gpurun_out/ab_{sys.argv[1]}/*kernel_stats.csv")[0]
-for r in csv.DictReader(open(f)):
-    n = r["Name"].split("(")[0]
-    if any(k in n for k in ("k_cconv", "k_trans_")):
-        print(f"   {n[:34]:34s} {float(r['AverageNs'])/1e3:8.1f} us")
-PY
+  bash tools/prof.sh ab_$tag python $GRAFT_REPO_ROOT/tools/trans_perf.py 30 ${AB_MODE:-fp32} ${AB_FROZEN:-} > /dev/null 2>&1
+  echo "== $defs"; grep iter gpurun_out/ab_$tag/run.log | tail -1
+  python tools/kstats.py gpurun_out/ab_$tag/p_kernel_stats.csv 90 12 | grep "k_trans_\|kernel ms"
 done
 NF_EXTRA_DEFS="" python -m neurofluid_amd.build > /dev/null 2>&1
 rm -rf gpurun_out/ab_*

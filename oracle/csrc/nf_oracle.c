@@ -97,6 +97,43 @@ void nfo_radius_csr(const float* q, int64_t nq, const float* p, int64_t np,
     }
 }
 
+/* How much of the ball query depends on FP contraction ("parity unpinned" caveat): pytorch3d's CUDA kernel accumulates
+ * `dist2 += diff * diff` over d = 0, 1, 2 and nvcc contracts that to FMAs by default, the restatement above evaluates mul + add.  For every
+ * (query, point) pair both sums are formed (the contracted one with fmaf; only pairs within 1e-5 relative of r*r can differ and are evaluated
+ * twice) and compared against r*r with the library's strict < (inclusive = 0: pytorch3d ball_query) or <= (inclusive = 1: Open3D
+ * FixedRadiusSearch; K = a bound above any count then).
+ * out[0] = pairs tested, out[1] = pairs whose in / out decision differs, out[2] = queries whose first-K index list differs,
+ * out[3] = pairs whose decision agrees but whose fp32 d2 differs by an ulp or more (reported in dists, not in the set). */
+#include <math.h>
+void nfo_ball_query_contraction_sensitivity(const float* q, int64_t nq, const float* p, int64_t np, float radius, int K, int inclusive,
+                                            int64_t* out)
+{
+    const float r2 = radius * radius, band = r2 * 1e-5f;
+    int64_t flips = 0, qdiff = 0, ulps = 0;
+#pragma omp parallel for schedule(dynamic, 256) reduction(+:flips, qdiff, ulps)
+    for (int64_t i = 0; i < nq; ++i) {
+        int ca = 0, cb = 0, differs = 0;
+        for (int64_t j = 0; j < np && (ca < K || cb < K); ++j) {
+            const float* a = q + 3 * i; const float* b = p + 3 * j;
+            const float s = d2f(a, b);
+            int ina = inclusive ? s <= r2 : s < r2, inb = ina;
+            if (fabsf(s - r2) <= band || ina) {
+                const float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+                float t = dx * dx;
+                t = fmaf(dy, dy, t);
+                t = fmaf(dz, dz, t);
+                inb = inclusive ? t <= r2 : t < r2;
+                if (ina && inb && t != s) ++ulps;
+            }
+            if (ina != inb) { ++flips; if (ca < K && cb < K) differs = 1; }
+            else if (ina && (ca < K) != (cb < K)) differs = 1;
+            ca += ina && ca < K; cb += inb && cb < K;
+        }
+        qdiff += differs;
+    }
+    out[0] = nq * np; out[1] = flips; out[2] = qdiff; out[3] = ulps;
+}
+
 /* thread control for the timed CPU baseline (bench.py): n <= 0 leaves the OpenMP default */
 #ifdef _OPENMP
 #include <omp.h>

@@ -73,3 +73,18 @@ def fixed_radius_search(points, queries, radius, ignore_query_point=True):
     lib.nfo_radius_csr(_p(q), ctypes.c_int64(Q), _p(pts), ctypes.c_int64(pts.shape[0]),
                        ctypes.c_float(radius), ctypes.c_int(int(ignore_query_point)), _p(rs), _p(idx), _p(d2))
     return idx, rs, d2
+
+
+def ball_query_contraction_sensitivity(p1, p2, radius, K, inclusive=False):
+    """How many decisions of the ball query (strict d2 < r2, first K by index) change when `dx^2 + dy^2 + dz^2` is contracted to
+    FMAs (nvcc's default for pytorch3d's kernel) instead of evaluated as mul + add (this oracle, the HIP kernel).
+    inclusive=True: the same question for Open3D's FixedRadiusSearch (d2 <= r2; pass K above any neighbour count).
+    -> dict(pairs, flipped_pairs, queries_with_a_different_list, in_ball_pairs_with_another_d2)."""
+    lib = _load()
+    p1 = np.ascontiguousarray(p1, dtype=np.float32).reshape(-1, 3)
+    p2 = np.ascontiguousarray(p2, dtype=np.float32).reshape(-1, 3)
+    out = np.zeros((4,), np.int64)
+    lib.nfo_ball_query_contraction_sensitivity(_p(p1), ctypes.c_int64(p1.shape[0]), _p(p2), ctypes.c_int64(p2.shape[0]),
+                                               ctypes.c_float(radius), ctypes.c_int(K), ctypes.c_int(int(inclusive)), _p(out))
+    return dict(pairs=int(out[0]), flipped_pairs=int(out[1]), queries_with_a_different_list=int(out[2]),
+                in_ball_pairs_with_another_d2=int(out[3]))

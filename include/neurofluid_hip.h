@@ -470,7 +470,8 @@ typedef struct {
 } nf_trans_step_t;
 int nf_trans_all_pairs_max_points(void);
 int nf_trans_step(const nf_trans_step_t* s /*[host]*/, const float* pos, const float* vel, float* num_fluid_nbrs, float* pos_c,
-                  float* vel_c, int32_t* host_flag3 /* see nf_trans_front */, int step_id, nf_stream_t stream);
+                  float* vel_c, int32_t* host_flag3 /* as nf_trans_front's; inside the step [2] = step_id is raised by the first layer's launch as it
+                                                       starts (the searches and their overflow words [0], [1] are complete then) */, int step_id, nf_stream_t stream);
 
 #ifdef __cplusplus
 }

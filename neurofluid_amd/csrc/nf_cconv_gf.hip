@@ -50,6 +50,8 @@ struct GfArgs {
     const float* wp;           // packed filter (nf_cconv_gf_pack)
     float* scratch;            // [tiles][maxseg][4][COUTP][32] partial accumulators
     int tiles, nwg, maxseg, ctot;
+    volatile int* done_word;   // or null: a host-mapped word that receives step_id when this launch STARTS (nf_trans_step: everything in
+    int step_id;               // front of the layers — search, overflow words — is complete then; the host spins on it)
 };
 
 // workgroup w owns the units g with gf_begin(w) <= g < gf_begin(w + 1); unit g = tile * 17 + u starts at cost
@@ -93,6 +95,7 @@ __global__ void __launch_bounds__(GF_THREADS) k_cconv_gf(GfArgs A)
     const float* const a_wp = A.wp;
     float* const a_scratch = A.scratch;
     const int w = blockIdx.x;
+    if (A.done_word && w == 0 && threadIdx.x == 0) *A.done_word = A.step_id;
     const int g0 = gf_begin(w, a_nwg, a_ctot), g1 = gf_begin(w + 1, a_nwg, a_ctot);
     const int nun = g1 - g0;
     // the role is a SCALAR (wave-uniform) value: the two halves below are separate scalar branches, each wave meets exactly
@@ -701,9 +704,11 @@ static int gf_launch(const GfArgs& a, hipStream_t st)
 // One G-free layer: y = cconv(act(x)) + Linear(act(x)) + biases (+ residual) [+ position / velocity update when pos != NULL]
 // the contraction kernel of one layer into the partial slabs; fills the epilogue's description of them
 static int gf_run_conv(const float* x, int n, int cin, int cout, int relu, const uint16_t* roff, const uint32_t* ent, int pitch,
-                       const void* packed, int split, float* scratch, int max_wg, hipStream_t st, GfEpi* e)
+                       const void* packed, int split, float* scratch, int max_wg, hipStream_t st, GfEpi* e,
+                       int32_t* done_word = nullptr, int step_id = 0)
 {
     GfArgs a;
+    a.done_word = (volatile int*)done_word; a.step_id = step_id;
     a.x = x; a.n = n; a.relu = relu; a.roff = roff; a.ent = ent; a.pitch = pitch; a.wp = (const float*)packed; a.scratch = scratch;
     size_t sf;
     if (nf_cconv_gf_plan(n, cout, max_wg, &a.tiles, &a.nwg, &a.maxseg, &sf) != NF_OK) return NF_EINVAL;
@@ -725,10 +730,24 @@ static int gf_run_conv(const float* x, int n, int cin, int cout, int relu, const
     return NF_OK;
 }
 
+static int gf_layer(const float* x, int n, int cin, int cout, int relu, const uint16_t* roff, const uint32_t* ent,
+                    int pitch, const void* packed, int split, const float* bias_conv, const float* bias_dense,
+                    const float* residual, float* out, float* out_relu, float* scratch, int max_wg, const float* pos,
+                    const float* pos_new, float scale, float dt, float* pos_c, float* vel_c, nf_stream_t stream, int32_t* done_word, int step_id);
+
 extern "C" int nf_cconv_gf_layer(const float* x, int n, int cin, int cout, int relu, const uint16_t* roff, const uint32_t* ent,
                                  int pitch, const void* packed, int split, const float* bias_conv, const float* bias_dense,
                                  const float* residual, float* out, float* out_relu, float* scratch, int max_wg, const float* pos,
                                  const float* pos_new, float scale, float dt, float* pos_c, float* vel_c, nf_stream_t stream)
+{
+    return gf_layer(x, n, cin, cout, relu, roff, ent, pitch, packed, split, bias_conv, bias_dense, residual, out, out_relu, scratch, max_wg, pos,
+                    pos_new, scale, dt, pos_c, vel_c, stream, nullptr, 0);
+}
+
+static int gf_layer(const float* x, int n, int cin, int cout, int relu, const uint16_t* roff, const uint32_t* ent,
+                    int pitch, const void* packed, int split, const float* bias_conv, const float* bias_dense,
+                    const float* residual, float* out, float* out_relu, float* scratch, int max_wg, const float* pos,
+                    const float* pos_new, float scale, float dt, float* pos_c, float* vel_c, nf_stream_t stream, int32_t* done_word, int step_id)
 {
     NF_CHECK_ARG(x && roff && ent && packed && bias_conv && bias_dense && (out || out_relu) && scratch, "null pointer");
     NF_CHECK_ARG(((cin == 96 && cout > 32) || cin == 64) && cout >= 1 && cout <= 64,
@@ -737,7 +756,7 @@ extern "C" int nf_cconv_gf_layer(const float* x, int n, int cin, int cout, int r
     if (n <= 0) return NF_OK;
     hipStream_t st = (hipStream_t)stream;
     GfEpi e;
-    const int rc = gf_run_conv(x, n, cin, cout, relu, roff, ent, pitch, packed, split, scratch, max_wg, st, &e);
+    const int rc = gf_run_conv(x, n, cin, cout, relu, roff, ent, pitch, packed, split, scratch, max_wg, st, &e, done_word, step_id);
     if (rc != NF_OK) return rc;
     e.bias_c = bias_conv; e.bias_d = bias_dense; e.residual = residual; e.out = out; e.out_relu = out_relu;
     e.pos = pos; e.pos_new = pos_new; e.pos_c = pos_c; e.vel_c = vel_c; e.scale = scale; e.dt = dt;
@@ -969,8 +988,10 @@ extern "C" int nf_trans_step(const nf_trans_step_t* s, const float* pos, const f
     if (rc != NF_OK) return rc;
     // every layer reads relu(previous layer) (models/transmodel.py:124): the producers of a0 / a1 / a2 store the activated
     // values (a0r, a1r, a2r), a1 itself is kept for conv2's residual
-    rc = nf_cconv_gf_layer(s->a0, s->n, 96, 64, 0, s->roff, s->ent, s->pitch_f, s->wp1, s->split, s->bc1, s->bd1, nullptr, s->a1, s->a1r, s->scratch,
-                           s->max_wg, nullptr, nullptr, 0.f, 0.f, nullptr, nullptr, stream);
+    // (the completion word the host spins on is written by the FIRST layer's launch as it starts: the front of the step — both searches
+    // and their overflow words — is complete then; a last-workgroup protocol at the end of the front kernel cost that kernel ~2 us)
+    rc = gf_layer(s->a0, s->n, 96, 64, 0, s->roff, s->ent, s->pitch_f, s->wp1, s->split, s->bc1, s->bd1, nullptr, s->a1, s->a1r, s->scratch,
+                  s->max_wg, nullptr, nullptr, 0.f, 0.f, nullptr, nullptr, stream, host_flag3 ? host_flag3 + 2 : nullptr, step_id);
     if (rc != NF_OK) return rc;
     // conv2's output is read by conv3 only (a 64 -> 3 layer has no residual): it never goes to global memory
     rc = nf_cconv_gf_layer_g3(s->a1r, s->n, 64, 0, s->roff, s->ent, s->pitch_f, s->wp2, s->split, s->bc2, s->bd2, s->a1, nullptr, nullptr,

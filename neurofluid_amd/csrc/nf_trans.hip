@@ -907,7 +907,7 @@ __device__ __forceinline__ void tf_body_rows(const TfArgs& A, const TfLds& L, in
 // the completion word: the LAST workgroup of the launch to arrive writes step_id into the pinned host word
 __device__ __forceinline__ void tf_arrive(const TfArgs& A, unsigned total)
 {
-    if (!A.host_flag) return;
+    if (!A.host_flag || !A.done_ctr) return;
     __syncthreads();
     if (threadIdx.x == 0) {
         // (this workgroup's overflow words, if it raised any, were followed by their own system-scope fence; the arrival itself is
@@ -1488,7 +1488,8 @@ int nf_trans_stage12(const nf_trans_step_t* s, const float* pos, const float* ve
     A.counts2 = s->counts2; A.num_nbrs = num_nbrs; A.idx_f = s->idx_f; A.d2_f = s->d2_f; A.roff = s->roff; A.ent = s->ent;
     A.k_fluid = s->k_fluid; A.b_fluid = s->b_fluid; A.k_obst = s->k_obst; A.b_obst = s->b_obst;
     A.dense_w = s->dense0_w; A.dense_b = s->dense0_b; A.a0 = s->a0; A.overflow2 = (unsigned long long*)s->overflow2;
-    A.host_flag = (volatile int*)host_flag3; A.done_ctr = s->done_counter; A.step_id = step_id;
+    // (no completion protocol in these launches: nf_trans_step's first layer raises the word when it starts)
+    A.host_flag = (volatile int*)host_flag3; A.done_ctr = nullptr; A.step_id = step_id;
     if (all_pairs) {
         tb_launch(S, A, (hipStream_t)stream);
         NF_CHECK_LAUNCH();

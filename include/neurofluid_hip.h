@@ -449,6 +449,15 @@ int nf_adam_step(int count, float* const* params /*[host]*/, const float* const*
                  const float* bc2_sqrt /*[host]*/, double beta1, double beta2 /* (1 - beta) is formed in double, as torch forms its scalars */,
                  float eps, float weight_decay, nf_stream_t stream);
 
+/* The loss of the end-to-end training step (trainer/trainer_e2e.py:264-280; trainer/basetrainer.py:108-116, :136 for the boundary
+ * term) and its gradients for a unit upstream gradient, ONE launch:
+ *   loss = (sum (rgb0 - rgb)^2 [+ sum (rgb1 - rgb)^2]) / denom + w_boundary * mean |pos - clamp(pos, lo, hi)|
+ * n_rgb values per colour array (views x rays x 3), denom = values per view (the views' MSE means share it); rgb1 / g_rgb1 NULL: no
+ * fine pass; n_points = 0: no boundary term.  lo / hi: [host]. */
+int nf_e2e_loss(const float* rgb0, const float* rgb1 /*or NULL*/, const float* rgb, int n_rgb, int denom, const float* pos /*(n_points, 3)*/,
+                int n_points, const float lo[3] /*[host]*/, const float hi[3] /*[host]*/, float w_boundary, float* loss /*[1]*/,
+                float* g_rgb0, float* g_rgb1 /*or NULL*/, float* g_pos, nf_stream_t stream);
+
 typedef struct {
     /* model (device pointers; wpK = nf_cconv_gf_pack of convK / denseK) */
     const float *k_fluid, *b_fluid, *k_obst, *b_obst, *dense0_w, *dense0_b;

@@ -135,6 +135,8 @@ PROTOTYPES = {
                                 c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "nf_adam_step": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_double, ctypes.c_double,
                              c_float, c_float, c_void_p]),
+    "nf_e2e_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_float,
+                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nf_trans_step": (c_int, [ctypes.POINTER(TransStep), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                               c_void_p]),
 }

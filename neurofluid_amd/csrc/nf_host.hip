@@ -154,3 +154,58 @@ extern "C" int nf_adam_step(int count, float* const* params, const float* const*
     NF_CHECK_LAUNCH();
     return NF_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// The loss of the end-to-end training step (trainer/trainer_e2e.py:264-280) and its gradients in ONE launch:
+//     loss = ( sum (rgb0 - rgb)^2 [+ sum (rgb1 - rgb)^2] ) / denom  +  w_boundary * mean | pos - clamp(pos, lo, hi) |
+// (the views of a step are equally sized, so the sum of their MSE means is one sum over one denominator; the boundary term is
+// basetrainer.py:108-116's per-axis clamp under an L1 mean).  As torch ops this chain and its autograd backward were ~35 launches of
+// 3-9 us in a 3.2 ms step.  One workgroup: 12 k colour values and 15 k coordinates are nothing to reduce.
+// Outputs: the loss and the gradients for a unit upstream gradient (the caller scales them).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_e2e_loss(const float* __restrict__ rgb0, const float* __restrict__ rgb1, const float* __restrict__ rgb,
+                                                   int n_rgb, float inv_denom, const float* __restrict__ pos, int n_pos3, float lo0, float lo1,
+                                                   float lo2, float hi0, float hi1, float hi2, float wb, float* __restrict__ loss,
+                                                   float* __restrict__ g_rgb0, float* __restrict__ g_rgb1, float* __restrict__ g_pos)
+{
+    __shared__ float s_a[16], s_b[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    float acc = 0.f, accb = 0.f;
+    for (int i = tid; i < n_rgb; i += 1024) {
+        const float t = rgb[i];
+        const float d0 = rgb0[i] - t;
+        acc += d0 * d0;
+        g_rgb0[i] = 2.f * d0 * inv_denom;
+        if (rgb1) { const float d1 = rgb1[i] - t; acc += d1 * d1; g_rgb1[i] = 2.f * d1 * inv_denom; }
+    }
+    const float inv_n = n_pos3 > 0 ? 1.f / (float)n_pos3 : 0.f;
+    for (int i = tid; i < n_pos3; i += 1024) {
+        const int d = i % 3;
+        const float l = d == 0 ? lo0 : (d == 1 ? lo1 : lo2), h = d == 0 ? hi0 : (d == 1 ? hi1 : hi2);
+        const float p = pos[i], dp = p - fminf(fmaxf(p, l), h);
+        accb += fabsf(dp);
+        g_pos[i] = (dp > 0.f ? 1.f : (dp < 0.f ? -1.f : 0.f)) * (wb * inv_n);
+    }
+    acc = nf_wave_sum(acc); accb = nf_wave_sum(accb);
+    if (lane == 0) { s_a[wv] = acc; s_b[wv] = accb; }
+    __syncthreads();
+    if (tid == 0) {
+        float a = 0.f, b = 0.f;
+        for (int w = 0; w < 16; ++w) { a += s_a[w]; b += s_b[w]; }
+        *loss = a * inv_denom + wb * (b * inv_n);
+    }
+}
+
+extern "C" int nf_e2e_loss(const float* rgb0, const float* rgb1, const float* rgb, int n_rgb, int denom, const float* pos, int n_points,
+                           const float lo[3], const float hi[3], float w_boundary, float* loss, float* g_rgb0, float* g_rgb1, float* g_pos,
+                           nf_stream_t stream)
+{
+    NF_CHECK_ARG(rgb0 && rgb && loss && g_rgb0 && (!rgb1 || g_rgb1) && n_rgb >= 0 && denom > 0, "bad colour arguments");
+    NF_CHECK_ARG(n_points >= 0 && (n_points == 0 || (pos && lo && hi && g_pos)), "bad position arguments");
+    hipLaunchKernelGGL(k_e2e_loss, dim3(1), dim3(1024), 0, (hipStream_t)stream, rgb0, rgb1, rgb, n_rgb, 1.f / (float)denom, pos, 3 * n_points,
+                       n_points ? lo[0] : 0.f, n_points ? lo[1] : 0.f, n_points ? lo[2] : 0.f, n_points ? hi[0] : 0.f, n_points ? hi[1] : 0.f,
+                       n_points ? hi[2] : 0.f, w_boundary, loss, g_rgb0, g_rgb1, g_pos);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}

@@ -3,6 +3,8 @@ for each of the 4 warm-up views sample `ray_chunk` random pixels of frame 0 (cen
 `precrop_iters` steps, trainer/basetrainer.py:171-193), render them from the GT particles, loss = sum over views
 of MSE(rgb0) + MSE(rgb1); zero_grad / backward / Adam / ExponentialLR (utils/lr_schedulers.py:3-12).
 Used by bench.py --workload train and by the Trainer in neurofluid_amd/trainers.py."""
+import ctypes
+
 import numpy as np
 import torch
 
@@ -252,6 +254,46 @@ def summed_view_mse(out, rgbs, n_views, fine):
     if fine:
         tot = tot + torch.nn.functional.mse_loss(out["rgb1"], rgbs, reduction="sum")
     return tot / denom
+
+
+class _E2ELossFn(torch.autograd.Function):
+    """loss = summed_view_mse(rgb0 [, rgb1]) + w_boundary * L1(pos, clamp(pos, lo, hi)) (trainer/trainer_e2e.py:264-280) as ONE launch
+    (nf_e2e_loss, csrc/nf_host.hip) that also leaves the gradients for a unit upstream gradient; backward scales them.  The chain of
+    torch ops it replaces — two mse_loss, the clamp / sub / abs / mean of the boundary term, the adds, and their ~20 autograd nodes —
+    was ~35 launches of 3-9 us in a 3.2 ms step."""
+
+    @staticmethod
+    def forward(ctx, rgb0, rgb1, rgbs, pos, lo, hi, wb, denom):
+        from . import _lib
+        lib = _lib.load()
+        rgb0c, rgbsc = rgb0.contiguous(), rgbs.contiguous()
+        rgb1c = None if rgb1 is None else rgb1.contiguous()
+        posc = None if pos is None else pos.contiguous()
+        loss = torch.empty(1, dtype=torch.float32, device=rgb0.device)
+        g0 = torch.empty_like(rgb0c)
+        g1 = None if rgb1c is None else torch.empty_like(rgb1c)
+        gp = None if posc is None else torch.empty_like(posc)
+        f3 = ctypes.c_float * 3
+        ptr = lambda t: 0 if t is None else t.data_ptr()        # noqa: E731
+        _lib.check(lib.nf_e2e_loss(ptr(rgb0c), ptr(rgb1c), ptr(rgbsc), rgb0c.numel(), int(denom), ptr(posc),
+                                   0 if posc is None else posc.shape[0], f3(*[float(v) for v in lo]), f3(*[float(v) for v in hi]), float(wb),
+                                   loss.data_ptr(), ptr(g0), ptr(g1), ptr(gp), _lib.stream()), "nf_e2e_loss")
+        ctx.g = (g0, g1, gp)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        g0, g1, gp = ctx.g
+        return g0 * g, (None if g1 is None else g1 * g), None, (None if gp is None else gp * g), None, None, None, None
+
+
+def e2e_loss(out, rgbs, n_views, fine, pos=None, bounds=None, w_boundary=0.0):
+    """The end-to-end step's loss: sum over views of MSE(rgb0_v) [+ MSE(rgb1_v)] + w_boundary * mean |pos - clamp(pos, bounds)|
+    (equally sized views).  GPU tensors only (the HIP entry point); `bounds` = ((lo_x, lo_y, lo_z), (hi_x, hi_y, hi_z))."""
+    use_pos = pos is not None and w_boundary != 0.0
+    lo, hi = bounds if use_pos else ((0.0, 0.0, 0.0), (0.0, 0.0, 0.0))
+    return _E2ELossFn.apply(out["rgb0"], out["rgb1"] if fine else None, rgbs, pos if use_pos else None, lo, hi, w_boundary if use_pos else 0.0,
+                            rgbs.numel() // n_views)
 
 
 class PixelSampler:

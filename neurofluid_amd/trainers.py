@@ -21,7 +21,7 @@ from .point_eval import FluidErrors
 from .render_loop import render_image as _render_image
 from .renderer import RenderNet
 from .train_step import (ExponentialLR, PixelSampler, random_sample_coords, _upload, choice_without_replacement, gather_view_pixels,
-                         make_adam, summed_view_mse, portable_optimizer_state, load_optimizer_state)
+                         make_adam, summed_view_mse, e2e_loss, portable_optimizer_state, load_optimizer_state)
 from .transmodel import ParticleNet, PairCapacityExceeded
 
 to8b = lambda x: (255 * np.clip(x, 0, 1)).astype(np.uint8)   # noqa: E731  trainer/basetrainer.py:16
@@ -322,7 +322,10 @@ class RendererTrainer(BaseTrainer):
                                             [data['cw'][v] for v in range(view_num)], coords, sels, H, W)
         out = self.renderer(data['particles_pos'], ro, rays, None, None)
         fine = self.renderer.N_importance > 0
-        if type(self.rgb_criterion) is torch.nn.MSELoss and self.rgb_criterion.reduction == 'mean':
+        std_rgb = type(self.rgb_criterion) is torch.nn.MSELoss and self.rgb_criterion.reduction == 'mean'
+        if std_rgb and rgbs.is_cuda:
+            return e2e_loss(out, rgbs, view_num, fine)          # the views' MSE sums and their gradients in one launch
+        if std_rgb:
             total = summed_view_mse(out, rgbs, view_num, fine)
         else:
             total = 0.
@@ -483,7 +486,14 @@ class E2ETrainer(BaseTrainer):
                                             [data['cw_1'][v] for v in range(view_num)], coords, sels, H, W)
         out = self.renderer(pred_pos, ro, rays, None, None)
         fine = self.renderer.N_importance > 0
-        if type(self.rgb_criterion) is torch.nn.MSELoss and self.rgb_criterion.reduction == 'mean':
+        wb = self.options.TRAIN.loss_weight['boundary_loss']
+        std_rgb = type(self.rgb_criterion) is torch.nn.MSELoss and self.rgb_criterion.reduction == 'mean'
+        std_l1 = type(self.L1_criterion) is torch.nn.L1Loss and self.L1_criterion.reduction == 'mean'
+        if std_rgb and std_l1 and rgbs.is_cuda and pred_pos.dim() == 2 and pred_pos.dtype == torch.float32:
+            # the whole loss and its gradients in one launch (train_step.e2e_loss); the criteria of the reference's configuration
+            return e2e_loss(out, rgbs, view_num, fine, pred_pos, ((self.x_bound[1], self.y_bound[1], self.z_bound[1]),
+                                                                 (self.x_bound[0], self.y_bound[0], self.z_bound[0])), wb)
+        if std_rgb:
             total = summed_view_mse(out, rgbs, view_num, fine)
         else:
             total = 0.
@@ -492,7 +502,6 @@ class E2ETrainer(BaseTrainer):
                 total = total + self.rgb_criterion(out['rgb0'][sl], rgbs[sl])
                 if fine:
                     total = total + self.rgb_criterion(out['rgb1'][sl], rgbs[sl])
-        wb = self.options.TRAIN.loss_weight['boundary_loss']
         if wb != 0.:
             total = total + self.cal_boundary_loss(pred_pos) * wb
         return total

@@ -241,3 +241,47 @@ def test_hip_adam_matches_torch_adam():
     before = [x.detach().clone() for x in pa]
     oa2.step()
     assert all(torch.equal(a, b.detach()) for a, b in zip(before, pa))
+
+
+@pytest.mark.gpu
+def test_fused_e2e_loss_matches_torch_ops():
+    """train_step.e2e_loss (nf_e2e_loss: the end-to-end step's loss and its gradients in one launch) against the torch expression
+    it replaces — the reference's own: sum over views of MSELoss(rgb0_v) + MSELoss(rgb1_v) + w * L1Loss(pos, clip(pos))
+    (trainer/trainer_e2e.py:264-280, trainer/basetrainer.py:108-116): loss to 1e-6 relative, every gradient to 1e-6 of its scale
+    (one-pass fp32 sums in a different order), an upstream gradient other than 1 included; without the fine pass and without the
+    boundary term too."""
+    from neurofluid_amd.train_step import e2e_loss
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    V, R = 3, 257
+    lo, hi = (-0.975, -0.975, -0.975), (0.975, 0.975, 2.4302)
+    for fine, wb in ((True, 0.3), (False, 0.3), (True, 0.0)):
+        rgb0 = torch.rand(V * R, 3, generator=g).to(dev).requires_grad_(True)
+        rgb1 = torch.rand(V * R, 3, generator=g).to(dev).requires_grad_(True)
+        rgbs = torch.rand(V * R, 3, generator=g).to(dev)
+        pos = ((torch.rand(4913, 3, generator=g) - 0.5) * 2.2 + torch.tensor([0.0, 0.0, 0.7])).to(dev).requires_grad_(True)
+        out = {"rgb0": rgb0, "rgb1": rgb1}
+        loss = e2e_loss(out, rgbs, V, fine, pos, (lo, hi), wb)
+        (loss * 1.7).backward()
+        got = [loss.detach().clone(), rgb0.grad.clone(), rgb1.grad.clone() if fine else None, pos.grad.clone() if wb else None]
+        for t in (rgb0, rgb1, pos):
+            t.grad = None
+        ref = 0.
+        for v in range(V):
+            sl = slice(v * R, (v + 1) * R)
+            ref = ref + torch.nn.functional.mse_loss(rgb0[sl], rgbs[sl])
+            if fine:
+                ref = ref + torch.nn.functional.mse_loss(rgb1[sl], rgbs[sl])
+        if wb:
+            clipped = torch.clamp(pos, torch.tensor(lo, device=dev), torch.tensor(hi, device=dev))
+            ref = ref + torch.nn.functional.l1_loss(pos, clipped) * wb
+        (ref * 1.7).backward()
+        assert abs(float(got[0]) - float(ref)) <= 1e-6 * abs(float(ref))
+        assert float((got[1] - rgb0.grad).abs().max()) <= 1e-6 * float(rgb0.grad.abs().max())
+        if fine:
+            assert float((got[2] - rgb1.grad).abs().max()) <= 1e-6 * float(rgb1.grad.abs().max())
+        else:
+            assert rgb1.grad is None
+        if wb:
+            assert float((pos.grad != 0).float().mean()) > 0.01            # some particles are outside the box
+            assert float((got[3] - pos.grad).abs().max()) <= 1e-6 * float(pos.grad.abs().max())

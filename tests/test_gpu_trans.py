@@ -845,3 +845,40 @@ def test_fused_step_all_pairs_search_equals_grid_search_and_oracle(dev):
         nns = pk.conv0_fluid.nns
         r0 = nns.neighbors_index[: int(nns.neighbors_row_splits[1])].tolist()
         assert sorted(r0) == kat.FIXED_RADIUS_EXPECTED_IGNORE, mode
+
+
+def test_fused_step_search_at_the_all_pairs_limit(dev):
+    """The all-pairs search at its largest cloud (nf_trans_all_pairs_max_points() particles: the largest LDS footprint of
+    k_trans_stage1b, chunk bounds for 64 chunks) and one particle beyond it, where "auto" must take the cell grid: neighbour
+    counts, row splits, index rows and squared distances against the C oracle on the integrated positions (rows sorted for the
+    grid's cell order), for a random cloud at the fluid's density inside the container."""
+    from neurofluid_amd import _lib
+    from oracle import neighbors as onb
+    from oracle import trans_oracle as to
+    box, bn = [t.to(dev) for t in to.watercube_box()]
+    nmax = _lib.load().nf_trans_all_pairs_max_points()
+    g = torch.Generator().manual_seed(11)
+    for n, expect in ((nmax, 2), (nmax + 1, 1), (130, 2)):
+        side = (n * 0.05 ** 3) ** (1.0 / 3.0)
+        P = ((torch.rand(n, 3, generator=g) - 0.5) * side + torch.tensor([0.0, 0.0, 0.2])).to(dev)
+        V = torch.zeros_like(P)
+        pn, _ = make_pn(dev)
+        with torch.no_grad():
+            _, _, nn_ = pn(P, V, box, bn)
+        assert pn._fused is not None, "the fused step must serve this cloud"
+        # (auto resolves inside the library: nf_trans_step_t.search == 0; which path ran shows in the row order)
+        nns = pn.conv0_fluid.nns
+        rs = nns.neighbors_row_splits.cpu().numpy()
+        vn = V + pn.gravity.to(dev) * pn.time_step
+        q = (P + (V + vn) / 2 * pn.time_step).cpu().numpy()
+        oi, ors, od2 = onb.fixed_radius_search(q, q, 0.5 * float(pn.filter_extent), True)
+        assert np.array_equal(ors, rs) and np.array_equal(nn_.cpu().numpy(), (ors[1:] - ors[:-1]).astype(np.float32))
+        idx = nns.neighbors_index[: int(rs[-1])].cpu().numpy().astype(np.int64)
+        d2 = nns.neighbors_distance[: int(rs[-1])].cpu().numpy()
+        rows = np.repeat(np.arange(n), rs[1:] - rs[:-1])
+        if expect == 2:                                     # all pairs: ascending index, element by element
+            assert np.array_equal(idx, oi) and np.array_equal(d2, od2)
+        else:                                               # cell grid: the same sets (and distances) in cell order
+            order = np.lexsort((idx, rows))
+            assert np.array_equal(idx[order], oi) and np.array_equal(d2[order], od2)
+            assert not np.array_equal(idx, oi)

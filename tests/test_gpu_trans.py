@@ -452,6 +452,16 @@ def test_gfree_conv_layer_vs_oracle_and_transform_gather(dev):
                                  ptr(counts2), ptr(nn), ptr(idx_f), ptr(d2_f), ptr(roff), ptr(ent), *[ptr(t) for t in args0], ptr(a0),
                                  0, ptr(ovf), None, None, 0, _lib.stream()), "nf_trans_front")
         assert ovf.tolist() == [0, 0]
+        # the stand-alone entry point's completion word (the fused step raises its word from the first layer's launch instead): the LAST
+        # workgroup writes step_id into the pinned word and leaves the device counter at rest; same outputs
+        flag = torch.zeros(4, dtype=i32).pin_memory()
+        done = torch.zeros(1, dtype=i32, device=dev)
+        a0b = torch.empty_like(a0)
+        check(lib.nf_trans_front(ptr(fgrid.ws), ptr(bgrid.ws), ptr(Pd), ptr(feats4), ptr(bnd), n, radius, extent, 1, pitch_f, pitch_b,
+                                 ptr(counts2), ptr(nn), ptr(idx_f), ptr(d2_f), ptr(roff), ptr(ent), *[ptr(t) for t in args0], ptr(a0b),
+                                 0, ptr(ovf), lib.nf_pinned_device_ptr(flag.data_ptr()), ptr(done), 77, _lib.stream()), "nf_trans_front")
+        torch.cuda.synchronize()
+        assert flag.tolist() == [0, 0, 77, 0] and int(done) == 0 and torch.equal(a0b, a0)
         # ---- the search and layer 0 against the oracle
         f_idx, f_rs, f_d2 = to.radius_search(P, P, radius, True)
         b_idx, b_rs, b_d2 = to.radius_search(box, P, radius, True)

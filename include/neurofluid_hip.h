@@ -128,7 +128,9 @@ int nf_render_search(const void* grid_ws, const float* rays, const float* z, con
 /* A3 + A4 + A5: local-geometry features + positional encodings for every active row, written in
  * the MLP operand layout X[tile][q][lane][4] (tile = row/32; lane = 32*h + row%32; float e of
  * group q holds feature 8q+4h+e; pos-like features first (padded to 8*QX), then dir-like (8*QD)).
- * enc_flags: bit0 density, bit1 smoothed_pos, bit2 var, bit3 smoothed_dir (models/renderer.py:30-44). */
+ * enc_flags: bit0 density, bit1 smoothed_pos, bit2 var, bit3 smoothed_dir (models/renderer.py:30-44); bit4 =
+ * encoding.exclude_ray=False (models/renderer.py:100-106: the smoothed position is ray_pos * (1 - alpha) + weighted_nn * alpha,
+ * alpha = 0.9, or 0.1 where num_nn <= 20), bit5 (with bit4) = encoding.same_smooth_factor (alpha = 0.9 everywhere). */
 int nf_render_features(const float* particles /*Np*3*/, const float* rays, const float* z, const float* z_table,
                        int R, int S, float radius, int K, int enc_flags,
                        const float* ro /*3, or R*3 when ro_per_ray (several views batched in one call)*/, int ro_per_ray,

@@ -25,6 +25,13 @@ def _stale(target, deps):
 
 def build(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
+    import fcntl
+    with open(os.path.join(LIBDIR, ".build.lock"), "w") as lock:      # one builder at a time (ranks starting together)
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        return _build_locked(force, verbose)
+
+
+def _build_locked(force, verbose):
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "neurofluid_hip.h"))
     objs = []
@@ -48,12 +55,6 @@ def build(force=False, verbose=False):
             if verbose:
                 print(" ".join(cmd))
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-    # leftovers of removed sources / of `llvm-objdump --offloading` runs in this directory must not ship with the package
-    keep = set(objs) | {o + ".cmd" for o in objs} | {LIB}
-    for f in os.listdir(LIBDIR):
-        fp = os.path.join(LIBDIR, f)
-        if fp not in keep and (f.endswith(".o") or f.endswith(".o.cmd") or ".o." in f):
-            os.remove(fp)
     failed = False
     for src, p in procs:
         out, _ = p.communicate()
@@ -64,6 +65,14 @@ def build(force=False, verbose=False):
             print(out.decode())
     if failed:
         raise RuntimeError("hipcc failed")
+    # leftovers of removed sources / of `llvm-objdump --offloading` runs in this directory must not ship with the package.
+    # Only after every compile job has finished, and never the compiler's own temporaries (`name-XXXX.o.tmp`): another process
+    # building at the same moment (several ranks finding a stale library) must not lose its outputs mid-compile.
+    keep = set(objs) | {o + ".cmd" for o in objs} | {LIB}
+    for f in os.listdir(LIBDIR):
+        fp = os.path.join(LIBDIR, f)
+        if fp not in keep and not f.endswith(".tmp") and (f.endswith(".o") or f.endswith(".o.cmd") or ".hipv4-" in f or ".host-" in f):
+            os.remove(fp)
     for stamp, text in stamps:
         with open(stamp, "w") as f:
             f.write(text)

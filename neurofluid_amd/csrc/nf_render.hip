@@ -410,7 +410,7 @@ k_features(const float* __restrict__ particles, const float* __restrict__ rays,
                                                   const float* __restrict__ z, const float* __restrict__ z_table, int S,
                                                   float radius, int K, const float* __restrict__ ro_base, int ro_stride,
                                                   const int* __restrict__ row_sample, const int* __restrict__ row_nbr,
-                                                  const int* __restrict__ n_rows, int max_rows, void* __restrict__ X)
+                                                  const int* __restrict__ n_rows, int max_rows, void* __restrict__ X, int blend)
 {
     constexpr int CX = 63 + ((FLAGS & 1) ? 9 : 0) + ((FLAGS & 2) ? 63 : 0) + ((FLAGS & 4) ? 63 : 0);
     constexpr int CD = 27 + ((FLAGS & 8) ? 27 : 0);
@@ -464,6 +464,14 @@ k_features(const float* __restrict__ particles, const float* __restrict__ rays,
         }
         float den = sw + 1e-12f;
         float sm[3] = {swx / den, swy / den, swz / den};
+        if (blend) {
+            // encoding.exclude_ray=False (models/renderer.py:100-106): pos = ray_pos * (1 - alpha) + weighted_nn * alpha with
+            // alpha = 0.9, or 0.1 where num_nn <= 20 (the literal of :105) unless same_smooth_factor (blend == 2);
+            // (1 - alpha) is the fp32 difference torch forms, the sum is mul, mul, add (no FMA: -ffp-contract=off)
+            const float alpha = (blend == 2 || nvalid > 20) ? 0.9f : 0.1f, oma = 1.f - alpha;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) sm[c] = px[c] * oma + sm[c] * alpha;
+        }
         float nn_f = (float)nvalid + 1e-12f;
         float mean[3] = {sx / nn_f, sy / nn_f, sz / nn_f};
         float var[3] = {0.f, 0.f, 0.f};
@@ -511,7 +519,9 @@ extern "C" int nf_render_features(const float* particles, const float* rays, con
                                   void* X, int x_fp16, nf_stream_t stream)
 {
     NF_CHECK_ARG(particles && rays && (z || z_table) && ro && row_sample && row_nbr && n_rows && X, "null pointer");
-    NF_CHECK_ARG(enc_flags >= 0 && enc_flags < 16, "bad enc_flags");
+    NF_CHECK_ARG(enc_flags >= 0 && enc_flags < 64 && (enc_flags >> 4) != 2, "bad enc_flags");
+    const int blend = (enc_flags & 16) ? ((enc_flags & 32) ? 2 : 1) : 0;       // exclude_ray=False [, same_smooth_factor]
+    enc_flags &= 15;
     if (x_fp16) {
         int qx = 0, qd = 0;
         nf_render_feature_dims(enc_flags, nullptr, nullptr, &qx, &qd);
@@ -527,16 +537,16 @@ extern "C" int nf_render_features(const float* particles, const float* rays, con
     case F:                                                                                                          \
         if (x_fp16 && k20)                                                                                           \
             hipLaunchKernelGGL((k_features<F, true, 20>), dim3(blocks), dim3(128), 0, st, particles, rays, z, z_table, S, radius, \
-                               K, ro, ro_per_ray ? 3 : 0, row_sample, row_nbr, n_rows, max_rows, X);                 \
+                               K, ro, ro_per_ray ? 3 : 0, row_sample, row_nbr, n_rows, max_rows, X, blend);               \
         else if (x_fp16)                                                                                             \
             hipLaunchKernelGGL((k_features<F, true, 0>), dim3(blocks), dim3(128), 0, st, particles, rays, z, z_table, S, radius, \
-                               K, ro, ro_per_ray ? 3 : 0, row_sample, row_nbr, n_rows, max_rows, X);                 \
+                               K, ro, ro_per_ray ? 3 : 0, row_sample, row_nbr, n_rows, max_rows, X, blend);               \
         else if (k20)                                                                                                \
             hipLaunchKernelGGL((k_features<F, false, 20>), dim3(blocks), dim3(128), 0, st, particles, rays, z, z_table, S, radius, \
-                               K, ro, ro_per_ray ? 3 : 0, row_sample, row_nbr, n_rows, max_rows, X);                 \
+                               K, ro, ro_per_ray ? 3 : 0, row_sample, row_nbr, n_rows, max_rows, X, blend);               \
         else                                                                                                         \
             hipLaunchKernelGGL((k_features<F, false, 0>), dim3(blocks), dim3(128), 0, st, particles, rays, z, z_table, S, radius, \
-                               K, ro, ro_per_ray ? 3 : 0, row_sample, row_nbr, n_rows, max_rows, X);                 \
+                               K, ro, ro_per_ray ? 3 : 0, row_sample, row_nbr, n_rows, max_rows, X, blend);               \
         break;
     switch (enc_flags) {
         NF_FEAT_CASE(0) NF_FEAT_CASE(1) NF_FEAT_CASE(2) NF_FEAT_CASE(3) NF_FEAT_CASE(4) NF_FEAT_CASE(5) NF_FEAT_CASE(6)
@@ -1492,7 +1502,7 @@ __global__ void __launch_bounds__(128) k_features_bwd(const float* __restrict__ 
                                                       int ro_stride, const int* __restrict__ row_sample,
                                                       const int* __restrict__ row_nbr, const int* __restrict__ n_rows,
                                                       int max_rows, const float* __restrict__ dX /*row-major*/,
-                                                      float* __restrict__ dparticles)
+                                                      float* __restrict__ dparticles, int blend)
 {
     constexpr int CX = 63 + ((FLAGS & 1) ? 9 : 0) + ((FLAGS & 2) ? 63 : 0) + ((FLAGS & 4) ? 63 : 0);
     constexpr int CD = 27 + ((FLAGS & 8) ? 27 : 0);
@@ -1523,7 +1533,15 @@ __global__ void __launch_bounds__(128) k_features_bwd(const float* __restrict__ 
             if (valid) { sd[0] += d[0]; sd[1] += d[1]; sd[2] += d[2]; ++nvalid; }
         }
         const float den = sw + 1e-12f, nn_f = (float)nvalid + 1e-12f;
-        float sm[3] = {swp[0] / den, swp[1] / den, swp[2] / den};
+        const float smw[3] = {swp[0] / den, swp[1] / den, swp[2] / den};      // weighted neighbour mean
+        // exclude_ray=False (k_features): the encoded position is ray_pos * (1 - alpha) + smw * alpha; d smw = alpha * d pos
+        const float alpha = blend ? ((blend == 2 || nvalid > 20) ? 0.9f : 0.1f) : 1.f;
+        float sm[3] = {smw[0], smw[1], smw[2]};
+        if (blend) {
+            const float oma = 1.f - alpha;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) sm[c] = px[c] * oma + smw[c] * alpha;
+        }
         float mean[3] = {sd[0] / nn_f, sd[1] / nn_f, sd[2] / nn_f};
         float var[3] = {0.f, 0.f, 0.f}, resid[3] = {0.f, 0.f, 0.f};
         if (FLAGS & 4)
@@ -1550,9 +1568,10 @@ __global__ void __launch_bounds__(128) k_features_bwd(const float* __restrict__ 
 #pragma unroll
             for (int c = 0; c < 3; ++c) d_sm[c] += (d_sdir[c] - sdir[c] * dot) / nu;
         }
-        // sm = N / den, density = sw
+        // smw = N / den, density = sw
+        if (blend) { d_sm[0] *= alpha; d_sm[1] *= alpha; d_sm[2] *= alpha; }
         float dN[3] = {d_sm[0] / den, d_sm[1] / den, d_sm[2] / den};
-        float d_sw = d_den - (d_sm[0] * sm[0] + d_sm[1] * sm[1] + d_sm[2] * sm[2]) / den;
+        float d_sw = d_den - (d_sm[0] * smw[0] + d_sm[1] * smw[1] + d_sm[2] * smw[2]) / den;
         // ---- scatter to the neighbours
         for (int k = 0; k < K; ++k) {
             int j = row_nbr[(size_t)row * K + k];
@@ -1598,7 +1617,7 @@ __global__ void __launch_bounds__(256) k_features_bwd_w(const float* __restrict_
                                                         int ro_stride, const int* __restrict__ row_sample,
                                                         const int* __restrict__ row_nbr, const int* __restrict__ n_rows,
                                                         int max_rows, const float* __restrict__ dX /*row-major*/,
-                                                        float* __restrict__ dparticles)
+                                                        float* __restrict__ dparticles, int blend)
 {
     constexpr int CX = 63 + ((FLAGS & 1) ? 9 : 0) + ((FLAGS & 2) ? 63 : 0) + ((FLAGS & 4) ? 63 : 0);
     constexpr int CD = 27 + ((FLAGS & 8) ? 27 : 0);
@@ -1635,7 +1654,14 @@ __global__ void __launch_bounds__(256) k_features_bwd_w(const float* __restrict_
         const float sd[3] = {wave_sum(valid ? d[0] : 0.f), wave_sum(valid ? d[1] : 0.f), wave_sum(valid ? d[2] : 0.f)};
         const int nvalid = __popcll(__ballot(valid));
         const float den = sw + 1e-12f, nn_f = (float)nvalid + 1e-12f;
-        const float sm[3] = {swp[0] / den, swp[1] / den, swp[2] / den};
+        const float smw[3] = {swp[0] / den, swp[1] / den, swp[2] / den};
+        const float alpha = blend ? ((blend == 2 || nvalid > 20) ? 0.9f : 0.1f) : 1.f;   // exclude_ray=False, see k_features_bwd
+        float sm[3] = {smw[0], smw[1], smw[2]};
+        if (blend) {
+            const float oma = 1.f - alpha;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) sm[c] = px[c] * oma + smw[c] * alpha;
+        }
         const float mean[3] = {sd[0] / nn_f, sd[1] / nn_f, sd[2] / nn_f};
         float var[3] = {0.f, 0.f, 0.f}, resid[3] = {0.f, 0.f, 0.f};
         if (FLAGS & 4) {
@@ -1681,8 +1707,9 @@ __global__ void __launch_bounds__(256) k_features_bwd_w(const float* __restrict_
 #pragma unroll
             for (int c = 0; c < 3; ++c) d_sm[c] += (d_sdir[c] - sdir[c] * dot) / nu;
         }
+        if (blend) { d_sm[0] *= alpha; d_sm[1] *= alpha; d_sm[2] *= alpha; }
         const float dN[3] = {d_sm[0] / den, d_sm[1] / den, d_sm[2] / den};
-        const float d_sw = d_den - (d_sm[0] * sm[0] + d_sm[1] * sm[1] + d_sm[2] * sm[2]) / den;
+        const float d_sw = d_den - (d_sm[0] * smw[0] + d_sm[1] * smw[1] + d_sm[2] * smw[2]) / den;
         // ---- scatter: lane k -> neighbour k
         if (j >= 0) {
             const float dw = dN[0] * n[0] + dN[1] * n[1] + dN[2] * n[2] + d_sw;
@@ -1708,7 +1735,9 @@ extern "C" int nf_render_features_bwd(const float* particles, const float* rays,
 {
     NF_CHECK_ARG(particles && rays && (z || z_table) && ro && row_sample && row_nbr && n_rows && dX && dparticles,
                  "null pointer");
-    NF_CHECK_ARG(enc_flags >= 0 && enc_flags < 16, "bad enc_flags");
+    NF_CHECK_ARG(enc_flags >= 0 && enc_flags < 64 && (enc_flags >> 4) != 2, "bad enc_flags");
+    const int blend = (enc_flags & 16) ? ((enc_flags & 32) ? 2 : 1) : 0;
+    enc_flags &= 15;
     if (max_rows <= 0) return NF_OK;
     int blocks = (max_rows + 127) / 128;
     if (blocks > 4096) blocks = 4096;
@@ -1719,10 +1748,10 @@ extern "C" int nf_render_features_bwd(const float* particles, const float* rays,
     case F:                                                                                                             \
         if (K <= 64)                                                                                                    \
             hipLaunchKernelGGL(k_features_bwd_w<F>, dim3(blocks_w), dim3(256), 0, st, particles, rays, z, z_table, S, radius, \
-                               K, ro, ro_per_ray ? 3 : 0, row_sample, row_nbr, n_rows, max_rows, dX, dparticles);       \
+                               K, ro, ro_per_ray ? 3 : 0, row_sample, row_nbr, n_rows, max_rows, dX, dparticles, blend); \
         else                                                                                                            \
             hipLaunchKernelGGL(k_features_bwd<F>, dim3(blocks), dim3(128), 0, st, particles, rays, z, z_table, S, radius, K, \
-                               ro, ro_per_ray ? 3 : 0, row_sample, row_nbr, n_rows, max_rows, dX, dparticles);           \
+                               ro, ro_per_ray ? 3 : 0, row_sample, row_nbr, n_rows, max_rows, dX, dparticles, blend);    \
         break;
     switch (enc_flags) {
         NF_FB_CASE(0) NF_FB_CASE(1) NF_FB_CASE(2) NF_FB_CASE(3) NF_FB_CASE(4) NF_FB_CASE(5) NF_FB_CASE(6) NF_FB_CASE(7)

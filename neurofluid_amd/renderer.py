@@ -45,8 +45,6 @@ class RenderNet(nn.Module):
             raise ValueError("RENDERER.mlp_dtype must be fp32, fp16 or split")
         if not self.fix_radius:
             raise NotImplementedError("fix_radius=False is dead code in the reference (models/renderer.py:119-121)")
-        if not _get(cfg, "encoding.exclude_ray", True):
-            raise NotImplementedError("encoding.exclude_ray=False is not on the hot path (configs/*.yaml use True)")
         self.embedding_xyz = Embedding(3, 10)
         self.embedding_dir = Embedding(3, 4)
         in_xyz, in_dir = self.embedding_xyz.out_channels, self.embedding_dir.out_channels
@@ -64,6 +62,9 @@ class RenderNet(nn.Module):
         if _get(cfg, "encoding.smoothed_dir"):
             in_dir += self.embedding_dir.out_channels
             self.enc_flags |= 8
+        if not _get(cfg, "encoding.exclude_ray", True):
+            # models/renderer.py:100-106: the smoothed position is blended with the ray position (k_features' `blend`)
+            self.enc_flags |= 16 | (32 if _get(cfg, "encoding.same_smooth_factor", False) else 0)
         self.in_channels_xyz, self.in_channels_dir = in_xyz, in_dir
         self.nerf_coarse = NeRF(in_channels_xyz=in_xyz, in_channels_dir=in_dir)
         self.nerf_fine = NeRF(in_channels_xyz=in_xyz, in_channels_dir=in_dir)

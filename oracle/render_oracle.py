@@ -134,19 +134,30 @@ def search(ray_particles, particles, radius, K):
     """models/renderer.py:112-122: the reference replicates the particle cloud once per ray and
     calls pytorch3d ball_query; every ray sees the same cloud, so one flat query is identical."""
     R, S, _ = ray_particles.shape
-    d, i, nn = neighbors.ball_query_firstk(ray_particles.reshape(-1, 3).numpy(), particles.numpy(), radius, K)
-    return (torch.from_numpy(d).view(R, S, K), torch.from_numpy(i).view(R, S, K),
-            torch.from_numpy(nn).view(R, S, K, 3))
+    d, i, nn = neighbors.ball_query_firstk(ray_particles.detach().reshape(-1, 3).numpy(), particles.detach().numpy(), radius, K)
+    d, i, nn = torch.from_numpy(d).view(R, S, K), torch.from_numpy(i).view(R, S, K), torch.from_numpy(nn).view(R, S, K, 3)
+    if particles.requires_grad:
+        # e2e training (A12): the indices are data, `nn` a differentiable gather of the cloud (the same values, bit for bit)
+        nn = torch.where((i >= 0).unsqueeze(-1), particles[i.clamp(min=0)], torch.zeros(1))
+    return d, i, nn
 
 
 # ----------------------------------------------------------------------------------------------
 # A3 / A4  local geometry features
 # ----------------------------------------------------------------------------------------------
-def smoothing_position(ray_pos, nn_poses, radius):
-    """models/renderer.py:96-109 with exclude_ray=True (configs/warmup.yaml:44)."""
+def smoothing_position(ray_pos, nn_poses, radius, num_nn=None, exclude_ray=True, same_smooth_factor=False,
+                       larger_alpha=0.9, smaller_alpha=0.1):
+    """models/renderer.py:96-109.  exclude_ray=True (configs/warmup.yaml:44): the weighted neighbour mean; False (:100-106):
+    the ray position blended with it, alpha = 0.9, or 0.1 where `num_nn.le(20)` (the literal 20 of :105, whatever K is)
+    unless same_smooth_factor.  Pinned by tests/golden/cfg_incl_ray*.npz."""
     dists = torch.norm(nn_poses - ray_pos.unsqueeze(-2), dim=-1)
     w = torch.clamp(1 - (dists / radius) ** 3, min=0)
     pos = (w.unsqueeze(-1) * nn_poses).sum(-2) / (w.sum(-1, keepdim=True) + 1e-12)
+    if not exclude_ray:
+        alpha = torch.ones(ray_pos.shape[0], ray_pos.shape[1], 1) * larger_alpha
+        if not same_smooth_factor:
+            alpha[num_nn.le(20)] = smaller_alpha
+        pos = ray_pos * (1 - alpha) + pos * alpha
     return pos, w.sum(-1, keepdim=True)
 
 
@@ -164,7 +175,8 @@ def embedding_local_geometry(dists, neighbors_xyz, radius, ray_particles, rays, 
     num_nn = nn_mask.sum(-1, keepdim=True)
     pos_feats = [embed(ray_particles.reshape(-1, 3), 10)]
     dir_feats = [torch.repeat_interleave(embed(rays[:, 3:], 4), repeats=S, dim=0)]
-    smoothed, density = smoothing_position(ray_particles, neighbors_xyz, radius)
+    smoothed, density = smoothing_position(ray_particles, neighbors_xyz, radius, num_nn, cfg.get("exclude_ray", True),
+                                           cfg.get("same_smooth_factor", False))
     sdir = particle_direction(smoothed.reshape(-1, 3), ro)
     if cfg["density"]:
         pos_feats.append(embed(density.reshape(-1, 1), 4))

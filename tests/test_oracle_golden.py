@@ -195,3 +195,54 @@ def test_ball_query_fp_contraction_sensitivity():
         res2 = onb.ball_query_contraction_sensitivity(P, pts, r2_, 1 << 20, inclusive=True)
         print("fixed-radius search, mul+add vs FMA-contracted d2:", res2)
         assert res2["flipped_pairs"] == 0
+
+
+# ------------------------------------------------------------------------------------------------
+# non-default renderer configurations (tests/golden/gen_golden_configs.py: the reference's own forward + autograd)
+# ------------------------------------------------------------------------------------------------
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+from gen_golden_configs import VARIANTS, oracle_cfg      # noqa: E402  (the variant table only; nothing of /root/reference)
+
+
+@pytest.mark.parametrize("name", sorted(VARIANTS))
+def test_config_variants_forward_and_autograd(golden, name):
+    """Every encoding ablation (models/renderer.py:30-44, :141-175), N_neighbor 8 / 32, other sample counts and the three
+    exclude_ray=False branches (:100-106): the oracle's forward dict vs the reference's, and torch autograd through the
+    oracle (loss, every parameter's gradient norm, dL/d particles through the differentiable gather) vs the reference's."""
+    g = golden("cfg_" + name)
+    cfg = oracle_cfg(name)
+    st = {k: v.clone().requires_grad_(True) for k, v in ro.deterministic_nerf_state(cfg=cfg).items()}
+    P = ro.watercube_particles().clone().requires_grad_(True)
+    rays, tgt = T(g["rays"]), T(g["target"])
+    out = ro.render_forward(st, P, T(g["ro"]), rays, 9.0, 13.0, cfg)
+    keys_i = ["num_nn_0", "mask_0"] + (["num_nn_1", "mask_1"] if cfg["N_importance"] > 0 else [])
+    keys_f = ["rgb0", "depth0", "opacity0"] + (["rgb1", "depth1", "opacity1"] if cfg["N_importance"] > 0 else [])
+    assert ("rgb1" in g) == (cfg["N_importance"] > 0) == ("rgb1" in out)
+    for k in keys_i:
+        assert torch.equal(out[k], T(g[k])), k
+    for k in keys_f:
+        torch.testing.assert_close(out[k].detach(), T(g[k]), rtol=0, atol=2e-6, msg=k)
+    loss = torch.nn.functional.mse_loss(out["rgb0"], tgt)
+    if "rgb1" in out:
+        loss = loss + torch.nn.functional.mse_loss(out["rgb1"], tgt)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-6
+    n = 0
+    for key, ref in g.items():
+        if key.startswith("gnorm__"):
+            got = float(st[key[len("gnorm__"):].replace("__", ".")].grad.norm())
+            assert abs(got - float(ref)) <= 1e-4 * float(ref) + 1e-9, (key, got, float(ref))
+            n += 1
+    assert n == (48 if cfg["N_importance"] > 0 else 24)
+    dP, ref = (P.grad if P.grad is not None else torch.zeros_like(P)), T(g["dparticles"])
+    if name == "plain":
+        assert not ref.any() and not dP.any()        # no particle-dependent feature left: only the mask sees the cloud
+    else:
+        assert float((dP - ref).norm() / ref.norm()) < 1e-4
+    # the variants must differ from the default configuration where they are meant to
+    assert float(out["mask_0"].max()) > 3

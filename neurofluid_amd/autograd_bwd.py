@@ -328,10 +328,15 @@ class _TransGraphs:
         self.serial = 0
 
 
-def _tg_key(pn, n, box, box_feats):
+def _tg_key(pn, n, box, box_feats, bgrid, bbox):
+    """Everything a captured launch sequence has baked in: sizes, capacities, every storage pointer it reads — the container
+    grid's WORKSPACE included: ParticleNet._box_cache holds one entry, a call on another container replaces it, and a graph
+    captured against the old workspace would be replayed on freed memory when training resumes with the first container —
+    and the host scalars that travel as kernel arguments (time step, filter extent, the scene box)."""
     caps = pn.__dict__.get("_pair_caps", {}).get(n)
     return (n, caps, box.data_ptr(), box._version, box.shape[0], box_feats.data_ptr(), box_feats._version, bool(pn.use_window),
-            tuple(p.data_ptr() for p in _pn_params(pn)), pn.gravity._version)
+            tuple(p.data_ptr() for p in _pn_params(pn)), pn.gravity._version, bgrid.ws.data_ptr(),
+            float(pn.time_step), float(pn.filter_extent), tuple(float(v) for v in bbox))
 
 
 def particle_net_graphed(pn, pos, vel, box, box_feats):
@@ -353,8 +358,8 @@ def _tg_prepare(pn, pos, vel, box, box_feats):
     """The graphs of this (cloud size, capacities, scene, parameter storage), captured on first use."""
     tg = pn.__dict__.setdefault("_tgraphs", _TransGraphs())
     n, dev = pos.shape[0], pos.device
-    pn._scene_bbox(box); pn._box_grid(box)                       # caches filled OUTSIDE any capture (they may sync)
-    key = _tg_key(pn, n, box, box_feats)
+    bbox, bgrid = pn._scene_bbox(box), pn._box_grid(box)         # caches filled OUTSIDE any capture (they may sync)
+    key = _tg_key(pn, n, box, box_feats, bgrid, bbox)
     if tg.key == key:
         return tg
     tg.key, tg.bwd = None, {}
@@ -362,7 +367,7 @@ def _tg_prepare(pn, pos, vel, box, box_feats):
     tg.pos_s, tg.vel_s = torch.empty(n, 3, device=dev), torch.empty(n, 3, device=dev)
     tg.tot_pinned = torch.zeros(2, dtype=torch.int32).pin_memory()
     tg.ev = torch.cuda.Event()
-    tg.box, tg.box_feats = box, box_feats                        # pins the storages the graphs read
+    tg.box, tg.box_feats, tg.bgrid = box, box_feats, bgrid       # pins the storages the graphs read (incl. the grid workspace)
     tg.total_fluid = lambda: _tg_totals(tg)[0]
     cap_state = {"tot_pinned": tg.tot_pinned, "total_fluid": lambda: tg.total_fluid()}
     tg.pos_s.copy_(pos.detach()); tg.vel_s.copy_(vel.detach())

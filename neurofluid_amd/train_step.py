@@ -69,6 +69,16 @@ class HipAdam(torch.optim.Adam):
                     return False
         return True
 
+    def state_dict(self):
+        """The parameters of a group share ONE `step` tensor object here; written out as is, torch.save keeps the aliasing and a
+        plain torch.optim.Adam (the reference's trainer) that loads the file advances the shared counter once per PARAMETER.
+        Every parameter gets its own copy in the dict, as torch.optim.Adam writes it."""
+        sd = super().state_dict()
+        for st in sd["state"].values():
+            if torch.is_tensor(st.get("step")):
+                st["step"] = st["step"].detach().clone()
+        return sd
+
     @torch.no_grad()
     def step(self, closure=None):
         import ctypes

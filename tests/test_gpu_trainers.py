@@ -235,6 +235,19 @@ def test_hip_adam_matches_torch_adam():
     load_optimizer_state(ob2, sda)
     run(3, oa2, ob2, pa, pb)
     assert float(oa2.state[pa[0]]["step"]) == 9.0
+    # the RAW state_dict() (no portable_optimizer_state): every parameter has its own `step` tensor — HipAdam shares one object per
+    # group internally, and an aliased counter in a checkpoint makes a plain Adam advance it once per parameter — so a
+    # torch.optim.Adam that loads the raw dict through a torch.save round trip takes ONE step per step
+    import io
+    raw = oa2.state_dict()
+    assert len({id(st["step"]) for st in raw["state"].values()}) == len(raw["state"])
+    buf = io.BytesIO(); torch.save(raw, buf); buf.seek(0)
+    ob3 = torch.optim.Adam(groups(pb), betas=(0.9, 0.999), eps=1e-8, foreach=False, fused=False)
+    ob3.load_state_dict(torch.load(buf, weights_only=False))
+    for y in pb:
+        y.grad = torch.zeros_like(y)
+    ob3.step()
+    assert all(float(ob3.state[y]["step"]) == 10.0 for y in pb)
     # a parameter without a gradient is skipped, like torch does
     for x in pa:
         x.grad = None

@@ -171,6 +171,15 @@ int nf_nerf_pack_stream(const float* packed, int cx, int cd, float* wstream, nf_
 int nf_nerf_mlp_fwd_l(const float* packed, const float* wstream, int cx, int cd, const float* X,
                       const int32_t* n_rows, int max_rows, const int32_t* row_sample, float* rgbsigma,
                       nf_stream_t stream);
+/* The same computation, hand-scheduled (nf_mlp_a.hip: the kernel body is one asm statement generated by gen_mlp_a.py).  Its weight
+ * stream carries no padding slots (nf_nerf_pack_stream_a / nf_nerf_stream_a_floats: 1 312 slots of 2 KB for 198 + 54 features);
+ * results are bit-identical to nf_nerf_mlp_fwd_l (same K order, bias as the last K-step, the heads' mul/add order and the compiler's
+ * expansion of 1 / (1 + expf(-c))).  Inference, default encodings only. */
+size_t nf_nerf_stream_a_floats(int cx, int cd);
+int nf_nerf_pack_stream_a(const float* packed, int cx, int cd, float* wstream, nf_stream_t stream);
+int nf_nerf_mlp_fwd_a(const float* packed, const float* wstream, int cx, int cd, const float* X,
+                      const int32_t* n_rows, int max_rows, const int32_t* row_sample, float* rgbsigma, nf_stream_t stream);
+
 
 /* A6 for small launches (models/nerf.py:83-124, the forward of a training step; nf_mlp_n.hip): one 32-row tile per WORKGROUP, a layer's 8 output blocks split over its 4 waves,
  * activations exchanged through an LDS image — a quarter of nf_nerf_mlp_fwd's per-tile latency (it keeps a tile in one

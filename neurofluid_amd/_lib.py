@@ -67,6 +67,9 @@ PROTOTYPES = {
     "nf_nerf_stream_floats": (c_size_t, [c_int, c_int]),
     "nf_nerf_pack_stream": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "nf_nerf_mlp_fwd_l": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "nf_nerf_stream_a_floats": (c_size_t, [c_int, c_int]),
+    "nf_nerf_pack_stream_a": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "nf_nerf_mlp_fwd_a": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "nf_nerf_packed_h2_bytes": (c_size_t, []),
     "nf_nerf_pack_h2": (c_int, [ctypes.POINTER(NerfParams), c_int, c_int, c_void_p, c_void_p]),
     "nf_nerf_mlp_fwd_h2": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libneurofluid_hip.so")
-SOURCES = ["nf_grid.hip", "nf_render.hip", "nf_mlp.hip", "nf_mlp_l.hip", "nf_mlp_n.hip", "nf_mlp_h2.hip", "nf_mlp_s.hip", "nf_cconv.hip", "nf_cconv_gf.hip", "nf_trans.hip", "nf_host.hip", "nf_metrics.hip", "nf_embed.hip", "nf_gemm.hip"]
+SOURCES = ["nf_grid.hip", "nf_render.hip", "nf_mlp.hip", "nf_mlp_l.hip", "nf_mlp_a.hip", "nf_mlp_n.hip", "nf_mlp_h2.hip", "nf_mlp_s.hip", "nf_cconv.hip", "nf_cconv_gf.hip", "nf_trans.hip", "nf_host.hip", "nf_metrics.hip", "nf_embed.hip", "nf_gemm.hip"]
 # per-file flags.  nf_mlp_h2.hip: MFMA accumulators in VGPRs (the finished blocks are converted by VALU instructions,
 # which cannot read AGPRs: AGPR accumulators cost 16 v_accvgpr_read per block and tile)
 EXTRA_FLAGS = {"nf_mlp_h2.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "nf_mlp_s.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
@@ -31,8 +31,20 @@ def build(force=False, verbose=False):
         return _build_locked(force, verbose)
 
 
+# generated sources: (generator script, output) — the body of nf_mlp_a.hip's asm statement is written by gen_mlp_a.py
+GENERATED = [("gen_mlp_a.py", "nf_mlp_a_body.inc")]
+
+
+def _generate():
+    for gen, out in GENERATED:
+        gp, op = os.path.join(CSRC, gen), os.path.join(CSRC, out)
+        if _stale(op, [gp]):
+            subprocess.check_call([sys.executable, gp, op], stderr=subprocess.DEVNULL)
+
+
 def _build_locked(force, verbose):
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    _generate()
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h") or f.endswith(".inc")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "neurofluid_hip.h"))
     objs = []
     procs = []

@@ -311,7 +311,11 @@ __global__ void __launch_bounds__(256) k_mlp_fwd_l(NfMlpLayout L, const float* _
         // layer 0 = xyz_encoding_1
         l_xpart8<0, true>(c, xt, xs, accA);
         l_bias8(c, accA);
+#ifdef NF_L_UNROLL
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
         for (int l = 1; l < 9; l += 2) {
             l_hpart8<true>(c, accA, accB);
             l_bias8(c, accB);

@@ -7,6 +7,7 @@ These are the operator boundaries of SURVEY §8b:
 All tensors must be CUDA (ROCm) fp32/int tensors; torch only provides memory and the stream.
 """
 import ctypes
+import os
 import math
 
 import torch
@@ -262,15 +263,31 @@ def pack_nerf_n(packed, cx, cd):
     return out
 
 
-def pack_nerf_stream(packed, cx, cd):
-    """Weight stream of the LDS-ring fp32 kernel (nf_nerf_mlp_fwd_l) from the packed blob, or None when the feature
-    row is not the default 198 + 54 one (the direct-from-L2 kernel nf_nerf_mlp_fwd then serves the pass)."""
+# which LDS-ring kernel serves the fp32 inference passes: "a" = hand-scheduled (nf_mlp_a.hip, generated asm), "l" = the
+# compiler-scheduled one (nf_mlp_l.hip).  Bit-identical results; the streams differ (no padding slots in "a").
+RING_KERNEL = os.environ.get("NF_RING_KERNEL", "l")
+
+
+def pack_nerf_stream(packed, cx, cd, kind=None):
+    """Weight stream of the LDS-ring fp32 kernels (nf_nerf_mlp_fwd_a / _l) from the packed blob, or None when the feature
+    row is not the default 198 + 54 one (the direct-from-L2 kernel nf_nerf_mlp_fwd then serves the pass).  The tensor carries
+    the kernel it was packed for (`nf_kind`)."""
     if ((cx + 7) // 8, (cd + 7) // 8) != (25, 7):
         return None
+    kind = kind or RING_KERNEL
     lib = _lib.load()
-    out = torch.empty(lib.nf_nerf_stream_floats(cx, cd), dtype=torch.float32, device=packed.device)
-    check(lib.nf_nerf_pack_stream(ptr(packed), cx, cd, ptr(out), _lib.stream()), "nf_nerf_pack_stream")
+    if kind == "a":
+        out = torch.empty(lib.nf_nerf_stream_a_floats(cx, cd), dtype=torch.float32, device=packed.device)
+        check(lib.nf_nerf_pack_stream_a(ptr(packed), cx, cd, ptr(out), _lib.stream()), "nf_nerf_pack_stream_a")
+    else:
+        out = torch.empty(lib.nf_nerf_stream_floats(cx, cd), dtype=torch.float32, device=packed.device)
+        check(lib.nf_nerf_pack_stream(ptr(packed), cx, cd, ptr(out), _lib.stream()), "nf_nerf_pack_stream")
+    out.nf_kind = kind
     return out
+
+
+def _ring_fwd(lib, wstream):
+    return (lib.nf_nerf_mlp_fwd_a, "nf_nerf_mlp_fwd_a") if getattr(wstream, "nf_kind", "l") == "a" else (lib.nf_nerf_mlp_fwd_l, "nf_nerf_mlp_fwd_l")
 
 
 class PackedH2:
@@ -489,8 +506,8 @@ def render_pass(grid, particles, rays, z, z_table, S, radius, K, enc_flags, use_
         elif packed_h is not None:
             raise RuntimeError("unknown fp16 weight stream (expected PackedH2 or PackedS)")
         elif wstream is not None and not save_acts:      # fp32, weight stream shared through LDS (inference)
-            check(lib.nf_nerf_mlp_fwd_l(ptr(packed), ptr(wstream), cx, cd, X_, ptr(nrows_t), mx, rs_, ptr(b.rgbsigma), stream_),
-                  "nf_nerf_mlp_fwd_l")
+            fn, name = _ring_fwd(lib, wstream)
+            check(fn(ptr(packed), ptr(wstream), cx, cd, X_, ptr(nrows_t), mx, rs_, ptr(b.rgbsigma), stream_), name)
         elif save_acts and (qx, qd) == (25, 7):
             # training forward (activations saved; launches of a few hundred to a few thousand tiles): a tile per WORKGROUP
             # (nf_mlp_n.hip) — a third of the per-tile latency of the tile-per-wave kernel, bit-identical outputs.  (The
@@ -661,8 +678,8 @@ def mlp_rows(packed, cx, cd, x, save_acts=False, packed_h=None, wstream=None):
             return out
         raise RuntimeError("unknown fp16 weight stream (expected PackedH2 or PackedS)")
     if wstream is not None:
-        check(lib.nf_nerf_mlp_fwd_l(ptr(packed), ptr(wstream), cx, cd, ptr(X), ptr(n_rows), n, ptr(row_sample), ptr(out),
-                                    _lib.stream()), "nf_nerf_mlp_fwd_l")
+        fn, name = _ring_fwd(lib, wstream)
+        check(fn(ptr(packed), ptr(wstream), cx, cd, ptr(X), ptr(n_rows), n, ptr(row_sample), ptr(out), _lib.stream()), name)
         return out
     check(lib.nf_nerf_mlp_fwd(ptr(packed), cx, cd, ptr(X), ptr(n_rows), n, ptr(row_sample), ptr(out), ptr(acts),
                               _lib.stream()), "nf_nerf_mlp_fwd")

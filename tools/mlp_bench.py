@@ -67,3 +67,37 @@ if len(sys.argv) > 3 and sys.argv[3] == "split":
         print(f"split iter {it}: rows {n} {ms:.3f} ms  {n*1331968/ms/1e9:.1f} TFLOP/s fp32-equivalent ({3*n*1331968/ms/1e9:.0f} TFLOP/s of fp16 MFMA)")
     err = (out2 - out).abs()
     print("split max abs err rgb", float(err[:, :3].max()), "sigma", float(err[:, 3].max()), "sigma scale", float(out[:, 3].abs().max()))
+if len(sys.argv) > 3 and sys.argv[3] == "asm":
+    # hand-scheduled kernel (nf_mlp_a.hip) vs the compiler-scheduled ring kernel: must be bit-identical
+    ws = torch.empty(lib.nf_nerf_stream_floats(198, 54), dtype=torch.float32, device=dev)
+    check(lib.nf_nerf_pack_stream(ptr(packed), 198, 54, ptr(ws), _lib.stream()))
+    wa = torch.empty(lib.nf_nerf_stream_a_floats(198, 54), dtype=torch.float32, device=dev)
+    check(lib.nf_nerf_pack_stream_a(ptr(packed), 198, 54, ptr(wa), _lib.stream()))
+    out3 = torch.zeros(n, 4, device=dev)
+    out4 = torch.full((n, 4), 7.0, device=dev)
+    for name, fn, w, o in (("ring", lib.nf_nerf_mlp_fwd_l, ws, out3), ("asm", lib.nf_nerf_mlp_fwd_a, wa, out4)):
+        for it in range(iters):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            check(fn(ptr(packed), ptr(w), 198, 54, ptr(X), ptr(n_rows), n, ptr(row_sample), ptr(o), _lib.stream()))
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1)
+            print(f"{name} iter {it}: rows {n} {ms:.3f} ms  {n*1331968/ms/1e9:.1f} TFLOP/s", flush=True)
+    err = (out4 - out3).abs()
+    print("asm vs ring: max abs err rgb", float(err[:, :3].max()), "sigma", float(err[:, 3].max()), "bit-equal", bool(torch.equal(out3, out4)),
+          "rows differing", int((err.max(1)[0] > 0).sum()))
+    bad = torch.nonzero(err.max(1)[0] > 0).flatten()[:8].tolist()
+    for r in bad:
+        print(" row", r, out3[r].tolist(), out4[r].tolist())
+    if len(sys.argv) > 4:
+        eq = (err.max(1)[0] == 0)
+        for t0 in (0, 32, 64, 96, 128, 32 * 1024, 32 * 2048):
+            print("tile", t0 // 32, "".join("1" if bool(e) else "." for e in eq[t0:t0 + 32].tolist()),
+                  " sigma finite", "".join("1" if bool(e) else "x" for e in torch.isfinite(out4[t0:t0 + 32, 3]).tolist()))
+        print("equal rows per tile (first 16 tiles):", eq[:512].view(16, 32).sum(1).tolist())
+        per_tile = eq.view(-1, 32).sum(1)
+        print("fully equal tiles:", int((per_tile == 32).sum()), "of", per_tile.numel(), " partially:", int(((per_tile > 0) & (per_tile < 32)).sum()))
+        full = torch.nonzero(per_tile == 32).flatten()
+        print("first equal tiles:", full[:20].tolist(), " last:", full[-5:].tolist())
+        print("equal tiles by (tile % 4):", [int((per_tile.view(-1, 4)[:, w] == 32).sum()) for w in range(4)])
+        print("equal tiles by round:", [int((per_tile[r * 1024:(r + 1) * 1024] == 32).sum()) for r in range(per_tile.numel() // 1024)])

@@ -16,12 +16,24 @@ every instruction of the tile body placed by this script instead of by the compi
 Output: a C string literal (one "...\\n" line per instruction) included by nf_mlp_a.hip as the body of ONE asm statement.
 Usage: python gen_mlp_a.py [out.inc]      (neurofluid_amd/build.py runs it before compiling nf_mlp_a.hip)
 """
+import os
 import sys
+
+
+def knob(name, default=0):
+    """A/B switches of the schedule (tools/ab_mlp_a.py); the shipped kernel is the all-defaults build."""
+    return int(os.environ.get("NF_A_" + name, default))
+
 
 QX, QD = 25, 7                 # feature groups of 8 (198 + 54 features padded to 200 + 56)
 CH = 8                         # slots per chunk
 SLOT_B, CHUNK_B = 2048, 16384
-RING_B = 3 * CHUNK_B
+# PIPEPUB (default): the four 1 KB pieces a wave owns of chunk k + 1 are published ONE PER SLOT in slots 0..3 of chunk k (each
+# behind the load that brought it in during chunk k - 1, and in front of the load that refills its staging quad with chunk
+# k + 2), instead of four stores per wave right behind the rendezvous.  The chunk being published is the NEXT one, so two
+# chunks of LDS are enough, the ring phase is the chunk parity (164 chunks per tile: even) and no address register rotates.
+PIPEPUB = knob("PIPEPUB", 1)
+RING_B = (2 if PIPEPUB else 3) * CHUNK_B
 STASH_B = QX * 1024            # per wave
 HW_BASE = RING_B + 4 * STASH_B  # head weights in LDS: sigma [2][128] floats, then rgb [3][2][64]
 LDS_BYTES = HW_BASE + 1024 + 1536
@@ -120,6 +132,15 @@ def long_branch_scc1(p, target):
     p.i(f"s_addc_u32 s{S_TMP + 1}, s{S_TMP + 1}, ({target}-.Lnf_a_pc{n}_%=)>>32")
     p.i(f"s_setpc_b64 {sp(S_TMP)}")
     p.i(f".Lnf_a_skip{n}_%=:")
+
+
+VBR = list(range(192, 200)) + list(range(226, 234))      # B-operand registers of the hidden parts: the sigma head's weight quads
+#                                                           and the sigmoid temporaries, both idle between layer 0 and the view branch
+
+
+def vb_reg(k):
+    rb = knob("RELU_BATCH", 4)
+    return VBR[((k // rb) & 1) * rb + k % rb]
 
 
 def mfma(dst, a, b, c):
@@ -258,7 +279,7 @@ def gen():
     p.i(f"s_ashr_i32 s{S_NGROUPS}, s{S_NGROUPS}, 2")
     # ring: chunks 0 and 1 in place, chunk 2 is fetched during chunk 0
     p.i(f"s_mov_b64 {sp(S_WCUR)}, {sp(S_WBASE)}")
-    for c in range(2):
+    for c in range(1 if PIPEPUB else 2):
         for q in range(4):
             p.i(f"global_load_dwordx4 v[{ST + 4 * q}:{ST + 4 * q + 3}], v{V_WOFF}, {sp(S_WCUR)} offset:{1024 * q}")
         p.i(f"s_add_u32 s{S_WCUR}, s{S_WCUR}, {CHUNK_B}")
@@ -279,6 +300,11 @@ def gen():
     p.i(f"ds_read_b128 v[{P[0]}:{P[0] + 3}], v{V_T0}")
     p.i(f"ds_read_b128 v[{P[0] + 4}:{P[0] + 7}], v{V_T0} offset:1024")
     p.vmem(f"global_load_dwordx4 v[{XV[0]}:{XV[0] + 3}], v{V_LANE16}, {sp(S_XNEXT)} nt", "x0")
+    if PIPEPUB:                 # chunk 1 rides in the staging quads (published during chunk 0), as at every later tile start
+        for q in range(4):
+            p.vmem(f"global_load_dwordx4 v[{ST + 4 * q}:{ST + 4 * q + 3}], v{V_WOFF}, {sp(S_WCUR)} offset:{1024 * q}", f"w{q}")
+        p.i(f"s_add_u32 s{S_WCUR}, s{S_WCUR}, {CHUNK_B}")
+        p.i(f"s_addc_u32 s{S_WCUR + 1}, s{S_WCUR + 1}, 0")
     p.i(".Lnf_a_tile_%=:")
 
     # ------------------------------------------------------------------ per-tile scalar setup
@@ -299,8 +325,11 @@ def gen():
     rgb_items = rgb_head_items()
     sig_items = sigma_head_items()
     fill_plan = {}                                   # slot idx -> list of (gap, [instr])
-    place_fillers(slots, [s.idx for s in slots if s.kind == "x" and s.layer == 0], rgb_items, fill_plan, p)
-    place_fillers(slots, [s.idx for s in slots if s.kind in ("vx", "vh")][:-2], sig_items, fill_plan, p)
+    skipb = knob("FILL_SKIP_BOUNDARY")
+    ok = lambda s: not (skipb and s.idx % CH == CH - 1)        # noqa: E731
+    if not knob("NOHEADS"):
+        place_fillers(slots, [s.idx for s in slots if s.kind == "x" and s.layer == 0 and ok(s)], rgb_items, fill_plan, p)
+        place_fillers(slots, [s.idx for s in slots if s.kind in ("vx", "vh") and ok(s)][:-2], sig_items, fill_plan, p)
 
     # ------------------------------------------------------------------ the slots
     for n, s in enumerate(slots):
@@ -441,7 +470,7 @@ def place_fillers(slots, idxs, items, plan, p):
         nonlocal cur
         while True:
             gaps = (2, 3) if kind == "lds" else (4, 5, 6, 7)
-            cap = 1 if kind == "lds" else 2
+            cap = 1 if kind == "lds" else knob("VALU_CAP", 2)
             for g in gaps:
                 if used.get((cur, g), 0) < cap:
                     used[(cur, g)] = used.get((cur, g), 0) + 1
@@ -472,8 +501,9 @@ def emit_slot(p, slots, n, fillers, nchunks):
     pre = []
 
     # ---- operands of THIS slot are ready: LDS reads of the previous slot, X registers
-    pre.append("s_waitcnt lgkmcnt(0)")
-    if s.kind == "x" and s.layer == 0 and s.k % 4 == 0:
+    if not knob("NOLGKM"):
+        pre.append("s_waitcnt lgkmcnt(0)")
+    if s.kind == "x" and s.layer == 0 and s.k % 4 == 0 and not knob("XNOWAIT"):
         pre.append(lambda pp: pp.wait_vm("x0" if s.k == 0 else f"x{s.k // 4}"))
     if s.kind == "vx" and s.k == 0:
         pre.append(lambda pp: pp.wait_vm(f"d{QD - 1}"))
@@ -486,7 +516,7 @@ def emit_slot(p, slots, n, fillers, nchunks):
         if s.kind == "x":
             bop = f"v{XV[(s.k // 4) & 1] + (s.k & 3)}"
         elif s.kind == "h":
-            bop = f"v{VB[s.k & 1]}"
+            bop = f"v{vb_reg(s.k)}"
         else:
             bop = f"v{V_ONE}"
         for b in range(8):
@@ -507,7 +537,10 @@ def emit_slot(p, slots, n, fillers, nchunks):
 
     # ---- the NEXT slot's A operands (issued early: complete at the next slot's lgkmcnt(0))
     boundary = pos == CH - 1
-    if boundary:
+    if PIPEPUB:
+        o = (((chunk + 1) & 1) * CHUNK_B) if boundary else ((chunk & 1) * CHUNK_B + (pos + 1) * SLOT_B)
+        rd = [f"ds_read_b128 v[{An}:{An + 3}], v{V_LANE16} offset:{o}", f"ds_read_b128 v[{An + 4}:{An + 7}], v{V_LANE16} offset:{o + 1024}"]
+    elif boundary:
         rd = [f"ds_read_b128 v[{An}:{An + 3}], v{V_T1}", f"ds_read_b128 v[{An + 4}:{An + 7}], v{V_T1} offset:1024"]
     else:
         o = (pos + 1) * SLOT_B
@@ -517,35 +550,60 @@ def emit_slot(p, slots, n, fillers, nchunks):
     if pos < 4:
         def fetch(pp, q=pos):
             return p_vmem(pp, f"global_load_dwordx4 v[{ST + 4 * q}:{ST + 4 * q + 3}], v{V_WOFF}, {sp(S_WCUR)} offset:{1024 * q}", f"w{q}")
-        gap[3].append(fetch)
+        if PIPEPUB and not knob("NOPUB"):
+            # this wave's piece `pos` of the NEXT chunk: landed (requested one chunk ago), into the other half of the ring
+            gap[knob("PUB_GAP", 2)].append(lambda pp, q=pos: pp.wait_vm(f"w{q}"))
+            gap[knob("PUB_GAP", 2)].append(f"ds_write_b128 v{V_WOFF}, v[{ST + 4 * pos}:{ST + 4 * pos + 3}] "
+                                           f"offset:{((chunk + 1) & 1) * CHUNK_B + 1024 * pos}")
+        if not knob("NOFETCH"):
+            gap[3].append(fetch)
         if pos == 3:
             if chunk == nchunks - 3:        # chunk + 2 was the stream's last: the next refill starts over (the next tile's chunk 0)
                 gap[3].append(f"s_mov_b64 {sp(S_WCUR)}, {sp(S_WBASE)}")
             else:
                 gap[3] += [f"s_add_u32 s{S_WCUR}, s{S_WCUR}, {CHUNK_B}", f"s_addc_u32 s{S_WCUR + 1}, s{S_WCUR + 1}, 0"]
-    if boundary:
-        gap[0].append(lambda pp: pp.wait_vm("w3"))
-        gap[0].append("s_barrier")
-        gap[0] += rd
-        gap[1].append(f"v_add_u32 v{V_PUB}, v{V_T2}, v{V_WAVE4K}")
-        for q in range(4):
-            gap[1 + q].append(f"ds_write_b128 v{V_PUB}, v[{ST + 4 * q}:{ST + 4 * q + 3}] offset:{1024 * q}")
+    if knob("NOREADS"):
+        rd = []
+    if boundary and PIPEPUB:
+        bg = knob("BAR_GAP", 0)
+        if not knob("NOBAR"):
+            gap[bg].append("s_barrier")           # chunk + 1 is complete and visible; everybody is done with this chunk's half
+        gap[bg] += rd
+    elif boundary:
+        bg = knob("BAR_GAP", 0)
+        gap[bg].append(lambda pp: pp.wait_vm("w3"))
+        if not knob("NOBAR"):
+            gap[bg].append("s_barrier")
+        gap[bg] += rd
+        gap[bg + 1].append(f"v_add_u32 v{V_PUB}, v{V_T2}, v{V_WAVE4K}")
+        if not knob("NOPUB"):
+            for q in range(4):
+                gap[bg + 1 + q].append(f"ds_write_b128 v{V_PUB}, v[{ST + 4 * q}:{ST + 4 * q + 3}] offset:{1024 * q}")
         gap[6] += [f"v_mov_b32 v{V_TMP}, v{V_T0}", f"v_mov_b32 v{V_T0}, v{V_T1}", f"v_mov_b32 v{V_T1}, v{V_T2}",
                    f"v_mov_b32 v{V_T2}, v{V_TMP}"]
-    else:
-        gap[0].append(rd[0])
-        gap[1].append(rd[1])
+    elif rd:
+        gap[knob("RD0_GAP", 0)].append(rd[0])
+        gap[knob("RD1_GAP", 1)].append(rd[1])
 
-    # ---- the NEXT slot's B operand
-    if nxt.kind == "h":
-        b, r = divmod(nxt.k, 16)
-        k = 16 * b + r
-        tgt = VB[nxt.k & 1]
-        g = 4 if s.kind == "b" else 2          # behind a bias slot: block 0 got its last term in this slot's first MFMA
-        if nxt.layer % 2 == 1:                  # src = accA (VGPRs)
-            gap[g].append(f"v_max_f32 v{tgt}, 0, v{k}")
-        else:                                   # src = accB (AGPRs)
-            gap[g] += [f"v_accvgpr_read_b32 v{tgt}, a{k}", f"v_max_f32 v{tgt}, 0, v{tgt}"]
+    # ---- B operands of the hidden K-steps: relu(src register), RELU_BATCH K-steps per VALU burst (a burst costs the matrix pipe
+    # about the same whether it holds one instruction or eight: measured), double-buffered groups
+    RB = knob("RELU_BATCH", 4)
+    grp = None
+    if nxt.kind == "h" and nxt.k == 0:
+        grp, g = (nxt.layer, 0), (4 if s.kind == "b" else 2)      # behind a bias slot: block 0 got its last term in this slot's first MFMA
+    elif s.kind == "h" and s.k % RB == 0 and s.k + RB < 128:
+        grp, g = (s.layer, s.k // RB + 1), knob("RELU_GAP", 3)
+    if grp is not None and not knob("NORELU"):
+        layer, gi = grp
+        for k in range(gi * RB, (gi + 1) * RB):
+            tgt = vb_reg(k)
+            if layer % 2 == 1:                  # src = accA (VGPRs)
+                gap[g].append(f"v_max_f32 v{tgt}, 0, v{k}")
+            else:                               # src = accB (AGPRs)
+                gap[g].append(f"v_accvgpr_read_b32 v{tgt}, a{k}")
+        if layer % 2 == 0:
+            for k in range(gi * RB, (gi + 1) * RB):
+                gap[g].append(f"v_max_f32 v{vb_reg(k)}, 0, v{vb_reg(k)}")
 
     # ---- X traffic
     if s.kind == "x" and s.layer == 0:
@@ -590,12 +648,16 @@ def emit_slot(p, slots, n, fillers, nchunks):
     for g, ins in fillers:
         gap[min(g, nm - 1)] += ins
 
+    if knob("BARE"):          # ceiling probe: the MFMAs alone (garbage results)
+        pre, gap = [], [[] for _ in range(8)]
     # ---- emit
     for x in pre:
         t = x(p) if callable(x) else x
         if t:
             p.i(t)
     for m in range(nm):
+        if knob("ALIGN") == 1 or (knob("ALIGN") == 2 and m == 0):
+            p.i(".p2align 3")
         p.i(mf[m])
         gi = m if nm == 8 else m            # (4-MFMA slot: gaps 0..3; the rest of its fillers follow the last MFMA)
         for x in gap[gi]:
@@ -616,6 +678,7 @@ def main():
     if out:
         with open(out, "w") as f:
             f.write("// generated by gen_mlp_a.py — do not edit\n")
+            f.write("#define NF_A_LDS_BYTES %d\n" % LDS_BYTES)
             f.write(text)
     else:
         sys.stdout.write(text)

@@ -265,7 +265,7 @@ def pack_nerf_n(packed, cx, cd):
 
 # which LDS-ring kernel serves the fp32 inference passes: "a" = hand-scheduled (nf_mlp_a.hip, generated asm), "l" = the
 # compiler-scheduled one (nf_mlp_l.hip).  Bit-identical results; the streams differ (no padding slots in "a").
-RING_KERNEL = os.environ.get("NF_RING_KERNEL", "l")
+RING_KERNEL = os.environ.get("NF_RING_KERNEL", "a")
 
 
 def pack_nerf_stream(packed, cx, cd, kind=None):

@@ -728,16 +728,17 @@ def test_full_frame_size_independent_properties(dev, side):
     assert ro.psnr(h["rgb1"].cpu(), full["rgb1"].cpu()) >= 45.0
 
 
-def test_mlp_lds_ring_kernel(dev):
-    """A6 through nf_nerf_mlp_fwd_l (weight stream shared through an LDS ring): the golden rows of the reference's
-    NeRF.forward, and the direct-from-L2 kernel on row counts around every tile / workgroup boundary (the four waves
-    of a workgroup rendezvous on the stream: ragged groups must not deadlock or leak rows)."""
+@pytest.mark.parametrize("kind", ["a", "l"])
+def test_mlp_lds_ring_kernel(dev, kind):
+    """A6 through nf_nerf_mlp_fwd_a (hand-scheduled, the inference default) / nf_nerf_mlp_fwd_l (weight stream shared through an
+    LDS ring): the golden rows of the reference's NeRF.forward, and the direct-from-L2 kernel on row counts around every tile /
+    workgroup boundary (the four waves of a workgroup rendezvous on the stream: ragged groups must not deadlock or leak rows)."""
     from neurofluid_amd import ops
     g = load_golden("a6_nerf")
     net = make_net(dev)
     pk = net.packed_weights(net.nerf_coarse)
-    wst = ops.pack_nerf_stream(pk, net.in_channels_xyz, net.in_channels_dir)
-    assert wst is not None
+    wst = ops.pack_nerf_stream(pk, net.in_channels_xyz, net.in_channels_dir, kind=kind)
+    assert wst is not None and wst.nf_kind == kind
     x = T(g["x"], dev)
     out = ops.mlp_rows(pk, net.in_channels_xyz, net.in_channels_dir, x, wstream=wst)
     torch.testing.assert_close(out.cpu(), T(g["out"]), rtol=1e-4, atol=2e-5)
@@ -749,6 +750,36 @@ def test_mlp_lds_ring_kernel(dev):
         torch.testing.assert_close(b, a, rtol=1e-5, atol=3e-5)
     # a non-default feature row has no ring variant
     assert ops.pack_nerf_stream(pk, 63, 27) is None
+
+
+def test_mlp_hand_scheduled_kernel_bit_equal_to_compiler_scheduled(dev):
+    """nf_nerf_mlp_fwd_a (one generated asm statement: gen_mlp_a.py) against nf_nerf_mlp_fwd_l: the same K order, the bias as the last
+    K-step, the heads' mul / add order and the compiler's own expansion of 1 / (1 + expf(-c)) — so the outputs must be BIT-equal,
+    on both nets, on row counts around every tile / tile-group / round boundary (a persistent grid of 256 x 4 waves: 1 024 tiles per
+    round), with a non-trivial row_sample permutation (the store goes through it) and a row count below the capacity passed in."""
+    from neurofluid_amd import ops, _lib
+    from neurofluid_amd._lib import check, ptr
+    lib = _lib.load()
+    net = make_net(dev)
+    gen = torch.Generator().manual_seed(12)
+    for nerf in (net.nerf_coarse, net.nerf_fine):
+        pk = net.packed_weights(nerf)
+        wa = ops.pack_nerf_stream(pk, 198, 54, kind="a")
+        wl = ops.pack_nerf_stream(pk, 198, 54, kind="l")
+        for n in (1, 32, 33, 127, 129, 4096, 32 * 1024 + 5, 32 * 1024 * 3 + 77):
+            cap = n + 100
+            X = ((torch.rand((cap + 31) // 32 * 32 * 256, generator=gen) * 2 - 1) * 1.5).to(dev)
+            perm = torch.randperm(cap, generator=gen).to(torch.int32).to(dev)
+            n_rows = torch.tensor([n], dtype=torch.int32, device=dev)
+            outs = []
+            for fn, w in ((lib.nf_nerf_mlp_fwd_a, wa), (lib.nf_nerf_mlp_fwd_l, wl)):
+                o = torch.full((cap, 4), -7.0, device=dev)
+                check(fn(ptr(pk), ptr(w), 198, 54, ptr(X), ptr(n_rows), cap, ptr(perm), ptr(o), _lib.stream()), "mlp")
+                outs.append(o)
+            assert torch.equal(outs[0], outs[1]), (n, float((outs[0] - outs[1]).abs().max()))
+            written = torch.zeros(cap, dtype=torch.bool, device=dev)
+            written[perm[:n].long()] = True
+            assert bool((outs[0][~written] == -7.0).all()) and bool(torch.isfinite(outs[0][written]).all())      # rows >= n_rows untouched
 
 
 # ------------------------------------------------------------------------------------------------

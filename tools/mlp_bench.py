@@ -67,6 +67,23 @@ if len(sys.argv) > 3 and sys.argv[3] == "split":
         print(f"split iter {it}: rows {n} {ms:.3f} ms  {n*1331968/ms/1e9:.1f} TFLOP/s fp32-equivalent ({3*n*1331968/ms/1e9:.0f} TFLOP/s of fp16 MFMA)")
     err = (out2 - out).abs()
     print("split max abs err rgb", float(err[:, :3].max()), "sigma", float(err[:, 3].max()), "sigma scale", float(out[:, 3].abs().max()))
+if len(sys.argv) > 3 and sys.argv[3] == "asmonly":
+    # timing of the hand-scheduled kernel alone + equality with the direct kernel's rows (A/B variant libraries)
+    wa = torch.empty(lib.nf_nerf_stream_a_floats(198, 54), dtype=torch.float32, device=dev)
+    check(lib.nf_nerf_pack_stream_a(ptr(packed), 198, 54, ptr(wa), _lib.stream()))
+    ws = torch.empty(lib.nf_nerf_stream_floats(198, 54), dtype=torch.float32, device=dev)
+    check(lib.nf_nerf_pack_stream(ptr(packed), 198, 54, ptr(ws), _lib.stream()))
+    out3 = torch.zeros(n, 4, device=dev)
+    check(lib.nf_nerf_mlp_fwd_l(ptr(packed), ptr(ws), 198, 54, ptr(X), ptr(n_rows), n, ptr(row_sample), ptr(out3), _lib.stream()))
+    out4 = torch.full((n, 4), 7.0, device=dev)
+    for it in range(iters):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib.nf_nerf_mlp_fwd_a(ptr(packed), ptr(wa), 198, 54, ptr(X), ptr(n_rows), n, ptr(row_sample), ptr(out4), _lib.stream()))
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        print(f"asm iter {it}: rows {n} {ms:.3f} ms  {n*1331968/ms/1e9:.1f} TFLOP/s", flush=True)
+    print("asm vs ring: bit-equal", bool(torch.equal(out3, out4)))
 if len(sys.argv) > 3 and sys.argv[3] == "asm":
     # hand-scheduled kernel (nf_mlp_a.hip) vs the compiler-scheduled ring kernel: must be bit-identical
     ws = torch.empty(lib.nf_nerf_stream_floats(198, 54), dtype=torch.float32, device=dev)

@@ -42,8 +42,8 @@ F32_MATRIX_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f3
 F16_MATRIX_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense fp16 MFMA
 F32_VECTOR_PEAK_TFLOPS = 157.3
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s
-PMC_FILES = ("round4_mlp_pmc.json", "round3_mlp_pmc.json", "round2_mlp_pmc.json", "round1_mlp_pmc.json")      # newest first
-TRANS_PMC_FILES = ("round4_transition_pmc.json", "round3_transition_pmc.json", "round2_transition_pmc.json")
+PMC_FILES = ("round5_mlp_pmc.json", "round4_mlp_pmc.json", "round3_mlp_pmc.json", "round2_mlp_pmc.json", "round1_mlp_pmc.json")      # newest first
+TRANS_PMC_FILES = ("round5_transition_pmc.json", "round4_transition_pmc.json", "round3_transition_pmc.json", "round2_transition_pmc.json")
 TRANS_STATS_FILES = ("round4_transition_kernel_stats.csv", "round3_transition_kernel_stats.csv", "round2_transition_kernel_stats.csv")
 
 
@@ -118,8 +118,10 @@ def cpu_baseline(scene400, hip_frame=None, hip_step=None):
         for _ in range(len(hip_step)):
             op, ov, _ = to.particle_net_forward(sc["trans_state"], op, ov, sc["box"], sc["bn"])
         hp, hv = hip_step[-1]
-        parity = {"against": "oracle (CPU restatement of the reference path, pinned to the reference by tests/golden), same "
-                             "inputs, same fp32 weights",
+        parity = {"against": "oracle (CPU restatement of the reference path; the renderer half is pinned to the reference's own outputs by "
+                             "tests/golden, the third-party half — pytorch3d ball_query, Open3D ContinuousConv / FixedRadiusSearch — is "
+                             "UNPINNED: restated from the published algorithms, tests/test_oracle_thirdparty.py skips), same inputs, "
+                             "same fp32 weights",
                   "render_rays_compared": int(rays_n.shape[0]),
                   "rgb_coarse": c0, "rgb_fine": c1,
                   "rollout_steps": len(hip_step),
@@ -155,6 +157,19 @@ def _git_blob(path):
         return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
 
 
+MLP_KERNEL_SOURCES = {"k_mlp_fwd_a": ("neurofluid_amd/csrc/gen_mlp_a.py", "neurofluid_amd/csrc/nf_mlp_a.hip", "neurofluid_amd/csrc/nf_mlp_layout.h"),
+                      "k_mlp_fwd_l": ("neurofluid_amd/csrc/nf_mlp_l.hip", "neurofluid_amd/csrc/nf_mlp_layout.h")}
+
+
+def kernel_source_sha1(kernel):
+    """sha1 over the sources the named MLP kernel is built from (the generated asm body is a pure function of gen_mlp_a.py): what
+    tools/r5_refresh_profiles.sh records next to a PMC pass, and what this run compares with — a profile of OTHER code is flagged."""
+    h = hashlib.sha1()
+    for rel in MLP_KERNEL_SOURCES.get(kernel, ()):
+        h.update(open(os.path.join(ROOT, rel), "rb").read())
+    return h.hexdigest()
+
+
 def committed_traffic():
     """HBM bytes per launch of the dominant kernel from the COMMITTED rocprofv3 PMC passes of this command (PMC counters
     cannot be read from inside the process; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, tools/summarize_profiles.py).
@@ -163,8 +178,12 @@ def committed_traffic():
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             d = json.load(open(path))
+            now = kernel_source_sha1(d.get("kernel"))
             return d.get("hbm_bytes_per_launch"), {"file": "profiles/" + name, "git_blob": _git_blob(path),
                                                    "kernel": d.get("kernel"), "launches_profiled": d.get("launches_profiled"),
+                                                   "kernel_source_sha1_profiled": d.get("kernel_source_sha1"),
+                                                   "kernel_source_sha1_now": now,
+                                                   "matches_this_build": d.get("kernel_source_sha1") == now,
                                                    "note": "recorded by separate rocprofv3 --pmc passes of `bench.py --no-cpu-"
                                                            "baseline`, NOT measured by this run"}
     return None, None
@@ -302,11 +321,10 @@ def main():
                 state["pos"], state["vel"] = P0.clone(), torch.zeros_like(P0)      # clumps no real rollout has -> restart
             state["k"] += 1
             state["pos"], state["vel"], _ = pn(state["pos"], state["vel"], box, bn)
-            # The rendered cloud is the initial one, so that step time is stationary (the synthetic weights let the
-            # body fall out of view within a few frames); the transition step above is real work on the evolving
-            # state, and the renderer's particle grid is REBUILT every step, as a real rollout must (the cloud moved)
-            net.invalidate_grid()
-            out = render_image(net, P0, n_rays, roc, rays, None, None, iseval=True, ray_chunk=args.chunk, rank=rank,
+            # COUPLED (round 5; eval_e2e.py:58-134): the renderer consumes what the transition step produced — a moving cloud,
+            # its particle grid rebuilt on real motion, the bbox hint one frame stale, row capacities tracking the spreading
+            # fluid.  (Rounds 1-4 rendered the initial cloud every frame; that figure stays as the extra `static_initial_cloud`.)
+            out = render_image(net, state["pos"], n_rays, roc, rays, None, None, iseval=True, ray_chunk=args.chunk, rank=rank,
                                world=world, gather=False, device_chunk=device_chunk)      # gather=False: RGB tiles only
         return out
 
@@ -353,7 +371,13 @@ def main():
     n_launch = max(len(prof["mlp"]), 1)
     achieved = rows * MLP_FLOP_PER_ROW / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
     traffic, traffic_src = committed_traffic() if args.workload == "render" and world == 1 and image == 400 else (None, None)
-    roofline = {"bound": "mfma", "kernel": "k_mlp_fwd_l (fp32 v_mfma_f32_32x32x2_f32, weights through an LDS ring)",
+    traffic, traffic_src = committed_traffic() if args.workload == "render" and world == 1 and image == 400 else (None, None)
+    kname = ("k_mlp_fwd_a (fp32 v_mfma_f32_32x32x2_f32, hand-scheduled instruction stream, weights through an LDS ring)"
+             if ops.RING_KERNEL == "a" else "k_mlp_fwd_l (fp32 v_mfma_f32_32x32x2_f32, weights through an LDS ring)")
+    if traffic_src is not None and not traffic_src.get("matches_this_build", True):
+        sys.stderr.write("bench.py: WARNING: %s was profiled on kernel %s with other sources than this build's (%s): `roofline.traffic` "
+                         "is stale; re-run tools/r5_measure.sh pmc\n" % (traffic_src["file"], traffic_src.get("kernel"), traffic_src.get("kernel_source_sha1_now")))
+    roofline = {"bound": "mfma", "kernel": kname,
                 "achieved": achieved, "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_MATRIX_PEAK_TFLOPS,
                 "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": traffic_src,
                 "launches": len(prof["mlp"]), "avg_launch_ms": mlp_ms / n_launch,
@@ -498,33 +522,32 @@ def main():
                             "note": "render only; same tolerance as the fp32 path (tests/test_gpu_render.py::test_split_precision_path); "
                                     "not the headline value"})
 
-    # ---- extra: the frame body with the renderer consuming what the transition step PRODUCED (a moving cloud: grid rebuild
-    # on real motion, bbox hint one frame stale, row capacities tracking the spreading fluid); the state is reset to P0
-    # every 8 frames so that the body stays in view.  The stationary headline above renders P0 every frame.
+    # ---- extra: the headline of rounds 1-4 — the transition step advances its state, the renderer draws the INITIAL cloud every
+    # frame (grid rebuilt all the same).  Kept so that the rounds compare; the headline above is the coupled frame.
     if args.workload == "render" and not args.no_extras:
         cst = {"i": 0, "pos": P0.clone(), "vel": torch.zeros_like(P0)}
 
-        def step_coupled():
+        def step_static():
             with torch.no_grad():
                 if cst["i"] % 8 == 0:
                     cst["pos"], cst["vel"] = P0.clone(), torch.zeros_like(P0)
                 cst["i"] += 1
                 cst["pos"], cst["vel"], _ = pn(cst["pos"], cst["vel"], box, bn)
-                return render_image(net, cst["pos"], n_rays, roc, rays, None, None, iseval=True, ray_chunk=args.chunk, rank=rank,
+                net.invalidate_grid()
+                return render_image(net, P0, n_rays, roc, rays, None, None, iseval=True, ray_chunk=args.chunk, rank=rank,
                                     world=world, gather=False, device_chunk=device_chunk)
-        for _ in range(8):
-            step_coupled()
+        for _ in range(3):
+            step_static()
         sync()
         per_step = []
-        for _ in range(16):
+        for _ in range(8):
             t4 = time.perf_counter()
-            step_coupled()
+            step_static()
             sync()
             per_step.append(time.perf_counter() - t4)
         dtc = sorted(per_step)[len(per_step) // 2]
-        coupled_extra = {"workload": "ParticleNet step -> render of the PREDICTED positions (state reset to P0 every 8 frames)",
-                         "ms_per_step_median": dtc * 1e3, "rays_per_sec": n_rays / dtc,
-                         "ms_per_step_by_frame_of_cycle": [round(sum(per_step[k::8]) / len(per_step[k::8]) * 1e3, 3) for k in range(8)]}
+        coupled_extra = {"workload": "ParticleNet step on the evolving state + render of the INITIAL cloud (the headline of rounds 1-4)",
+                         "ms_per_step_median": dtc * 1e3, "rays_per_sec": n_rays / dtc}
 
     # ---- extra: BASELINE configs[2] (train_e2e.py step: transition forward -> render of the predicted particles from the config's
     # views -> rgb loss -> backward through both models -> two Adams) through the E2ETrainer itself on a synthetic on-disk dataset
@@ -731,9 +754,10 @@ def main():
 
     if rank == 0:
         if args.workload == "render":
-            wl = ("eval_e2e per-frame body: ParticleNet step (4913 particles, replicated) + grid rebuild + full %dx%d "
-                  "coarse+fine render of %d view(s), %d rays, %d chunk(s) of %d rays interleaved over %d rank(s), RGB "
-                  "all-gather" % (image, image, n_views, n_rays, n_chunks, args.chunk, world))
+            wl = ("eval_e2e per-frame body: ParticleNet step (4913 particles, replicated) -> grid rebuild on the PREDICTED positions -> "
+                  "full %dx%d coarse+fine render of them, %d view(s), %d rays, %d chunk(s) of %d rays interleaved over %d rank(s), RGB "
+                  "all-gather; the state returns to the initial cloud every 8 frames (the synthetic weights are no fluid)"
+                  % (image, image, n_views, n_rays, n_chunks, args.chunk, world))
         else:
             wl = "train_renderer.py step: 4 views x 1024 rays per rank, fwd+bwd+Adam"
         res = {"metric": ("rays/sec (renderer coarse+fine forward) coupled with one transition step per frame, watercube %d^2" % image
@@ -751,7 +775,7 @@ def main():
                "roofline": roofline, "roofline_transition": trans_roofline, "load_balance": balance,
                "max_over_mean": balance["max_over_mean"] if balance else None,
                "fp16_mfma_path": fp16_extra, "split_precision_path": split_extra,
-               "train_step": train_extra, "train_e2e_step": e2e_extra, "coupled_moving_cloud": coupled_extra}
+               "train_step": train_extra, "train_e2e_step": e2e_extra, "static_initial_cloud": coupled_extra}
         if cfg45_extra:
             res.update(cfg45_extra)
         if single_dev and world > 1:
@@ -767,7 +791,10 @@ def main():
                     for _ in range(5):
                         hp, hv, _ = pn(hp, hv, box, bn)
                         hip_step.append((hp.cpu(), hv.cpu()))
-                hip_frame = (out["pred_rgbs_0"].float().cpu(), out["pred_rgbs_1"].float().cpu())
+                with torch.no_grad():      # the parity frame: the INITIAL cloud (what the oracle sample below renders), untimed
+                    pf = render_image(net, P0, n_rays, roc, rays, None, None, iseval=True, ray_chunk=args.chunk, rank=rank, world=world,
+                                      gather=False, device_chunk=device_chunk)
+                hip_frame = (pf["pred_rgbs_0"].float().cpu(), pf["pred_rgbs_1"].float().cpu())
             res["cpu_baseline"], parity = cpu_baseline(scene if image == 400 else build_scene(400), hip_frame, hip_step)
             if parity is not None:
                 res["parity"] = parity

@@ -314,18 +314,35 @@ def main():
 
     ops.PROFILE = None
     state = {"pos": P0.clone(), "vel": torch.zeros_like(P0), "k": 0}
+    # N > 1, one view: every rank GENERATES the rays of its own 1024-ray chunks on the device (nf_get_rays_chunks) — no
+    # (H*W, 6) tensor per rank, nothing scattered.  N = 1 keeps the scene's precomputed rays (the ones the oracle sample renders).
+    own_rays_arg, camera_arg = rays, None
+    if world > 1 and strong and args.workload == "render":
+        from neurofluid_amd import synthetic as _syn
+        own_rays_arg, camera_arg = None, (image, image, _syn.camera_focal(image), scene["c2w"].to(dev))
 
     def step_render():
         with torch.no_grad():
             if state["k"] % 8 == 0:     # the synthetic weights are no fluid: after some tens of steps the body collapses into
                 state["pos"], state["vel"] = P0.clone(), torch.zeros_like(P0)      # clumps no real rollout has -> restart
             state["k"] += 1
+            tm = state.get("timings")
+            if tm is not None:
+                e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                e[0].record()
             state["pos"], state["vel"], _ = pn(state["pos"], state["vel"], box, bn)
+            if tm is not None:
+                e[1].record()
+                net.grid_for(state["pos"])          # (cached: the render below reuses it) — timed on its own for the breakdown
+                e[2].record()
+                tm.setdefault("transition", []).append((e[0], e[1]))
+                tm.setdefault("grid", []).append((e[1], e[2]))
             # COUPLED (round 5; eval_e2e.py:58-134): the renderer consumes what the transition step produced — a moving cloud,
             # its particle grid rebuilt on real motion, the bbox hint one frame stale, row capacities tracking the spreading
             # fluid.  (Rounds 1-4 rendered the initial cloud every frame; that figure stays as the extra `static_initial_cloud`.)
-            out = render_image(net, state["pos"], n_rays, roc, rays, None, None, iseval=True, ray_chunk=args.chunk, rank=rank,
-                               world=world, gather=False, device_chunk=device_chunk)      # gather=False: RGB tiles only
+            out = render_image(net, state["pos"], n_rays, roc, own_rays_arg, None, None, iseval=True, ray_chunk=args.chunk, rank=rank,
+                               world=world, gather=False, device_chunk=device_chunk, camera=camera_arg,
+                               timings=tm)      # gather=False: RGB tiles only
         return out
 
     if args.workload == "train":
@@ -349,19 +366,41 @@ def main():
     if ops.PROFILE["mlp"]:
         ops.PROFILE["mlp"][0][0].elapsed_time(ops.PROFILE["mlp"][0][1])
     ops.PROFILE = {"mlp": [], "rows": []}
+    if args.workload == "render":
+        state["timings"] = {}
     t0 = time.perf_counter()
     host_marks = []
     for _ in range(args.steps):
         out = step_fn()
         host_marks.append(time.perf_counter() - t0)
+    torch.cuda.synchronize()
+    own_wall = time.perf_counter() - t0          # this rank's own finish, before the closing barrier: max - min over ranks = skew
     sync()
     dt = time.perf_counter() - t0
+    tm_run, state["timings"] = state.get("timings"), None
     prof = ops.PROFILE
     ops.PROFILE = None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # ---- per-rank breakdown of the timed region (HIP events on the launch stream): where a sub-linear scaling curve comes from
+    breakdown = None
+    if tm_run:
+        mine = {k + "_ms_per_step": round(sum(a.elapsed_time(b) for a, b in v) / args.steps, 4) for k, v in tm_run.items()}
+        mine["own_wall_ms_per_step"] = round(own_wall / args.steps * 1e3, 4)
+        mine["rank"] = rank
+        if world > 1:
+            allr = [None] * world
+            dist.all_gather_object(allr, mine)
+        else:
+            allr = [mine]
+        walls = [r["own_wall_ms_per_step"] for r in allr]
+        breakdown = {"per_rank": allr, "finish_skew_ms_per_step": round(max(walls) - min(walls), 4),
+                     "note": "transition = the replicated ParticleNet step; grid = the renderer's particle-grid rebuild on the predicted "
+                             "cloud; render = this rank's chunks (ray generation, both passes, incl. the grid wait); gather = RGB all-gather "
+                             "(RCCL) + reorder; own_wall = host clock from the opening barrier to this rank's own device-idle, i.e. before the "
+                             "closing barrier — the slowest rank sets `value`"}
     rays_per_step = n_rays if args.workload == "render" else 4096 * world
     value = rays_per_step * args.steps / dt
 
@@ -772,7 +811,7 @@ def main():
                "particle_steps_per_sec": pstep,
                "particle_steps_note": "ParticleNet.forward alone on one GPU; the 4913-particle step does not shard (replicas only: "
                                       "every rank advances the same state), so this figure is per replica, not multiplied by N",
-               "roofline": roofline, "roofline_transition": trans_roofline, "load_balance": balance,
+               "roofline": roofline, "roofline_transition": trans_roofline, "load_balance": balance, "per_rank_breakdown": breakdown,
                "max_over_mean": balance["max_over_mean"] if balance else None,
                "fp16_mfma_path": fp16_extra, "split_precision_path": split_extra,
                "train_step": train_extra, "train_e2e_step": e2e_extra, "static_initial_cloud": coupled_extra}

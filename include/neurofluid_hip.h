@@ -103,6 +103,12 @@ int nf_nearest(const float* pts, int n_pts, const float* queries, int nq, double
  * c2w: 3x4 row-major camera-to-world on the device. */
 int nf_get_rays(int H, int W, float focal, const float* c2w /*12*/, int row0, int nrows, float* rays /*nrows*W*6*/,
                 nf_stream_t stream);
+/* The rays of one rank's chunks (image chunk first + j * stride for j = 0, 1, ...; `chunk` consecutive rays each, row-major pixel
+ * order), in ownership order, n_own_rays of them in all (the image's last chunk may be ragged): the ray-tile sharding of SURVEY 8e
+ * without a full (H*W, 6) tensor per rank.  Bit-identical to the corresponding rows of nf_get_rays' output. */
+int nf_get_rays_chunks(int H, int W, float focal, const float* c2w /*3x4 row-major*/, int chunk, int first, int stride,
+                       int n_own_rays, float* rays /*n_own_rays*6*/, nf_stream_t stream);
+
 
 /* A1 + cell test: xyz = o + d*z (utils/ray_utils.py:232-256 / :227); num_nn and mask are cleared
  * for EVERY sample here (the search overwrites the candidates); samples whose 27-cell neighbourhood

@@ -41,6 +41,7 @@ PROTOTYPES = {
     "nf_csr_clamp": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_void_p]),
     "nf_nearest": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "nf_get_rays": (c_int, [c_int, c_int, c_float, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "nf_get_rays_chunks": (c_int, [c_int, c_int, c_float, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "nf_render_classify": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p]),
     "nf_render_search": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_int, c_void_p,

@@ -1469,6 +1469,41 @@ extern "C" int nf_get_rays(int H, int W, float focal, const float* c2w, int row0
     return NF_OK;
 }
 
+// The rays of ONE RANK's chunks, in ownership order, in one launch ("rays generated on-device per tile so no ray tensor
+// is scattered"): chunk j of this rank is the image's chunk first + j * stride (chunk k -> rank k mod world: first = rank, stride =
+// world), a chunk = `chunk` consecutive rays in row-major pixel order; the image's last chunk may be ragged.  Same arithmetic as
+// k_get_rays (utils/ray_utils.py:85-130), so a rank's rays are bit-identical to the rows of the full tensor it used to index.
+__global__ void k_get_rays_chunks(int H, int W, float focal, const float* __restrict__ c2w, int chunk, int first, int stride,
+                                  int n_own_rays, float* __restrict__ rays)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_own_rays) return;
+    const long long g = (long long)(first + (t / chunk) * stride) * chunk + t % chunk;      // index of the ray in the image
+    int j = (int)(g / W), i = (int)(g % W);
+    float dx = ((float)i - (float)W / 2) / focal, dy = -((float)j - (float)H / 2) / focal, dz = -1.f;
+    float r[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) r[k] = dx * c2w[4 * k] + dy * c2w[4 * k + 1] + dz * c2w[4 * k + 2];
+    float n = sqrtf(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    float* o = rays + 6 * (size_t)t;
+    o[0] = c2w[3]; o[1] = c2w[7]; o[2] = c2w[11];
+    o[3] = r[0] / n; o[4] = r[1] / n; o[5] = r[2] / n;
+}
+
+extern "C" int nf_get_rays_chunks(int H, int W, float focal, const float* c2w, int chunk, int first, int stride, int n_own_rays,
+                                  float* rays, nf_stream_t stream)
+{
+    NF_CHECK_ARG(c2w && (rays || n_own_rays == 0), "null pointer");
+    NF_CHECK_ARG(H > 0 && W > 0 && focal > 0.f && chunk > 0 && first >= 0 && stride > 0 && n_own_rays >= 0, "bad image geometry");
+    if (n_own_rays == 0) return NF_OK;
+    const long long last = (long long)(first + ((n_own_rays - 1) / chunk) * stride) * chunk + (n_own_rays - 1) % chunk;
+    NF_CHECK_ARG(last < (long long)H * W, "the rank's chunks reach beyond the image");
+    hipLaunchKernelGGL(k_get_rays_chunks, dim3((n_own_rays + 255) / 256), dim3(256), 0, (hipStream_t)stream, H, W, focal, c2w, chunk,
+                       first, stride, n_own_rays, rays);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // features backward (A12, e2e): dL/d(particles) from dL/d(feature row) through density, smoothed
 // position, variance and smoothed direction (the only particle-dependent columns; gradients reach the

@@ -67,3 +67,17 @@ def allreduce_grads(params, world):
         n = g.numel()
         g.copy_(flat[o:o + n].view_as(g))
         o += n
+
+
+def mean_over_ranks_hook(world):
+    """Tensor hook for the e2e step: the ranks render different rays of the SAME predicted particles, so dL/d(pred_pos)
+    (Np x 3 fp32 = 59 KB) is all-reduced (mean) BEFORE it is back-propagated into the replicated transition model — whose
+    692 902-parameter gradients are then identical on every rank and need no all-reduce of their own (2.8 MB saved per step).
+    Usage: pred_pos.register_hook(mean_over_ranks_hook(world)); allreduce_grads() then takes the renderer's parameters only."""
+    def hook(g):
+        if world == 1:
+            return g
+        g = g.contiguous().clone()
+        dist.all_reduce(g, op=dist.ReduceOp.SUM)
+        return g / world
+    return hook

@@ -36,3 +36,19 @@ def get_rays_device(H, W, focal, c2w, row0=0, nrows=None, device=None):
     out = torch.empty(nrows * W, 6, dtype=torch.float32, device=device)
     check(lib.nf_get_rays(H, W, float(focal), ptr(c), row0, nrows, ptr(out), _lib.stream()), "nf_get_rays")
     return out
+
+
+def get_rays_own_chunks(H, W, focal, c2w, ray_chunk, rank, world, device=None):
+    """A0 for ONE RANK of a ray-chunk-sharded render (dist.my_chunks: chunk k -> rank k mod world): the rays of this rank's chunks in
+    ownership order, generated on the device in one launch (nf_get_rays_chunks) — no (H*W, 6) tensor per rank, nothing scattered
+    (SURVEY 8e).  Bit-identical to `get_rays_device(H, W, focal, c2w).index_select(0, own)`."""
+    lib = _lib.load()
+    device = device or c2w.device
+    n_ray = H * W
+    n_chunks = (n_ray + ray_chunk - 1) // ray_chunk
+    own = list(range(rank, n_chunks, world))
+    n_own = sum(min((k + 1) * ray_chunk, n_ray) - k * ray_chunk for k in own)
+    c = c2w.detach().to(device).contiguous().float()
+    out = torch.empty(n_own, 6, dtype=torch.float32, device=device)
+    check(lib.nf_get_rays_chunks(H, W, float(focal), ptr(c), ray_chunk, rank, world, n_own, ptr(out), _lib.stream()), "nf_get_rays_chunks")
+    return out

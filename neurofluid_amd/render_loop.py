@@ -22,7 +22,7 @@ def _own_ray_index(n_chunks, ray_chunk, N_ray, rank, world, device):
 
 
 def render_image(renderer, particle_pos, N_ray, ro, rays, focal_length=None, cw=None, iseval=False, ray_chunk=1024,
-                 rank=0, world=1, gather=True, device_chunk=None):
+                 rank=0, world=1, gather=True, device_chunk=None, camera=None, timings=None):
     """Same result dict as the reference: pred_rgbs_0/1 (N_ray,3), num_nn_0/1 (N_ray*S), mask_0/1 (N_ray,1) if iseval.
 
     ray_chunk    the reference's chunk (the unit of its loop, and the unit that is dealt to the ranks);
@@ -31,7 +31,12 @@ def render_image(renderer, particle_pos, N_ray, ro, rays, focal_length=None, cw=
     With world > 1 the chunks are interleaved over the ranks (chunk k -> rank k mod world: the fluid covers a minority
     of the pixels, so the cost follows the active samples; fine interleaving balances it) and every rank renders ALL
     its chunks in as few fused calls as device_chunk allows — 1024-ray balance at full-GPU launch sizes.  The RGB
-    tiles are all-gathered; num_nn / mask stay local unless gather=True."""
+    tiles are all-gathered; num_nn / mask stay local unless gather=True.
+
+    camera = (H, W, focal, c2w) with rays=None: every rank GENERATES the rays of its own chunks on the device (nf_get_rays_chunks,
+    SURVEY 8e: no ray tensor is materialised per rank, nothing is scattered) — bit-identical to indexing the full tensor.
+    timings: a dict that receives ("render", "gather") pairs of torch.cuda.Event (start, end) of this call, for the per-rank
+    breakdown of `bench.py --gpus N`."""
     n_imp = renderer.N_importance
     n_chunks = (N_ray + ray_chunk - 1) // ray_chunk
     device_chunk = max(int(device_chunk or ray_chunk), 1)
@@ -39,7 +44,17 @@ def render_image(renderer, particle_pos, N_ray, ro, rays, focal_length=None, cw=
     if n_imp > 0:
         keys += ["rgb1", "num_nn_1"] + (["mask_1"] if iseval else [])
     per_ray_ro = ro is not None and ro.dim() == 2          # fused multi-view calls carry one camera position per ray
-    if world > 1:
+    ev = None
+    if timings is not None:
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev[0].record()
+    if rays is None:
+        from . import ray_utils
+        H_, W_, focal_, c2w_ = camera
+        assert H_ * W_ == N_ray and not per_ray_ro
+        my_rays = ray_utils.get_rays_own_chunks(H_, W_, focal_, c2w_, ray_chunk, rank, world, device=particle_pos.device)
+        my_ro = ro
+    elif world > 1:
         own = _own_ray_index(n_chunks, ray_chunk, N_ray, rank, world, rays.device)
         my_rays = rays.index_select(0, own)
         my_ro = ro.index_select(0, own) if per_ray_ro else ro
@@ -58,6 +73,9 @@ def render_image(renderer, particle_pos, N_ray, ro, rays, focal_length=None, cw=
             parts[key].append(v.view(v.shape[0], -1) if key.startswith("num_nn") else v)
     names = {"rgb0": "pred_rgbs_0", "rgb1": "pred_rgbs_1"}
     ret = LazyResults()
+    if ev is not None:
+        ev[1].record()
+        timings.setdefault("render", []).append((ev[0], ev[1]))
     if world == 1:
         for key in keys:
             t = parts[key][0] if len(parts[key]) == 1 else torch.cat(parts[key], dim=0)     # one fused call: no copy
@@ -67,7 +85,7 @@ def render_image(renderer, particle_pos, N_ray, ro, rays, focal_length=None, cw=
                 ret[names.get(key, key)] = t.reshape(-1) if key.startswith("num_nn") else t
         return ret
     share = nfdist.share_size(n_chunks, world)
-    dev = rays.device
+    dev = my_rays.device
     S0, S1 = renderer.N_samples, renderer.N_samples + n_imp
     widths = {"rgb0": 3, "rgb1": 3, "mask_0": 1, "mask_1": 1, "num_nn_0": S0, "num_nn_1": S1}
     for key in keys:
@@ -85,4 +103,7 @@ def render_image(renderer, particle_pos, N_ray, ro, rays, focal_length=None, cw=
             ret.set_lazy(key, full, (full.numel(),))
         else:
             ret[names.get(key, key)] = full.reshape(-1) if key.startswith("num_nn") else full
+    if ev is not None:
+        ev[2].record()
+        timings.setdefault("gather", []).append((ev[1], ev[2]))
     return ret

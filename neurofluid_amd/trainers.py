@@ -158,14 +158,15 @@ class BaseTrainer:
         return rays_hw6[sc[:, 0], sc[:, 1]], rgbs.view(H, W, -1)[sc[:, 0], sc[:, 1]]
 
     # ---- the chunk loop (trainer/basetrainer.py:264-309)
-    def render_image(self, particle_pos, N_ray, ro, rays, focal_length, cw, iseval=False):
+    def render_image(self, particle_pos, N_ray, ro, rays, focal_length, cw, iseval=False, camera=None):
+        """rays=None + camera=(H, W, focal, c2w): every rank generates the rays of its own chunks (render_loop.render_image)."""
         rc = self.options.RENDERER.ray.ray_chunk
         dev_chunk = rc
         if N_ray > rc:   # full-image loops: larger fused calls, still multiples of the reference's chunk
             dev_chunk = max(rc, int(self.options.RENDERER.get('device_ray_chunk', rc)) // rc * rc)
         shard = iseval and self.world > 1      # reference chunks interleaved over the ranks, fused per rank (render_loop)
         return _render_image(self.renderer, particle_pos, N_ray, ro, rays, focal_length, cw, iseval=iseval, ray_chunk=rc,
-                             device_chunk=dev_chunk, rank=self.rank if shard else 0, world=self.world if shard else 1)
+                             device_chunk=dev_chunk, rank=self.rank if shard else 0, world=self.world if shard else 1, camera=camera)
 
     # ---- image dumps
     def vis_rgbs(self, rgbs, channel=3, test=False):
@@ -472,6 +473,9 @@ class E2ETrainer(BaseTrainer):
 
     def train_step(self, data, data_idx, view_num, H, W, global_step):
         pred_pos = self.trainsition_step_for_training(data, data_idx)
+        if self.world > 1 and pred_pos.requires_grad:
+            # data-parallel over rays: dL/d(pred_pos) is averaged over the ranks (59 KB) before the replicated transition backward
+            pred_pos.register_hook(nfdist.mean_over_ranks_hook(self.world))
         log = (global_step + 1) % self.options.TRAIN.log_interval == 0
         if log:
             d = self.tmp_fluid_error.cal_errors(pred_pos.detach(), data['particles_pos_1'], data_idx + 1)
@@ -512,7 +516,9 @@ class E2ETrainer(BaseTrainer):
         if self.separate:
             self.transition_optimizer.zero_grad()
         loss.backward()
-        nfdist.allreduce_grads(list(self.renderer.parameters()) + list(self.transition_model.parameters()), self.world)
+        # renderer gradients: one flat-bucket all-reduce (5.35 MB); the transition model's are already identical on every rank
+        # (its only upstream gradient, dL/d pred_pos, was averaged by train_step's hook: SURVEY 8e)
+        nfdist.allreduce_grads(list(self.renderer.parameters()), self.world)
         if clip != 0:
             torch.nn.utils.clip_grad_norm_(self.renderer.parameters(), clip)
             torch.nn.utils.clip_grad_norm_(self.transition_model.parameters(), clip)
@@ -618,7 +624,11 @@ class RendererEvaluation(BaseTrainer):
                                 [-0.2077273577451706, 0.15678563714027405, -0.32383665442466736, -8.387124061584473],
                                 [0.0, 0.37393447756767273, 0.181040421128273, 4.688809871673584]])
         c2w = c2w.to(self.device)
-        return {'cw': c2w, 'focal': focal, 'rays': ray_utils.get_rays_device(H, W, focal, c2w)}
+        if getattr(self, 'world', 1) > 1:
+            # ray-tile sharding: no (H*W, 6) tensor per rank — each rank generates its own chunks' rays per frame
+            return {'cw': c2w, 'focal': focal, 'rays': None, 'camera': (H, W, focal, c2w), 'n_ray': H * W}
+        rays = ray_utils.get_rays_device(H, W, focal, c2w)
+        return {'cw': c2w, 'focal': focal, 'rays': rays, 'camera': None, 'n_ray': rays.shape[0]}
 
     def eval(self, max_frames=53, dump=True):
         self.renderer.eval()
@@ -627,7 +637,8 @@ class RendererEvaluation(BaseTrainer):
         with torch.no_grad():
             for i, f in enumerate(self.files[:max_frames]):
                 pos = torch.from_numpy(np.load(f)['pos']).float().to(self.device)
-                ret = self.render_image(pos, rp['rays'].shape[0], self.renderer.set_ro(rp['cw']), rp['rays'], rp['focal'], rp['cw'], iseval=True)
+                ret = self.render_image(pos, rp['n_ray'], self.renderer.set_ro(rp['cw']), rp['rays'], rp['focal'], rp['cw'], iseval=True,
+                                        camera=rp['camera'])
                 out.append(ret)
                 if dump and self.rank == 0:
                     name = osp.basename(f)[:-4]

@@ -134,3 +134,57 @@ def test_single_process_keeps_reference_stream():
     a = np.random.choice(1000, size=[8], replace=False)
     np.random.seed(10)
     assert np.array_equal(a, np.random.choice(1000, size=[8], replace=False))
+
+
+def _e2e_hook_worker(rank, world, port, q):
+    """SURVEY 8e, e2e training: all-reducing dL/d(pred_pos) (a tensor hook, 59 KB at 4 913 particles) in front of the REPLICATED
+    transition backward gives every rank the gradients that all-reducing the transition model's own parameter gradients gives."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from neurofluid_amd import dist as nfdist
+    nfdist.init_from_env(backend="gloo")
+    torch.manual_seed(3)                                  # identical replicas
+    trans = torch.nn.Sequential(torch.nn.Linear(3, 16), torch.nn.Tanh(), torch.nn.Linear(16, 3))      # "transition model"
+    rend = torch.nn.Linear(3, 3)                          # "renderer"
+    pos = torch.randn(50, 3, generator=torch.Generator().manual_seed(1))
+    sel = torch.randperm(50, generator=torch.Generator().manual_seed(100 + rank))[:20]               # this rank's "rays"
+    tgt = torch.rand(20, 3, generator=torch.Generator().manual_seed(200 + rank))
+
+    def loss_of(pred):
+        return torch.nn.functional.mse_loss(rend(pred[sel]), tgt) + 0.1 * pred.abs().mean()          # rgb loss + a boundary-like term
+
+    # (a) the scheme of rounds 1-4: all-reduce every parameter gradient
+    for p in list(trans.parameters()) + list(rend.parameters()):
+        p.grad = None
+    loss_of(trans(pos)).backward()
+    nfdist.allreduce_grads(list(trans.parameters()) + list(rend.parameters()), world)
+    ref = [p.grad.clone() for p in list(trans.parameters()) + list(rend.parameters())]
+    # (b) hook on pred_pos + renderer-only all-reduce
+    for p in list(trans.parameters()) + list(rend.parameters()):
+        p.grad = None
+    pred = trans(pos)
+    pred.register_hook(nfdist.mean_over_ranks_hook(world))
+    loss_of(pred).backward()
+    nfdist.allreduce_grads(list(rend.parameters()), world)
+    got = [p.grad.clone() for p in list(trans.parameters()) + list(rend.parameters())]
+    ok = all(torch.allclose(a, b, rtol=1e-5, atol=1e-7) for a, b in zip(ref, got))
+    gathered = [None] * world
+    dist.all_gather_object(gathered, [g.clone() for g in got])
+    ok = ok and all(torch.equal(a, b) for a, b in zip(gathered[0], gathered[1]))       # identical on every rank, without a second all-reduce
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_e2e_dpos_allreduce_equals_parameter_allreduce():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_e2e_hook_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]

@@ -66,6 +66,12 @@ def test_bench_launches_its_own_ranks():
     assert res["max_over_mean"] is not None and 1.0 <= res["max_over_mean"] < 1.1
     assert len(res["load_balance"]["executed_rows_per_rank_per_step"]) == 2
     assert res["value"] > 0 and "single_device_emulation" in res
+    # the per-rank breakdown a sub-linear scaling curve is diagnosed from: every rank reports its phases and its own finish
+    br = res["per_rank_breakdown"]
+    assert [r["rank"] for r in br["per_rank"]] == [0, 1] and br["finish_skew_ms_per_step"] >= 0
+    for r in br["per_rank"]:
+        assert r["transition_ms_per_step"] > 0 and r["grid_ms_per_step"] > 0 and r["render_ms_per_step"] > 0
+        assert r["gather_ms_per_step"] >= 0 and r["own_wall_ms_per_step"] > 0
 
 
 def test_bench_more_ranks_than_devices_is_refused_with_a_message():
@@ -74,3 +80,36 @@ def test_bench_more_ranks_than_devices_is_refused_with_a_message():
     r = _bench(["--gpus", str(n), "--steps", "1", "--warmup", "1", "--no-extras", "--no-cpu-baseline"], {"NF_BENCH_SINGLE_DEVICE": "0"}, timeout=300)
     assert r.returncode == 2
     assert "device(s) visible" in r.stderr and "AssertionError" not in r.stderr and "Traceback" not in r.stderr
+
+
+def test_own_chunk_rays_bit_equal_to_the_indexed_full_tensor():
+    """a rank generates the rays of ITS chunks (nf_get_rays_chunks) instead of indexing an (H*W, 6) tensor — the same bits,
+    for every rank of worlds 1 / 2 / 3 / 8, ragged last chunk included (400 x 400 = 156.25 chunks of 1024)."""
+    import torch
+    from neurofluid_amd import ray_utils, synthetic
+    from neurofluid_amd import dist as nfdist
+    dev = torch.device("cuda:0")
+    c2w = synthetic.eval_camera().to(dev)
+    for H, W, chunk in ((400, 400, 1024), (37, 53, 64)):
+        focal = synthetic.camera_focal(W)
+        full = ray_utils.get_rays_device(H, W, focal, c2w)
+        n_chunks = (H * W + chunk - 1) // chunk
+        for world in (1, 2, 3, 8):
+            for rank in range(world):
+                own = torch.cat([torch.arange(k * chunk, min((k + 1) * chunk, H * W)) for k in nfdist.my_chunks(n_chunks, rank, world)]).to(dev)
+                got = ray_utils.get_rays_own_chunks(H, W, focal, c2w, chunk, rank, world, device=dev)
+                assert torch.equal(got, full.index_select(0, own)), (H, W, world, rank)
+
+
+def test_rccl_two_ranks_two_devices():
+    """The N > 1 path over real RCCL / xGMI: skipped on the one-GPU boxes of this pool, runs wherever two devices are visible —
+    `bench.py --gpus 2` (strong ray-tile scaling, own-chunk ray generation, RGB all-gather through RCCL)."""
+    import json
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two MI355X devices (RCCL refuses two ranks on one device)")
+    r = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-extras", "--no-cpu-baseline"], {"NF_BENCH_SINGLE_DEVICE": "0"})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert res["n_gpus"] == 2 and "single_device_emulation" not in res and res["value"] > 0
+    assert len(res["per_rank_breakdown"]["per_rank"]) == 2

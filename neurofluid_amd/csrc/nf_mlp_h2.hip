@@ -267,26 +267,37 @@ __device__ __forceinline__ void h2_block(H2Ctx& c, int& slot, f32x16 (&acc)[2], 
     } else {
         h2_step<0, 0>(c, slot, bb, bb2, acc[0], acc[1], true);
     }
+    // The eight conversion pieces of the previous block ride in this block's first 8 / H2_PPS steps, H2_PPS pieces (4 VALU each) per
+    // step (round 5: a VALU burst between two MFMAs costs the matrix pipe about the same whether it holds two instructions or four —
+    // measured on the fp32 kernel, gen_mlp_a.py RELU_BATCH — so fewer, larger bursts)
+#ifndef H2_PPS
+#define H2_PPS 1
+#endif
+    constexpr int CS = 8 / H2_PPS, NV = 4 * H2_PPS;
     int s = 1;      // step inside the block (static)
 #pragma unroll
     for (int t = 0; t < NX; ++t, ++s) {
-        if (CVT && s <= 8) h2_cvt_piece<CVT>(s - 1, prev, outA, outB, pblk);
+        if (CVT && s <= CS) {
+#pragma unroll
+            for (int u = 0; u < H2_PPS; ++u) h2_cvt_piece<CVT>((s - 1) * H2_PPS + u, prev, outA, outB, pblk);
+        }
         if (XMODE == 2) {
             if (t + 2 < NX) { xr[0][(t + 2) & 3] = stash[(t + 2) * 64]; xr[1][(t + 2) & 3] = stash[(H2_XS + t + 2) * 64]; }
-            if (CVT && s <= 8) { if (t + 2 < NX) h2_step<2, 4>(c, slot, xr[0][t & 3], xr[1][t & 3], acc[0], acc[1], false);
-                                 else h2_step<0, 4>(c, slot, xr[0][t & 3], xr[1][t & 3], acc[0], acc[1], false); }
+            if (CVT && s <= CS) { if (t + 2 < NX) h2_step<2, NV>(c, slot, xr[0][t & 3], xr[1][t & 3], acc[0], acc[1], false);
+                                  else h2_step<0, NV>(c, slot, xr[0][t & 3], xr[1][t & 3], acc[0], acc[1], false); }
             else { if (t + 2 < NX) h2_step<2, 0>(c, slot, xr[0][t & 3], xr[1][t & 3], acc[0], acc[1], false);
                    else h2_step<0, 0>(c, slot, xr[0][t & 3], xr[1][t & 3], acc[0], acc[1], false); }
         } else {
-            if (CVT && s <= 8) h2_step<0, 4>(c, slot, xA[t], xB[t], acc[0], acc[1], false);
+            if (CVT && s <= CS) h2_step<0, NV>(c, slot, xA[t], xB[t], acc[0], acc[1], false);
             else h2_step<0, 0>(c, slot, xA[t], xB[t], acc[0], acc[1], false);
         }
     }
 #pragma unroll
     for (int k = 0; k < NH; ++k, ++s) {
-        if (CVT && s <= 8) {
-            h2_cvt_piece<CVT>(s - 1, prev, outA, outB, pblk);
-            h2_step<0, 4>(c, slot, inA[k], inB[k], acc[0], acc[1], false);
+        if (CVT && s <= CS) {
+#pragma unroll
+            for (int u = 0; u < H2_PPS; ++u) h2_cvt_piece<CVT>((s - 1) * H2_PPS + u, prev, outA, outB, pblk);
+            h2_step<0, NV>(c, slot, inA[k], inB[k], acc[0], acc[1], false);
         } else {
             h2_step<0, 0>(c, slot, inA[k], inB[k], acc[0], acc[1], false);
         }

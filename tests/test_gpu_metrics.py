@@ -44,3 +44,26 @@ def test_ssim_frame_sized_vs_oracle_and_properties(dev):
         metrics.ssim(pred, gt)                     # CPU tensors: no fallback
     with pytest.raises(NotImplementedError):
         metrics.ssim(pred.to(dev), gt.to(dev), w_size=7)
+
+
+def test_lpips_architecture_vs_oracle_with_stand_in_weights(dev, tmp_path):
+    """SURVEY 8(f) row 4, LPIPS (utils/evaluate_images.ipynb cell 6: lpips.LPIPS(net='vgg')): neurofluid_amd.metrics.LPIPS (13 convolutions as im2col +
+    nf_gemm_f32) against the oracle's restatement of the package's architecture, with a deterministic stand-in for the pretrained state dict (same keys
+    and shapes — the real weights cannot be fetched here; with them the class computes the package's numbers).  Odd image sizes exercise the pools' floor."""
+    from neurofluid_amd import metrics
+    from oracle import metrics_oracle as mo
+    sd = mo.lpips_random_weights(seed=5)
+    path = str(tmp_path / "lpips_vgg.pt")
+    torch.save(sd, path)                              # the documented hand-over: a saved state dict
+    net = metrics.LPIPS(path, device=dev)
+    g = torch.Generator().manual_seed(2)
+    for shape in ((2, 3, 64, 64), (1, 3, 37, 50)):
+        gt = torch.rand(*shape, generator=g)
+        pred = (gt + 0.1 * torch.randn(*shape, generator=g)).clamp(0, 1)
+        want = float(mo.lpips(pred, gt, sd))
+        got = float(net(pred.to(dev), gt.to(dev)))
+        assert want > 1e-5 and abs(got - want) <= 2e-5 * want + 1e-9, (shape, got, want)
+        assert abs(float(net(gt.to(dev), gt.to(dev)))) <= 1e-12             # identical images: distance 0
+        assert abs(float(net(gt.to(dev), pred.to(dev))) - got) <= 1e-6 * got      # symmetric
+    with pytest.raises(RuntimeError):
+        net(pred, gt)                                  # CPU tensors: no fallback

@@ -32,14 +32,20 @@ def build(force=False, verbose=False):
 
 
 # generated sources: (generator script, output) — the body of nf_mlp_a.hip's asm statement is written by gen_mlp_a.py
-GENERATED = [("gen_mlp_a.py", "nf_mlp_a_body.inc")]
+# one body per feature-row shape: (qx, qd) = 8-feature groups of the position-like / direction-like features
+MLP_A_SHAPES = [(qx, qd) for qx in (8, 9, 16, 17, 24, 25) for qd in (4, 7)]
+GENERATED = [("gen_mlp_a.py", "nf_mlp_a_body_%d_%d.inc" % s, [str(s[0]), str(s[1])]) for s in MLP_A_SHAPES]
 
 
 def _generate():
-    for gen, out in GENERATED:
+    procs = []
+    for gen, out, args in GENERATED:
         gp, op = os.path.join(CSRC, gen), os.path.join(CSRC, out)
         if _stale(op, [gp]):
-            subprocess.check_call([sys.executable, gp, op], stderr=subprocess.DEVNULL)
+            procs.append(subprocess.Popen([sys.executable, gp, op] + args, stderr=subprocess.DEVNULL))
+    for p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("gen_mlp_a.py failed")
 
 
 def _build_locked(force, verbose):

@@ -25,7 +25,10 @@ def knob(name, default=0):
     return int(os.environ.get("NF_A_" + name, default))
 
 
-QX, QD = 25, 7                 # feature groups of 8 (198 + 54 features padded to 200 + 56)
+# feature groups of 8: (25, 7) = the default 198 + 54 row; the other encodings of models/renderer.py:30-44 give qx in {8, 9, 16, 17, 24, 25},
+# qd in {4, 7} (argv[2], argv[3]; nf_mlp_a.hip instantiates all twelve)
+QX, QD = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (25, 7)
+assert 1 <= QX <= 25 and 1 <= QD <= 7
 CH = 8                         # slots per chunk
 SLOT_B, CHUNK_B = 2048, 16384
 # PIPEPUB (default): the four 1 KB pieces a wave owns of chunk k + 1 are published ONE PER SLOT in slots 0..3 of chunk k (each
@@ -183,7 +186,11 @@ def build_tile():
     for k in range(64):
         slots.append(Slot("vh", 9, k))
     slots.append(Slot("vb", 9, 0))
-    assert len(slots) == 1312 and len(slots) % CH == 0 and (len(slots) // CH) % 2 == 0
+    assert len(slots) == 8 * QX + 2 * QD + 1098
+    # the ring's phase is the chunk parity and the A-operand sets alternate with the slot parity: a tile is a whole, EVEN number of chunks.
+    # Feature rows that do not give one are padded with slots that hold no MFMA (ring bookkeeping only; the stream carries zeros there)
+    while len(slots) % (2 * CH):
+        slots.append(Slot("pad", 10, 0))
     for n, s in enumerate(slots):
         s.idx = n
     return slots
@@ -328,7 +335,9 @@ def gen():
     skipb = knob("FILL_SKIP_BOUNDARY")
     ok = lambda s: not (skipb and s.idx % CH == CH - 1)        # noqa: E731
     if not knob("NOHEADS"):
-        place_fillers(slots, [s.idx for s in slots if s.kind == "x" and s.layer == 0 and ok(s)], rgb_items, fill_plan, p)
+        # (layer 1's slots take what a narrow feature row's layer 0 cannot hold: the head's registers are free until layer 8)
+        place_fillers(slots, [s.idx for s in slots if ((s.kind == "x" and s.layer == 0) or (s.kind == "h" and s.layer == 1)) and ok(s)],
+                      rgb_items, fill_plan, p)
         place_fillers(slots, [s.idx for s in slots if s.kind in ("vx", "vh") and ok(s)][:-2], sig_items, fill_plan, p)
 
     # ------------------------------------------------------------------ the slots
@@ -363,8 +372,8 @@ def emit_tile_select(p, s_tg, s_xout):
     p.i(f"s_add_u32 s{S_TILE}, s{S_TILE}, s{S_WAVE}")
     p.i(f"s_add_i32 s{S_TMP}, s{S_NTILES}, -1")
     p.i(f"s_min_i32 s{S_TILE}, s{S_TILE}, s{S_TMP}")
-    p.i(f"s_lshl_b32 s{S_TMP}, s{S_TILE}, 15")                  # tile * 32 groups * 1 KB   (low word)
-    p.i(f"s_lshr_b32 s{S_TMP + 1}, s{S_TILE}, 17")              # (high word)
+    p.i(f"s_mul_hi_u32 s{S_TMP + 1}, s{S_TILE}, {(QX + QD) * 1024}")      # tile * (QX + QD) groups * 1 KB   (high word)
+    p.i(f"s_mul_i32 s{S_TMP}, s{S_TILE}, {(QX + QD) * 1024}")             # (low word)
     p.i(f"s_add_u32 s{s_xout}, s{S_XBASE}, s{S_TMP}")
     p.i(f"s_addc_u32 s{s_xout + 1}, s{S_XBASE + 1}, s{S_TMP + 1}")
 
@@ -530,10 +539,10 @@ def emit_slot(p, slots, n, fillers, nchunks):
         for half in range(2):
             for b in range(4):
                 mf.append(mfma(HD(b), A + 4 * half + b, f"v{2 * s.k + half}", HD(b)))      # B = accA raw (xyz_encoding_final has no activation)
-    else:  # vb
+    elif s.kind == "vb":
         for b in range(4):
             mf.append(mfma(HD(b), A + b, f"v{V_ONE}", HD(b)))
-    nm = len(mf)
+    nm = len(mf)          # (a "pad" slot has none)
 
     # ---- the NEXT slot's A operands (issued early: complete at the next slot's lgkmcnt(0))
     boundary = pos == CH - 1
@@ -678,7 +687,8 @@ def main():
     if out:
         with open(out, "w") as f:
             f.write("// generated by gen_mlp_a.py — do not edit\n")
-            f.write("#define NF_A_LDS_BYTES %d\n" % LDS_BYTES)
+            f.write("#define NF_A_LDS_BYTES_%d_%d %d\n" % (QX, QD, LDS_BYTES))
+            f.write("#define NF_A_SLOTS_%d_%d %d\n" % (QX, QD, len(build_tile())))
             f.write(text)
     else:
         sys.stdout.write(text)

@@ -268,13 +268,18 @@ def pack_nerf_n(packed, cx, cd):
 RING_KERNEL = os.environ.get("NF_RING_KERNEL", "a")
 
 
+MLP_A_SHAPES = tuple((qx, qd) for qx in (8, 9, 16, 17, 24, 25) for qd in (4, 7))
+
+
 def pack_nerf_stream(packed, cx, cd, kind=None):
-    """Weight stream of the LDS-ring fp32 kernels (nf_nerf_mlp_fwd_a / _l) from the packed blob, or None when the feature
-    row is not the default 198 + 54 one (the direct-from-L2 kernel nf_nerf_mlp_fwd then serves the pass).  The tensor carries
-    the kernel it was packed for (`nf_kind`)."""
-    if ((cx + 7) // 8, (cd + 7) // 8) != (25, 7):
-        return None
+    """Weight stream of the LDS-ring fp32 kernels (nf_nerf_mlp_fwd_a / _l) from the packed blob, or None when there is no ring
+    kernel for the feature row (the direct-from-L2 kernel nf_nerf_mlp_fwd then serves the pass).  The tensor carries the kernel
+    it was packed for (`nf_kind`)."""
     kind = kind or RING_KERNEL
+    shape = ((cx + 7) // 8, (cd + 7) // 8)
+    # "a" is instantiated for every feature row the encoding flags of models/renderer.py:30-44 can give; "l" for the default one
+    if shape not in (MLP_A_SHAPES if kind == "a" else ((25, 7),)):
+        return None
     lib = _lib.load()
     if kind == "a":
         out = torch.empty(lib.nf_nerf_stream_a_floats(cx, cd), dtype=torch.float32, device=packed.device)

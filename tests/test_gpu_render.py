@@ -748,8 +748,31 @@ def test_mlp_lds_ring_kernel(dev, kind):
         a = ops.mlp_rows(pk, net.in_channels_xyz, net.in_channels_dir, xr)
         b = ops.mlp_rows(pk, net.in_channels_xyz, net.in_channels_dir, xr, wstream=wst)
         torch.testing.assert_close(b, a, rtol=1e-5, atol=3e-5)
-    # a non-default feature row has no ring variant
-    assert ops.pack_nerf_stream(pk, 63, 27) is None
+    # a non-default feature row: the hand-scheduled kernel is instantiated for it, the compiler-scheduled ring kernel is not
+    assert (ops.pack_nerf_stream(pk, 63, 27, kind=kind) is None) == (kind == "l")
+
+
+@pytest.mark.parametrize("flags", [0, 1, 2, 4, 8, 3, 5, 6, 7, 9, 10, 12, 11, 13, 14])
+def test_mlp_hand_scheduled_kernel_every_feature_row(dev, flags):
+    """nf_nerf_mlp_fwd_a is instantiated for every feature row the four encoding flags can give (models/renderer.py:30-44: cx in {63, 72, 126, 135,
+    189, 198}, cd in {27, 54}); each against the direct-from-L2 kernel nf_nerf_mlp_fwd on random rows (the two differ only in the place of the
+    bias in the fp32 sums), ragged row counts included — rows of narrow feature sets end in padding slots of the weight stream."""
+    from neurofluid_amd import ops
+    from oracle import render_oracle as ro
+    cfg = dict(ro.DEFAULT_CFG, density=bool(flags & 1), smoothed_pos=bool(flags & 2), var=bool(flags & 4), smoothed_dir=bool(flags & 8))
+    cx, cd = ro.nerf_channels(cfg)
+    st = ro.deterministic_nerf_state(prefixes=("nerf_coarse",), cfg=cfg)
+    W = [st[f"nerf_coarse.{k}.weight"].to(dev) for k in ops.NERF_LAYER_NAMES]
+    B = [st[f"nerf_coarse.{k}.bias"].to(dev) for k in ops.NERF_LAYER_NAMES]
+    pk = ops.pack_nerf(W, B, cx, cd)
+    wst = ops.pack_nerf_stream(pk, cx, cd, kind="a")
+    assert wst is not None
+    gen = torch.Generator().manual_seed(flags)
+    for n in (1, 33, 4097, 32 * 1024 + 3):
+        xr = (torch.rand(n, cx + cd, generator=gen) * 2 - 1).to(dev)
+        a = ops.mlp_rows(pk, cx, cd, xr)
+        b = ops.mlp_rows(pk, cx, cd, xr, wstream=wst)
+        torch.testing.assert_close(b, a, rtol=1e-5, atol=3e-5)
 
 
 def test_mlp_hand_scheduled_kernel_bit_equal_to_compiler_scheduled(dev):

@@ -440,7 +440,10 @@ class E2ETrainer(BaseTrainer):
                 self.tmp_fluid_error = FluidErrors()
                 for data_idx in range(len(self.dataset)):
                     data = self._frame_on_device(self.dataset, data_idx)
-                    saved = (getattr(self, 'pos_for_next_step', None), getattr(self, 'vel_for_next_step', None), np.random.get_state())
+                    # everything a redone step must start from again: the carried state and EVERY random stream the step draws from
+                    # (numpy: the pixel choice; torch CPU / device generators: noise_std / perturb draws of the renderer)
+                    saved = (getattr(self, 'pos_for_next_step', None), getattr(self, 'vel_for_next_step', None), np.random.get_state(),
+                             torch.get_rng_state(), torch.cuda.get_rng_state(self.device) if torch.cuda.is_available() else None)
                     try:
                         loss = self.train_step(data, data_idx, len(self.train_view_names), H, W, global_step)
                         self.update_step(loss, global_step)
@@ -449,6 +452,9 @@ class E2ETrainer(BaseTrainer):
                         # capacities have been raised): redo THIS step from the state and the random stream it started with
                         self.pos_for_next_step, self.vel_for_next_step = saved[0], saved[1]
                         np.random.set_state(saved[2])
+                        torch.set_rng_state(saved[3])
+                        if saved[4] is not None:
+                            torch.cuda.set_rng_state(saved[4], self.device)
                         loss = self.train_step(data, data_idx, len(self.train_view_names), H, W, global_step)
                         self.update_step(loss, global_step)
                     global_step += 1; done += 1
@@ -478,6 +484,9 @@ class E2ETrainer(BaseTrainer):
             pred_pos.register_hook(nfdist.mean_over_ranks_hook(self.world))
         log = (global_step + 1) % self.options.TRAIN.log_interval == 0
         if log:
+            # a truncated step (graph-replayed forward beyond its pair capacities) must not reach the logged metric: verify NOW on log
+            # steps (raises PairCapacityExceeded before any side effect; every other step is verified at the start of backward())
+            self.transition_model.verify_training_step()
             d = self.tmp_fluid_error.cal_errors(pred_pos.detach(), data['particles_pos_1'], data_idx + 1)
             self.summary_writer.add_scalar('Train/pred2gt_distance', d, global_step)
         rc = self.options.RENDERER.ray.ray_chunk

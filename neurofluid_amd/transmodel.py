@@ -264,6 +264,15 @@ class ParticleNet(nn.Module):
                 return self._forward_fused(pos, vel, box, box_feats)
             return self._forward_impl(pos, vel, box, box_feats, other=feats)[:3]
 
+    def verify_training_step(self):
+        """training_graph: compare the LAST graph-replayed forward's true pair totals with the capacities its graphs were captured for — now,
+        instead of at the start of backward() — and raise PairCapacityExceeded on overflow (capacities already raised).  For a caller that is
+        about to USE the step's outputs for something backward() cannot undo (a logged metric); waits for the forward replay's event."""
+        tg = self.__dict__.get("_tgraphs")
+        if self.training_graph and tg is not None and tg.key is not None and not getattr(tg, "checked", True):
+            from .autograd_bwd import _tg_check
+            _tg_check(self, tg)
+
     # ------------------------------------------------------------------
     # Fused inference step, round 3 (DESIGN.md section 6): ONE C call = prepare (integrate + fluid grid, one workgroup) ->
     # front (search of both clouds, row-entry lists, layer 0) -> three G-free continuous convolutions (gather a patch per

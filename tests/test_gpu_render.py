@@ -929,13 +929,17 @@ def test_features_backward_kernel_vs_oracle_autograd(dev):
         p0, p1, rays_c, ro_c, grid = _run_passes(net, P0.to(dev), roc.to(dev), rays.to(dev), True, True, save_acts=True)
     z_table, _ = net._tables(dev)
     R = rays.shape[0]
-    for pb, z, zt, S in ((p0, None, z_table, 64), (p1, p1.z, None, 192)):
+    # the three forms of the smoothed position: exclude_ray=True (configs), exclude_ray=False with alpha = 0.1 (num_nn <= 20: always at K = 20)
+    # and with same_smooth_factor (alpha = 0.9) — enc_flags bits 4 / 5 (models/renderer.py:100-106); the row lists do not depend on them
+    for extra, ocfg in ((0, ro.DEFAULT_CFG), (16, dict(ro.DEFAULT_CFG, exclude_ray=False)),
+                        (48, dict(ro.DEFAULT_CFG, exclude_ray=False, same_smooth_factor=True))):
+      for pb, z, zt, S in ((p0, None, z_table, 64), (p1, p1.z, None, 192)):
         n = int(pb.n_rows.item())
         assert n > 500
         dX = torch.randn(n, 252, generator=torch.Generator().manual_seed(S)).to(dev)
         dP = torch.zeros(P0.shape, device=dev)
         check(lib.nf_render_features_bwd(ptr(grid.points), ptr(rays_c), ptr(z), ptr(zt), R, S, float(net.raduis),
-                                         net.num_neighbor, net.enc_flags, ptr(ro_c), 0, ptr(pb.row_sample), ptr(pb.row_nbr),
+                                         net.num_neighbor, net.enc_flags | extra, ptr(ro_c), 0, ptr(pb.row_sample), ptr(pb.row_nbr),
                                          ptr(pb.n_rows), n, ptr(dX), ptr(dP), _lib.stream()), "nf_render_features_bwd")
         Pc = P0.clone().requires_grad_(True)
         zz = (z_table.cpu()[None].expand(R, 64) if z is None else z.cpu())
@@ -944,14 +948,14 @@ def test_features_backward_kernel_vs_oracle_autograd(dev):
             _, xyz = ro.coarse_sample_ray(9.0, 13.0, rays, 64)          # the reference's own expression (no FMA)
         dists, idx, _ = ro.search(xyz, Pc.detach(), 0.225, 20)
         nn = torch.where((idx >= 0).unsqueeze(-1), Pc[idx.clamp(min=0)], torch.zeros(1))
-        feats, _ = ro.embedding_local_geometry(dists, nn, 0.225, xyz, rays, roc)
+        feats, _ = ro.embedding_local_geometry(dists, nn, 0.225, xyz, rays, roc, ocfg)
         rows = pb.row_sample[:n].cpu().long()
         assert bool(torch.all(dists.view(-1, 20)[rows] != 0))             # the active rows are the full-K samples
         (feats[rows] * dX.cpu()).sum().backward()
         ref = Pc.grad
         rel = float((dP.cpu() - ref).norm() / ref.norm())
-        print(f"features backward, S={S}: {n} rows, relative error {rel:.2e}")
-        assert rel < 1e-4, (S, rel)
+        print(f"features backward, enc_flags | {extra}, S={S}: {n} rows, relative error {rel:.2e}")
+        assert rel < 1e-4, (extra, S, rel)
         assert torch.equal(ref.abs().sum(1) > 0, dP.cpu().abs().sum(1) > 0)
     # K <= 64 runs a wave per row, K > 64 a thread per row: the same rows through both, the neighbour lists padded to 72
     # columns with -1 for the second.  A padded entry counts as a particle at the origin in the density sums (as in the
@@ -968,16 +972,17 @@ def test_features_backward_kernel_vs_oracle_autograd(dev):
     dX = torch.randn(n, 252, generator=torch.Generator().manual_seed(7)).to(dev)
     nbr72 = torch.full((n, 72), -1, dtype=torch.int32, device=dev)
     nbr72[:, :K] = q0.row_nbr[:n * K].view(n, K)
-    got = []
-    for kk, nbr in ((K, q0.row_nbr), (72, nbr72)):
-        dP = torch.zeros(P0.shape, device=dev)
-        check(lib.nf_render_features_bwd(ptr(grid_s.points), ptr(rays_sc), None, ptr(z_table), R, 64, float(net.raduis), kk,
-                                         net.enc_flags, ptr(ro_sc), 0, ptr(q0.row_sample), ptr(nbr), ptr(q0.n_rows), n,
-                                         ptr(dX), ptr(dP), _lib.stream()), "nf_render_features_bwd")
-        got.append(dP)
-    rel72 = float((got[1] - got[0]).norm() / got[0].norm())
-    print(f"thread-per-row kernel (K = 72, padded) vs wave-per-row (K = {K}): {rel72:.2e}")
-    assert rel72 < 3e-4, rel72
+    for extra in (0, 16, 48):
+        got = []
+        for kk, nbr in ((K, q0.row_nbr), (72, nbr72)):
+            dP = torch.zeros(P0.shape, device=dev)
+            check(lib.nf_render_features_bwd(ptr(grid_s.points), ptr(rays_sc), None, ptr(z_table), R, 64, float(net.raduis), kk,
+                                             net.enc_flags | extra, ptr(ro_sc), 0, ptr(q0.row_sample), ptr(nbr), ptr(q0.n_rows), n,
+                                             ptr(dX), ptr(dP), _lib.stream()), "nf_render_features_bwd")
+            got.append(dP)
+        rel72 = float((got[1] - got[0]).norm() / got[0].norm())
+        print(f"thread-per-row kernel (K = 72, padded) vs wave-per-row (K = {K}), enc_flags | {extra}: {rel72:.2e}")
+        assert rel72 < 3e-4, rel72
 
 
 def test_fine_rendering_entry_point(dev):

@@ -233,7 +233,11 @@ __device__ __forceinline__ void h2_cvt_piece(int p, const f32x16 (&prev)[2], u32
 {
     const int tile = p >> 2, q = p & 3;
     const f32x16& a = prev[tile];
+#ifdef H2_AB_NOCVT          /* ceiling probe (garbage results): the finished block's registers taken as they are, no conversion VALU */
+    const unsigned r0 = __float_as_uint(a[4 * q]), r1 = __float_as_uint(a[4 * q + 2]);
+#else
     const unsigned r0 = h2_pk<CVT == 1>(a[4 * q], a[4 * q + 1]), r1 = h2_pk<CVT == 1>(a[4 * q + 2], a[4 * q + 3]);
+#endif
     u32x4& dst = tile ? outB[2 * blk + (q >> 1)] : outA[2 * blk + (q >> 1)];
     dst[2 * (q & 1)] = r0;
     dst[2 * (q & 1) + 1] = r1;

@@ -728,6 +728,33 @@ def test_full_frame_size_independent_properties(dev, side):
     assert ro.psnr(h["rgb1"].cpu(), full["rgb1"].cpu()) >= 45.0
 
 
+def test_full_frame_hand_scheduled_equals_compiler_scheduled(dev):
+    """The whole 400 x 400 frame (160 000 rays, ~3.1 M executed MLP rows in two launches) through RenderNet with the hand-scheduled MLP
+    kernel (ops.RING_KERNEL = "a", the default) and with the compiler-scheduled one ("l"): every key of the result dict bit-equal — the
+    two kernels are the same arithmetic in the same order, at the size and on the row lists the benchmark runs."""
+    from oracle import render_oracle as ro
+    from neurofluid_amd import ops, ray_utils
+    P = ro.watercube_particles().to(dev)
+    c2w = ro.eval_camera()
+    rays = ray_utils.get_rays_cpu(400, 400, ro.camera_focal(400), c2w).view(-1, 6).to(dev)
+    roc = c2w[:, 3].to(dev)
+    outs = {}
+    old = ops.RING_KERNEL
+    try:
+        for kind in ("a", "l"):
+            ops.RING_KERNEL = kind
+            net = make_net(dev)                      # a fresh module: its packed-weight cache holds the stream of ITS kernel
+            with torch.no_grad():
+                outs[kind] = net(P, roc, rays, None, None)
+            _, ws, _ = net.packed_for_inference(net.nerf_fine, False)
+            assert ws.nf_kind == kind
+    finally:
+        ops.RING_KERNEL = old
+    assert float(outs["a"]["mask_1"].sum()) > 1e5
+    for k in ("rgb0", "rgb1", "depth0", "depth1", "opacity0", "opacity1", "num_nn_0", "num_nn_1", "mask_0", "mask_1"):
+        assert torch.equal(outs["a"][k], outs["l"][k]), k
+
+
 @pytest.mark.parametrize("kind", ["a", "l"])
 def test_mlp_lds_ring_kernel(dev, kind):
     """A6 through nf_nerf_mlp_fwd_a (hand-scheduled, the inference default) / nf_nerf_mlp_fwd_l (weight stream shared through an

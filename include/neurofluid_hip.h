@@ -423,6 +423,9 @@ int nf_trans_front(const void* fluid_grid, const void* box_grid, const float* qu
                                          of a batch of launches completes with the batch, not behind this kernel) */,
                    uint32_t* done_counter /* device word, zero between launches */, int step_id, nf_stream_t stream);
 void* nf_pinned_device_ptr(void* host_ptr /*[host] page-locked*/);
+/* [host code] Spin until the pinned host word holds `expected` (0) or `timeout_s` seconds have passed (1): the wait for nf_trans_step's
+ * completion word (host_flag3[2]) outside the interpreter — a ctypes call releases the GIL. */
+int nf_host_wait_word(const volatile int32_t* word /*[host] page-locked*/, int32_t expected, double timeout_s);
 size_t nf_cconv_gf_packed_floats(int cin, int cout);
 int nf_cconv_gf_pack(const float* kernel, const float* dense_w, int cin, int cout, float* packed, nf_stream_t stream);
 /* split-precision form of the same contraction (nf_cconv_gf_layer(split = 1)): every operand as hi + lo fp16, three fp16 MFMAs

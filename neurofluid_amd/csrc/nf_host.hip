@@ -11,6 +11,7 @@
 // outputs), same swap order as RandomState.shuffle on a 1-D array, so the indices AND the generator state afterwards are
 // those numpy would produce (tests/test_host_logic.py checks both against numpy).
 #include "nf_common.h"
+#include <time.h>
 #include <stdlib.h>
 
 namespace {
@@ -84,6 +85,31 @@ extern "C" void* nf_pinned_device_ptr(void* host_ptr)
     void* d = nullptr;
     if (!host_ptr || hipHostGetDevicePointer(&d, host_ptr, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     return d;
+}
+
+// Host code: wait until a pinned host word (written by a kernel through its device address, nf_pinned_device_ptr) holds `expected`.
+// The caller of nf_trans_step waits for the front kernel's completion word while the convolutions behind it are still running; round 5
+// moved the spin out of the Python interpreter (a Python loop polled the word with the interpreter lock held on every rollout frame):
+// a foreign call through ctypes releases the lock, and the loop here is plain volatile loads with a pause, the clock read every 1 024 polls.
+// Returns 0 when the word arrived, 1 on timeout (the caller then synchronises the device to surface what went wrong).
+extern "C" int nf_host_wait_word(const volatile int32_t* word, int32_t expected, double timeout_s)
+{
+    if (!word) return 1;
+    unsigned spins = 0;
+    bool armed = false;
+    struct timespec t0 = {0, 0};
+    while (*word != expected) {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#endif
+        if ((++spins & 0x3ff) == 0) {
+            struct timespec now;
+            clock_gettime(CLOCK_MONOTONIC, &now);
+            if (!armed) { t0 = now; armed = true; }
+            else if ((double)(now.tv_sec - t0.tv_sec) + 1e-9 * (double)(now.tv_nsec - t0.tv_nsec) > timeout_s) return *word == expected ? 0 : 1;
+        }
+    }
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -438,17 +438,11 @@ class ParticleNet(nn.Module):
         # no runtime call): the overflow words are final then, and the three convolutions are still to run — the wait costs
         # no GPU time.  (A HIP event recorded between the launches of one batch completes with the batch.)
         flag = st["flag_np"]
-        spins, deadline = 0, None
-        while flag[2] != sid:
-            spins += 1
-            if spins & 0x3ff == 0:             # the clock is read every 1024 polls: the common case (tens of us) never reads it
-                now = _time.perf_counter()
-                if deadline is None:
-                    deadline = now + 2.0
-                elif now > deadline:           # 2 s without the word: surface whatever went wrong on the device
-                    torch.cuda.synchronize()
-                    if flag[2] != sid:
-                        raise RuntimeError("nf_trans_step: the front kernel never reported completion")
+        # (round 5: the spin runs in C, nf_host_wait_word — ctypes releases the interpreter lock for the call; a Python loop held it)
+        if lib.nf_host_wait_word(flag.ctypes.data + 8, sid, 2.0) != 0:      # 2 s without the word: surface whatever went wrong on the device
+            torch.cuda.synchronize()
+            if flag[2] != sid:
+                raise RuntimeError("nf_trans_step: the front kernel never reported completion")
         if flag[0] or flag[1]:
             return self._fused_overflow(st, pos, vel, box, box_feats)
         self.num_fluid_neighbors = nn

@@ -426,6 +426,14 @@ void* nf_pinned_device_ptr(void* host_ptr /*[host] page-locked*/);
 /* [host code] Spin until the pinned host word holds `expected` (0) or `timeout_s` seconds have passed (1): the wait for nf_trans_step's
  * completion word (host_flag3[2]) outside the interpreter — a ctypes call releases the GIL. */
 int nf_host_wait_word(const volatile int32_t* word /*[host] page-locked*/, int32_t expected, double timeout_s);
+
+/* B8 glue (round 5): the elementwise / reduction steps between the launches of the transition model's backward.
+ * nf_relu_bwd_add: out = (prev > 0 ? dx : 0) + (res or 0) — the ReLU in front of a layer back-propagated (+ the residual branch), n floats.
+ * nf_colsum: out[c] (and out2[c] if given) = sum_r a[r * lda + c] — bias gradients; deterministic.
+ * nf_cconv_split_db: dB (Cin x 65*Cout) -> dK (64, Cin, Cout) filter gradient + dW (Cout, Cin) Linear gradient (models/transmodel.py:116-131). */
+int nf_relu_bwd_add(const float* dx, const float* prev, const float* res /*or NULL*/, float* out, int64_t n, nf_stream_t stream);
+int nf_colsum(const float* a, int rows, int cols, int lda, float* out, float* out2 /*or NULL*/, nf_stream_t stream);
+int nf_cconv_split_db(const float* dB, int cin, int cout, float* dK, float* dW, nf_stream_t stream);
 size_t nf_cconv_gf_packed_floats(int cin, int cout);
 int nf_cconv_gf_pack(const float* kernel, const float* dense_w, int cin, int cout, float* packed, nf_stream_t stream);
 /* split-precision form of the same contraction (nf_cconv_gf_layer(split = 1)): every operand as hi + lo fp16, three fp16 MFMAs

@@ -120,6 +120,9 @@ PROTOTYPES = {
     "nf_trans_front": (c_int, [c_void_p] * 5 + [c_int, c_float, c_float, c_int, c_int, c_int] + [c_void_p] * 13 + [c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "nf_pinned_device_ptr": (c_void_p, [c_void_p]),
     "nf_host_wait_word": (c_int, [c_void_p, c_int, ctypes.c_double]),
+    "nf_relu_bwd_add": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "nf_colsum": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "nf_cconv_split_db": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "nf_cconv_gf_packed_floats": (c_size_t, [c_int, c_int]),
     "nf_cconv_gf_pack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "nf_cconv_gf_plan": (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int),

@@ -258,15 +258,17 @@ def _trans_backward(pn, aux, box_feats_c, in_grad, g_pos, g_vel):
                   "nf_cconv_gather_bwd")
             dB = ops.gemm(prev.t(), dG, relu_a=True)                 # relu(prev)^T dG: (Cin, 65*Cout), split-K over the particles
             cin = prev.shape[1]
-            grads[conv.kernel] = dB[:, :64 * cout].reshape(cin, 64, cout).permute(1, 0, 2).reshape(conv.kernel.shape)
-            grads[dense.weight] = dB[:, 64 * cout:].t().contiguous()
-            grads[conv.bias] = dy.sum(0)
-            grads[dense.bias] = grads[conv.bias].clone()
+            # round 5: the glue between the launches as HIP kernels (nf_host.hip) instead of ~8 ATen launches per layer
+            gK, gW = torch.empty_like(conv.kernel), torch.empty_like(dense.weight)
+            check(lib.nf_cconv_split_db(ptr(dB), cin, cout, ptr(gK), ptr(gW), st), "nf_cconv_split_db")
+            gb, gb2 = torch.empty(cout, dtype=torch.float32, device=dev), torch.empty(cout, dtype=torch.float32, device=dev)
+            check(lib.nf_colsum(ptr(dy), n, cout, cout, ptr(gb), ptr(gb2), st), "nf_colsum")
+            grads[conv.kernel], grads[dense.weight], grads[conv.bias], grads[dense.bias] = gK, gW, gb, gb2
             dx = ops.gemm(dG, _virtual_b(conv.kernel, dense.weight).t())      # (n, Cin)
-            dprev = torch.ops.aten.threshold_backward(dx, prev, 0.0)  # dx where prev > 0, else 0 (one kernel)
-            if dense.out_features == prev.shape[-1]:
-                dprev = dprev + dy                                   # residual branch (transmodel.py:127-128)
-            dy = dprev.contiguous()
+            dprev = torch.empty_like(dx)        # dx where prev > 0, + dy on the residual branch (transmodel.py:127-128)
+            check(lib.nf_relu_bwd_add(ptr(dx), ptr(prev), ptr(dy) if dense.out_features == prev.shape[-1] else None, ptr(dprev),
+                                      dx.numel(), st), "nf_relu_bwd_add")
+            dy = dprev
         # layer 0: dy is d[obstacle(32) | fluid(32) | dense0(32)]
         ff = aux["fluid_feats"]
         c0f, c0o, d0 = pn.conv0_fluid, pn.conv0_obstacle, pn.dense0_fluid
@@ -288,8 +290,10 @@ def _trans_backward(pn, aux, box_feats_c, in_grad, g_pos, g_vel):
             dB0 = ops.gemm(ff.t(), dG0[:, :64 * 32])
             dKf = dB0.reshape(cin0, 64, 32).permute(1, 0, 2).reshape(c0f.kernel.shape).contiguous()
         grads[c0o.kernel], grads[c0f.kernel] = dKo, dKf
-        grads[c0o.bias], grads[c0f.bias] = dy[:, :32].sum(0), dy[:, 32:64].sum(0)
-        grads[d0.weight], grads[d0.bias] = ops.gemm(dy[:, 64:].t(), ff), dy[:, 64:].sum(0)
+        gb0 = torch.empty(96, dtype=torch.float32, device=dev)
+        check(lib.nf_colsum(ptr(dy), n, 96, 96, ptr(gb0), None, st), "nf_colsum")
+        grads[c0o.bias], grads[c0f.bias] = gb0[:32], gb0[32:64]
+        grads[d0.weight], grads[d0.bias] = ops.gemm(dy[:, 64:].t(), ff), gb0[64:]
         # input gradients (2-step unrolls, trainer_transmodel.py): through integrate/update and the velocity features
         g_in_pos = g_in_vel = None
         if in_grad[0]:

@@ -235,3 +235,79 @@ extern "C" int nf_e2e_loss(const float* rgb0, const float* rgb1, const float* rg
     NF_CHECK_LAUNCH();
     return NF_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Round 5: the glue between the HIP launches of the transition model's backward (autograd_bwd._trans_backward) as three small kernels
+// instead of ~25 ATen launches per step (threshold_backward, add, contiguous, sum(0), clone, reshape / permute copies).
+// ------------------------------------------------------------------------------------------------
+// out = (prev > 0 ? dx : 0) [+ res]: the ReLU in front of a layer (models/transmodel.py:121), back-propagated, plus the residual branch's
+// gradient (:127-128).  Row-major contiguous, n elements.
+__global__ void __launch_bounds__(256) k_relu_bwd_add(const float* __restrict__ dx, const float* __restrict__ prev, const float* __restrict__ res,
+                                                      float* __restrict__ out, long long n)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float v = prev[i] > 0.f ? dx[i] : 0.f;
+    if (res) v += res[i];
+    out[i] = v;
+}
+
+extern "C" int nf_relu_bwd_add(const float* dx, const float* prev, const float* res, float* out, int64_t n, nf_stream_t stream)
+{
+    NF_CHECK_ARG(dx && prev && out && n >= 0, "bad arguments");
+    if (n == 0) return NF_OK;
+    hipLaunchKernelGGL(k_relu_bwd_add, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dx, prev, res, out, (long long)n);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+// Column sums of a (rows x cols) row-major matrix with leading dimension lda (a column slice of a wider matrix is fine): the bias
+// gradients.  One workgroup per 16 columns, 16 x 16 threads: thread (r, c) walks rows r, r + 16, ... of its column, then a fixed tree
+// over the 16 partial sums in LDS — deterministic.  out2 (optional) receives a second copy (conv.bias and dense.bias of a layer get the
+// same gradient).
+__global__ void __launch_bounds__(256) k_colsum(const float* __restrict__ a, int rows, int cols, int lda, float* __restrict__ out, float* __restrict__ out2)
+{
+    __shared__ float part[16][17];
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15), r0 = threadIdx.x >> 4;
+    float s = 0.f;
+    if (c < cols)
+        for (int r = r0; r < rows; r += 16) s += a[(size_t)r * lda + c];
+    part[r0][threadIdx.x & 15] = s;
+    __syncthreads();
+    if (r0 == 0 && c < cols) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += part[k][threadIdx.x & 15];
+        out[c] = t;
+        if (out2) out2[c] = t;
+    }
+}
+
+extern "C" int nf_colsum(const float* a, int rows, int cols, int lda, float* out, float* out2, nf_stream_t stream)
+{
+    NF_CHECK_ARG(a && out && rows >= 0 && cols > 0 && lda >= cols, "bad arguments");
+    hipLaunchKernelGGL(k_colsum, dim3((cols + 15) / 16), dim3(256), 0, (hipStream_t)stream, a, rows, cols, lda, out, out2);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+// dB (Cin x 65*Cout: the gradient of [filter as (Cin x 64*Cout) | dense_w^T]) -> the filter's gradient in its own layout (64 cells, Cin, Cout)
+// and the Linear weight's (Cout, Cin): what `dB[:, :64*Cout].reshape(Cin, 64, Cout).permute(1, 0, 2)` and `dB[:, 64*Cout:].t()` copied.
+__global__ void __launch_bounds__(256) k_cconv_split_db(const float* __restrict__ dB, int cin, int cout, float* __restrict__ dK, float* __restrict__ dW)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, w = 65 * cout;
+    if (i >= cin * w) return;
+    const int ci = i / w, col = i % w;
+    const float v = dB[i];
+    if (col < 64 * cout) dK[((size_t)(col / cout) * cin + ci) * cout + col % cout] = v;
+    else dW[(size_t)(col - 64 * cout) * cin + ci] = v;
+}
+
+extern "C" int nf_cconv_split_db(const float* dB, int cin, int cout, float* dK, float* dW, nf_stream_t stream)
+{
+    NF_CHECK_ARG(dB && dK && dW && cin > 0 && cout > 0, "bad arguments");
+    const int n = cin * 65 * cout;
+    hipLaunchKernelGGL(k_cconv_split_db, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, dB, cin, cout, dK, dW);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}

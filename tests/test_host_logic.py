@@ -372,3 +372,45 @@ def test_bench_without_a_gpu_fails_with_a_message_not_an_assert():
                            capture_output=True, text=True, timeout=300, env=env, cwd=root)
         assert r.returncode != 0
         assert "MI355X" in r.stderr and "Traceback" not in r.stderr, r.stderr[-2000:]
+
+
+# ------------------------------------------------------------------------------------------------
+# the generator of the hand-scheduled MLP kernel (neurofluid_amd/csrc/gen_mlp_a.py): structure checks that need no GPU
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("qx,qd", [(25, 7), (25, 4), (24, 7), (17, 4), (8, 4), (9, 7)])
+def test_mlp_asm_generator_structure(qx, qd, tmp_path):
+    """gen_mlp_a.py for a feature-row shape: the instruction stream holds exactly the MFMAs of one tile (8 per 8-block K-step, 4 per view-branch
+    half-step), a tile is a whole EVEN number of 8-slot chunks (ring phase = chunk parity; narrow rows end in padding slots), the LDS fits, every
+    counted wait is within the 6-bit vmcnt, every accumulator range is one of the three sets, and one s_barrier per chunk + the prologue's."""
+    import re
+    import subprocess
+    import sys as _sys
+    gen = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "neurofluid_amd", "csrc", "gen_mlp_a.py")
+    out = str(tmp_path / "body.inc")
+    r = subprocess.run([_sys.executable, gen, out, str(qx), str(qd)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    text = open(out).read()
+    lines = [ln[1:-3] for ln in text.splitlines() if ln.startswith('"')]
+    slots = 8 * qx + 2 * qd + 1098
+    padded = (slots + 15) // 16 * 16
+    assert f"#define NF_A_SLOTS_{qx}_{qd} {padded}" in text
+    lds = int(re.search(rf"#define NF_A_LDS_BYTES_{qx}_{qd} (\d+)", text).group(1))
+    assert lds == 2 * 16384 + 4 * qx * 1024 + 2560 and lds <= 160 * 1024
+    mf = [ln for ln in lines if ln.startswith("v_mfma_f32_32x32x2_f32")]
+    assert len(mf) == 8 * (8 * qx + 9 + 8 * 128) + 4 * (4 * qd + 128 + 1)
+    for ln in mf:          # destinations: accA v[16b:16b+15], accB a[16b:...], view accumulators a[128+16b:...]
+        m = re.match(r"v_mfma_f32_32x32x2_f32 ([va])\[(\d+):(\d+)\], v(\d+), ([va])(\d+), (0|[va]\[\d+:\d+\])$", ln)
+        assert m, ln
+        lo, hi = int(m.group(2)), int(m.group(3))
+        assert hi == lo + 15 and lo % 16 == 0 and lo < (128 if m.group(1) == "v" else 192)
+        assert 128 <= int(m.group(4)) < 144                     # A operands: the two operand sets
+    assert sum(ln == "s_barrier" for ln in lines) == padded // 8 + 1
+    for ln in lines:
+        m = re.match(r"s_waitcnt vmcnt\((\d+)\)", ln)
+        if m:
+            assert int(m.group(1)) < 64
+    assert not any("None" in ln for ln in lines)
+    # every global_load of the ring refill is followed, later in its chunk cycle, by exactly one publish of the same staging quad
+    refill = [ln for ln in lines if ln.startswith("global_load_dwordx4") and ", v177, s[42:43]" in ln]
+    publish = [ln for ln in lines if ln.startswith("ds_write_b128 v177")]
+    assert len(publish) == 4 * (padded // 8) and len(refill) == len(publish) + 8      # + the prologue's chunks 0 and 1

@@ -154,21 +154,17 @@ def mfma(dst, a, b, c):
 # the slot list of one tile
 # ------------------------------------------------------------------------------------------------------------------------
 class Slot:
-    __slots__ = ("kind", "layer", "k", "mf", "pre", "gap", "post", "idx")
+    """One 2 KB slot of the weight stream = one K-step of an 8-block layer ("x": X operand, "h": hidden operand, "b": bias), two half-steps of the
+    4-block view branch ("vx", "vh", "vb") or a padding slot ("pad"); `k` = its index inside its part, `idx` = its index inside the tile."""
+    __slots__ = ("kind", "layer", "k", "idx")
 
     def __init__(self, kind, layer, k):
         self.kind, self.layer, self.k = kind, layer, k
-        self.mf = []                        # MFMA texts
-        self.pre = []                       # before the first MFMA
-        self.gap = [[] for _ in range(8)]   # gap[i]: behind MFMA i
-        self.post = []
 
 
-def layer_sets(layer):
-    """(dst accessor, src accessor or None, src is VGPR) of the 9 eight-block layers: 0 -> A, 1 -> B, 2 -> A, ..."""
-    if layer % 2 == 0:
-        return ACC_A, "B"
-    return ACC_B, "A"
+def layer_dst(layer):
+    """Accumulator set the 8-block layer `layer` writes: 0 -> accA, 1 -> accB, 2 -> accA, ... (its hidden operand is the other set)."""
+    return ACC_A if layer % 2 == 0 else ACC_B
 
 
 def build_tile():
@@ -194,12 +190,6 @@ def build_tile():
     for n, s in enumerate(slots):
         s.idx = n
     return slots
-
-
-def relu_src(layer, k):
-    """Instructions that put relu(src[k]) of hidden layer `layer` into VB[...]: src = the other accumulator set."""
-    b, r = divmod(k, 16)
-    return b, r
 
 
 def gen():
@@ -520,7 +510,7 @@ def emit_slot(p, slots, n, fillers, nchunks):
     # ---- MFMAs
     mf = []
     if s.kind in ("x", "h", "b"):
-        dst, _ = layer_sets(s.layer)
+        dst = layer_dst(s.layer)
         first = (s.kind == "x" and s.k == 0) or (s.kind == "h" and s.k == 0 and s.layer != 4)
         if s.kind == "x":
             bop = f"v{XV[(s.k // 4) & 1] + (s.k & 3)}"

@@ -779,6 +779,39 @@ def test_mlp_lds_ring_kernel(dev, kind):
     assert (ops.pack_nerf_stream(pk, 63, 27, kind=kind) is None) == (kind == "l")
 
 
+def test_mlp_hand_scheduled_kernel_under_contention(dev):
+    """The generated stream counts its own waits (vmcnt / lgkmcnt) and synchronises its four waves by hand: a missing wait would be a TIMING bug, invisible
+    on an idle chip.  So: the kernel on one stream while a second stream saturates HBM and the L2 with 1 GB copies (its weight-stream refills and X loads
+    then take several times longer), twelve times, two launches in flight back to back — every result bit-equal to the compiler-scheduled kernel's, run alone."""
+    from neurofluid_amd import ops, _lib
+    from neurofluid_amd._lib import check, ptr
+    lib = _lib.load()
+    net = make_net(dev)
+    pk = net.packed_weights(net.nerf_fine)
+    wa, wl = ops.pack_nerf_stream(pk, 198, 54, kind="a"), ops.pack_nerf_stream(pk, 198, 54, kind="l")
+    n = 32 * 1024 * 2 + 1234
+    gen = torch.Generator().manual_seed(21)
+    X = ((torch.rand((n + 31) // 32 * 32 * 256, generator=gen) * 2 - 1)).to(dev)
+    rs = torch.arange(n, dtype=torch.int32, device=dev)
+    n_rows = torch.tensor([n], dtype=torch.int32, device=dev)
+    ref = torch.empty(n, 4, device=dev)
+    check(lib.nf_nerf_mlp_fwd_l(ptr(pk), ptr(wl), 198, 54, ptr(X), ptr(n_rows), n, ptr(rs), ptr(ref), _lib.stream()), "ref")
+    torch.cuda.synchronize()
+    big_a, big_b = torch.empty(1 << 28, device=dev), torch.ones(1 << 28, device=dev)
+    side = torch.cuda.Stream(device=dev)
+    outs = [torch.full((n, 4), -1.0, device=dev) for _ in range(2)]
+    for rep in range(12):
+        with torch.cuda.stream(side):
+            for _ in range(6):
+                big_a.copy_(big_b)
+        for o in outs:
+            o.fill_(-1.0)
+            check(lib.nf_nerf_mlp_fwd_a(ptr(pk), ptr(wa), 198, 54, ptr(X), ptr(n_rows), n, ptr(rs), ptr(o), _lib.stream()), "asm")
+        torch.cuda.synchronize()
+        for o in outs:
+            assert torch.equal(o, ref), (rep, float((o - ref).abs().max()))
+
+
 @pytest.mark.parametrize("flags", [0, 1, 2, 4, 8, 3, 5, 6, 7, 9, 10, 12, 11, 13, 14])
 def test_mlp_hand_scheduled_kernel_every_feature_row(dev, flags):
     """nf_nerf_mlp_fwd_a is instantiated for every feature row the four encoding flags can give (models/renderer.py:30-44: cx in {63, 72, 126, 135,

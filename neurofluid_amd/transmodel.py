@@ -148,6 +148,32 @@ class _PitchedNeighbors:
     neighbors_distance = property(lambda self: self._build()[2])
 
 
+class AsyncStep:
+    """A ParticleNet inference step in flight (ParticleNet.step_async)."""
+
+    def __init__(self, pn, handle, out, stream, event):
+        self.pn, self.handle, self.out, self.stream, self.event = pn, handle, out, stream, event
+
+    def result(self):
+        """(pos, vel, num_fluid_neighbors) of the step, usable on the caller's CURRENT stream."""
+        pn = self.pn
+        if pn._async_pending is not self:
+            raise RuntimeError("AsyncStep.result: this step was already consumed")
+        pn._async_pending = None
+        if self.out is None:
+            with torch.no_grad(), torch.cuda.stream(self.stream):
+                self.out = pn._fused_finish(self.handle)       # (an overflowing step is redone on the exact path, on the step's stream)
+                self.event = torch.cuda.Event()
+                self.event.record(self.stream)
+            self.handle = None
+        cur = torch.cuda.current_stream(self.out[0].device)
+        cur.wait_event(self.event)
+        for t in self.out:
+            if torch.is_tensor(t):
+                t.record_stream(cur)            # allocated on the step's stream, consumed on the caller's
+        return self.out
+
+
 class ParticleNet(nn.Module):
     def __init__(self, kernel_size=[4, 4, 4], radius_scale=1.5, coordinate_mapping='ball_to_cube_volume_preserving',
                  interpolation='linear', use_window=True, particle_radius=0.025, timestep=1 / 50,
@@ -205,6 +231,7 @@ class ParticleNet(nn.Module):
         # beyond), "grid", "all_pairs".  Same neighbour sets and counts; the order inside a row differs (cell order / index order)
         self.fused_search = "auto"
         self._fused, self._fused_skip = None, 0
+        self._async_pending = None          # the AsyncStep in flight (step_async), if any
         self._lib_cached = None
 
     _window_poly6 = staticmethod(_window_poly6)
@@ -259,6 +286,8 @@ class ParticleNet(nn.Module):
                 if out is not None:
                     return out
             return particle_net_with_grad(self, pos, vel, box, box_feats, feats)
+        if self._async_pending is not None and self._async_pending.handle is not None:
+            raise RuntimeError("ParticleNet.forward: an AsyncStep is in flight (its scratch is the module's): consume it with result() first")
         with torch.no_grad():
             if feats is None and self.fused_inference and self._fused_ok(pos, box):
                 return self._forward_fused(pos, vel, box, box_feats)
@@ -400,6 +429,38 @@ class ParticleNet(nn.Module):
         return None
 
     def _forward_fused(self, pos, vel, box, box_feats):
+        return self._fused_finish(self._fused_enqueue(pos, vel, box, box_feats))
+
+    def step_async(self, pos, vel, box, box_feats, stream=None, wait_current=True):
+        """One inference step ENQUEUED on `stream` (default: the current one) without waiting for its completion word: returns an
+        AsyncStep whose result() does the wait (and the exact-path redo of an overflowing step) and hands (pos, vel, num_neighbors) to the
+        caller's current stream.  Round 5: a rollout enqueues the step of frame t + 1 on a side stream while frame t renders — the step
+        depends on the previous state only (eval_e2e.py:58-134), and its 0.18 ms then run in the idle tails of the renderer's persistent
+        MLP launches instead of in front of the next frame (neurofluid_amd/rollout.py).  ONE step may be pending per module (the fused
+        step's scratch and flag words are the module's).  wait_current=False: the inputs are already complete for `stream` (they were produced on
+        it, or long ago) — the step then does NOT queue behind what the caller's stream still has in flight, which is the point of a lookahead."""
+        if self._async_pending is not None:
+            raise RuntimeError("ParticleNet.step_async: the previous AsyncStep has not been consumed (call its result())")
+        cur = torch.cuda.current_stream(pos.device)
+        stream = stream or cur
+        ev_in = None
+        if wait_current and stream is not cur:
+            ev_in = torch.cuda.Event()
+            ev_in.record(cur)                   # the inputs are complete on the caller's stream here
+        with torch.no_grad(), torch.cuda.stream(stream):
+            if ev_in is not None:
+                stream.wait_event(ev_in)
+            if self.fused_inference and self._fused_ok(pos, box):
+                handle, out = self._fused_enqueue(pos, vel, box, box_feats), None
+            else:                               # clouds / settings the fused step does not serve: the ordinary forward, on that stream
+                handle, out = None, self.forward(pos, vel, box, box_feats)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+        step = AsyncStep(self, handle, out, stream, ev)
+        self._async_pending = step
+        return step
+
+    def _fused_enqueue(self, pos, vel, box, box_feats):
         # The host side of a step is on the critical path of a rollout (it must fit behind the ~100 us of GPU work that follow
         # the front kernel): nothing here allocates or converts unless an input really needs it.
         lib = self._lib_cached
@@ -434,6 +495,12 @@ class ParticleNet(nn.Module):
                                st["flag_dev"], sid, torch.cuda.current_stream().cuda_stream)
         if rc != 0:
             check(rc, "nf_trans_step")
+        return st, sid, pos, vel, box, box_feats, nn, pos_c, vel_c
+
+    def _fused_finish(self, handle):
+        """Second half of a fused step: wait for its completion word, redo it on the exact path if a neighbour row overflowed."""
+        st, sid, pos, vel, box, box_feats, nn, pos_c, vel_c = handle
+        lib = self._lib_cached
         # The front kernel's last workgroup writes `sid` into a pinned word; the host spins on that word (plain memory reads,
         # no runtime call): the overflow words are final then, and the three convolutions are still to run — the wait costs
         # no GPU time.  (A HIP event recorded between the launches of one batch completes with the batch.)

@@ -892,3 +892,46 @@ def test_fused_step_search_at_the_all_pairs_limit(dev):
             order = np.lexsort((idx, rows))
             assert np.array_equal(idx[order], oi) and np.array_equal(d2[order], od2)
             assert not np.array_equal(idx, oi)
+
+
+def test_lookahead_rollout_bit_equal_to_sequential():
+    """neurofluid_amd/rollout.py::CoupledRollout (the step of frame t + 1 enqueued on a side stream while frame t is consumed; ParticleNet.step_async):
+    30 frames with a restart from the initial cloud every 8 — positions, velocities and neighbour counts bit-equal to the plain sequential loop's, with
+    renderer-sized work on the main stream between the frames (so that the side stream really runs beside something), and the guards: one step in
+    flight per module, forward() refused while one is."""
+    from neurofluid_amd.rollout import CoupledRollout
+    from neurofluid_amd.transmodel import ParticleNet
+    from oracle import render_oracle as ro, trans_oracle as to
+    dev = torch.device("cuda:0")
+    P0 = ro.watercube_particles().to(dev)
+    V0 = torch.zeros_like(P0)
+    box, bn = [t.to(dev) for t in to.watercube_box()]
+    pn = ParticleNet(gravity=(0, 0, -9.81))
+    pn.load_state_dict(to.deterministic_transition_state(), strict=False)
+    pn = pn.to(dev)
+    # sequential reference
+    seq = []
+    with torch.no_grad():
+        p, v = P0, V0
+        for k in range(30):
+            if k % 8 == 0:
+                p, v = P0, V0
+            p, v, n = pn(p, v, box, bn)
+            seq.append((p.clone(), v.clone(), n.clone()))
+    pn2 = ParticleNet(gravity=(0, 0, -9.81))
+    pn2.load_state_dict(to.deterministic_transition_state(), strict=False)
+    pn2 = pn2.to(dev)
+    roll = CoupledRollout(pn2, box, bn, device=dev)
+    busy_a, busy_b = torch.randn(4096, 4096, device=dev), torch.randn(4096, 4096, device=dev)
+    roll.start(P0, V0)
+    with pytest.raises(RuntimeError), torch.no_grad():
+        pn2(P0, V0, box, bn)                        # a step is in flight: the module's scratch is taken
+    with pytest.raises(RuntimeError):
+        pn2.step_async(P0, V0, box, bn)
+    for k in range(30):
+        p, v, n = roll.next_state(then=(P0, V0) if (k + 1) % 8 == 0 else None)
+        (busy_a @ busy_b).sum()                     # main-stream work the lookahead step runs beside
+        assert torch.equal(p, seq[k][0]) and torch.equal(v, seq[k][1]) and torch.equal(n, seq[k][2]), k
+    roll.drop()
+    with torch.no_grad():
+        pn2(P0, V0, box, bn)                        # at rest again

@@ -581,12 +581,18 @@ class E2EEvaluator(BaseTrainer):
         self.transition_model.eval(); self.renderer.eval()
         dists, psnrs = [], []
         self.fluid_error = FluidErrors()
+        from .rollout import CoupledRollout
+        roll = None
         with torch.no_grad():
             for data_idx in range(len(self.test_dataset)):
                 data = self._to_dev(self.test_dataset[data_idx])
                 if data_idx == 0:
-                    pos, vel = data['particles_pos'], data['particles_vel']
-                pos, vel, _ = self.transition_model(pos, vel, data['box'], data['box_normals'])
+                    # the rollout (eval_e2e.py:75-84: pos, vel = transition_model(pos, vel, box, box_normals) in front of every frame) with the step
+                    # of frame t + 1 in flight on a side stream while frame t is measured, dumped and rendered (rollout.CoupledRollout: same
+                    # states bit for bit).  The container of a scene is static (datasets: one box.pt per scene): the first frame's is kept.
+                    roll = CoupledRollout(self.transition_model, data['box'], data['box_normals'], device=self.device)
+                    roll.start(data['particles_pos'], data['particles_vel'])
+                pos, vel, _ = roll.next_state()
                 dists.append(self.fluid_error.cal_errors(pos, data['particles_pos_1'], data_idx + 1))
                 if dump and self.rank == 0:
                     for sub, p, col in (('Pred', pos, (255, 0, 0)), ('GT', data['particles_pos_1'], (3, 168, 158))):
@@ -603,6 +609,8 @@ class E2EEvaluator(BaseTrainer):
                             if dump and self.rank == 0:
                                 self._write_png(self.vis_rgbs(data['rgb_1'][v], test=True), f'{self.imgpath}/{lvl}/{view}/GT/{data_idx + 1:05d}.png')
                                 self._write_png(self.vis_rgbs(ret[key], test=True), f'{self.imgpath}/{lvl}/{view}/Pred/{data_idx + 1:05d}.png')
+        if roll is not None:
+            roll.drop()
         if dump and self.rank == 0:
             import joblib
             joblib.dump({'dist': dists}, osp.join(self.exppath, 'pred2gt.pt'))

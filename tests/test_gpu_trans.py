@@ -932,6 +932,14 @@ def test_lookahead_rollout_bit_equal_to_sequential():
         p, v, n = roll.next_state(then=(P0, V0) if (k + 1) % 8 == 0 else None)
         (busy_a @ busy_b).sum()                     # main-stream work the lookahead step runs beside
         assert torch.equal(p, seq[k][0]) and torch.equal(v, seq[k][1]) and torch.equal(n, seq[k][2]), k
+    # a long run does not accumulate memory (outputs cross streams: record_stream'ed blocks must come back to the allocator)
+    torch.cuda.synchronize()
+    m0 = torch.cuda.memory_allocated(dev)
+    for k in range(200):
+        p, v, n = roll.next_state(then=(P0, V0) if (k + 1) % 8 == 0 else None)
+    torch.cuda.synchronize()
+    del p, v, n
+    assert torch.cuda.memory_allocated(dev) - m0 < (1 << 20), torch.cuda.memory_allocated(dev) - m0
     roll.drop()
     with torch.no_grad():
         pn2(P0, V0, box, bn)                        # at rest again

@@ -738,17 +738,21 @@ def main():
         n_roll = 24
         hst = {}
 
+        roll_h = CoupledRollout(pn_h, box, bn, device=dev)      # the step one frame ahead on a side stream, as in the headline loop
+
         def rollout():
-            pos, vel = Ph.clone(), torch.zeros_like(Ph)
             per = []
             with torch.no_grad():
+                roll_h.start(Ph.clone(), torch.zeros_like(Ph))
+                sync()
                 for _ in range(n_roll):
                     t7 = time.perf_counter()
-                    pos, vel, _ = pn_h(pos, vel, box, bn)
+                    pos, vel, _ = roll_h.next_state()
                     out_h = render_image(net_h, pos, n8, roc, rays8, None, None, iseval=True, ray_chunk=1024, gather=False,
                                          device_chunk=device_chunk)
                     sync()
                     per.append(time.perf_counter() - t7)
+                roll_h.drop()
             hst["per"], hst["final"], hst["hit"] = per, pos, float((out_h["mask_1"] > 0).float().mean())
         rollout()                               # learns row capacities / pitches along the trajectory
         redo0, ovf0 = getattr(net_h, "capacity_redos", 0), getattr(pn_h, "fused_overflows", 0)

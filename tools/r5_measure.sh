@@ -16,7 +16,7 @@ strong)
       NF_BENCH_SINGLE_DEVICE=1 python bench.py --gpus $n --image $img --steps 2 --warmup 1 --no-extras 2>> $O/r5_strong.err | tail -1 > $O/r5_strong_${img}_w${n}.json
   done; done; ls -la $O/r5_strong_* ;;
 pmc)
-  RB="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extras --steps 3 --warmup 1"
+  RB="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extras --steps 8 --warmup 3"
   for mode in fp32 split; do
     TR="python $GRAFT_REPO_ROOT/tools/trans_perf.py 30 $mode"
     bash tools/prof.sh r5_stats_trans_$mode $TR > /dev/null

@@ -723,7 +723,7 @@ def main():
         bunny = {"workload": "one 800x800 frame (640 000 rays) of the bunny-shaped cloud, %d particles in random index order, grid rebuilt "
                              "every frame, fp32 path" % Pb.shape[0],
                  "ms_per_frame": dtb * 1e3, "rays_per_sec": n8 / dtb, "executed_mlp_rows_per_frame": rws / 3,
-                 "roofline": {"bound": "mfma", "kernel": "k_mlp_fwd_l", "achieved": tfb, "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                 "roofline": {"bound": "mfma", "kernel": "k_mlp_fwd_" + ops.RING_KERNEL, "achieved": tfb, "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": tfb / F32_MATRIX_PEAK_TFLOPS, "mlp_ms_per_frame": ms / 3, "flop_per_row": MLP_FLOP_PER_ROW}}
         del net_b
         # (b) config 5's body: rollout + fp16 render of the predicted cloud
@@ -775,7 +775,7 @@ def main():
                  "transition_steps_redone_on_the_exact_path": int(getattr(pn_h, "fused_overflows", 0) - ovf0),
                  "renderer_calls_redone_for_row_capacity": int(getattr(net_h, "capacity_redos", 0) - redo0),
                  "first_pass": {"transition_steps_redone": int(ovf0), "renderer_calls_redone": int(redo0)},
-                 "roofline": {"bound": "mfma", "kernel": "k_mlp_fwd_h2 (v_mfma_f32_32x32x16_f16)", "achieved": tfh, "peak": F16_MATRIX_PEAK_TFLOPS,
+                 "roofline": {"bound": "mfma", "kernel": "k_mlp_fwd_%s (v_mfma_f32_32x32x16_f16%s)" % (ops.FP16_KERNEL, ", hand-scheduled" if ops.FP16_KERNEL == "ha" else ""), "achieved": tfh, "peak": F16_MATRIX_PEAK_TFLOPS,
                               "unit": "TFLOP/s", "frac": tfh / F16_MATRIX_PEAK_TFLOPS, "mlp_ms_per_frame": msh / n_roll,
                               "flop_per_row": MLP_FLOP_PER_ROW}}
         cfg45_extra = {"bunny_800_fp32": bunny, "honeycone_800_fp16_rollout": honey}

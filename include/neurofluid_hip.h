@@ -201,6 +201,10 @@ size_t nf_nerf_packed_h2_bytes(void);
 int nf_nerf_pack_h2(const nf_nerf_params_t* params, int cx, int cd, void* stream_h2, nf_stream_t stream);
 int nf_nerf_mlp_fwd_h2(const void* stream_h2, int cx, int cd, const void* X, const int32_t* n_rows, int max_rows,
                        const int32_t* row_sample, float* rgbsigma, nf_stream_t stream);
+/* The same forward, same operands, same weight stream, bit-identical results, as a hand-scheduled instruction stream (nf_mlp_ha.hip; body generated by
+ * csrc/gen_mlp_ha.py): the kernel the fp16 path runs. */
+int nf_nerf_mlp_fwd_ha(const void* stream_h2, int cx, int cd, const void* X, const int32_t* n_rows, int max_rows,
+                       const int32_t* row_sample, float* rgbsigma, nf_stream_t stream);
 
 /* Split-precision forward of A6 (models/nerf.py:83-124; nf_mlp_s.hip): every operand as hi + lo fp16, three fp16 MFMAs per product, fp32 accumulate —
  * fp32-level accuracy (max-abs <= 2e-4 on RGB vs the fp32 path) at a multiple of the fp32-MFMA kernel's speed.  Takes

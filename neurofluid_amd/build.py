@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libneurofluid_hip.so")
-SOURCES = ["nf_grid.hip", "nf_render.hip", "nf_mlp.hip", "nf_mlp_l.hip", "nf_mlp_a.hip", "nf_mlp_n.hip", "nf_mlp_h2.hip", "nf_mlp_s.hip", "nf_cconv.hip", "nf_cconv_gf.hip", "nf_trans.hip", "nf_host.hip", "nf_metrics.hip", "nf_embed.hip", "nf_gemm.hip"]
+SOURCES = ["nf_grid.hip", "nf_render.hip", "nf_mlp.hip", "nf_mlp_l.hip", "nf_mlp_a.hip", "nf_mlp_n.hip", "nf_mlp_h2.hip", "nf_mlp_ha.hip", "nf_mlp_s.hip", "nf_cconv.hip", "nf_cconv_gf.hip", "nf_trans.hip", "nf_host.hip", "nf_metrics.hip", "nf_embed.hip", "nf_gemm.hip"]
 # per-file flags.  nf_mlp_h2.hip: MFMA accumulators in VGPRs (the finished blocks are converted by VALU instructions,
 # which cannot read AGPRs: AGPR accumulators cost 16 v_accvgpr_read per block and tile)
 EXTRA_FLAGS = {"nf_mlp_h2.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "nf_mlp_s.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
@@ -34,7 +34,8 @@ def build(force=False, verbose=False):
 # generated sources: (generator script, output) — the body of nf_mlp_a.hip's asm statement is written by gen_mlp_a.py
 # one body per feature-row shape: (qx, qd) = 8-feature groups of the position-like / direction-like features
 MLP_A_SHAPES = [(qx, qd) for qx in (8, 9, 16, 17, 24, 25) for qd in (4, 7)]
-GENERATED = [("gen_mlp_a.py", "nf_mlp_a_body_%d_%d.inc" % s, [str(s[0]), str(s[1])]) for s in MLP_A_SHAPES]
+GENERATED = [("gen_mlp_a.py", "nf_mlp_a_body_%d_%d.inc" % s, [str(s[0]), str(s[1])]) for s in MLP_A_SHAPES] + \
+    [("gen_mlp_ha.py", "nf_mlp_ha_body.inc", [])]       # the fp16 kernel's body (nf_mlp_ha.hip)
 
 
 def _generate():
@@ -45,7 +46,7 @@ def _generate():
             procs.append(subprocess.Popen([sys.executable, gp, op] + args, stderr=subprocess.DEVNULL))
     for p in procs:
         if p.wait() != 0:
-            raise RuntimeError("gen_mlp_a.py failed")
+            raise RuntimeError("a kernel-body generator (gen_mlp_a.py / gen_mlp_ha.py) failed")
 
 
 def _build_locked(force, verbose):

@@ -295,8 +295,23 @@ def _ring_fwd(lib, wstream):
     return (lib.nf_nerf_mlp_fwd_a, "nf_nerf_mlp_fwd_a") if getattr(wstream, "nf_kind", "l") == "a" else (lib.nf_nerf_mlp_fwd_l, "nf_nerf_mlp_fwd_l")
 
 
+# Which kernel serves the fp16-MFMA weight stream: "ha" = the hand-scheduled instruction stream (nf_mlp_ha.hip, generated by
+# csrc/gen_mlp_ha.py), "h2" = the compiler-scheduled kernel it restates (nf_mlp_h2.hip; same stream, same X layout, bit-identical results,
+# kept as the reference of the equality tests).
+FP16_KERNEL = os.environ.get("NF_FP16_KERNEL", "ha")
+
+
+def _fp16_fwd(lib, kind=None):
+    kind = kind or FP16_KERNEL
+    if kind == "ha":
+        return lib.nf_nerf_mlp_fwd_ha, "nf_nerf_mlp_fwd_ha"
+    if kind == "h2":
+        return lib.nf_nerf_mlp_fwd_h2, "nf_nerf_mlp_fwd_h2"
+    raise ValueError("NF_FP16_KERNEL must be 'ha' or 'h2', not %r" % (kind,))
+
+
 class PackedH2:
-    """Weight stream of the fp16-MFMA MLP (nf_nerf_pack_h2 / nf_nerf_mlp_fwd_h2)."""
+    """Weight stream of the fp16-MFMA MLP (nf_nerf_pack_h2 / nf_nerf_mlp_fwd_ha, nf_nerf_mlp_fwd_h2)."""
 
     def __init__(self, blob):
         self.blob = blob
@@ -506,8 +521,8 @@ def render_pass(grid, particles, rays, z, z_table, S, radius, K, enc_flags, use_
             check(lib.nf_nerf_mlp_fwd_s(ptr(packed_h.blob), cx, cd, X_, ptr(nrows_t), mx, rs_, ptr(b.rgbsigma), stream_),
                   "nf_nerf_mlp_fwd_s")
         elif isinstance(packed_h, PackedH2):      # fp16-MFMA, two tiles per wave (inference only); X holds an even tile count
-            check(lib.nf_nerf_mlp_fwd_h2(ptr(packed_h.blob), cx, cd, X_, ptr(nrows_t), mx, rs_, ptr(b.rgbsigma), stream_),
-                  "nf_nerf_mlp_fwd_h2")
+            fn, name = _fp16_fwd(lib)
+            check(fn(ptr(packed_h.blob), cx, cd, X_, ptr(nrows_t), mx, rs_, ptr(b.rgbsigma), stream_), name)
         elif packed_h is not None:
             raise RuntimeError("unknown fp16 weight stream (expected PackedH2 or PackedS)")
         elif wstream is not None and not save_acts:      # fp32, weight stream shared through LDS (inference)
@@ -678,8 +693,8 @@ def mlp_rows(packed, cx, cd, x, save_acts=False, packed_h=None, wstream=None):
         if isinstance(packed_h, PackedH2):
             if T % 2:       # the two-tiles-per-wave kernel reads whole tile pairs
                 Xh = torch.cat([Xh, torch.zeros(Xh.numel() // T, dtype=Xh.dtype, device=Xh.device)])
-            check(lib.nf_nerf_mlp_fwd_h2(ptr(packed_h.blob), cx, cd, ptr(Xh), ptr(n_rows), n, ptr(row_sample), ptr(out),
-                                         _lib.stream()), "nf_nerf_mlp_fwd_h2")
+            fn, name = _fp16_fwd(lib)
+            check(fn(ptr(packed_h.blob), cx, cd, ptr(Xh), ptr(n_rows), n, ptr(row_sample), ptr(out), _lib.stream()), name)
             return out
         raise RuntimeError("unknown fp16 weight stream (expected PackedH2 or PackedS)")
     if wstream is not None:

@@ -755,6 +755,30 @@ def test_full_frame_hand_scheduled_equals_compiler_scheduled(dev):
         assert torch.equal(outs["a"][k], outs["l"][k]), k
 
 
+def test_full_frame_fp16_hand_scheduled_equals_compiler_scheduled(dev):
+    """`mlp_dtype: fp16` on the whole 400 x 400 frame with the hand-scheduled fp16 kernel (ops.FP16_KERNEL = "ha", the default) and with
+    the compiler-scheduled one ("h2"): every key of the result dict bit-equal (same weight stream, same arithmetic, same order)."""
+    from oracle import render_oracle as ro
+    from neurofluid_amd import ops, ray_utils
+    P = ro.watercube_particles().to(dev)
+    c2w = ro.eval_camera()
+    rays = ray_utils.get_rays_cpu(400, 400, ro.camera_focal(400), c2w).view(-1, 6).to(dev)
+    roc = c2w[:, 3].to(dev)
+    outs = {}
+    old = ops.FP16_KERNEL
+    net = make_net(dev, dict(make_cfg(), mlp_dtype="fp16"))
+    try:
+        for kind in ("ha", "h2"):
+            ops.FP16_KERNEL = kind
+            with torch.no_grad():
+                outs[kind] = net(P, roc, rays, None, None)
+    finally:
+        ops.FP16_KERNEL = old
+    assert float(outs["ha"]["mask_1"].sum()) > 1e5
+    for k in ("rgb0", "rgb1", "depth0", "depth1", "opacity0", "opacity1", "num_nn_0", "num_nn_1", "mask_0", "mask_1"):
+        assert torch.equal(outs["ha"][k], outs["h2"][k]), k
+
+
 @pytest.mark.parametrize("kind", ["a", "l"])
 def test_mlp_lds_ring_kernel(dev, kind):
     """A6 through nf_nerf_mlp_fwd_a (hand-scheduled, the inference default) / nf_nerf_mlp_fwd_l (weight stream shared through an
@@ -863,6 +887,75 @@ def test_mlp_hand_scheduled_kernel_bit_equal_to_compiler_scheduled(dev):
             written = torch.zeros(cap, dtype=torch.bool, device=dev)
             written[perm[:n].long()] = True
             assert bool((outs[0][~written] == -7.0).all()) and bool(torch.isfinite(outs[0][written]).all())      # rows >= n_rows untouched
+
+
+def test_fp16_hand_scheduled_kernel_bit_equal_to_compiler_scheduled(dev):
+    """nf_nerf_mlp_fwd_ha (one generated asm statement: gen_mlp_ha.py) against nf_nerf_mlp_fwd_h2, the compiler-scheduled kernel it
+    restates: same weight stream (nf_nerf_pack_h2), same fp16 X layout, same K order per accumulator, same rounding of every finished
+    block (v_cvt_pk_f16_f32 + packed max), same expansion of 1 / (1 + expf(-c)) — so the outputs must be BIT-equal, on both nets, on row
+    counts around every tile / pair / pair-group / round boundary (a persistent grid of 256 x 4 waves, one PAIR of 32-row tiles per wave:
+    1 024 pairs = 65 536 rows per round), through a row_sample permutation, with a row count below the capacity passed in; and the fp16
+    rows stay within the fp16 path's stated 2e-2 of the fp32 rows."""
+    from neurofluid_amd import ops, _lib
+    from neurofluid_amd._lib import check, ptr
+    lib = _lib.load()
+    net = make_net(dev)
+    gen = torch.Generator().manual_seed(14)
+    for nerf in (net.nerf_coarse, net.nerf_fine):
+        ph = net.packed_weights_h(nerf)
+        for n in (1, 31, 32, 33, 64, 65, 127, 129, 255, 257, 4096, 65536 - 3, 65536 + 70, 3 * 65536 + 77):
+            cap = n + 100
+            tiles = (cap + 31) // 32
+            tiles += tiles & 1                       # the kernels read whole tile pairs
+            Xh = ((torch.rand(tiles * 32 * 256, generator=gen) * 2 - 1) * 1.5).to(torch.float16).to(dev)
+            perm = torch.randperm(cap, generator=gen).to(torch.int32).to(dev)
+            n_rows = torch.tensor([n], dtype=torch.int32, device=dev)
+            outs = []
+            for fn in (lib.nf_nerf_mlp_fwd_ha, lib.nf_nerf_mlp_fwd_h2):
+                o = torch.full((cap, 4), -7.0, device=dev)
+                check(fn(ptr(ph.blob), 198, 54, ptr(Xh), ptr(n_rows), cap, ptr(perm), ptr(o), _lib.stream()), "mlp fp16")
+                outs.append(o)
+            assert torch.equal(outs[0], outs[1]), (n, float((outs[0] - outs[1]).abs().max()))
+            written = torch.zeros(cap, dtype=torch.bool, device=dev)
+            written[perm[:n].long()] = True
+            assert bool((outs[0][~written] == -7.0).all()) and bool(torch.isfinite(outs[0][written]).all())      # rows >= n_rows untouched
+    # against the fp32 rows, through ops.mlp_rows (which now runs the hand-scheduled kernel)
+    assert ops.FP16_KERNEL == "ha"
+    xr = (torch.rand(1000, 252, generator=gen) * 2 - 1).to(dev)
+    ref = ops.mlp_rows(net.packed_weights(net.nerf_fine), 198, 54, xr)
+    got = ops.mlp_rows(net.packed_weights(net.nerf_fine), 198, 54, xr, packed_h=net.packed_weights_h(net.nerf_fine))
+    assert float((got - ref)[:, :3].abs().max()) < 2e-2
+
+
+def test_fp16_hand_scheduled_kernel_under_contention(dev):
+    """The ring protocol of nf_nerf_mlp_fwd_ha (LDS-DMA refill behind a rendezvous, counted vmcnt in front of the next one) with the
+    machine busy: a second stream keeps every CU's memory path loaded with a copy loop while the kernel runs, ten times over, and every
+    run must reproduce the bits of the quiet run (a DMA that lands late or a read that starts early shows up as a wrong tile)."""
+    from neurofluid_amd import ops, _lib
+    from neurofluid_amd._lib import check, ptr
+    lib = _lib.load()
+    net = make_net(dev)
+    ph = net.packed_weights_h(net.nerf_fine)
+    gen = torch.Generator().manual_seed(15)
+    n = 5 * 65536 + 1234
+    tiles = (n + 31) // 32
+    tiles += tiles & 1
+    Xh = ((torch.rand(tiles * 32 * 256, generator=gen) * 2 - 1)).to(torch.float16).to(dev)
+    rs = torch.arange(n, dtype=torch.int32, device=dev)
+    n_rows = torch.tensor([n], dtype=torch.int32, device=dev)
+    quiet = torch.empty(n, 4, device=dev)
+    check(lib.nf_nerf_mlp_fwd_ha(ptr(ph.blob), 198, 54, ptr(Xh), ptr(n_rows), n, ptr(rs), ptr(quiet), _lib.stream()), "ha")
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    big = torch.empty(64 * 2 ** 20, device=dev)
+    for rep in range(10):
+        with torch.cuda.stream(side):
+            for _ in range(6):
+                big.copy_(big.roll(1))
+        o = torch.full((n, 4), -1.0, device=dev)
+        check(lib.nf_nerf_mlp_fwd_ha(ptr(ph.blob), 198, 54, ptr(Xh), ptr(n_rows), n, ptr(rs), ptr(o), _lib.stream()), "ha")
+        torch.cuda.synchronize()
+        assert torch.equal(o, quiet), (rep, int((o != quiet).any(1).sum()))
 
 
 # ------------------------------------------------------------------------------------------------

@@ -118,3 +118,46 @@ if len(sys.argv) > 3 and sys.argv[3] == "asm":
         print("first equal tiles:", full[:20].tolist(), " last:", full[-5:].tolist())
         print("equal tiles by (tile % 4):", [int((per_tile.view(-1, 4)[:, w] == 32).sum()) for w in range(4)])
         print("equal tiles by round:", [int((per_tile[r * 1024:(r + 1) * 1024] == 32).sum()) for r in range(per_tile.numel() // 1024)])
+if len(sys.argv) > 3 and sys.argv[3] == "fp16asm":
+    # hand-scheduled fp16 kernel (nf_mlp_ha.hip) vs the compiler-scheduled one (nf_mlp_h2.hip): must be bit-identical
+    ph = ops.pack_nerf_h2(W, B, 198, 54)
+    T = X.numel() // (32 * 256)
+    Xh = X.view(T, 16, 2, 64, 4).permute(0, 1, 3, 2, 4).reshape(-1).to(torch.float16).contiguous()
+    if T % 2:
+        Xh = torch.cat([Xh, torch.zeros(Xh.numel() // T, dtype=Xh.dtype, device=dev)])
+    out2 = torch.zeros(n, 4, device=dev)
+    out5 = torch.full((n, 4), 7.0, device=dev)
+    for name, fn, o in (("h2", lib.nf_nerf_mlp_fwd_h2, out2), ("ha", lib.nf_nerf_mlp_fwd_ha, out5)):
+        for it in range(iters):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            check(fn(ptr(ph.blob), 198, 54, ptr(Xh), ptr(n_rows), n, ptr(row_sample), ptr(o), _lib.stream()))
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1)
+            print(f"{name} iter {it}: rows {n} {ms:.3f} ms  {n*1331968/ms/1e9:.1f} TFLOP/s", flush=True)
+    err = (out5 - out2).abs()
+    print("ha vs h2: max abs err rgb", float(err[:, :3].max()), "sigma", float(err[:, 3].max()), "bit-equal", bool(torch.equal(out2, out5)),
+          "rows differing", int((err.max(1)[0] > 0).sum()), " vs fp32: rgb", float((out5 - out)[:, :3].abs().max()))
+    bad = torch.nonzero(err.max(1)[0] > 0).flatten()[:8].tolist()
+    for r in bad:
+        print(" row", r, out2[r].tolist(), out5[r].tolist())
+    eq = (err.max(1)[0] == 0)
+    per_pair = eq[:n // 64 * 64].view(-1, 64).sum(1)
+    print("fully equal pairs:", int((per_pair == 64).sum()), "of", per_pair.numel(), " by wave:", [int((per_pair.view(-1, 4)[:, w] == 64).sum()) for w in range(4)] if per_pair.numel() % 4 == 0 else "")
+if len(sys.argv) > 3 and sys.argv[3] == "fp16asmonly":
+    ph = ops.pack_nerf_h2(W, B, 198, 54)
+    T = X.numel() // (32 * 256)
+    Xh = X.view(T, 16, 2, 64, 4).permute(0, 1, 3, 2, 4).reshape(-1).to(torch.float16).contiguous()
+    if T % 2:
+        Xh = torch.cat([Xh, torch.zeros(Xh.numel() // T, dtype=Xh.dtype, device=dev)])
+    out2 = torch.zeros(n, 4, device=dev)
+    out5 = torch.full((n, 4), 7.0, device=dev)
+    check(lib.nf_nerf_mlp_fwd_h2(ptr(ph.blob), 198, 54, ptr(Xh), ptr(n_rows), n, ptr(row_sample), ptr(out2), _lib.stream()))
+    for it in range(iters):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib.nf_nerf_mlp_fwd_ha(ptr(ph.blob), 198, 54, ptr(Xh), ptr(n_rows), n, ptr(row_sample), ptr(out5), _lib.stream()))
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        print(f"ha iter {it}: rows {n} {ms:.3f} ms  {n*1331968/ms/1e9:.1f} TFLOP/s", flush=True)
+    print("ha vs h2: bit-equal", bool(torch.equal(out2, out5)))

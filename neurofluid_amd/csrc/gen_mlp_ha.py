@@ -54,7 +54,7 @@ S_WBASE = _salloc(2, 2); S_WCUR = _salloc(2, 2); S_XH = _salloc(2, 2); S_XD = _s
 S_XN = _salloc(2, 2); S_XNB = _salloc(2, 2); S_RS = _salloc(2, 2); S_OUT = _salloc(2, 2); S_TMP = _salloc(2, 2)
 S_SAVE = _salloc(2, 2); S_EXA = _salloc(2, 2); S_EXB = _salloc(2, 2); S_DV = _salloc(2, 2)
 S_NROWS = _salloc(); S_NPAIRS = _salloc(); S_NGROUPS = _salloc(); S_TG = _salloc(); S_WAVE = _salloc(); S_NBLK = _salloc()
-S_PAIR = _salloc(); S_LASTP = _salloc(); S_NL2E = _salloc(); S_EHI = _salloc(); S_ELO = _salloc(); S_T1 = _salloc(); S_OWNER = _salloc(); S_WAVE4K = _salloc()
+S_PAIR = _salloc(); S_LASTP = _salloc(); S_NL2E = _salloc(); S_EHI = _salloc(); S_ELO = _salloc(); S_T1 = _salloc(); S_OWNER = _salloc(); S_WAVE4K = _salloc(); S_PEXA = _salloc(2, 2); S_PEXB = _salloc(2, 2)
 assert _s <= 100
 
 
@@ -95,12 +95,13 @@ BIASB = "v[208:211]"
 V_T = [212, 213, 214, 215]
 V_LANE16, V_STASH, V_PUB = 216, 217, 218
 V_SIG = [220, 221]
-V_RGB = [222, 223, 224, 225, 226, 227]      # tile A r, g, b; tile B r, g, b (raw head outputs)
+V_PRGB = [222, 223, 224, 225, 226, 227]     # the PREVIOUS pair's raw rgb head outputs: tile A r, g, b; tile B r, g, b
 V_ROW, V_IDXOFF = 228, 229
 V_IDX = [230, 231]
-V_ADDR = 232                                 # 2 registers
+V_PADDR = [232, 234]                         # the previous pair's two store addresses (2 registers each)
 V_O = 236                                    # 4 registers
 V_E = list(range(240, 256))
+V_PSIG = [240, 241]                          # the previous pair's sigma (E[0], E[1]: the sigmoid uses E[3..14])
 
 
 def STAGE(q):
@@ -248,27 +249,37 @@ def cvt_piece(p_, cv):
     return ins
 
 
-def sigmoid(x, out):
-    """1 / (1 + expf(-x)) as the compiler expands it in k_mlp_fwd_h2 (same operations, same order: bit-identical)."""
+def sigmoid_pieces(x, out):
+    """1 / (1 + expf(-x)) as the compiler expands it in k_mlp_fwd_h2 (same operations, same order: bit-identical), cut into pieces that
+    keep every VCC producer with its consumer (v_div_fmas reads VCC implicitly)."""
     E = V_E
     t, ph, r, ri, e = E[3], E[4], E[5], E[6], E[7]
-    ins = [f"v_mul_f32 v{t}, 0xbfb8aa3b, v{x}", f"v_fma_f32 v{ph}, v{x}, s{S_NL2E}, -v{t}",
-           f"v_rndne_f32 v{r}, v{t}", f"v_fmac_f32 v{ph}, 0xb2a5705f, v{x}", f"v_sub_f32 v{t}, v{t}, v{r}",
-           f"v_add_f32 v{t}, v{t}, v{ph}",
-           f"v_cvt_i32_f32 v{ri}, v{r}", f"v_exp_f32 v{e}, v{t}", "s_nop 0", f"v_ldexp_f32 v{e}, v{e}, v{ri}",
-           f"v_cmp_nlt_f32 vcc, s{S_EHI}, v{x}", "s_nop 1", f"v_cndmask_b32 v{e}, 0, v{e}, vcc",
-           f"v_mov_b32 v{E[8]}, 0x7f800000",
-           f"v_cmp_ngt_f32 vcc, s{S_ELO}, v{x}", "s_nop 1", f"v_cndmask_b32 v{e}, v{E[8]}, v{e}, vcc",
-           f"v_add_f32 v{e}, 1.0, v{e}"]
     d, ds, rc, e0, ns, q_, e1 = e, E[9], E[10], E[11], E[12], E[13], E[14]
-    ins += [f"v_div_scale_f32 v{ds}, {sp(S_DV)}, v{d}, v{d}, 1.0", f"v_rcp_f32 v{rc}, v{ds}", "s_nop 0",
-            f"v_fma_f32 v{e0}, -v{ds}, v{rc}, 1.0",
-            f"v_div_scale_f32 v{ns}, vcc, 1.0, v{d}, 1.0", f"v_fmac_f32 v{rc}, v{e0}, v{rc}",
-            f"v_mul_f32 v{q_}, v{ns}, v{rc}", f"v_fma_f32 v{e1}, -v{ds}, v{q_}, v{ns}",
-            f"v_fmac_f32 v{q_}, v{e1}, v{rc}", f"v_fma_f32 v{e1}, -v{ds}, v{q_}, v{ns}", "s_nop 1",
-            f"v_div_fmas_f32 v{e1}, v{e1}, v{rc}, v{q_}",
-            f"v_div_fixup_f32 v{out}, v{e1}, v{d}, 1.0"]
-    return ins
+    return [
+        [f"v_mul_f32 v{t}, 0xbfb8aa3b, v{x}", f"v_fma_f32 v{ph}, v{x}, s{S_NL2E}, -v{t}", f"v_rndne_f32 v{r}, v{t}",
+         f"v_fmac_f32 v{ph}, 0xb2a5705f, v{x}", f"v_sub_f32 v{t}, v{t}, v{r}", f"v_add_f32 v{t}, v{t}, v{ph}"],
+        [f"v_cvt_i32_f32 v{ri}, v{r}", f"v_exp_f32 v{e}, v{t}", "s_nop 0", f"v_ldexp_f32 v{e}, v{e}, v{ri}"],
+        [f"v_cmp_nlt_f32 vcc, s{S_EHI}, v{x}", "s_nop 1", f"v_cndmask_b32 v{e}, 0, v{e}, vcc", f"v_mov_b32 v{E[8]}, 0x7f800000"],
+        [f"v_cmp_ngt_f32 vcc, s{S_ELO}, v{x}", "s_nop 1", f"v_cndmask_b32 v{e}, v{E[8]}, v{e}, vcc", f"v_add_f32 v{e}, 1.0, v{e}"],
+        [f"v_div_scale_f32 v{ds}, {sp(S_DV)}, v{d}, v{d}, 1.0", f"v_rcp_f32 v{rc}, v{ds}", "s_nop 0", f"v_fma_f32 v{e0}, -v{ds}, v{rc}, 1.0"],
+        [f"v_div_scale_f32 v{ns}, vcc, 1.0, v{d}, 1.0", f"v_fmac_f32 v{rc}, v{e0}, v{rc}", f"v_mul_f32 v{q_}, v{ns}, v{rc}",
+         f"v_fma_f32 v{e1}, -v{ds}, v{q_}, v{ns}", f"v_fmac_f32 v{q_}, v{e1}, v{rc}", f"v_fma_f32 v{e1}, -v{ds}, v{q_}, v{ns}", "s_nop 1",
+         f"v_div_fmas_f32 v{e1}, v{e1}, v{rc}, v{q_}"],
+        [f"v_div_fixup_f32 v{out}, v{e1}, v{d}, 1.0"],
+    ]
+
+
+def epilogue_pieces():
+    """the PREVIOUS pair's outputs (lanes h == 0 hold one row of tile A and one of tile B): rgb = sigmoid(raw head outputs carried over in
+    V_PRGB), sigma carried in V_PSIG, the store addresses in V_PADDR, the store masks in S_PEXA / S_PEXB."""
+    out = []
+    for tile in range(2):
+        for c in range(3):
+            out += sigmoid_pieces(V_PRGB[3 * tile + c], V_O + c)
+        out.append([f"v_mov_b32 v{V_O + 3}, v{V_PSIG[tile]}", f"s_mov_b64 {sp(S_TMP)}, exec", f"s_mov_b64 exec, {sp(S_PEXA if tile == 0 else S_PEXB)}",
+                    ("vmem", f"global_store_dwordx4 v[{V_PADDR[tile]}:{V_PADDR[tile] + 1}], v[{V_O}:{V_O + 3}], off", "st"),
+                    "s_nop 1", f"s_mov_b64 exec, {sp(S_TMP)}"])          # (S_TMP: only ever live inside one piece)
+    return out
 
 
 def emit_pair_select(p, s_tg, s_pair):
@@ -383,6 +394,8 @@ def gen():
     p.i("s_barrier")
     for s in range(PF):
         p.lds(f"ds_read_b128 {ASL(s)}, v{V_LANE16} offset:{1024 * s}", f"A{s}")
+    p.i(f"s_mov_b64 {sp(S_PEXA)}, 0")                  # no previous pair yet
+    p.i(f"s_mov_b64 {sp(S_PEXB)}, 0")
     p.i(".Lnf_ha_pair_%=:")
 
     # ------------------------------------------------------------------ everything that is not an MFMA or an operand read
@@ -431,6 +444,10 @@ def gen():
     ]
     for i, g in enumerate(groups):
         piece("setup", 2 * (1 + i), 2 * 100, g)
+    # ---- the previous pair's epilogue (sigmoid + store), spread over layer 0 and layer 1
+    if not knob("NOEPI"):
+        for g in epilogue_pieces():
+            piece("epi", 2 * 4, 2 * 600, g)
 
     # ---- X of the next pair -> stash: batch t loaded from block t of layers 5-6 on, stored two blocks later (the stash is free
     # once the skip layer has run)
@@ -590,8 +607,8 @@ def gen():
         for text, tag in reads_of(n):
             p.lds(text, tag)
         if not real:
-            if n == nreal and not knob("NOEPI"):
-                emit_epilogue(p)
+            if n == nreal:
+                emit_handover(p)
             emit_items(p, pad_items.get(n, []))
             continue
         blk, s = step_of[n]
@@ -616,6 +633,9 @@ def gen():
     p.i(f"s_add_u32 s{S_TG}, s{S_TG}, s{S_NBLK}")
     p.i(f"s_cmp_lt_i32 s{S_TG}, s{S_NGROUPS}")
     long_branch_scc1(p, ".Lnf_ha_pair_%=")
+    # the last pair's epilogue
+    for g in epilogue_pieces():
+        emit_items(p, g)
     p.i(".Lnf_ha_done_%=:")
     p.i("s_waitcnt vmcnt(0) lgkmcnt(0)")
     return p.lines, NSLOT, nreal
@@ -634,26 +654,23 @@ def emit_items(p, items):
             p.i(it)
 
 
-def emit_epilogue(p):
-    """the pair's outputs (lanes h == 0 hold one row of tile A and one of tile B): rgb = sigmoid(registers 0..2 of the rgb block's
-    accumulators), sigma saved earlier; runs in the padding steps behind the last MFMA."""
+def emit_handover(p):
+    """behind the pair's last MFMA: what the deferred epilogue (inside the NEXT pair, or behind the loop) needs is moved out of the registers
+    the next pair overwrites — the raw rgb head outputs (registers 0..2 of the rgb block's accumulators), sigma, the two store addresses
+    (row_sample[row] * 16 + out) and the store masks."""
     p.i("s_nop 15")
-    p.i("s_nop 7")
     for tile in range(2):
         for c in range(3):
-            for ins in sigmoid(acc_reg(1, tile, c), V_O + c):
-                p.i(ins)
-        p.i(f"v_mov_b32 v{V_O + 3}, v{V_SIG[tile]}")
-        if tile == 0:
-            p.wait_vm("idx")
-        p.i(f"v_ashrrev_i32 v{V_ADDR + 1}, 31, v{V_IDX[tile]}")
-        p.i(f"v_mov_b32 v{V_ADDR}, v{V_IDX[tile]}")
-        p.i(f"v_lshl_add_u64 v[{V_ADDR}:{V_ADDR + 1}], v[{V_ADDR}:{V_ADDR + 1}], 4, {sp(S_OUT)}")
-        p.i(f"s_mov_b64 {sp(S_SAVE)}, exec")
-        p.i(f"s_mov_b64 exec, {sp(S_EXA if tile == 0 else S_EXB)}")
-        p.vmem(f"global_store_dwordx4 v[{V_ADDR}:{V_ADDR + 1}], v[{V_O}:{V_O + 3}], off", "st")
-        p.i("s_nop 1")
-        p.i(f"s_mov_b64 exec, {sp(S_SAVE)}")
+            p.i(f"v_mov_b32 v{V_PRGB[3 * tile + c]}, v{acc_reg(1, tile, c)}")
+        p.i(f"v_mov_b32 v{V_PSIG[tile]}, v{V_SIG[tile]}")
+    p.wait_vm("idx")
+    for tile in range(2):
+        a = V_PADDR[tile]
+        p.i(f"v_ashrrev_i32 v{a + 1}, 31, v{V_IDX[tile]}")
+        p.i(f"v_mov_b32 v{a}, v{V_IDX[tile]}")
+        p.i(f"v_lshl_add_u64 v[{a}:{a + 1}], v[{a}:{a + 1}], 4, {sp(S_OUT)}")
+    p.i(f"s_mov_b64 {sp(S_PEXA)}, {sp(S_EXA)}")
+    p.i(f"s_mov_b64 {sp(S_PEXB)}, {sp(S_EXB)}")
 
 
 def main():

@@ -201,9 +201,13 @@ size_t nf_nerf_packed_h2_bytes(void);
 int nf_nerf_pack_h2(const nf_nerf_params_t* params, int cx, int cd, void* stream_h2, nf_stream_t stream);
 int nf_nerf_mlp_fwd_h2(const void* stream_h2, int cx, int cd, const void* X, const int32_t* n_rows, int max_rows,
                        const int32_t* row_sample, float* rgbsigma, nf_stream_t stream);
-/* The same forward, same operands, same weight stream, bit-identical results, as a hand-scheduled instruction stream (nf_mlp_ha.hip; body generated by
- * csrc/gen_mlp_ha.py): the kernel the fp16 path runs. */
-int nf_nerf_mlp_fwd_ha(const void* stream_h2, int cx, int cd, const void* X, const int32_t* n_rows, int max_rows,
+/* The same forward with bit-identical results as a hand-scheduled instruction stream (nf_mlp_ha.hip; body generated by csrc/gen_mlp_ha.py): the
+ * kernel the fp16 path runs.  Same X operand; its weight stream is nf_nerf_pack_h2's WITHOUT the 78 bias K-steps (their value — fp32(hi) + fp32(lo),
+ * exact — is the C operand of each output block's first MFMA instead) followed by that bias table: nf_nerf_pack_ha re-packs an h2 stream on the
+ * device (stream_ha: nf_nerf_packed_ha_bytes() bytes). */
+size_t nf_nerf_packed_ha_bytes(void);
+int nf_nerf_pack_ha(const void* stream_h2, void* stream_ha, nf_stream_t stream);
+int nf_nerf_mlp_fwd_ha(const void* stream_ha, int cx, int cd, const void* X, const int32_t* n_rows, int max_rows,
                        const int32_t* row_sample, float* rgbsigma, nf_stream_t stream);
 
 /* Split-precision forward of A6 (models/nerf.py:83-124; nf_mlp_s.hip): every operand as hi + lo fp16, three fp16 MFMAs per product, fp32 accumulate —

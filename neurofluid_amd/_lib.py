@@ -74,6 +74,8 @@ PROTOTYPES = {
     "nf_nerf_packed_h2_bytes": (c_size_t, []),
     "nf_nerf_pack_h2": (c_int, [ctypes.POINTER(NerfParams), c_int, c_int, c_void_p, c_void_p]),
     "nf_nerf_mlp_fwd_h2": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "nf_nerf_packed_ha_bytes": (c_size_t, []),
+    "nf_nerf_pack_ha": (c_int, [c_void_p, c_void_p, c_void_p]),
     "nf_nerf_mlp_fwd_ha": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "nf_nerf_packed_s_bytes": (c_size_t, []),
     "nf_nerf_pack_s": (c_int, [ctypes.POINTER(NerfParams), c_int, c_int, c_void_p, c_void_p]),

@@ -37,7 +37,7 @@ PF = 3                           # A-operand prefetch distance (steps)
 DMA = knob("DMA", 1)               # ring refill by LDS-DMA (0: global_load -> registers -> ds_write)
 XPF = 2                          # stash-operand prefetch distance (steps)
 
-IN = dict(stream="%0", X="%1", n_rows="%2", row_sample="%3", out="%4", max_rows="%5", wave="%6", block="%7", nblocks="%8")
+IN = dict(stream="%0", X="%1", n_rows="%2", row_sample="%3", out="%4", max_rows="%5", wave="%6", block="%7", nblocks="%8", btab="%9")
 
 _s = 40
 
@@ -54,7 +54,7 @@ S_WBASE = _salloc(2, 2); S_WCUR = _salloc(2, 2); S_XH = _salloc(2, 2); S_XD = _s
 S_XN = _salloc(2, 2); S_XNB = _salloc(2, 2); S_RS = _salloc(2, 2); S_OUT = _salloc(2, 2); S_TMP = _salloc(2, 2)
 S_SAVE = _salloc(2, 2); S_EXA = _salloc(2, 2); S_EXB = _salloc(2, 2); S_DV = _salloc(2, 2)
 S_NROWS = _salloc(); S_NPAIRS = _salloc(); S_NGROUPS = _salloc(); S_TG = _salloc(); S_WAVE = _salloc(); S_NBLK = _salloc()
-S_PAIR = _salloc(); S_LASTP = _salloc(); S_NL2E = _salloc(); S_EHI = _salloc(); S_ELO = _salloc(); S_T1 = _salloc(); S_OWNER = _salloc(); S_WAVE4K = _salloc(); S_PEXA = _salloc(2, 2); S_PEXB = _salloc(2, 2)
+S_PAIR = _salloc(); S_LASTP = _salloc(); S_NL2E = _salloc(); S_EHI = _salloc(); S_ELO = _salloc(); S_T1 = _salloc(); S_OWNER = _salloc(); S_WAVE4K = _salloc(); S_PEXA = _salloc(2, 2); S_PEXB = _salloc(2, 2); S_BTBASE = _salloc(2, 2); S_BTCUR = _salloc(2, 2)
 assert _s <= 100
 
 
@@ -88,10 +88,11 @@ def bank_quad(bank, tile, k):
 
 
 def ASL(i):
-    return f"v[{192 + 4 * (i & 3)}:{195 + 4 * (i & 3)}]"
+    return f"a[{224 + 4 * (i & 3)}:{227 + 4 * (i & 3)}]"
 
 
-BIASB = "v[208:211]"
+BIASC = 192                                  # v[192:207]: the C operand of a block's first MFMAs (the block's biases, from the table)
+V_H64 = 208                                  # (lane >> 5) * 64: the lane half's row of a bias-table entry
 V_T = [212, 213, 214, 215]
 V_LANE16, V_STASH, V_PUB = 216, 217, 218
 V_SIG = [220, 221]
@@ -192,7 +193,7 @@ class Block:
 
 def build_blocks():
     B = []
-    bias = [("bias", 0)]
+    bias = []                                               # (nf_mlp_h2.hip's bias K-step: here the C operand of the block's first MFMAs)
     xs = [("xs", t) for t in range(XS)]
     h16 = [("h", k) for k in range(16)]
     for b in range(8):                                       # layer 0: X (stash) -> bank 1
@@ -328,13 +329,9 @@ def gen():
     p.i(f"v_mbcnt_hi_u32_b32 v{V_E[0]}, -1, v{V_E[0]}")                 # lane
     p.i(f"v_lshlrev_b32 v{V_LANE16}, 4, v{V_E[0]}")
     p.i(f"v_and_b32 v{V_ROW}, 31, v{V_E[0]}")                            # j
-    # bias B operand: halves k = 0, 1 are 1.0 for the lanes h == 0, everything else 0
-    p.i(f"v_cmp_gt_u32 vcc, 32, v{V_E[0]}")
-    p.i(f"v_mov_b32 v{V_E[1]}, 0x3c003c00")
-    p.i("v_cndmask_b32 v208, 0, v%d, vcc" % V_E[1])
-    p.i("v_mov_b32 v209, 0")
-    p.i("v_mov_b32 v210, 0")
-    p.i("v_mov_b32 v211, 0")
+    p.i(f"v_lshrrev_b32 v{V_H64}, 5, v{V_E[0]}")
+    p.i(f"v_lshlrev_b32 v{V_H64}, 6, v{V_H64}")                          # h * 64
+    p.i(f"s_mov_b64 {sp(S_BTBASE)}, {IN['btab']}")
     p.i(f"s_lshl_b32 s{S_T1}, s{S_WAVE}, 12")
     p.i(f"v_add_u32 v{V_PUB}, s{S_T1}, v{V_LANE16}")                     # wave * 4096 + lane * 16 (ring write address AND stream offset)
     p.i(f"s_mul_i32 s{S_T1}, s{S_WAVE}, {STASH_W}")
@@ -394,6 +391,12 @@ def gen():
     p.i("s_barrier")
     for s in range(PF):
         p.lds(f"ds_read_b128 {ASL(s)}, v{V_LANE16} offset:{1024 * s}", f"A{s}")
+    for t in range(XPF):
+        p.lds(f"ds_read_b128 {XR(0, t)}, v{V_STASH} offset:{1024 * t}", f"X{t}")          # (steps 0, 1 of the pair = K-steps 0, 1 of layer 0)
+        p.lds(f"ds_read_b128 {XR(1, t)}, v{V_STASH} offset:{1024 * (XS + t)}", f"X{t}")
+    p.i(f"s_mov_b64 {sp(S_BTCUR)}, {sp(S_BTBASE)}")
+    for q in range(4):
+        p.vmem(f"global_load_dwordx4 v[{BIASC + 4 * q}:{BIASC + 4 * q + 3}], v{V_H64}, {sp(S_BTCUR)} offset:{16 * q}", "b0")
     p.i(f"s_mov_b64 {sp(S_PEXA)}, 0")                  # no previous pair yet
     p.i(f"s_mov_b64 {sp(S_PEXB)}, 0")
     p.i(".Lnf_ha_pair_%=:")
@@ -522,6 +525,19 @@ def gen():
             # tile A's last MFMA is two MFMAs old when the bias step's first one has issued; tile B's one more gap later
             piece(f"cvt{bi}", 2 * blk.first + (0 if tile == 0 else 2), dl, cvt_piece(pc, blk.cvt))
 
+    # ---- the NEXT block's biases (16 floats per lane: the lane half's row of the table entry) into the C-operand registers, behind this
+    # block's first two MFMAs (which read them)
+    def bias_piece(j):
+        adv = [f"s_mov_b64 {sp(S_BTCUR)}, {sp(S_BTBASE)}"] if j == 0 else [f"s_add_u32 s{S_BTCUR}, s{S_BTCUR}, 128", f"s_addc_u32 s{S_BTCUR + 1}, s{S_BTCUR + 1}, 0"]
+        return [adv + [("vmem", f"global_load_dwordx4 v[{BIASC + 4 * q}:{BIASC + 4 * q + 3}], v{V_H64}, {sp(S_BTCUR)} offset:{16 * q}", f"b{j}") for q in range(2)],
+                [("vmem", f"global_load_dwordx4 v[{BIASC + 4 * q}:{BIASC + 4 * q + 3}], v{V_H64}, {sp(S_BTCUR)} offset:{16 * q}", f"b{j}") for q in range(2, 4)]]
+
+    for bi, blk in enumerate(blocks):
+        j = (bi + 1) % len(blocks)
+        last = 2 * (blk.first + len(blk.steps) - 1) + 1
+        for pc_ in bias_piece(j):
+            piece("bias", 2 * blk.first + 2, last - 2, pc_)
+
     # ------------------------------------------------------------------ placement
     C_VALU, C_LDSW, C_LDSR, C_VMEM, BUDGET = knob("C_VALU", 4), knob("C_LDSW", 26), knob("C_LDSR", 8), knob("C_VMEM", 16), knob("BUDGET", 24)
 
@@ -540,17 +556,15 @@ def gen():
         m = (n + PF) % NSLOT
         if m < nreal and not knob("NOAREAD"):
             r.append((f"ds_read_b128 {ASL(m)}, v{V_LANE16} offset:{1024 * (m % RING)}", f"A{m}"))
-        if n < nreal:
-            blk, s = step_of[n]
-            kind, idx = blk.steps[s]
-            want = []
-            if kind == "bias" and len(blk.steps) > 1 and blk.steps[1][0] == "xs":
-                want = list(range(XPF))
-            elif kind == "xs" and idx + XPF < XS:
-                want = [idx + XPF]
-            for t in ([] if knob("NOXS") else want):
-                r.append((f"ds_read_b128 {XR(0, t)}, v{V_STASH} offset:{1024 * t}", f"X{blk.first}_{t}"))
-                r.append((f"ds_read_b128 {XR(1, t)}, v{V_STASH} offset:{1024 * (XS + t)}", f"X{blk.first}_{t}"))
+        mx = (n + XPF) % NSLOT                           # the stash operands of the step XPF ahead (into the next pair's layer 0 at the very end)
+        if mx < nreal and not knob("NOXS"):
+            bx, sx = step_of[mx]
+            kx, ix = bx.steps[sx]
+            if kx == "xs":
+                # (operand slot = the STEP's index mod 4, not the K-step's: the next block's K-step 0 is requested while this block's
+                # K-step 12 — the same slot by K-step index — is still waiting for its MFMAs)
+                r.append((f"ds_read_b128 {XR(0, mx)}, v{V_STASH} offset:{1024 * ix}", f"X{mx}"))
+                r.append((f"ds_read_b128 {XR(1, mx)}, v{V_STASH} offset:{1024 * (XS + ix)}", f"X{mx}"))
         return r
 
     ngaps = 2 * nreal
@@ -613,20 +627,20 @@ def gen():
             continue
         blk, s = step_of[n]
         kind, idx = blk.steps[s]
-        p.wait_lds([f"A{n}"] + ([f"X{blk.first}_{idx}"] if kind == "xs" else []))
+        p.wait_lds([f"A{n}"] + ([f"X{n}"] if kind == "xs" else []))
         if kind == "xd" and idx == 0 and blk.blk == 0:
             p.wait_vm("d3")
+        if s == 0:
+            p.wait_vm(f"b{blocks.index(blk)}")            # the block's biases: the C operand of its first two MFMAs
         for tile in range(2):
-            if kind == "bias":
-                bop = BIASB
-            elif kind == "xs":
-                bop = XR(tile, idx)
+            if kind == "xs":
+                bop = XR(tile, n)
             elif kind == "xd":
                 bop = DIR(tile, idx)
             else:
                 bop = bank_quad(blk.inb, tile, idx)
             acc = ACC(blk.acc, tile)
-            p.i(f"v_mfma_f32_32x32x16_f16 {acc}, {ASL(n)}, {bop}, {'0' if s == 0 else acc}")
+            p.i(f"v_mfma_f32_32x32x16_f16 {acc}, {ASL(n)}, {bop}, {f'v[{BIASC}:{BIASC + 15}]' if s == 0 else acc}")
             emit_items(p, gaps[2 * n + tile])
 
     # ------------------------------------------------------------------ loop back

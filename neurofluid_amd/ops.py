@@ -311,10 +311,15 @@ def _fp16_fwd(lib, kind=None):
 
 
 class PackedH2:
-    """Weight stream of the fp16-MFMA MLP (nf_nerf_pack_h2 / nf_nerf_mlp_fwd_ha, nf_nerf_mlp_fwd_h2)."""
+    """Weight streams of the fp16-MFMA MLP: `blob` = nf_nerf_pack_h2's (the operand of nf_nerf_mlp_fwd_h2), `blob_ha` = the same blocks
+    without the bias K-steps + the bias table (nf_nerf_pack_ha: the operand of nf_nerf_mlp_fwd_ha, the kernel that runs)."""
 
-    def __init__(self, blob):
+    def __init__(self, blob, blob_ha=None):
         self.blob = blob
+        self.blob_ha = blob_ha
+
+    def stream(self, kind):
+        return self.blob_ha if kind == "ha" else self.blob
 
 
 def pack_nerf_h2(weights, biases, cx, cd):
@@ -328,7 +333,9 @@ def pack_nerf_h2(weights, biases, cx, cd):
         keep += [w, b]
         P.w[i], P.b[i] = w.data_ptr(), b.data_ptr()
     check(lib.nf_nerf_pack_h2(ctypes.byref(P), cx, cd, ptr(out), _lib.stream()), "nf_nerf_pack_h2")
-    return PackedH2(out)
+    out_ha = torch.empty(lib.nf_nerf_packed_ha_bytes(), dtype=torch.uint8, device=out.device)
+    check(lib.nf_nerf_pack_ha(ptr(out), ptr(out_ha), _lib.stream()), "nf_nerf_pack_ha")
+    return PackedH2(out, out_ha)
 
 
 class PackedS:
@@ -522,7 +529,7 @@ def render_pass(grid, particles, rays, z, z_table, S, radius, K, enc_flags, use_
                   "nf_nerf_mlp_fwd_s")
         elif isinstance(packed_h, PackedH2):      # fp16-MFMA, two tiles per wave (inference only); X holds an even tile count
             fn, name = _fp16_fwd(lib)
-            check(fn(ptr(packed_h.blob), cx, cd, X_, ptr(nrows_t), mx, rs_, ptr(b.rgbsigma), stream_), name)
+            check(fn(ptr(packed_h.stream(FP16_KERNEL)), cx, cd, X_, ptr(nrows_t), mx, rs_, ptr(b.rgbsigma), stream_), name)
         elif packed_h is not None:
             raise RuntimeError("unknown fp16 weight stream (expected PackedH2 or PackedS)")
         elif wstream is not None and not save_acts:      # fp32, weight stream shared through LDS (inference)
@@ -694,7 +701,7 @@ def mlp_rows(packed, cx, cd, x, save_acts=False, packed_h=None, wstream=None):
             if T % 2:       # the two-tiles-per-wave kernel reads whole tile pairs
                 Xh = torch.cat([Xh, torch.zeros(Xh.numel() // T, dtype=Xh.dtype, device=Xh.device)])
             fn, name = _fp16_fwd(lib)
-            check(fn(ptr(packed_h.blob), cx, cd, ptr(Xh), ptr(n_rows), n, ptr(row_sample), ptr(out), _lib.stream()), name)
+            check(fn(ptr(packed_h.stream(FP16_KERNEL)), cx, cd, ptr(Xh), ptr(n_rows), n, ptr(row_sample), ptr(out), _lib.stream()), name)
             return out
         raise RuntimeError("unknown fp16 weight stream (expected PackedH2 or PackedS)")
     if wstream is not None:

@@ -903,7 +903,7 @@ def test_fp16_hand_scheduled_kernel_bit_equal_to_compiler_scheduled(dev):
     gen = torch.Generator().manual_seed(14)
     for nerf in (net.nerf_coarse, net.nerf_fine):
         ph = net.packed_weights_h(nerf)
-        for n in (1, 31, 32, 33, 64, 65, 127, 129, 255, 257, 4096, 65536 - 3, 65536 + 70, 3 * 65536 + 77):
+        for n in (0, 1, 31, 32, 33, 64, 65, 127, 129, 255, 257, 4096, 65536 - 3, 65536 + 70, 3 * 65536 + 77):      # (0: an empty pass leaves every row alone)
             cap = n + 100
             tiles = (cap + 31) // 32
             tiles += tiles & 1                       # the kernels read whole tile pairs
@@ -911,9 +911,9 @@ def test_fp16_hand_scheduled_kernel_bit_equal_to_compiler_scheduled(dev):
             perm = torch.randperm(cap, generator=gen).to(torch.int32).to(dev)
             n_rows = torch.tensor([n], dtype=torch.int32, device=dev)
             outs = []
-            for fn in (lib.nf_nerf_mlp_fwd_ha, lib.nf_nerf_mlp_fwd_h2):
+            for fn, blob in ((lib.nf_nerf_mlp_fwd_ha, ph.blob_ha), (lib.nf_nerf_mlp_fwd_h2, ph.blob)):
                 o = torch.full((cap, 4), -7.0, device=dev)
-                check(fn(ptr(ph.blob), 198, 54, ptr(Xh), ptr(n_rows), cap, ptr(perm), ptr(o), _lib.stream()), "mlp fp16")
+                check(fn(ptr(blob), 198, 54, ptr(Xh), ptr(n_rows), cap, ptr(perm), ptr(o), _lib.stream()), "mlp fp16")
                 outs.append(o)
             assert torch.equal(outs[0], outs[1]), (n, float((outs[0] - outs[1]).abs().max()))
             written = torch.zeros(cap, dtype=torch.bool, device=dev)
@@ -944,7 +944,7 @@ def test_fp16_hand_scheduled_kernel_under_contention(dev):
     rs = torch.arange(n, dtype=torch.int32, device=dev)
     n_rows = torch.tensor([n], dtype=torch.int32, device=dev)
     quiet = torch.empty(n, 4, device=dev)
-    check(lib.nf_nerf_mlp_fwd_ha(ptr(ph.blob), 198, 54, ptr(Xh), ptr(n_rows), n, ptr(rs), ptr(quiet), _lib.stream()), "ha")
+    check(lib.nf_nerf_mlp_fwd_ha(ptr(ph.blob_ha), 198, 54, ptr(Xh), ptr(n_rows), n, ptr(rs), ptr(quiet), _lib.stream()), "ha")
     torch.cuda.synchronize()
     side = torch.cuda.Stream()
     big = torch.empty(64 * 2 ** 20, device=dev)
@@ -953,7 +953,7 @@ def test_fp16_hand_scheduled_kernel_under_contention(dev):
             for _ in range(6):
                 big.copy_(big.roll(1))
         o = torch.full((n, 4), -1.0, device=dev)
-        check(lib.nf_nerf_mlp_fwd_ha(ptr(ph.blob), 198, 54, ptr(Xh), ptr(n_rows), n, ptr(rs), ptr(o), _lib.stream()), "ha")
+        check(lib.nf_nerf_mlp_fwd_ha(ptr(ph.blob_ha), 198, 54, ptr(Xh), ptr(n_rows), n, ptr(rs), ptr(o), _lib.stream()), "ha")
         torch.cuda.synchronize()
         assert torch.equal(o, quiet), (rep, int((o != quiet).any(1).sum()))
 

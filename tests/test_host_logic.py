@@ -417,10 +417,11 @@ def test_mlp_asm_generator_structure(qx, qd, tmp_path):
 
 
 def test_fp16_mlp_asm_generator_structure(tmp_path):
-    """gen_mlp_ha.py: the instruction stream holds exactly the MFMAs of one pair of tiles (two per step of nf_mlp_h2.hip's stream: 1 414 steps),
-    the pair is a whole number of 48-block rings (1 440 blocks = what nf_nerf_pack_h2 writes), the LDS fits, every counted wait is inside its
-    counter, accumulators are the four VGPR sets, A operands the four slots, B operands come from a bank / the stash slots / the direction
-    registers / the bias operand, one rendezvous per 16-step chunk + the prologue's, four LDS-DMA pieces per chunk + the prologue's two chunks,
+    """gen_mlp_ha.py: the instruction stream holds exactly the MFMAs of one pair of tiles (two per non-bias step of nf_mlp_h2.hip's stream: 1 414 - 78
+    = 1 336 steps; the bias K-step of every output block is the C operand of the block's first MFMAs instead), the pair is a whole number of
+    48-block rings (1 344 blocks = what nf_nerf_pack_ha writes), the LDS fits, every counted wait is inside its counter, accumulators are the four
+    VGPR sets, A operands the four AGPR slots, B operands come from a bank / the stash slots / the direction registers, one rendezvous per
+    16-step chunk + the prologue's, four LDS-DMA pieces per chunk + the prologue's two chunks, four bias-table loads per block + the prologue's,
     and every finished block is rounded exactly once (16 v_cvt_pk_f16_f32 per converted block)."""
     import re
     import subprocess
@@ -431,33 +432,37 @@ def test_fp16_mlp_asm_generator_structure(tmp_path):
     assert r.returncode == 0, r.stderr
     text = open(out).read()
     lines = [ln[1:-3] for ln in text.splitlines() if ln.startswith('"')]
-    steps = 8 * 14 + 3 * 8 * 17 + 8 * 30 + 4 * 8 * 17 + 17 + 4 * 21 + 9
-    assert steps == 1414
-    assert "#define NF_HA_STEPS 1414" in text and "#define NF_HA_SLOTS 1440" in text
+    nblocks = 8 + 8 * 8 + 1 + 4 + 1
+    steps = 8 * 14 + 3 * 8 * 17 + 8 * 30 + 4 * 8 * 17 + 17 + 4 * 21 + 9 - nblocks
+    assert (nblocks, steps) == (78, 1336)
+    assert "#define NF_HA_STEPS 1336" in text and "#define NF_HA_SLOTS 1344" in text
     lds = int(re.search(r"#define NF_HA_LDS_BYTES (\d+)", text).group(1))
     assert lds == 48 * 1024 + 4 * 2 * 13 * 1024 and lds <= 160 * 1024
     mf = [ln for ln in lines if ln.startswith("v_mfma_f32_32x32x16_f16")]
     assert len(mf) == 2 * steps
-    zero_c = 0
+    first = 0
     for ln in mf:
-        m = re.match(r"v_mfma_f32_32x32x16_f16 v\[(\d+):(\d+)\], v\[(\d+):(\d+)\], ([va])\[(\d+):(\d+)\], (0|v\[\d+:\d+\])$", ln)
+        m = re.match(r"v_mfma_f32_32x32x16_f16 v\[(\d+):(\d+)\], a\[(\d+):(\d+)\], ([va])\[(\d+):(\d+)\], v\[(\d+):(\d+)\]$", ln)
         assert m, ln
         lo, hi = int(m.group(1)), int(m.group(2))
         assert hi == lo + 15 and lo in (0, 16, 32, 48)
-        assert m.group(8) in ("0", f"v[{lo}:{hi}]")
-        zero_c += m.group(8) == "0"
+        c = (int(m.group(8)), int(m.group(9)))
+        assert c in ((lo, hi), (192, 207))                # accumulate, or start from the block's biases
+        first += c == (192, 207)
         a0 = int(m.group(3))
-        assert a0 in (192, 196, 200, 204) and int(m.group(4)) == a0 + 3
+        assert a0 in (224, 228, 232, 236) and int(m.group(4)) == a0 + 3
         b0, b1 = int(m.group(6)), int(m.group(7))
         assert b1 == b0 + 3 and b0 % 4 == 0
         if m.group(5) == "v":
-            assert 64 <= b0 < 192 or b0 == 208            # bank 0 / the bias operand
+            assert 64 <= b0 < 192                         # bank 0
         else:
             assert b0 < 128 or 160 <= b0 < 224            # bank 1 / direction operands / stash slots
-    assert zero_c == 2 * (8 + 8 * 8 + 1 + 4 + 1)           # a block (78 of them) starts from C = 0, once per tile
-    assert sum(ln == "s_barrier" for ln in lines) == 1440 // 16 + 1
+    assert first == 2 * nblocks
+    assert sum(ln == "s_barrier" for ln in lines) == 1344 // 16 + 1
     dma = [ln for ln in lines if ln.startswith("global_load_lds_dwordx4")]
-    assert len(dma) == 4 * (1440 // 16) + 8
+    assert len(dma) == 4 * (1344 // 16) + 8
+    bias = [ln for ln in lines if re.match(r"global_load_dwordx4 v\[(192|196|200|204):", ln)]
+    assert len(bias) == 4 * nblocks + 4
     for ln in lines:
         m = re.match(r"s_waitcnt vmcnt\((\d+)\)", ln)
         if m:
@@ -465,5 +470,5 @@ def test_fp16_mlp_asm_generator_structure(tmp_path):
         m = re.match(r"s_waitcnt lgkmcnt\((\d+)\)", ln)
         if m:
             assert int(m.group(1)) < 16
-    assert sum(ln.startswith("v_cvt_pk_f16_f32") for ln in lines) == 16 * (7 + 8 * 8 + 1 + 3 + 1)
+    assert sum(ln.startswith("v_cvt_pk_f16_f32") for ln in lines) == 16 * (nblocks - 2)     # 76 blocks convert their predecessor (all but layer 0 block 0 and view block 0)
     assert not any("None" in ln for ln in lines)

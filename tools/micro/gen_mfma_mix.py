@@ -21,7 +21,11 @@ def body(mode):
     for i in range(64):
         e("v_accvgpr_write_b32 a%d, 0" % i)
     e("s_waitcnt vmcnt(0)")
-    if mode == 8:
+    if mode == 16:
+        e("s_mov_b64 s[46:47], %[src]")
+        e("s_mov_b64 s[48:49], %[src]")
+        e("s_mov_b32 s45, 0")
+    if mode == 8 or mode >= 13:
         e("s_add_u32 s44, s43, 0xc000")
         e("s_mov_b32 m0, s44")
     if mode == 3:
@@ -46,12 +50,25 @@ def body(mode):
                     fill.append("v_cvt_pkrtz_f16_f32 v52, v50, v51")
                     fill.append("v_pk_max_f16 v53, v52, v52")
         mem = {}
-        if mode >= 4:
+        if 4 <= mode <= 11:
             op = {4: "ds_write_b128 v70, v[54:57]", 5: "ds_write_b128 v70, a[64:67]", 6: "global_load_dwordx4 v[54:57], %[roff], %[src]",
                   7: "global_load_dwordx4 a[64:67], %[roff], %[src]", 8: "global_load_lds_dwordx4 %[roff], %[src]",
                   9: "ds_write_b128 v70, v[54:57]", 10: "ds_write_b64 v70, v[54:55]", 11: "ds_write_b32 v70, v54"}[mode]
             for k in range(4):
                 mem[8 * k + (2 if mode == 9 else 1)] = (op + " offset:%d" % (1024 * k),)
+        elif mode >= 12:
+            # the shipped ring protocol in parts: 12 = rendezvous only, 13 = four LDS-DMA pieces per chunk only, 14 = DMA + the counted wait,
+            # 15 = DMA + wait + rendezvous (the kernel's pattern)
+            if mode in (12, 15, 16):
+                mem[23] = ("s_barrier",)
+            if mode in (14, 15, 16):
+                mem[22] = ("s_waitcnt vmcnt(0)",)
+            if mode >= 13:
+                for k in range(4):
+                    mem[24 + 2 * k] = ("global_load_lds_dwordx4 %%[roff], %s offset:%d" % ("s[46:47]" if mode == 16 else "%[src]", 1024 * k),)
+            if mode == 16:      # ... and the source walks a 1.44 MB stream (90 chunks of 16 KB), as the kernel's does: real L2 traffic
+                mem[31] = ("s_add_u32 s46, s46, 0x4000", "s_addc_u32 s47, s47, 0", "s_add_u32 s45, s45, 1", "s_cmp_eq_u32 s45, 90",
+                           "s_cselect_b32 s45, 0, s45", "s_cselect_b32 s46, s48, s46", "s_cselect_b32 s47, s49, s47")
         elif mode >= 3:
             # the rendezvous of the planned kernel: barrier in front of step 12, then one (publish, refill) pair per step in steps 12..15
             mem[23] = ("s_barrier",)
@@ -100,7 +117,7 @@ def body(mode):
 
 def main():
     out = open(sys.argv[1], "w")
-    for mode in range(1, 12):
+    for mode in range(1, 17):
         out.write("#define MIX_BODY_%d \\\n" % mode)
         out.write(" \\\n".join('    "%s\\n"' % l for l in body(mode)))
         out.write("\n\n")

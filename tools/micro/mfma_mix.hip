@@ -44,6 +44,11 @@ __global__ void __launch_bounds__(256) k_mix_asm(const u32x4* __restrict__ src, 
     if (MODE == 9) asm volatile(MIX_BODY_9 : : [iters] "s"(iters), [lds] "v"(lds), [loff] "v"(loff), [roff] "v"(roff), [src] "s"(src), [bsrc] "s"(bsrc), [bsrc2] "s"(bsrc + 256) : MIX_CLOB, "m0");
     if (MODE == 10) asm volatile(MIX_BODY_10 : : [iters] "s"(iters), [lds] "v"(lds), [loff] "v"(loff), [roff] "v"(roff), [src] "s"(src), [bsrc] "s"(bsrc), [bsrc2] "s"(bsrc + 256) : MIX_CLOB, "m0");
     if (MODE == 11) asm volatile(MIX_BODY_11 : : [iters] "s"(iters), [lds] "v"(lds), [loff] "v"(loff), [roff] "v"(roff), [src] "s"(src), [bsrc] "s"(bsrc), [bsrc2] "s"(bsrc + 256) : MIX_CLOB, "m0");
+    if (MODE == 12) asm volatile(MIX_BODY_12 : : [iters] "s"(iters), [lds] "v"(lds), [loff] "v"(loff), [roff] "v"(roff), [src] "s"(src), [bsrc] "s"(bsrc), [bsrc2] "s"(bsrc + 256) : MIX_CLOB, "m0");
+    if (MODE == 13) asm volatile(MIX_BODY_13 : : [iters] "s"(iters), [lds] "v"(lds), [loff] "v"(loff), [roff] "v"(roff), [src] "s"(src), [bsrc] "s"(bsrc), [bsrc2] "s"(bsrc + 256) : MIX_CLOB, "m0");
+    if (MODE == 14) asm volatile(MIX_BODY_14 : : [iters] "s"(iters), [lds] "v"(lds), [loff] "v"(loff), [roff] "v"(roff), [src] "s"(src), [bsrc] "s"(bsrc), [bsrc2] "s"(bsrc + 256) : MIX_CLOB, "m0");
+    if (MODE == 15) asm volatile(MIX_BODY_15 : : [iters] "s"(iters), [lds] "v"(lds), [loff] "v"(loff), [roff] "v"(roff), [src] "s"(src), [bsrc] "s"(bsrc), [bsrc2] "s"(bsrc + 256) : MIX_CLOB, "m0");
+    if (MODE == 16) asm volatile(MIX_BODY_16 : : [iters] "s"(iters), [lds] "v"(lds), [loff] "v"(loff), [roff] "v"(roff), [src] "s"(src), [bsrc] "s"(bsrc), [bsrc2] "s"(bsrc + 256) : MIX_CLOB, "m0", "s45", "s46", "s47", "s48", "s49");
     const unsigned long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
     out[blockIdx.x * 256 + threadIdx.x] = 0.f;
     if (lane == 0) {
@@ -126,7 +131,7 @@ int main(int argc, char** argv)
     const int iters = argc > 1 ? atoi(argv[1]) : 20000;
     u32x4* src; float* out; unsigned long long* ticks;
     const int nq = 48 * 64 + 8 * 64;
-    hipMalloc(&src, nq * 16); hipMalloc(&out, 256 * 256 * 4); hipMalloc(&ticks, 1024 * 16);
+    hipMalloc(&src, 2 << 20); hipMemset(src, 0, 2 << 20); /* (mode 16 walks 1.44 MB of it) */ hipMalloc(&out, 256 * 256 * 4); hipMalloc(&ticks, 1024 * 16);
     const char* names[3] = {"A random, B random", "A random, B post-ReLU (half zero)", "A small weights (|w|<0.06), B post-ReLU"};
     for (int fill = 0; fill < 3; ++fill) {
         std::vector<unsigned> h(nq * 4);
@@ -142,7 +147,7 @@ int main(int argc, char** argv)
             h[i] = f2h(v[0]) | ((unsigned)f2h(v[1]) << 16);
         }
         hipMemcpy(src, h.data(), h.size() * 4, hipMemcpyHostToDevice);
-        for (int mode = 0; mode < 15; ++mode)
+        for (int mode = 0; mode < 20; ++mode)
             for (int rep = 0; rep < 3; ++rep) {
                 hipEvent_t e0, e1;
                 hipEventCreate(&e0); hipEventCreate(&e1);
@@ -162,6 +167,11 @@ int main(int argc, char** argv)
                 if (mode == 12) hipLaunchKernelGGL(k_mix_asm<9>, dim3(256), dim3(256), 65536, 0, src, out, ticks, iters);
                 if (mode == 13) hipLaunchKernelGGL(k_mix_asm<10>, dim3(256), dim3(256), 65536, 0, src, out, ticks, iters);
                 if (mode == 14) hipLaunchKernelGGL(k_mix_asm<11>, dim3(256), dim3(256), 65536, 0, src, out, ticks, iters);
+                if (mode == 15) hipLaunchKernelGGL(k_mix_asm<12>, dim3(256), dim3(256), 65536, 0, src, out, ticks, iters);
+                if (mode == 16) hipLaunchKernelGGL(k_mix_asm<13>, dim3(256), dim3(256), 65536, 0, src, out, ticks, iters);
+                if (mode == 17) hipLaunchKernelGGL(k_mix_asm<14>, dim3(256), dim3(256), 65536, 0, src, out, ticks, iters);
+                if (mode == 18) hipLaunchKernelGGL(k_mix_asm<15>, dim3(256), dim3(256), 65536, 0, src, out, ticks, iters);
+                if (mode == 19) hipLaunchKernelGGL(k_mix_asm<16>, dim3(256), dim3(256), 65536, 0, src, out, ticks, iters);
                 hipEventRecord(e1);
                 hipEventSynchronize(e1);
                 float ms;

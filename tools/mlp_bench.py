@@ -127,11 +127,11 @@ if len(sys.argv) > 3 and sys.argv[3] == "fp16asm":
         Xh = torch.cat([Xh, torch.zeros(Xh.numel() // T, dtype=Xh.dtype, device=dev)])
     out2 = torch.zeros(n, 4, device=dev)
     out5 = torch.full((n, 4), 7.0, device=dev)
-    for name, fn, o in (("h2", lib.nf_nerf_mlp_fwd_h2, out2), ("ha", lib.nf_nerf_mlp_fwd_ha, out5)):
+    for name, fn, o, blob in (("h2", lib.nf_nerf_mlp_fwd_h2, out2, ph.blob), ("ha", lib.nf_nerf_mlp_fwd_ha, out5, ph.blob_ha)):
         for it in range(iters):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            check(fn(ptr(ph.blob), 198, 54, ptr(Xh), ptr(n_rows), n, ptr(row_sample), ptr(o), _lib.stream()))
+            check(fn(ptr(blob), 198, 54, ptr(Xh), ptr(n_rows), n, ptr(row_sample), ptr(o), _lib.stream()))
             e1.record(); torch.cuda.synchronize()
             ms = e0.elapsed_time(e1)
             print(f"{name} iter {it}: rows {n} {ms:.3f} ms  {n*1331968/ms/1e9:.1f} TFLOP/s", flush=True)
@@ -156,7 +156,7 @@ if len(sys.argv) > 3 and sys.argv[3] == "fp16asmonly":
     for it in range(iters):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        check(lib.nf_nerf_mlp_fwd_ha(ptr(ph.blob), 198, 54, ptr(Xh), ptr(n_rows), n, ptr(row_sample), ptr(out5), _lib.stream()))
+        check(lib.nf_nerf_mlp_fwd_ha(ptr(ph.blob_ha), 198, 54, ptr(Xh), ptr(n_rows), n, ptr(row_sample), ptr(out5), _lib.stream()))
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1)
         print(f"ha iter {it}: rows {n} {ms:.3f} ms  {n*1331968/ms/1e9:.1f} TFLOP/s", flush=True)

@@ -200,10 +200,45 @@ __global__ void __launch_bounds__(SG_BLOCK) k_search(const void* __restrict__ ws
                     // (requesting the next passing chunks ahead of the test was measured: 961 -> 1 223 us for the fine pass — the
                     // loads wasted by the early exit at the K-th hit cost more than the latency they hide; the kernel is bound
                     // by the requests it issues, not by the requests it keeps in flight)
+#ifndef SG_PAIR
+#define SG_PAIR 1        // passing chunks walked TWO per trip (round 5): both chunks' entries are requested together, so a full row's ~8 dependent trips become ~4
+#endif
                     while (m && cnt < K) {
                         const int bit = __ffs(m) - 1;
                         m &= m - 1u;
                         const int t = cb0 + (cbase + bit) * NF_DIL_CHUNK + l;      // NF_DIL_CHUNK == SG_LANES: one entry per lane
+#if SG_PAIR
+                        const bool two = m != 0u;                                  // (uniform inside the quarter-wave)
+                        const int bit2 = two ? __ffs(m) - 1 : 0;
+                        if (two) m &= m - 1u;
+                        const int t2 = cb0 + (cbase + bit2) * NF_DIL_CHUNK + l;
+                        const bool in1 = t >= s && t < e, in2 = two && t2 >= s && t2 < e;
+                        float4 p = make_float4(0.f, 0.f, 0.f, 0.f), p2 = p;
+                        if (in1) p = g.dil_pos[t];
+                        if (in2) p2 = g.dil_pos[t2];
+                        bool hit = false, nonzero = false, hit2 = false, nonzero2 = false;
+                        if (in1) {
+                            const float d2 = nf_dist2(x, y, zz, p.x, p.y, p.z);
+                            hit = d2 < r2;
+                            nonzero = d2 != 0.f;
+                        }
+                        if (in2) {
+                            const float d2 = nf_dist2(x, y, zz, p2.x, p2.y, p2.z);
+                            hit2 = d2 < r2;
+                            nonzero2 = d2 != 0.f;
+                        }
+                        const unsigned hm = (unsigned)(__ballot(hit) >> gsh) & 0xffffu;
+                        const unsigned hm2 = (unsigned)(__ballot(hit2) >> gsh) & 0xffffu;
+                        const int pos = cnt + __popc(hm & lt);
+                        const int cnt1 = cnt + __popc(hm);
+                        const int pos2 = cnt1 + __popc(hm2 & lt);
+                        const bool take = hit && pos < K, take2 = hit2 && pos2 < K;
+                        if (take) s_list_w[slot * pitch + pos] = __float_as_int(p.w);
+                        if (take2) s_list_w[slot * pitch + pos2] = __float_as_int(p2.w);
+                        nz += __popc((unsigned)(__ballot(take && nonzero) >> gsh) & 0xffffu) +       // nn_mask = dists.ne(0)
+                              __popc((unsigned)(__ballot(take2 && nonzero2) >> gsh) & 0xffffu);
+                        cnt = cnt1 + __popc(hm2);
+#else
                         bool hit = false, nonzero = false;
                         int pi = 0;
                         if (t >= s && t < e) {
@@ -219,6 +254,7 @@ __global__ void __launch_bounds__(SG_BLOCK) k_search(const void* __restrict__ ws
                         if (take) s_list_w[slot * pitch + pos] = pi;
                         nz += __popc((unsigned)(__ballot(take && nonzero) >> gsh) & 0xffffu);   // nn_mask = dists.ne(0)
                         cnt += __popc(hm);
+#endif
                     }
                 }
                 if (cnt > K) cnt = K;

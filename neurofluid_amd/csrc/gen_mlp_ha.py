@@ -314,6 +314,12 @@ def gen():
 
     # ------------------------------------------------------------------ prologue
     p.i(f"s_mov_b64 {sp(S_WBASE)}, {IN['stream']}")
+    if knob("TIMING"):          # dev: block 0 / wave 0 leaves (shader cycles, 100 MHz ticks) of its residency in the stream's first padding block
+        p.i("s_memtime s[92:93]")
+        p.i("s_memrealtime s[94:95]")
+        p.i("s_waitcnt lgkmcnt(0)")
+        p.i("s_mov_b32 s90, s92")
+        p.i("s_mov_b32 s91, s94")
     p.i(f"s_mov_b64 {sp(S_XH)}, {IN['X']}")
     p.i(f"s_mov_b64 {sp(S_RS)}, {IN['row_sample']}")
     p.i(f"s_mov_b64 {sp(S_OUT)}, {IN['out']}")
@@ -652,6 +658,22 @@ def gen():
         emit_items(p, g)
     p.i(".Lnf_ha_done_%=:")
     p.i("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    if knob("TIMING"):
+        p.i("s_memtime s[92:93]")
+        p.i("s_memrealtime s[94:95]")
+        p.i("s_waitcnt lgkmcnt(0)")
+        p.i("s_sub_u32 s92, s92, s90")
+        p.i("s_sub_u32 s94, s94, s91")
+        p.i(f"s_or_b32 s90, {IN['block']}, s{S_WAVE}")
+        p.i("s_cmp_eq_u32 s90, 0")
+        p.i("s_cbranch_scc0 .Lnf_ha_notime_%=")
+        p.i("v_mov_b32 v0, s92")
+        p.i("v_mov_b32 v1, s94")
+        p.i(f"v_mov_b32 v2, {nreal * 1024}")
+        p.i("s_mov_b64 exec, 1")
+        p.i(f"global_store_dwordx2 v2, v[0:1], {sp(S_WBASE)}")
+        p.i("s_waitcnt vmcnt(0)")
+        p.i(".Lnf_ha_notime_%=:")
     return p.lines, NSLOT, nreal
 
 

@@ -471,7 +471,9 @@ def renderer_train_step(renderer, optimizer, scheduler, particles, views, H, W, 
     rays, rgbs, ro = gather_view_pixels([v["rays"] for v in views], [v["rgb"] for v in views], [v["cw"] for v in views],
                                         coords, sels, H, W)
     out = renderer(particles, ro, rays, None, None)
-    total = summed_view_mse(out, rgbs, len(views), renderer.N_importance > 0)
+    fine = renderer.N_importance > 0
+    # (GPU: the views' MSE sums and their gradients in one launch, as RendererTrainer.train_step does)
+    total = e2e_loss(out, rgbs, len(views), fine) if rgbs.is_cuda else summed_view_mse(out, rgbs, len(views), fine)
     optimizer.zero_grad()
     total.backward()
     nfdist.allreduce_grads(list(renderer.parameters()), world)

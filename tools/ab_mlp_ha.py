@@ -49,12 +49,13 @@ def run(rows, iters):
     for f in sorted(os.listdir(VARD)):
         if not f.endswith(".so"):
             continue
-        env = dict(os.environ, NF_LIB_PATH=os.path.join(VARD, f))
+        env = dict(os.environ, NF_LIB_PATH=os.path.join(VARD, f), NF_HA_TIMING_READ="1" if "timing" in f else "")
         out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "mlp_bench.py"), str(rows), str(iters), "fp16asmonly"], env=env,
                              capture_output=True, text=True, timeout=600).stdout
         ts = [float(l.split()[-2]) for l in out.splitlines() if l.startswith("ha iter")]
         eq = [l for l in out.splitlines() if l.startswith("ha vs")]
-        print("%-24s %s  best %.1f TFLOP/s   %s" % (f[4:-3], " ".join("%.1f" % t for t in ts), max(ts) if ts else 0, eq[0] if eq else ""), flush=True)
+        tm = [l for l in out.splitlines() if l.startswith("timing")]
+        print("%-24s %s  best %.1f TFLOP/s   %s  %s" % (f[4:-3], " ".join("%.1f" % t for t in ts), max(ts) if ts else 0, eq[0] if eq else "", tm[0] if tm else ""), flush=True)
 
 
 if __name__ == "__main__":

@@ -161,3 +161,8 @@ if len(sys.argv) > 3 and sys.argv[3] == "fp16asmonly":
         ms = e0.elapsed_time(e1)
         print(f"ha iter {it}: rows {n} {ms:.3f} ms  {n*1331968/ms/1e9:.1f} TFLOP/s", flush=True)
     print("ha vs h2: bit-equal", bool(torch.equal(out2, out5)))
+    if os.environ.get("NF_HA_TIMING_READ"):
+        tt = ph.blob_ha[1336 * 1024:1336 * 1024 + 8].view(torch.int32).cpu().tolist()
+        pairs = (n + 63) // 64
+        rounds = (pairs + 1023) // 1024
+        print(f"timing: {tt[0]} shader cycles, {tt[1]} ticks of 10 ns -> {tt[0] / max(tt[1], 1) * 0.1:.3f} GHz, {tt[0] / (rounds * 2672):.2f} cycles per MFMA over {rounds} pairs per wave", flush=True)

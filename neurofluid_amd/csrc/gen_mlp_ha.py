@@ -1,24 +1,26 @@
 #!/usr/bin/env python3
 """Generator of the hand-scheduled instruction stream of k_mlp_fwd_ha (nf_mlp_ha.hip): the fp16-MFMA NeRF MLP forward
-(/root/reference/models/nerf.py:83-124) of nf_mlp_h2.hip — the SAME weight stream (nf_nerf_pack_h2: 1 KB A blocks in consumption
-order), the same X layout, the same arithmetic in the same order (v_mfma_f32_32x32x16_f16, fp32 accumulate, out-block-major, two
-32-row tiles per wave, every finished block rounded to packed fp16 once) — with every instruction of the pair body placed by this
-script instead of by the compiler:
+(/root/reference/models/nerf.py:83-124) of nf_mlp_h2.hip — its weight blocks (nf_nerf_pack_h2's 1 KB A blocks in consumption order, re-packed
+by nf_nerf_pack_ha WITHOUT the 78 bias K-steps: their exact value fp32(hi) + fp32(lo) is the C operand of each output block's first MFMAs, read
+from a table behind the stream), the same X layout, the same arithmetic in the same order (v_mfma_f32_32x32x16_f16, fp32 accumulate,
+out-block-major, two 32-row tiles per wave, every finished block rounded to packed fp16 once) — bit-identical results, with every instruction of
+the pair body placed by this script instead of by the compiler:
 
-  * the whole pair (1 414 steps of one A block x two tiles, + 26 padding steps without arithmetic = 90 chunks of 16) is
-    straight-line code: ring positions, register names, wait counts and the rendezvous steps are constants;
-  * per step: the ds_read_b128 of the A block three steps ahead, (X steps) the two stash reads two steps ahead, ONE counted
-    s_waitcnt, two MFMAs; everything else sits behind one of the two MFMAs: the conversion pieces of the previous block (one piece
-    of 4-6 VALU per step in steps 1..8), the ring rendezvous (s_barrier in front of step 12 of every chunk, then one publish
-    ds_write + one refill load per step in steps 12..15), the staging of the next pair's X into the LDS stash (layers 5-6), the
-    direction-feature loads (layer 8) and the row_sample loads;
-  * registers: four accumulators v[0:63] (VGPR form: the VALU converts them directly), activation bank 0 v[64:191], four A-operand
-    slots v[192:207]; activation bank 1 a[0:127] (MFMA B operands are read from AGPRs directly), ring staging a[128:143], X
-    staging a[144:159], direction operands a[160:191], stash operand slots a[192:223] — every memory instruction that feeds an
-    MFMA B operand loads straight into AGPRs.
+  * the whole pair (1 336 steps of one A block x two tiles + 8 padding steps without arithmetic = 84 chunks of 16 = 28 rings) is straight-line
+    code: ring positions, register names, wait counts and the rendezvous steps are constants;
+  * per step: the ds_read_b128 of the A block three steps ahead, (X steps) the two stash reads two steps ahead, ONE counted s_waitcnt, two
+    MFMAs; everything else is a `piece` placed by a budgeted list scheduler into the shadow of a named MFMA: the conversion pieces of the
+    previous block, the ring refill (s_barrier in front of step 12 of every chunk, then four LDS-DMA pieces; waited for by vmcnt in front of
+    the next rendezvous), the next block's bias-table loads, the staging of the next pair's X into the LDS stash (layers 5-6), the
+    direction-feature loads (layer 8), the row_sample loads, the per-pair scalar setup and the PREVIOUS pair's sigmoid + store;
+  * registers: four accumulators v[0:63] (VGPR form: the VALU converts them directly), activation bank 0 v[64:191], the bias C operand
+    v[192:207]; activation bank 1 a[0:127] (MFMA A / B operands are read from AGPRs directly), X staging a[144:159], direction operands
+    a[160:191], stash operand slots a[192:223], A-operand slots a[224:239].
 
 Output: a C string literal (one "...\\n" line per instruction) included by nf_mlp_ha.hip as the body of ONE asm statement.
 Usage: python gen_mlp_ha.py [out.inc]      (neurofluid_amd/build.py runs it before compiling nf_mlp_ha.hip)
+Dev switches: NF_HA_* in the environment (tools/ab_mlp_ha.py builds A/B libraries from them); NF_HA_TIMING=1 leaves block 0 / wave 0's
+shader cycles and 100 MHz ticks in the stream's first padding block.
 """
 import os
 import sys

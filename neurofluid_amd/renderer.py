@@ -66,6 +66,10 @@ class RenderNet(nn.Module):
             # models/renderer.py:100-106: the smoothed position is blended with the ray position (k_features' `blend`)
             self.enc_flags |= 16 | (32 if _get(cfg, "encoding.same_smooth_factor", False) else 0)
         self.in_channels_xyz, self.in_channels_dir = in_xyz, in_dir
+        if self.mlp_dtype != "fp32" and ((in_xyz + 7) // 8, (in_dir + 7) // 8) != (25, 7):
+            # the fp16 / split weight streams (nf_nerf_pack_h2 / _s) exist for the default feature row only: say so here, not inside the first frame
+            raise NotImplementedError("RENDERER.mlp_dtype = %s is built for the default encoding (198 + 54 features); this configuration has %d + %d"
+                                      % (self.mlp_dtype, in_xyz, in_dir))
         self.nerf_coarse = NeRF(in_channels_xyz=in_xyz, in_channels_dir=in_dir)
         self.nerf_fine = NeRF(in_channels_xyz=in_xyz, in_channels_dir=in_dir)
         self._z_table = None

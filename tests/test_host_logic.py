@@ -472,3 +472,25 @@ def test_fp16_mlp_asm_generator_structure(tmp_path):
             assert int(m.group(1)) < 16
     assert sum(ln.startswith("v_cvt_pk_f16_f32") for ln in lines) == 16 * (nblocks - 2)     # 76 blocks convert their predecessor (all but layer 0 block 0 and view block 0)
     assert not any("None" in ln for ln in lines)
+
+
+def test_reduced_precision_mlp_refuses_other_feature_rows_at_construction():
+    """RENDERER.mlp_dtype fp16 / split have weight streams for the default 198 + 54 feature row only: a configuration with another encoding is refused
+    when the module is built (CPU, no library needed), not inside its first frame; fp32 accepts every encoding (tests/golden/cfg_*.npz)."""
+    import pytest
+    from neurofluid_amd.renderer import RenderNet
+
+    def renderer_cfg():
+        return dict(use_mask=True, ray=dict(ray_chunk=1024, N_importance=128, N_samples=64),
+                    NN_search=dict(fix_radius=True, particle_radius=0.025, search_raduis_scale=9.0, N_neighbor=20),
+                    encoding=dict(density=True, var=True, smoothed_pos=True, smoothed_dir=True, exclude_ray=True, same_smooth_factor=False))
+    for dt in ("fp16", "split"):
+        cfg = renderer_cfg(); cfg["mlp_dtype"] = dt
+        RenderNet(cfg, 9.0, 13.0)                                      # the default row: fine
+        cfg["encoding"] = dict(cfg["encoding"], smoothed_dir=False)
+        with pytest.raises(NotImplementedError, match="198 \\+ 54"):
+            RenderNet(cfg, 9.0, 13.0)
+    cfg = renderer_cfg(); cfg["encoding"] = dict(cfg["encoding"], smoothed_dir=False)
+    assert RenderNet(cfg, 9.0, 13.0).in_channels_dir == 27
+    with pytest.raises(ValueError):
+        RenderNet(dict(renderer_cfg(), mlp_dtype="bf16"), 9.0, 13.0)

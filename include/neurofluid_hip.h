@@ -435,6 +435,13 @@ void* nf_pinned_device_ptr(void* host_ptr /*[host] page-locked*/);
  * completion word (host_flag3[2]) outside the interpreter — a ctypes call releases the GIL. */
 int nf_host_wait_word(const volatile int32_t* word /*[host] page-locked*/, int32_t expected, double timeout_s);
 
+/* The pixel gathers of one training step (trainer/basetrainer.py:186-193: rays[v][ys, xs], rgbs[v][ys, xs] of every view + the view's camera
+ * position c2w[v][:, 3] per ray) in one launch.  rays / rgb / c2w: HOST arrays of n_views (<= 16) device pointers to (H*W, 6), (H*W, rgb_c), (3, 4)
+ * row-major tensors; flat: n_views * per_view pixel indices in [0, n_pixels) (device, view-major; validated by the caller on the host, where they
+ * are drawn — the kernel clamps strays to pixel 0); outputs view-major (n_views * per_view, 6 / rgb_c / 3). */
+int nf_gather_view_pixels(int n_views, const float* const* rays, const float* const* rgb, const float* const* c2w, int per_view, int rgb_c,
+                          int64_t n_pixels, const int64_t* flat, float* rays_out, float* rgb_out, float* ro_out, nf_stream_t stream);
+
 /* B8 glue (round 5): the elementwise / reduction steps between the launches of the transition model's backward.
  * nf_relu_bwd_add: out = (prev > 0 ? dx : 0) + (res or 0) — the ReLU in front of a layer back-propagated (+ the residual branch), n floats.
  * nf_colsum: out[c] (and out2[c] if given) = sum_r a[r * lda + c] — bias gradients; deterministic.

@@ -123,6 +123,7 @@ PROTOTYPES = {
     "nf_trans_front": (c_int, [c_void_p] * 5 + [c_int, c_float, c_float, c_int, c_int, c_int] + [c_void_p] * 13 + [c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "nf_pinned_device_ptr": (c_void_p, [c_void_p]),
     "nf_host_wait_word": (c_int, [c_void_p, c_int, ctypes.c_double]),
+    "nf_gather_view_pixels": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, ctypes.c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nf_relu_bwd_add": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "nf_colsum": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "nf_cconv_split_db": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -261,6 +261,54 @@ extern "C" int nf_relu_bwd_add(const float* dx, const float* prev, const float* 
     return NF_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The pixel gathers of one training step (trainer/basetrainer.py:186-193: rays[v][ys, xs], rgbs[v][ys, xs] per view, and the view's camera
+// position per ray) in ONE launch: thread i = view v * per_view + k copies row flat[i] of view v's (H*W, 6) rays and (H*W, C) colours and
+// writes the view's origin c2w[v][:, 3].  Replaces, per step, 2 index_select per view + 3 cat + a repeat_interleave.
+// ------------------------------------------------------------------------------------------------
+#define NF_GATHER_MAX_VIEWS 16
+struct NfGatherViews { const float* rays[NF_GATHER_MAX_VIEWS]; const float* rgb[NF_GATHER_MAX_VIEWS]; const float* c2w[NF_GATHER_MAX_VIEWS]; };
+
+__global__ void __launch_bounds__(256) k_gather_view_pixels(NfGatherViews V, int n_views, int per_view, int rgb_c, long long n_pixels,
+                                                            const long long* __restrict__ flat, float* __restrict__ rays_out,
+                                                            float* __restrict__ rgb_out, float* __restrict__ ro_out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_views * per_view) return;
+    const int v = i / per_view;
+    long long px = flat[i];
+    if (px < 0 || px >= n_pixels) px = 0;          // (never read out of bounds; the host wrapper validates the indices before it uploads them)
+    const float* r = V.rays[v] + px * 6;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) rays_out[(size_t)i * 6 + c] = r[c];
+    const float* g = V.rgb[v] + px * rgb_c;
+    for (int c = 0; c < rgb_c; ++c) rgb_out[(size_t)i * rgb_c + c] = g[c];
+    const float* cw = V.c2w[v];
+    ro_out[(size_t)i * 3 + 0] = cw[3]; ro_out[(size_t)i * 3 + 1] = cw[7]; ro_out[(size_t)i * 3 + 2] = cw[11];
+}
+
+// rays / rgb / c2w: HOST arrays of n_views device pointers ((H*W, 6), (H*W, rgb_c), (3, 4) row-major contiguous); flat: n_views * per_view int64
+// pixel indices on the device, each in [0, n_pixels) (the caller validates them on the host, where they are drawn; the kernel clamps strays to 0).
+extern "C" int nf_gather_view_pixels(int n_views, const float* const* rays, const float* const* rgb, const float* const* c2w, int per_view,
+                                     int rgb_c, int64_t n_pixels, const int64_t* flat, float* rays_out, float* rgb_out, float* ro_out,
+                                     nf_stream_t stream)
+{
+    NF_CHECK_ARG(rays && rgb && c2w && flat && rays_out && rgb_out && ro_out, "null pointer");
+    NF_CHECK_ARG(n_views >= 1 && n_views <= NF_GATHER_MAX_VIEWS && per_view >= 0 && rgb_c >= 1 && n_pixels >= 1, "bad sizes (at most 16 views per call)");
+    if (per_view == 0) return NF_OK;
+    NfGatherViews V;
+    for (int v = 0; v < n_views; ++v) {
+        NF_CHECK_ARG(rays[v] && rgb[v] && c2w[v], "null view pointer");
+        V.rays[v] = rays[v]; V.rgb[v] = rgb[v]; V.c2w[v] = c2w[v];
+    }
+    for (int v = n_views; v < NF_GATHER_MAX_VIEWS; ++v) { V.rays[v] = nullptr; V.rgb[v] = nullptr; V.c2w[v] = nullptr; }
+    const int n = n_views * per_view;
+    hipLaunchKernelGGL(k_gather_view_pixels, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, V, n_views, per_view, rgb_c,
+                       (long long)n_pixels, (const long long*)flat, rays_out, rgb_out, ro_out);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
 // Column sums of a (rows x cols) row-major matrix with leading dimension lda (a column slice of a wider matrix is fine): the bias
 // gradients.  One workgroup per 16 columns, 16 x 16 threads: thread (r, c) walks rows r, r + 16, ... of its column, then a fixed tree
 // over the 16 partial sums in LDS — deterministic.  out2 (optional) receives a second copy (conv.bias and dense.bias of a layer get the

@@ -236,7 +236,7 @@ def choice_without_replacement(rng, n, size):
 
 
 def gather_view_pixels(rays_list, rgb_list, cw_list, coords, sels, H, W):
-    """The pixel gathers of all views of one step with ONE upload and one index_select per tensor (the reference indexes
+    """The pixel gathers of all views of one step with ONE upload and (GPU tensors) ONE launch (the reference indexes
     every view separately, trainer/basetrainer.py:186-193: 2 two-index gathers + 1 upload per view = 16 small dispatches
     and 1.4 ms of host time per step).  rays_list[v] (H, W, 6), rgb_list[v] (H*W, C), cw_list[v] (3, 4) on the device,
     coords (n, 2) on the host, sels[v] the selected rows of coords.  Returns rays (V*rc, 6), rgbs (V*rc, C), ro (V*rc, 3),
@@ -244,7 +244,29 @@ def gather_view_pixels(rays_list, rgb_list, cw_list, coords, sels, H, W):
     dev = rays_list[0].device
     V, rc = len(rays_list), len(sels[0])
     yx = torch.cat([coords[torch.as_tensor(s)] for s in sels]).long()
-    flat = _upload(yx[:, 0] * W + yx[:, 1], dev)          # pixel index inside its own view: ONE upload for all views
+    flat_host = yx[:, 0] * W + yx[:, 1]                       # pixel index inside its own view
+    if dev.type == "cuda" and 1 <= V <= 16 and all(t.dtype is torch.float32 for t in list(rays_list) + list(rgb_list) + list(cw_list)):
+        # ONE upload + ONE launch (nf_gather_view_pixels) for all views and all three tensors
+        if rc and (int(flat_host.min()) < 0 or int(flat_host.max()) >= H * W):
+            raise IndexError("pixel selection outside the %d x %d image" % (H, W))
+        from . import _lib
+        lib = _lib.load()
+        flat = _upload(flat_host, dev)
+        rl = [r.reshape(H * W, -1).contiguous() for r in rays_list]
+        gl = [g.reshape(H * W, -1).contiguous() for g in rgb_list]
+        cl = [c.contiguous() for c in cw_list]
+        C = gl[0].shape[1]
+        if any(r.shape[1] != 6 for r in rl) or any(g.shape[1] != C for g in gl) or any(tuple(c.shape) != (3, 4) for c in cl):
+            raise ValueError("gather_view_pixels: rays (H, W, 6), colours (H*W, C) and c2w (3, 4) expected for every view")
+        rays = torch.empty(V * rc, 6, device=dev)
+        rgbs = torch.empty(V * rc, C, device=dev)
+        ro = torch.empty(V * rc, 3, device=dev)
+        arr = ctypes.c_void_p * V
+        _lib.check(lib.nf_gather_view_pixels(V, arr(*[t.data_ptr() for t in rl]), arr(*[t.data_ptr() for t in gl]), arr(*[t.data_ptr() for t in cl]),
+                                             rc, C, H * W, flat.data_ptr(), rays.data_ptr(), rgbs.data_ptr(), ro.data_ptr(), _lib.stream()),
+                   "nf_gather_view_pixels")
+        return rays, rgbs, ro
+    flat = _upload(flat_host, dev)          # ONE upload for all views
     # one index_select per view and tensor on that view's own storage (round 2 concatenated the whole images of all views
     # first: 23 MB of copies per step at 400^2, 92 MB at 800^2, to read 4 096 rows)
     rays = torch.cat([rays_list[v].reshape(H * W, -1).index_select(0, flat[v * rc:(v + 1) * rc]) for v in range(V)]) if V > 1 \

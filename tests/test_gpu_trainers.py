@@ -298,3 +298,31 @@ def test_fused_e2e_loss_matches_torch_ops():
         if wb:
             assert float((pos.grad != 0).float().mean()) > 0.01            # some particles are outside the box
             assert float((got[3] - pos.grad).abs().max()) <= 1e-6 * float(pos.grad.abs().max())
+
+
+@pytest.mark.gpu
+def test_gather_view_pixels_one_launch_equals_per_view_indexing():
+    """train_step.gather_view_pixels on GPU tensors (nf_gather_view_pixels: one upload + one launch for all views' rays, colours and camera
+    positions) against indexing every view on its own (trainer/basetrainer.py:186-193): the same rows, bit for bit, for 1 / 4 / 16 views, RGB and
+    RGBA colours, at the training size (400 x 400, 1 024 pixels per view); more than 16 views take the per-view path; a selection outside the
+    image is refused on the host."""
+    from neurofluid_amd.train_step import gather_view_pixels
+    dev = torch.device("cuda:0")
+    H = W = 400
+    g = torch.Generator().manual_seed(3)
+    coords = torch.stack(torch.meshgrid(torch.arange(H).float(), torch.arange(W).float(), indexing="ij"), -1).reshape(-1, 2)
+    for V, C, rc in ((1, 3, 1024), (4, 3, 1024), (16, 4, 333), (17, 3, 64)):
+        rays = [torch.randn(H, W, 6, generator=g).to(dev) for _ in range(V)]
+        rgbs = [torch.rand(H * W, C, generator=g).to(dev) for _ in range(V)]
+        cws = [torch.randn(3, 4, generator=g).to(dev) for _ in range(V)]
+        sels = [np.random.RandomState(10 + v).choice(H * W, rc, replace=False) for v in range(V)]
+        r, c, ro = gather_view_pixels(rays, rgbs, cws, coords, sels, H, W)
+        assert r.shape == (V * rc, 6) and c.shape == (V * rc, C) and ro.shape == (V * rc, 3)
+        for v in range(V):
+            yx = coords[sels[v]].long().to(dev)
+            assert torch.equal(r[v * rc:(v + 1) * rc], rays[v][yx[:, 0], yx[:, 1]])
+            assert torch.equal(c[v * rc:(v + 1) * rc], rgbs[v][yx[:, 0] * W + yx[:, 1]])
+            assert torch.equal(ro[v * rc:(v + 1) * rc], cws[v][:, 3].expand(rc, 3))
+    bad = torch.cat([coords, torch.tensor([[float(H), 0.0]])])
+    with pytest.raises(IndexError):
+        gather_view_pixels(rays[:1], rgbs[:1], cws[:1], bad, [np.array([H * W])], H, W)

@@ -310,31 +310,54 @@ extern "C" int nf_gather_view_pixels(int n_views, const float* const* rays, cons
 }
 
 // Column sums of a (rows x cols) row-major matrix with leading dimension lda (a column slice of a wider matrix is fine): the bias
-// gradients.  One workgroup per 16 columns, 16 x 16 threads: thread (r, c) walks rows r, r + 16, ... of its column, then a fixed tree
-// over the 16 partial sums in LDS — deterministic.  out2 (optional) receives a second copy (conv.bias and dense.bias of a layer get the
-// same gradient).
-__global__ void __launch_bounds__(256) k_colsum(const float* __restrict__ a, int rows, int cols, int lda, float* __restrict__ out, float* __restrict__ out2)
+// gradients.  One workgroup per FOUR columns, 256 threads: thread r walks rows r, r + 256, ... with one 16-byte load per row (scalar loads
+// when the slice is not 16-byte aligned), then the 256 partial sums of each column are added in a fixed order from LDS — deterministic.
+// (Round 5: the first version gave a workgroup 16 columns and a thread every 16th row — 4 workgroups walking 307 rows each at 4 913
+// particles, 65-80 us of load latency per call, four calls per end-to-end step.)  out2 (optional) receives a second copy (conv.bias and
+// dense.bias of a layer get the same gradient).
+__global__ void __launch_bounds__(256) k_colsum(const float* __restrict__ a, int rows, int cols, int lda, float* __restrict__ out, float* __restrict__ out2,
+                                                int vec)
 {
-    __shared__ float part[16][17];
-    const int c = blockIdx.x * 16 + (threadIdx.x & 15), r0 = threadIdx.x >> 4;
-    float s = 0.f;
-    if (c < cols)
-        for (int r = r0; r < rows; r += 16) s += a[(size_t)r * lda + c];
-    part[r0][threadIdx.x & 15] = s;
+    __shared__ float part[4][257];
+    const int c0 = blockIdx.x * 4, t = threadIdx.x;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (vec) {
+        for (int r = t; r < rows; r += 256) {
+            const float4 v = *(const float4*)(a + (size_t)r * lda + c0);
+            s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
+        }
+    } else {
+        const int nc = min(4, cols - c0);
+        for (int r = t; r < rows; r += 256) {
+            const float* p = a + (size_t)r * lda + c0;
+            s0 += p[0];
+            if (nc > 1) s1 += p[1];
+            if (nc > 2) s2 += p[2];
+            if (nc > 3) s3 += p[3];
+        }
+    }
+    part[0][t] = s0; part[1][t] = s1; part[2][t] = s2; part[3][t] = s3;
     __syncthreads();
-    if (r0 == 0 && c < cols) {
-        float t = 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) t += part[k][threadIdx.x & 15];
-        out[c] = t;
-        if (out2) out2[c] = t;
+    // column c of the four: 64 threads add 4 partials each (fixed order), then lane 0 of the group adds the 64
+    const int c = t >> 6, l = t & 63;
+    float q = part[c][4 * l] + part[c][4 * l + 1] + part[c][4 * l + 2] + part[c][4 * l + 3];
+    __syncthreads();
+    part[c][l] = q;
+    __syncthreads();
+    if (l == 0 && c0 + c < cols) {
+        float tot = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < 64; ++k) tot += part[c][k];
+        out[c0 + c] = tot;
+        if (out2) out2[c0 + c] = tot;
     }
 }
 
 extern "C" int nf_colsum(const float* a, int rows, int cols, int lda, float* out, float* out2, nf_stream_t stream)
 {
     NF_CHECK_ARG(a && out && rows >= 0 && cols > 0 && lda >= cols, "bad arguments");
-    hipLaunchKernelGGL(k_colsum, dim3((cols + 15) / 16), dim3(256), 0, (hipStream_t)stream, a, rows, cols, lda, out, out2);
+    const int vec = (cols % 4 == 0) && (lda % 4 == 0) && (((uintptr_t)a & 15) == 0);
+    hipLaunchKernelGGL(k_colsum, dim3((cols + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, rows, cols, lda, out, out2, vec);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }

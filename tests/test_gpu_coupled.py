@@ -62,3 +62,37 @@ def test_coupled_e2e_gradients_vs_oracle_autograd(dev):
         worst_r = max(worst_r, rel)
         assert rel < 2e-2, (name, rel)
     print("coupled e2e gradients: worst relative error  transition params", worst_t, " renderer params", worst_r)
+
+
+def test_backward_glue_kernels_vs_torch(dev):
+    """The three kernels that replaced ATen glue in the transition model's backward (csrc/nf_host.hip): nf_colsum (bias gradients: column sums of a
+    row-major matrix or of a column slice of a wider one, aligned and unaligned, with the second copy), nf_relu_bwd_add and nf_cconv_split_db,
+    each against the torch expression it stands for.  Column sums: a fixed summation order, so two runs are bit-equal; vs float64 within 2e-6 relative."""
+    from neurofluid_amd import _lib
+    from neurofluid_amd._lib import check, ptr
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5)
+    for rows, cols, lda, off in ((4913, 64, 64, 0), (4913, 96, 96, 0), (1, 64, 64, 0), (0, 32, 32, 0), (777, 3, 3, 0), (5000, 64, 195, 65), (300, 37, 40, 2)):
+        full = torch.randn(max(rows, 1), lda, generator=g).to(dev)
+        a = full[:, off:]
+        out, out2 = torch.full((cols,), 7.0, device=dev), torch.full((cols,), 7.0, device=dev)
+        check(lib.nf_colsum(a.data_ptr(), rows, cols, lda, ptr(out), ptr(out2), _lib.stream()), "nf_colsum")
+        ref = full[:rows, off:off + cols].double().sum(0)
+        scale = full[:rows, off:off + cols].double().abs().sum(0).clamp_min(1e-30)
+        assert float(((out.double() - ref).abs() / scale).max()) < 2e-6 if rows else bool((out == 0).all())
+        assert torch.equal(out, out2)
+        again = torch.empty(cols, device=dev)
+        check(lib.nf_colsum(a.data_ptr(), rows, cols, lda, ptr(again), None, _lib.stream()), "nf_colsum")
+        assert torch.equal(again, out)
+    dx, prev, res = (torch.randn(1000, 64, generator=g).to(dev) for _ in range(3))
+    o = torch.empty_like(dx)
+    check(lib.nf_relu_bwd_add(ptr(dx), ptr(prev), ptr(res), ptr(o), dx.numel(), _lib.stream()), "nf_relu_bwd_add")
+    assert torch.equal(o, torch.where(prev > 0, dx, torch.zeros_like(dx)) + res)
+    check(lib.nf_relu_bwd_add(ptr(dx), ptr(prev), None, ptr(o), dx.numel(), _lib.stream()), "nf_relu_bwd_add")
+    assert torch.equal(o, torch.where(prev > 0, dx, torch.zeros_like(dx)))
+    cin, cout = 96, 64
+    dB = torch.randn(cin, 65 * cout, generator=g).to(dev)
+    dK, dW = torch.empty(64, cin, cout, device=dev), torch.empty(cout, cin, device=dev)
+    check(lib.nf_cconv_split_db(ptr(dB), cin, cout, ptr(dK), ptr(dW), _lib.stream()), "nf_cconv_split_db")
+    assert torch.equal(dK, dB[:, :64 * cout].reshape(cin, 64, cout).permute(1, 0, 2))
+    assert torch.equal(dW, dB[:, 64 * cout:].t())

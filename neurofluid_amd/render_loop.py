@@ -91,13 +91,15 @@ def render_image(renderer, particle_pos, N_ray, ro, rays, focal_length=None, cw=
     for key in keys:
         if not gather and not key.startswith("rgb"):
             continue
-        dtype = parts[key][0].dtype if parts[key] else (torch.int32 if key.startswith("num_nn") else torch.float32)
+        # the slab's dtype must not depend on what THIS rank rendered (a rank that owns no chunk of a small image has nothing to look at,
+        # and every rank must bring the same bytes to the all-gather): neighbour counts travel as int32, everything else as fp32
+        dtype = torch.int32 if key.startswith("num_nn") else torch.float32
         # own chunks in ownership order; only the image's last chunk can be ragged and it is the last of its owner, so
         # the rendered rows are a prefix of this rank's (share * ray_chunk)-row slab
         local = torch.zeros(share * ray_chunk, widths[key], dtype=dtype, device=dev)
         if parts[key]:
             t = parts[key][0] if len(parts[key]) == 1 else torch.cat(parts[key], dim=0)
-            local[:t.shape[0]] = t
+            local[:t.shape[0]] = t                  # (copy_ converts an int64 count / another float type)
         full = nfdist.gather_chunks(local, n_chunks, ray_chunk, N_ray, rank, world)
         if key.startswith("num_nn") and full.dtype == torch.int32:
             ret.set_lazy(key, full, (full.numel(),))

@@ -54,9 +54,9 @@ def _worker(rank, world, port, n_rays, chunk, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_rays,chunk", [(1000, 128), (1024, 256), (130, 64)])
-def test_sharded_render_image_equals_unsharded(n_rays, chunk):
-    world = 2
+@pytest.mark.parametrize("n_rays,chunk,world", [(1000, 128, 2), (1024, 256, 2), (130, 64, 2), (1000, 128, 3), (130, 64, 4)])
+def test_sharded_render_image_equals_unsharded(n_rays, chunk, world):
+    """(world 3: an odd rank count, ragged last chunk; world 4 with 3 chunks: one rank owns NO chunk and still takes part in the gather)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -67,7 +67,7 @@ def test_sharded_render_image_equals_unsharded(n_rays, chunk):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert sorted(res) == [(0, True), (1, True)]
+    assert sorted(res) == [(r, True) for r in range(world)]
 
 
 def _dp_worker(rank, world, port, q):

@@ -577,15 +577,12 @@ def gen():
 
     ngaps = 2 * nreal
     gaps = [[] for _ in range(ngaps)]
-    tail = []                                            # pieces that fall into the padding steps (no MFMA to hide behind)
     heads = {k: 0 for k in streams}
     for G in range(ngaps):
         n, g = divmod(G, 2)
         used = 0
         if g == 1 and n + 1 < NSLOT:
             used = C_LDSR * len(reads_of(n + 1)) + 1
-        if g == 0 and n % CHUNK == 12 and not knob("NOBAR"):
-            pass
         while True:
             cand = []
             for k, lst in streams.items():

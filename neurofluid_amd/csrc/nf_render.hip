@@ -83,7 +83,11 @@ __global__ void __launch_bounds__(256) k_classify(const void* __restrict__ ws, c
             }
             const float zv = z ? (whole ? zq[e] : z[i]) : z_table[i % S];
             const float x = nf_madd_nofma(o0, d0, zv), y = nf_madd_nofma(o1, d1, zv), zz = nf_madd_nofma(o2, d2, zv);
+#ifdef CL_AB_NOREACH      /* dev probe (wrong candidates): what the 27-box reach test costs */
+            if (!use_mask || nf_near_points_aabb(g, x, y, zz, radius))
+#else
             if (!use_mask || (nf_near_points_aabb(g, x, y, zz, radius) && nf_any_cell_in_reach(g, x, y, zz, r2)))
+#endif
                 flags |= 1u << (u * 4 + e);
         }
         if (whole) {

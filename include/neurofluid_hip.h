@@ -442,6 +442,11 @@ int nf_host_wait_word(const volatile int32_t* word /*[host] page-locked*/, int32
 int nf_gather_view_pixels(int n_views, const float* const* rays, const float* const* rgb, const float* const* c2w, int per_view, int rgb_c,
                           int64_t n_pixels, const int64_t* flat, float* rays_out, float* rgb_out, float* ro_out, nf_stream_t stream);
 
+/* out_x = x * *scale for up to three contiguous float buffers (any of them empty; out_x == x allowed), *scale one float in device memory: the fused
+ * loss's backward scales its three gradients by the upstream gradient in one launch. */
+int nf_scale3(const float* a, int64_t na, const float* b, int64_t nb, const float* c, int64_t nc, const float* scale, float* out_a, float* out_b,
+              float* out_c, nf_stream_t stream);
+
 /* B8 glue (round 5): the elementwise / reduction steps between the launches of the transition model's backward.
  * nf_relu_bwd_add: out = (prev > 0 ? dx : 0) + (res or 0) — the ReLU in front of a layer back-propagated (+ the residual branch), n floats.
  * nf_colsum: out[c] (and out2[c] if given) = sum_r a[r * lda + c] — bias gradients; deterministic.

@@ -124,6 +124,7 @@ PROTOTYPES = {
     "nf_pinned_device_ptr": (c_void_p, [c_void_p]),
     "nf_host_wait_word": (c_int, [c_void_p, c_int, ctypes.c_double]),
     "nf_gather_view_pixels": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, ctypes.c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nf_scale3": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nf_relu_bwd_add": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "nf_colsum": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "nf_cconv_split_db": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -236,6 +236,32 @@ extern "C" int nf_e2e_loss(const float* rgb0, const float* rgb1, const float* rg
     return NF_OK;
 }
 
+// Up to three contiguous float buffers scaled by one scalar read from device memory (the upstream gradient autograd hands to the fused loss's
+// backward), out of place (out == in is allowed): one launch instead of one aten::mul per buffer.
+__global__ void __launch_bounds__(256) k_scale3(const float* __restrict__ a, long long na, const float* __restrict__ b, long long nb, const float* __restrict__ c,
+                                                long long nc, const float* __restrict__ scale, float* oa, float* ob, float* oc)
+{
+    const float s = *scale;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < na) { oa[i] = a[i] * s; return; }
+    i -= na;
+    if (i < nb) { ob[i] = b[i] * s; return; }
+    i -= nb;
+    if (i < nc) oc[i] = c[i] * s;
+}
+
+extern "C" int nf_scale3(const float* a, int64_t na, const float* b, int64_t nb, const float* c, int64_t nc, const float* scale, float* out_a, float* out_b,
+                         float* out_c, nf_stream_t stream)
+{
+    NF_CHECK_ARG(scale && na >= 0 && nb >= 0 && nc >= 0 && ((a && out_a) || !na) && ((b && out_b) || !nb) && ((c && out_c) || !nc), "bad arguments");
+    const long long n = (long long)na + nb + nc;
+    if (n == 0) return NF_OK;
+    hipLaunchKernelGGL(k_scale3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, (long long)na, b, (long long)nb, c, (long long)nc, scale,
+                       out_a, out_b, out_c);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Round 5: the glue between the HIP launches of the transition model's backward (autograd_bwd._trans_backward) as three small kernels
 // instead of ~25 ATen launches per step (threshold_backward, add, contiguous, sum(0), clone, reshape / permute copies).

@@ -316,6 +316,16 @@ class _E2ELossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         g0, g1, gp = ctx.g
+        if g.is_cuda and g.dtype is torch.float32 and g.numel() == 1:
+            # the three gradients times the upstream gradient in ONE launch (out of place: the saved unit-gradient buffers stay intact for a
+            # second backward under retain_graph)
+            from . import _lib
+            gs = g.contiguous()
+            o0, o1, op = torch.empty_like(g0), (None if g1 is None else torch.empty_like(g1)), (None if gp is None else torch.empty_like(gp))
+            n = lambda t: 0 if t is None else t.numel()          # noqa: E731
+            p = lambda t: 0 if t is None else t.data_ptr()       # noqa: E731
+            _lib.check(_lib.load().nf_scale3(p(g0), n(g0), p(g1), n(g1), p(gp), n(gp), gs.data_ptr(), p(o0), p(o1), p(op), _lib.stream()), "nf_scale3")
+            return o0, o1, None, op, None, None, None, None
         return g0 * g, (None if g1 is None else g1 * g), None, (None if gp is None else gp * g), None, None, None, None
 
 

@@ -64,7 +64,7 @@ def _median(xs):
     return xs[len(xs) // 2]
 
 
-def cpu_baseline(scene400, hip_frame=None, hip_step=None):
+def cpu_baseline(scene400, hip_frame=None, hip_step=None, alt_frames=None):
     """The oracle (CPU port of the reference path) on a bounded, representative sample, about 20-30 s of CPU work:
       n-thread: every 160th ray of the 400^2 image (1000 rays, same hit ratio as the full frame), 1 warm-up + 3 timed
                 repetitions (median); 2 warm + 3 x 2 transition steps on the 4 913 particles
@@ -72,7 +72,10 @@ def cpu_baseline(scene400, hip_frame=None, hip_step=None):
     Threads: torch intra-op AND the C neighbour oracle's OpenMP loops are set to the same count (the process's CPU
     budget, capped at 16: the oracle's ops are small and lose time beyond that).
     hip_frame / hip_step: the HIP path's 400^2 frame (coarse, fine RGB) and a 5-step rollout [(pos, vel), ...] from the SAME
-    inputs; the oracle's sample doubles as the checker (parity reported with the numbers) -> "parity"."""
+    inputs; the oracle's sample doubles as the checker (parity reported with the numbers) -> "parity".
+    alt_frames: {name: (coarse, fine)} — every 160th ray of the same frame rendered by the reduced-precision MLP paths (fp16, split);
+    compared with the SAME oracle sample -> parity["alt_paths"][name] (their accuracy stated against the reference's arithmetic,
+    /root/reference/models/nerf.py:83-124, not against the HIP fp32 path)."""
     from oracle import neighbors, render_oracle as ro, trans_oracle as to
     from neurofluid_amd import effective_cpus
     cores = max(1, min(effective_cpus(), 16))
@@ -133,6 +136,10 @@ def cpu_baseline(scene400, hip_frame=None, hip_step=None):
                                "rolled-out positions within 1e-4 mean L2",
                   "within_tolerance": bool(c0["psnr_db"] >= 60 and c1["psnr_db"] >= 60 and c0["max_abs"] <= 2e-4 and
                                            float((hp.double() - op.double()).norm(dim=1).mean()) <= 1e-4)}
+        if alt_frames:
+            parity["alt_paths"] = {name: {"rgb_coarse": cmp(a0, ref_n["rgb0"]), "rgb_fine": cmp(a1, ref_n["rgb1"]),
+                                          "stated_bar_db": 45.0 if name == "fp16" else 60.0}
+                                   for name, (a0, a1) in alt_frames.items()}
     torch.set_num_threads(1)
     neighbors.set_threads(1)
     rays_1 = sc["rays"][::640].contiguous()
@@ -147,6 +154,33 @@ def cpu_baseline(scene400, hip_frame=None, hip_step=None):
                       f"on every 640th ray ({rays_1.shape[0]} rays) and 2 steps; {os.cpu_count()} host cores visible, CPU budget "
                       f"{effective_cpus()}; {time.perf_counter() - t_all:.0f} s in total",
             "particle_steps_per_sec": p_n, "value_1_thread": r_1, "particle_steps_per_sec_1_thread": p_1}, parity
+
+
+def _device_activity(fn, n_steps):
+    """(launches per step, GPU-busy ms per step) of n_steps calls of fn under torch.profiler (device activity only).  Busy time is the
+    UNION of the kernels' intervals — two kernels side by side on two streams count once — so busy / wall is the fraction of the step in
+    which the GPU had work at all; what is left is launch gaps and host stalls.  (None, None) when the profiler is not usable."""
+    try:
+        from torch.profiler import profile as _tprof, ProfilerActivity as _PA
+        with _tprof(activities=[_PA.CUDA]) as prof:
+            for _ in range(n_steps):
+                fn()
+            torch.cuda.synchronize()
+        iv = sorted((e.time_range.start, e.time_range.end) for e in prof.events()
+                    if e.device_type == torch.autograd.DeviceType.CUDA and e.time_range.end > e.time_range.start)
+        if not iv:
+            return None, None
+        busy, (cs, ce) = 0.0, iv[0]
+        for a, b in iv[1:]:
+            if a > ce:
+                busy += ce - cs
+                cs, ce = a, b
+            else:
+                ce = max(ce, b)
+        busy += ce - cs
+        return len(iv) / n_steps, busy / n_steps / 1e3
+    except Exception:          # noqa: BLE001  (a diagnostic: the timed figures do not depend on it)
+        return None, None
 
 
 def _git_blob(path):
@@ -528,6 +562,7 @@ def main():
     #   fp16:  the fp16-MFMA MLP, fp32 accumulate (BASELINE config 5)
     #   split: hi + lo fp16 operands, three fp16 MFMAs per product — fp32-level accuracy on the fp16 matrix pipe
     split_extra = None
+    alt_strided = {}            # every 160th ray of the reduced-precision frames: checked against the oracle sample by cpu_baseline
     if args.workload == "render" and not args.no_extras:
         def alt_path(dtype):
             cfg = renderer_cfg(); cfg["mlp_dtype"] = dtype
@@ -565,11 +600,14 @@ def main():
                     "max_abs_rgb_diff_vs_f32_path_coarse_image": float((outa["pred_rgbs_0"] - out["pred_rgbs_0"]).abs().max()),
                     "max_abs_rgb_diff_vs_f32_path_fine_image": float(diff.abs().max()),
                     "pixels_fine_image_beyond_2e-4": int((diff.abs().max(dim=1).values > 2e-4).sum()),
-                    "mlp_tflops_row_equivalent": acha}
+                    "mlp_tflops_row_equivalent": acha,
+                    "_strided": (outa["pred_rgbs_0"][::160].float().cpu(), outa["pred_rgbs_1"][::160].float().cpu())}
         fp16_extra = alt_path("fp16")
+        alt_strided["fp16"] = fp16_extra.pop("_strided")
         fp16_extra.update({"dtype": "f16 MFMA, f32 accumulate", "mlp_frac_of_dense_f16_peak": fp16_extra["mlp_tflops_row_equivalent"] / F16_MATRIX_PEAK_TFLOPS,
                            "note": "render only (grid rebuild included, no transition step); not the headline value"})
         split_extra = alt_path("split")
+        alt_strided["split"] = split_extra.pop("_strided")
         split_extra.update({"dtype": "hi+lo f16 operands, 3 f16 MFMAs per product, f32 accumulate (fp32-level accuracy)",
                             "mlp_f16_mfma_tflops": 3 * split_extra["mlp_tflops_row_equivalent"],
                             "mlp_frac_of_dense_f16_peak": 3 * split_extra["mlp_tflops_row_equivalent"] / F16_MATRIX_PEAK_TFLOPS,
@@ -646,19 +684,12 @@ def main():
             erows = sum(int(r.item()) if torch.is_tensor(r) else int(r) for r in pe["rows"]) / (3 * n_frames)
             nv, rc = len(tr.train_view_names), int(cfg.RENDERER.ray.ray_chunk)
             # launches and GPU-busy time of a step: four steps under torch.profiler (device activity only)
-            n_launch = busy_ms = None
-            try:
-                from torch.profiler import profile as _tprof, ProfilerActivity as _PA
+            def _four():
                 tr.start_step = 0
-                with _tprof(activities=[_PA.CUDA]) as prof:
-                    tr.train(max_steps=4)
-                    torch.cuda.synchronize()
-                kev = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
-                n_launch = len(kev) / 4
-                busy_ms = sum(e.device_time_total if hasattr(e, "device_time_total") else e.cuda_time_total for e in kev) / 4 / 1e3
-            except Exception as ex:          # the profiler is a diagnostic: the step time above does not depend on it
-                n_launch = busy_ms = None
-                prof_err = repr(ex)
+                tr.train(max_steps=4)
+            n_launch, busy_ms = _device_activity(_four, 1)
+            if n_launch is not None:
+                n_launch, busy_ms = n_launch / 4, busy_ms / 4
             npart = int(P0.shape[0])
             flop = erows * 3 * MLP_FLOP_PER_ROW + npart * 3 * PARTICLE_STEP_FLOP
             e2e_extra = {"workload": "train_e2e.py step (E2ETrainer): transition forward + render of %d view(s) x %d rays of the predicted "
@@ -791,20 +822,27 @@ def main():
         for _ in range(8):
             tstep()
         sync()
+        # >= 3 blocks of 20 steps, MEDIAN block (round 5 timed one block: a single host hiccup moved the figure by 20 % between boxes)
         ops.PROFILE = {"mlp": [], "rows": []}
-        t3 = time.perf_counter()
-        for _ in range(20):
-            tstep()
-        sync()
-        dtt = (time.perf_counter() - t3) / 20
+        tblocks = []
+        for _ in range(5):
+            t3 = time.perf_counter()
+            for _ in range(20):
+                tstep()
+            sync()
+            tblocks.append((time.perf_counter() - t3) / 20)
+        dtt = sorted(tblocks)[len(tblocks) // 2]
         pt = ops.PROFILE
         ops.PROFILE = None
-        trows = sum(int(r.item()) if torch.is_tensor(r) else int(r) for r in pt["rows"]) / 20
+        trows = sum(int(r.item()) if torch.is_tensor(r) else int(r) for r in pt["rows"]) / (20 * len(tblocks))
+        t_launches, t_busy = _device_activity(tstep, 8)
         # executed FLOP of the step's matrix work: forward + data gradient + weight gradient of every active MLP row
         # (3 x 1 331 968 per row), against the fp32 matrix peak; Adam, composite, search, features are not counted
         ttf = trows * MLP_FLOP_PER_ROW * 3 / dtt / 1e12
         train_extra = {"workload": "train_renderer.py step: 4 views x 1024 rays per rank, forward + backward + Adam (+ grad all-reduce)",
                        "ms_per_step": dtt * 1e3, "rays_per_sec": 4096 * world / dtt,
+                       "blocks_ms": [round(b * 1e3, 3) for b in tblocks], "launches_per_step": t_launches,
+                       "gpu_busy_ms_per_step": t_busy, "gpu_busy_fraction": (t_busy / (dtt * 1e3)) if t_busy else None,
                        "executed_mlp_rows_per_step": trows, "flop_per_row_fwd_bwd_wgrad": 3 * MLP_FLOP_PER_ROW,
                        "roofline": {"bound": "mfma", "achieved": ttf, "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                                     "frac": ttf / F32_MATRIX_PEAK_TFLOPS,
@@ -853,9 +891,15 @@ def main():
                     pf = render_image(net, P0, n_rays, roc, rays, None, None, iseval=True, ray_chunk=args.chunk, rank=rank, world=world,
                                       gather=False, device_chunk=device_chunk)
                 hip_frame = (pf["pred_rgbs_0"].float().cpu(), pf["pred_rgbs_1"].float().cpu())
-            res["cpu_baseline"], parity = cpu_baseline(scene if image == 400 else build_scene(400), hip_frame, hip_step)
+            alt_frames = dict(alt_strided) if (hip_frame is not None and image == 400) else None
+            res["cpu_baseline"], parity = cpu_baseline(scene if image == 400 else build_scene(400), hip_frame, hip_step, alt_frames)
             if parity is not None:
                 res["parity"] = parity
+                for name, key in (("fp16", "fp16_mfma_path"), ("split", "split_precision_path")):
+                    if res.get(key) and parity.get("alt_paths", {}).get(name):
+                        ap = parity["alt_paths"][name]
+                        res[key]["psnr_vs_reference_oracle_db"] = {"coarse": ap["rgb_coarse"]["psnr_db"], "fine": ap["rgb_fine"]["psnr_db"],
+                                                                   "rays": int(parity["render_rays_compared"])}
             if args.workload == "render":
                 res["speedup_vs_cpu_port"] = value / res["cpu_baseline"]["value"]
         print(json.dumps(res))

@@ -6,7 +6,11 @@ rank of a multi-GPU run), while the renderer's two MLP launches are persistent g
 quantisation: DESIGN section 5e).  Enqueued a frame ahead on a side stream, the step's kernels run in those tails instead of in front of the
 next frame's first kernel, and the host's wait for the step's completion word (ParticleNet.step_async / AsyncStep.result) finds it long set.
 Same kernels, same operands, same order per step: the states are bit-identical to the sequential loop's
-(tests/test_gpu_trans.py::test_lookahead_rollout_bit_equal_to_sequential)."""
+(tests/test_gpu_trans.py::test_lookahead_rollout_bit_equal_to_sequential).
+
+Under the lookahead the transition module's per-call side results (`pn._y3`, `pn.conv0_fluid.nns`, ...) alias scratch that the NEXT step is
+already overwriting when next_state() returns: only the returned (pos, vel, num_neighbors) are valid; a caller that needs the neighbour
+lists of a frame uses the sequential `pn(...)` call."""
 import torch
 
 
@@ -15,11 +19,12 @@ class CoupledRollout:
         self.pn, self.box, self.box_feats = transition_model, box, box_feats
         self.side = torch.cuda.Stream(device=device if device is not None else box.device)
         self._pending = None
-        self._seen = set()
+        self._seen = {}
 
     def start(self, pos, vel):
         """(Re)start from a state: the step that produces the FIRST frame's particles is enqueued now."""
         self.drop()
+        self._seen.clear()
         self._then_seen((pos, vel))
         self._pending = self.pn.step_async(pos, vel, self.box, self.box_feats, stream=self.side)
 
@@ -42,8 +47,15 @@ class CoupledRollout:
         return pos, vel, nn
 
     def _then_seen(self, then):
-        """A restart state the rollout has been given before (same tensors) is complete on every stream by now; a NEW one is waited for once."""
-        key = (then[0].data_ptr(), then[0]._version, then[1].data_ptr(), then[1]._version)
-        seen = key in self._seen
-        self._seen.add(key)
-        return seen
+        """A restart state the rollout has been given before (the SAME tensor objects, unmodified) is complete on every stream by now; a
+        NEW one is waited for once.  The seen states are held by strong reference: an address-based key alone could be recycled by the
+        allocator for a fresh tensor (`P0.clone()` per cycle) that the caller's stream is still writing — it would then be taken for
+        complete and read by the side stream too early.  At most 8 states are remembered (an unseen state only costs one event wait)."""
+        key = (id(then[0]), then[0]._version, id(then[1]), then[1]._version)
+        hit = self._seen.get(key)
+        if hit is not None and hit[0] is then[0] and hit[1] is then[1]:
+            return True
+        if len(self._seen) >= 8:
+            self._seen.clear()
+        self._seen[key] = (then[0], then[1])
+        return False

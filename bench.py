@@ -834,7 +834,12 @@ def main():
         dtt = sorted(tblocks)[len(tblocks) // 2]
         pt = ops.PROFILE
         ops.PROFILE = None
-        trows = sum(int(r.item()) if torch.is_tensor(r) else int(r) for r in pt["rows"]) / (20 * len(tblocks))
+        gst = getattr(tstep, "graphed", None)
+        if gst is not None and gst.steps_total:       # replayed steps: the rows come from the steps' device-side records
+            gst.verify()
+            trows = gst.rows_total / gst.steps_total
+        else:
+            trows = sum(int(r.item()) if torch.is_tensor(r) else int(r) for r in pt["rows"]) / (20 * len(tblocks))
         t_launches, t_busy = _device_activity(tstep, 8)
         # executed FLOP of the step's matrix work: forward + data gradient + weight gradient of every active MLP row
         # (3 x 1 331 968 per row), against the fp32 matrix peak; Adam, composite, search, features are not counted
@@ -844,6 +849,8 @@ def main():
                        "blocks_ms": [round(b * 1e3, 3) for b in tblocks], "launches_per_step": t_launches,
                        "gpu_busy_ms_per_step": t_busy, "gpu_busy_fraction": (t_busy / (dtt * 1e3)) if t_busy else None,
                        "executed_mlp_rows_per_step": trows, "flop_per_row_fwd_bwd_wgrad": 3 * MLP_FLOP_PER_ROW,
+                       "replayed_as_hip_graph": bool(gst is not None and gst.steps_total),
+                       "graph_captures": (gst.captures if gst is not None else 0), "graph_redone_steps": (gst.redone_steps if gst is not None else 0),
                        "roofline": {"bound": "mfma", "achieved": ttf, "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                                     "frac": ttf / F32_MATRIX_PEAK_TFLOPS,
                                     "note": "whole-step wall time (host + all kernels) against the MLP FLOP only"}}

@@ -272,6 +272,11 @@ size_t nf_nerf_wgrad_floats(int cx, int cd);
 size_t nf_nerf_wgrad_workspace_floats(int cx, int cd, int nslices);
 int nf_nerf_wgrad(const float* dpre, const float* acts, const float* X, int cx, int cd, int n_rows, int nslices,
                   float* workspace, float* dweights, float* dbias, nf_stream_t stream);
+/* The same with the row count in device memory (*n_rows, clamped to max_rows; the grid is sized for nslices slices and the kernels
+ * derive nf_nerf_wgrad's slicing for the actual count: bit-identical sums).  For a training step replayed as a HIP graph, whose
+ * launch arguments are frozen (trainer/trainer_renderer.py:94-99 is the step). */
+int nf_nerf_wgrad_dev(const float* dpre, const float* acts, const float* X, int cx, int cd, const int32_t* n_rows, int max_rows,
+                      int nslices, float* workspace, float* dweights, float* dbias, nf_stream_t stream);
 
 /* A8: alpha compositing (models/renderer.py:182-208), one thread per ray, sequential products.
  * gate_by_mask != 0 (use_mask): rgbsigma is read only where mask != 0 and taken as zero elsewhere
@@ -431,6 +436,8 @@ int nf_trans_front(const void* fluid_grid, const void* box_grid, const float* qu
                                          of a batch of launches completes with the batch, not behind this kernel) */,
                    uint32_t* done_counter /* device word, zero between launches */, int step_id, nf_stream_t stream);
 void* nf_pinned_device_ptr(void* host_ptr /*[host] page-locked*/);
+/* Diagnostics: the calling thread's pending HIP error code (hipPeekAtLastError; 0 = none), left in place. */
+int nf_hip_peek_error(void);
 /* [host code] Spin until the pinned host word holds `expected` (0) or `timeout_s` seconds have passed (1): the wait for nf_trans_step's
  * completion word (host_flag3[2]) outside the interpreter — a ctypes call releases the GIL. */
 int nf_host_wait_word(const volatile int32_t* word /*[host] page-locked*/, int32_t expected, double timeout_s);
@@ -496,6 +503,17 @@ int nf_adam_step(int count, float* const* params /*[host]*/, const float* const*
                  float* const* exp_avg_sq /*[host]*/, const int64_t* sizes /*[host]*/, const float* step_size /*[host]*/,
                  const float* bc2_sqrt /*[host]*/, double beta1, double beta2 /* (1 - beta) is formed in double, as torch forms its scalars */,
                  float eps, float weight_decay, nf_stream_t stream);
+/* The same step for a training step replayed as a HIP graph: sched[0] = step_size, sched[1] = bc2_sqrt of THIS step in device memory
+ * (all tensors have taken the same number of steps); *skip != 0 (skip may be NULL) makes the launch a no-op. */
+int nf_adam_step_dev(int count, float* const* params /*[host]*/, const float* const* grads /*[host]*/, float* const* exp_avg /*[host]*/,
+                     float* const* exp_avg_sq /*[host]*/, const int64_t* sizes /*[host]*/, const float* sched /*[2], device*/,
+                     const int32_t* skip /*device or NULL*/, double beta1, double beta2, float eps, float weight_decay, nf_stream_t stream);
+/* Overflow bookkeeping of a replayed training step: state (5 device words) = {poisoned, first poisoned step, step counter, count0,
+ * count1}; the counter advances per call, the poison word is set — and stays set until the host clears it — when *count0 > cap0 or
+ * *count1 > cap1 (either pointer may be NULL).  nf_adam_step_dev's `skip` points at state[0].  host_ring (or NULL): the device
+ * address (nf_pinned_device_ptr) of 64 mapped host words = 8 records; step s writes record s & 7, word 2 (= s + 1) last. */
+int nf_note_overflow(const int32_t* count0, int cap0, const int32_t* count1, int cap1, int32_t* state, int32_t* host_ring,
+                     nf_stream_t stream);
 
 /* The loss of the end-to-end training step (trainer/trainer_e2e.py:264-280; trainer/basetrainer.py:108-116, :136 for the boundary
  * term) and its gradients for a unit upstream gradient, ONE launch:

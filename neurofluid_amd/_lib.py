@@ -83,6 +83,7 @@ PROTOTYPES = {
     "nf_nerf_wgrad_floats": (c_size_t, [c_int, c_int]),
     "nf_nerf_wgrad_workspace_floats": (c_size_t, [c_int, c_int, c_int]),
     "nf_nerf_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nf_nerf_wgrad_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nf_composite_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                  c_void_p, c_void_p, c_int, c_void_p]),
     "nf_nerf_packed_bwd_floats": (c_size_t, []),
@@ -122,6 +123,7 @@ PROTOTYPES = {
     "nf_trans_all_pairs_max_points": (c_int, []),
     "nf_trans_front": (c_int, [c_void_p] * 5 + [c_int, c_float, c_float, c_int, c_int, c_int] + [c_void_p] * 13 + [c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "nf_pinned_device_ptr": (c_void_p, [c_void_p]),
+    "nf_hip_peek_error": (c_int, []),
     "nf_host_wait_word": (c_int, [c_void_p, c_int, ctypes.c_double]),
     "nf_gather_view_pixels": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, ctypes.c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nf_scale3": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -148,6 +150,9 @@ PROTOTYPES = {
                                 c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "nf_adam_step": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_double, ctypes.c_double,
                              c_float, c_float, c_void_p]),
+    "nf_adam_step_dev": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_double, ctypes.c_double,
+                                 c_float, c_float, c_void_p]),
+    "nf_note_overflow": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "nf_e2e_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_float,
                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nf_trans_step": (c_int, [ctypes.POINTER(TransStep), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,

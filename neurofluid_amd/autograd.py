@@ -30,9 +30,22 @@ def _run_passes(net, particles, ro, rays, white_bg, fine, save_acts, _retry=Fals
     # the middle of each pass — left the GPU idle for ~100 us twice per call; a blocking torch.cat(...).tolist() at the end
     # of the call waits for the whole frame: 0.13 ms of idle GPU per frame, and 9.3 vs 8.3 ms per training step in round 1.)
     caps = ws.row_cap if ws is not None else net.train_row_cap
-    fetch = ops.HostFetch(dev)
-    fetch.add(grid.aabb_words())            # words 0..5: the cloud's bounds (the next grid's bbox hint), then one count per pass
-    after = lambda n_rows: fetch.add(n_rows)
+    # Under HIP-graph capture of a whole training step (train_step.GraphedRendererStep sets net._capture) nothing may wait for the
+    # device: the passes run against the learnt capacities, the counts stay on the device (the step's overflow bookkeeping reads them
+    # there, nf_note_overflow) and every row-sized launch of forward AND backward is sized by the capacity.
+    capture = getattr(net, "_capture", None)
+    if capture is not None:
+        if not save_acts or _retry:
+            raise RuntimeError("graph capture is for the training forward")
+        need = [(rays_c.shape[0], net.N_samples)] + ([(rays_c.shape[0], net.N_samples + net.N_importance)] if fine else [])
+        if any(k not in caps for k in need):
+            raise RuntimeError("graph capture of the training step needs learnt row capacities: run an eager step of this shape first")
+        fetch = None
+        after = lambda n_rows: capture["counts"].append(n_rows)
+    else:
+        fetch = ops.HostFetch(dev)
+        fetch.add(grid.aabb_words())            # words 0..5: the cloud's bounds (the next grid's bbox hint), then one count per pass
+        after = lambda n_rows: fetch.add(n_rows)
     opt = not _retry
     if save_acts:
         pk0, ws0, ph0 = net.packed_weights(net.nerf_coarse), None, None
@@ -75,6 +88,12 @@ def _run_passes(net, particles, ro, rays, white_bg, fine, save_acts, _retry=Fals
     # Inference passes ran against learnt row capacities without a host round trip: verify ONCE, here, with the whole
     # call enqueued (a real rollout reads the image back anyway).  On overflow the capacities grow and the call is redone
     # with exact sizing; capacities also grow ahead of need when a count comes within 10 % of them.
+    if capture is not None:
+        for p in (p0, p1):
+            if p is not None:
+                p.n_active, p.graph_mode = p.cap, True          # launches sized by the capacity, counts read on the device
+        capture["caps"] = [p.cap for p in (p0, p1) if p is not None]
+        return p0, p1, rays_c, ro_c, grid
     cap_runs = [(p, p.cap) for p in (p0, p1) if p is not None and p.cap is not None]
     got = fetch.get()                       # waits for the LAST search kernel only; the MLPs behind it stay queued
     net.note_point_bounds(ops.decode_aabb(got[:6]))          # the next frame's grid bbox: no reduction + sync

@@ -80,8 +80,12 @@ def _pass_backward(net, nerf, pb, rays_c, z, z_table, g_rgb, white_bg, particles
     blob = torch.empty(lib.nf_nerf_wgrad_floats(cx, cd), dtype=torch.float32, device=dev)
     wsp = torch.empty(lib.nf_nerf_wgrad_workspace_floats(cx, cd, nsl), dtype=torch.float32, device=dev)
     colsum = torch.empty(DPRE, dtype=torch.float32, device=dev)
-    check(lib.nf_nerf_wgrad(ptr(dpre_full), ptr(pb.acts), ptr(pb.X), cx, cd, n, nsl, ptr(wsp), ptr(blob), ptr(colsum), st),
-          "nf_nerf_wgrad")
+    if getattr(pb, "graph_mode", False):        # a captured step: n is the CAPACITY, the true count is read on the device (same slicing, same sums)
+        check(lib.nf_nerf_wgrad_dev(ptr(dpre_full), ptr(pb.acts), ptr(pb.X), cx, cd, ptr(pb.n_rows), n, nsl, ptr(wsp), ptr(blob), ptr(colsum), st),
+              "nf_nerf_wgrad_dev")
+    else:
+        check(lib.nf_nerf_wgrad(ptr(dpre_full), ptr(pb.acts), ptr(pb.X), cx, cd, n, nsl, ptr(wsp), ptr(blob), ptr(colsum), st),
+              "nf_nerf_wgrad")
     gw, o = [], 0
     for l in layers:
         k = l.weight.numel()
@@ -146,37 +150,42 @@ class _RenderFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
-        net = ctx.net
         g = dict(zip(ctx.keys, grads))
-        z_table, _ = net._tables(ctx.rays_c.device, ctx.use_disp)
-        z0 = getattr(ctx.p0, "z", None)                  # perturb > 0: the coarse pass ran on per-ray depths
-        zt0 = None if z0 is not None else z_table
         dpart = torch.zeros_like(ctx.pts) if ctx.particles_need_grad else None
-        extra = dict(particles=ctx.pts, ro_c=ctx.ro_c, dparticles=dpart)
-        both = g.get("rgb0") is not None and ctx.fine and g.get("rgb1") is not None and TWO_STREAM_BACKWARD
-        if both:
-            # The two passes' backward chains are independent (two networks; the importance samples are detached), and the
-            # MLP kernels quantise badly on their own: one wave per 32-row tile for 0.35 ms, 1 024 waves per round, so the
-            # coarse pass (~600 tiles) leaves 40 % of the chip idle for a whole round and the fine pass (~2 100 tiles) pays
-            # a third round for 2.04 rounds of work.  On two streams the dispatcher fills the CUs from both launches.
-            cur = torch.cuda.current_stream(ctx.rays_c.device)
-            side = _side_stream(ctx.rays_c.device)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                gc = _pass_backward(net, net.nerf_coarse, ctx.p0, ctx.rays_c, z0, zt0, g["rgb0"], ctx.white_bg, **extra)
-                for t in gc:
-                    if t is not None:
-                        t.record_stream(cur)        # allocated on the side stream, consumed on the current one
-            gf = _pass_backward(net, net.nerf_fine, ctx.p1, ctx.rays_c, ctx.p1.z, None, g["rgb1"], ctx.white_bg, **extra)
-            cur.wait_stream(side)
-            return (None, dpart, None, None, None, None) + tuple(gc) + tuple(gf)
-        gc = _pass_backward(net, net.nerf_coarse, ctx.p0, ctx.rays_c, z0, zt0, g["rgb0"], ctx.white_bg, **extra) \
-            if g.get("rgb0") is not None else [None] * 24
-        if ctx.fine and g.get("rgb1") is not None:
-            gf = _pass_backward(net, net.nerf_fine, ctx.p1, ctx.rays_c, ctx.p1.z, None, g["rgb1"], ctx.white_bg, **extra)
-        else:
-            gf = [None] * 24
+        gc, gf = render_backward(ctx.net, ctx.p0, ctx.p1 if ctx.fine else None, ctx.rays_c, g.get("rgb0"), g.get("rgb1") if ctx.fine else None,
+                                 ctx.white_bg, ctx.use_disp, particles=ctx.pts, ro_c=ctx.ro_c, dparticles=dpart)
         return (None, dpart, None, None, None, None) + tuple(gc) + tuple(gf)
+
+
+def render_backward(net, p0, p1, rays_c, g_rgb0, g_rgb1, white_bg, use_disp=False, particles=None, ro_c=None, dparticles=None):
+    """The renderer's backward from the pass buffers of a training forward (_run_passes(save_acts=True)): the 24 parameter gradients of
+    each NeRF (None where a pass received no gradient), dL/d particles accumulated into `dparticles` when given.  Used by the autograd
+    Function above and, directly, by the captured training step (train_step.GraphedRendererStep: no autograd engine inside the graph)."""
+    z_table, _ = net._tables(rays_c.device, use_disp)
+    z0 = getattr(p0, "z", None)                  # perturb > 0: the coarse pass ran on per-ray depths
+    zt0 = None if z0 is not None else z_table
+    extra = dict(particles=particles, ro_c=ro_c, dparticles=dparticles)
+    fine = p1 is not None
+    both = g_rgb0 is not None and fine and g_rgb1 is not None and TWO_STREAM_BACKWARD
+    if both:
+        # The two passes' backward chains are independent (two networks; the importance samples are detached), and the
+        # MLP kernels quantise badly on their own: one wave per 32-row tile for 0.35 ms, 1 024 waves per round, so the
+        # coarse pass (~600 tiles) leaves 40 % of the chip idle for a whole round and the fine pass (~2 100 tiles) pays
+        # a third round for 2.04 rounds of work.  On two streams the dispatcher fills the CUs from both launches.
+        cur = torch.cuda.current_stream(rays_c.device)
+        side = _side_stream(rays_c.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            gc = _pass_backward(net, net.nerf_coarse, p0, rays_c, z0, zt0, g_rgb0, white_bg, **extra)
+            for t in gc:
+                if t is not None:
+                    t.record_stream(cur)        # allocated on the side stream, consumed on the current one
+        gf = _pass_backward(net, net.nerf_fine, p1, rays_c, p1.z, None, g_rgb1, white_bg, **extra)
+        cur.wait_stream(side)
+        return gc, gf
+    gc = _pass_backward(net, net.nerf_coarse, p0, rays_c, z0, zt0, g_rgb0, white_bg, **extra) if g_rgb0 is not None else [None] * 24
+    gf = _pass_backward(net, net.nerf_fine, p1, rays_c, p1.z, None, g_rgb1, white_bg, **extra) if (fine and g_rgb1 is not None) else [None] * 24
+    return gc, gf
 
 
 def render_with_grad(net, particles, ro, rays, white_bg, fine, use_disp=False, noise_std=0.0, perturb=0.0):

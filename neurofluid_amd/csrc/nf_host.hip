@@ -87,6 +87,9 @@ extern "C" void* nf_pinned_device_ptr(void* host_ptr)
     return d;
 }
 
+// Diagnostics: the calling thread's pending HIP error code (hipPeekAtLastError; 0 = none), not cleared.
+extern "C" int nf_hip_peek_error(void) { return (int)hipPeekAtLastError(); }
+
 // Host code: wait until a pinned host word (written by a kernel through its device address, nf_pinned_device_ptr) holds `expected`.
 // The caller of nf_trans_step waits for the front kernel's completion word while the convolutions behind it are still running; round 5
 // moved the spin out of the Python interpreter (a Python loop polled the word with the interpreter lock held on every rollout frame):
@@ -128,6 +131,8 @@ struct NfAdamArgs {
     float step_size[NA_MAX], bc2_sqrt[NA_MAX];
     int count;
     float beta2, w1, w2, eps, weight_decay;      // w1 = 1 - beta1, w2 = 1 - beta2, rounded from the DOUBLE differences (as torch's scalars are)
+    const float* sched;     // nf_adam_step_dev: {step_size, bc2_sqrt} of THIS step in device memory (a replayed graph's arguments are frozen)
+    const int* skip;        // nf_adam_step_dev: a non-zero word makes the step a no-op (a training step whose forward was truncated)
 };
 
 __global__ void __launch_bounds__(256) k_adam(NfAdamArgs A)
@@ -140,7 +145,8 @@ __global__ void __launch_bounds__(256) k_adam(NfAdamArgs A)
     const float* __restrict__ g = A.g[t];
     float* __restrict__ m = A.m[t];
     float* __restrict__ v = A.v[t];
-    const float ss = A.step_size[t], bc = A.bc2_sqrt[t], w1 = A.w1, w2 = A.w2;
+    if (A.skip && *A.skip) return;
+    const float ss = A.sched ? A.sched[0] : A.step_size[t], bc = A.sched ? A.sched[1] : A.bc2_sqrt[t], w1 = A.w1, w2 = A.w2;
 #pragma unroll 4
     for (int k = 0; k < NA_CHUNK / 256; ++k) {
         const int i = base + k * 256 + threadIdx.x;
@@ -157,11 +163,10 @@ __global__ void __launch_bounds__(256) k_adam(NfAdamArgs A)
     }
 }
 
-extern "C" int nf_adam_step(int count, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
-                            const int64_t* sizes, const float* step_size, const float* bc2_sqrt, double beta1, double beta2, float eps,
-                            float weight_decay, nf_stream_t stream)
+static int adam_launch(int count, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                       const int64_t* sizes, const float* step_size, const float* bc2_sqrt, const float* sched, const int* skip,
+                       double beta1, double beta2, float eps, float weight_decay, nf_stream_t stream)
 {
-    NF_CHECK_ARG(count >= 0 && (count == 0 || (params && grads && exp_avg && exp_avg_sq && sizes && step_size && bc2_sqrt)), "null pointer");
     for (int t0 = 0; t0 < count; t0 += NA_MAX) {
         NfAdamArgs A;
         const int c = count - t0 < NA_MAX ? count - t0 : NA_MAX;
@@ -170,13 +175,65 @@ extern "C" int nf_adam_step(int count, float* const* params, const float* const*
             NF_CHECK_ARG(sizes[t0 + t] >= 0 && sizes[t0 + t] < (1ll << 31), "tensor too large");
             A.p[t] = params[t0 + t]; A.g[t] = grads[t0 + t]; A.m[t] = exp_avg[t0 + t]; A.v[t] = exp_avg_sq[t0 + t];
             A.n[t] = (int)sizes[t0 + t]; A.chunk0[t] = chunks;
-            A.step_size[t] = step_size[t0 + t]; A.bc2_sqrt[t] = bc2_sqrt[t0 + t];
+            A.step_size[t] = step_size ? step_size[t0 + t] : 0.f; A.bc2_sqrt[t] = bc2_sqrt ? bc2_sqrt[t0 + t] : 1.f;
             chunks += (A.n[t] + NA_CHUNK - 1) / NA_CHUNK;
         }
         A.chunk0[c] = chunks;
         A.count = c; A.beta2 = (float)beta2; A.w1 = (float)(1.0 - beta1); A.w2 = (float)(1.0 - beta2); A.eps = eps; A.weight_decay = weight_decay;
+        A.sched = sched; A.skip = skip;
         if (chunks > 0) hipLaunchKernelGGL(k_adam, dim3(chunks), dim3(256), 0, (hipStream_t)stream, A);
     }
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+extern "C" int nf_adam_step(int count, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                            const int64_t* sizes, const float* step_size, const float* bc2_sqrt, double beta1, double beta2, float eps,
+                            float weight_decay, nf_stream_t stream)
+{
+    NF_CHECK_ARG(count >= 0 && (count == 0 || (params && grads && exp_avg && exp_avg_sq && sizes && step_size && bc2_sqrt)), "null pointer");
+    return adam_launch(count, params, grads, exp_avg, exp_avg_sq, sizes, step_size, bc2_sqrt, nullptr, nullptr, beta1, beta2, eps, weight_decay, stream);
+}
+
+// The same step for a REPLAYED training step (HIP graph): the two per-step scalars come from device memory (sched[0] = step_size,
+// sched[1] = bc2_sqrt, shared by all tensors: they have taken the same number of steps), and a non-zero *skip (or NULL) turns the
+// launch into a no-op — the step's forward overflowed its row capacities, the host redoes it (nf_note_overflow).
+extern "C" int nf_adam_step_dev(int count, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                                const int64_t* sizes, const float* sched, const int32_t* skip, double beta1, double beta2, float eps,
+                                float weight_decay, nf_stream_t stream)
+{
+    NF_CHECK_ARG(count >= 0 && (count == 0 || (params && grads && exp_avg && exp_avg_sq && sizes && sched)), "null pointer");
+    return adam_launch(count, params, grads, exp_avg, exp_avg_sq, sizes, nullptr, nullptr, sched, (const int*)skip, beta1, beta2, eps, weight_decay, stream);
+}
+
+// One thread: state = {poisoned, first poisoned step, step counter, count[0], count[1]}.  The counter advances by one per call;
+// if a count (device words, e.g. the active rows of a render pass) exceeds its capacity the poison word is set and STAYS set
+// (every optimiser step that follows is skipped through nf_adam_step_dev's `skip` until the host clears the word), and the first
+// such step's counter value is kept.  host_ring (optional): 8 records of 8 words in host memory mapped into the device address
+// space; the record of step s goes to slot s & 7, its word 2 (= s + 1) is written last behind a system-scope fence, so a host that
+// finds word 2 == s + 1 reads a complete record of step s.
+__global__ void k_note_overflow(const int* __restrict__ c0, int cap0, const int* __restrict__ c1, int cap1, int* __restrict__ state,
+                                volatile int* host_ring)
+{
+    const int n0 = c0 ? *c0 : 0, n1 = c1 ? *c1 : 0;
+    const int step = state[2];
+    if ((n0 > cap0 || n1 > cap1) && !state[0]) { state[0] = 1; state[1] = step; }
+    state[2] = step + 1;
+    state[3] = n0; state[4] = n1;
+    if (host_ring) {
+        volatile int* h = host_ring + (step & 7) * 8;
+        h[0] = state[0]; h[1] = state[1]; h[3] = n0; h[4] = n1;
+        __threadfence_system();
+        h[2] = step + 1;
+    }
+}
+
+extern "C" int nf_note_overflow(const int32_t* count0, int cap0, const int32_t* count1, int cap1, int32_t* state, int32_t* host_ring,
+                                nf_stream_t stream)
+{
+    NF_CHECK_ARG(state, "null pointer");
+    hipLaunchKernelGGL(k_note_overflow, dim3(1), dim3(1), 0, (hipStream_t)stream, (const int*)count0, cap0, (const int*)count1, cap1, (int*)state,
+                       (volatile int*)host_ring);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }

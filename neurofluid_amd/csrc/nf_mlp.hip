@@ -748,11 +748,18 @@ extern "C" size_t nf_nerf_wgrad_floats(int cx, int cd) { return (size_t)wgrad_pl
 #define WG2_D 5
 __global__ void __launch_bounds__(256) k_wgrad2(NfWgradPlan P, const float* __restrict__ dpre, const float* __restrict__ acts,
                                                 const float* __restrict__ xtiles, int Q, int n_rows, int rows_per_slice,
-                                                int nslices, float* __restrict__ partial)
+                                                int nslices, float* __restrict__ partial, const int* __restrict__ n_rows_dev)
 {
     __shared__ float4 wg2_ring[4][WG2_D + 1][2][64];          // per wave: WG2_D + 1 slots x (A quad, B quad) x 64 lanes = 12 KB
     const int lane = threadIdx.x & 63;
     const int v = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (n_rows_dev) {       // nf_nerf_wgrad_dev: the row count lives on the device (graph replay); the slicing nf_nerf_wgrad does on the host
+        n_rows = min(__builtin_amdgcn_readfirstlane(*n_rows_dev), n_rows);         // (n_rows = the caller's capacity)
+        if (n_rows <= 0) return;
+        const int want = nslices;
+        rows_per_slice = ((n_rows + want - 1) / want + 31) / 32 * 32;
+        nslices = (n_rows + rows_per_slice - 1) / rows_per_slice;
+    }
     if (v >= P.ntiles * nslices) return;
     const int by = v / P.ntiles, bx = v - by * P.ntiles;
     int gi = 0;
@@ -916,11 +923,19 @@ __global__ void __launch_bounds__(256) k_wgrad2(NfWgradPlan P, const float* __re
 // partial[slice][total + NF_DPRE_STRIDE] -> dweights[total] | dbias[NF_DPRE_STRIDE]; one float4 per thread, the slices in
 // groups of 4 independent loads (total and NF_DPRE_STRIDE are multiples of 4 floats)
 __global__ void k_wgrad_reduce(const float* __restrict__ partial, int total, int nslices, float* __restrict__ out,
-                               float* __restrict__ dbias)
+                               float* __restrict__ dbias, const int* __restrict__ n_rows_dev, int max_rows)
 {
     const int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
     const int stride = total + NF_DPRE_STRIDE;
     if (i >= stride) return;
+    if (n_rows_dev) {       // the slices k_wgrad2 wrote for this row count (0 rows: zeros)
+        const int n = min(*n_rows_dev, max_rows);
+        if (n <= 0) nslices = 0;
+        else {
+            const int rp = ((n + nslices - 1) / nslices + 31) / 32 * 32;
+            nslices = (n + rp - 1) / rp;
+        }
+    }
     const float* p = partial + i;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     int z = 0;
@@ -961,9 +976,27 @@ extern "C" int nf_nerf_wgrad(const float* dpre, const float* acts, const float* 
     rows_per = (rows_per + 31) / 32 * 32;          // slices start on a 32-row boundary (the X tiles' granule)
     int ns = (n_rows + rows_per - 1) / rows_per;
     hipLaunchKernelGGL(k_wgrad2, dim3((P.ntiles * ns + 3) / 4), dim3(256), 0, st, P, dpre, acts, X, (cx + 7) / 8 + (cd + 7) / 8, n_rows,
-                       rows_per, ns, workspace);
+                       rows_per, ns, workspace, (const int*)nullptr);
     hipLaunchKernelGGL(k_wgrad_reduce, dim3(((P.total + NF_DPRE_STRIDE) / 4 + 255) / 256), dim3(256), 0, st,
-                       (const float*)workspace, P.total, ns, dweights, dbias);
+                       (const float*)workspace, P.total, ns, dweights, dbias, (const int*)nullptr, 0);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+// The same launch pair with the row count in DEVICE memory (*n_rows, clamped to max_rows): what a replayed training step needs (a HIP
+// graph's launch arguments are frozen; the active rows change from step to step).  The grid is sized for nslices slices; the
+// kernels derive the slicing of nf_nerf_wgrad(..., n_rows = *n_rows, nslices, ...) themselves, so the sums are the same bit for bit.
+extern "C" int nf_nerf_wgrad_dev(const float* dpre, const float* acts, const float* X, int cx, int cd, const int32_t* n_rows, int max_rows,
+                                 int nslices, float* workspace, float* dweights, float* dbias, nf_stream_t stream)
+{
+    NF_CHECK_ARG(dpre && acts && X && workspace && dweights && n_rows, "null pointer");
+    NF_CHECK_ARG(nslices >= 1 && nslices <= 65535 && max_rows >= 1, "bad slice count / capacity");
+    NfWgradPlan P = wgrad_plan(cx, cd);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_wgrad2, dim3((P.ntiles * nslices + 3) / 4), dim3(256), 0, st, P, dpre, acts, X, (cx + 7) / 8 + (cd + 7) / 8, max_rows,
+                       0, nslices, workspace, (const int*)n_rows);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(((P.total + NF_DPRE_STRIDE) / 4 + 255) / 256), dim3(256), 0, st,
+                       (const float*)workspace, P.total, nslices, dweights, dbias, (const int*)n_rows, max_rows);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }

@@ -4,6 +4,7 @@ for each of the 4 warm-up views sample `ray_chunk` random pixels of frame 0 (cen
 of MSE(rgb0) + MSE(rgb1); zero_grad / backward / Adam / ExponentialLR (utils/lr_schedulers.py:3-12).
 Used by bench.py --workload train and by the Trainer in neurofluid_amd/trainers.py."""
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -79,6 +80,81 @@ class HipAdam(torch.optim.Adam):
                 st["step"] = st["step"].detach().clone()
         return sd
 
+    def _table(self, gi, ps):
+        """The pointer / size table of param group gi over the parameters ps (those with a gradient), (re)built when the list or the
+        state tensors changed."""
+        import ctypes
+        n = len(ps)
+        key = tuple(id(p) for p in ps)
+        tab = self._tables.get(gi)
+        if tab is None or tab["key"] != key or (tab["step"] is not None and self.state[ps[0]].get("step") is not tab["step"]):
+            # (re)build the table: state tensors are created here as a default torch.optim.Adam creates them; the parameters of
+            # a group that have taken the same number of steps SHARE one `step` tensor (one host increment per step instead
+            # of one per tensor; state_dict() writes its value under every parameter, as torch does)
+            PA, FA, LA = ctypes.c_void_p * n, ctypes.c_float * n, ctypes.c_int64 * n
+            tab = self._tables[gi] = {"key": key, "p": PA(), "g": PA(), "m": PA(), "v": PA(), "sz": LA(), "ss": FA(), "bc": FA(),
+                                      "step": None, "refs": []}
+            steps = []
+            for k, p in enumerate(ps):
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                if st["step"].is_cuda:                   # a state loaded from a fused optimizer's checkpoint
+                    st["step"] = st["step"].detach().to("cpu", torch.float32)
+                steps.append(float(st["step"]))
+                tab["p"][k], tab["m"][k], tab["v"][k] = p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+                tab["sz"][k] = p.numel()
+                tab["refs"].append((st["exp_avg"], st["exp_avg_sq"]))
+            if len(set(steps)) == 1:
+                shared = torch.tensor(steps[0], dtype=torch.float32)
+                for p in ps:
+                    self.state[p]["step"] = shared
+                tab["step"] = shared
+        return tab
+
+    # ---- the step inside a replayed HIP graph (GraphedRendererStep): the per-step scalars travel through device memory
+    def graph_scalars(self):
+        """(step_size, bc2_sqrt) of the NEXT step; advances the shared step counter as step() does.  None when this optimizer cannot run
+        from a graph (several groups, per-tensor step counts, non-default switches)."""
+        if len(self.param_groups) != 1 or not self._eligible():
+            return None
+        group = self.param_groups[0]
+        ps = [p for p in group["params"] if p.grad is not None]
+        if not ps or len(ps) != len(group["params"]):
+            return None
+        tab = self._table(0, ps)
+        if tab["step"] is None:
+            return None
+        beta1, beta2 = group["betas"]
+        tab["step"] += 1
+        t = float(tab["step"])
+        return float(group["lr"]) / (1.0 - beta1 ** t), (1.0 - beta2 ** t) ** 0.5
+
+    def graph_rewind(self, steps):
+        """Take back `steps` counter advances (replayed steps that were skipped on the device and are redone)."""
+        tab = self._tables.get(0)
+        if tab is not None and tab["step"] is not None:
+            tab["step"] -= steps
+
+    @torch.no_grad()
+    def graph_enqueue(self, sched_dev, skip_dev):
+        """The step's launch with its scalars in device memory (nf_adam_step_dev); called under capture, after backward."""
+        from . import _lib
+        group = self.param_groups[0]
+        ps = list(group["params"])
+        tab = self._table(0, ps)
+        beta1, beta2 = group["betas"]
+        for k, p in enumerate(ps):
+            g = p.grad
+            if g is None or not g.is_contiguous() or g.dtype is not torch.float32:
+                raise RuntimeError("HipAdam.graph_enqueue: every parameter needs a contiguous fp32 gradient")
+            tab["p"][k], tab["g"][k] = p.data_ptr(), g.data_ptr()
+        _lib.check(_lib.load().nf_adam_step_dev(len(ps), tab["p"], tab["g"], tab["m"], tab["v"], tab["sz"], sched_dev.data_ptr(),
+                                                None if skip_dev is None else skip_dev.data_ptr(), float(beta1), float(beta2),
+                                                float(group["eps"]), float(group["weight_decay"]), _lib.stream()), "nf_adam_step_dev")
+
     @torch.no_grad()
     def step(self, closure=None):
         import ctypes
@@ -97,33 +173,7 @@ class HipAdam(torch.optim.Adam):
             beta1, beta2 = group["betas"]
             lr, eps, wd = float(group["lr"]), float(group["eps"]), float(group["weight_decay"])
             n = len(ps)
-            key = tuple(id(p) for p in ps)
-            tab = self._tables.get(gi)
-            if tab is None or tab["key"] != key or (tab["step"] is not None and self.state[ps[0]].get("step") is not tab["step"]):
-                # (re)build the table: state tensors are created here as a default torch.optim.Adam creates them; the parameters of
-                # a group that have taken the same number of steps SHARE one `step` tensor (one host increment per step instead
-                # of one per tensor; state_dict() writes its value under every parameter, as torch does)
-                PA, FA, LA = ctypes.c_void_p * n, ctypes.c_float * n, ctypes.c_int64 * n
-                tab = self._tables[gi] = {"key": key, "p": PA(), "g": PA(), "m": PA(), "v": PA(), "sz": LA(), "ss": FA(), "bc": FA(),
-                                          "step": None, "refs": []}
-                steps = []
-                for k, p in enumerate(ps):
-                    st = self.state[p]
-                    if len(st) == 0:
-                        st["step"] = torch.tensor(0.0, dtype=torch.float32)
-                        st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                        st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    if st["step"].is_cuda:                   # a state loaded from a fused optimizer's checkpoint
-                        st["step"] = st["step"].detach().to("cpu", torch.float32)
-                    steps.append(float(st["step"]))
-                    tab["p"][k], tab["m"][k], tab["v"][k] = p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
-                    tab["sz"][k] = p.numel()
-                    tab["refs"].append((st["exp_avg"], st["exp_avg_sq"]))
-                if len(set(steps)) == 1:
-                    shared = torch.tensor(steps[0], dtype=torch.float32)
-                    for p in ps:
-                        self.state[p]["step"] = shared
-                    tab["step"] = shared
+            tab = self._table(gi, ps)
             if tab["step"] is not None:
                 tab["step"] += 1
                 t = float(tab["step"])
@@ -515,6 +565,228 @@ def renderer_train_step(renderer, optimizer, scheduler, particles, views, H, W, 
     return total.detach()
 
 
+class GraphedRendererStep:
+    """The whole warm-up optimiser step (trainer/trainer_renderer.py:94-143: pixel gather -> coarse + fine forward -> loss -> backward ->
+    Adam) captured ONCE as a HIP graph and replayed: per step the host uploads the pixel selection and the optimiser's two scalars
+    (one pinned staging slot, stream-ordered copies) and launches one graph.  The eager step is a chain of ~40 launches with one host
+    round trip in the middle (the passes' row counts, autograd._run_passes); it is GPU-bound on a quiet host, but every host stall lands
+    on the GPU's critical path (round 5: 3.39 ms on one box, 4.17 ms on another).  Replayed, the host needs ~0.1 ms per 3 ms step and
+    runs one step ahead of the GPU.
+
+    What makes the step capturable:
+      * row-sized launches of forward and backward run against the learnt row CAPACITIES of the two passes; the true counts stay on the
+        device (kernels clamp to them; nf_nerf_wgrad_dev derives the eager call's row slicing from the device count: same sums);
+      * Adam reads its step size / bias correction from device memory (nf_adam_step_dev);
+      * a pass that meets more active rows than its capacity sets a sticky poison word on the device (nf_note_overflow) that turns this
+        and every following optimiser launch into a no-op.  The host reads each step's record one step late (from mapped pinned memory,
+        behind that step's event), raises the capacities, recaptures and REDOES the skipped steps from their kept selections: the
+        parameter trajectory is the eager loop's.  (The loss tensor returned for a poisoned step first holds the truncated forward's
+        value; the redo writes the true value into the SAME tensor.  verify() settles everything enqueued — the trainer calls it
+        before it reads a loss on the host.)
+    The same kernels with the same operands as the eager step: losses and parameters agree bit for bit
+    (tests/test_gpu_render.py::test_graph_replayed_renderer_step_equals_eager).  Single process (world = 1) only: a data-parallel
+    run keeps the eager step with its gradient all-reduce."""
+
+    def __init__(self, renderer, optimizer, particles, views, H, W, ray_chunk):
+        from . import _lib
+        self.net, self.opt, self.P, self.views, self.H, self.W, self.rc = renderer, optimizer, particles, views, H, W, int(ray_chunk)
+        self.dev = particles.device
+        self.V = len(views)
+        self.graph = None
+        self.captures = 0           # diagnostics
+        self.redone_steps = 0
+        n = self.V * self.rc
+        R = n
+        self._cap_keys = [(R, renderer.N_samples)] + ([(R, renderer.N_samples + renderer.N_importance)] if renderer.N_importance > 0 else [])
+        self.flat_dev = torch.zeros(n, dtype=torch.int64, device=self.dev)
+        self.sched_dev = torch.zeros(2, dtype=torch.float32, device=self.dev)
+        self.state_dev = torch.zeros(8, dtype=torch.int32, device=self.dev)       # nf_note_overflow's words
+        self.ring_host = torch.zeros(64, dtype=torch.int32).pin_memory()          # 8 records, written by the device (mapped memory)
+        self._ring_np = self.ring_host.numpy()
+        self._ring_dev = _lib.load().nf_pinned_device_ptr(self.ring_host.data_ptr())
+        if not self._ring_dev:
+            raise RuntimeError("pinned host memory is not mapped into the device address space (nf_pinned_device_ptr)")
+        self._stage = [[torch.empty(n, dtype=torch.int64).pin_memory(), torch.empty(2, dtype=torch.float32).pin_memory(), None] for _ in range(4)]
+        self._si = 0
+        self._launched = []         # [(device step index, flat_host, (ss, bc), event)] not yet checked, oldest first
+        self._steps = 0             # replays since the last capture = the device counter
+        self._rl = [v["rays"].reshape(H * W, -1).contiguous() for v in views]
+        self._gl = [v["rgb"].reshape(H * W, -1).contiguous() for v in views]
+        self._cl = [v["cw"].contiguous() for v in views]
+        self._keep = None
+        self._recapture = False
+        self.rows_total = self.steps_total = 0      # active MLP rows / settled steps (bench.py's roofline)
+
+    @staticmethod
+    def eligible(renderer, optimizer, particles, world):
+        return bool(world == 1 and particles.is_cuda and isinstance(optimizer, HipAdam) and len(optimizer.param_groups) == 1 and
+                    not particles.requires_grad and getattr(renderer, "mlp_dtype", "fp32") == "fp32" and
+                    all(p.requires_grad for p in renderer.parameters()))
+
+    def ready(self):
+        """True once an eager step of this shape has learnt the passes' row capacities (the capture needs them)."""
+        return all(k in self.net.train_row_cap for k in self._cap_keys) and all(p.grad is not None for p in self.net.parameters())
+
+    # ------------------------------------------------------------------
+    def _body(self):
+        """One step's launches (runs under capture)."""
+        from . import _lib
+        lib = _lib.load()
+        V, rc, H, W = self.V, self.rc, self.H, self.W
+        C = self._gl[0].shape[1]
+        rays = torch.empty(V * rc, 6, device=self.dev)
+        rgbs = torch.empty(V * rc, C, device=self.dev)
+        ro = torch.empty(V * rc, 3, device=self.dev)
+        arr = ctypes.c_void_p * V
+        _lib.check(lib.nf_gather_view_pixels(V, arr(*[t.data_ptr() for t in self._rl]), arr(*[t.data_ptr() for t in self._gl]),
+                                             arr(*[t.data_ptr() for t in self._cl]), rc, C, H * W, self.flat_dev.data_ptr(),
+                                             rays.data_ptr(), rgbs.data_ptr(), ro.data_ptr(), _lib.stream()), "nf_gather_view_pixels")
+        # forward, loss and backward WITHOUT the autograd engine: the step's graph is known (two render passes -> one loss), and
+        # the engine brings its own stream bookkeeping (AccumulateGrad streams, leaf-stream joins) into the capture
+        from .autograd import _run_passes
+        from .autograd_bwd import render_backward, _nerf_params
+        net = self.net
+        fine = net.N_importance > 0
+        cap = {"counts": [], "caps": []}
+        net._capture = cap
+        try:
+            p0, p1, rays_c, ro_c, grid = _run_passes(net, self.P, ro, rays, True, fine, save_acts=True)
+        finally:
+            net._capture = None
+        loss = torch.empty(1, dtype=torch.float32, device=self.dev)
+        g0 = torch.empty_like(p0.rgb)
+        g1 = torch.empty_like(p1.rgb) if fine else None
+        f3 = ctypes.c_float * 3
+        _lib.check(lib.nf_e2e_loss(p0.rgb.data_ptr(), p1.rgb.data_ptr() if fine else None, rgbs.data_ptr(), p0.rgb.numel(), rgbs.numel() // V,
+                                   None, 0, f3(0, 0, 0), f3(0, 0, 0), 0.0, loss.data_ptr(), g0.data_ptr(), g1.data_ptr() if fine else None, None,
+                                   _lib.stream()), "nf_e2e_loss")
+        gc, gf = render_backward(net, p0, p1, rays_c, g0, g1, True)
+        grads = list(gc) + (list(gf) if fine else [])
+        params = _nerf_params(net)[:len(grads)]
+        for p_, g_ in zip(params, grads):
+            p_.grad = g_                      # views of the passes' gradient blobs (static storage of the graph's pool)
+        c, k = cap["counts"], cap["caps"]
+        _lib.check(lib.nf_note_overflow(c[0].data_ptr(), int(k[0]), c[1].data_ptr() if len(c) > 1 else None, int(k[1]) if len(k) > 1 else 0,
+                                        self.state_dev.data_ptr(), self._ring_dev, _lib.stream()), "nf_note_overflow")
+        self.opt.graph_enqueue(self.sched_dev, self.state_dev[0:1])
+        out = {"rgb0": p0.rgb}
+        if fine:
+            out["rgb1"] = p1.rgb
+        self._keep = (out, rgbs, c, p0, p1, grads)
+        self.caps = [int(v) for v in k]
+        return loss[0]
+
+    def _capture_graph(self):
+        self.graph = None
+        self._keep = None
+        torch.cuda.synchronize(self.dev)
+        self.state_dev.zero_()
+        self._ring_np[:] = 0
+        self._steps = 0
+        self._recapture = False
+        # gradients the eager steps left must not be what the captured backward accumulates into
+        self.opt.zero_grad(set_to_none=True)
+        from . import ops
+        prof, ops.PROFILE = ops.PROFILE, None      # (timing events cannot be recorded into a capture)
+        g = torch.cuda.CUDAGraph()
+        try:
+            with torch.no_grad(), torch.cuda.graph(g):
+                self.loss_static = self._body()
+        finally:
+            ops.PROFILE = prof
+        torch.cuda.synchronize(self.dev)
+        self.graph = g
+        self.captures += 1
+
+    def _launch(self, flat_host, scal, loss_out=None):
+        slot = self._stage[self._si % len(self._stage)]
+        self._si += 1
+        if slot[2] is not None:
+            slot[2].synchronize()           # the copies that last read this staging slot are done
+        slot[0].copy_(flat_host)
+        slot[1][0], slot[1][1] = scal[0], scal[1]
+        self.flat_dev.copy_(slot[0], non_blocking=True)
+        self.sched_dev.copy_(slot[1], non_blocking=True)
+        slot[2] = torch.cuda.Event()
+        slot[2].record()
+        self.graph.replay()
+        if loss_out is None:
+            loss_out = self.loss_static.clone()
+        else:
+            loss_out.copy_(self.loss_static)        # a redone step: the tensor the caller already holds gets the true value
+        ev = torch.cuda.Event()
+        ev.record()
+        self._launched.append((self._steps, flat_host, scal, ev, loss_out))
+        self._steps += 1
+        return loss_out
+
+    def _settle(self, keep_in_flight):
+        """Reads the records of all launched steps but the newest `keep_in_flight` (waiting for them); on a poisoned step raises the
+        capacities, recaptures and redoes every step from it on.  Returns the redone last step's loss, or None."""
+        redo_loss = None
+        while len(self._launched) > keep_in_flight:
+            idx, _, _, ev, _ = self._launched[0]
+            ev.synchronize()
+            rec = self._ring_np[(idx & 7) * 8:(idx & 7) * 8 + 8]
+            if int(rec[2]) != idx + 1:
+                raise RuntimeError("GraphedRendererStep: step %d finished without its overflow record (found counter %d)" % (idx, int(rec[2])))
+            poisoned, counts = int(rec[0]), [int(rec[3]), int(rec[4])]
+            caps = self.net.train_row_cap
+            if poisoned:
+                todo = list(self._launched)             # this step and everything enqueued behind it were no-ops on the device
+                torch.cuda.synchronize(self.dev)
+                for key, n, cap in zip(self._cap_keys, counts, self.caps):
+                    if n > cap:
+                        caps[key] = max(caps.get(key, 0), ops_round_rows(n + n // 2 + 4096))
+                self._launched = []
+                self._capture_graph()
+                for _, flat_host, scal, _, loss_t in todo:
+                    redo_loss = self._launch(flat_host, scal, loss_t)
+                    self.redone_steps += 1
+                continue                                  # the redone steps are settled by the same loop
+            self._launched.pop(0)
+            self.rows_total += counts[0] + counts[1]
+            self.steps_total += 1
+            for key, n, cap in zip(self._cap_keys, counts, self.caps):
+                if n > cap * 0.9 and caps.get(key, 0) <= cap:       # grow ahead of need (as the eager passes do)
+                    caps[key] = ops_round_rows(n + n // 4 + 4096)
+                    self._recapture = True                # taken up by the next step()
+        return redo_loss
+
+    def step(self, coords, sels):
+        """coords (n, 2) host pixel grid, sels[v] = the selected rows for view v (PixelSampler / choice_without_replacement).
+        Returns the step's loss (a fresh 0-dim tensor)."""
+        yx = torch.cat([coords[torch.as_tensor(s)] for s in sels]).long()
+        flat_host = yx[:, 0] * self.W + yx[:, 1]
+        if flat_host.numel() != self.V * self.rc:
+            raise ValueError("GraphedRendererStep: %d pixels per step expected" % (self.V * self.rc))
+        if int(flat_host.min()) < 0 or int(flat_host.max()) >= self.H * self.W:
+            raise IndexError("pixel selection outside the %d x %d image" % (self.H, self.W))
+        if self.graph is None or self._recapture:
+            redo = self._settle(0)          # (a redo in here recaptures with the raised capacities itself)
+            if self.graph is None or (self._recapture and redo is None):
+                self._capture_graph()
+        scal = self.opt.graph_scalars()
+        if scal is None:
+            raise RuntimeError("GraphedRendererStep: the optimizer cannot step from a graph (see HipAdam.graph_scalars)")
+        loss = self._launch(flat_host, scal)
+        redo = self._settle(1)          # the previous step's record, with this step already queued behind it
+        return redo if redo is not None else loss
+
+    def verify(self):
+        """Settle every enqueued step (redoing poisoned ones: their loss tensors are corrected in place)."""
+        self._settle(0)
+
+    def last_outputs(self):
+        """(renderer result dict, target colours) of the LAST replayed step — static tensors, valid until the next step."""
+        return self._keep[0], self._keep[1]
+
+
+def ops_round_rows(n):
+    from . import ops
+    return ops._round_rows(n)
+
+
 def make_train_step(net, scene, dev, rank=0, world=1, lr=5e-4, decay_epochs=10000, seed=10):
     """Synthetic warm-up workload for bench.py: 4 views (the synthetic camera), random target colours."""
     H = W = 400
@@ -531,9 +803,19 @@ def make_train_step(net, scene, dev, rank=0, world=1, lr=5e-4, decay_epochs=1000
     state = {"step": 1000}   # past precrop_iters: full-frame sampling (steady state of the 100k-step schedule)
     sampler = PixelSampler(rng, len(views), 1024, lambda s: random_sample_coords(H, W, s, 500).shape[0], state["step"])
 
+    use_graph = os.environ.get("NF_TRAIN_GRAPH", "1") != "0" and GraphedRendererStep.eligible(net, opt, P, world)
+    gstep = GraphedRendererStep(net, opt, P, views, H, W, 1024) if use_graph else None
+
     def step():
-        loss = renderer_train_step(net, opt, sched, P, views, H, W, state["step"], 1024, 500, rng, rank, world, sampler)
+        if gstep is not None and state["step"] >= 1003 and gstep.ready():       # three eager steps first (they learn the row capacities)
+            coords = random_sample_coords(H, W, state["step"], 500)
+            loss = gstep.step(coords, sampler.next(state["step"]))
+            sched.step()
+        else:
+            loss = renderer_train_step(net, opt, sched, P, views, H, W, state["step"], 1024, 500, rng, rank, world, sampler)
         state["step"] += 1
         return loss
 
+    step.graphed = gstep
+    step.sampler = sampler          # (close() it when done: the read-ahead thread)
     return step

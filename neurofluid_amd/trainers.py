@@ -21,7 +21,7 @@ from .point_eval import FluidErrors
 from .render_loop import render_image as _render_image
 from .renderer import RenderNet
 from .train_step import (ExponentialLR, PixelSampler, random_sample_coords, _upload, choice_without_replacement, gather_view_pixels,
-                         make_adam, summed_view_mse, e2e_loss, portable_optimizer_state, load_optimizer_state)
+                         make_adam, summed_view_mse, e2e_loss, portable_optimizer_state, load_optimizer_state, GraphedRendererStep)
 from .transmodel import ParticleNet, PairCapacityExceeded
 
 to8b = lambda x: (255 * np.clip(x, 0, 1)).astype(np.uint8)   # noqa: E731  trainer/basetrainer.py:16
@@ -292,13 +292,43 @@ class RendererTrainer(BaseTrainer):
         # the global np.random stream, drawn in the reference's order but one step ahead on a host thread
         self._sampler = PixelSampler(np.random, len(self.train_view_names), o.RENDERER.ray.ray_chunk,
                                      lambda s: self.random_sample_coords(H, W, s).shape[0], self.start_step)
+        # Steady state: the whole step (gather -> forward -> loss -> backward -> Adam) replayed as ONE HIP graph
+        # (train_step.GraphedRendererStep; TRAIN.renderer_graph: False keeps the eager step).  The first three steps of a run are eager:
+        # they learn the passes' row capacities the capture needs.
+        nv, rc = len(self.train_view_names), int(o.RENDERER.ray.ray_chunk)
+        std_rgb = type(self.rgb_criterion) is torch.nn.MSELoss and self.rgb_criterion.reduction == 'mean'
+        gstep = None
+        if bool(getattr(o.TRAIN, 'renderer_graph', True)) and std_rgb and \
+                GraphedRendererStep.eligible(self.renderer, self.optimizer, data['particles_pos'], self.world):
+            gstep = GraphedRendererStep(self.renderer, self.optimizer, data['particles_pos'],
+                                        [dict(rays=data['rays'][v], rgb=data['rgb'][v], cw=data['cw'][v]) for v in range(nv)], H, W, rc)
+        self._graph_step = gstep
         try:
             for step_idx in range(self.start_step, last):
-                loss = self.train_step(data, len(self.train_view_names), H, W, step_idx)
-                self.update_step(loss)
+                if gstep is not None and step_idx - self.start_step >= 3 and gstep.ready():
+                    loss = gstep.step(self.random_sample_coords(H, W, step_idx), self._sampler.next(step_idx))
+                    if self.lr_scheduler is not None:
+                        self.lr_scheduler.step()
+                    if (step_idx + 1) % o.TRAIN.log_interval == 0:
+                        gstep.verify()              # a truncated (and redone) step must not reach the logged values
+                        out, rgbs = gstep.last_outputs()
+                        with torch.no_grad():
+                            for v in range(nv):
+                                sl = slice(v * rc, (v + 1) * rc)
+                                lv = self.rgb_criterion(out['rgb0'][sl], rgbs[sl])
+                                if self.renderer.N_importance > 0:
+                                    lv = lv + self.rgb_criterion(out['rgb1'][sl], rgbs[sl])
+                                self.summary_writer.add_scalar(f'{self.train_view_names[v]}/rgbloss', lv.item(), step_idx)
+                else:
+                    loss = self.train_step(data, nv, H, W, step_idx)
+                    self.update_step(loss)
                 if (step_idx + 1) % o.TRAIN.save_interval == 0:
+                    if gstep is not None:
+                        gstep.verify()
                     self.eval(step_idx)
                     self.save_checkpoint(step_idx)
+            if gstep is not None:
+                gstep.verify()
         finally:                      # also on an exception: the worker thread must not outlive the loop
             self._sampler.close()
             self._sampler = None

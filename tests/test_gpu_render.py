@@ -1919,3 +1919,70 @@ def test_config_variants_vs_reference_goldens(dev, name):
               f"dL/dpos {rel:.2e}, same depths as the reference: {same_depths}, smallest |pre-activation| {kink}")
     # (1b) the reference's coarse gradient norms: tight unless a coarse unit sits on its kink
     assert worst_c <= (3e-2 if kink["nerf_coarse"] < 2e-5 else 2e-5), (worst_c, kink)
+
+
+# ------------------------------------------------------------------------------------------------
+# the warm-up optimiser step replayed as ONE HIP graph (train_step.GraphedRendererStep)
+# ------------------------------------------------------------------------------------------------
+def _train_pair(dev, n_steps, monkeypatch, spoil=None):
+    """n_steps of the synthetic warm-up workload, once eagerly and once with the graph (three eager steps, then replays).
+    Returns (eager losses, graphed losses, eager net, graphed net, the GraphedRendererStep)."""
+    from neurofluid_amd import train_step as ts
+    from neurofluid_amd.renderer import RenderNet
+    from neurofluid_amd.synthetic import watercube_scene
+    scene = watercube_scene(400, 400)
+    res = []
+    for graph in ("0", "1"):
+        monkeypatch.setenv("NF_TRAIN_GRAPH", graph)
+        net = RenderNet(make_cfg(), 9.0, 13.0)
+        net.load_state_dict(scene["nerf_state"], strict=True)
+        net = net.to(dev)
+        step = ts.make_train_step(net, scene, dev)
+        losses = []
+        for i in range(n_steps):
+            if graph == "1" and spoil is not None and i == 3:
+                spoil(net)
+            losses.append(step())
+        if step.graphed is not None:
+            step.graphed.verify()
+        torch.cuda.synchronize()
+        step.sampler.close()
+        res.append((torch.stack([l.detach().reshape(()) for l in losses]).cpu(), net, step.graphed))
+    return res[0][0], res[1][0], res[0][1], res[1][1], res[1][2]
+
+
+def _same_trajectory(le, lg, ne, ng, dev):
+    """The eager step is itself reproducible only to rounding: the active-row lists are compacted with atomics, so the ORDER of the rows
+    — and with it the fp32 summation order of every weight gradient — changes from run to run (two eager runs differ by ~1e-3 of a
+    gradient's scale, and Adam's first steps normalise those differences up).  Bars: every step's loss within 2e-5 relative (observed
+    1e-6), the parameter UPDATE of the whole run within 2 % in L2 (observed ~1e-3)."""
+    assert torch.allclose(le, lg, rtol=2e-5, atol=0), (le, lg)
+    p0 = make_net(dev).state_dict()
+    num = den = 0.0
+    for (k, a), (_, b) in zip(ne.state_dict().items(), ng.state_dict().items()):
+        num += float(((a - p0[k]) - (b - p0[k])).double().pow(2).sum())
+        den += float((a - p0[k]).double().pow(2).sum())
+    assert den > 0 and (num / den) ** 0.5 < 2e-2, (num / den) ** 0.5
+    return (num / den) ** 0.5
+
+
+def test_graph_replayed_renderer_step_equals_eager(dev, monkeypatch):
+    """BASELINE config 2's step (trainer/trainer_renderer.py:94-143) replayed as a HIP graph: same kernels, same operands — the
+    losses of every step and all 48 parameters after 9 steps follow the eager loop's (to the eager loop's own run-to-run rounding)."""
+    le, lg, ne, ng, gs = _train_pair(dev, 9, monkeypatch)
+    assert gs is not None and gs.captures == 1 and gs.redone_steps == 0 and gs.steps_total == 6
+    rel = _same_trajectory(le, lg, ne, ng, dev)
+    print("graph-replayed vs eager: per-step loss difference", (lg.double() - le.double()).tolist(), " update L2 rel", rel)
+
+
+def test_graph_replayed_renderer_step_redoes_an_overflowed_step(dev, monkeypatch):
+    """A replayed step that meets more active rows than the capacities its graph was captured for must leave the parameters alone
+    (sticky poison word, nf_adam_step_dev's skip), and the host must redo it and every step enqueued behind it: the trajectory stays
+    the eager loop's (a skipped or doubled optimiser step would move the losses by ~1e-2)."""
+    def spoil(net):         # capacities far below the ~7 k / ~72 k active rows of a step: the first replay overflows both passes
+        for k in list(net.train_row_cap):
+            net.train_row_cap[k] = 8192
+    le, lg, ne, ng, gs = _train_pair(dev, 8, monkeypatch, spoil)
+    assert gs.redone_steps >= 1 and gs.captures >= 2
+    rel = _same_trajectory(le, lg, ne, ng, dev)
+    print("overflow redo: redone steps", gs.redone_steps, "captures", gs.captures, " update L2 rel", rel)

@@ -42,6 +42,8 @@ def test_renderer_trainer_and_eval(workdir):
     before = [p.detach().clone() for p in tr.renderer.parameters()]
     loss = tr.train()
     assert np.isfinite(float(loss))
+    # steps 0-2 ran eagerly (they learn the row capacities), step 3 was the first replay of the captured step
+    assert tr._graph_step is not None and tr._graph_step.captures >= 1 and tr._graph_step.steps_total >= 1
     assert any(not torch.equal(a, b.detach()) for a, b in zip(before, tr.renderer.parameters()))
     ck = workdir / "exps" / "warm" / "models" / "3.pt"
     assert ck.exists()

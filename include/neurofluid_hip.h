@@ -190,9 +190,18 @@ int nf_nerf_mlp_fwd_a(const float* packed, const float* wstream, int cx, int cd,
 /* A6 for small launches (models/nerf.py:83-124, the forward of a training step; nf_mlp_n.hip): one 32-row tile per WORKGROUP, a layer's 8 output blocks split over its 4 waves,
  * activations exchanged through an LDS image — a quarter of nf_nerf_mlp_fwd's per-tile latency (it keeps a tile in one
  * wave for 0.35 ms: a launch costs ceil(tiles / 1024) such rounds however empty the last one is).  packed_n = nf_nerf_pack_n
- * of the standard blob; same operand X, same outputs (rgbsigma, and acts when not NULL) BIT FOR BIT. */
+ * of the standard blob; same operand X; the saved activations (acts, when not NULL) equal nf_nerf_mlp_fwd's BIT FOR BIT; round 6: the
+ * sigma / rgb heads are summed by the four waves (a quarter of each head's products per wave, then the four partials) instead of one
+ * chain per lane by one wave while three wait, so rgbsigma agrees with nf_nerf_mlp_fwd's to the last bits (1e-6 relative), not bit for bit. */
 int nf_nerf_mlp_fwd_n(const float* packed_n, int cx, int cd, const float* X, const int32_t* n_rows, int max_rows,
                       const int32_t* row_sample, float* rgbsigma, float* acts /*or NULL*/, nf_stream_t stream);
+/* The training forward proper (round 6): nf_nerf_mlp_fwd_n + the ReLU masks of every hidden unit as BITS — amask[tile][10][4 waves][64 lanes]
+ * uint32 (nf_nerf_amask_words(max_rows) words; slot = activation slot 0..7, 9; bit 31 - (16 i + r) of a word = [pre-activation > 0] of the
+ * wave's block i, accumulator register r; the view branch's single block: bit 15 - r) — which is all nf_nerf_mlp_bwd_n2 needs of the forward: it reads one word per lane and layer
+ * instead of 128 B of saved activations (acts are still written: the weight gradients' operand). */
+size_t nf_nerf_amask_words(int max_rows);
+int nf_nerf_mlp_fwd_n2(const float* packed_n, int cx, int cd, const float* X, const int32_t* n_rows, int max_rows,
+                       const int32_t* row_sample, float* rgbsigma, float* acts, uint32_t* amask, nf_stream_t stream);
 
 /* fp16-MFMA forward of A6 (models/nerf.py:83-124), version 3 (nf_mlp_h2.hip): two 32-row tiles per wave, out-block-major, packed fp16 activations
  * between layers, sigma / rgb heads on the matrix pipe.  Operand X: the fp16 layout written
@@ -261,6 +270,10 @@ int nf_nerf_pack_bwd_n(const float* packed_t, float* packed_tn, nf_stream_t stre
 int nf_nerf_mlp_bwd_n(const float* packed, const float* packed_t, int cx, int cd, const float* acts,
                       const int32_t* n_rows, int max_rows, const int32_t* row_sample, const float* rgbsigma,
                       const float* d_rgbsigma, float* dpre, nf_stream_t stream);
+/* The same again with the ReLU masks taken from nf_nerf_mlp_fwd_n2's mask words instead of the saved activations (same dpre, bit for bit). */
+int nf_nerf_mlp_bwd_n2(const float* packed, const float* packed_t, int cx, int cd, const uint32_t* amask,
+                       const int32_t* n_rows, int max_rows, const int32_t* row_sample, const float* rgbsigma,
+                       const float* d_rgbsigma, float* dpre, nf_stream_t stream);
 
 /* A12 (weight gradients of the nn.Linear layers of models/nerf.py:55-81): all 15 GEMMs dW_l = dpre_l^T * input_l of one NeRF in one batched fp32-MFMA launch +
  * one deterministic slice reduction.  X = the MLP operand of nf_render_features (tile layout) that the forward consumed.

@@ -56,6 +56,8 @@ PROTOTYPES = {
     "nf_nerf_pack": (c_int, [ctypes.POINTER(NerfParams), c_int, c_int, c_void_p, c_void_p]),
     "nf_nerf_mlp_fwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nf_nerf_mlp_fwd_n": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nf_nerf_mlp_fwd_n2": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nf_nerf_amask_words": (c_size_t, [c_int]),
     "nf_composite_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "nf_composite_fwd_noise": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
@@ -94,6 +96,8 @@ PROTOTYPES = {
     "nf_nerf_pack_bwd_n": (c_int, [c_void_p, c_void_p, c_void_p]),
     "nf_nerf_mlp_bwd_n": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_void_p]),
+    "nf_nerf_mlp_bwd_n2": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p]),
     "nf_embed_fwd": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "nf_embed_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "nf_gemm_f32_workspace_floats": (c_size_t, [c_int, c_int, c_int]),

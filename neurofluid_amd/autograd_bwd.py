@@ -73,10 +73,14 @@ def _pass_backward(net, nerf, pb, rays_c, z, z_table, g_rgb, white_bg, particles
     cap = ops._round_rows(n)
     dpre_full = torch.empty(cap, DPRE, dtype=torch.float32, device=dev)
     dpre = dpre_full[:n]
-    check(lib.nf_nerf_mlp_bwd_n(ptr(pb.packed), ptr(packed_t), cx, cd, ptr(pb.acts), ptr(pb.n_rows), n, ptr(pb.row_sample),
-                              ptr(pb.rgbsigma), ptr(d_rs), ptr(dpre_full), st), "nf_nerf_mlp_bwd_n")
+    if getattr(pb, "amask", None) is not None:      # the forward left the ReLU masks as bits: no read of the saved activations here
+        check(lib.nf_nerf_mlp_bwd_n2(ptr(pb.packed), ptr(packed_t), cx, cd, ptr(pb.amask), ptr(pb.n_rows), n, ptr(pb.row_sample),
+                                     ptr(pb.rgbsigma), ptr(d_rs), ptr(dpre_full), st), "nf_nerf_mlp_bwd_n2")
+    else:
+        check(lib.nf_nerf_mlp_bwd_n(ptr(pb.packed), ptr(packed_t), cx, cd, ptr(pb.acts), ptr(pb.n_rows), n, ptr(pb.row_sample),
+                                    ptr(pb.rgbsigma), ptr(d_rs), ptr(dpre_full), st), "nf_nerf_mlp_bwd_n")
     # weight gradients: one batched fp32-MFMA launch for all 15 GEMMs of the net (nf_nerf_wgrad)
-    nsl = 22          # 46 tiles x 22 row slices = 1 012 waves, one per SIMD (a 128 x 128 tile per wave needs the whole register file)
+    nsl = 21          # 12 jobs (workgroups of up to four 128 x 128 tiles that share operand blocks) x 21 row slices = 252 workgroups, one per CU
     blob = torch.empty(lib.nf_nerf_wgrad_floats(cx, cd), dtype=torch.float32, device=dev)
     wsp = torch.empty(lib.nf_nerf_wgrad_workspace_floats(cx, cd, nsl), dtype=torch.float32, device=dev)
     colsum = torch.empty(DPRE, dtype=torch.float32, device=dev)

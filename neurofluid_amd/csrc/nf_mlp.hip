@@ -920,6 +920,240 @@ __global__ void __launch_bounds__(256) k_wgrad2(NfWgradPlan P, const float* __re
     }
 }
 
+// ---- round 6: the four waves of a workgroup SHARE their operands (k_wgrad3).  k_wgrad2 runs at 0.59 of the matrix peak on the 63 000
+// rows of a training step's fine pass and its time does not depend on how the rows are sliced (20 / 21 / 22 / 44 slices: 930 / 912 /
+// 905 / 915 us): it is bound by the bytes it asks for.  Every wave streams its own A and B block (2 KB per two rows), although the
+// 2 x 2 tiles of a layer need only two A and two B blocks between them: 3.0 GB of requests per launch, every one of them reaching the
+// L2 (hit rate 0.18: the twin request arrives while the first is still in flight) and 2.4 GB the memory side, for 1.2 GB of operands.
+// Here a workgroup is a JOB: up to four 128 x 128 tiles that share A / B blocks (a 256 x 256 layer: 2 + 2 blocks; the view branch:
+// one A block, the two halves of `final` and the direction features; the heads: the dsigma / drgb quad and h8's halves, hd).  Wave w
+// brings block w of the job into a workgroup-wide LDS ring with ONE LDS-DMA per step (1 KB; k_wgrad2: two), every wave reads its A and
+// its B block from the ring: half the requests, each operand byte fetched once per job.  One s_barrier per step (16 MFMAs) in the middle
+// of the step's MFMAs: behind it every wave's piece of step s + 1 has landed (each wave waits for its own DMA before the barrier) and the
+// slot that the next DMA overwrites (ring of WG3_P + 1 steps, requests WG3_P steps ahead) was read before the barrier of the step before.
+// Same per-tile arithmetic as k_wgrad2 — same MFMAs in the same order over the same slices — so the sums are bit-identical.
+#ifndef WG3_P
+#define WG3_P 6
+#endif
+#define WG3_D (WG3_P + 1)
+#define WG_MAX_JOBS 16
+struct NfWgradJob { int nloads, ntiles; int load[4]; /* gemm | kind << 8 | block << 16 (block = m0 or n0 in units of 128) */
+                    int tile[4];  /* gemm | (m0 / 128) << 8 | (n0 / 128) << 12 | slot of A << 16 | slot of B << 20 */ };
+struct NfWgradJobs { int njobs; NfWgradJob j[WG_MAX_JOBS]; };
+
+static NfWgradJobs wgrad_jobs(const NfWgradPlan& P)
+{
+    NfWgradJobs J;
+    J.njobs = 0;
+    int open_al = -1, open_span = 0;         // the A block of the job that may still take tiles (one m-tile GEMMs only)
+    for (int gi = 0; gi < P.ngemm; ++gi) {
+        const NfWgradGemm& g = P.g[gi];
+        const int mt = (g.M + 127) / 128, nt = g.tiles_n;
+        const int a_shift = g.a_col & 3, a_al = g.a_col - a_shift, a_span = g.M + a_shift < 128 ? g.M + a_shift : 128;
+        if (mt == 2) {
+            NfWgradJob& j = J.j[J.njobs++];
+            j.nloads = 2 + nt; j.ntiles = 2 * nt;
+            j.load[0] = gi | 0 << 8 | 0 << 16; j.load[1] = gi | 0 << 8 | 1 << 16;
+            for (int b = 0; b < nt; ++b) j.load[2 + b] = gi | 1 << 8 | b << 16;
+            for (int a = 0; a < 2; ++a)
+                for (int b = 0; b < nt; ++b) j.tile[a * nt + b] = gi | a << 8 | b << 12 | a << 16 | (2 + b) << 20;
+            open_al = -1;
+            continue;
+        }
+        bool fits = false;
+        if (open_al == a_al && (open_span == a_span || (open_span <= 4 && a_span <= 4))) {
+            const NfWgradJob& o = J.j[J.njobs - 1];
+            fits = o.nloads + nt <= 4 && o.ntiles + nt <= 4;
+        }
+        if (!fits) {
+            NfWgradJob& j = J.j[J.njobs++];
+            j.nloads = 1; j.ntiles = 0;
+            j.load[0] = gi | 0 << 8 | 0 << 16;
+            open_al = a_al; open_span = a_span;
+        }
+        NfWgradJob& j = J.j[J.njobs - 1];
+        for (int b = 0; b < nt; ++b) {
+            j.tile[j.ntiles++] = gi | 0 << 8 | b << 12 | 0 << 16 | j.nloads << 20;
+            j.load[j.nloads++] = gi | 1 << 8 | b << 16;
+        }
+    }
+    return J;
+}
+
+__global__ void __launch_bounds__(256) k_wgrad3(NfWgradPlan P, NfWgradJobs J, const float* __restrict__ dpre, const float* __restrict__ acts,
+                                                const float* __restrict__ xtiles, int Q, int n_rows, int rows_per_slice,
+                                                int nslices, float* __restrict__ partial, const int* __restrict__ n_rows_dev)
+{
+    __shared__ float4 wg3_ring[WG3_D][4][64];          // WG3_D steps x 4 blocks x 64 lanes x 16 B = 28 KB
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (n_rows_dev) {       // nf_nerf_wgrad_dev: the row count lives on the device (graph replay); the slicing nf_nerf_wgrad does on the host
+        n_rows = min(__builtin_amdgcn_readfirstlane(*n_rows_dev), n_rows);         // (n_rows = the caller's capacity)
+        if (n_rows <= 0) return;
+        const int want = nslices;
+        rows_per_slice = ((n_rows + want - 1) / want + 31) / 32 * 32;
+        nslices = (n_rows + rows_per_slice - 1) / rows_per_slice;
+    }
+    const int by = blockIdx.x / J.njobs, ji = blockIdx.x - by * J.njobs;
+    if (by >= nslices) return;
+    const NfWgradJob& JB = J.j[ji];
+    const int i32 = lane & 31, h = lane >> 5;
+    const int r0 = by * rows_per_slice, r1 = min(n_rows, r0 + rows_per_slice);      // r0 is a multiple of 32
+    const int nsteps = (r1 - r0 + 1) >> 1;
+    const int lim_even = (n_rows - 1 - r0) & ~1;
+    const bool odd_end = ((n_rows - r0) & 1) != 0;
+    const unsigned xq4 = (unsigned)Q * 1024u;
+    // ---- this wave's LOAD: block w of the job (address arithmetic of k_wgrad2's dma_a / dma_b); a wave beyond the job's blocks
+    // repeats block 0 into its own (unread) ring slot, so that the loop has no branch on it
+    const char* sL;
+    unsigned voL, voL_last;
+    unsigned pitchS, xqS, x16S;            // byte offset of row pair r2: r2 * pitchS + (r2 >> 5) * xqS + (r2 & 31) * x16S
+    {
+        const int ld = JB.load[w < JB.nloads ? w : 0];
+        const NfWgradGemm& GL = P.g[ld & 255];
+        const int blk = (ld >> 16) * 128;
+        if (((ld >> 8) & 255) == 0) {           // an A block: the quad of dpre columns a_al + m0 + 4 i
+            const int a_shift = GL.a_col & 3, a_al = GL.a_col - a_shift;
+            const int a_span = min(128, GL.M - blk + a_shift);
+            const unsigned cA = 4u * (unsigned)(a_al + blk + (4 * i32 < a_span ? 4 * i32 : 0));
+            sL = (const char*)(dpre + (size_t)r0 * NF_DPRE_STRIDE);
+            pitchS = (unsigned)(NF_DPRE_STRIDE * 4); xqS = 0; x16S = 0;
+            voL = cA + (unsigned)h * pitchS;
+            voL_last = odd_end ? cA : voL;
+        } else {                                // a B block: activations (row-major) or the feature tiles
+            const int f0 = GL.b_col + blk + 4 * i32;
+            const bool b_ok = GL.b_src ? f0 < 8 * Q : 4 * i32 < GL.N - blk;
+            const int fb = b_ok ? f0 : GL.b_col + blk;
+            const bool xL = GL.b_src != 0;
+            sL = xL ? (const char*)(xtiles + (size_t)(r0 >> 5) * Q * 256) : (const char*)(acts + (size_t)r0 * NF_ACT_STRIDE);
+            const unsigned cB = xL ? 4u * (unsigned)(((fb >> 3) * 2 + ((fb >> 2) & 1)) * 128) : 4u * (unsigned)fb;
+            const unsigned pitchL = xL ? 16u : (unsigned)(NF_ACT_STRIDE * 4);
+            pitchS = xL ? 0u : pitchL; xqS = xL ? xq4 : 0u; x16S = xL ? 16u : 0u;
+            voL = cB + (unsigned)h * pitchL;
+            voL_last = odd_end ? cB : voL;
+        }
+    }
+    // ---- this wave's TILE
+    const bool has_tile = w < JB.ntiles;
+    const int td = has_tile ? JB.tile[w] : JB.tile[0];
+    const NfWgradGemm G = P.g[td & 255];
+    const int m0 = ((td >> 8) & 15) * 128, n0 = ((td >> 12) & 15) * 128;
+    const int slotA = (td >> 16) & 15, slotB = (td >> 20) & 15;
+    const int a_shift = G.a_col & 3;
+    const int a_span = min(128, G.M - m0 + a_shift);
+    int cmask = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) if (c >= a_shift && c - a_shift < G.M - m0) cmask |= 1 << c;
+    if (G.M - m0 + a_shift > 4) cmask = 15;
+    if (!has_tile) cmask = 0;
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const bool do_colsum = has_tile && G.colsum && n0 == 0;
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    float4* const ring = &wg3_ring[0][0][0];
+    const unsigned ring_lane = (unsigned)(size_t)(lptr_t)ring + 16u * (unsigned)lane;
+    const unsigned rdA = ring_lane + 1024u * (unsigned)slotA, rdB = ring_lane + 1024u * (unsigned)slotB;
+    auto dma = [&](int s, int slot) __attribute__((always_inline)) {
+        const int r2 = min(2 * s, lim_even);                                      // scalar
+        const size_t off = (size_t)((unsigned)r2 * pitchS) + (size_t)((unsigned)(r2 >> 5) * xqS) + (size_t)((unsigned)(r2 & 31) * x16S);
+        const char* pa = sL + off + (r2 == lim_even ? voL_last : voL);
+        __builtin_amdgcn_global_load_lds((gptr_t)pa, (lptr_t)(ring + (slot * 4 + w) * 64), 16, 0, 0);
+    };
+    auto k_loop = [&](auto full_tag, auto cs_tag) __attribute__((always_inline)) {
+        constexpr bool CS = decltype(cs_tag)::value;              // this tile also sums its dpre columns (bias gradients)
+        constexpr bool FULL = decltype(full_tag)::value;          // whole tiles: 16 MFMAs per step, no test inside the loop
+#pragma unroll
+        for (int d = 0; d < WG3_P; ++d) dma(d, d);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WG3_P - 1) : "memory");          // step 0 has landed (this wave's piece)
+        __builtin_amdgcn_s_barrier();                                                // ... and everybody's
+        f32x4 a, b;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(a) : "v"(rdA));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(b) : "v"(rdB));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)::"memory");
+        auto group = [&](int s0, auto mask_tag) __attribute__((always_inline)) {
+            constexpr bool MASK = decltype(mask_tag)::value;      // the slice's last group: rows past its end contribute nothing
+#pragma unroll
+            for (int d = 0; d < WG3_D; ++d) {
+                const int s = s0 + d;
+                f32x4 an, bn;
+                if (MASK && r0 + 2 * s + h >= r1) a = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (CS) { cs.x += a[0]; cs.y += a[1]; cs.z += a[2]; cs.w += a[3]; }
+                const float av[4] = {a[0], a[1], a[2], a[3]}, bv[4] = {b[0], b[1], b[2], b[3]};
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (FULL || (cmask >> c & 1)) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[c][e] = MFMA32(av[c], bv[e], acc[c][e]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#ifndef NF_W3_NODMA                 // (dev ablations: garbage results, one thing removed from the instruction stream)
+                    if (c == 0) dma(s + WG3_P, (d + WG3_P) % WG3_D);       // the slot of step s - 1: read before the barrier of step s - 1
+#endif
+                    if (c == 1) {
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WG3_P - 1) : "memory");       // this wave's piece of step s + 1 has landed
+#ifndef NF_W3_NOBAR
+                        __builtin_amdgcn_s_barrier();
+#endif
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(an) : "v"(rdA), "n"(((d + 1) % WG3_D) * 4096));
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bn) : "v"(rdB), "n"(((d + 1) % WG3_D) * 4096));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(an), "+v"(bn)::"memory");
+                a = an; b = bn;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // every wave of the job walks the same number of steps (the barriers): whole groups, then one masked group
+        const int nfull = (r1 - r0) / (2 * WG3_D) * WG3_D;       // steps in whole, unmasked groups
+#pragma unroll 1
+        for (int s0 = 0; s0 < nfull; s0 += WG3_D) group(s0, std::false_type{});
+        if (nfull < nsteps) group(nfull, std::true_type{});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    if (cmask == 15) { if (do_colsum) k_loop(std::true_type{}, std::true_type{}); else k_loop(std::true_type{}, std::false_type{}); }
+    else k_loop(std::false_type{}, std::true_type{});
+    if (!has_tile) return;
+    float* const slice = partial + (size_t)by * (P.total + NF_DPRE_STRIDE);
+    if (do_colsum) {        // bias gradients: the two row parities of a column quad sit in lanes i and i + 32
+        cs.x += __shfl_xor(cs.x, 32, 64); cs.y += __shfl_xor(cs.y, 32, 64);
+        cs.z += __shfl_xor(cs.z, 32, 64); cs.w += __shfl_xor(cs.w, 32, 64);
+        if (h == 0) {
+            const float cv[4] = {cs.x, cs.y, cs.z, cs.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int m = m0 + 4 * i32 + c - a_shift;
+                if (m >= m0 && m < G.M && 4 * i32 < a_span) slice[P.total + G.a_col + m] = cv[c];
+            }
+        }
+    }
+    float* const out = slice + G.c_off + G.c_col;
+    const bool vec = (G.ldc & 3) == 0 && ((G.c_off + G.c_col + n0) & 3) == 0 && G.N - n0 >= 128;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (!(cmask >> c & 1)) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + 4 * ((r & 3) + 8 * (r >> 2) + 4 * h) + c - a_shift;
+            if (m < m0 || m >= G.M) continue;
+            float* o = out + (size_t)m * G.ldc + n0 + 4 * i32;
+            if (vec) *(float4*)o = make_float4(acc[c][0][r], acc[c][1][r], acc[c][2][r], acc[c][3][r]);
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (n0 + 4 * i32 + e < G.N) o[e] = acc[c][e][r];
+            }
+        }
+    }
+}
+
 // partial[slice][total + NF_DPRE_STRIDE] -> dweights[total] | dbias[NF_DPRE_STRIDE]; one float4 per thread, the slices in
 // groups of 4 independent loads (total and NF_DPRE_STRIDE are multiples of 4 floats)
 __global__ void k_wgrad_reduce(const float* __restrict__ partial, int total, int nslices, float* __restrict__ out,
@@ -975,8 +1209,14 @@ extern "C" int nf_nerf_wgrad(const float* dpre, const float* acts, const float* 
     int rows_per = (n_rows + nslices - 1) / nslices;
     rows_per = (rows_per + 31) / 32 * 32;          // slices start on a 32-row boundary (the X tiles' granule)
     int ns = (n_rows + rows_per - 1) / rows_per;
+#ifdef NF_WGRAD2
     hipLaunchKernelGGL(k_wgrad2, dim3((P.ntiles * ns + 3) / 4), dim3(256), 0, st, P, dpre, acts, X, (cx + 7) / 8 + (cd + 7) / 8, n_rows,
                        rows_per, ns, workspace, (const int*)nullptr);
+#else
+    const NfWgradJobs J = wgrad_jobs(P);
+    hipLaunchKernelGGL(k_wgrad3, dim3(J.njobs * ns), dim3(256), 0, st, P, J, dpre, acts, X, (cx + 7) / 8 + (cd + 7) / 8, n_rows,
+                       rows_per, ns, workspace, (const int*)nullptr);
+#endif
     hipLaunchKernelGGL(k_wgrad_reduce, dim3(((P.total + NF_DPRE_STRIDE) / 4 + 255) / 256), dim3(256), 0, st,
                        (const float*)workspace, P.total, ns, dweights, dbias, (const int*)nullptr, 0);
     NF_CHECK_LAUNCH();
@@ -993,8 +1233,14 @@ extern "C" int nf_nerf_wgrad_dev(const float* dpre, const float* acts, const flo
     NF_CHECK_ARG(nslices >= 1 && nslices <= 65535 && max_rows >= 1, "bad slice count / capacity");
     NfWgradPlan P = wgrad_plan(cx, cd);
     hipStream_t st = (hipStream_t)stream;
+#ifdef NF_WGRAD2
     hipLaunchKernelGGL(k_wgrad2, dim3((P.ntiles * nslices + 3) / 4), dim3(256), 0, st, P, dpre, acts, X, (cx + 7) / 8 + (cd + 7) / 8, max_rows,
                        0, nslices, workspace, (const int*)n_rows);
+#else
+    const NfWgradJobs J = wgrad_jobs(P);
+    hipLaunchKernelGGL(k_wgrad3, dim3(J.njobs * nslices), dim3(256), 0, st, P, J, dpre, acts, X, (cx + 7) / 8 + (cd + 7) / 8, max_rows,
+                       0, nslices, workspace, (const int*)n_rows);
+#endif
     hipLaunchKernelGGL(k_wgrad_reduce, dim3(((P.total + NF_DPRE_STRIDE) / 4 + 255) / 256), dim3(256), 0, st,
                        (const float*)workspace, P.total, nslices, dweights, dbias, (const int*)n_rows, max_rows);
     NF_CHECK_LAUNCH();

@@ -34,18 +34,68 @@ __device__ __forceinline__ f32x4 n_wload(__amdgpu_buffer_rsrc_t r, unsigned voff
 {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0));
 }
+// Saved activations / mask words are written with buffer stores: resource = the TILE's 32 rows (scalar registers), one vector offset per
+// lane for every store of the tile (row j x pitch + the wave's and the half's share of a 256-feature slot), the slot as the scalar
+// offset, block / quad as the immediate.  Per-lane 64-bit pointers (one per store site) had the forward kernel at 85 spilled registers.
+struct NSave { __amdgpu_buffer_rsrc_t rs; unsigned voff; bool ok; };
+// mask word, one value at a time: m = 2 m + [x > 0] as v_cmp + v_addc (two vector instructions per value; beside a co-resident
+// workgroup's fp32 MFMAs every vector instruction costs matrix time).  After n values, value k sits at bit n - 1 - k.
+// relu as ONE v_max_f32: fmaxf(x, 0) compiles to a canonicalising v_max x, x in front of it (same value for every non-NaN x)
+__device__ __forceinline__ float n_relu(float x)
+{
+    float y;
+    asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
+    return y;
+}
+__device__ __forceinline__ void n_mask_push(unsigned& m, float x)
+{
+    asm("v_cmp_gt_f32 vcc, %1, 0\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(x) : "vcc");
+}
+__device__ __forceinline__ void n_save4(const NSave& sv, int soff_bytes, int imm_bytes, f32x4 v)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(n_u32x4, v), sv.rs, (int)sv.voff + imm_bytes, soff_bytes, 0);
+}
 #ifndef NH_DEPTH
 #define NH_DEPTH 4               // read-ahead of the hidden parts' K loops, in K-step pairs
+#endif
+#ifndef NX_WD
+#define NX_WD 2                  // read-ahead of the X parts' weight operands, in groups of 4 K-steps
 #endif
 
 struct NCtx {
     int lane, h, j, w, g, c0;      // wave w owns blocks 2w, 2w + 1 = half g = w >> 1, components c0, c0 + 1 of its 16-B operands
 };
 
-// bias K-step (A = bias, B = 1, C = 0) of an 8-block layer: [2][64][4]
-__device__ __forceinline__ void n_bias2(const NCtx& c, const f32x4* __restrict__ p, f32x16 (&acc)[2])
+// dev build (-DNF_N_TIMING): where a tile's time goes — every wave stamps s_memtime at the phase boundaries below and adds the
+// differences (shader cycles) to nf_n_prof[kernel][wave][phase]; read / reset through nf_dev_n_prof (tools/n_timing.py).
+#ifdef NF_N_TIMING
+__device__ unsigned long long nf_n_prof[2][4][16];
+#define NT_DECL unsigned long long nt_t = __builtin_amdgcn_s_memtime(), nt_acc[16] = {}
+#define NT_MARK(ph) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 0" ::: "memory"); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+                         nt_acc[ph] += t_ - nt_t; nt_t = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define NT_FLUSH(kern) do { if (c.lane == 0) { for (int p_ = 0; p_ < 15; ++p_) atomicAdd(&nf_n_prof[kern][c.w][p_], nt_acc[p_]); \
+                                               atomicAdd(&nf_n_prof[kern][c.w][15], 1ull); } } while (0)
+extern "C" int nf_dev_n_prof(unsigned long long* out, int reset)
 {
-    const f32x2 wv = *(const f32x2*)((const float*)(p + c.g * 64 + c.lane) + c.c0);
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(nf_n_prof), sizeof(unsigned long long) * 128) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[128] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(nf_n_prof), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
+#else
+#define NT_DECL
+#define NT_MARK(ph)
+#define NT_FLUSH(kern)
+#endif
+
+// bias K-step (A = bias, B = 1, C = 0) of an 8-block layer: [2][64][4].  The operand is requested by n_bias_load AHEAD of the
+// epilogue + barrier in front of the layer (round 6: the load used to sit right in front of its MFMA, an L2 round trip of
+// ~3 600 cycles per layer on the tile's critical path).
+__device__ __forceinline__ f32x2 n_bias_load(const NCtx& c, const f32x4* __restrict__ p)
+{
+    return *(const f32x2*)((const float*)(p + c.g * 64 + c.lane) + c.c0);
+}
+__device__ __forceinline__ void n_bias2(const f32x2 wv, f32x16 (&acc)[2])
+{
     const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     acc[0] = MFMA32(wv[0], 1.f, z);
     acc[1] = MFMA32(wv[1], 1.f, z);
@@ -61,13 +111,13 @@ __device__ __forceinline__ void n_xpart2(const NCtx& c, __amdgpu_buffer_rsrc_t w
     const unsigned voff = (unsigned)(c.w * 64 + c.lane) * 16u;          // pair stride: 4 KB; a group of 4 K-steps = 2 pairs
     // a group is only 4 K-steps x 2 MFMAs = 512 cycles here: X (HBM the first time, L2 the second) is requested XD groups
     // ahead, the weights (L2) two groups ahead
-    constexpr int XD = 6;
+    constexpr int XD = 6, WD = NX_WD;
     f32x4 xr[XD];
-    f32x4 wr[2][2];
+    f32x4 wr[WD][2];
 #pragma unroll
     for (int q = 0; q < XD; ++q) xr[q] = q < nq ? xt[q * 64] : xt[0];
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+    for (int q = 0; q < WD; ++q)
 #pragma unroll
         for (int i = 0; i < 2; ++i) wr[q][i] = n_wload(wr_, voff, poff + (q * 2 + i) * 4096);
 #pragma unroll
@@ -79,11 +129,13 @@ __device__ __forceinline__ void n_xpart2(const NCtx& c, __amdgpu_buffer_rsrc_t w
 #pragma unroll
         for (int k = 0; k + 1 < XD; ++k) xr[k] = xr[k + 1];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) wr[0][i] = wr[1][i];
-        if (q + XD < nq) xr[XD - 1] = xt[(q + XD) * 64];
-        if (q + 2 < nq) {
+        for (int k = 0; k + 1 < WD; ++k)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) wr[1][i] = n_wload(wr_, voff, poff + ((q + 2) * 2 + i) * 4096);
+            for (int i = 0; i < 2; ++i) wr[k][i] = wr[k + 1][i];
+        if (q + XD < nq) xr[XD - 1] = xt[(q + XD) * 64];
+        if (q + WD < nq) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) wr[WD - 1][i] = n_wload(wr_, voff, poff + ((q + WD) * 2 + i) * 4096);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -96,9 +148,19 @@ __device__ __forceinline__ void n_xpart2(const NCtx& c, __amdgpu_buffer_rsrc_t w
 }
 
 // hidden part: acc += W * act, act read from the LDS image (already activated); 128 K-steps = 8 source blocks x 16
-template <int NS = 128>
+// the first NH_DEPTH weight operands of a hidden part, requested AHEAD of the epilogue + barrier in front of that part (they do not
+// depend on the barrier; the activations do): the part then starts on operands that have landed instead of on an L2 round trip
+__device__ __forceinline__ void n_hpre(const NCtx& c, __amdgpu_buffer_rsrc_t wr_, int poff, f32x4 (&pre)[NH_DEPTH])
+{
+    const unsigned voff = (unsigned)(c.w * 64 + c.lane) * 16u;
+#pragma unroll
+    for (int s = 0; s < NH_DEPTH; ++s) pre[s] = n_wload(wr_, voff, poff + s * 4096);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int NS = 128, bool PRE = false>
 __device__ __forceinline__ void n_hpart2(const NCtx& c, __amdgpu_buffer_rsrc_t wr_, int poff /* part offset in bytes, N layout */,
-                                         const float* __restrict__ act, f32x16 (&acc)[2])
+                                         const float* __restrict__ act, f32x16 (&acc)[2], const f32x4* pre = nullptr)
 {
     constexpr int NP = NS / 2, D = NH_DEPTH;          // K-step pairs; read-ahead in pairs
     const unsigned voff = (unsigned)(c.w * 64 + c.lane) * 16u;
@@ -108,7 +170,8 @@ __device__ __forceinline__ void n_hpart2(const NCtx& c, __amdgpu_buffer_rsrc_t w
 #define NH_F(S) ((32 * ((S) >> 4) + ((S) & 3) + 8 * (((S) & 15) >> 2)) * 32)
 #pragma unroll
     for (int s = 0; s < D; ++s) {
-        ring[s] = n_wload(wr_, voff, poff + s * 4096);
+        if (PRE) ring[s] = pre[s];
+        else ring[s] = n_wload(wr_, voff, poff + s * 4096);
         b0[s] = ap[NH_F(2 * s)];
         b1[s] = ap[NH_F(2 * s + 1)];
     }
@@ -138,44 +201,65 @@ __device__ __forceinline__ void n_hpart2(const NCtx& c, __amdgpu_buffer_rsrc_t w
 #undef NH_F
 }
 
-// the wave's two blocks -> LDS image (RELU or raw) and, when training, the saved-activation row (row-major, as k_mlp_fwd)
-template <bool RELU, bool SAVE>
-__device__ __forceinline__ void n_store2(const NCtx& c, const f32x16 (&acc)[2], float* __restrict__ act, float* __restrict__ save_row,
-                                         bool row_ok)
+// the wave's two blocks -> LDS image (RELU or raw) and, when training, the saved-activation row (row-major, as k_mlp_fwd).
+// mword (training): the sign bits of the wave's 32 values, bit 31 - (16 i + r) = [acc[i][r] > 0] — the backward kernel's ReLU masks, one
+// dword per lane and layer instead of the 128 B of activations it used to fetch (HBM) at every layer of every tile.
+// SIG: this is h8 — the wave also sums its 64 features' share of the sigma head (a partial per lane -> sp[wave][lane]).
+template <bool RELU, bool SAVE, bool SIG = false>
+__device__ __forceinline__ void n_store2(const NCtx& c, const f32x16 (&acc)[2], float* __restrict__ act, const NSave& sv, int slot,
+                                         unsigned* __restrict__ mtile = nullptr, const float* __restrict__ wsig = nullptr,
+                                         float* __restrict__ sp = nullptr)
 {
+    unsigned m = 0;
+    float part = 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int b = 2 * c.w + i;
         float v[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            v[r] = RELU ? fmaxf(acc[i][r], 0.f) : acc[i][r];
+            v[r] = RELU ? n_relu(acc[i][r]) : acc[i][r];
             act[(32 * b + (r & 3) + 8 * (r >> 2) + 4 * c.h) * 32 + c.j] = v[r];
+            if (SAVE && RELU) n_mask_push(m, acc[i][r]);              // value 16 i + r -> bit 31 - (16 i + r)
+            if (SIG) part += v[r] * wsig[(i * 16 + r) * 2];            // wsig: the LDS table + 64 w + h
         }
-        if (SAVE && row_ok) {
+        if (SAVE && sv.ok) {
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq) {
                 f32x4 o = {v[4 * rq], v[4 * rq + 1], v[4 * rq + 2], v[4 * rq + 3]};
-                *(f32x4*)(save_row + 32 * b + 8 * rq + 4 * c.h) = o;
+                n_save4(sv, slot * 1024, i * 128 + rq * 32, o);        // row + 256 slot + 32 b + 8 rq + 4 h
             }
         }
     }
+    if (SAVE && RELU && mtile) mtile[slot * 256 + c.w * 64 + c.lane] = m;
+    if (SIG) sp[c.w * 64 + c.lane] = part;
 }
 
+#define NN_HEADS (4 * 64 + 12 * 64 + 512 + 384)     // floats behind the two images: sigma partials [wave][lane], rgb partials [wave][channel][lane],
+                                                    // the head weights w_sigma [256][2], w_rgb [3][64][2] (per-lane reads: + half)
+#define NF_AMASK_SLOTS 10                  // mask words per (tile, wave, lane): activation slots 0..7 (h1..h8) and 9 (view branch); 8 unused
+
 template <bool SAVE, int QX, int QD>
-__global__ void __launch_bounds__(256) k_mlp_fwd_n(NfMlpLayout L, const float* __restrict__ packed, const float* __restrict__ X,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_mlp_fwd_n(NfMlpLayout L, const float* __restrict__ packed, const float* __restrict__ X,
                                                    const int* __restrict__ n_rows, int max_rows,
                                                    const int* __restrict__ row_sample, float4* __restrict__ rgbsigma,
-                                                   float* __restrict__ acts)
+                                                   float* __restrict__ acts, unsigned* __restrict__ amask)
 {
-    extern __shared__ float nlds[];        // act image A, act image B
+    extern __shared__ float nlds[];        // act image A, act image B, head partials
     float* actA = nlds;
     float* actB = nlds + NN_ACT;
+    float* sp = nlds + 2 * NN_ACT;         // [4][64] sigma partials
+    float* rp = sp + 4 * 64;               // [4][3][64] rgb partials
+    float* hw = rp + 12 * 64;              // head weights
     NCtx c;
     c.lane = threadIdx.x & 63; c.h = c.lane >> 5; c.j = c.lane & 31; c.w = threadIdx.x >> 6; c.g = c.w >> 1; c.c0 = 2 * (c.w & 1);
     const int nrows = min(*n_rows, max_rows);
     const int ntiles = (nrows + 31) >> 5;
     constexpr int Q = QX + QD;
+    for (int i = threadIdx.x; i < 512 + 384; i += 256) hw[i] = i < 512 ? packed[L.off_wsig + i] : packed[L.off_wrgb + i - 512];
+    __syncthreads();
+    const float* hw_sig = hw + 64 * c.w + c.h;             // this wave's two blocks of w_sigma, this lane's half
+    const float* hw_rgb = hw + 512 + 32 * c.w + c.h;       // this wave's block of w_rgb (channel stride 128)
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int z0 = opaque_zero();
         const float* __restrict__ pk = packed + z0;
@@ -184,53 +268,76 @@ __global__ void __launch_bounds__(256) k_mlp_fwd_n(NfMlpLayout L, const float* _
         const f32x4* xt = (const f32x4*)X + (size_t)tile * Q * 64 + c.lane;
         const int row = tile * 32 + c.j;
         const bool row_ok = row < nrows;
-        float* arow = SAVE ? acts + (size_t)(row_ok ? row : 0) * NF_ACT_STRIDE : nullptr;
+        NSave sv;
+        sv.ok = SAVE && row_ok;
+        sv.voff = (unsigned)c.j * (unsigned)(NF_ACT_STRIDE * 4) + (unsigned)c.w * 256u + (unsigned)c.h * 16u;
+        sv.rs = __builtin_amdgcn_make_buffer_rsrc(SAVE ? (void*)(acts + (size_t)tile * 32 * NF_ACT_STRIDE) : (void*)packed, 0,
+                                                  32 * NF_ACT_STRIDE * 4, 0x27000);
+        unsigned* mtile = (SAVE && amask) ? amask + (size_t)tile * NF_AMASK_SLOTS * 256 : nullptr;     // [slot][wave][lane]
         f32x16 acc[2];
         f32x4 xdir[QD];         // the view-direction feature groups, requested now, used ~100 us later
+        NT_DECL;
 #pragma unroll
         for (int q = 0; q < QD; ++q) xdir[q] = xt[(QX + q) * 64];
 
         // layer 0 = xyz_encoding_1 -> h1 in A
-        n_bias2(c, P4 + (L.off_bstep[0] >> 2), acc);
+        n_bias2(n_bias_load(c, P4 + (L.off_bstep[0] >> 2)), acc);
         n_xpart2<QX>(c, wr_, L.off_x[0] * 4 + z0, xt, acc);
-        n_store2<true, SAVE>(c, acc, actA, arow, row_ok);
+        NT_MARK(0);
+        f32x2 bnext = n_bias_load(c, P4 + (L.off_bstep[1] >> 2));
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef NN_PREFETCH
+        f32x4 pre[NH_DEPTH];
+        n_hpre(c, wr_, L.off_h[1] * 4 + z0, pre);
+#endif
+        n_store2<true, SAVE>(c, acc, actA, sv, 0, mtile);
+        NT_MARK(1);
         __syncthreads();
+        NT_MARK(2);
         float* cur = actA;
         float* nxt = actB;
         float sigma = 0.f;
+        float bdir = 0.f;
 #pragma unroll 1
         for (int l = 1; l < 9; ++l) {
-            n_bias2(c, P4 + (L.off_bstep[l] >> 2), acc);
+            n_bias2(bnext, acc);
             if (L.off_x[l] >= 0) n_xpart2<QX>(c, wr_, L.off_x[l] * 4 + z0, xt, acc);
+            NT_MARK(3);
+#ifdef NN_PREFETCH
+            n_hpart2<128, true>(c, wr_, L.off_h[l] * 4 + z0, cur, acc, pre);
+            if (l < 8) n_hpre(c, wr_, L.off_h[l + 1] * 4 + z0, pre);
+#else
             n_hpart2(c, wr_, L.off_h[l] * 4 + z0, cur, acc);
+#endif
+            NT_MARK(4);
+            // the next layer's bias operand (the view branch's after the last layer), ahead of this layer's epilogue + barrier
+            if (l < 8) bnext = n_bias_load(c, P4 + (L.off_bstep[l + 1] >> 2));
+            else bdir = ((const float*)(P4 + (L.off_bstep_dir >> 2) + c.lane))[c.w];
+            __builtin_amdgcn_sched_barrier(0);
             if (l == 8) {
-                // `cur` holds h8: the sigma head, by wave 0, in k_mlp_fwd's order (its lanes sum their own 128 features)
+                // the sigma head: the four waves' partials over h8 (left in sp by layer 7's epilogue, behind its barrier)
                 if (c.w == 0) {
-                    const float* ws_ = pk + L.off_wsig;
-                    float part = 0.f;
-#pragma unroll
-                    for (int b = 0; b < 8; ++b)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const float w0 = ws_[(b * 16 + r) * 2], w1 = ws_[(b * 16 + r) * 2 + 1];
-                            part += cur[(32 * b + (r & 3) + 8 * (r >> 2) + 4 * c.h) * 32 + c.j] * (c.h ? w1 : w0);
-                        }
+                    const float part = ((sp[c.lane] + sp[64 + c.lane]) + sp[128 + c.lane]) + sp[192 + c.lane];
                     sigma = part + __shfl_xor(part, 32, 64) + pk[L.off_bsig];
                 }
-                n_store2<false, SAVE>(c, acc, nxt, SAVE ? arow + 8 * 256 : nullptr, row_ok);      // xyz_encoding_final: no activation
+                NT_MARK(5);
+                n_store2<false, SAVE>(c, acc, nxt, sv, 8);      // xyz_encoding_final: no activation
+            } else if (l == 7) {
+                n_store2<true, SAVE, true>(c, acc, nxt, sv, l, mtile, hw_sig, sp);    // h8
             } else {
-                n_store2<true, SAVE>(c, acc, nxt, SAVE ? arow + l * 256 : nullptr, row_ok);        // h_{l+1}
+                n_store2<true, SAVE>(c, acc, nxt, sv, l, mtile);        // h_{l+1}
             }
+            NT_MARK(6);
             __syncthreads();
+            NT_MARK(7);
             float* t = cur; cur = nxt; nxt = t;
         }
         // view branch: hd = relu(W_dir [final | dir feats] + b), one block per wave; `cur` holds final
         f32x16 hd;
         {
             const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            const f32x4* pb = P4 + (L.off_bstep_dir >> 2) + c.lane;
-            hd = MFMA32(((const float*)pb)[c.w], 1.f, z);
-            const unsigned voff = (unsigned)(c.w * 64 + c.lane) * 16u;               // N layout: [group of 4 steps][wave][64] x 16 B
+            hd = MFMA32(bdir, 1.f, z);
+            const unsigned voff = (unsigned)(c.w * 64 + c.lane) * 16u;               // N layout: [group of 4 steps][wave = block][64] x 16 B
 #pragma unroll
             for (int q = 0; q < QD; ++q) {
                 const f32x4 wv = n_wload(wr_, voff, L.off_dir_x * 4 + z0 + q * 4096);
@@ -248,35 +355,42 @@ __global__ void __launch_bounds__(256) k_mlp_fwd_n(NfMlpLayout L, const float* _
                 }
             }
         }
+        NT_MARK(8);
         {
+            // epilogue of the view branch: the wave's block of hd -> saved activations + mask word, and its share of the rgb head
+            // (three partial sums over its 32 features' lane halves -> rp; wave 0 adds the four waves' partials behind the barrier).
+            // k_mlp_fwd sums a head's 128 / 256 products in ONE chain per lane; here four chains of a quarter each: rgb / sigma agree
+            // with it to the last bits, not bit for bit (the hidden activations still do).
             float v[16];
+            unsigned m = 0;
+            float c0 = 0.f, c1 = 0.f, c2 = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                v[r] = fmaxf(hd[r], 0.f);
-                nxt[(32 * c.w + (r & 3) + 8 * (r >> 2) + 4 * c.h) * 32 + c.j] = v[r];
+                v[r] = n_relu(hd[r]);
+                if (SAVE) n_mask_push(m, hd[r]);                       // value r -> bit 15 - r
+                c0 += v[r] * hw_rgb[2 * r];
+                c1 += v[r] * hw_rgb[128 + 2 * r];
+                c2 += v[r] * hw_rgb[256 + 2 * r];
             }
-            if (SAVE && row_ok) {
+            rp[(c.w * 3 + 0) * 64 + c.lane] = c0;
+            rp[(c.w * 3 + 1) * 64 + c.lane] = c1;
+            rp[(c.w * 3 + 2) * 64 + c.lane] = c2;
+            if (SAVE && sv.ok) {
 #pragma unroll
                 for (int rq = 0; rq < 4; ++rq) {
                     f32x4 o = {v[4 * rq], v[4 * rq + 1], v[4 * rq + 2], v[4 * rq + 3]};
-                    *(f32x4*)(arow + 9 * 256 + 32 * c.w + 8 * rq + 4 * c.h) = o;
+                    n_save4(sv, 9 * 1024, rq * 32 - (int)c.w * 128, o);        // block w of slot 9: 32 w, not the 64 w of the vector offset
                 }
             }
+            if (SAVE && mtile) mtile[9 * 256 + c.w * 64 + c.lane] = m;
         }
+        NT_MARK(9);
         __syncthreads();
+        NT_MARK(10);
         if (c.w == 0) {
-            const float* wr = pk + L.off_wrgb;
-            float c0 = 0.f, c1 = 0.f, c2 = 0.f;
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float v = nxt[(32 * b + (r & 3) + 8 * (r >> 2) + 4 * c.h) * 32 + c.j];
-                    const int k = (b * 16 + r) * 2;
-                    c0 += v * (c.h ? wr[k + 1] : wr[k]);
-                    c1 += v * (c.h ? wr[128 + k + 1] : wr[128 + k]);
-                    c2 += v * (c.h ? wr[256 + k + 1] : wr[256 + k]);
-                }
+            float c0 = ((rp[c.lane] + rp[192 + c.lane]) + rp[384 + c.lane]) + rp[576 + c.lane];
+            float c1 = ((rp[64 + c.lane] + rp[256 + c.lane]) + rp[448 + c.lane]) + rp[640 + c.lane];
+            float c2 = ((rp[128 + c.lane] + rp[320 + c.lane]) + rp[512 + c.lane]) + rp[704 + c.lane];
             c0 += __shfl_xor(c0, 32, 64); c1 += __shfl_xor(c1, 32, 64); c2 += __shfl_xor(c2, 32, 64);
             c0 += pk[L.off_brgb]; c1 += pk[L.off_brgb + 1]; c2 += pk[L.off_brgb + 2];
             if (c.h == 0 && row_ok) {
@@ -285,7 +399,10 @@ __global__ void __launch_bounds__(256) k_mlp_fwd_n(NfMlpLayout L, const float* _
                 rgbsigma[row_sample[row]] = o;
             }
         }
-        __syncthreads();        // the images are rewritten by the next tile
+        NT_MARK(11);
+        __syncthreads();        // the images and the partials are rewritten by the next tile
+        NT_MARK(12);
+        NT_FLUSH(0);
     }
 }
 
@@ -342,9 +459,10 @@ extern "C" int nf_nerf_pack_bwd_n(const float* packed_t, float* packed_tn, nf_st
 // Why: one wave per tile for ~0.45 ms makes a launch cost ceil(tiles / 1024) rounds whatever the fill of the last one — the
 // fine pass of a 4 x 1024-ray training step (2 250 tiles) paid three rounds for 2.2, its coarse pass (220 tiles) a whole round.
 // ================================================================================================
-template <int MODE>
+// BITS: the ReLU masks come from the forward kernel's mask word (bit 16 i + r of `mbits`) instead of the saved activations
+template <int MODE, bool BITS = false>
 __device__ __forceinline__ void n_bwd_slot(const NCtx& c, const f32x16 (&raw)[2], const float* __restrict__ hrow, const float* __restrict__ wsig,
-                                           float dsig, float* __restrict__ img, float* __restrict__ save_row, bool row_ok)
+                                           float dsig, float* __restrict__ img, float* __restrict__ save_row, bool row_ok, unsigned mbits = 0)
 {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -353,13 +471,16 @@ __device__ __forceinline__ void n_bwd_slot(const NCtx& c, const f32x16 (&raw)[2]
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
             f32x4 hv = {1.f, 1.f, 1.f, 1.f};
-            if (MODE != 0) hv = *(const f32x4*)(hrow + 32 * b + 8 * rq + 4 * c.h);
+            if (MODE != 0 && !BITS) hv = *(const f32x4*)(hrow + 32 * b + 8 * rq + 4 * c.h);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int r = 4 * rq + e;
                 float x = raw[i][r];
                 if (MODE == 2) x += dsig * (c.h ? wsig[(b * 16 + r) * 2 + 1] : wsig[(b * 16 + r) * 2]);
-                if (MODE != 0) x = hv[e] > 0.f ? x : 0.f;
+                if (MODE != 0) {
+                    if (BITS) x = __builtin_bit_cast(float, __builtin_bit_cast(int, x) & ((int)(mbits << (16 * i + r)) >> 31));    // bit 31 - (16 i + r)
+                    else x = hv[e] > 0.f ? x : 0.f;
+                }
                 v[r] = x;
                 if (img) img[(32 * b + (r & 3) + 8 * (r >> 2) + 4 * c.h) * 32 + c.j] = x;
             }
@@ -382,8 +503,10 @@ __device__ __forceinline__ void n_zero2(f32x16 (&acc)[2])
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 }
 
-__global__ void __launch_bounds__(256) k_mlp_bwd_n(NfMlpLayout L, NfMlpLayoutT T, const float* __restrict__ packed,
+template <bool BITS>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_mlp_bwd_n(NfMlpLayout L, NfMlpLayoutT T, const float* __restrict__ packed,
                                                    const float* __restrict__ packed_t, const float* __restrict__ acts,
+                                                   const unsigned* __restrict__ amask,
                                                    const int* __restrict__ n_rows, int max_rows, const int* __restrict__ row_sample,
                                                    const float4* __restrict__ rgbsigma, const float4* __restrict__ d_rgbsigma,
                                                    float* __restrict__ dpre)
@@ -401,9 +524,15 @@ __global__ void __launch_bounds__(256) k_mlp_bwd_n(NfMlpLayout L, NfMlpLayoutT T
         const __amdgpu_buffer_rsrc_t wt_ = __builtin_amdgcn_make_buffer_rsrc((void*)packed_t, 0, T.total * 4, 0x27000);
         const int row = tile * 32 + c.j;
         const bool valid = row < nrows;
-        const float* arow = acts + (size_t)(valid ? row : 0) * NF_ACT_STRIDE;
+        const float* arow = BITS ? nullptr : acts + (size_t)(valid ? row : 0) * NF_ACT_STRIDE;
         float* drow = dpre + (size_t)(valid ? row : 0) * NF_DPRE_STRIDE;
+        // BITS: the ReLU masks of this wave's blocks, one dword per layer (nf_nerf_mlp_fwd_n2 wrote them): the view branch's now, a
+        // layer's in front of the K loop that precedes its use — k_mlp_bwd_n without them fetched 128 B of saved activations per lane
+        // (HBM) at every slot, with nothing to do until they arrived: as long as the MFMAs of the layer (179 k of 413 k cycles per tile)
+        const unsigned* mrow = BITS ? amask + ((size_t)tile * NF_AMASK_SLOTS * 4 + c.w) * 64 + c.lane : nullptr;
+        unsigned mcur = BITS ? mrow[9 * 256] : 0u;
         float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f), g4 = o4;
+        NT_DECL;
         if (valid) {
             const int sample = row_sample[row];
             o4 = rgbsigma[sample];
@@ -420,13 +549,14 @@ __global__ void __launch_bounds__(256) k_mlp_bwd_n(NfMlpLayout L, NfMlpLayoutT T
             float v[16];
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq) {
-                const f32x4 hv = *(const f32x4*)(arow + 9 * 256 + 32 * b + 8 * rq + 4 * c.h);
+                f32x4 hv = {1.f, 1.f, 1.f, 1.f};
+                if (!BITS) hv = *(const f32x4*)(arow + 9 * 256 + 32 * b + 8 * rq + 4 * c.h);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * rq + e, k = (b * 16 + r) * 2;
                     const float x = dz0 * (c.h ? wr[k + 1] : wr[k]) + dz1 * (c.h ? wr[128 + k + 1] : wr[128 + k]) +
                                     dz2 * (c.h ? wr[256 + k + 1] : wr[256 + k]);
-                    v[r] = hv[e] > 0.f ? x : 0.f;
+                    v[r] = BITS ? __builtin_bit_cast(float, __builtin_bit_cast(int, x) & ((int)(mcur << (16 + r)) >> 31)) : (hv[e] > 0.f ? x : 0.f);
                     cur[(32 * b + (r & 3) + 8 * (r >> 2) + 4 * c.h) * 32 + c.j] = v[r];
                 }
             }
@@ -438,33 +568,58 @@ __global__ void __launch_bounds__(256) k_mlp_bwd_n(NfMlpLayout L, NfMlpLayoutT T
                 }
             }
         }
+        NT_MARK(0);
+#ifdef NN_PREFETCH
+        f32x4 pre[NH_DEPTH];
+        n_hpre(c, wt_, T.off_dir * 4 + z0, pre);
+#endif
         __syncthreads();
+        NT_MARK(1);
         // raw d(final) = W_dir[:, :256]^T slot 9: 64 K-steps over the 128 hidden units
         f32x16 acc[2];
         n_zero2(acc);
+#ifdef NN_PREFETCH
+        n_hpart2<64, true>(c, wt_, T.off_dir * 4 + z0, cur, acc, pre);
+#else
         n_hpart2<64>(c, wt_, T.off_dir * 4 + z0, cur, acc);
+#endif
+        NT_MARK(2);
         const float* ws_ = pk + L.off_wsig;
 #pragma unroll 1
         for (int g = 8; g >= 1; --g) {
-            if (g == 8) n_bwd_slot<0>(c, acc, nullptr, ws_, dsig, nxt, drow + 8 * 256, valid);
-            else if (g == 7) n_bwd_slot<2>(c, acc, arow + 7 * 256, ws_, dsig, nxt, drow + 7 * 256, valid);
-            else n_bwd_slot<1>(c, acc, arow + g * 256, ws_, dsig, nxt, drow + g * 256, valid);
+#ifdef NN_PREFETCH
+            n_hpre(c, wt_, T.off_h[g] * 4 + z0, pre);
+#endif
+            if (g == 8) n_bwd_slot<0, BITS>(c, acc, nullptr, ws_, dsig, nxt, drow + 8 * 256, valid);
+            else if (g == 7) n_bwd_slot<2, BITS>(c, acc, arow + 7 * 256, ws_, dsig, nxt, drow + 7 * 256, valid, mcur);
+            else n_bwd_slot<1, BITS>(c, acc, arow + g * 256, ws_, dsig, nxt, drow + g * 256, valid, mcur);
+            NT_MARK(3);
             __syncthreads();
+            NT_MARK(4);
             float* t = cur; cur = nxt; nxt = t;
+            if (BITS) mcur = mrow[(g - 1) * 256];           // the next slot's masks (slot g - 1; slot 0 after the loop)
             n_zero2(acc);
+#ifdef NN_PREFETCH
+            n_hpart2<128, true>(c, wt_, T.off_h[g] * 4 + z0, cur, acc, pre);
+#else
             n_hpart2<128>(c, wt_, T.off_h[g] * 4 + z0, cur, acc);
+#endif
+            NT_MARK(5);
         }
         // slot 0 = [h1 > 0] d_h1
-        n_bwd_slot<1>(c, acc, arow, ws_, dsig, nullptr, drow, valid);
+        n_bwd_slot<1, BITS>(c, acc, arow, ws_, dsig, nullptr, drow, valid, mcur);
+        NT_MARK(6);
         __syncthreads();        // the images are rewritten by the next tile
+        NT_MARK(7);
+        NT_FLUSH(1);
     }
 }
 
-extern "C" int nf_nerf_mlp_bwd_n(const float* packed, const float* packed_t, int cx, int cd, const float* acts,
-                                 const int32_t* n_rows, int max_rows, const int32_t* row_sample, const float* rgbsigma,
-                                 const float* d_rgbsigma, float* dpre, nf_stream_t stream)
+static int mlp_bwd_n_launch(const float* packed, const float* packed_t, int cx, int cd, const float* acts, const uint32_t* amask,
+                            const int32_t* n_rows, int max_rows, const int32_t* row_sample, const float* rgbsigma,
+                            const float* d_rgbsigma, float* dpre, nf_stream_t stream)
 {
-    NF_CHECK_ARG(packed && packed_t && acts && n_rows && row_sample && rgbsigma && d_rgbsigma && dpre, "null pointer");
+    NF_CHECK_ARG(packed && packed_t && (acts || amask) && n_rows && row_sample && rgbsigma && d_rgbsigma && dpre, "null pointer");
     NF_CHECK_ARG(cx >= 1 && cx <= 256 && cd >= 1 && cd <= 256, "bad channel counts");
     if (max_rows <= 0) return NF_OK;
     NfMlpLayout L = mlp_layout(cx, cd);
@@ -472,16 +627,40 @@ extern "C" int nf_nerf_mlp_bwd_n(const float* packed, const float* packed_t, int
     const int tiles = (max_rows + 31) / 32;
     const size_t lds = (size_t)(2 * NN_ACT) * sizeof(float);       // 64 KB: two workgroups per CU
     static bool attr_set[64] = {};
-    if (nf_first_use_on_device(attr_set))
-        hipFuncSetAttribute((const void*)k_mlp_bwd_n, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL(k_mlp_bwd_n, dim3(tiles), dim3(256), lds, (hipStream_t)stream, L, T, packed, packed_t, acts, n_rows, max_rows,
-                       row_sample, (const float4*)rgbsigma, (const float4*)d_rgbsigma, dpre);
+    if (nf_first_use_on_device(attr_set)) {
+        hipFuncSetAttribute((const void*)k_mlp_bwd_n<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)k_mlp_bwd_n<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
+    if (amask)
+        hipLaunchKernelGGL(k_mlp_bwd_n<true>, dim3(tiles), dim3(256), lds, (hipStream_t)stream, L, T, packed, packed_t, acts, amask, n_rows,
+                           max_rows, row_sample, (const float4*)rgbsigma, (const float4*)d_rgbsigma, dpre);
+    else
+        hipLaunchKernelGGL(k_mlp_bwd_n<false>, dim3(tiles), dim3(256), lds, (hipStream_t)stream, L, T, packed, packed_t, acts, amask, n_rows,
+                           max_rows, row_sample, (const float4*)rgbsigma, (const float4*)d_rgbsigma, dpre);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }
 
-extern "C" int nf_nerf_mlp_fwd_n(const float* packed, int cx, int cd, const float* X, const int32_t* n_rows, int max_rows,
-                                 const int32_t* row_sample, float* rgbsigma, float* acts, nf_stream_t stream)
+extern "C" int nf_nerf_mlp_bwd_n(const float* packed, const float* packed_t, int cx, int cd, const float* acts,
+                                 const int32_t* n_rows, int max_rows, const int32_t* row_sample, const float* rgbsigma,
+                                 const float* d_rgbsigma, float* dpre, nf_stream_t stream)
+{
+    NF_CHECK_ARG(acts, "null pointer");
+    return mlp_bwd_n_launch(packed, packed_t, cx, cd, acts, nullptr, n_rows, max_rows, row_sample, rgbsigma, d_rgbsigma, dpre, stream);
+}
+
+extern "C" int nf_nerf_mlp_bwd_n2(const float* packed, const float* packed_t, int cx, int cd, const uint32_t* amask,
+                                  const int32_t* n_rows, int max_rows, const int32_t* row_sample, const float* rgbsigma,
+                                  const float* d_rgbsigma, float* dpre, nf_stream_t stream)
+{
+    NF_CHECK_ARG(amask, "null pointer");
+    return mlp_bwd_n_launch(packed, packed_t, cx, cd, nullptr, amask, n_rows, max_rows, row_sample, rgbsigma, d_rgbsigma, dpre, stream);
+}
+
+extern "C" size_t nf_nerf_amask_words(int max_rows) { return (size_t)((max_rows + 31) / 32) * NF_AMASK_SLOTS * 256; }
+
+static int mlp_fwd_n_launch(const float* packed, int cx, int cd, const float* X, const int32_t* n_rows, int max_rows,
+                            const int32_t* row_sample, float* rgbsigma, float* acts, uint32_t* amask, nf_stream_t stream)
 {
     NF_CHECK_ARG(packed && X && n_rows && row_sample && rgbsigma, "null pointer");
     NF_CHECK_ARG(cx >= 1 && cx <= 256 && cd >= 1 && cd <= 256, "bad channel counts");
@@ -489,7 +668,7 @@ extern "C" int nf_nerf_mlp_fwd_n(const float* packed, int cx, int cd, const floa
     NfMlpLayout L = mlp_layout(cx, cd);
     NF_CHECK_ARG(L.qx == 25 && L.qd == 7, "built for the default 198 + 54 feature row (other encodings: nf_nerf_mlp_fwd)");
     const int tiles = (max_rows + 31) / 32;
-    const size_t lds = (size_t)(2 * NN_ACT) * sizeof(float);       // 64 KB: two workgroups per CU
+    const size_t lds = (size_t)(2 * NN_ACT + NN_HEADS) * sizeof(float);       // 68 KB: two workgroups per CU
     static bool attr_set[64] = {};
     if (nf_first_use_on_device(attr_set)) {
         hipFuncSetAttribute((const void*)k_mlp_fwd_n<true, 25, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -498,11 +677,23 @@ extern "C" int nf_nerf_mlp_fwd_n(const float* packed, int cx, int cd, const floa
     hipStream_t st = (hipStream_t)stream;
     if (acts)
         hipLaunchKernelGGL((k_mlp_fwd_n<true, 25, 7>), dim3(tiles), dim3(256), lds, st, L, packed, X, n_rows, max_rows, row_sample,
-                           (float4*)rgbsigma, acts);
+                           (float4*)rgbsigma, acts, amask);
     else
         hipLaunchKernelGGL((k_mlp_fwd_n<false, 25, 7>), dim3(tiles), dim3(256), lds, st, L, packed, X, n_rows, max_rows, row_sample,
-                           (float4*)rgbsigma, acts);
+                           (float4*)rgbsigma, acts, (uint32_t*)nullptr);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }
 
+extern "C" int nf_nerf_mlp_fwd_n(const float* packed, int cx, int cd, const float* X, const int32_t* n_rows, int max_rows,
+                                 const int32_t* row_sample, float* rgbsigma, float* acts, nf_stream_t stream)
+{
+    return mlp_fwd_n_launch(packed, cx, cd, X, n_rows, max_rows, row_sample, rgbsigma, acts, nullptr, stream);
+}
+
+extern "C" int nf_nerf_mlp_fwd_n2(const float* packed, int cx, int cd, const float* X, const int32_t* n_rows, int max_rows,
+                                  const int32_t* row_sample, float* rgbsigma, float* acts, uint32_t* amask, nf_stream_t stream)
+{
+    NF_CHECK_ARG(acts && amask, "null pointer (the mask words go with saved activations)");
+    return mlp_fwd_n_launch(packed, cx, cd, X, n_rows, max_rows, row_sample, rgbsigma, acts, amask, stream);
+}

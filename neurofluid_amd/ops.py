@@ -513,6 +513,7 @@ def render_pass(grid, particles, rays, z, z_table, S, radius, K, enc_flags, use_
     x16 = packed_h is not None and not isinstance(packed_h, PackedS)      # the fp16-MFMA MLPs take fp16 operands (half the bytes)
     b.X = scratch("X", rows_alloc // 32 * (qx + qd) * (128 if x16 else 256), torch.float32)
     b.acts = torch.empty(rows_alloc * 2432, dtype=torch.float32, device=dev) if save_acts else None
+    b.amask = None          # the ReLU masks as bits (nf_nerf_mlp_fwd_n2 -> nf_nerf_mlp_bwd_n2), training forward of the default feature row
     x_tile = (qx + qd) * (128 if x16 else 256)           # floats of X per 32-row tile
     ro_per_ray = int(ro.dim() == 2)
 
@@ -543,8 +544,9 @@ def render_pass(grid, particles, rays, z, z_table, S, radius, K, enc_flags, use_
             if getattr(b, "packed_n", None) is None:        # the tile-per-workgroup kernels' own arrangement of the blob
                 b.packed_n = torch.empty_like(packed)
                 check(lib.nf_nerf_pack_n(ptr(packed), cx, cd, ptr(b.packed_n), stream_), "nf_nerf_pack_n")
-            check(lib.nf_nerf_mlp_fwd_n(ptr(b.packed_n), cx, cd, X_, ptr(nrows_t), mx, rs_, ptr(b.rgbsigma), ptr(b.acts), stream_),
-                  "nf_nerf_mlp_fwd_n")
+            b.amask = torch.empty(lib.nf_nerf_amask_words(rows_alloc), dtype=torch.int32, device=dev)
+            check(lib.nf_nerf_mlp_fwd_n2(ptr(b.packed_n), cx, cd, X_, ptr(nrows_t), mx, rs_, ptr(b.rgbsigma), ptr(b.acts), ptr(b.amask), stream_),
+                  "nf_nerf_mlp_fwd_n2")
         else:
             check(lib.nf_nerf_mlp_fwd(ptr(packed), cx, cd, X_, ptr(nrows_t), mx, rs_, ptr(b.rgbsigma), ptr(b.acts), stream_),
                   "nf_nerf_mlp_fwd")

@@ -1499,8 +1499,11 @@ def test_grid_bbox_hint_and_weight_cache_do_not_change_results(dev):
 
 def test_mlp_tile_per_workgroup_bit_equal(dev):
     """nf_nerf_mlp_fwd_n (nf_mlp_n.hip: a 32-row tile per workgroup, a layer's output blocks split over its 4 waves, activations
-    through an LDS image) against nf_nerf_mlp_fwd (a tile per wave): rgbsigma and the saved activations bit for bit, at row
-    counts around the tile / workgroup boundaries, with a permuted row_sample, and fewer rows than max_rows."""
+    through an LDS image) against nf_nerf_mlp_fwd (a tile per wave): the saved activations bit for bit, at row counts around the
+    tile / workgroup boundaries, with a permuted row_sample, and fewer rows than max_rows.  rgbsigma: round 6 sums the two heads as
+    four partial chains (one per wave) instead of one chain per lane, so sigma / rgb agree to the last bits (2e-6 relative to the
+    head's magnitude), identically with and without saved activations — and bit for bit with the mask-writing entry point
+    nf_nerf_mlp_fwd_n2, whose mask words must be exactly the signs of the saved activations."""
     from neurofluid_amd import _lib, ops
     from oracle import render_oracle as ro
     lib = _lib.load()
@@ -1523,10 +1526,77 @@ def test_mlp_tile_per_workgroup_bit_equal(dev):
                 _lib.check(fn(blob.data_ptr(), 198, 54, X.data_ptr(), n_rows.data_ptr(), n, row_sample.data_ptr(), out.data_ptr(),
                               acts.data_ptr() if save else None, _lib.stream()))
                 outs.append((out, acts[:live * 2432] if save else None))
-        assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[1][0], outs[3][0]) and torch.equal(outs[0][0], outs[1][0])
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[2][0], outs[3][0])
         assert torch.equal(outs[1][1], outs[3][1])
         touched = (outs[2][0] != -7.0).any(dim=1)
         assert int(touched.sum()) == live           # exactly the live rows' samples were written
+        a, b = outs[0][0][touched], outs[2][0][touched]
+        assert float((a[:, :3] - b[:, :3]).abs().max()) < 2e-6                                        # sigmoid outputs in (0, 1)
+        assert float((a[:, 3] - b[:, 3]).abs().max()) <= 2e-6 * max(1.0, float(a[:, 3].abs().max()))
+        # the mask-writing entry point: same outputs, and bit 31 - (16 i + r) of word [tile][slot][wave][lane] = [activation > 0]
+        out2 = torch.full((n, 4), -7.0, device=dev)
+        acts2 = torch.full(((n + 31) // 32 * 32 * 2432,), -7.0, device=dev)
+        amask = torch.zeros(lib.nf_nerf_amask_words(n), dtype=torch.int32, device=dev)
+        _lib.check(lib.nf_nerf_mlp_fwd_n2(packed_n.data_ptr(), 198, 54, X.data_ptr(), n_rows.data_ptr(), n, row_sample.data_ptr(), out2.data_ptr(),
+                                          acts2.data_ptr(), amask.data_ptr(), _lib.stream()))
+        assert torch.equal(out2, outs[3][0]) and torch.equal(acts2[:live * 2432], outs[3][1])
+        T = (live + 31) // 32
+        A = torch.zeros(T * 32, 2432, device=dev)
+        A[:live] = acts2[:live * 2432].view(live, 2432)
+        mw = amask.view(-1, 10, 4, 2, 32)[:T].to(torch.int64) & 0xFFFFFFFF                            # [tile][slot][wave][half][row in tile]
+        r = torch.arange(16, device=dev)
+        for slot in list(range(8)) + [9]:
+            nblk = 1 if slot == 9 else 2
+            for i in range(nblk):
+                bits = (mw[:, slot, :, :, :, None] >> ((15 if slot == 9 else 31 - 16 * i) - r)) & 1        # [tile][wave][half][row][r]
+                wv = torch.arange(4, device=dev)[None, :, None, None, None]
+                hf = torch.arange(2, device=dev)[None, None, :, None, None]
+                feat = 32 * ((wv if slot == 9 else 2 * wv + i)) + (r & 3) + 8 * (r >> 2) + 4 * hf      # [1][wave][half][1][r]
+                rows = (torch.arange(T, device=dev)[:, None, None, None, None] * 32 + torch.arange(32, device=dev)[None, None, None, :, None])
+                want = A[rows.expand(T, 4, 2, 32, 16), (slot * 256 + feat).expand(T, 4, 2, 32, 16)] > 0
+                live_rows = (rows < live).expand(T, 4, 2, 32, 16)
+                assert torch.equal(bits.bool()[live_rows], want[live_rows]), (n, live, slot, i)
+
+
+def test_mlp_backward_from_mask_words_bit_equal(dev):
+    """nf_nerf_mlp_bwd_n2 (ReLU masks from nf_nerf_mlp_fwd_n2's mask words) against nf_nerf_mlp_bwd_n (masks from the saved activations):
+    the same dpre, bit for bit, at row counts around the tile boundaries."""
+    import ctypes
+    from neurofluid_amd import _lib, ops
+    from oracle import render_oracle as ro
+    lib = _lib.load()
+    st = ro.deterministic_nerf_state()
+    W = [st[f"nerf_fine.{k}.weight"].to(dev) for k in ops.NERF_LAYER_NAMES]
+    B = [st[f"nerf_fine.{k}.bias"].to(dev) for k in ops.NERF_LAYER_NAMES]
+    packed = ops.pack_nerf(W, B, 198, 54)
+    packed_n = ops.pack_nerf_n(packed, 198, 54)
+    packed_t = torch.empty(lib.nf_nerf_packed_bwd_floats(), device=dev)
+    P = _lib.NerfParams()
+    for i in range(12):
+        P.w[i], P.b[i] = W[i].data_ptr(), B[i].data_ptr()
+    _lib.check(lib.nf_nerf_pack_bwd(ctypes.byref(P), 198, 54, packed_t.data_ptr(), _lib.stream()))
+    packed_tn = torch.empty_like(packed_t)
+    _lib.check(lib.nf_nerf_pack_bwd_n(packed_t.data_ptr(), packed_tn.data_ptr(), _lib.stream()))
+    g = torch.Generator().manual_seed(5)
+    for n, live in [(1, 1), (33, 33), (4096, 4096), (5000, 4321)]:
+        x = (torch.rand(n, 252, generator=g) * 2 - 1).to(dev)
+        X = ops.rows_to_tiles(x, 198, 54)
+        n_rows = torch.tensor([live], dtype=torch.int32, device=dev)
+        row_sample = torch.randperm(n, generator=g).to(torch.int32).to(dev)
+        out = torch.zeros(n, 4, device=dev)
+        acts = torch.zeros((n + 31) // 32 * 32 * 2432, device=dev)
+        amask = torch.zeros(lib.nf_nerf_amask_words(n), dtype=torch.int32, device=dev)
+        _lib.check(lib.nf_nerf_mlp_fwd_n2(packed_n.data_ptr(), 198, 54, X.data_ptr(), n_rows.data_ptr(), n, row_sample.data_ptr(), out.data_ptr(),
+                                          acts.data_ptr(), amask.data_ptr(), _lib.stream()))
+        gout = torch.randn(n, 4, generator=g).to(dev)
+        d1 = torch.full(((n + 31) // 32 * 32, 2436), -3.0, device=dev)
+        d2 = torch.full_like(d1, -3.0)
+        _lib.check(lib.nf_nerf_mlp_bwd_n(packed.data_ptr(), packed_tn.data_ptr(), 198, 54, acts.data_ptr(), n_rows.data_ptr(), n, row_sample.data_ptr(),
+                                         out.data_ptr(), gout.data_ptr(), d1.data_ptr(), _lib.stream()))
+        _lib.check(lib.nf_nerf_mlp_bwd_n2(packed.data_ptr(), packed_tn.data_ptr(), 198, 54, amask.data_ptr(), n_rows.data_ptr(), n, row_sample.data_ptr(),
+                                          out.data_ptr(), gout.data_ptr(), d2.data_ptr(), _lib.stream()))
+        assert torch.equal(d1, d2)
+        assert float(d1[:live].abs().sum()) > 0
 
 
 

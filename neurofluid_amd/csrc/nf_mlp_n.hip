@@ -26,6 +26,21 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 #define NN_ACT (256 * 32)          // floats of one activation image
+// NN_WPE = workgroups per CU = waves per SIMD.  2: two activation images per workgroup (a layer writes the image the next one reads:
+// one barrier per layer), <= 256 registers.  3 (round 6): ONE image — a layer's outputs replace its inputs behind a second barrier
+// ("everybody has read") — 40 KB of LDS and <= 168 registers per wave, so that three tiles share a CU's matrix pipes: a tile's
+// epilogues / barriers / operand latencies are covered by two other tiles instead of one, and a launch has 768 tile slots instead of
+// 512 (the coarse pass of a 4 x 1024-ray training step, ~530 tiles, paid a second round for its last 20).
+#ifndef NN_WPE_F
+#define NN_WPE_F 3               // forward kernel
+#endif
+#ifndef NN_WPE_B
+#define NN_WPE_B 4               // backward kernel (<= 128 registers since its head weights come from an LDS table; 4 x 35.5 KB of LDS)
+#endif
+#ifndef NN_IMGS_F
+#define NN_IMGS_F (NN_WPE_F >= 3 ? 1 : 2)
+#endif
+#define NN_IMGS_B (NN_WPE_B >= 3 ? 1 : 2)
 // Weight operands are fetched with buffer loads: resource = the blob (scalar registers), scalar offset = part + K-step pair,
 // vector offset = the lane's constant 16-B slot.  A global load from a per-lane 64-bit pointer paid two vector adds per load
 // (the pair stride of 4 KB does not fit the instruction's immediate) — on the ALUs the fp32 MFMA runs on.
@@ -38,22 +53,34 @@ __device__ __forceinline__ f32x4 n_wload(__amdgpu_buffer_rsrc_t r, unsigned voff
 // lane for every store of the tile (row j x pitch + the wave's and the half's share of a 256-feature slot), the slot as the scalar
 // offset, block / quad as the immediate.  Per-lane 64-bit pointers (one per store site) had the forward kernel at 85 spilled registers.
 struct NSave { __amdgpu_buffer_rsrc_t rs; unsigned voff; bool ok; };
+// The slot's offset goes into the VECTOR offset (one v_add per epilogue), the scalar offset is the literal 0.  With the slot in an
+// SGPR soffset the compiler scheduled `buffer_store_dwordx4 v[0:3], ..., s85 offen` / `v_or_b32 v0, 64, v149` back to back: LLVM's
+// hazard recogniser holds that a store of more than 64 bits whose soffset is a REGISTER reads its data early enough for the next
+// VALU to overwrite it (GCNHazardRecognizer::createsVALUHazard), and on gfx950 that is not so — the saved activations came back
+// with the next store's address in their first dword, in lanes 12-15 of every 16, a few hundred elements per launch, run-dependent.
+// Without a register soffset the compiler inserts the wait state itself.
+__device__ __forceinline__ void n_save4(const NSave& sv, int slot_bytes, int imm_bytes, f32x4 v)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(n_u32x4, v), sv.rs, (int)sv.voff + slot_bytes + imm_bytes, 0, 0);
+}
 // mask word, one value at a time: m = 2 m + [x > 0] as v_cmp + v_addc (two vector instructions per value; beside a co-resident
-// workgroup's fp32 MFMAs every vector instruction costs matrix time).  After n values, value k sits at bit n - 1 - k.
-// relu as ONE v_max_f32: fmaxf(x, 0) compiles to a canonicalising v_max x, x in front of it (same value for every non-NaN x)
+// workgroup's fp32 MFMAs every vector instruction costs matrix time; the compiler's own selection of the C expression is v_cmp,
+// v_cndmask, v_or3, v_lshl with s_nops).  After n values, value k sits at bit n - 1 - k.  relu as ONE v_max_f32: fmaxf(x, 0) — and
+// __builtin_amdgcn_fmed3f(x, 0, inf) — compile to a canonicalising v_max x, x in front of the v_max (same value for every non-NaN x).
+// HAZARD: an asm statement that reads an MFMA's result registers is invisible to the compiler's hazard recogniser — no s_nop in front
+// of it when it comes first behind the MFMA (the first version of this file stored accumulator garbage into the saved activations as
+// soon as the register allocator scheduled such a read first).  Every epilogue therefore starts with N_MFMA_DRAIN (18 wait states: a
+// 16-pass MFMA's results are readable), and these statements are volatile, so they stay behind it.
+#define N_MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 3")
 __device__ __forceinline__ float n_relu(float x)
 {
     float y;
-    asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
+    asm volatile("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
     return y;
 }
 __device__ __forceinline__ void n_mask_push(unsigned& m, float x)
 {
-    asm("v_cmp_gt_f32 vcc, %1, 0\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(x) : "vcc");
-}
-__device__ __forceinline__ void n_save4(const NSave& sv, int soff_bytes, int imm_bytes, f32x4 v)
-{
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(n_u32x4, v), sv.rs, (int)sv.voff + imm_bytes, soff_bytes, 0);
+    asm volatile("v_cmp_gt_f32 vcc, %1, 0\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(x) : "vcc");
 }
 #ifndef NH_DEPTH
 #define NH_DEPTH 4               // read-ahead of the hidden parts' K loops, in K-step pairs
@@ -70,16 +97,22 @@ struct NCtx {
 // differences (shader cycles) to nf_n_prof[kernel][wave][phase]; read / reset through nf_dev_n_prof (tools/n_timing.py).
 #ifdef NF_N_TIMING
 __device__ unsigned long long nf_n_prof[2][4][16];
+__device__ unsigned long long nf_n_trace[2][4096][2];        // [kernel][tile] = {start, end} (s_memtime) of the last launch
 #define NT_DECL unsigned long long nt_t = __builtin_amdgcn_s_memtime(), nt_acc[16] = {}
 #define NT_MARK(ph) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 0" ::: "memory"); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
                          nt_acc[ph] += t_ - nt_t; nt_t = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
-#define NT_FLUSH(kern) do { if (c.lane == 0) { for (int p_ = 0; p_ < 15; ++p_) atomicAdd(&nf_n_prof[kern][c.w][p_], nt_acc[p_]); \
-                                               atomicAdd(&nf_n_prof[kern][c.w][15], 1ull); } } while (0)
+#define NT_FLUSH(kern) do { if (c.lane == 0) { unsigned long long tot_ = 0; for (int p_ = 0; p_ < 15; ++p_) { atomicAdd(&nf_n_prof[kern][c.w][p_], nt_acc[p_]); tot_ += nt_acc[p_]; } \
+                                               atomicAdd(&nf_n_prof[kern][c.w][15], 1ull); \
+                                               if (c.w == 0 && tile < 4096) { nf_n_trace[kern][tile][0] = nt_t - tot_; nf_n_trace[kern][tile][1] = nt_t; } } } while (0)
 extern "C" int nf_dev_n_prof(unsigned long long* out, int reset)
 {
     if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(nf_n_prof), sizeof(unsigned long long) * 128) != hipSuccess) return 1;
     if (reset) { unsigned long long z[128] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(nf_n_prof), z, sizeof(z)) != hipSuccess) return 1; }
     return 0;
+}
+extern "C" int nf_dev_n_trace(unsigned long long* out)       // out[2][4096][2]
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(nf_n_trace), sizeof(unsigned long long) * 2 * 4096 * 2) != hipSuccess;
 }
 #else
 #define NT_DECL
@@ -104,10 +137,13 @@ __device__ __forceinline__ void n_bias2(const f32x2 wv, f32x16 (&acc)[2])
 // K-steps whose B operand comes from the feature matrix (25 groups x 4 steps), read from global X both times (layer 0 and the
 // skip layer ~30 us later: 32 KB per tile that the L2 still holds; no LDS stash, so two workgroups fit a CU and each SIMD
 // has a second tile's wave to issue from while the first one waits at a layer barrier).
+// (X, too, is read with buffer loads: resource = the tile's feature groups, vector offset 16 lane, the group as the immediate)
+#define N_XLOAD(q) n_wload(xr_, xvoff, (q) * 1024)
 template <int nq>
 __device__ __forceinline__ void n_xpart2(const NCtx& c, __amdgpu_buffer_rsrc_t wr_, int poff /* part offset in bytes, N layout */,
-                                         const f32x4* __restrict__ xt /* + lane */, f32x16 (&acc)[2])
+                                         __amdgpu_buffer_rsrc_t xr_ /* the tile's X */, f32x16 (&acc)[2])
 {
+    const unsigned xvoff = (unsigned)c.lane * 16u;
     const unsigned voff = (unsigned)(c.w * 64 + c.lane) * 16u;          // pair stride: 4 KB; a group of 4 K-steps = 2 pairs
     // a group is only 4 K-steps x 2 MFMAs = 512 cycles here: X (HBM the first time, L2 the second) is requested XD groups
     // ahead, the weights (L2) two groups ahead
@@ -115,7 +151,7 @@ __device__ __forceinline__ void n_xpart2(const NCtx& c, __amdgpu_buffer_rsrc_t w
     f32x4 xr[XD];
     f32x4 wr[WD][2];
 #pragma unroll
-    for (int q = 0; q < XD; ++q) xr[q] = q < nq ? xt[q * 64] : xt[0];
+    for (int q = 0; q < XD; ++q) xr[q] = q < nq ? N_XLOAD(q) : N_XLOAD(0);
 #pragma unroll
     for (int q = 0; q < WD; ++q)
 #pragma unroll
@@ -132,7 +168,7 @@ __device__ __forceinline__ void n_xpart2(const NCtx& c, __amdgpu_buffer_rsrc_t w
         for (int k = 0; k + 1 < WD; ++k)
 #pragma unroll
             for (int i = 0; i < 2; ++i) wr[k][i] = wr[k + 1][i];
-        if (q + XD < nq) xr[XD - 1] = xt[(q + XD) * 64];
+        if (q + XD < nq) xr[XD - 1] = N_XLOAD(q + XD);
         if (q + WD < nq) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) wr[WD - 1][i] = n_wload(wr_, voff, poff + ((q + WD) * 2 + i) * 4096);
@@ -212,6 +248,7 @@ __device__ __forceinline__ void n_store2(const NCtx& c, const f32x16 (&acc)[2], 
 {
     unsigned m = 0;
     float part = 0.f;
+    N_MFMA_DRAIN();
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int b = 2 * c.w + i;
@@ -240,15 +277,15 @@ __device__ __forceinline__ void n_store2(const NCtx& c, const f32x16 (&acc)[2], 
 #define NF_AMASK_SLOTS 10                  // mask words per (tile, wave, lane): activation slots 0..7 (h1..h8) and 9 (view branch); 8 unused
 
 template <bool SAVE, int QX, int QD>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_mlp_fwd_n(NfMlpLayout L, const float* __restrict__ packed, const float* __restrict__ X,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NN_WPE_F, NN_WPE_F))) k_mlp_fwd_n(NfMlpLayout L, const float* __restrict__ packed, const float* __restrict__ X,
                                                    const int* __restrict__ n_rows, int max_rows,
                                                    const int* __restrict__ row_sample, float4* __restrict__ rgbsigma,
                                                    float* __restrict__ acts, unsigned* __restrict__ amask)
 {
     extern __shared__ float nlds[];        // act image A, act image B, head partials
     float* actA = nlds;
-    float* actB = nlds + NN_ACT;
-    float* sp = nlds + 2 * NN_ACT;         // [4][64] sigma partials
+    float* actB = nlds + (NN_IMGS_F - 1) * NN_ACT;
+    float* sp = nlds + NN_IMGS_F * NN_ACT;   // [4][64] sigma partials
     float* rp = sp + 4 * 64;               // [4][3][64] rgb partials
     float* hw = rp + 12 * 64;              // head weights
     NCtx c;
@@ -265,7 +302,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         const float* __restrict__ pk = packed + z0;
         const f32x4* P4 = (const f32x4*)pk;
         const __amdgpu_buffer_rsrc_t wr_ = __builtin_amdgcn_make_buffer_rsrc((void*)packed, 0, L.total * 4, 0x27000);
-        const f32x4* xt = (const f32x4*)X + (size_t)tile * Q * 64 + c.lane;
+        const __amdgpu_buffer_rsrc_t xr_ = __builtin_amdgcn_make_buffer_rsrc((void*)(X + (size_t)tile * Q * 256), 0, Q * 1024, 0x27000);
+        const unsigned xvoff = (unsigned)c.lane * 16u;
         const int row = tile * 32 + c.j;
         const bool row_ok = row < nrows;
         NSave sv;
@@ -275,14 +313,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                                                   32 * NF_ACT_STRIDE * 4, 0x27000);
         unsigned* mtile = (SAVE && amask) ? amask + (size_t)tile * NF_AMASK_SLOTS * 256 : nullptr;     // [slot][wave][lane]
         f32x16 acc[2];
-        f32x4 xdir[QD];         // the view-direction feature groups, requested now, used ~100 us later
+        f32x4 xdir[QD];         // the view-direction feature groups: requested in front of the last layer's K loop, used behind it
         NT_DECL;
-#pragma unroll
-        for (int q = 0; q < QD; ++q) xdir[q] = xt[(QX + q) * 64];
 
         // layer 0 = xyz_encoding_1 -> h1 in A
         n_bias2(n_bias_load(c, P4 + (L.off_bstep[0] >> 2)), acc);
-        n_xpart2<QX>(c, wr_, L.off_x[0] * 4 + z0, xt, acc);
+        n_xpart2<QX>(c, wr_, L.off_x[0] * 4 + z0, xr_, acc);
         NT_MARK(0);
         f32x2 bnext = n_bias_load(c, P4 + (L.off_bstep[1] >> 2));
         __builtin_amdgcn_sched_barrier(0);
@@ -301,8 +337,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll 1
         for (int l = 1; l < 9; ++l) {
             n_bias2(bnext, acc);
-            if (L.off_x[l] >= 0) n_xpart2<QX>(c, wr_, L.off_x[l] * 4 + z0, xt, acc);
+            if (L.off_x[l] >= 0) n_xpart2<QX>(c, wr_, L.off_x[l] * 4 + z0, xr_, acc);
             NT_MARK(3);
+            if (l == 8) {
+#pragma unroll
+                for (int q = 0; q < QD; ++q) xdir[q] = N_XLOAD(QX + q);
+            }
 #ifdef NN_PREFETCH
             n_hpart2<128, true>(c, wr_, L.off_h[l] * 4 + z0, cur, acc, pre);
             if (l < 8) n_hpre(c, wr_, L.off_h[l + 1] * 4 + z0, pre);
@@ -314,6 +354,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             if (l < 8) bnext = n_bias_load(c, P4 + (L.off_bstep[l + 1] >> 2));
             else bdir = ((const float*)(P4 + (L.off_bstep_dir >> 2) + c.lane))[c.w];
             __builtin_amdgcn_sched_barrier(0);
+            if (NN_IMGS_F == 1) __syncthreads();          // one image: everybody has read this layer's inputs
             if (l == 8) {
                 // the sigma head: the four waves' partials over h8 (left in sp by layer 7's epilogue, behind its barrier)
                 if (c.w == 0) {
@@ -364,6 +405,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             float v[16];
             unsigned m = 0;
             float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+            N_MFMA_DRAIN();
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 v[r] = n_relu(hd[r]);
@@ -462,7 +504,7 @@ extern "C" int nf_nerf_pack_bwd_n(const float* packed_t, float* packed_tn, nf_st
 // BITS: the ReLU masks come from the forward kernel's mask word (bit 16 i + r of `mbits`) instead of the saved activations
 template <int MODE, bool BITS = false>
 __device__ __forceinline__ void n_bwd_slot(const NCtx& c, const f32x16 (&raw)[2], const float* __restrict__ hrow, const float* __restrict__ wsig,
-                                           float dsig, float* __restrict__ img, float* __restrict__ save_row, bool row_ok, unsigned mbits = 0)
+                                           float dsig, float* __restrict__ img, const NSave& sv, int slot, unsigned mbits = 0)
 {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -476,7 +518,7 @@ __device__ __forceinline__ void n_bwd_slot(const NCtx& c, const f32x16 (&raw)[2]
             for (int e = 0; e < 4; ++e) {
                 const int r = 4 * rq + e;
                 float x = raw[i][r];
-                if (MODE == 2) x += dsig * (c.h ? wsig[(b * 16 + r) * 2 + 1] : wsig[(b * 16 + r) * 2]);
+                if (MODE == 2) x += dsig * wsig[(i * 16 + r) * 2];              // wsig: the LDS table + 64 w + h
                 if (MODE != 0) {
                     if (BITS) x = __builtin_bit_cast(float, __builtin_bit_cast(int, x) & ((int)(mbits << (16 * i + r)) >> 31));    // bit 31 - (16 i + r)
                     else x = hv[e] > 0.f ? x : 0.f;
@@ -485,11 +527,11 @@ __device__ __forceinline__ void n_bwd_slot(const NCtx& c, const f32x16 (&raw)[2]
                 if (img) img[(32 * b + (r & 3) + 8 * (r >> 2) + 4 * c.h) * 32 + c.j] = x;
             }
         }
-        if (row_ok) {
+        if (sv.ok) {
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq) {
                 f32x4 o = {v[4 * rq], v[4 * rq + 1], v[4 * rq + 2], v[4 * rq + 3]};
-                *(f32x4*)(save_row + 32 * b + 8 * rq + 4 * c.h) = o;
+                n_save4(sv, slot * 1024, i * 128 + rq * 32, o);
             }
         }
     }
@@ -504,7 +546,7 @@ __device__ __forceinline__ void n_zero2(f32x16 (&acc)[2])
 }
 
 template <bool BITS>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_mlp_bwd_n(NfMlpLayout L, NfMlpLayoutT T, const float* __restrict__ packed,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NN_WPE_B, NN_WPE_B))) k_mlp_bwd_n(NfMlpLayout L, NfMlpLayoutT T, const float* __restrict__ packed,
                                                    const float* __restrict__ packed_t, const float* __restrict__ acts,
                                                    const unsigned* __restrict__ amask,
                                                    const int* __restrict__ n_rows, int max_rows, const int* __restrict__ row_sample,
@@ -513,9 +555,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 {
     extern __shared__ float nlds[];
     float* cur = nlds;
-    float* nxt = nlds + NN_ACT;
+    float* nxt = nlds + (NN_IMGS_B - 1) * NN_ACT;
+    float* hw = nlds + NN_IMGS_B * NN_ACT;          // head weights w_sigma [256][2], w_rgb [3][64][2]: per-lane reads (+ half) without per-lane pointers
     NCtx c;
     c.lane = threadIdx.x & 63; c.h = c.lane >> 5; c.j = c.lane & 31; c.w = threadIdx.x >> 6; c.g = c.w >> 1; c.c0 = 2 * (c.w & 1);
+    for (int i = threadIdx.x; i < 512 + 384; i += 256) hw[i] = i < 512 ? packed[L.off_wsig + i] : packed[L.off_wrgb + i - 512];
+    __syncthreads();
+    const float* hw_sig = hw + 64 * c.w + c.h;
+    const float* hw_rgb = hw + 512 + 32 * c.w + c.h;
     const int nrows = min(*n_rows, max_rows);
     const int ntiles = (nrows + 31) >> 5;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -525,7 +572,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         const int row = tile * 32 + c.j;
         const bool valid = row < nrows;
         const float* arow = BITS ? nullptr : acts + (size_t)(valid ? row : 0) * NF_ACT_STRIDE;
-        float* drow = dpre + (size_t)(valid ? row : 0) * NF_DPRE_STRIDE;
+        NSave sv;              // this lane's dpre row, as the forward's saved-activation stores (pitch NF_DPRE_STRIDE)
+        sv.ok = valid;
+        sv.voff = (unsigned)c.j * (unsigned)(NF_DPRE_STRIDE * 4) + (unsigned)c.w * 256u + (unsigned)c.h * 16u;
+        sv.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(dpre + (size_t)tile * 32 * NF_DPRE_STRIDE), 0, 32 * NF_DPRE_STRIDE * 4, 0x27000);
         // BITS: the ReLU masks of this wave's blocks, one dword per layer (nf_nerf_mlp_fwd_n2 wrote them): the view branch's now, a
         // layer's in front of the K loop that precedes its use — k_mlp_bwd_n without them fetched 128 B of saved activations per lane
         // (HBM) at every slot, with nothing to do until they arrived: as long as the MFMAs of the layer (179 k of 413 k cycles per tile)
@@ -541,10 +591,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         // rgb = sigmoid(z): dz = g * y (1 - y)
         const float dz0 = g4.x * o4.x * (1.f - o4.x), dz1 = g4.y * o4.y * (1.f - o4.y), dz2 = g4.z * o4.z * (1.f - o4.z);
         const float dsig = g4.w;
-        if (valid && c.h == 0 && c.w == 0) *(float4*)(drow + 2432) = make_float4(dz0, dz1, dz2, dsig);
+        if (valid && c.h == 0 && c.w == 0) *(float4*)(dpre + (size_t)row * NF_DPRE_STRIDE + 2432) = make_float4(dz0, dz1, dz2, dsig);
         // slot 9: d(view-branch hidden) = [hd > 0] W_rgb^T dz, block w by wave w
         {
-            const float* wr = pk + L.off_wrgb;
             const int b = c.w;
             float v[16];
 #pragma unroll
@@ -553,9 +602,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                 if (!BITS) hv = *(const f32x4*)(arow + 9 * 256 + 32 * b + 8 * rq + 4 * c.h);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int r = 4 * rq + e, k = (b * 16 + r) * 2;
-                    const float x = dz0 * (c.h ? wr[k + 1] : wr[k]) + dz1 * (c.h ? wr[128 + k + 1] : wr[128 + k]) +
-                                    dz2 * (c.h ? wr[256 + k + 1] : wr[256 + k]);
+                    const int r = 4 * rq + e;
+                    const float x = dz0 * hw_rgb[2 * r] + dz1 * hw_rgb[128 + 2 * r] + dz2 * hw_rgb[256 + 2 * r];
                     v[r] = BITS ? __builtin_bit_cast(float, __builtin_bit_cast(int, x) & ((int)(mcur << (16 + r)) >> 31)) : (hv[e] > 0.f ? x : 0.f);
                     cur[(32 * b + (r & 3) + 8 * (r >> 2) + 4 * c.h) * 32 + c.j] = v[r];
                 }
@@ -564,7 +612,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
                 for (int rq = 0; rq < 4; ++rq) {
                     f32x4 o = {v[4 * rq], v[4 * rq + 1], v[4 * rq + 2], v[4 * rq + 3]};
-                    *(f32x4*)(drow + 9 * 256 + 32 * b + 8 * rq + 4 * c.h) = o;
+                    n_save4(sv, 9 * 1024, rq * 32 - (int)c.w * 128, o);        // block w of slot 9: 32 w, not the 64 w of the vector offset
                 }
             }
         }
@@ -584,15 +632,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         n_hpart2<64>(c, wt_, T.off_dir * 4 + z0, cur, acc);
 #endif
         NT_MARK(2);
-        const float* ws_ = pk + L.off_wsig;
+        const float* ws_ = hw_sig;
 #pragma unroll 1
         for (int g = 8; g >= 1; --g) {
 #ifdef NN_PREFETCH
             n_hpre(c, wt_, T.off_h[g] * 4 + z0, pre);
 #endif
-            if (g == 8) n_bwd_slot<0, BITS>(c, acc, nullptr, ws_, dsig, nxt, drow + 8 * 256, valid);
-            else if (g == 7) n_bwd_slot<2, BITS>(c, acc, arow + 7 * 256, ws_, dsig, nxt, drow + 7 * 256, valid, mcur);
-            else n_bwd_slot<1, BITS>(c, acc, arow + g * 256, ws_, dsig, nxt, drow + g * 256, valid, mcur);
+            if (NN_IMGS_B == 1) __syncthreads();
+            if (g == 8) n_bwd_slot<0, BITS>(c, acc, nullptr, ws_, dsig, nxt, sv, 8);
+            else if (g == 7) n_bwd_slot<2, BITS>(c, acc, arow + 7 * 256, ws_, dsig, nxt, sv, 7, mcur);
+            else n_bwd_slot<1, BITS>(c, acc, arow + g * 256, ws_, dsig, nxt, sv, g, mcur);
             NT_MARK(3);
             __syncthreads();
             NT_MARK(4);
@@ -607,7 +656,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             NT_MARK(5);
         }
         // slot 0 = [h1 > 0] d_h1
-        n_bwd_slot<1, BITS>(c, acc, arow, ws_, dsig, nullptr, drow, valid, mcur);
+        n_bwd_slot<1, BITS>(c, acc, arow, ws_, dsig, nullptr, sv, 0, mcur);
         NT_MARK(6);
         __syncthreads();        // the images are rewritten by the next tile
         NT_MARK(7);
@@ -615,6 +664,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
 }
 
+#ifdef NN_PERSIST            // dev: a fixed grid of NN_PERSIST workgroups walking the tiles (is it the dispatch of ~2 000 workgroups that costs?)
+#define NN_GRID(t) ((t) < NN_PERSIST ? (t) : NN_PERSIST)
+#else
+#define NN_GRID(t) (t)
+#endif
 static int mlp_bwd_n_launch(const float* packed, const float* packed_t, int cx, int cd, const float* acts, const uint32_t* amask,
                             const int32_t* n_rows, int max_rows, const int32_t* row_sample, const float* rgbsigma,
                             const float* d_rgbsigma, float* dpre, nf_stream_t stream)
@@ -625,17 +679,17 @@ static int mlp_bwd_n_launch(const float* packed, const float* packed_t, int cx, 
     NfMlpLayout L = mlp_layout(cx, cd);
     NfMlpLayoutT T = mlp_layout_t();
     const int tiles = (max_rows + 31) / 32;
-    const size_t lds = (size_t)(2 * NN_ACT) * sizeof(float);       // 64 KB: two workgroups per CU
+    const size_t lds = (size_t)(NN_IMGS_B * NN_ACT + 512 + 384) * sizeof(float);       // 35.5 KB (NN_WPE = 3) / 67.5 KB
     static bool attr_set[64] = {};
     if (nf_first_use_on_device(attr_set)) {
         hipFuncSetAttribute((const void*)k_mlp_bwd_n<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipFuncSetAttribute((const void*)k_mlp_bwd_n<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     if (amask)
-        hipLaunchKernelGGL(k_mlp_bwd_n<true>, dim3(tiles), dim3(256), lds, (hipStream_t)stream, L, T, packed, packed_t, acts, amask, n_rows,
+        hipLaunchKernelGGL(k_mlp_bwd_n<true>, dim3(NN_GRID(tiles)), dim3(256), lds, (hipStream_t)stream, L, T, packed, packed_t, acts, amask, n_rows,
                            max_rows, row_sample, (const float4*)rgbsigma, (const float4*)d_rgbsigma, dpre);
     else
-        hipLaunchKernelGGL(k_mlp_bwd_n<false>, dim3(tiles), dim3(256), lds, (hipStream_t)stream, L, T, packed, packed_t, acts, amask, n_rows,
+        hipLaunchKernelGGL(k_mlp_bwd_n<false>, dim3(NN_GRID(tiles)), dim3(256), lds, (hipStream_t)stream, L, T, packed, packed_t, acts, amask, n_rows,
                            max_rows, row_sample, (const float4*)rgbsigma, (const float4*)d_rgbsigma, dpre);
     NF_CHECK_LAUNCH();
     return NF_OK;
@@ -668,7 +722,7 @@ static int mlp_fwd_n_launch(const float* packed, int cx, int cd, const float* X,
     NfMlpLayout L = mlp_layout(cx, cd);
     NF_CHECK_ARG(L.qx == 25 && L.qd == 7, "built for the default 198 + 54 feature row (other encodings: nf_nerf_mlp_fwd)");
     const int tiles = (max_rows + 31) / 32;
-    const size_t lds = (size_t)(2 * NN_ACT + NN_HEADS) * sizeof(float);       // 68 KB: two workgroups per CU
+    const size_t lds = (size_t)(NN_IMGS_F * NN_ACT + NN_HEADS) * sizeof(float);       // 39.5 KB (NN_WPE = 3) / 71.5 KB
     static bool attr_set[64] = {};
     if (nf_first_use_on_device(attr_set)) {
         hipFuncSetAttribute((const void*)k_mlp_fwd_n<true, 25, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -676,10 +730,10 @@ static int mlp_fwd_n_launch(const float* packed, int cx, int cd, const float* X,
     }
     hipStream_t st = (hipStream_t)stream;
     if (acts)
-        hipLaunchKernelGGL((k_mlp_fwd_n<true, 25, 7>), dim3(tiles), dim3(256), lds, st, L, packed, X, n_rows, max_rows, row_sample,
+        hipLaunchKernelGGL((k_mlp_fwd_n<true, 25, 7>), dim3(NN_GRID(tiles)), dim3(256), lds, st, L, packed, X, n_rows, max_rows, row_sample,
                            (float4*)rgbsigma, acts, amask);
     else
-        hipLaunchKernelGGL((k_mlp_fwd_n<false, 25, 7>), dim3(tiles), dim3(256), lds, st, L, packed, X, n_rows, max_rows, row_sample,
+        hipLaunchKernelGGL((k_mlp_fwd_n<false, 25, 7>), dim3(NN_GRID(tiles)), dim3(256), lds, st, L, packed, X, n_rows, max_rows, row_sample,
                            (float4*)rgbsigma, acts, (uint32_t*)nullptr);
     NF_CHECK_LAUNCH();
     return NF_OK;

@@ -34,6 +34,26 @@ def prof(kern, names_, mfma_cycles):
               "  ".join("%s %.0f" % (names_[p], v[p] / n) for p in range(len(names_))))
 
 
+def span(kern, fn, label, ntiles):
+    """one launch alone: the tiles' start / end stamps (s_memtime) against the launch's HIP-event time"""
+    if not has_prof: return
+    import numpy as np
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3
+    buf = (ctypes.c_ulonglong * (2 * 4096 * 2))()
+    assert raw.nf_dev_n_trace(buf) == 0
+    a = np.frombuffer(buf, dtype=np.uint64).reshape(2, 4096, 2)[kern, :min(ntiles, 4096)].astype(np.int64)
+    a = a[0::8]                  # workgroups go round-robin over the 8 XCDs, and every XCD has its own s_memtime base: XCD 0's tiles
+    t0 = a[:, 0].min()
+    st, en = np.sort(a[:, 0] - t0), np.sort(a[:, 1] - t0)
+    q = lambda v, f: int(v[min(len(v) - 1, int(f * len(v)))])
+    print("    %s: one launch %.1f us between events; span first start -> last end %d ticks (%.0f ticks/us); tile starts at 25/50/75/100 %%: %d %d %d %d; "
+          "tile ends at 25/50/75/100 %%: %d %d %d %d; mean tile duration %d" %
+          (label, us, en[-1], en[-1] / us, q(st, .25), q(st, .5), q(st, .75), st[-1], q(en, .25), q(en, .5), q(en, .75), en[-1], int((a[:, 1] - a[:, 0]).mean())))
+
+
 def t(fn, it=8):
     for _ in range(2): fn()
     torch.cuda.synchronize()
@@ -60,6 +80,7 @@ for n in rows:
     a = t(lambda: check(lib.nf_nerf_mlp_fwd_n2(ptr(packed_n), 198, 54, ptr(X), ptr(n_rows), n, ptr(row_sample), ptr(out), ptr(acts), ptr(amask), _lib.stream())))
     print("rows %6d (%4d tiles): fwd_n %7.1f us (%5.1f TFLOP/s of 1.332 MFLOP rows)" % (n, (n + 31) // 32, a, n * 1.331968 / a))
     if has_prof: prof(0, FWD_PH, (2 * (1 + 100) + 8 * 2 * (1 + 128) + 2 * 100 + 157) * 64)
+    span(0, lambda: check(lib.nf_nerf_mlp_fwd_n2(ptr(packed_n), 198, 54, ptr(X), ptr(n_rows), n, ptr(row_sample), ptr(out), ptr(acts), ptr(amask), _lib.stream())), "fwd", (n + 31) // 32)
     packed_t = torch.empty(lib.nf_nerf_packed_bwd_floats(), device=dev)
     P = _lib.NerfParams()
     for i in range(12):
@@ -78,6 +99,7 @@ for n in rows:
     print("             bwd_n2 %6.1f us (%5.1f TFLOP/s of 1.114 MFLOP rows)   [bwd_n, masks from the activations: %.1f us]   checksums %.6e %.6e" %
           (b, n * 1.114112 / b, b0, float(d2[:n].double().abs().sum()), cs0))
     if has_prof: prof(1, BWD_PH, (64 * 2 + 8 * 256) * 64)
+    span(1, lambda: check(lib.nf_nerf_mlp_bwd_n2(ptr(packed), ptr(packed_tn), 198, 54, ptr(amask), ptr(n_rows), n, ptr(row_sample), ptr(out), ptr(gr), ptr(d2), _lib.stream())), "bwd", (n + 31) // 32)
     blob = torch.empty(lib.nf_nerf_wgrad_floats(198, 54), device=dev)
     wsp = torch.empty(lib.nf_nerf_wgrad_workspace_floats(198, 54, nsl), device=dev)
     colsum = torch.empty(2436, device=dev)

@@ -274,6 +274,13 @@ int nf_nerf_mlp_bwd_n(const float* packed, const float* packed_t, int cx, int cd
 int nf_nerf_mlp_bwd_n2(const float* packed, const float* packed_t, int cx, int cd, const uint32_t* amask,
                        const int32_t* n_rows, int max_rows, const int32_t* row_sample, const float* rgbsigma,
                        const float* d_rgbsigma, float* dpre, nf_stream_t stream);
+/* nf_nerf_mlp_bwd_n2 + the gradient of the feature row in the same launch (the end-to-end step's dL/dX, models/nerf.py:85-122 under
+ * autograd towards models/renderer.py:55-180): dX[row][0:cx] = dpre_1 W_1[:, :cx] + dpre_5 W_5[:, :cx], dX[row][cx:cx+cd] =
+ * dpre_dir W_dir[:, 256:], row-major with pitch cx + cd, for rows < *n_rows — what nf_render_features_bwd scatters to the particles.
+ * Replaces three nf_gemm_f32 calls per pass over dpre. */
+int nf_nerf_mlp_bwd_n3(const float* packed, const float* packed_t, int cx, int cd, const uint32_t* amask,
+                       const int32_t* n_rows, int max_rows, const int32_t* row_sample, const float* rgbsigma,
+                       const float* d_rgbsigma, float* dpre, float* dX, nf_stream_t stream);
 
 /* A12 (weight gradients of the nn.Linear layers of models/nerf.py:55-81): all 15 GEMMs dW_l = dpre_l^T * input_l of one NeRF in one batched fp32-MFMA launch +
  * one deterministic slice reduction.  X = the MLP operand of nf_render_features (tile layout) that the forward consumed.

@@ -98,6 +98,8 @@ PROTOTYPES = {
                                   c_void_p, c_void_p]),
     "nf_nerf_mlp_bwd_n2": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p]),
+    "nf_nerf_mlp_bwd_n3": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_void_p]),
     "nf_embed_fwd": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "nf_embed_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "nf_gemm_f32_workspace_floats": (c_size_t, [c_int, c_int, c_int]),

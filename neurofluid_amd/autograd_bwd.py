@@ -73,7 +73,13 @@ def _pass_backward(net, nerf, pb, rays_c, z, z_table, g_rgb, white_bg, particles
     cap = ops._round_rows(n)
     dpre_full = torch.empty(cap, DPRE, dtype=torch.float32, device=dev)
     dpre = dpre_full[:n]
-    if getattr(pb, "amask", None) is not None:      # the forward left the ReLU masks as bits: no read of the saved activations here
+    dX = None
+    if getattr(pb, "amask", None) is not None and dparticles is not None:
+        # end-to-end step: dL/dX comes out of the same launch (three more K loops over images the kernel holds anyway)
+        dX = torch.empty(cap, cx + cd, dtype=torch.float32, device=dev)
+        check(lib.nf_nerf_mlp_bwd_n3(ptr(pb.packed), ptr(packed_t), cx, cd, ptr(pb.amask), ptr(pb.n_rows), n, ptr(pb.row_sample),
+                                     ptr(pb.rgbsigma), ptr(d_rs), ptr(dpre_full), ptr(dX), st), "nf_nerf_mlp_bwd_n3")
+    elif getattr(pb, "amask", None) is not None:      # the forward left the ReLU masks as bits: no read of the saved activations here
         check(lib.nf_nerf_mlp_bwd_n2(ptr(pb.packed), ptr(packed_t), cx, cd, ptr(pb.amask), ptr(pb.n_rows), n, ptr(pb.row_sample),
                                      ptr(pb.rgbsigma), ptr(d_rs), ptr(dpre_full), st), "nf_nerf_mlp_bwd_n2")
     else:
@@ -101,11 +107,12 @@ def _pass_backward(net, nerf, pb, rays_c, z, z_table, g_rgb, white_bg, particles
     if dparticles is not None:
         # dL/dX = dpre W for the three layers that read the feature matrix (fp32-MFMA GEMMs on column slices of dpre, the
         # skip layer's term accumulated in place), then HIP scatter
-        W1, W5, Wd = layers[0].weight.detach(), layers[4].weight.detach(), layers[9].weight.detach()
-        dX = torch.empty(cap, cx + cd, dtype=torch.float32, device=dev)
-        ops.gemm(dpre[:, 0:256], W1, out=dX[:n, :cx])
-        ops.gemm(dpre[:, 4 * 256:5 * 256], W5[:, :cx], out=dX[:n, :cx], accumulate=True)
-        ops.gemm(dpre[:, 9 * 256:9 * 256 + 128], Wd[:, 256:], out=dX[:n, cx:])
+        if dX is None:          # (the tile-per-wave forward of a non-default feature row: no mask words, no fused dX)
+            W1, W5, Wd = layers[0].weight.detach(), layers[4].weight.detach(), layers[9].weight.detach()
+            dX = torch.empty(cap, cx + cd, dtype=torch.float32, device=dev)
+            ops.gemm(dpre[:, 0:256], W1, out=dX[:n, :cx])
+            ops.gemm(dpre[:, 4 * 256:5 * 256], W5[:, :cx], out=dX[:n, :cx], accumulate=True)
+            ops.gemm(dpre[:, 9 * 256:9 * 256 + 128], Wd[:, 256:], out=dX[:n, cx:])
         check(lib.nf_render_features_bwd(ptr(particles), ptr(rays_c), ptr(z), ptr(z_table), R, S, float(net.raduis),
                                          net.num_neighbor, net.enc_flags, ptr(ro_c), int(ro_c.dim() == 2),
                                          ptr(pb.row_sample), ptr(pb.row_nbr), ptr(pb.n_rows), n, ptr(dX), ptr(dparticles),

@@ -450,6 +450,18 @@ __global__ void k_mlp_pack_bwd(NfMlpLayoutT T, int cx, int cd, NfNerfPtrs P, flo
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= T.total) return;
+    if (i >= T.off_dx0) {           // the feature-gradient parts: K = the layer's output units, outputs = feature columns (zero beyond cx / cd)
+        const int part = i >= T.off_dxd ? 2 : (i >= T.off_dx4 ? 1 : 0);
+        int k = i - (part == 2 ? T.off_dxd : (part == 1 ? T.off_dx4 : T.off_dx0)), e = k & 3, lane = (k >> 2) & 63, g = (k >> 8) & 1, s = k >> 9;
+        int o = frag_feature(s >> 4, s & 15, lane >> 5);          // the layer's output unit (K index): < 256, dir: < 128
+        int in = 32 * (4 * g + e) + (lane & 31);                   // feature column
+        float v = 0.f;
+        if (part == 0) { if (in < cx) v = P.w[0][(size_t)o * cx + in]; }
+        else if (part == 1) { if (in < cx) v = P.w[4][(size_t)o * (cx + 256) + in]; }
+        else if (in < cd) v = P.w[9][(size_t)o * (256 + cd) + 256 + in];
+        out[i] = v;
+        return;
+    }
     if (i >= T.off_dir) {
         int k = i - T.off_dir, e = k & 3, lane = (k >> 2) & 63, g = (k >> 8) & 1, s = k >> 9;
         int o = frag_feature(s >> 4, s & 15, lane >> 5);          // dir hidden unit (K index), < 128

@@ -51,6 +51,11 @@ static inline NfMlpLayout mlp_layout(int cx, int cd)
 struct NfMlpLayoutT {
     int off_h[9];   // l = 1..8: W_l^T hidden part [128 steps][2][64][4]   (index 0 unused)
     int off_dir;    // W_dir[:, :256]^T  [64 steps][2][64][4]
+    // round 6, the feature gradient dL/dX inside the tile-per-workgroup backward (nf_nerf_mlp_bwd_n3): the three weight blocks that
+    // read the feature row, transposed like the hidden parts, output features (rows of X) padded with zeros to 8 blocks of 32
+    int off_dx0;    // W_1[:, :cx]^T          [128 steps][2][64][4]
+    int off_dx4;    // W_5[:, :cx]^T          [128 steps][2][64][4]
+    int off_dxd;    // W_dir[:, 256:256+cd]^T [64 steps][2][64][4]
     int total;
 };
 
@@ -61,6 +66,9 @@ static inline NfMlpLayoutT mlp_layout_t()
     T.off_h[0] = -1;
     for (int l = 1; l < 9; ++l) { T.off_h[l] = o; o += 128 * 512; }
     T.off_dir = o; o += 64 * 512;
+    T.off_dx0 = o; o += 128 * 512;
+    T.off_dx4 = o; o += 128 * 512;
+    T.off_dxd = o; o += 64 * 512;
     T.total = o;
     return T;
 }

@@ -545,13 +545,38 @@ __device__ __forceinline__ void n_zero2(f32x16 (&acc)[2])
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 }
 
-template <bool BITS>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NN_WPE_B, NN_WPE_B))) k_mlp_bwd_n(NfMlpLayout L, NfMlpLayoutT T, const float* __restrict__ packed,
+// the wave's two blocks of a feature-gradient accumulator -> dX rows (row-major, pitch cx + cd floats): columns col0 + 64 w + 32 i +
+// 8 rq + 4 h + e; whole quads where they fit under `ncols`, single floats at the boundary (the next column belongs to the other part
+// of the row, or to the next row)
+__device__ __forceinline__ void n_dx_store(const NCtx& c, const f32x16 (&acc)[2], const NSave& sx, int col0, int ncols)
+{
+    if (!sx.ok) return;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const int f0 = 64 * c.w + 32 * i + 8 * rq + 4 * c.h;
+            const f32x4 o = {acc[i][4 * rq], acc[i][4 * rq + 1], acc[i][4 * rq + 2], acc[i][4 * rq + 3]};
+            if (f0 + 4 <= ncols) n_save4(sx, col0 * 4, i * 128 + rq * 32, o);
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (f0 + e < ncols)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][4 * rq + e]), sx.rs, (int)sx.voff + col0 * 4 + i * 128 + rq * 32 + e * 4, 0, 0);
+            }
+        }
+}
+
+// DX (round 6): the kernel also produces dL/dX = dpre_1 W_1[:, :cx] + dpre_5 W_5[:, :cx] | dpre_dir W_dir[:, 256:] (the gradient of the
+// feature row, what the end-to-end step scatters to the particles) as three more K loops over images it has in LDS anyway, instead
+// of three latency-bound GEMMs over dpre per pass behind it (53 us each at the end-to-end step's 5-17 thousand rows).
+template <bool BITS, bool DX>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DX ? 2 : NN_WPE_B, DX ? 2 : NN_WPE_B))) k_mlp_bwd_n(NfMlpLayout L, NfMlpLayoutT T, const float* __restrict__ packed,
                                                    const float* __restrict__ packed_t, const float* __restrict__ acts,
                                                    const unsigned* __restrict__ amask,
                                                    const int* __restrict__ n_rows, int max_rows, const int* __restrict__ row_sample,
                                                    const float4* __restrict__ rgbsigma, const float4* __restrict__ d_rgbsigma,
-                                                   float* __restrict__ dpre)
+                                                   float* __restrict__ dpre, float* __restrict__ dX)
 {
     extern __shared__ float nlds[];
     float* cur = nlds;
@@ -576,6 +601,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NN_WPE
         sv.ok = valid;
         sv.voff = (unsigned)c.j * (unsigned)(NF_DPRE_STRIDE * 4) + (unsigned)c.w * 256u + (unsigned)c.h * 16u;
         sv.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(dpre + (size_t)tile * 32 * NF_DPRE_STRIDE), 0, 32 * NF_DPRE_STRIDE * 4, 0x27000);
+        NSave sx;              // this lane's dX row
+        const int xpitch = L.cx + L.cd;
+        sx.ok = DX && valid;
+        sx.voff = (unsigned)c.j * (unsigned)(xpitch * 4) + (unsigned)c.w * 256u + (unsigned)c.h * 16u;
+        sx.rs = __builtin_amdgcn_make_buffer_rsrc(DX ? (void*)(dX + (size_t)tile * 32 * xpitch) : (void*)dpre, 0, 32 * xpitch * 4, 0x27000);
+        f32x16 accx[2];        // DX: the position-like features' gradient, summed over the skip layer (slot 4) and the first layer (slot 0)
         // BITS: the ReLU masks of this wave's blocks, one dword per layer (nf_nerf_mlp_fwd_n2 wrote them): the view branch's now, a
         // layer's in front of the K loop that precedes its use — k_mlp_bwd_n without them fetched 128 B of saved activations per lane
         // (HBM) at every slot, with nothing to do until they arrived: as long as the MFMAs of the layer (179 k of 413 k cycles per tile)
@@ -631,6 +662,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NN_WPE
 #else
         n_hpart2<64>(c, wt_, T.off_dir * 4 + z0, cur, acc);
 #endif
+        if (DX) {              // the direction-like features' gradient, from the same image (slot 9)
+            n_zero2(accx);
+            n_hpart2<64>(c, wt_, T.off_dxd * 4 + z0, cur, accx);
+            n_dx_store(c, accx, sx, L.cx, L.cd);
+            n_zero2(accx);
+        }
         NT_MARK(2);
         const float* ws_ = hw_sig;
 #pragma unroll 1
@@ -653,9 +690,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NN_WPE
 #else
             n_hpart2<128>(c, wt_, T.off_h[g] * 4 + z0, cur, acc);
 #endif
+            if (DX && g == 4) n_hpart2<128>(c, wt_, T.off_dx4 * 4 + z0, cur, accx);        // the image holds slot 4 (the skip layer's dpre)
             NT_MARK(5);
         }
         // slot 0 = [h1 > 0] d_h1
+        if (DX) {              // slot 0 goes to the image, too: dX += dpre_1 W_1[:, :cx]
+            if (NN_IMGS_B == 1) __syncthreads();
+            n_bwd_slot<1, BITS>(c, acc, arow, ws_, dsig, nxt, sv, 0, mcur);
+            __syncthreads();
+            n_hpart2<128>(c, wt_, T.off_dx0 * 4 + z0, nxt, accx);
+            n_dx_store(c, accx, sx, 0, L.cx);
+        } else
         n_bwd_slot<1, BITS>(c, acc, arow, ws_, dsig, nullptr, sv, 0, mcur);
         NT_MARK(6);
         __syncthreads();        // the images are rewritten by the next tile
@@ -671,7 +716,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NN_WPE
 #endif
 static int mlp_bwd_n_launch(const float* packed, const float* packed_t, int cx, int cd, const float* acts, const uint32_t* amask,
                             const int32_t* n_rows, int max_rows, const int32_t* row_sample, const float* rgbsigma,
-                            const float* d_rgbsigma, float* dpre, nf_stream_t stream)
+                            const float* d_rgbsigma, float* dpre, float* dX, nf_stream_t stream)
 {
     NF_CHECK_ARG(packed && packed_t && (acts || amask) && n_rows && row_sample && rgbsigma && d_rgbsigma && dpre, "null pointer");
     NF_CHECK_ARG(cx >= 1 && cx <= 256 && cd >= 1 && cd <= 256, "bad channel counts");
@@ -682,15 +727,19 @@ static int mlp_bwd_n_launch(const float* packed, const float* packed_t, int cx, 
     const size_t lds = (size_t)(NN_IMGS_B * NN_ACT + 512 + 384) * sizeof(float);       // 35.5 KB (NN_WPE = 3) / 67.5 KB
     static bool attr_set[64] = {};
     if (nf_first_use_on_device(attr_set)) {
-        hipFuncSetAttribute((const void*)k_mlp_bwd_n<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute((const void*)k_mlp_bwd_n<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)k_mlp_bwd_n<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)k_mlp_bwd_n<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)k_mlp_bwd_n<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
-    if (amask)
-        hipLaunchKernelGGL(k_mlp_bwd_n<true>, dim3(NN_GRID(tiles)), dim3(256), lds, (hipStream_t)stream, L, T, packed, packed_t, acts, amask, n_rows,
-                           max_rows, row_sample, (const float4*)rgbsigma, (const float4*)d_rgbsigma, dpre);
+    if (amask && dX)
+        hipLaunchKernelGGL((k_mlp_bwd_n<true, true>), dim3(NN_GRID(tiles)), dim3(256), lds, (hipStream_t)stream, L, T, packed, packed_t, acts, amask, n_rows,
+                           max_rows, row_sample, (const float4*)rgbsigma, (const float4*)d_rgbsigma, dpre, dX);
+    else if (amask)
+        hipLaunchKernelGGL((k_mlp_bwd_n<true, false>), dim3(NN_GRID(tiles)), dim3(256), lds, (hipStream_t)stream, L, T, packed, packed_t, acts, amask, n_rows,
+                           max_rows, row_sample, (const float4*)rgbsigma, (const float4*)d_rgbsigma, dpre, dX);
     else
-        hipLaunchKernelGGL(k_mlp_bwd_n<false>, dim3(NN_GRID(tiles)), dim3(256), lds, (hipStream_t)stream, L, T, packed, packed_t, acts, amask, n_rows,
-                           max_rows, row_sample, (const float4*)rgbsigma, (const float4*)d_rgbsigma, dpre);
+        hipLaunchKernelGGL((k_mlp_bwd_n<false, false>), dim3(NN_GRID(tiles)), dim3(256), lds, (hipStream_t)stream, L, T, packed, packed_t, acts, amask, n_rows,
+                           max_rows, row_sample, (const float4*)rgbsigma, (const float4*)d_rgbsigma, dpre, dX);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }
@@ -700,7 +749,7 @@ extern "C" int nf_nerf_mlp_bwd_n(const float* packed, const float* packed_t, int
                                  const float* d_rgbsigma, float* dpre, nf_stream_t stream)
 {
     NF_CHECK_ARG(acts, "null pointer");
-    return mlp_bwd_n_launch(packed, packed_t, cx, cd, acts, nullptr, n_rows, max_rows, row_sample, rgbsigma, d_rgbsigma, dpre, stream);
+    return mlp_bwd_n_launch(packed, packed_t, cx, cd, acts, nullptr, n_rows, max_rows, row_sample, rgbsigma, d_rgbsigma, dpre, nullptr, stream);
 }
 
 extern "C" int nf_nerf_mlp_bwd_n2(const float* packed, const float* packed_t, int cx, int cd, const uint32_t* amask,
@@ -708,7 +757,15 @@ extern "C" int nf_nerf_mlp_bwd_n2(const float* packed, const float* packed_t, in
                                   const float* d_rgbsigma, float* dpre, nf_stream_t stream)
 {
     NF_CHECK_ARG(amask, "null pointer");
-    return mlp_bwd_n_launch(packed, packed_t, cx, cd, nullptr, amask, n_rows, max_rows, row_sample, rgbsigma, d_rgbsigma, dpre, stream);
+    return mlp_bwd_n_launch(packed, packed_t, cx, cd, nullptr, amask, n_rows, max_rows, row_sample, rgbsigma, d_rgbsigma, dpre, nullptr, stream);
+}
+
+extern "C" int nf_nerf_mlp_bwd_n3(const float* packed, const float* packed_t, int cx, int cd, const uint32_t* amask,
+                                  const int32_t* n_rows, int max_rows, const int32_t* row_sample, const float* rgbsigma,
+                                  const float* d_rgbsigma, float* dpre, float* dX, nf_stream_t stream)
+{
+    NF_CHECK_ARG(amask && dX, "null pointer");
+    return mlp_bwd_n_launch(packed, packed_t, cx, cd, nullptr, amask, n_rows, max_rows, row_sample, rgbsigma, d_rgbsigma, dpre, dX, stream);
 }
 
 extern "C" size_t nf_nerf_amask_words(int max_rows) { return (size_t)((max_rows + 31) / 32) * NF_AMASK_SLOTS * 256; }

@@ -1597,6 +1597,17 @@ def test_mlp_backward_from_mask_words_bit_equal(dev):
                                           out.data_ptr(), gout.data_ptr(), d2.data_ptr(), _lib.stream()))
         assert torch.equal(d1, d2)
         assert float(d1[:live].abs().sum()) > 0
+        # nf_nerf_mlp_bwd_n3: the same dpre and, in the same launch, dL/dX = dpre_1 W_1[:, :cx] + dpre_5 W_5[:, :cx] | dpre_dir W_dir[:, 256:]
+        d3 = torch.full_like(d1, -3.0)
+        dX = torch.full(((n + 31) // 32 * 32, 252), -5.0, device=dev)
+        _lib.check(lib.nf_nerf_mlp_bwd_n3(packed.data_ptr(), packed_tn.data_ptr(), 198, 54, amask.data_ptr(), n_rows.data_ptr(), n, row_sample.data_ptr(),
+                                          out.data_ptr(), gout.data_ptr(), d3.data_ptr(), dX.data_ptr(), _lib.stream()))
+        assert torch.equal(d1, d3)
+        dd = d1[:live].double()
+        want = torch.cat([dd[:, 0:256] @ W[0].double() + dd[:, 1024:1280] @ W[4].double()[:, :198], dd[:, 2304:2432] @ W[9].double()[:, 256:]], 1)
+        err = float((dX[:live].double() - want).abs().max() / want.abs().max())
+        assert err < 2e-6, err
+        assert bool((dX[live:] == -5.0).all())              # rows beyond the live count are not touched
 
 
 

@@ -81,3 +81,26 @@ def mean_over_ranks_hook(world):
         dist.all_reduce(g, op=dist.ReduceOp.SUM)
         return g / world
     return hook
+
+
+def replicas_in_sync(params, world, resync_from=0):
+    """Checks that a module every rank updates WITHOUT a gradient all-reduce (the e2e trainer's transition model: its only upstream
+    gradient is averaged by mean_over_ranks_hook, so equal replicas stay equal only as long as its forward and backward are bitwise
+    deterministic on every rank — no float atomics, no rank-local summation order) still holds the same bits everywhere.
+    An exact, order-free checksum of the parameter bits (int64 sum of the int32 words) is all-reduced as (max, -min); on a mismatch
+    the parameters are broadcast from `resync_from` (None: leave them).  Returns True when the replicas agreed.  One 16-byte
+    collective: called at checkpoint time (trainers.E2ETrainer), not per step."""
+    params = [p for p in params]
+    if world == 1 or not params:
+        return True
+    dev = params[0].device
+    cs = torch.zeros((), dtype=torch.int64, device=dev)
+    for p in params:
+        cs = cs + p.detach().contiguous().view(-1).view(torch.int32).to(torch.int64).sum()
+    pair = torch.stack([cs, -cs])
+    dist.all_reduce(pair, op=dist.ReduceOp.MAX)
+    same = bool((pair[0] == -pair[1]).item())
+    if not same and resync_from is not None:
+        for p in params:
+            dist.broadcast(p.data, src=resync_from)
+    return same

@@ -292,7 +292,15 @@ def pack_nerf_stream(packed, cx, cd, kind=None):
 
 
 def _ring_fwd(lib, wstream):
-    return (lib.nf_nerf_mlp_fwd_a, "nf_nerf_mlp_fwd_a") if getattr(wstream, "nf_kind", "l") == "a" else (lib.nf_nerf_mlp_fwd_l, "nf_nerf_mlp_fwd_l")
+    """The ring kernel a weight stream was packed for.  The kind travels as an attribute of the tensor, which .to() / .clone() /
+    .detach() / pickling drop: a stream without it is refused (the two layouts differ in size and padding; feeding an "a" stream
+    to the "l" kernel would read out of bounds) — re-pack with pack_nerf_stream instead of copying a stream."""
+    kind = getattr(wstream, "nf_kind", None)
+    if kind == "a":
+        return lib.nf_nerf_mlp_fwd_a, "nf_nerf_mlp_fwd_a"
+    if kind == "l":
+        return lib.nf_nerf_mlp_fwd_l, "nf_nerf_mlp_fwd_l"
+    raise RuntimeError("weight stream without its kernel kind (nf_kind): it was copied or moved after pack_nerf_stream; pack it again")
 
 
 # Which kernel serves the fp16-MFMA weight stream: "ha" = the hand-scheduled instruction stream (nf_mlp_ha.hip, generated by

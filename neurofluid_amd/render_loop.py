@@ -21,6 +21,21 @@ def _own_ray_index(n_chunks, ray_chunk, N_ray, rank, world, device):
     return idx
 
 
+def _fit_device_chunk(renderer, device_chunk, ray_chunk, device):
+    """Rays per fused call, bounded by what the device can hold.  With `use_mask` only active samples get row buffers (their number is
+    data: the OutOfMemoryError path of render_image handles a call that does not fit); WITHOUT the mask every sample is a row
+    (1 KB of MLP operand + the 8 + 4 K bytes of its row lists + 21 B of per-sample arrays), so the size is known up front and the
+    call is cut to 60 % of the free memory.  A bound learnt from an earlier failure (`_device_chunk_limit`) is kept."""
+    device_chunk = min(device_chunk, int(getattr(renderer, "_device_chunk_limit", device_chunk)))
+    if device.type == "cuda" and not getattr(renderer, "use_mask", True):
+        S1 = renderer.N_samples + renderer.N_importance         # the arena is reused by the passes: the larger one counts
+        per_ray = S1 * (1024 + 8 + 4 * renderer.num_neighbor + 21) + 64
+        free, _ = torch.cuda.mem_get_info(device)
+        fit = int(free * 0.6) // per_ray // ray_chunk * ray_chunk
+        device_chunk = min(device_chunk, max(ray_chunk, fit))
+    return max(int(device_chunk), 1)
+
+
 def render_image(renderer, particle_pos, N_ray, ro, rays, focal_length=None, cw=None, iseval=False, ray_chunk=1024,
                  rank=0, world=1, gather=True, device_chunk=None, camera=None, timings=None):
     """Same result dict as the reference: pred_rgbs_0/1 (N_ray,3), num_nn_0/1 (N_ray*S), mask_0/1 (N_ray,1) if iseval.
@@ -61,9 +76,24 @@ def render_image(renderer, particle_pos, N_ray, ro, rays, focal_length=None, cw=
     else:
         my_rays, my_ro = rays[:N_ray], ro
     parts = {k: [] for k in keys}
-    for i in range(0, my_rays.shape[0], device_chunk):
-        res = renderer(particle_pos, my_ro[i:i + device_chunk] if per_ray_ro else my_ro, my_rays[i:i + device_chunk],
-                       focal_length, cw)
+    device_chunk = _fit_device_chunk(renderer, device_chunk, ray_chunk, my_rays.device)
+    i = 0
+    while i < my_rays.shape[0]:
+        try:
+            res = renderer(particle_pos, my_ro[i:i + device_chunk] if per_ray_ro else my_ro, my_rays[i:i + device_chunk],
+                           focal_length, cw)
+        except torch.cuda.OutOfMemoryError:
+            # the row buffers of a fused call scale with its ACTIVE samples, which only the device knows: a call that does not
+            # fit is redone at half the size (results are chunk-independent bit for bit) and the module remembers the bound
+            if device_chunk <= ray_chunk:
+                raise
+            device_chunk = max(ray_chunk, device_chunk // 2 // ray_chunk * ray_chunk)
+            renderer._device_chunk_limit = device_chunk
+            if getattr(renderer, "_workspace", None) is not None:
+                renderer._workspace = None          # drop the arena that grew towards the failed size
+            torch.cuda.empty_cache()
+            continue
+        i += device_chunk
         for key in keys:
             raw = res.raw_int32(key) if key.startswith("num_nn") and hasattr(res, "raw_int32") else None
             if raw is not None:             # the kernels' int32 counts: widened to the reference's int64 when first read

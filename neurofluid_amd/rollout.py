@@ -34,12 +34,16 @@ class CoupledRollout:
             self._pending.result()
             self._pending = None
 
-    def next_state(self, then=None):
+    def next_state(self, then=None, last=False):
         """(pos, vel, num_neighbors) of the next frame.  The step AFTER it is enqueued at once, from this state — or from `then` = (pos, vel)
-        when the caller knows the rollout restarts there (a benchmark that returns to the initial cloud every few frames)."""
+        when the caller knows the rollout restarts there (a benchmark that returns to the initial cloud every few frames).
+        last=True: this is the rollout's final frame — nothing is enqueued behind it (start() begins a new rollout)."""
         if self._pending is None:
             raise RuntimeError("CoupledRollout.next_state before start()")
         pos, vel, nn = self._pending.result()
+        if last:
+            self._pending = None
+            return pos, vel, nn
         src = (pos, vel) if then is None else then
         # the next step's inputs were produced on the side stream itself (or, `then`, before this call): it must NOT wait for the frame the
         # caller's stream is still rendering — it is meant to run beside it

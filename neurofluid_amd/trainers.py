@@ -489,6 +489,12 @@ class E2ETrainer(BaseTrainer):
                         self.update_step(loss, global_step)
                     global_step += 1; done += 1
                     if (global_step + 1) % o.TRAIN.save_interval == 0:
+                        # the transition replicas are kept equal by determinism alone (update_step): verify before rank 0's copy
+                        # becomes THE checkpoint, and re-seed the others from it if a replica drifted
+                        if not nfdist.replicas_in_sync(self.transition_model.parameters(), self.world):
+                            self.replica_resyncs = getattr(self, 'replica_resyncs', 0) + 1
+                            if self.rank == 0:
+                                print(f'[e2e] step {global_step}: transition-model replicas differed; re-broadcast from rank 0')
                         self.eval(global_step)
                         self.save_checkpoint(global_step)
                     if max_steps is not None and done >= max_steps:
@@ -556,7 +562,9 @@ class E2ETrainer(BaseTrainer):
             self.transition_optimizer.zero_grad()
         loss.backward()
         # renderer gradients: one flat-bucket all-reduce (5.35 MB); the transition model's are already identical on every rank
-        # (its only upstream gradient, dL/d pred_pos, was averaged by train_step's hook: SURVEY 8e)
+        # (its only upstream gradient, dL/d pred_pos, was averaged by train_step's hook: SURVEY 8e).  REQUIREMENT: the transition
+        # forward / backward must be bitwise deterministic on every rank (true of nf_cconv / nf_gemm: no float atomics, index-sorted
+        # grid; capacity redos replay the same sums) — train() checks the replicas' bits at every checkpoint (dist.replicas_in_sync)
         nfdist.allreduce_grads(list(self.renderer.parameters()), self.world)
         if clip != 0:
             torch.nn.utils.clip_grad_norm_(self.renderer.parameters(), clip)
@@ -591,6 +599,10 @@ class E2ETrainer(BaseTrainer):
         return dists
 
 
+def _same_tensor(a, b):
+    return a is b or (a.shape == b.shape and a.dtype == b.dtype and bool(torch.equal(a, b)))
+
+
 # ================================================================================================
 class E2EEvaluator(BaseTrainer):
     """eval_e2e.py:24-160: roll the transition model over the test frames, render every frame from every test view."""
@@ -614,15 +626,25 @@ class E2EEvaluator(BaseTrainer):
         from .rollout import CoupledRollout
         roll = None
         with torch.no_grad():
-            for data_idx in range(len(self.test_dataset)):
-                data = self._to_dev(self.test_dataset[data_idx])
+            n_frames = len(self.test_dataset)
+            box_dev = None
+            for data_idx in range(n_frames):
+                data = self._to_dev(self.test_dataset[data_idx])       # (an unchanged container comes back as the SAME device tensors)
                 if data_idx == 0:
                     # the rollout (eval_e2e.py:75-84: pos, vel = transition_model(pos, vel, box, box_normals) in front of every frame) with the step
                     # of frame t + 1 in flight on a side stream while frame t is measured, dumped and rendered (rollout.CoupledRollout: same
-                    # states bit for bit).  The container of a scene is static (datasets: one box.pt per scene): the first frame's is kept.
+                    # states bit for bit).  The lookahead assumes the NEXT frame's container is this frame's (datasets: one box.pt per scene)
                     roll = CoupledRollout(self.transition_model, data['box'], data['box_normals'], device=self.device)
                     roll.start(data['particles_pos'], data['particles_vel'])
-                pos, vel, _ = roll.next_state()
+                    box_dev = (data['box'], data['box_normals'])
+                elif not (_same_tensor(data['box'], box_dev[0]) and _same_tensor(data['box_normals'], box_dev[1])):
+                    # a per-frame container (the reference passes data['box'] of EVERY frame, eval_e2e.py:72-77): the step in flight was
+                    # computed against the previous frame's box — discard it and redo this frame's step with its own container
+                    roll.drop()
+                    roll = CoupledRollout(self.transition_model, data['box'], data['box_normals'], device=self.device)
+                    roll.start(pos, vel)
+                    box_dev = (data['box'], data['box_normals'])
+                pos, vel, _ = roll.next_state(last=data_idx == n_frames - 1)
                 dists.append(self.fluid_error.cal_errors(pos, data['particles_pos_1'], data_idx + 1))
                 if dump and self.rank == 0:
                     for sub, p, col in (('Pred', pos, (255, 0, 0)), ('GT', data['particles_pos_1'], (3, 168, 158))):

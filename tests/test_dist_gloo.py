@@ -49,6 +49,18 @@ def _worker(rank, world, port, n_rays, chunk, q):
     p.grad = torch.full((5,), float(rank + 1))
     nfdist.allreduce_grads([p], world)
     ok = ok and torch.allclose(p.grad, torch.full((5,), (1 + world) / 2))
+    # replicas that are kept equal by determinism alone (the e2e trainer's transition model): equal bits pass, a drifted replica is seen
+    # on EVERY rank and re-seeded from rank 0
+    m = torch.nn.Linear(4, 3)
+    with torch.no_grad():
+        for t in m.parameters():
+            t.copy_(torch.arange(t.numel(), dtype=torch.float32).view_as(t) * 0.25)
+    ok = ok and nfdist.replicas_in_sync(m.parameters(), world)
+    if rank == world - 1:
+        with torch.no_grad():
+            m.bias[1] += 1e-7 * 4           # one ulp-sized difference on one rank
+    ok = ok and not nfdist.replicas_in_sync(m.parameters(), world)
+    ok = ok and nfdist.replicas_in_sync(m.parameters(), world) and float(m.bias[1]) == 0.25
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()

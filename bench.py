@@ -42,9 +42,9 @@ F32_MATRIX_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f3
 F16_MATRIX_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense fp16 MFMA
 F32_VECTOR_PEAK_TFLOPS = 157.3
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s
-PMC_FILES = ("round5_mlp_pmc.json", "round4_mlp_pmc.json", "round3_mlp_pmc.json", "round2_mlp_pmc.json", "round1_mlp_pmc.json")      # newest first
-TRANS_PMC_FILES = ("round5_transition_pmc.json", "round4_transition_pmc.json", "round3_transition_pmc.json", "round2_transition_pmc.json")
-TRANS_STATS_FILES = ("round4_transition_kernel_stats.csv", "round3_transition_kernel_stats.csv", "round2_transition_kernel_stats.csv")
+PMC_FILES = ("round6_mlp_pmc.json", "round5_mlp_pmc.json", "round4_mlp_pmc.json", "round3_mlp_pmc.json", "round2_mlp_pmc.json", "round1_mlp_pmc.json")      # newest first
+TRANS_PMC_FILES = ("round6_transition_pmc.json", "round5_transition_pmc.json", "round4_transition_pmc.json", "round3_transition_pmc.json", "round2_transition_pmc.json")
+TRANS_STATS_FILES = ("round6_transition_kernel_stats.csv", "round5_transition_kernel_stats.csv", "round4_transition_kernel_stats.csv", "round3_transition_kernel_stats.csv", "round2_transition_kernel_stats.csv")
 
 
 def renderer_cfg():
@@ -564,6 +564,15 @@ def main():
     split_extra = None
     alt_strided = {}            # every 160th ray of the reduced-precision frames: checked against the oracle sample by cpu_baseline
     if args.workload == "render" and not args.no_extras:
+        # the fp32 frame the reduced-precision frames are compared with: the SAME cloud (P0) through the fp32 path.  (The headline's last
+        # frame is a frame of the coupled rollout, i.e. of a cloud that has moved: comparing with it measured the motion, not the arithmetic.)
+        with torch.no_grad():
+            net.invalidate_grid()
+            out_p0 = render_image(net, P0, n_rays, roc, rays, None, None, iseval=True, ray_chunk=args.chunk,
+                                  rank=rank, world=world, gather=False, device_chunk=device_chunk)
+            out_p0 = {k: out_p0[k].clone() for k in ("pred_rgbs_0", "pred_rgbs_1")}
+        sync()
+
         def alt_path(dtype):
             cfg = renderer_cfg(); cfg["mlp_dtype"] = dtype
             neta = RenderNet(cfg, 9.0, 13.0)
@@ -590,14 +599,14 @@ def main():
             ops.PROFILE = None
             msa = sum(a.elapsed_time(b) for a, b in pa["mlp"])
             acha = sum(pa["rows"]) * MLP_FLOP_PER_ROW / (msa * 1e-3) / 1e12 if msa > 0 else 0.0
-            diff = (outa["pred_rgbs_1"] - out["pred_rgbs_1"])
+            diff = (outa["pred_rgbs_1"] - out_p0["pred_rgbs_1"])
             mse = torch.mean(diff ** 2).item()
             # coarse image: same sample positions on both paths (pure MLP + compositing difference); fine image: also the
             # inverse-CDF resampling, which is discontinuous in the coarse weights (a sample may move one bin: isolated
             # pixels move by ~1e-3 for ANY change of rounding, the fp32 GPU path vs the CPU oracle included)
             return {"rays_per_sec": n_rays / dta, "ms_per_step": dta * 1e3, "ms_per_step_all": [round(t * 1e3, 3) for t in per_step],
                     "psnr_vs_f32_path_db": (-10.0 * math.log10(mse)) if mse > 0 else float("inf"),
-                    "max_abs_rgb_diff_vs_f32_path_coarse_image": float((outa["pred_rgbs_0"] - out["pred_rgbs_0"]).abs().max()),
+                    "max_abs_rgb_diff_vs_f32_path_coarse_image": float((outa["pred_rgbs_0"] - out_p0["pred_rgbs_0"]).abs().max()),
                     "max_abs_rgb_diff_vs_f32_path_fine_image": float(diff.abs().max()),
                     "pixels_fine_image_beyond_2e-4": int((diff.abs().max(dim=1).values > 2e-4).sum()),
                     "mlp_tflops_row_equivalent": acha,
@@ -704,9 +713,9 @@ def main():
                          "roofline": {"bound": "mfma", "achieved": flop / dte / 1e12, "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                                       "frac": flop / dte / 1e12 / F32_MATRIX_PEAK_TFLOPS,
                                       "note": "whole-step wall time against the matrix FLOP of both models (MLP rows x 3 x 1 331 968 + "
-                                              "particles x 3 x 1 385 088); kernel-level evidence: profiles/round4_e2e_kernel_stats.csv"},
-                         "note": "launch-bound: a step is a chain of ~170 launches of a few microseconds to 0.17 ms (tools/e2e_perf.py, "
-                                 "tools/e2e_opcount.py)"}
+                                              "particles x 3 x 1 385 088); kernel-level evidence: profiles/round6_e2e_kernel_stats.csv"},
+                         "note": "a chain of dependent launches of a few microseconds to 0.2 ms, most of them inside two HIP-graph replays "
+                                 "(`launches_per_step` counts them; tools/e2e_perf.py has the phase breakdown)"}
             del tr
         finally:
             shutil.rmtree(root, ignore_errors=True)

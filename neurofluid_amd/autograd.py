@@ -69,6 +69,11 @@ def _run_passes(net, particles, ro, rays, white_bg, fine, save_acts, _retry=Fals
                          noise=nz0)
     p0.packed = pk0
     p0.z = z0
+    if capture is not None and capture.get("after_coarse") is not None:
+        # the captured training step starts the coarse pass's backward HERE, on a side stream (its loss term needs nothing from the
+        # fine pass): it runs under the fine pass's sampling / search / feature launches and beside its forward MLP
+        p0.n_active, p0.graph_mode = p0.cap, True
+        capture["after_coarse"](p0, rays_c, ro_c, z0, None if z0 is not None else z_table)
     p1 = None
     if fine:
         if pu1 is not None:

@@ -410,6 +410,11 @@ def _tg_prepare(pn, pos, vel, box, box_feats):
     return tg
 
 
+# The graph-replayed backward hands its gradient buffers to the parameters directly (see _GraphedParticleNetFn.backward); False = through
+# autograd's AccumulateGrad (a clone per parameter).  Parameters with tensor hooks always take the autograd route.
+GRAPH_GRADS_DIRECT = True
+
+
 class _GraphedParticleNetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pn, tg, pos, vel, *params):
@@ -463,7 +468,26 @@ class _GraphedParticleNetFn(torch.autograd.Function):
         if b["graph"] is None:
             with torch.no_grad():
                 return (None, None, None, None) + _trans_backward(pn, aux, tg.box_feats, (False, False, False), gp, gv)[3]
+        params = _pn_params(pn)
+        direct = GRAPH_GRADS_DIRECT and all(p.is_leaf and not p._backward_hooks and not getattr(p, "_post_accumulate_grad_hooks", None)
+                                            for p in params)
+        if direct:
+            # A gradient that autograd accumulates into a leaf is CLONED when somebody else holds the tensor (the graph does): 17 copy
+            # launches per step.  The replayed backward's output buffers are handed to the parameters as their .grad instead — they
+            # stay valid until the next replay, i.e. through clip + optimiser step of this iteration.  A .grad left over from an
+            # earlier backward (no zero_grad in between) is accumulated into; if it IS one of the graph's buffers it is moved out
+            # first, so the replay cannot overwrite what was accumulated.
+            for p_, g_ in zip(params, b["out"][3]):
+                if p_.grad is not None and p_.grad.data_ptr() == g_.data_ptr():
+                    p_.grad = p_.grad.clone()
         b["graph"].replay()
+        if direct:
+            for p_, g_ in zip(params, b["out"][3]):
+                if p_.grad is None:
+                    p_.grad = g_
+                else:
+                    p_.grad.add_(g_)
+            return (None, None, None, None) + (None,) * len(params)
         return (None, None, None, None) + b["out"][3]
 
 

@@ -674,6 +674,15 @@ def test_graph_replayed_training_step_equals_eager(dev):
         assert torch.equal(ga.conv0_fluid.nns.neighbors_index, ea.conv0_fluid.nns.neighbors_index)
         p, v = pe, ve
     assert getattr(ga, "_tgraphs", None) is not None and ga._tgraphs.serial >= 3          # the graphs did run (step 0 learnt the capacities)
+    # the replayed backward hands its gradient buffers to the parameters directly (no clone per parameter): a .grad that is NOT zeroed
+    # between two backward passes must still accumulate, although the second replay rewrites the very buffers the first one handed over
+    ga.zero_grad(); ea.zero_grad()
+    for _ in range(2):
+        for m in (ga, ea):
+            m(p, v, box, bn)[0].square().mean().backward()
+    for (name, a), (_, b) in zip(ga.named_parameters(), ea.named_parameters()):
+        if a.grad is not None:
+            assert torch.equal(a.grad, b.grad), ("accumulated", name)
     # one outstanding forward per backward
     a1 = ga(p, v, box, bn)[0]
     a2 = ga(p, v, box, bn)[0]

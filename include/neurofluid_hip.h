@@ -469,6 +469,12 @@ int nf_host_wait_word(const volatile int32_t* word /*[host] page-locked*/, int32
 int nf_gather_view_pixels(int n_views, const float* const* rays, const float* const* rgb, const float* const* c2w, int per_view, int rgb_c,
                           int64_t n_pixels, const int64_t* flat, float* rays_out, float* rgb_out, float* ro_out, nf_stream_t stream);
 
+/* The same gather with the views' pointers in DEVICE memory: table[3 v + {0, 1, 2}] = the 64-bit device addresses of view v's rays, rgb, c2w.
+ * A step replayed as a HIP graph bakes its launch arguments; the frame it draws from changes per step (trainer/trainer_e2e.py:189-236
+ * walks the sequence's frames), so the caller rewrites the table instead. */
+int nf_gather_view_pixels_tab(int n_views, const uint64_t* table /*device, 3 * n_views*/, int per_view, int rgb_c, int64_t n_pixels,
+                              const int64_t* flat, float* rays_out, float* rgb_out, float* ro_out, nf_stream_t stream);
+
 /* out_x = x * *scale for up to three contiguous float buffers (any of them empty; out_x == x allowed), *scale one float in device memory: the fused
  * loss's backward scales its three gradients by the upstream gradient in one launch. */
 int nf_scale3(const float* a, int64_t na, const float* b, int64_t nb, const float* c, int64_t nc, const float* scale, float* out_a, float* out_b,
@@ -534,6 +540,12 @@ int nf_adam_step_dev(int count, float* const* params /*[host]*/, const float* co
  * address (nf_pinned_device_ptr) of 64 mapped host words = 8 records; step s writes record s & 7, word 2 (= s + 1) last. */
 int nf_note_overflow(const int32_t* count0, int cap0, const int32_t* count1, int cap1, int32_t* state, int32_t* host_ring,
                      nf_stream_t stream);
+
+/* nf_note_overflow over up to four (count, capacity) pairs (the end-to-end step: two render passes' rows + the transition step's two
+ * pair totals).  counts: HOST array of 4 device pointers (NULL = unused), caps: HOST array of 4; state: 7 device words = {poisoned,
+ * first poisoned step, step counter, count[0..3]}; host_ring as above (words 3..6 = the counts). */
+int nf_note_overflow4(const int32_t* const* counts /*[host] 4*/, const int32_t* caps /*[host] 4*/, int32_t* state, int32_t* host_ring,
+                      nf_stream_t stream);
 
 /* The loss of the end-to-end training step (trainer/trainer_e2e.py:264-280; trainer/basetrainer.py:108-116, :136 for the boundary
  * term) and its gradients for a unit upstream gradient, ONE launch:

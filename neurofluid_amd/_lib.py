@@ -159,6 +159,8 @@ PROTOTYPES = {
     "nf_adam_step_dev": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_double, ctypes.c_double,
                                  c_float, c_float, c_void_p]),
     "nf_note_overflow": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "nf_note_overflow4": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nf_gather_view_pixels_tab": (c_int, [c_int, c_void_p, c_int, c_int, ctypes.c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nf_e2e_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_float,
                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nf_trans_step": (c_int, [ctypes.POINTER(TransStep), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,

@@ -44,9 +44,11 @@ def _pack_bwd(nerf, cx, cd, dev, n_layout=True):
     return out_n
 
 
-def _pass_backward(net, nerf, pb, rays_c, z, z_table, g_rgb, white_bg, particles=None, ro_c=None, dparticles=None):
+def _pass_backward(net, nerf, pb, rays_c, z, z_table, g_rgb, white_bg, particles=None, ro_c=None, dparticles=None, wgrad_on=None):
     """Returns the 24 parameter gradients (12 weights, 12 biases) of one NeRF for one render pass; when
-    `dparticles` is given also accumulates dL/d(particle positions) into it (e2e training)."""
+    `dparticles` is given also accumulates dL/d(particle positions) into it (e2e training).
+    wgrad_on: a stream for the weight-gradient launch (it forks behind the data-gradient kernel; the CALLER joins it) — nothing on the
+    way to dL/d particles waits for the weight gradients, so the end-to-end step's transition backward can start while they run."""
     lib = _lib.load()
     st = _lib.stream()
     dev = rays_c.device
@@ -87,15 +89,31 @@ def _pass_backward(net, nerf, pb, rays_c, z, z_table, g_rgb, white_bg, particles
                                     ptr(pb.rgbsigma), ptr(d_rs), ptr(dpre_full), st), "nf_nerf_mlp_bwd_n")
     # weight gradients: one batched fp32-MFMA launch for all 15 GEMMs of the net (nf_nerf_wgrad)
     nsl = 21          # 12 jobs (workgroups of up to four 128 x 128 tiles that share operand blocks) x 21 row slices = 252 workgroups, one per CU
-    blob = torch.empty(lib.nf_nerf_wgrad_floats(cx, cd), dtype=torch.float32, device=dev)
-    wsp = torch.empty(lib.nf_nerf_wgrad_workspace_floats(cx, cd, nsl), dtype=torch.float32, device=dev)
-    colsum = torch.empty(DPRE, dtype=torch.float32, device=dev)
-    if getattr(pb, "graph_mode", False):        # a captured step: n is the CAPACITY, the true count is read on the device (same slicing, same sums)
-        check(lib.nf_nerf_wgrad_dev(ptr(dpre_full), ptr(pb.acts), ptr(pb.X), cx, cd, ptr(pb.n_rows), n, nsl, ptr(wsp), ptr(blob), ptr(colsum), st),
-              "nf_nerf_wgrad_dev")
+
+    def launch_wgrad():
+        st_ = _lib.stream()
+        blob = torch.empty(lib.nf_nerf_wgrad_floats(cx, cd), dtype=torch.float32, device=dev)
+        wsp = torch.empty(lib.nf_nerf_wgrad_workspace_floats(cx, cd, nsl), dtype=torch.float32, device=dev)
+        colsum = torch.empty(DPRE, dtype=torch.float32, device=dev)
+        if getattr(pb, "graph_mode", False):        # a captured step: n is the CAPACITY, the true count is read on the device (same slicing, same sums)
+            check(lib.nf_nerf_wgrad_dev(ptr(dpre_full), ptr(pb.acts), ptr(pb.X), cx, cd, ptr(pb.n_rows), n, nsl, ptr(wsp), ptr(blob), ptr(colsum), st_),
+                  "nf_nerf_wgrad_dev")
+        else:
+            check(lib.nf_nerf_wgrad(ptr(dpre_full), ptr(pb.acts), ptr(pb.X), cx, cd, n, nsl, ptr(wsp), ptr(blob), ptr(colsum), st_),
+                  "nf_nerf_wgrad")
+        return blob, colsum
+
+    if wgrad_on is not None:
+        here = torch.cuda.current_stream(dev)
+        wgrad_on.wait_stream(here)                  # dpre is complete behind everything enqueued here so far
+        with torch.cuda.stream(wgrad_on):
+            blob, colsum = launch_wgrad()
+        for t_ in (dpre_full, pb.acts, pb.X):       # read by the fork: their blocks must not be handed out again before it is done
+            if t_ is not None:
+                t_.record_stream(wgrad_on)
+        blob.record_stream(here); colsum.record_stream(here)
     else:
-        check(lib.nf_nerf_wgrad(ptr(dpre_full), ptr(pb.acts), ptr(pb.X), cx, cd, n, nsl, ptr(wsp), ptr(blob), ptr(colsum), st),
-              "nf_nerf_wgrad")
+        blob, colsum = launch_wgrad()
     gw, o = [], 0
     for l in layers:
         k = l.weight.numel()
@@ -121,11 +139,16 @@ def _pass_backward(net, nerf, pb, rays_c, z, z_table, g_rgb, white_bg, particles
 
 
 TWO_STREAM_BACKWARD = True
+# End-to-end step (particles need a gradient): the two passes' weight-gradient launches run on a third stream that is joined when the
+# WHOLE backward is over (an engine callback), so the transition model's backward — which needs dL/d particles only — starts ~0.3 ms
+# earlier instead of behind them.  Only when no parameter holds a .grad yet (an accumulation into an existing .grad would be enqueued
+# on the backward's own stream, ahead of the join).
+WGRAD_SIDE_STREAM = True
 _SIDE = {}
 
 
-def _side_stream(device):
-    key = (device.type, device.index)
+def _side_stream(device, which=0):
+    key = (device.type, device.index, which)
     if key not in _SIDE:
         _SIDE[key] = torch.cuda.Stream(device=device)
     return _SIDE[key]
@@ -163,19 +186,25 @@ class _RenderFn(torch.autograd.Function):
     def backward(ctx, *grads):
         g = dict(zip(ctx.keys, grads))
         dpart = torch.zeros_like(ctx.pts) if ctx.particles_need_grad else None
+        wside = None
+        if ctx.particles_need_grad and WGRAD_SIDE_STREAM and all(p.grad is None for p in _nerf_params(ctx.net)):
+            wside = _side_stream(ctx.pts.device, 1)
         gc, gf = render_backward(ctx.net, ctx.p0, ctx.p1 if ctx.fine else None, ctx.rays_c, g.get("rgb0"), g.get("rgb1") if ctx.fine else None,
-                                 ctx.white_bg, ctx.use_disp, particles=ctx.pts, ro_c=ctx.ro_c, dparticles=dpart)
+                                 ctx.white_bg, ctx.use_disp, particles=ctx.pts, ro_c=ctx.ro_c, dparticles=dpart, wgrad_on=wside)
+        if wside is not None:
+            here = torch.cuda.current_stream(ctx.pts.device)
+            torch.autograd.Variable._execution_engine.queue_callback(lambda: here.wait_stream(wside))
         return (None, dpart, None, None, None, None) + tuple(gc) + tuple(gf)
 
 
-def render_backward(net, p0, p1, rays_c, g_rgb0, g_rgb1, white_bg, use_disp=False, particles=None, ro_c=None, dparticles=None):
+def render_backward(net, p0, p1, rays_c, g_rgb0, g_rgb1, white_bg, use_disp=False, particles=None, ro_c=None, dparticles=None, wgrad_on=None):
     """The renderer's backward from the pass buffers of a training forward (_run_passes(save_acts=True)): the 24 parameter gradients of
     each NeRF (None where a pass received no gradient), dL/d particles accumulated into `dparticles` when given.  Used by the autograd
     Function above and, directly, by the captured training step (train_step.GraphedRendererStep: no autograd engine inside the graph)."""
     z_table, _ = net._tables(rays_c.device, use_disp)
     z0 = getattr(p0, "z", None)                  # perturb > 0: the coarse pass ran on per-ray depths
     zt0 = None if z0 is not None else z_table
-    extra = dict(particles=particles, ro_c=ro_c, dparticles=dparticles)
+    extra = dict(particles=particles, ro_c=ro_c, dparticles=dparticles, wgrad_on=wgrad_on)
     fine = p1 is not None
     both = g_rgb0 is not None and fine and g_rgb1 is not None and TWO_STREAM_BACKWARD
     if both:

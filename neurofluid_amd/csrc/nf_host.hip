@@ -228,6 +228,41 @@ __global__ void k_note_overflow(const int* __restrict__ c0, int cap0, const int*
     }
 }
 
+// The same bookkeeping over up to FOUR (count, capacity) pairs — the end-to-end step replayed as a graph watches the two render passes'
+// active rows AND the transition step's two neighbour-pair totals.  state = {poisoned, first poisoned step, step counter, count[0..3]};
+// the host record carries the same words (word 2 last).
+struct NfOverflow4 { const int* c[4]; int cap[4]; };
+__global__ void k_note_overflow4(NfOverflow4 A, int* __restrict__ state, volatile int* host_ring)
+{
+    int n[4];
+    bool over = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { n[k] = A.c[k] ? *A.c[k] : 0; over |= n[k] > A.cap[k]; }
+    const int step = state[2];
+    if (over && !state[0]) { state[0] = 1; state[1] = step; }
+    state[2] = step + 1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) state[3 + k] = n[k];
+    if (host_ring) {
+        volatile int* h = host_ring + (step & 7) * 8;
+        h[0] = state[0]; h[1] = state[1];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) h[3 + k] = n[k];
+        __threadfence_system();
+        h[2] = step + 1;
+    }
+}
+
+extern "C" int nf_note_overflow4(const int32_t* const* counts, const int32_t* caps, int32_t* state, int32_t* host_ring, nf_stream_t stream)
+{
+    NF_CHECK_ARG(counts && caps && state, "null pointer");
+    NfOverflow4 A;
+    for (int k = 0; k < 4; ++k) { A.c[k] = (const int*)counts[k]; A.cap[k] = caps[k]; }
+    hipLaunchKernelGGL(k_note_overflow4, dim3(1), dim3(1), 0, (hipStream_t)stream, A, (int*)state, (volatile int*)host_ring);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
 extern "C" int nf_note_overflow(const int32_t* count0, int cap0, const int32_t* count1, int cap1, int32_t* state, int32_t* host_ring,
                                 nf_stream_t stream)
 {
@@ -388,6 +423,40 @@ extern "C" int nf_gather_view_pixels(int n_views, const float* const* rays, cons
     const int n = n_views * per_view;
     hipLaunchKernelGGL(k_gather_view_pixels, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, V, n_views, per_view, rgb_c,
                        (long long)n_pixels, (const long long*)flat, rays_out, rgb_out, ro_out);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+// The same gather with the views' pointers read from DEVICE memory: table[3 * v + {0, 1, 2}] = rays, rgb, c2w of view v (64-bit device
+// addresses).  For a training step that is replayed as a HIP graph while the frame it draws from changes from step to step
+// (train_e2e.py walks the frames of a sequence): the launch's arguments are baked into the graph, the table is rewritten per step.
+__global__ void __launch_bounds__(256) k_gather_view_pixels_tab(const unsigned long long* __restrict__ table, int n_views, int per_view, int rgb_c,
+                                                                long long n_pixels, const long long* __restrict__ flat, float* __restrict__ rays_out,
+                                                                float* __restrict__ rgb_out, float* __restrict__ ro_out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_views * per_view) return;
+    const int v = i / per_view;
+    long long px = flat[i];
+    if (px < 0 || px >= n_pixels) px = 0;
+    const float* r = (const float*)table[3 * v] + px * 6;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) rays_out[(size_t)i * 6 + c] = r[c];
+    const float* g = (const float*)table[3 * v + 1] + px * rgb_c;
+    for (int c = 0; c < rgb_c; ++c) rgb_out[(size_t)i * rgb_c + c] = g[c];
+    const float* cw = (const float*)table[3 * v + 2];
+    ro_out[(size_t)i * 3 + 0] = cw[3]; ro_out[(size_t)i * 3 + 1] = cw[7]; ro_out[(size_t)i * 3 + 2] = cw[11];
+}
+
+extern "C" int nf_gather_view_pixels_tab(int n_views, const uint64_t* table, int per_view, int rgb_c, int64_t n_pixels, const int64_t* flat,
+                                         float* rays_out, float* rgb_out, float* ro_out, nf_stream_t stream)
+{
+    NF_CHECK_ARG(table && flat && rays_out && rgb_out && ro_out, "null pointer");
+    NF_CHECK_ARG(n_views >= 1 && per_view >= 0 && rgb_c >= 1 && n_pixels >= 1, "bad sizes");
+    if (per_view == 0) return NF_OK;
+    const int n = n_views * per_view;
+    hipLaunchKernelGGL(k_gather_view_pixels_tab, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const unsigned long long*)table, n_views,
+                       per_view, rgb_c, (long long)n_pixels, (const long long*)flat, rays_out, rgb_out, ro_out);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }

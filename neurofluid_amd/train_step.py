@@ -115,16 +115,21 @@ class HipAdam(torch.optim.Adam):
         return tab
 
     # ---- the step inside a replayed HIP graph (GraphedRendererStep): the per-step scalars travel through device memory
-    def graph_scalars(self):
-        """(step_size, bc2_sqrt) of the NEXT step; advances the shared step counter as step() does.  None when this optimizer cannot run
-        from a graph (several groups, per-tensor step counts, non-default switches)."""
-        if len(self.param_groups) != 1 or not self._eligible():
+    def graph_scalars(self, gi=None):
+        """(step_size, bc2_sqrt) of the NEXT step of param group gi; advances the group's shared step counter as step() does.  None when the
+        group cannot run from a graph (per-tensor step counts, a parameter without a gradient, non-default switches).  gi=None: the
+        optimizer's only group (None if it has several)."""
+        if gi is None:
+            if len(self.param_groups) != 1:
+                return None
+            gi = 0
+        if not self._eligible():
             return None
-        group = self.param_groups[0]
+        group = self.param_groups[gi]
         ps = [p for p in group["params"] if p.grad is not None]
         if not ps or len(ps) != len(group["params"]):
             return None
-        tab = self._table(0, ps)
+        tab = self._table(gi, ps)
         if tab["step"] is None:
             return None
         beta1, beta2 = group["betas"]
@@ -132,19 +137,19 @@ class HipAdam(torch.optim.Adam):
         t = float(tab["step"])
         return float(group["lr"]) / (1.0 - beta1 ** t), (1.0 - beta2 ** t) ** 0.5
 
-    def graph_rewind(self, steps):
+    def graph_rewind(self, steps, gi=0):
         """Take back `steps` counter advances (replayed steps that were skipped on the device and are redone)."""
-        tab = self._tables.get(0)
+        tab = self._tables.get(gi)
         if tab is not None and tab["step"] is not None:
             tab["step"] -= steps
 
     @torch.no_grad()
-    def graph_enqueue(self, sched_dev, skip_dev):
-        """The step's launch with its scalars in device memory (nf_adam_step_dev); called under capture, after backward."""
+    def graph_enqueue(self, sched_dev, skip_dev, gi=0):
+        """The step's launch of param group gi with its scalars in device memory (nf_adam_step_dev); called under capture, after backward."""
         from . import _lib
-        group = self.param_groups[0]
+        group = self.param_groups[gi]
         ps = list(group["params"])
-        tab = self._table(0, ps)
+        tab = self._table(gi, ps)
         beta1, beta2 = group["betas"]
         for k, p in enumerate(ps):
             g = p.grad

@@ -9,6 +9,7 @@ One process per GPU: when launched through torch.distributed.run the full-image 
 and training all-reduces gradients (neurofluid_amd/dist.py)."""
 import json
 import os
+import sys
 import os.path as osp
 import random
 
@@ -462,6 +463,13 @@ class E2ETrainer(BaseTrainer):
         H, W = int(o.TRAIN.imgH // o.TRAIN.scale), int(o.TRAIN.imgW // o.TRAIN.scale)
         global_step, done, loss = self.start_step, 0, None
         self.transition_model.train(); self.renderer.train()
+        # Steady state: the WHOLE step replayed as one HIP graph (e2e_graph.GraphedE2EStep; TRAIN.e2e_graph: False keeps the eager step).
+        # The first steps of a run are eager: they learn the pair / row capacities the capture needs and create the optimiser state.
+        gstep = self.__dict__.get('_graph_step')
+        if gstep is None and bool(getattr(o.TRAIN, 'e2e_graph', True)):
+            from .e2e_graph import GraphedE2EStep
+            if GraphedE2EStep.eligible(self):
+                gstep = self._graph_step = GraphedE2EStep(self, H, W)
 
         # (The warm-up trainer draws its pixels one step ahead on a host thread.  Here that was measured a loss — 4.5 -> 6.9 ms
         # per step: this step is bound by the host's launch sequence, and a second Python thread costs it the GIL.)
@@ -472,6 +480,21 @@ class E2ETrainer(BaseTrainer):
                     data = self._frame_on_device(self.dataset, data_idx)
                     # everything a redone step must start from again: the carried state and EVERY random stream the step draws from
                     # (numpy: the pixel choice; torch CPU / device generators: noise_std / perturb draws of the renderer)
+                    if gstep is not None and self.__dict__.get('_eager_steps', 0) >= 3 and gstep.ready(data):
+                        loss = self._graph_train_step(gstep, data, data_idx, len(self.train_view_names), H, W, global_step)
+                        global_step += 1; done += 1
+                        if (global_step + 1) % o.TRAIN.save_interval == 0:
+                            gstep.verify()
+                            self.eval(global_step)
+                            self.save_checkpoint(global_step)
+                        if max_steps is not None and done >= max_steps:
+                            gstep.verify()
+                            return loss
+                        continue
+                    if gstep is not None:
+                        gstep.verify()
+                        gstep.invalidate_state()            # this step runs outside the graph: the carried state is the trainer's again
+                    self._eager_steps = self.__dict__.get('_eager_steps', 0) + 1
                     saved = (getattr(self, 'pos_for_next_step', None), getattr(self, 'vel_for_next_step', None), np.random.get_state(),
                              torch.get_rng_state(), torch.cuda.get_rng_state(self.device) if torch.cuda.is_available() else None)
                     try:
@@ -500,8 +523,25 @@ class E2ETrainer(BaseTrainer):
                     if max_steps is not None and done >= max_steps:
                         return loss
         finally:
+            if gstep is not None and sys.exc_info()[0] is None:
+                gstep.verify()                  # every enqueued step settled (a redo corrects the returned loss tensor in place)
             if not getattr(self, 'keep_frame_cache', False):      # (a caller that calls train() block by block — bench.py — keeps it)
                 self.release_frame_cache()      # the cached frames are only useful inside the epoch loop
+        return loss
+
+    def _graph_train_step(self, gstep, data, data_idx, view_num, H, W, global_step):
+        """train_step + update_step through the replayed graph: the same random draws in the same order (pixel grid, then one selection per
+        view), the schedulers stepped behind the launch, the logged distance read from the step's own prediction once it is verified."""
+        rc = self.options.RENDERER.ray.ray_chunk
+        coords = self.random_sample_coords(H, W, global_step)
+        sels = [choice_without_replacement(np.random, coords.shape[0], rc) for _ in range(view_num)]
+        loss = gstep.step(data, data_idx, coords, sels)
+        for s in self.schedulers:
+            s.step()
+        if (global_step + 1) % self.options.TRAIN.log_interval == 0:
+            gstep.verify()                      # a truncated (and redone) step must not reach the logged metric
+            d = self.tmp_fluid_error.cal_errors(gstep.pred_pos().detach(), data['particles_pos_1'], data_idx + 1)
+            self.summary_writer.add_scalar('Train/pred2gt_distance', d, global_step)
         return loss
 
     def trainsition_step_for_training(self, data, data_idx):

@@ -576,7 +576,9 @@ class ParticleNet(nn.Module):
             check(lib.nf_csr_clamp(ptr(f_rs), n, nnz_f, tot.data_ptr(), st), "nf_csr_clamp")
             check(lib.nf_csr_clamp(ptr(b_rs), n, nnz_b, tot.data_ptr() + 4, st), "nf_csr_clamp")
             if _capture is not None:        # under graph capture: the totals go to the caller's pinned words (a copy node), the
-                _capture["tot_pinned"].copy_(tot, non_blocking=True)      # caller compares them after the replay's event
+                _capture["tot_dev"] = tot   # caller compares them after the replay's event — or on the device (e2e_graph: nf_note_overflow4)
+                if _capture.get("tot_pinned") is not None:
+                    _capture["tot_pinned"].copy_(tot, non_blocking=True)
             else:
                 fetch = ops.HostFetch(pos.device)
                 fetch.add(tot)

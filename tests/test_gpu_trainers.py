@@ -80,6 +80,45 @@ def test_e2e_trainer_and_evaluator(workdir):
     assert (workdir / "exps" / "e2e_eval" / "images" / "fine" / "view_5" / "Pred" / "00001.png").exists()
 
 
+def test_graph_replayed_e2e_step_equals_eager(workdir):
+    """trainer_e2e.py's step replayed as ONE HIP graph (e2e_graph.GraphedE2EStep: transition forward, render, loss, backward through both
+    models, both parameter groups' Adam, the carried state) against the eager step from the same seed: after 11 steps over a 3-frame
+    sequence (the state restarts at frame 0 inside the replayed range) every parameter of both models, the carried state and the
+    last loss are BIT-equal; the graph did replay (steps 0-2 are eager: they learn the capacities)."""
+    import configs
+    from neurofluid_amd.trainers import E2ETrainer
+
+    def run(name, graph):
+        cfg = _cfg(workdir, configs.end2end_training_config, name)
+        cfg.TRAIN.epochs = 10
+        cfg.TRAIN.save_interval = 10 ** 9
+        cfg.TRAIN.e2e_graph = graph
+        tr = E2ETrainer(cfg)
+        loss = tr.train(max_steps=11)
+        torch.cuda.synchronize()
+        return tr, float(loss)
+    ea, le = run("e2e_eager", False)
+    gr, lg = run("e2e_graph", True)
+    g = gr._graph_step
+    assert g is not None and g.captures >= 1 and g.steps_total >= 6, (g and (g.captures, g.steps_total))
+    assert ea.__dict__.get("_graph_step") is None
+    assert le == lg
+    for m in ("renderer", "transition_model"):
+        for (name, a), (_, b) in zip(getattr(ea, m).named_parameters(), getattr(gr, m).named_parameters()):
+            assert torch.equal(a.detach(), b.detach()), (m, name)
+    assert torch.equal(ea.pos_for_next_step, gr.pos_for_next_step) and torch.equal(ea.vel_for_next_step, gr.vel_for_next_step)
+    # a capacity the graph was captured with is exceeded: the poisoned steps are redone, the trajectory is still the eager one
+    gr.renderer.train_row_cap = {k: max(64, v // 64) for k, v in gr.renderer.train_row_cap.items()}
+    g._recapture = True
+    gr.train(max_steps=4)              # (all four through the graph: the eager warm-up steps are per trainer, not per call)
+    ea.train(max_steps=4)
+    torch.cuda.synchronize()
+    assert g.redone_steps >= 1
+    for m in ("renderer", "transition_model"):
+        for (name, a), (_, b) in zip(getattr(ea, m).named_parameters(), getattr(gr, m).named_parameters()):
+            assert torch.equal(a.detach(), b.detach()), ("after redo", m, name)
+
+
 def test_transmodel_eval_and_train(workdir):
     import configs
     from neurofluid_amd.trainers import TransModelEvaluation, TransModelTrainer

@@ -691,6 +691,10 @@ def main():
             ops.PROFILE = None
             dte = sorted(blocks)[1]
             erows = sum(int(r.item()) if torch.is_tensor(r) else int(r) for r in pe["rows"]) / (3 * n_frames)
+            ge = tr.__dict__.get("_graph_step")
+            if ge is not None and ge.steps_total > 0:      # replayed steps do not pass through the Python that feeds ops.PROFILE: the step's own device-side counts
+                ge.verify()
+                erows = ge.rows_total / ge.steps_total
             nv, rc = len(tr.train_view_names), int(cfg.RENDERER.ray.ray_chunk)
             # launches and GPU-busy time of a step: four steps under torch.profiler (device activity only)
             def _four():
@@ -710,12 +714,15 @@ def main():
                          "launches_per_step": n_launch, "gpu_busy_ms_per_step": busy_ms,
                          "gpu_busy_fraction": (busy_ms / (dte * 1e3)) if busy_ms else None,
                          "pair_capacity_redos": int(getattr(tr.transition_model, "pair_capacity_redos", 0)),
+                         "replayed_as_hip_graph": bool(ge is not None and ge.steps_total > 0),
+                         "graph_captures": int(ge.captures) if ge is not None else 0,
+                         "graph_redone_steps": int(ge.redone_steps) if ge is not None else 0,
                          "roofline": {"bound": "mfma", "achieved": flop / dte / 1e12, "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                                       "frac": flop / dte / 1e12 / F32_MATRIX_PEAK_TFLOPS,
                                       "note": "whole-step wall time against the matrix FLOP of both models (MLP rows x 3 x 1 331 968 + "
                                               "particles x 3 x 1 385 088); kernel-level evidence: profiles/round6_e2e_kernel_stats.csv"},
-                         "note": "a chain of dependent launches of a few microseconds to 0.2 ms, most of them inside two HIP-graph replays "
-                                 "(`launches_per_step` counts them; tools/e2e_perf.py has the phase breakdown)"}
+                         "note": "the whole step is ONE HIP-graph replay (neurofluid_amd/e2e_graph.py); `launches_per_step` counts the kernels "
+                                 "and copies inside it as the device saw them (tools/e2e_perf.py has the phase breakdown)"}
             del tr
         finally:
             shutil.rmtree(root, ignore_errors=True)

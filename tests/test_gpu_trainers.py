@@ -91,7 +91,8 @@ def test_graph_replayed_e2e_step_equals_eager(workdir):
     def run(name, graph):
         cfg = _cfg(workdir, configs.end2end_training_config, name)
         cfg.TRAIN.epochs = 10
-        cfg.TRAIN.save_interval = 10 ** 9
+        cfg.TRAIN.save_interval = 6         # an evaluation + checkpoint in the middle of the replayed range
+        cfg.TRAIN.log_interval = 3          # logged steps verify (and read the step's own prediction) before the next replay
         cfg.TRAIN.e2e_graph = graph
         tr = E2ETrainer(cfg)
         loss = tr.train(max_steps=11)

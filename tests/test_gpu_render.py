@@ -56,6 +56,37 @@ def test_ball_query_exact(dev):
     assert (i_ref[:, -1] >= 0).sum() > 500 and (i_ref[:, 0] < 0).sum() > 100   # both regimes exercised
 
 
+def test_render_search_counts_exclude_zero_distance_hits(dev):
+    """models/renderer.py:135-138: nn_mask = dists.ne(0), num_nn = nn_mask.sum(-1) over the first-K set.  k_search counts the kept hits and
+    subtracts the zero-distance ones behind a wave-uniform test (they are rare): rays whose every sample COINCIDES with a particle
+    (direction 0, origin = the particle) next to ordinary rays, counts against the oracle's first-K lists, bit for bit."""
+    from neurofluid_amd import ops
+    from oracle import neighbors, render_oracle as ro
+    P = ro.watercube_particles()
+    g = torch.Generator().manual_seed(11)
+    pick = torch.randint(0, P.shape[0], (24,), generator=g)
+    on = torch.cat([P[pick], torch.zeros(24, 3)], 1)                                    # x = o + 0 * z = the particle, exactly
+    o = torch.tensor([0.0, 0.0, -11.0]) + 0.3 * torch.randn(40, 3, generator=g)
+    tgt = P[torch.randint(0, P.shape[0], (40,), generator=g)] + 0.05 * torch.randn(40, 3, generator=g)
+    d = tgt - o
+    d = d / d.norm(dim=1, keepdim=True)
+    rays = torch.cat([on, torch.cat([o, d], 1)])[torch.randperm(64, generator=g)].contiguous()
+    S, K, r = 64, 20, 0.225
+    out = ops.debug_features(P.to(dev), rays.to(dev), 9.0, 13.0, S, r, K, 15, torch.zeros(3, device=dev))
+    t = torch.linspace(0, 1, S)
+    z = 9.0 * (1 - t) + 13.0 * t
+    pts = (rays[:, None, :3] + rays[:, None, 3:] * z[None, :, None]).reshape(-1, 3)     # (d = 0 rows: exact; the others: mul + add, no contraction on CPU torch)
+    d_ref, i_ref, _ = neighbors.ball_query_firstk(pts.numpy(), P.numpy(), r, K)
+    want = ((d_ref != 0) & (i_ref >= 0)).sum(1)
+    got = out["num_nn"].cpu().numpy()
+    assert np.array_equal(got, want)
+    zero_rows = (rays[:, 3:].abs().sum(1) == 0).repeat_interleave(S).numpy()
+    # the coinciding particle is IN the first-K set only when its index is among the K lowest in range: some rays have it (K - 1), most do not (K)
+    zero_hits = ((d_ref == 0) & (i_ref >= 0)).sum(1)
+    assert zero_hits[zero_rows].sum() >= S and zero_hits[~zero_rows].sum() == 0
+    assert (want[zero_rows] == K - 1).sum() >= S and (want[zero_rows] == K).sum() >= S
+
+
 def test_ball_query_edge_cases(dev):
     from neurofluid_amd import ops
     from oracle import neighbors

@@ -47,8 +47,11 @@ def _run_passes(net, particles, ro, rays, white_bg, fine, save_acts, _retry=Fals
         fetch.add(grid.aabb_words())            # words 0..5: the cloud's bounds (the next grid's bbox hint), then one count per pass
         after = lambda n_rows: fetch.add(n_rows)
     opt = not _retry
+    pre = getattr(net, "_prepacked", None) if capture is not None else None     # captured steps pack every blob up front, beside the front-end kernels
+    pre0 = pre.get(id(net.nerf_coarse)) if pre else None
+    pre1 = pre.get(id(net.nerf_fine)) if pre else None
     if save_acts:
-        pk0, ws0, ph0 = net.packed_weights(net.nerf_coarse), None, None
+        pk0, ws0, ph0 = (pre0["pk"] if pre0 else net.packed_weights(net.nerf_coarse)), None, None
     else:
         pk0, ws0, ph0 = net.packed_for_inference(net.nerf_coarse, use_h)
     # Random draws, all up front and in the reference's order, so that a seeded generator gives the reference's numbers: the
@@ -66,7 +69,7 @@ def _run_passes(net, particles, ro, rays, white_bg, fine, save_acts, _retry=Fals
     p0 = ops.render_pass(grid, pts, rays_c, z0, None if z0 is not None else z_table, net.N_samples, net.raduis, net.num_neighbor, net.enc_flags,
                          net.use_mask, ro_c, pk0, net.in_channels_xyz, net.in_channels_dir, white_bg, save_acts,
                          packed_h=ph0, ws=ws, need_weights=fine, optimistic=opt, caps=caps, wstream=ws0, after_search=after,
-                         noise=nz0)
+                         noise=nz0, packed_n=pre0["pk_n"] if pre0 else None, pre_mlp=pre["join"] if pre else None)
     p0.packed = pk0
     p0.z = z0
     if capture is not None and capture.get("after_coarse") is not None:
@@ -81,13 +84,13 @@ def _run_passes(net, particles, ro, rays, white_bg, fine, save_acts, _retry=Fals
         else:
             z1 = ops.importance_sample(z_table, p0.weights, u_table, net.N_importance, net.zero_row(dev, use_disp))
         if save_acts:
-            pk1, ws1, ph1 = net.packed_weights(net.nerf_fine), None, None
+            pk1, ws1, ph1 = (pre1["pk"] if pre1 else net.packed_weights(net.nerf_fine)), None, None
         else:
             pk1, ws1, ph1 = net.packed_for_inference(net.nerf_fine, use_h)
         p1 = ops.render_pass(grid, pts, rays_c, z1, None, net.N_samples + net.N_importance, net.raduis, net.num_neighbor,
                              net.enc_flags, net.use_mask, ro_c, pk1, net.in_channels_xyz, net.in_channels_dir, white_bg,
                              save_acts, packed_h=ph1, ws=ws, need_weights=False, optimistic=opt, caps=caps, wstream=ws1,
-                             after_search=after, noise=nz1)
+                             after_search=after, noise=nz1, packed_n=pre1["pk_n"] if pre1 else None)
         p1.z = z1
         p1.packed = pk1
     # Inference passes ran against learnt row capacities without a host round trip: verify ONCE, here, with the whole

@@ -68,7 +68,8 @@ def _pass_backward(net, nerf, pb, rays_c, z, z_table, g_rgb, white_bg, particles
     else:
         check(lib.nf_composite_bwd(ptr(pb.rgbsigma), ptr(z), ptr(z_table), ptr(rays_c), ptr(g), None, pb.gate, R, S,
                                    int(white_bg), ptr(scratch), ptr(d_rs), ptr(pb.num_nn), pb.K, st), "nf_composite_bwd")
-    packed_t = _pack_bwd(nerf, cx, cd, dev)
+    pre = (getattr(net, "_prepacked", None) or {}).get(id(nerf))
+    packed_t = pre["bwd_n"] if pre else _pack_bwd(nerf, cx, cd, dev)
     # every row-sized temporary is allocated at the pass's bucketed capacity (ops._round_rows): the active-row count
     # changes from step to step, and exact sizes make the caching allocator grow by a fresh block per step (and give
     # the GEMM library a new problem size per step); a handful of capacity buckets are re-used instead
@@ -136,6 +137,42 @@ def _pass_backward(net, nerf, pb, rays_c, z, z_table, g_rgb, white_bg, particles
                                          ptr(pb.row_sample), ptr(pb.row_nbr), ptr(pb.n_rows), n, ptr(dX), ptr(dparticles),
                                          st), "nf_render_features_bwd")
     return gw + gb
+
+
+def prepack_for_capture(net, dev):
+    """Every weight blob a captured training step needs — forward blob, its tile-per-workgroup arrangement and the backward blob of both
+    NeRFs: 8 small launches that otherwise sit between dependent kernels on the step's critical path (pack -> classify, pack_n -> forward
+    MLP, pack_bwd -> pack_n -> backward MLP, per pass) — enqueued on a side stream at the top of the capture, beside the pixel gather and
+    the coarse pass's classify / search / feature kernels.  Sets net._prepacked (consulted by autograd._run_passes, ops.render_pass and
+    _pass_backward while net._capture is set); "join" makes the calling stream wait for them once, in front of the first MLP launch.
+    The caller clears net._prepacked when the capture body is done."""
+    lib = _lib.load()
+    cur = torch.cuda.current_stream(dev)
+    side = _side_stream(dev, 2)
+    side.wait_stream(cur)               # the parameters are final on the capturing stream (the previous step's Adam)
+    cx, cd = net.in_channels_xyz, net.in_channels_dir
+    pre = {}
+    with torch.cuda.stream(side):
+        for nerf in (net.nerf_coarse, net.nerf_fine):
+            pk = net.packed_weights(nerf)
+            pk_n = None
+            if ((cx + 7) // 8, (cd + 7) // 8) == (25, 7):
+                pk_n = torch.empty_like(pk)
+                check(lib.nf_nerf_pack_n(ptr(pk), cx, cd, ptr(pk_n), _lib.stream()), "nf_nerf_pack_n")
+            bwd_n = _pack_bwd(nerf, cx, cd, dev)
+            for t in (pk, pk_n, bwd_n):
+                if t is not None:
+                    t.record_stream(cur)
+            pre[id(nerf)] = {"pk": pk, "pk_n": pk_n, "bwd_n": bwd_n}
+    state = {"joined": False}
+
+    def join():
+        if not state["joined"]:
+            torch.cuda.current_stream(dev).wait_stream(side)
+            state["joined"] = True
+    pre["join"] = join
+    net._prepacked = pre
+    return pre
 
 
 TWO_STREAM_BACKWARD = True

@@ -106,6 +106,10 @@ class GraphedE2EStep:
         tr, net, pn = self.tr, self.net, self.pn
         V, rc, H, W, C = self.V, self.rc, self.H, self.W, self._C
         box, bn = self._box
+        from .train_step import PREPACK_IN_CAPTURE
+        if PREPACK_IN_CAPTURE:          # the renderer's weight blobs, packed on a side stream while the transition forward runs
+            from .autograd_bwd import prepack_for_capture
+            prepack_for_capture(net, self.dev)
         cap_state = {"tot_pinned": None, "total_fluid": lambda: self._total_fluid()}
         pos_c, vel_c, nn, aux = pn._forward_impl(self.pos_s, self.vel_s, box, bn, keep=True, _capture=cap_state)
         tot = cap_state["tot_dev"]
@@ -123,6 +127,8 @@ class GraphedE2EStep:
             p0, p1, rays_c, ro_c, grid = _run_passes(net, pos_c, ro, rays, True, fine, save_acts=True)
         finally:
             net._capture = None
+        if getattr(net, "_prepacked", None):
+            net._prepacked["join"]()        # (idempotent: normally done in front of the coarse MLP launch; a forked stream must be joined inside the capture)
         wb = float(tr.options.TRAIN.loss_weight['boundary_loss'])
         use_pos = wb != 0.0
         loss = torch.empty(1, dtype=torch.float32, device=self.dev)
@@ -160,7 +166,8 @@ class GraphedE2EStep:
         if fine:
             out["rgb1"] = p1.rgb
         # pred_pos: its own buffer (pos_c is an output of the update kernel; the static copy survives until the next replay)
-        self._keep = (out, rgbs, pos_c, nn, c, tot, p0, p1, aux, rgrads, tgrads, g_tot)
+        self._keep = (out, rgbs, pos_c, nn, c, tot, p0, p1, aux, rgrads, tgrads, g_tot, getattr(net, "_prepacked", None))
+        net._prepacked = None
         self.caps = [int(v) for v in k] + [int(pc[0]), int(pc[1])]
         return loss[0]
 
@@ -201,6 +208,7 @@ class GraphedE2EStep:
                 self.loss_static = self._body()
         finally:
             ops.PROFILE = prof
+            self.net._prepacked = None
         torch.cuda.synchronize(self.dev)
         # (the capture does not execute: the state buffers still hold what was written above)
         self.graph = g

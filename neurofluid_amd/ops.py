@@ -447,7 +447,7 @@ class HostFetch:
 
 def render_pass(grid, particles, rays, z, z_table, S, radius, K, enc_flags, use_mask, ro, packed, cx, cd,
                 white_bg=True, save_acts=False, max_rows=None, packed_h=None, ws=None, need_weights=True, wstream=None,
-                optimistic=False, caps=None, after_search=None, noise=None):
+                optimistic=False, caps=None, after_search=None, noise=None, packed_n=None, pre_mlp=None):
     """Runs classify -> search -> features -> MLP -> composite for R rays x S samples.
     z: (R,S) per-ray depths or None (then z_table (S,) is shared by all rays).
     Returns a PassBuffers with rgb, depth, opacity, weights, num_nn, mask_sum and the row lists.
@@ -549,6 +549,8 @@ def render_pass(grid, particles, rays, z, z_table, S, radius, K, enc_flags, use_
             # (nf_mlp_n.hip) — a third of the per-tile latency of the tile-per-wave kernel, bit-identical outputs.  (The
             # inference passes stay on the ring kernel at every size: its sums differ in the place of the bias, and results
             # must not depend on how a frame is cut into calls.)
+            if packed_n is not None:                        # packed ahead by the caller (a captured step: beside its front-end kernels)
+                b.packed_n = packed_n
             if getattr(b, "packed_n", None) is None:        # the tile-per-workgroup kernels' own arrangement of the blob
                 b.packed_n = torch.empty_like(packed)
                 check(lib.nf_nerf_pack_n(ptr(packed), cx, cd, ptr(b.packed_n), stream_), "nf_nerf_pack_n")
@@ -571,6 +573,8 @@ def render_pass(grid, particles, rays, z, z_table, S, radius, K, enc_flags, use_
         features(0, b.n_rows, max_rows, st)
         if PROFILE is not None:
             e0.record()
+        if pre_mlp is not None:
+            pre_mlp()               # e.g. the join with a stream that packed the weights while classify / search / features ran
         mlp(0, b.n_rows, max_rows, st)
         if PROFILE is not None:
             e1.record()

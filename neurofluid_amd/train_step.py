@@ -575,6 +575,11 @@ def renderer_train_step(renderer, optimizer, scheduler, particles, views, H, W, 
 EARLY_COARSE_BACKWARD = os.environ.get("NF_EARLY_COARSE_BACKWARD", "1") != "0"
 
 
+# Captured steps pack every weight blob at the top of the graph on a side stream (autograd_bwd.prepack_for_capture); False = where the eager
+# step packs them, between the dependent kernels.
+PREPACK_IN_CAPTURE = os.environ.get("NF_PREPACK_IN_CAPTURE", "1") != "0"
+
+
 class GraphedRendererStep:
     """The whole warm-up optimiser step (trainer/trainer_renderer.py:94-143: pixel gather -> coarse + fine forward -> loss -> backward ->
     Adam) captured ONCE as a HIP graph and replayed: per step the host uploads the pixel selection and the optimiser's two scalars
@@ -686,10 +691,15 @@ class GraphedRendererStep:
                 early["gc"], early["side"], early["keep"] = gc_, side, (l0, g0_)
             cap["after_coarse"] = after_coarse
         net._capture = cap
+        if PREPACK_IN_CAPTURE:
+            from .autograd_bwd import prepack_for_capture
+            prepack_for_capture(net, self.dev)
         try:
             p0, p1, rays_c, ro_c, grid = _run_passes(net, self.P, ro, rays, True, fine, save_acts=True)
         finally:
             net._capture = None
+        if getattr(net, "_prepacked", None):
+            net._prepacked["join"]()        # (idempotent: normally done in front of the coarse MLP launch; a forked stream must be joined inside the capture)
         loss = torch.empty(1, dtype=torch.float32, device=self.dev)
         g0 = torch.empty_like(p0.rgb)
         g1 = torch.empty_like(p1.rgb) if fine else None
@@ -713,7 +723,8 @@ class GraphedRendererStep:
         out = {"rgb0": p0.rgb}
         if fine:
             out["rgb1"] = p1.rgb
-        self._keep = (out, rgbs, c, p0, p1, grads, early.get("keep"))
+        self._keep = (out, rgbs, c, p0, p1, grads, early.get("keep"), getattr(net, "_prepacked", None))
+        net._prepacked = None
         self.caps = [int(v) for v in k]
         return loss[0]
 
@@ -735,6 +746,7 @@ class GraphedRendererStep:
                 self.loss_static = self._body()
         finally:
             ops.PROFILE = prof
+            self.net._prepacked = None
         torch.cuda.synchronize(self.dev)
         self.graph = g
         self.captures += 1

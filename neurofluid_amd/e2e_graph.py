@@ -121,12 +121,14 @@ class GraphedE2EStep:
         fine = net.N_importance > 0
         cap = {"counts": [], "caps": []}
         net.invalidate_grid()               # the particle grid is rebuilt INSIDE the graph (the cloud moves every step) ...
+        hint = net._bbox_hint
         net._bbox_hint = tuple(pn._scene_bbox(box))         # ... over the scene's static bounds (any bbox gives the same bits)
         net._capture = cap
         try:
             p0, p1, rays_c, ro_c, grid = _run_passes(net, pos_c, ro, rays, True, fine, save_acts=True)
         finally:
             net._capture = None
+            net._bbox_hint = hint           # (the eager callers' hint — the previous cloud's tight bounds — is theirs again)
         if getattr(net, "_prepacked", None):
             net._prepacked["join"]()        # (idempotent: normally done in front of the coarse MLP launch; a forked stream must be joined inside the capture)
         wb = float(tr.options.TRAIN.loss_weight['boundary_loss'])
@@ -165,7 +167,7 @@ class GraphedE2EStep:
         out = {"rgb0": p0.rgb}
         if fine:
             out["rgb1"] = p1.rgb
-        # pred_pos: its own buffer (pos_c is an output of the update kernel; the static copy survives until the next replay)
+        # (pos_c — the step's prediction — is a buffer of the graph's own pool: valid until the next replay; pred_pos() hands it out)
         self._keep = (out, rgbs, pos_c, nn, c, tot, p0, p1, aux, rgrads, tgrads, g_tot, getattr(net, "_prepacked", None))
         net._prepacked = None
         self.caps = [int(v) for v in k] + [int(pc[0]), int(pc[1])]

@@ -248,6 +248,17 @@ def committed_transition():
     return None
 
 
+def committed_fp16_mfma_busy():
+    """MFMA utilisation of the fp16 kernel as the counters see it (SQ_VALU_MFMA_BUSY_CYCLES / (4 SQ_WAVE_CYCLES)), from the COMMITTED rocprofv3
+    --pmc pass of the honeycone 800^2 fp16 frame; NOT measured by this run."""
+    path = os.path.join(ROOT, "profiles", "round6_mlp_ha_pmc.json")
+    if not os.path.exists(path):
+        return None
+    d = json.load(open(path))
+    return {"mfma_busy_over_wave_cycles": d.get("mfma_busy_over_wave_cycles"), "kernel": d.get("kernel"), "file": "profiles/round6_mlp_ha_pmc.json",
+            "git_blob": _git_blob(path), "note": "separate rocprofv3 --pmc pass of `tools/frame_prof.py fp16 6 honeycone800`, NOT measured by this run"}
+
+
 def imbalance(per_chunk_rows, world, interleaved=True):
     n = len(per_chunk_rows)
     loads = [0] * world
@@ -824,7 +835,10 @@ def main():
                  "first_pass": {"transition_steps_redone": int(ovf0), "renderer_calls_redone": int(redo0)},
                  "roofline": {"bound": "mfma", "kernel": "k_mlp_fwd_%s (v_mfma_f32_32x32x16_f16%s)" % (ops.FP16_KERNEL, ", hand-scheduled" if ops.FP16_KERNEL == "ha" else ""), "achieved": tfh, "peak": F16_MATRIX_PEAK_TFLOPS,
                               "unit": "TFLOP/s", "frac": tfh / F16_MATRIX_PEAK_TFLOPS, "mlp_ms_per_frame": msh / n_roll,
-                              "flop_per_row": MLP_FLOP_PER_ROW}}
+                              "flop_per_row": MLP_FLOP_PER_ROW, "mfma_utilisation_pmc": committed_fp16_mfma_busy(),
+                              "note": "frac = executed FLOP / time / the NOMINAL 2.5 PFLOP/s; the chip's fp16 matrix clock depends on operand "
+                                      "switching (bare MFMA loop: 2.48 PFLOP/s on zeros, 1.67 on random, 2.05 on post-ReLU-like operands, "
+                                      "profiles/round6_mfma_clock.txt), so the counters' MFMA utilisation is given beside it"}}
         cfg45_extra = {"bunny_800_fp32": bunny, "honeycone_800_fp16_rollout": honey}
         del net_h, pn_h, rays8
 

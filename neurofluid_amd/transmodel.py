@@ -497,7 +497,7 @@ class ParticleNet(nn.Module):
             check(rc, "nf_trans_step")
         return st, sid, pos, vel, box, box_feats, nn, pos_c, vel_c
 
-    def _fused_finish(self, handle):
+    def _fused_finish(self, handle, _again=False):
         """Second half of a fused step: wait for its completion word, redo it on the exact path if a neighbour row overflowed."""
         st, sid, pos, vel, box, box_feats, nn, pos_c, vel_c = handle
         lib = self._lib_cached
@@ -511,7 +511,7 @@ class ParticleNet(nn.Module):
             if flag[2] != sid:
                 raise RuntimeError("nf_trans_step: the front kernel never reported completion")
         if flag[0] or flag[1]:
-            return self._fused_overflow(st, pos, vel, box, box_feats)
+            return self._fused_overflow(st, pos, vel, box, box_feats, _again)
         self.num_fluid_neighbors = nn
         self._y3 = st["y3"]
         nns = st["nns"]
@@ -519,13 +519,14 @@ class ParticleNet(nn.Module):
         self.conv0_fluid.nns = nns
         return pos_c, vel_c, nn
 
-    def _fused_overflow(self, st, pos, vel, box, box_feats):
-        """A particle had more neighbours than its row pitch: redo THIS step on the exact CSR path (same results as the
-        reference's uncapped search) and let the pitch grow for the following steps (up to what the front kernel stages;
-        beyond that the exact path serves the next steps and the fused one is retried later).  The exact path sums in another
-        order than the fused step (both within 2e-7 of the oracle per step; neighbour sets and counts bit-equal), so the low
-        bits of a rollout depend on which steps were redone, i.e. on the pitch history and on `fused_grow_pitch`: for
-        bit-reproducible rollouts across runs start from the same `max_*_neighbors` (or set `fused_inference = False`)."""
+    def _fused_overflow(self, st, pos, vel, box, box_feats, _again=False):
+        """A particle had more neighbours than its row pitch: the step is redone before its results are handed out, and the pitch
+        grows for the following steps (up to what the front kernel stages).  Round 6: when the grown pitch holds the step's longest
+        rows, the redo is the FUSED step again — its sums run over a row's entries in pair order, whatever the pitch — so a rollout's
+        bits no longer depend on the pitch history (tests: a model that starts at pitch 8 / 4 equals one that starts at 64 / 64, bit for
+        bit).  A row longer than the front kernel stages at all (or `fused_grow_pitch = False`) is redone on the exact CSR path — the
+        reference's uncapped search; same neighbour sets and counts, another summation order (both within 2e-7 of the oracle per step)
+        — and the exact path serves the next steps while the clump lasts."""
         of, ob = st["ovf"].tolist()            # (syncs: the exact maxima, for the pitch growth)
         st["ovf"].zero_()
         st["flag_np"][:2] = 0
@@ -538,6 +539,9 @@ class ParticleNet(nn.Module):
                 self.max_box_neighbors = min(cap, max(int(self.max_box_neighbors), ob + ob // 4 + 8))
         if of > cap or ob > cap:
             self._fused_skip = 16           # a clump denser than the front kernel stages: exact path for a while
+        elif self.fused_grow_pitch and of <= int(self.max_fluid_neighbors) and ob <= int(self.max_box_neighbors) and not _again:
+            handle = self._fused_enqueue(pos, vel, box, box_feats)          # (new buffers for the new pitch; the same stream)
+            return self._fused_finish(handle, _again=True)
         return self._forward_impl(pos, vel, box, box_feats)[:3]
 
     def _forward_impl(self, pos, vel, box, box_feats, keep=False, other=None, _exact=False, _capture=None):

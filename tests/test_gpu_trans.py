@@ -578,15 +578,19 @@ def test_fused_inference_step_vs_multi_launch_path(dev):
 
 
 def test_fused_step_overflow_is_redone_exactly(dev):
-    """A particle with more neighbours than its row pitch must not change results (the reference's search has no cap): the
-    step is redone on the exact CSR path before forward() returns — BIT-equal to the unfused path — and the pitch grows so that
-    the following steps run fused again.  With growth switched off every step is redone (still bit-equal, never NaN)."""
+    """A particle with more neighbours than its row pitch must not change results (the reference's search has no cap): the step is
+    redone before forward() returns.  With pitch growth (the default) the redo is the fused step at the grown pitch, and the whole
+    rollout is BIT-equal to a model that had a large pitch from the start — the low bits do not depend on the pitch history (round 6;
+    before, the redone step carried the exact path's summation order).  With growth switched off every step is redone on the exact CSR
+    path: BIT-equal to the unfused path, never NaN."""
     from neurofluid_amd import synthetic
     from oracle import trans_oracle as to
     box, bn = [t.to(dev) for t in to.watercube_box()]
     P = synthetic.watercube_particles().to(dev)
     ref, _ = make_pn(dev)
     ref.fused_inference = False
+    big, _ = make_pn(dev)
+    big.max_fluid_neighbors, big.max_box_neighbors = 96, 96
     for grow in (True, False):
         pc, _ = make_pn(dev)
         pc.max_fluid_neighbors, pc.max_box_neighbors, pc.fused_grow_pitch = 8, 4, grow
@@ -594,17 +598,21 @@ def test_fused_step_overflow_is_redone_exactly(dev):
         with torch.no_grad():
             for it in range(4):
                 pr, vr, nr = ref(p, v, box, bn)
-                pf, vf, nf = pc(p, v, box, bn)              # both step from the same state
+                pb, vb, nb = big(p, v, box, bn)
+                pf, vf, nf = pc(p, v, box, bn)              # all three step from the same state
                 assert not bool(torch.isnan(pf).any())
-                if it == 0 or not grow:                     # redone on the exact path: the unfused path's bits
-                    assert torch.equal(pf, pr) and torch.equal(vf, vr) and torch.equal(nf, nr), (grow, it)
-                else:                                       # pitch grown: fused again
-                    assert torch.equal(nf, nr) and float((pf - pr).abs().max()) <= 2e-7
+                assert torch.equal(nf, nr) and torch.equal(nb, nr)
+                if grow:                                    # fused at whatever pitch: one set of bits
+                    assert torch.equal(pf, pb) and torch.equal(vf, vb), (grow, it)
+                    assert float((pf - pr).abs().max()) <= 2e-7
+                else:                                       # redone on the exact path: the unfused path's bits
+                    assert torch.equal(pf, pr) and torch.equal(vf, vr), (grow, it)
                 p, v = pr, vr
         if grow:
             assert pc.fused_overflows == 1 and pc.max_fluid_neighbors > 40 and pc.max_box_neighbors > 4
         else:
             assert pc.fused_overflows == 4 and pc.max_fluid_neighbors == 8
+    assert getattr(big, "fused_overflows", 0) == 0
 
 
 def test_exact_path_pair_capacity_overflow_is_redone_exactly(dev):

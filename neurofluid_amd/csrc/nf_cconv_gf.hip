@@ -461,7 +461,11 @@ __global__ void __launch_bounds__(GF_THREADS) k_cconv_gf(GfArgs A)
                 };
                 auto request = [&](const TB& T, XS& S) __attribute__((always_inline)) {
                     S.jc = T.jc; S.w0 = T.w0; S.w1 = T.w1;
+#ifdef GF_AB_LOCAL_J        /* timing-only (garbage results): every gather reads one of 64 rows — what the producers would cost if a tile's neighbour rows sat next to them */
+                    const int j = (T.jc & 0x3fffffff) & 63;
+#else
                     const int j = T.jc & 0x3fffffff;
+#endif
 #pragma unroll
                     for (int k = 0; k < NQ; ++k) {
                         S.xv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
